@@ -1,0 +1,136 @@
+/* tvr.h — C-ABI of the MI355X-native TensoRF volume renderer (libtvr.so, gfx950).
+ *
+ * The reference (FREDZEL2020/jittor-MYC-NeRFs, tensorf-myc) has NO FFI on this path: the hot path is
+ * Python calling Jittor ops.  The boundary kept is therefore the Python call surface of the model and
+ * renderer; this header is the C-ABI underneath it.  Each entry point cites the
+ * reference interface (paths relative to /root/reference/) whose work it performs.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative tvr_status otherwise; tvr_last_error() gives a
+ *     thread-local message.  Nothing throws, nothing calls hipDeviceSynchronize.
+ *   - ALL device memory is caller-owned (torch allocations): fp32, contiguous, 16-byte aligned.
+ *     The library never allocates device memory; sizes come from the *_bytes() queries.
+ *   - all work is enqueued on the caller-supplied stream (a hipStream_t passed as void*).
+ *   - a tvr_scene may be used from one stream at a time; distinct scenes are independent.
+ */
+#ifndef TVR_H
+#define TVR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TVR_VERSION 100
+
+typedef enum {
+    TVR_OK = 0,
+    TVR_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    TVR_ERR_HIP = -2,          /* a HIP runtime call failed */
+    TVR_ERR_SCRATCH = -3,      /* scratch / packed buffer too small or misaligned */
+    TVR_ERR_UNSUPPORTED = -4   /* configuration outside what the kernels are built for */
+} tvr_status;
+
+typedef struct tvr_scene tvr_scene;
+typedef struct tvr_profile tvr_profile;
+
+/* Hyper-parameters of one field: TensorBase.__init__ (tensorf-myc/models/tensorBase.py:141-176),
+ * update_stepSize (:197-209) and TensorVMSplit.init_svd_volume (tensorf-myc/models/tensoRF.py:146-164). */
+typedef struct {
+    float aabb[6];                 /* lo[3], hi[3] */
+    int32_t grid[3];               /* gridSize (x, y, z) */
+    int32_t density_n_comp[3];     /* must be 16 each in this build */
+    int32_t app_n_comp[3];         /* must be 48 each in this build */
+    int32_t app_dim;               /* 27 */
+    int32_t featureC;              /* 128 */
+    int32_t view_pe, fea_pe;       /* 2, 2  (shadingMode MLP_Fea) */
+    float near_, far_;             /* near_far */
+    float step_size;               /* stepSize = mean(units)*step_ratio, computed by the host in fp32 */
+    float inv_aabb_size[3];        /* invaabbSize = 2/(hi-lo), computed by the host in fp32 (:201) */
+    float density_shift;           /* -10 */
+    float distance_scale;          /* 25 */
+    float weight_thres;            /* rayMarch_weight_thres 1e-4 */
+    int32_t fea2dense_act;         /* 0 softplus, 1 relu (:444-448) */
+} tvr_scene_desc;
+
+/* Device pointers to the parameters in the REFERENCE layout (tensoRF.py:154-164, tensorBase.py:69-71):
+ * planes (1,C,H,W) channel-first, lines (1,C,L,1), Linear weights [out,in] row-major. */
+typedef struct {
+    const float *density_plane[3], *density_line[3];
+    const float *app_plane[3], *app_line[3];
+    const float *basis_mat;              /* [app_dim, 144] */
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+} tvr_scene_params;
+
+/* Optional per-sample outputs (additional_output=True of TensorBase.execute, tensorBase.py:533-534,
+ * plus the intermediates the parity tests compare bit for bit).  Any pointer may be NULL. */
+typedef struct {
+    float *z;            /* [n,S]   z_vals */
+    uint8_t *valid;      /* [n,S]   ray_valid after the alpha mask */
+    uint8_t *bbox_valid; /* [n,S]   in-box test only */
+    int32_t *cell;       /* [n,S,3] floor of the un-normalised grid coordinate per axis */
+    float *sigma_feature;/* [n,S] */
+    float *sigma;        /* [n,S] */
+    float *alpha;        /* [n,S] */
+    float *weight;       /* [n,S] */
+    float *rgb;          /* [n,S,3] (zero where weight <= thres) */
+    float *bg_weight;    /* [n]     T after the last sample */
+    float *acc;          /* [n]     sum of weights */
+    float *t_min;        /* [n] */
+} tvr_dense_out;
+
+/* Counters added to by tvr_render when `stats` is non-NULL (device memory, 8 x uint64, caller zeroes). */
+enum { TVR_STAT_SAMPLES_EVAL = 0,   /* density samples actually gathered (valid, before termination) */
+       TVR_STAT_SAMPLES_BBOX = 1,   /* in-box samples visited (alpha-mask lookups when a mask is set) */
+       TVR_STAT_APP = 2,            /* appearance samples (weight > thres) */
+       TVR_STAT_RAYS_TERMINATED = 3,/* rays stopped early by eps_T */
+       TVR_STAT_COUNT = 8 };
+
+int tvr_version(void);
+const char *tvr_last_error(void);
+
+/* Packed (channels-last, zero-padded) copy of the parameters: size query, create, refresh, destroy.
+ * Replaces nothing in the reference — it is the HBM layout behind TensorVMSplit's ParameterLists. */
+size_t tvr_scene_packed_bytes(const tvr_scene_desc *desc);
+int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed_bytes, tvr_scene **out);
+int tvr_scene_update(tvr_scene *scene, const tvr_scene_params *params, void *stream);
+/* AlphaGridMask (tensorBase.py:39-59): volume (gz,gy,gx) fp32 in device memory, kept by reference; NULL clears. */
+int tvr_scene_set_alpha(tvr_scene *scene, const float *alpha_volume_dev, const int32_t agrid_xyz[3],
+                        const float alpha_aabb[6], const float alpha_inv_size[3]);
+int tvr_scene_destroy(tvr_scene *scene);
+
+/* TensorBase.execute over a ray batch (tensorBase.py:476-536, ndc_ray=False) as called by
+ * OctreeRender_trilinear_fast (tensorf-myc/renderer.py:12-27).
+ *   rays [n,6] (o,d); jitter [n] or NULL (is_train: one u per ray, tensorBase.py:351-353);
+ *   eps_T: stop a ray once transmittance < eps_T (0 = exact, never stop); must be <= weight_thres;
+ *   rgb_out [n,3], depth_out [n]; scratch of tvr_render_scratch_bytes(); dense/stats/prof may be NULL. */
+size_t tvr_render_scratch_bytes(const tvr_scene *scene, int64_t n_rays, int32_t n_samples);
+int tvr_render(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, int32_t white_bg,
+               const float *jitter, float eps_T, float *rgb_out, float *depth_out,
+               void *scratch, size_t scratch_bytes, const tvr_dense_out *dense, uint64_t *stats,
+               tvr_profile *prof, void *stream);
+
+/* TensorVMSplit.compute_densityfeature (tensoRF.py:209-225): xyz_norm [m,3] -> out [m]. */
+int tvr_density_feature(tvr_scene *scene, const float *xyz_norm, int64_t m, float *out, void *stream);
+/* TensorVMSplit.compute_appfeature (tensoRF.py:228-244): xyz_norm [m,3] -> out [m,app_dim]. */
+int tvr_app_feature(tvr_scene *scene, const float *xyz_norm, int64_t m, float *out, void *stream);
+/* MLPRender_Fea.execute (tensorBase.py:76-86): viewdirs [m,3], features [m,app_dim] -> rgb [m,3]. */
+int tvr_mlp_render(tvr_scene *scene, const float *viewdirs, const float *features, int64_t m, float *rgb, void *stream);
+/* AlphaGridMask.sample_alpha (tensorBase.py:50-56): xyz [m,3] (world) -> out [m].  Stand-alone (the reference's
+ * AlphaGridMask is its own module): volume (gz,gy,gx) fp32, grid (gx,gy,gz), aabb, invgridSize = 1/size*2 (:46). */
+int tvr_alpha_sample(const float *alpha_volume_dev, const int32_t agrid_xyz[3], const float alpha_aabb[6],
+                     const float alpha_inv_size[3], const float *xyz, int64_t m, float *out, void *stream);
+
+/* Per-kernel HIP-event timing of tvr_render calls (march / shade / composite), for bench.py's roofline. */
+int tvr_profile_create(int32_t max_calls, tvr_profile **out);
+int tvr_profile_reset(tvr_profile *prof);
+/* After the stream is synchronised: sums over recorded calls, ms[0..2] = march, shade, composite; returns #calls. */
+int tvr_profile_read(tvr_profile *prof, float ms[3]);
+int tvr_profile_destroy(tvr_profile *prof);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TVR_H */

@@ -1,0 +1,8 @@
+"""MI355X-native TensoRF volume renderer (package dir: jittor-myc-nerfs_amd; import as jittor_myc_nerfs_amd).
+
+Drop-in surface of the reference's render path (tensorf-myc): TensorVMSplit / AlphaGridMask / MLPRender_Fea
+(field.py), OctreeRender_trilinear_fast (render.py), Blender-format ray generation (rays.py), backed by
+hand-written HIP kernels for gfx950 behind the C-ABI in include/tvr.h (csrc/, built into lib/libtvr.so)."""
+from .field import AlphaGridMask, MLPRender_Fea, TensorBase, TensorVMSplit  # noqa: F401
+from .render import OctreeRender_trilinear_fast, render_sharded, shard_indices, shard_capacity  # noqa: F401
+from . import rays, synthetic  # noqa: F401

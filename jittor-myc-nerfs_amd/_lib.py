@@ -1,0 +1,86 @@
+"""ctypes binding of libtvr.so (include/tvr.h).  The product path has NO CPU fallback: if the HIP
+library is missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtvr.so")
+
+_FP = C.POINTER(C.c_float)
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("aabb", C.c_float * 6), ("grid", C.c_int32 * 3), ("density_n_comp", C.c_int32 * 3),
+                ("app_n_comp", C.c_int32 * 3), ("app_dim", C.c_int32), ("featureC", C.c_int32),
+                ("view_pe", C.c_int32), ("fea_pe", C.c_int32), ("near_", C.c_float), ("far_", C.c_float),
+                ("step_size", C.c_float), ("inv_aabb_size", C.c_float * 3), ("density_shift", C.c_float),
+                ("distance_scale", C.c_float), ("weight_thres", C.c_float), ("fea2dense_act", C.c_int32)]
+
+
+class SceneParams(C.Structure):
+    _fields_ = [("density_plane", C.c_void_p * 3), ("density_line", C.c_void_p * 3),
+                ("app_plane", C.c_void_p * 3), ("app_line", C.c_void_p * 3), ("basis_mat", C.c_void_p),
+                ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
+                ("W3", C.c_void_p), ("b3", C.c_void_p)]
+
+
+class DenseOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("z", "valid", "bbox_valid", "cell", "sigma_feature", "sigma", "alpha",
+                                          "weight", "rgb", "bg_weight", "acc", "t_min")]
+
+
+# name -> (restype, argtypes); every symbol include/tvr.h declares
+SYMBOLS = {
+    "tvr_version": (C.c_int, []),
+    "tvr_last_error": (C.c_char_p, []),
+    "tvr_scene_packed_bytes": (C.c_size_t, [C.POINTER(SceneDesc)]),
+    "tvr_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "tvr_scene_update": (C.c_int, [C.c_void_p, C.POINTER(SceneParams), C.c_void_p]),
+    "tvr_scene_set_alpha": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_float * 6),
+                                      C.POINTER(C.c_float * 3)]),
+    "tvr_scene_destroy": (C.c_int, [C.c_void_p]),
+    "tvr_render_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
+    "tvr_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DenseOut), C.c_void_p,
+                             C.c_void_p, C.c_void_p]),
+    "tvr_density_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_app_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_mlp_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_alpha_sample": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_float * 6), C.POINTER(C.c_float * 3),
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_profile_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "tvr_profile_reset": (C.c_int, [C.c_void_p]),
+    "tvr_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3)]),
+    "tvr_profile_destroy": (C.c_int, [C.c_void_p]),
+}
+
+STAT_SAMPLES_EVAL, STAT_SAMPLES_BBOX, STAT_APP, STAT_RAYS_TERMINATED, STAT_COUNT = 0, 1, 2, 3, 8
+
+
+class TvrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libtvr.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TvrError(f"HIP extension not built: {LIB_PATH} is missing (run `python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` or `make -C jittor-myc-nerfs_amd/csrc`). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)      # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc < 0:
+        raise TvrError(f"{what} failed ({rc}): {lib().tvr_last_error().decode(errors='replace')}")

@@ -1,0 +1,382 @@
+// tvr_api.hip — the C-ABI of libtvr.so (include/tvr.h).  Host code only: argument checks, packed-scene layout,
+// scratch carving and kernel launches on the caller's stream.  No device allocation, no synchronisation.
+#include "tvr_device.h"
+#include "tvr_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(TVR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static const int kMatH[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+static const int kVecH[3] = {2, 1, 0};
+
+struct PackedLayout {
+    size_t dplane[3], dline[3], aplane[3], aline[3];
+    size_t basisT, W1T, W2T, W3T, b1, b2, b3, total;
+};
+
+static PackedLayout packed_layout(const tvr_scene_desc &d)
+{
+    PackedLayout L;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
+    for (int i = 0; i < 3; ++i) {
+        const size_t W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
+        L.dplane[i] = take((H + 1) * (W + 1) * TVR_CD);
+        L.dline[i] = take((Ln + 1) * TVR_CD);
+        L.aplane[i] = take((H + 1) * (W + 1) * TVR_CA);
+        L.aline[i] = take((Ln + 1) * TVR_CA);
+    }
+    L.basisT = take(TVR_KAPP * 32);
+    L.W1T = take(TVR_NIN * TVR_FEATC);
+    L.W2T = take(TVR_FEATC * TVR_FEATC);
+    L.W3T = take(TVR_FEATC * 16);
+    L.b1 = take(TVR_FEATC);
+    L.b2 = take(TVR_FEATC);
+    L.b3 = take(16);
+    L.total = off;
+    return L;
+}
+
+struct tvr_scene {
+    tvr_scene_desc desc;
+    PackedLayout lay;
+    char *packed;
+    SceneDev dev;
+    bool params_set;
+};
+
+struct tvr_profile {
+    std::vector<hipEvent_t> ev;   // 4 per call
+    int max_calls, n_calls;
+};
+
+static int check_desc(const tvr_scene_desc *d)
+{
+    if (!d) return fail(TVR_ERR_INVALID, "desc is NULL");
+    for (int i = 0; i < 3; ++i) {
+        if (d->grid[i] < 2 || d->grid[i] > 4096) return fail(TVR_ERR_INVALID, "grid[%d]=%d out of [2,4096]", i, d->grid[i]);
+        if (d->density_n_comp[i] != TVR_CD) return fail(TVR_ERR_UNSUPPORTED, "density_n_comp[%d]=%d; this build supports %d", i, d->density_n_comp[i], TVR_CD);
+        if (d->app_n_comp[i] != TVR_CA) return fail(TVR_ERR_UNSUPPORTED, "appearance_n_comp[%d]=%d; this build supports %d", i, d->app_n_comp[i], TVR_CA);
+        if (!(d->aabb[3 + i] > d->aabb[i])) return fail(TVR_ERR_INVALID, "aabb hi <= lo on axis %d", i);
+    }
+    if (d->app_dim != TVR_APPDIM || d->featureC != TVR_FEATC || d->view_pe != 2 || d->fea_pe != 2)
+        return fail(TVR_ERR_UNSUPPORTED, "MLP_Fea shape app_dim=%d featureC=%d view_pe=%d fea_pe=%d; this build supports 27/128/2/2",
+                    d->app_dim, d->featureC, d->view_pe, d->fea_pe);
+    if (d->fea2dense_act != 0 && d->fea2dense_act != 1) return fail(TVR_ERR_INVALID, "fea2dense_act must be 0 or 1");
+    if (!(d->step_size > 0.0f)) return fail(TVR_ERR_INVALID, "step_size must be > 0");
+    return TVR_OK;
+}
+
+extern "C" {
+
+int tvr_version(void) { return TVR_VERSION; }
+const char *tvr_last_error(void) { return g_err; }
+
+size_t tvr_scene_packed_bytes(const tvr_scene_desc *desc)
+{
+    if (check_desc(desc) != TVR_OK) return 0;
+    return packed_layout(*desc).total;
+}
+
+int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed_bytes, tvr_scene **out)
+{
+    if (!out) return fail(TVR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = check_desc(desc);
+    if (rc != TVR_OK) return rc;
+    PackedLayout L = packed_layout(*desc);
+    if (!packed_dev || packed_bytes < L.total) return fail(TVR_ERR_SCRATCH, "packed buffer %zu B < required %zu B", packed_bytes, L.total);
+    if ((uintptr_t)packed_dev % 256) return fail(TVR_ERR_SCRATCH, "packed buffer must be 256-byte aligned");
+    tvr_scene *s = new (std::nothrow) tvr_scene;
+    if (!s) return fail(TVR_ERR_INVALID, "out of host memory");
+    s->desc = *desc;
+    s->lay = L;
+    s->packed = (char *)packed_dev;
+    s->params_set = false;
+    SceneDev &v = s->dev;
+    memset(&v, 0, sizeof(v));
+    for (int k = 0; k < 3; ++k) {
+        v.lo[k] = desc->aabb[k];
+        v.hi[k] = desc->aabb[3 + k];
+        v.inv[k] = desc->inv_aabb_size[k];
+        v.grid[k] = desc->grid[k];
+        v.gm1[k] = (float)(desc->grid[k] - 1);
+        v.dplane[k] = (const float4 *)(s->packed + L.dplane[k]);
+        v.dline[k] = (const float4 *)(s->packed + L.dline[k]);
+        v.aplane[k] = (const float4 *)(s->packed + L.aplane[k]);
+        v.aline[k] = (const float4 *)(s->packed + L.aline[k]);
+    }
+    v.basisT = (const float *)(s->packed + L.basisT);
+    v.W1T = (const float *)(s->packed + L.W1T);
+    v.W2T = (const float *)(s->packed + L.W2T);
+    v.W3T = (const float *)(s->packed + L.W3T);
+    v.b1 = (const float *)(s->packed + L.b1);
+    v.b2 = (const float *)(s->packed + L.b2);
+    v.b3 = (const float *)(s->packed + L.b3);
+    v.near_ = desc->near_;
+    v.far_ = desc->far_;
+    v.step = desc->step_size;
+    v.shift = desc->density_shift;
+    v.scale = desc->distance_scale;
+    v.thres = desc->weight_thres;
+    v.act = desc->fea2dense_act;
+    v.avol = nullptr;
+    *out = s;
+    return TVR_OK;
+}
+
+int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
+{
+    if (!s || !p) return fail(TVR_ERR_INVALID, "scene/params is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    const tvr_scene_desc &d = s->desc;
+    for (int i = 0; i < 3; ++i) {
+        if (!p->density_plane[i] || !p->density_line[i] || !p->app_plane[i] || !p->app_line[i])
+            return fail(TVR_ERR_INVALID, "plane/line pointer %d is NULL", i);
+        const int W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
+        HIP_TRY(launch_pack_plane(p->density_plane[i], (float *)(s->packed + s->lay.dplane[i]), TVR_CD, H, W, stream));
+        HIP_TRY(launch_pack_plane(p->density_line[i], (float *)(s->packed + s->lay.dline[i]), TVR_CD, Ln, 1, stream));
+        HIP_TRY(launch_pack_plane(p->app_plane[i], (float *)(s->packed + s->lay.aplane[i]), TVR_CA, H, W, stream));
+        HIP_TRY(launch_pack_plane(p->app_line[i], (float *)(s->packed + s->lay.aline[i]), TVR_CA, Ln, 1, stream));
+    }
+    if (!p->basis_mat || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3) return fail(TVR_ERR_INVALID, "MLP pointer is NULL");
+    HIP_TRY(launch_transpose_pad(p->basis_mat, (float *)(s->packed + s->lay.basisT), TVR_APPDIM, TVR_KAPP, 32, stream));
+    HIP_TRY(launch_transpose_pad(p->W1, (float *)(s->packed + s->lay.W1T), TVR_FEATC, TVR_NIN, TVR_FEATC, stream));
+    HIP_TRY(launch_transpose_pad(p->W2, (float *)(s->packed + s->lay.W2T), TVR_FEATC, TVR_FEATC, TVR_FEATC, stream));
+    HIP_TRY(launch_transpose_pad(p->W3, (float *)(s->packed + s->lay.W3T), 3, TVR_FEATC, 16, stream));
+    // biases are [n][K=1] -> [1][n_out]
+    HIP_TRY(launch_transpose_pad(p->b1, (float *)(s->packed + s->lay.b1), TVR_FEATC, 1, TVR_FEATC, stream));
+    HIP_TRY(launch_transpose_pad(p->b2, (float *)(s->packed + s->lay.b2), TVR_FEATC, 1, TVR_FEATC, stream));
+    HIP_TRY(launch_transpose_pad(p->b3, (float *)(s->packed + s->lay.b3), 3, 1, 16, stream));
+    s->params_set = true;
+    return TVR_OK;
+}
+
+int tvr_scene_set_alpha(tvr_scene *s, const float *vol, const int32_t ag[3], const float aabb[6], const float inv[3])
+{
+    if (!s) return fail(TVR_ERR_INVALID, "scene is NULL");
+    if (!vol) { s->dev.avol = nullptr; return TVR_OK; }
+    if (!ag || !aabb || !inv) return fail(TVR_ERR_INVALID, "alpha grid/aabb/inv is NULL");
+    for (int k = 0; k < 3; ++k) {
+        if (ag[k] < 1) return fail(TVR_ERR_INVALID, "alpha grid[%d]=%d", k, ag[k]);
+        s->dev.ag[k] = ag[k];
+        s->dev.alo[k] = aabb[k];
+        s->dev.ainv[k] = inv[k];
+        s->dev.agm1[k] = (float)(ag[k] - 1);
+    }
+    s->dev.avol = vol;
+    return TVR_OK;
+}
+
+int tvr_scene_destroy(tvr_scene *s)
+{
+    delete s;
+    return TVR_OK;
+}
+
+// scratch carving shared by the size query and tvr_render
+struct ScratchLayout { size_t counter, ray_off, ray_cnt, acc, q_pos, q_ray, q_j, total; };
+static ScratchLayout scratch_layout(int64_t n_rays, int32_t S)
+{
+    ScratchLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t cap = (size_t)n_rays * (size_t)S;
+    L.counter = take(256);
+    L.ray_off = take(n_rays * 4);
+    L.ray_cnt = take(n_rays * 4);
+    L.acc = take(n_rays * 4);
+    L.q_pos = take(cap * 16);
+    L.q_ray = take(cap * 4);
+    L.q_j = take(cap * 4);
+    L.total = off;
+    return L;
+}
+
+size_t tvr_render_scratch_bytes(const tvr_scene *s, int64_t n_rays, int32_t n_samples)
+{
+    (void)s;
+    if (n_rays <= 0 || n_samples <= 0) return 256;
+    return scratch_layout(n_rays, n_samples).total;
+}
+
+int tvr_render(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, const float *jitter, float eps_T,
+               float *rgb_out, float *depth_out, void *scratch, size_t scratch_bytes, const tvr_dense_out *dense,
+               uint64_t *stats, tvr_profile *prof, void *stream_)
+{
+    if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
+    if (n_rays == 0) return TVR_OK;
+    if (!rays || !rgb_out || !depth_out || n_rays < 0) return fail(TVR_ERR_INVALID, "rays/rgb_out/depth_out NULL or n_rays < 0");
+    if (S <= 0 || S > 4096) return fail(TVR_ERR_INVALID, "n_samples=%d out of [1,4096]", S);
+    if ((size_t)n_rays * (size_t)S >= (1ull << 32)) return fail(TVR_ERR_INVALID, "n_rays*n_samples must be < 2^32 per call (chunk the rays)");
+    if (!(eps_T >= 0.0f) || eps_T > s->desc.weight_thres)
+        return fail(TVR_ERR_INVALID, "eps_T=%g must be in [0, weight_thres=%g] so that no appearance sample is skipped", eps_T, s->desc.weight_thres);
+    ScratchLayout L = scratch_layout(n_rays, S);
+    if (!scratch || scratch_bytes < L.total) return fail(TVR_ERR_SCRATCH, "scratch %zu B < required %zu B", scratch_bytes, L.total);
+    if ((uintptr_t)scratch % 256) return fail(TVR_ERR_SCRATCH, "scratch must be 256-byte aligned");
+    if (prof && prof->n_calls >= prof->max_calls) return fail(TVR_ERR_INVALID, "profile is full (%d calls)", prof->max_calls);
+    hipStream_t stream = (hipStream_t)stream_;
+    char *b = (char *)scratch;
+    MarchOut mo;
+    mo.counter = (unsigned *)(b + L.counter);
+    mo.ray_off = (unsigned *)(b + L.ray_off);
+    mo.ray_cnt = (unsigned *)(b + L.ray_cnt);
+    mo.acc = (float *)(b + L.acc);
+    mo.depth = depth_out;
+    mo.q_pos = (float4 *)(b + L.q_pos);
+    mo.q_ray = (unsigned *)(b + L.q_ray);
+    mo.q_j = (dense && dense->rgb) ? (unsigned *)(b + L.q_j) : nullptr;
+    mo.stats = (unsigned long long *)stats;
+
+    hipEvent_t *ev = prof ? &prof->ev[(size_t)prof->n_calls * 4] : nullptr;
+    HIP_TRY(hipMemsetAsync(mo.counter, 0, 4, stream));
+    if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
+    HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, jitter, eps_T, mo, dense, stream));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
+    ShadeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.counter = mo.counter;
+    sa.q_pos = mo.q_pos;
+    sa.q_ray = mo.q_ray;
+    sa.rays = rays;
+    sa.stats = mo.stats;
+    HIP_TRY(launch_shade(s->dev, SH_SRC_QUEUE, SH_DST_QUEUE, sa, stream));
+    if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
+    if (dense && dense->rgb) {
+        HIP_TRY(hipMemsetAsync(dense->rgb, 0, (size_t)n_rays * S * 3 * sizeof(float), stream));
+        HIP_TRY(launch_scatter_rgb(mo, S, dense->rgb, stream));
+    }
+    HIP_TRY(launch_composite(mo, (int)n_rays, white_bg, rgb_out, stream));
+    if (ev) {
+        HIP_TRY(hipEventRecord(ev[3], stream));
+        prof->n_calls++;
+    }
+    return TVR_OK;
+}
+
+int tvr_density_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, void *stream)
+{
+    if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
+    if (m == 0) return TVR_OK;
+    if (!xyz || !out || m < 0) return fail(TVR_ERR_INVALID, "xyz/out NULL or m < 0");
+    HIP_TRY(launch_density_feature(s->dev, xyz, m, out, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_app_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, void *stream)
+{
+    if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
+    if (m == 0) return TVR_OK;
+    if (!xyz || !out || m < 0) return fail(TVR_ERR_INVALID, "xyz/out NULL or m < 0");
+    ShadeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.n = m;
+    sa.xyz = xyz;
+    sa.out = out;
+    HIP_TRY(launch_shade(s->dev, SH_SRC_XYZ, SH_DST_FEAT, sa, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_mlp_render(tvr_scene *s, const float *viewdirs, const float *features, int64_t m, float *rgb, void *stream)
+{
+    if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
+    if (m == 0) return TVR_OK;
+    if (!viewdirs || !features || !rgb || m < 0) return fail(TVR_ERR_INVALID, "viewdirs/features/rgb NULL or m < 0");
+    ShadeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.n = m;
+    sa.viewdirs = viewdirs;
+    sa.feats = features;
+    sa.out = rgb;
+    HIP_TRY(launch_shade(s->dev, SH_SRC_FEAT, SH_DST_RGB, sa, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_alpha_sample(const float *vol, const int32_t ag[3], const float aabb[6], const float inv[3], const float *xyz,
+                     int64_t m, float *out, void *stream)
+{
+    if (!vol || !ag || !aabb || !inv) return fail(TVR_ERR_INVALID, "alpha volume/grid/aabb/inv is NULL");
+    if (m == 0) return TVR_OK;
+    if (!xyz || !out || m < 0) return fail(TVR_ERR_INVALID, "xyz/out NULL or m < 0");
+    SceneDev v;
+    memset(&v, 0, sizeof(v));
+    for (int k = 0; k < 3; ++k) {
+        if (ag[k] < 1) return fail(TVR_ERR_INVALID, "alpha grid[%d]=%d", k, ag[k]);
+        v.ag[k] = ag[k];
+        v.alo[k] = aabb[k];
+        v.ainv[k] = inv[k];
+        v.agm1[k] = (float)(ag[k] - 1);
+    }
+    v.avol = vol;
+    HIP_TRY(launch_alpha_sample(v, xyz, m, out, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_profile_create(int32_t max_calls, tvr_profile **out)
+{
+    if (!out || max_calls <= 0 || max_calls > 100000) return fail(TVR_ERR_INVALID, "bad profile arguments");
+    tvr_profile *p = new (std::nothrow) tvr_profile;
+    if (!p) return fail(TVR_ERR_INVALID, "out of host memory");
+    p->max_calls = max_calls;
+    p->n_calls = 0;
+    p->ev.resize((size_t)max_calls * 4);
+    for (auto &e : p->ev) {
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) { delete p; return fail(TVR_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(rc)); }
+    }
+    *out = p;
+    return TVR_OK;
+}
+
+int tvr_profile_reset(tvr_profile *p)
+{
+    if (!p) return fail(TVR_ERR_INVALID, "profile is NULL");
+    p->n_calls = 0;
+    return TVR_OK;
+}
+
+int tvr_profile_read(tvr_profile *p, float ms[3])
+{
+    if (!p || !ms) return fail(TVR_ERR_INVALID, "profile/ms is NULL");
+    ms[0] = ms[1] = ms[2] = 0.f;
+    for (int c = 0; c < p->n_calls; ++c)
+        for (int k = 0; k < 3; ++k) {
+            float t = 0.f;
+            hipError_t rc = hipEventElapsedTime(&t, p->ev[(size_t)c * 4 + k], p->ev[(size_t)c * 4 + k + 1]);
+            if (rc != hipSuccess) return fail(TVR_ERR_HIP, "hipEventElapsedTime: %s", hipGetErrorString(rc));
+            ms[k] += t;
+        }
+    return p->n_calls;
+}
+
+int tvr_profile_destroy(tvr_profile *p)
+{
+    if (!p) return TVR_OK;
+    for (auto &e : p->ev) (void)hipEventDestroy(e);
+    delete p;
+    return TVR_OK;
+}
+
+}  // extern "C"

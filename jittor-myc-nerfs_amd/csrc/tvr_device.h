@@ -1,0 +1,146 @@
+// tvr_device.h — device-side scene descriptor and shared helpers (gfx950 only).
+//
+// HBM layout ("packed scene", built by pack kernels from the reference layout):
+//   density plane i : [H_i+1][W_i+1][16] fp32  (channels-last: one texel = 64 B = 4 x float4; the extra
+//                      row/column is zero, which realises grid_sample's zeros padding for the +1 taps)
+//   density line  i : [L_i+1][16]
+//   app plane     i : [H_i+1][W_i+1][48]       (192 B texel = 12 x float4)
+//   app line      i : [L_i+1][48]
+//   basisT [144][32] (cols >= 27 zero), W1T [150][128], W2T [128][128], W3T [128][16] (cols >= 3 zero),
+//   b1[128], b2[128], b3[16]   — K-major so MFMA B operands are coalesced 128-B rows.
+// Compiled with -ffp-contract=off: every a*b+c below is two rounded ops unless written as fmaf, so the
+// position / mask / cell-index arithmetic reproduces SURVEY.md Appendix A steps 1-7 bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TVR_CD 16      // density components per plane
+#define TVR_CA 48      // appearance components per plane
+#define TVR_APPDIM 27
+#define TVR_FEATC 128
+#define TVR_NIN 150    // 27 + 3 + 2*2*27 + 2*2*3
+#define TVR_KAPP 144
+
+struct SceneDev {
+    float lo[3], hi[3], inv[3];
+    float gm1[3];                 // float(grid-1)
+    int grid[3];
+    const float4 *dplane[3];      // packed
+    const float4 *dline[3];
+    const float4 *aplane[3];
+    const float4 *aline[3];
+    const float *basisT, *W1T, *W2T, *W3T, *b1, *b2, *b3;
+    float near_, far_, step, shift, scale, thres;
+    int act;
+    const float *avol;            // (gz,gy,gx) or nullptr
+    int ag[3];
+    float alo[3], ainv[3], agm1[3];
+};
+
+static const __device__ int kMat[3][2] = {{0, 1}, {0, 2}, {1, 2}};   // tensorBase.py:168
+static const __device__ int kVec[3] = {2, 1, 0};                     // tensorBase.py:169
+
+__device__ __forceinline__ float unnorm(float c, float gm1) { return ((c + 1.0f) / 2.0f) * gm1; }
+
+__device__ __forceinline__ float4 f4_fma(float s, float4 a, float4 acc)
+{
+    return make_float4(__builtin_fmaf(s, a.x, acc.x), __builtin_fmaf(s, a.y, acc.y),
+                       __builtin_fmaf(s, a.z, acc.z), __builtin_fmaf(s, a.w, acc.w));
+}
+__device__ __forceinline__ float4 f4_mul(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+// One quad-lane's share (4 of C channels, selected by `sub`) of  bilinear(plane)*linear(line)  for one
+// sample.  P: packed plane, texel = TPT float4s; Wp = W+1 (padded row length in texels).
+// CHECK=false assumes 0<=x0<=W-1, 0<=y0<=H-1, 0<=l0<=L-1 (in-box samples): the +1 taps land on the zero pad.
+template <int TPT, bool CHECK>
+__device__ __forceinline__ float4 vm_term(const float4 *__restrict__ P, const float4 *__restrict__ Ln, int W, int H, int L,
+                                          int x0, int y0, int l0, float wx, float wy, float wl, int sub)
+{
+    // weights in the grid_sampler formulation: (x1 - fx) etc.
+    const float ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
+    const int Wp = W + 1;
+    float4 t00, t01, t10, t11, l0v, l1v;
+    if (!CHECK) {
+        const float4 *p = P + ((size_t)y0 * Wp + x0) * TPT + sub;
+        t00 = p[0];
+        t01 = p[TPT];
+        t10 = p[(size_t)Wp * TPT];
+        t11 = p[(size_t)Wp * TPT + TPT];
+        const float4 *q = Ln + (size_t)l0 * TPT + sub;
+        l0v = q[0];
+        l1v = q[TPT];
+    } else {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool xi0 = (x0 >= 0) & (x0 < W), xi1 = (x0 + 1 >= 0) & (x0 + 1 < W);
+        const bool yi0 = (y0 >= 0) & (y0 < H), yi1 = (y0 + 1 >= 0) & (y0 + 1 < H);
+        const bool li0 = (l0 >= 0) & (l0 < L), li1 = (l0 + 1 >= 0) & (l0 + 1 < L);
+        const int xc = min(max(x0, 0), W - 1), yc = min(max(y0, 0), H - 1), lc = min(max(l0, 0), L - 1);
+        const int xd = min(max(x0 + 1, 0), W - 1), yd = min(max(y0 + 1, 0), H - 1), ld = min(max(l0 + 1, 0), L - 1);
+        t00 = (xi0 & yi0) ? P[((size_t)yc * Wp + xc) * TPT + sub] : z;
+        t01 = (xi1 & yi0) ? P[((size_t)yc * Wp + xd) * TPT + sub] : z;
+        t10 = (xi0 & yi1) ? P[((size_t)yd * Wp + xc) * TPT + sub] : z;
+        t11 = (xi1 & yi1) ? P[((size_t)yd * Wp + xd) * TPT + sub] : z;
+        l0v = li0 ? Ln[(size_t)lc * TPT + sub] : z;
+        l1v = li1 ? Ln[(size_t)ld * TPT + sub] : z;
+    }
+    float4 p4 = f4_mul(ux * uy, t00);
+    p4 = f4_fma(wx * uy, t01, p4);
+    p4 = f4_fma(ux * wy, t10, p4);
+    p4 = f4_fma(wx * wy, t11, p4);
+    float4 q4 = f4_mul(ul, l0v);
+    q4 = f4_fma(wl, l1v, q4);
+    return make_float4(p4.x * q4.x, p4.y * q4.y, p4.z * q4.z, p4.w * q4.w);
+}
+
+// trilinear lookup of the alpha volume at world position p (AlphaGridMask.sample_alpha, tensorBase.py:50-59)
+__device__ __forceinline__ float alpha_lookup(const SceneDev &sc, const float p[3])
+{
+    float f[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float q = (p[k] - sc.alo[k]) * sc.ainv[k] - 1.0f;
+        f[k] = unnorm(q, sc.agm1[k]);
+    }
+    const float x0f = floorf(f[0]), y0f = floorf(f[1]), z0f = floorf(f[2]);
+    const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+    const float tx = f[0] - x0f, ty = f[1] - y0f, tz = f[2] - z0f;
+    const int W = sc.ag[0], H = sc.ag[1], D = sc.ag[2];
+    float r = 0.0f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+                float w = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty);
+                w = w * (dz ? tz : 1.0f - tz);
+                if ((x >= 0) & (x < W) & (y >= 0) & (y < H) & (z >= 0) & (z < D))
+                    r = r + sc.avol[((size_t)z * H + y) * W + x] * w;
+            }
+    return r;
+}
+
+// sample_ray steps 1-3 (tensorBase.py:345-348): entry distance clamped to [near, far]
+__device__ __forceinline__ float ray_tmin(const SceneDev &sc, const float o[3], const float d[3])
+{
+    float t = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = (d[k] == 0.0f) ? 1e-6f : d[k];
+        const float ra = (sc.hi[k] - o[k]) / v, rb = (sc.lo[k] - o[k]) / v;
+        const float m = ra < rb ? ra : rb;      // jt.minimum
+        t = (m > t) ? m : t;                    // .max(-1)
+    }
+    return t < sc.near_ ? sc.near_ : (t > sc.far_ ? sc.far_ : t);
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// bijective XCD-aware remap: workgroups b, b+8, ... share an XCD (observed round-robin dispatch), so give each
+// XCD a contiguous run of logical tiles -> neighbouring ray tiles share that XCD's L2.  Speed only.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
+{
+    const unsigned q = nblk >> 3, r = nblk & 7u, x = b & 7u, i = b >> 3;
+    return x * q + (x < r ? x : r) + i;
+}

@@ -1,0 +1,46 @@
+// tvr_kernels.h — host-visible launcher declarations shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/tvr.h"
+
+struct SceneDev;
+
+// Outputs of the march kernel / inputs of shade + composite.  The "queue" holds one entry per appearance sample
+// (weight > thres); each ray's entries are contiguous and in sample order.
+struct MarchOut {
+    unsigned *counter;        // queue length (zeroed by the host before the march)
+    unsigned *ray_off;        // [n_rays] first entry of the ray
+    unsigned *ray_cnt;        // [n_rays] entries of the ray
+    float *acc;               // [n_rays] sum of ALL weights (tensorBase.py:520)
+    float *depth;             // [n_rays] final depth_map (written by the march kernel)
+    float4 *q_pos;            // [cap] {xyz_norm, weight}; the shade kernel overwrites xyz with rgb
+    unsigned *q_ray;          // [cap] ray index (for the view direction)
+    unsigned *q_j;            // [cap] sample index, or nullptr
+    unsigned long long *stats;// TVR_STAT_* counters or nullptr
+};
+
+enum { SH_SRC_QUEUE = 0, SH_SRC_XYZ = 1, SH_SRC_FEAT = 2 };
+enum { SH_DST_QUEUE = 0, SH_DST_FEAT = 1, SH_DST_RGB = 2 };
+
+struct ShadeArgs {
+    const unsigned *counter;   // SRC_QUEUE: entry count lives on the device
+    long long n;               // other modes: entry count
+    float4 *q_pos;
+    const unsigned *q_ray;
+    const float *rays;         // [n_rays,6]
+    const float *xyz;          // SRC_XYZ: xyz_norm [n,3]
+    const float *viewdirs;     // SRC_FEAT: [n,3]
+    const float *feats;        // SRC_FEAT: [n,27]
+    float *out;                // DST_FEAT [n,27] / DST_RGB [n,3]
+    unsigned long long *stats;
+};
+
+hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T,
+                        const MarchOut &mo, const tvr_dense_out *dense, hipStream_t stream);
+hipError_t launch_composite(const MarchOut &mo, int n_rays, int white_bg, float *rgb, hipStream_t stream);
+hipError_t launch_scatter_rgb(const MarchOut &mo, int S, float *rgb_dense, hipStream_t stream);
+hipError_t launch_density_feature(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream);
+hipError_t launch_alpha_sample(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream);
+hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream);
+hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, hipStream_t stream);
+hipError_t launch_transpose_pad(const float *in, float *out, int n_in, int K, int n_out, hipStream_t stream);

@@ -1,0 +1,354 @@
+// tvr_march.hip — kernel 1 of the render path: ray/AABB entry + uniform (or jittered) sampling + in-box / alpha
+// mask + VM density lookup + softplus + alpha + front-to-back transmittance scan, fused.
+//
+// Work it replaces in the reference (paths relative to /root/reference/tensorf-myc/):
+//   models/tensorBase.py:340-360 sample_ray, :491-496 alpha-mask merge, :503 normalize_coord,
+//   models/tensoRF.py:209-225 compute_densityfeature, tensorBase.py:444-448 feature2density,
+//   :17-24 raw2alpha, :513 app_mask, :520 acc_map, :530-531 depth_map.
+//
+// Mapping (wave64): one wave marches one ray, 64 consecutive samples per chunk.  Position / mask / index math is
+// lane-per-sample.  The density gather is quad-per-sample: 4 lanes each fetch one float4 (4 of the 16 channels) of
+// every texel, so a wave-level dwordx4 load covers 16 samples x 64 contiguous bytes (one texel per quad) — coalesced
+// 64-B segments instead of 64 unrelated 16-B pieces.  Four sub-steps cover the 64 samples (sub-step k serves
+// samples 4g+k), so after the quad reduction lane 4g+k owns sample 4g+k again with no permutation.
+// The transmittance is a 6-step wave scan (DPP/shuffle) with the carry in a register; the ray stops once T < eps_T
+// (eps_T <= weight threshold, so no appearance sample is ever skipped).  Appearance samples (w > thres) are compacted
+// with a ballot into a per-wave LDS list and flushed once per ray into a contiguous, sample-ordered segment of the
+// global queue (one atomicAdd per ray) -> the compositing order per ray is fixed, results are deterministic.
+#include "tvr_device.h"
+#include "tvr_kernels.h"
+
+#define MARCH_THREADS 256
+#define MARCH_WAVES 4
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(MARCH_THREADS) void march_kernel(const SceneDev sc, const float *__restrict__ rays,
+                                                              const int n_rays, const int S, const int s_cap,
+                                                              const float *__restrict__ jitter, const float eps_T,
+                                                              const int rays_per_block, MarchOut mo, const tvr_dense_out dn)
+{
+    extern __shared__ uint2 lds_buf[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint2 *buf = lds_buf + (size_t)wave * s_cap;
+    const unsigned blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int sub = lane & 3;
+    const int qbase = lane & ~3;
+
+    unsigned long long st_eval = 0, st_bbox = 0, st_term = 0;
+
+    for (int it = wave; it < rays_per_block; it += MARCH_WAVES) {
+        const int ray = blk * rays_per_block + it;
+        if (ray >= n_rays) break;
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = rays[(size_t)ray * 6 + k];
+            d[k] = rays[(size_t)ray * 6 + 3 + k];
+        }
+        const float tmin = ray_tmin(sc, o, d);
+        const bool has_jit = jitter != nullptr;
+        const float u = has_jit ? jitter[ray] : 0.0f;
+
+        float T = 1.0f, acc_l = 0.0f, dep_l = 0.0f;
+        int napp = 0;
+        bool seen = false, terminated = false;
+        int c = 0;
+        for (; c * 64 < S; ++c) {
+            const int j = c * 64 + lane;
+            const bool inr = j < S;
+            float fj = (float)j, fj1 = (float)(j + 1);
+            if (has_jit) { fj = fj + u; fj1 = fj1 + u; }
+            const float z = tmin + sc.step * fj;               // tensorBase.py:354-355
+            const float z1 = tmin + sc.step * fj1;
+            float p[3], n[3], f[3];
+            bool bbox = inr;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                p[k] = o[k] + d[k] * z;                        // :357
+                bbox = bbox & !((sc.lo[k] > p[k]) | (p[k] > sc.hi[k]));   // :358
+            }
+            bool valid = bbox;
+            if (sc.avol != nullptr) {
+                if (bbox) valid = alpha_lookup(sc, p) > 0.0f;  // :491-496
+            }
+            int i0[3];
+            float w[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                n[k] = (p[k] - sc.lo[k]) * sc.inv[k] - 1.0f;   // :223-224
+                f[k] = unnorm(n[k], sc.gm1[k]);
+                const float fl = floorf(f[k]);
+                i0[k] = (int)fl;
+                w[k] = f[k] - fl;
+            }
+            const unsigned long long mb = __ballot(bbox), mv = __ballot(valid);
+            if (DENSE) {
+                const size_t q = (size_t)ray * S + j;
+                if (inr) {
+                    if (dn.z) dn.z[q] = z;
+                    if (dn.valid) dn.valid[q] = valid;
+                    if (dn.bbox_valid) dn.bbox_valid[q] = bbox;
+                    if (dn.cell) { dn.cell[q * 3] = i0[0]; dn.cell[q * 3 + 1] = i0[1]; dn.cell[q * 3 + 2] = i0[2]; }
+                }
+            }
+            st_bbox += __popcll(mb);
+            if (mv == 0ull) {
+                // no density anywhere in this chunk: alpha = 0, T unchanged (1 - 0 + 1e-10 == 1 in fp32), weights 0
+                if (DENSE && inr) {
+                    const size_t q = (size_t)ray * S + j;
+                    if (dn.sigma_feature) dn.sigma_feature[q] = 0.f;
+                    if (dn.sigma) dn.sigma[q] = 0.f;
+                    if (dn.alpha) dn.alpha[q] = 0.f;
+                    if (dn.weight) dn.weight[q] = 0.f;
+                }
+                if (mb == 0ull && seen && !DENSE) break;        // left the (convex) box: nothing further can be valid
+                continue;
+            }
+            seen = true;
+            st_eval += __popcll(mv);
+
+            // ---- density feature: 4 sub-steps, quad-per-sample gather ----
+            float sf = 0.0f;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int src = qbase | k4;
+                const bool v = __shfl((int)valid, src) != 0;
+                if (__ballot(v) == 0ull) continue;
+                const int ix = __shfl(i0[0], src), iy = __shfl(i0[1], src), iz = __shfl(i0[2], src);
+                const float wx = __shfl(w[0], src), wy = __shfl(w[1], src), wz = __shfl(w[2], src);
+                float part = 0.0f;
+                if (v) {
+                    // plane0 (x,y)·line0(z) ; plane1 (x,z)·line1(y) ; plane2 (y,z)·line2(x)   (matMode / vecMode)
+                    const float4 a = vm_term<4, false>(sc.dplane[0], sc.dline[0], sc.grid[0], sc.grid[1], sc.grid[2], ix, iy, iz, wx, wy, wz, sub);
+                    const float4 b = vm_term<4, false>(sc.dplane[1], sc.dline[1], sc.grid[0], sc.grid[2], sc.grid[1], ix, iz, iy, wx, wz, wy, sub);
+                    const float4 cc = vm_term<4, false>(sc.dplane[2], sc.dline[2], sc.grid[1], sc.grid[2], sc.grid[0], iy, iz, ix, wy, wz, wx, sub);
+                    part = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((cc.x + cc.y) + (cc.z + cc.w));
+                }
+                part += __shfl_xor(part, 1);
+                part += __shfl_xor(part, 2);
+                if (sub == k4) sf = part;
+            }
+
+            float sigma = 0.0f;
+            if (valid) sigma = (sc.act == 0) ? softplus_f(sf + sc.shift) : fmaxf(sf, 0.0f);   // :444-448
+            float dist = (j < S - 1) ? (z1 - z) : 0.0f;           // :488
+            dist = dist * sc.scale;                               // :511
+            const float alpha = 1.0f - expf(-sigma * dist);       // :19
+            const float fT = (1.0f - alpha) + 1e-10f;             // :21
+            float incl = fT;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float t = __shfl_up(incl, off);
+                if (lane >= off) incl = incl * t;
+            }
+            float excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 1.0f;
+            const float Tj = T * excl;
+            const float wgt = alpha * Tj;                          // :23
+            acc_l += wgt;
+            dep_l += wgt * z;
+            const bool app = wgt > sc.thres;                       // :513
+            const unsigned long long ma = __ballot(app);
+            if (ma) {
+                const int pos = napp + __popcll(ma & ((1ull << lane) - 1ull));
+                if (app) buf[pos] = make_uint2((unsigned)j, __float_as_uint(wgt));
+                napp += __popcll(ma);
+            }
+            T = T * __shfl(incl, 63);
+            if (DENSE && inr) {
+                const size_t q = (size_t)ray * S + j;
+                if (dn.sigma_feature) dn.sigma_feature[q] = valid ? sf : 0.f;
+                if (dn.sigma) dn.sigma[q] = sigma;
+                if (dn.alpha) dn.alpha[q] = alpha;
+                if (dn.weight) dn.weight[q] = wgt;
+            }
+            if (T < eps_T) { terminated = true; ++c; break; }
+        }
+        if (DENSE) {
+            // samples never visited (early exit) get zeros so the dense arrays are fully defined
+            for (int cc = c; cc * 64 < S; ++cc) {
+                const int j = cc * 64 + lane;
+                if (j < S) {
+                    const size_t q = (size_t)ray * S + j;
+                    const float fjj = has_jit ? ((float)j + u) : (float)j;
+                    if (dn.z) dn.z[q] = tmin + sc.step * fjj;
+                    if (dn.valid) dn.valid[q] = 0;
+                    if (dn.bbox_valid) dn.bbox_valid[q] = 0;
+                    if (dn.cell) { dn.cell[q * 3] = 0; dn.cell[q * 3 + 1] = 0; dn.cell[q * 3 + 2] = 0; }
+                    if (dn.sigma_feature) dn.sigma_feature[q] = 0.f;
+                    if (dn.sigma) dn.sigma[q] = 0.f;
+                    if (dn.alpha) dn.alpha[q] = 0.f;
+                    if (dn.weight) dn.weight[q] = 0.f;
+                }
+            }
+        }
+        st_term += terminated ? 1 : 0;
+
+        const float acc = wave_sum(acc_l);
+        const float dep = wave_sum(dep_l);
+        unsigned base = 0;
+        if (lane == 0 && napp > 0) base = atomicAdd(mo.counter, (unsigned)napp);
+        base = __shfl(base, 0);
+        if (lane == 0) {
+            mo.ray_off[ray] = base;
+            mo.ray_cnt[ray] = (unsigned)napp;
+            mo.acc[ray] = acc;
+            mo.depth[ray] = dep + (1.0f - acc) * d[2];            // :531 (rays[..., -1] is d_z)
+            if (DENSE) {
+                if (dn.bg_weight) dn.bg_weight[ray] = T;
+                if (dn.acc) dn.acc[ray] = acc;
+                if (dn.t_min) dn.t_min[ray] = tmin;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int i = lane; i < napp; i += 64) {
+            const uint2 e = buf[i];
+            float fj = (float)e.x;
+            if (has_jit) fj = fj + u;
+            const float z = tmin + sc.step * fj;
+            float4 qv;
+            qv.x = ((o[0] + d[0] * z) - sc.lo[0]) * sc.inv[0] - 1.0f;
+            qv.y = ((o[1] + d[1] * z) - sc.lo[1]) * sc.inv[1] - 1.0f;
+            qv.z = ((o[2] + d[2] * z) - sc.lo[2]) * sc.inv[2] - 1.0f;
+            qv.w = __uint_as_float(e.y);
+            mo.q_pos[base + i] = qv;
+            mo.q_ray[base + i] = (unsigned)ray;
+            if (mo.q_j) mo.q_j[base + i] = e.x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (mo.stats) {
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_SAMPLES_EVAL], st_eval);
+            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_SAMPLES_BBOX], st_bbox);
+            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_RAYS_TERMINATED], st_term);
+        }
+    }
+}
+
+// composite tail (tensorBase.py:520-527): rgb_map = sum_j w_j*rgb_j (+ 1-acc if white_bg), clamp(0,1).
+// One thread per ray walks the ray's contiguous, sample-ordered queue segment: fixed summation order.
+__global__ __launch_bounds__(256) void composite_kernel(const MarchOut mo, const int n_rays, const int white_bg,
+                                                        float *__restrict__ rgb_out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const unsigned base = mo.ray_off[r], cnt = mo.ray_cnt[r];
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (unsigned i = 0; i < cnt; ++i) {
+        const float4 e = mo.q_pos[base + i];     // {r,g,b,w} after the shade kernel
+        c0 = c0 + e.w * e.x;
+        c1 = c1 + e.w * e.y;
+        c2 = c2 + e.w * e.z;
+    }
+    const float acc = mo.acc[r];
+    if (white_bg) {
+        const float bg = 1.0f - acc;
+        c0 = c0 + bg; c1 = c1 + bg; c2 = c2 + bg;
+    }
+    rgb_out[(size_t)r * 3 + 0] = fminf(fmaxf(c0, 0.f), 1.f);
+    rgb_out[(size_t)r * 3 + 1] = fminf(fmaxf(c1, 0.f), 1.f);
+    rgb_out[(size_t)r * 3 + 2] = fminf(fmaxf(c2, 0.f), 1.f);
+}
+
+// additional_output: scatter per-entry rgb back to the dense [n,S,3] array
+__global__ __launch_bounds__(256) void scatter_rgb_kernel(const MarchOut mo, const int S, float *__restrict__ rgb_dense)
+{
+    const unsigned n = *mo.counter;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const float4 v = mo.q_pos[e];
+        const size_t q = ((size_t)mo.q_ray[e] * S + mo.q_j[e]) * 3;
+        rgb_dense[q] = v.x; rgb_dense[q + 1] = v.y; rgb_dense[q + 2] = v.z;
+    }
+}
+
+// ---- generic feature lookups (compute_densityfeature / sample_alpha API): arbitrary coordinates, zeros padding ----
+__global__ __launch_bounds__(256) void density_feature_kernel(const SceneDev sc, const float *__restrict__ xyz, const long long m,
+                                                              float *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long s = t >> 2;
+    const int sub = threadIdx.x & 3;
+    float part = 0.0f;
+    if (s < m) {
+        int i0[3];
+        float w[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float f = unnorm(xyz[s * 3 + k], sc.gm1[k]);
+            const float fl = floorf(fminf(fmaxf(f, -2.0f), sc.gm1[k] + 2.0f));
+            i0[k] = (int)fl;
+            w[k] = f - fl;
+        }
+        const float4 a = vm_term<4, true>(sc.dplane[0], sc.dline[0], sc.grid[0], sc.grid[1], sc.grid[2], i0[0], i0[1], i0[2], w[0], w[1], w[2], sub);
+        const float4 b = vm_term<4, true>(sc.dplane[1], sc.dline[1], sc.grid[0], sc.grid[2], sc.grid[1], i0[0], i0[2], i0[1], w[0], w[2], w[1], sub);
+        const float4 c = vm_term<4, true>(sc.dplane[2], sc.dline[2], sc.grid[1], sc.grid[2], sc.grid[0], i0[1], i0[2], i0[0], w[1], w[2], w[0], sub);
+        part = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w));
+    }
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    if (s < m && sub == 0) out[s] = part;
+}
+
+__global__ __launch_bounds__(256) void alpha_sample_kernel(const SceneDev sc, const float *__restrict__ xyz, const long long m,
+                                                           float *__restrict__ out)
+{
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= m) return;
+    const float p[3] = {xyz[s * 3], xyz[s * 3 + 1], xyz[s * 3 + 2]};
+    out[s] = alpha_lookup(sc, p);
+}
+
+// ---- host launchers ----
+hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T,
+                        const MarchOut &mo, const tvr_dense_out *dense, hipStream_t stream)
+{
+    const int rpb = 16;
+    const int s_cap = S;
+    const size_t lds = (size_t)MARCH_WAVES * s_cap * sizeof(uint2);
+    const unsigned nblk = (unsigned)((n_rays + rpb - 1) / rpb);
+    if (dense) {
+        (void)hipFuncSetAttribute((const void *)march_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(march_kernel<true>, dim3(nblk), dim3(MARCH_THREADS), lds, stream, sc, rays, n_rays, S, s_cap, jitter,
+                           eps_T, rpb, mo, *dense);
+    } else {
+        tvr_dense_out none = {};
+        (void)hipFuncSetAttribute((const void *)march_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(march_kernel<false>, dim3(nblk), dim3(MARCH_THREADS), lds, stream, sc, rays, n_rays, S, s_cap, jitter,
+                           eps_T, rpb, mo, none);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_composite(const MarchOut &mo, int n_rays, int white_bg, float *rgb, hipStream_t stream)
+{
+    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, stream, mo, n_rays, white_bg, rgb);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_rgb(const MarchOut &mo, int S, float *rgb_dense, hipStream_t stream)
+{
+    hipLaunchKernelGGL(scatter_rgb_kernel, dim3(1024), dim3(256), 0, stream, mo, S, rgb_dense);
+    return hipGetLastError();
+}
+
+hipError_t launch_density_feature(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream)
+{
+    const long long blocks = (m * 4 + 255) / 256;
+    hipLaunchKernelGGL(density_feature_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, sc, xyz, m, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_alpha_sample(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(alpha_sample_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, sc, xyz, m, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,415 @@
+"""Host-side mirror of the reference's field model for the render path, backed by libtvr.so (HIP, gfx950).
+
+Same names, argument meaning and return tuples as the reference (paths relative to /root/reference/tensorf-myc/):
+  * AlphaGridMask             models/tensorBase.py:39-59
+  * MLPRender_Fea             models/tensorBase.py:62-86
+  * TensorBase / TensorVMSplit  models/tensorBase.py:140-536, models/tensoRF.py:141-244
+so `train.py` / `renderer.py` call sites (`tensorf(rays_chunk, is_train=…, white_bg=…, ndc_ray=…, N_samples=…)`,
+`compute_densityfeature`, `compute_appfeature`, `get_kwargs`, `save` / `load`) work unchanged, with torch tensors in
+place of jt.Var.  Parameters stay in the reference layout ((1,C,H,W) planes, (1,C,L,1) lines, Linear [out,in]) as
+the Python-visible truth; a packed channels-last device copy is refreshed automatically when they change.
+
+There is NO CPU fallback: every compute call goes through the C-ABI and raises if the HIP library is missing.
+Scope this round: inference (no autograd through the kernels), shadingMode 'MLP_Fea', ndc_ray=False.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class AlphaGridMask:
+    """tensorBase.py:39-59.  alpha_volume has shape (gz, gy, gx) (any leading 1s); values are used as given.
+    (A plain object rather than a Module: it holds no parameters, only the occupancy volume.)"""
+
+    def __init__(self, device, aabb, alpha_volume):
+        self.device = torch.device(device)
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).reshape(2, 3).cpu()
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invgridSize = 1.0 / self.aabbSize * 2                                 # :46
+        vol = torch.as_tensor(alpha_volume)
+        self.alpha_volume = _f32c(vol, self.device).view(1, 1, *vol.shape[-3:])     # :47
+        self.gridSize = torch.tensor([vol.shape[-1], vol.shape[-2], vol.shape[-3]], dtype=torch.int32)   # :48
+
+    def _c_args(self):
+        ag = (C.c_int32 * 3)(*[int(x) for x in self.gridSize])
+        ab = (C.c_float * 6)(*[float(x) for x in self.aabb.reshape(-1)])
+        inv = (C.c_float * 3)(*[float(x) for x in self.invgridSize])
+        return ag, ab, inv
+
+    def sample_alpha(self, xyz_sampled: torch.Tensor) -> torch.Tensor:
+        x = _f32c(xyz_sampled, self.device).view(-1, 3)
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        if x.shape[0] == 0:
+            return out
+        ag, ab, inv = self._c_args()
+        L.check(L.lib().tvr_alpha_sample(self.alpha_volume.data_ptr(), C.byref(ag), C.byref(ab), C.byref(inv),
+                                         x.data_ptr(), x.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+                "tvr_alpha_sample")
+        return out
+
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0].to(xyz_sampled.device)) * self.invgridSize.to(xyz_sampled.device) - 1
+
+
+class MLPRender_Fea(torch.nn.Module):
+    """tensorBase.py:62-86: parameters only; the arithmetic runs in the shade kernel of the owning field."""
+
+    def __init__(self, inChanel, viewpe=6, feape=6, featureC=128):
+        super().__init__()
+        self.in_mlpC = 2 * viewpe * 3 + 2 * feape * inChanel + 3 + inChanel
+        self.viewpe, self.feape = viewpe, feape
+        layer1 = torch.nn.Linear(self.in_mlpC, featureC)
+        layer2 = torch.nn.Linear(featureC, featureC)
+        layer3 = torch.nn.Linear(featureC, 3)
+        self.mlp = torch.nn.Sequential(layer1, torch.nn.ReLU(), layer2, torch.nn.ReLU(), layer3)
+        torch.nn.init.constant_(self.mlp[-1].bias, 0)
+        self._owner = None
+
+    def forward(self, pts, viewdirs, features):
+        if self._owner is None:
+            raise L.TvrError("MLPRender_Fea is not attached to a TensorVMSplit field (no packed weights on the device)")
+        return self._owner()._mlp_render(viewdirs, features)
+
+
+class TensorBase(torch.nn.Module):
+    """tensorBase.py:140-536 (render-path subset)."""
+
+    def __init__(self, aabb, gridSize, device, density_n_comp=8, appearance_n_comp=24, app_dim=27,
+                 shadingMode='MLP_PE', alphaMask=None, near_far=[2.0, 20.0],
+                 density_shift=-10, alphaMask_thres=0.001, distance_scale=25, rayMarch_weight_thres=0.0001,
+                 pos_pe=6, view_pe=6, fea_pe=6, featureC=128, step_ratio=2.0, fea2denseAct='softplus'):
+        super().__init__()
+        self.device = torch.device(device)
+        self.density_n_comp = list(density_n_comp) if hasattr(density_n_comp, "__len__") else [density_n_comp] * 3
+        self.app_n_comp = list(appearance_n_comp) if hasattr(appearance_n_comp, "__len__") else [appearance_n_comp] * 3
+        self.app_dim = app_dim
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).reshape(2, 3).cpu()
+        self.density_shift = density_shift
+        self.alphaMask_thres = alphaMask_thres
+        self.distance_scale = distance_scale
+        self.rayMarch_weight_thres = rayMarch_weight_thres
+        self.fea2denseAct = fea2denseAct
+        self.near_far = near_far
+        self.step_ratio = step_ratio
+        self.matMode = [[0, 1], [0, 2], [1, 2]]
+        self.vecMode = [2, 1, 0]
+        self.comp_w = [1, 1, 1]
+        self.eps_T = None            # early-termination threshold; None -> rayMarch_weight_thres (0 = exact)
+        self._scene = None           # tvr_scene*
+        self._packed = None
+        self._scratch = None
+        self._sig = None
+        self._alphaMask = None
+        self.update_stepSize(gridSize)
+        self.init_svd_volume(gridSize[0], device)
+        self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
+        self.init_render_func(shadingMode, pos_pe, view_pe, fea_pe, featureC, device)
+        self.alphaMask = alphaMask
+        self.to(self.device)
+
+    # ---- reference surface -------------------------------------------------------------------------------
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):      # :178-195
+        if shadingMode != 'MLP_Fea':
+            raise NotImplementedError(f"shadingMode {shadingMode!r}: only 'MLP_Fea' (what every shipped config uses, "
+                                      "configs/*.txt) is on the accelerated render path")
+        self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC)
+        import weakref
+        self.renderModule._owner = weakref.ref(self)
+
+    def update_stepSize(self, gridSize):                                                      # :197-209
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        gridSize = [int(i) for i in gridSize]
+        self.gridSize = torch.tensor(gridSize, dtype=torch.int32)
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.aabbDiag = torch.sqrt(torch.sum(torch.pow(self.aabbSize, 2)))
+        self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+        self._drop_scene()
+
+    def init_svd_volume(self, res, device):
+        raise NotImplementedError
+
+    def normalize_coord(self, xyz_sampled):                                                   # :223-224
+        return (xyz_sampled - self.aabb[0].to(xyz_sampled.device)) * self.invaabbSize.to(xyz_sampled.device) - 1
+
+    def feature2density(self, density_features):                                              # :444-448
+        if self.fea2denseAct == "softplus":
+            return torch.nn.functional.softplus(density_features + self.density_shift)
+        elif self.fea2denseAct == "relu":
+            return torch.relu(density_features)
+
+    def get_kwargs(self):                                                                     # :229-251
+        return {'aabb': self.aabb, 'gridSize': self.gridSize.tolist(), 'density_n_comp': self.density_n_comp,
+                'appearance_n_comp': self.app_n_comp, 'app_dim': self.app_dim,
+                'density_shift': self.density_shift, 'alphaMask_thres': self.alphaMask_thres,
+                'distance_scale': self.distance_scale, 'rayMarch_weight_thres': self.rayMarch_weight_thres,
+                'fea2denseAct': self.fea2denseAct, 'near_far': self.near_far, 'step_ratio': self.step_ratio,
+                'shadingMode': self.shadingMode, 'pos_pe': self.pos_pe, 'view_pe': self.view_pe,
+                'fea_pe': self.fea_pe, 'featureC': self.featureC}
+
+    def save(self, path, global_kwargs=None):                                                 # :253-264
+        ckpt = {'kwargs': self.get_kwargs(), 'state_dict': {k: v.detach().cpu() for k, v in self.state_dict().items()}}
+        if global_kwargs is not None:
+            ckpt.update(global_kwargs)
+        if self.alphaMask is not None:
+            alpha_volume = self.alphaMask.alpha_volume.bool().cpu().numpy()
+            ckpt.update({'alphaMask.shape': alpha_volume.shape})
+            ckpt.update({'alphaMask.mask': np.packbits(alpha_volume.reshape(-1))})
+            ckpt.update({'alphaMask.aabb': self.alphaMask.aabb})
+        torch.save(ckpt, path)
+
+    def load(self, ckpt):                                                                     # :266-272
+        if 'alphaMask.aabb' in ckpt.keys():
+            length = int(np.prod(ckpt['alphaMask.shape']))
+            vol = torch.from_numpy(np.unpackbits(ckpt['alphaMask.mask'])[:length].reshape(ckpt['alphaMask.shape']))
+            self.alphaMask = AlphaGridMask(self.device, ckpt['alphaMask.aabb'], vol.float())
+        self.load_state_dict(ckpt['state_dict'])
+
+    @property
+    def alphaMask(self) -> Optional[AlphaGridMask]:
+        return self._alphaMask
+
+    @alphaMask.setter
+    def alphaMask(self, m: Optional[AlphaGridMask]):
+        object.__setattr__(self, "_alphaMask", m)
+        self._alpha_dirty = True
+
+    # ---- device scene management -------------------------------------------------------------------------
+    def _drop_scene(self):
+        if getattr(self, "_scene", None):
+            L.lib().tvr_scene_destroy(self._scene)
+        self._scene, self._packed, self._sig = None, None, None
+        self._alpha_dirty = True
+
+    def __del__(self):
+        try:
+            self._drop_scene()
+        except Exception:
+            pass
+
+    def _param_list(self):
+        m = self.renderModule.mlp
+        return (list(self.density_plane) + list(self.density_line) + list(self.app_plane) + list(self.app_line)
+                + [self.basis_mat.weight, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias])
+
+    def _ensure_scene(self):
+        """Create the tvr_scene on first use and re-pack whenever a parameter tensor was replaced or written in place."""
+        lib = L.lib()
+        if self.device.type != "cuda":
+            raise L.TvrError(f"the render path runs on an MI355X (HIP) device only; model device is {self.device}. "
+                             "There is no CPU fallback.")
+        ps = self._param_list()
+        sig = tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in ps)
+        if self._scene is None:
+            d = L.SceneDesc()
+            d.aabb[:] = [float(x) for x in self.aabb.reshape(-1)]
+            d.grid[:] = [int(x) for x in self.gridSize]
+            d.density_n_comp[:] = [int(x) for x in self.density_n_comp]
+            d.app_n_comp[:] = [int(x) for x in self.app_n_comp]
+            d.app_dim, d.featureC, d.view_pe, d.fea_pe = self.app_dim, self.featureC, self.view_pe, self.fea_pe
+            d.near_, d.far_ = float(self.near_far[0]), float(self.near_far[1])
+            d.step_size = float(self.stepSize)
+            d.inv_aabb_size[:] = [float(x) for x in self.invaabbSize]
+            d.density_shift, d.distance_scale = float(self.density_shift), float(self.distance_scale)
+            d.weight_thres = float(self.rayMarch_weight_thres)
+            d.fea2dense_act = 0 if self.fea2denseAct == "softplus" else 1
+            nbytes = lib.tvr_scene_packed_bytes(C.byref(d))
+            if nbytes == 0:
+                raise L.TvrError("unsupported field configuration: " + lib.tvr_last_error().decode())
+            self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            h = C.c_void_p()
+            L.check(lib.tvr_scene_create(C.byref(d), self._packed.data_ptr(), nbytes, C.byref(h)), "tvr_scene_create")
+            self._scene = h
+            self._sig = None
+            self._alpha_dirty = True
+        if sig != self._sig:
+            for p in ps:
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.device != self._packed.device:
+                    raise L.TvrError("field parameters must be contiguous fp32 tensors on the model's device")
+            sp = L.SceneParams()
+            for i in range(3):
+                sp.density_plane[i], sp.density_line[i] = self.density_plane[i].data_ptr(), self.density_line[i].data_ptr()
+                sp.app_plane[i], sp.app_line[i] = self.app_plane[i].data_ptr(), self.app_line[i].data_ptr()
+            m = self.renderModule.mlp
+            sp.basis_mat = self.basis_mat.weight.data_ptr()
+            sp.W1, sp.b1 = m[0].weight.data_ptr(), m[0].bias.data_ptr()
+            sp.W2, sp.b2 = m[2].weight.data_ptr(), m[2].bias.data_ptr()
+            sp.W3, sp.b3 = m[4].weight.data_ptr(), m[4].bias.data_ptr()
+            L.check(lib.tvr_scene_update(self._scene, C.byref(sp), _stream_ptr(self.device)), "tvr_scene_update")
+            self._sig = sig
+        if self._alpha_dirty:
+            am = self._alphaMask
+            if am is None:
+                L.check(lib.tvr_scene_set_alpha(self._scene, None, None, None, None), "tvr_scene_set_alpha")
+            else:
+                ag, ab, inv = am._c_args()
+                L.check(lib.tvr_scene_set_alpha(self._scene, am.alpha_volume.data_ptr(), C.byref(ag), C.byref(ab), C.byref(inv)),
+                        "tvr_scene_set_alpha")
+            self._alpha_dirty = False
+        return self._scene
+
+    def _get_scratch(self, nbytes: int) -> torch.Tensor:
+        if self._scratch is None or self._scratch.numel() < nbytes:
+            self._scratch = None
+            self._scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._scratch
+
+    # ---- compute entry points ----------------------------------------------------------------------------
+    def compute_densityfeature(self, xyz_sampled):                                            # tensoRF.py:209-225
+        sc = self._ensure_scene()
+        x = _f32c(xyz_sampled, self.device).view(-1, 3)
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        L.check(L.lib().tvr_density_feature(sc, x.data_ptr(), x.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+                "tvr_density_feature")
+        return out
+
+    def compute_appfeature(self, xyz_sampled):                                                # tensoRF.py:228-244
+        sc = self._ensure_scene()
+        x = _f32c(xyz_sampled, self.device).view(-1, 3)
+        out = torch.empty((x.shape[0], self.app_dim), dtype=torch.float32, device=self.device)
+        L.check(L.lib().tvr_app_feature(sc, x.data_ptr(), x.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+                "tvr_app_feature")
+        return out
+
+    def _mlp_render(self, viewdirs, features):
+        sc = self._ensure_scene()
+        v = _f32c(viewdirs, self.device).view(-1, 3)
+        f = _f32c(features, self.device).view(-1, self.app_dim)
+        out = torch.empty((v.shape[0], 3), dtype=torch.float32, device=self.device)
+        L.check(L.lib().tvr_mlp_render(sc, v.data_ptr(), f.data_ptr(), v.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+                "tvr_mlp_render")
+        return out
+
+    def compute_alpha(self, xyz_locs, length=1):                                              # :451-473
+        xyz_locs = _f32c(xyz_locs, self.device)
+        flat = xyz_locs.view(-1, 3)
+        if self.alphaMask is not None:
+            alpha_mask = self.alphaMask.sample_alpha(flat) > 0
+        else:
+            alpha_mask = torch.ones(flat.shape[0], dtype=torch.bool, device=self.device)
+        sigma = torch.zeros(flat.shape[0], device=self.device)
+        if alpha_mask.any():
+            sf = self.compute_densityfeature(self.normalize_coord(flat[alpha_mask]))
+            sigma[alpha_mask] = self.feature2density(sf)
+        length = float(length) if not torch.is_tensor(length) else length.to(self.device)
+        return (1 - torch.exp(-sigma * length)).view(xyz_locs.shape[:-1])
+
+    def render_rays(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None, eps_T=None, dense=False,
+                    stats: Optional[torch.Tensor] = None, profile=None):
+        """One tvr_render call.  Returns (rgb_map [N,3], depth_map [N]) or, with dense=True, additionally a dict
+        of per-sample tensors.  `stats`: uint64/int64[8] device tensor the kernels add counters to."""
+        sc = self._ensure_scene()
+        lib = L.lib()
+        rays = _f32c(rays_chunk, self.device)
+        if rays.dim() != 2 or rays.shape[1] != 6:
+            raise ValueError(f"rays must be [N,6] (origin, direction); got {tuple(rays.shape)}")
+        n = rays.shape[0]
+        S = int(N_samples) if N_samples > 0 else self.nSamples                                # :341
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        depth = torch.empty((n,), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return (rgb, depth, {}) if dense else (rgb, depth)
+        if eps_T is None:
+            eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
+        nbytes = lib.tvr_render_scratch_bytes(sc, n, S)
+        scratch = self._get_scratch(nbytes)
+        jit = None if jitter is None else _f32c(jitter, self.device).view(-1)
+        if jit is not None and jit.shape[0] != n:
+            raise ValueError("jitter must hold one value per ray")
+        dn, out = None, {}
+        if dense:
+            dn = L.DenseOut()
+            dev = self.device
+            out = dict(z=torch.empty((n, S), device=dev), valid=torch.empty((n, S), dtype=torch.uint8, device=dev),
+                       bbox_valid=torch.empty((n, S), dtype=torch.uint8, device=dev),
+                       cell=torch.empty((n, S, 3), dtype=torch.int32, device=dev),
+                       sigma_feature=torch.empty((n, S), device=dev), sigma=torch.empty((n, S), device=dev),
+                       alpha=torch.empty((n, S), device=dev), weight=torch.empty((n, S), device=dev),
+                       rgb=torch.empty((n, S, 3), device=dev), bg_weight=torch.empty((n,), device=dev),
+                       acc=torch.empty((n,), device=dev), t_min=torch.empty((n,), device=dev))
+            for k, v in out.items():
+                setattr(dn, k, v.data_ptr())
+        L.check(lib.tvr_render(sc, rays.data_ptr(), n, S, int(bool(white_bg)), None if jit is None else jit.data_ptr(),
+                               float(eps_T), rgb.data_ptr(), depth.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                               None if dn is None else C.byref(dn), None if stats is None else stats.data_ptr(),
+                               profile, _stream_ptr(self.device)), "tvr_render")
+        return (rgb, depth, out) if dense else (rgb, depth)
+
+    def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1, additional_output=False):
+        """TensorBase.execute (tensorBase.py:476-536)."""
+        if ndc_ray:
+            raise NotImplementedError("ndc_ray=True (sample_ray_ndc) is outside the accelerated path; all shipped "
+                                      "configs render Blender-format scenes with ndc_ray=0")
+        jitter = None
+        if is_train:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError("training through the HIP kernels (autograd) is not built yet; call under "
+                                          "torch.no_grad() or with is_train=False")
+            jitter = torch.rand(rays_chunk.shape[0], device=self.device)                      # :351-353
+        if additional_output:
+            rgb_map, depth_map, d = self.render_rays(rays_chunk, white_bg, N_samples, jitter, dense=True)
+            return rgb_map, depth_map, d["rgb"], d["sigma"], d["alpha"], d["weight"], d["bg_weight"].view(-1, 1)
+        return self.render_rays(rays_chunk, white_bg, N_samples, jitter)
+
+    execute = forward
+
+
+class TensorVMSplit(TensorBase):
+    """tensoRF.py:141-244."""
+
+    def __init__(self, aabb, gridSize, device, **kargs):
+        super().__init__(aabb, gridSize, device, **kargs)
+
+    def init_svd_volume(self, res, device):                                                   # tensoRF.py:146-151
+        self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, self.gridSize, 0.1, device)
+        self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, self.gridSize, 0.1, device)
+        self.basis_mat = torch.nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False)
+
+    def init_one_svd(self, n_component, gridSize, scale, device):                             # tensoRF.py:154-164
+        plane_coef, line_coef = [], []
+        for i in range(len(self.vecMode)):
+            vec_id = self.vecMode[i]
+            mat_id_0, mat_id_1 = self.matMode[i]
+            plane_coef.append(torch.nn.Parameter(
+                scale * torch.randn((1, n_component[i], int(gridSize[mat_id_1]), int(gridSize[mat_id_0])))))
+            line_coef.append(torch.nn.Parameter(scale * torch.randn((1, n_component[i], int(gridSize[vec_id]), 1))))
+        return torch.nn.ParameterList(plane_coef), torch.nn.ParameterList(line_coef)
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):            # tensoRF.py:168-174
+        grad_vars = [{'params': self.density_line, 'lr': lr_init_spatialxyz}, {'params': self.density_plane, 'lr': lr_init_spatialxyz},
+                     {'params': self.app_line, 'lr': lr_init_spatialxyz}, {'params': self.app_plane, 'lr': lr_init_spatialxyz},
+                     {'params': self.basis_mat.parameters(), 'lr': lr_init_network}]
+        grad_vars += [{'params': self.renderModule.parameters(), 'lr': lr_init_network}]
+        return grad_vars
+
+    def load_arrays(self, arrs):
+        """Copy a flat array dict (synthetic.make_scene_arrays / oracle layout) into the parameters."""
+        with torch.no_grad():
+            for i in range(3):
+                self.density_plane[i].copy_(torch.as_tensor(arrs[f"density_plane.{i}"]))
+                self.density_line[i].copy_(torch.as_tensor(arrs[f"density_line.{i}"]))
+                self.app_plane[i].copy_(torch.as_tensor(arrs[f"app_plane.{i}"]))
+                self.app_line[i].copy_(torch.as_tensor(arrs[f"app_line.{i}"]))
+            self.basis_mat.weight.copy_(torch.as_tensor(arrs["basis_mat"]))
+            m = self.renderModule.mlp
+            for idx, (w, b) in zip((0, 2, 4), (("W1", "b1"), ("W2", "b2"), ("W3", "b3"))):
+                m[idx].weight.copy_(torch.as_tensor(arrs[w]))
+                m[idx].bias.copy_(torch.as_tensor(arrs[b]))
+        if "alpha_volume" in arrs:
+            self.alphaMask = AlphaGridMask(self.device, arrs["alpha_aabb"], torch.as_tensor(arrs["alpha_volume"]))
+        return self

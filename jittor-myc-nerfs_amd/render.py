@@ -1,0 +1,68 @@
+"""Ray-batch render loop and its multi-GPU sharding.
+
+  * OctreeRender_trilinear_fast — same signature and return tuple as tensorf-myc/renderer.py:12-27
+    (`(rgb [R,3], None, depth [R], None, None)`); each chunk is ONE tvr_render call (three kernels) on the current
+    stream, with no host synchronisation between chunks (the reference syncs and garbage-collects per chunk, :23-25).
+  * render_sharded — new functionality (the reference is single-GPU): rays are cut into fixed-size
+    tiles dealt round-robin to the ranks (interleaving evens out empty-vs-dense image regions), each rank renders
+    its tiles, and ONE all_gather (RCCL over xGMI when the backend is "nccl") returns every pixel to every rank.
+    Per-ray results do not depend on the partition, so the gathered image equals the single-GPU image bit for bit.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+
+def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray=False, white_bg=True, is_train=False,
+                                device='cuda'):
+    rgbs, depth_maps = [], []
+    N_rays_all = rays.shape[0]
+    for chunk_idx in range(N_rays_all // chunk + int(N_rays_all % chunk > 0)):
+        rays_chunk = rays[chunk_idx * chunk:(chunk_idx + 1) * chunk]
+        rgb_map, depth_map = tensorf(rays_chunk, is_train=is_train, white_bg=white_bg, ndc_ray=ndc_ray, N_samples=N_samples)
+        rgbs.append(rgb_map)
+        depth_maps.append(depth_map)
+    return torch.cat(rgbs), None, torch.cat(depth_maps), None, None
+
+
+def shard_indices(n_rays: int, rank: int, world: int, tile: int = 4096) -> torch.Tensor:
+    """Indices of the rays rank `rank` renders: tiles rank, rank+world, rank+2*world, ... of `tile` rays each."""
+    n_tiles = (n_rays + tile - 1) // tile
+    if rank >= n_tiles:
+        return torch.zeros(0, dtype=torch.long)
+    mine = torch.arange(rank, n_tiles, world)
+    idx = (mine[:, None] * tile + torch.arange(tile)[None, :]).reshape(-1)
+    return idx[idx < n_rays]
+
+
+def shard_capacity(n_rays: int, world: int, tile: int = 4096) -> int:
+    """Rays in the largest shard (rank 0's); every rank pads to this so one equal-size all_gather suffices."""
+    n_tiles = (n_rays + tile - 1) // tile
+    return ((n_tiles + world - 1) // world) * tile
+
+
+def render_sharded(rays: torch.Tensor, render_fn: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
+                   rank: int, world: int, tile: int = 4096, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Render `rays` [R,6] (the full batch, present on every rank) across `world` ranks.
+
+    render_fn(rays_subset) -> (rgb [n,3], depth [n]) renders on this rank's device.  Returns the full
+    (rgb [R,3], depth [R]) on every rank after one all_gather of [cap,4] fp32 (rgb + depth packed together)."""
+    import torch.distributed as dist
+    R = rays.shape[0]
+    if world == 1:
+        return render_fn(rays)
+    idx = shard_indices(R, rank, world, tile).to(rays.device)
+    cap = shard_capacity(R, world, tile)
+    rgb, depth = render_fn(rays.index_select(0, idx)) if idx.numel() else (rays.new_zeros((0, 3)), rays.new_zeros((0,)))
+    mine = rays.new_zeros((cap, 4))
+    mine[:idx.numel(), :3] = rgb
+    mine[:idx.numel(), 3] = depth
+    gathered = rays.new_empty((world * cap, 4))
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    out = rays.new_empty((R, 4))
+    for r in range(world):                                     # undo the interleave (index permutation only)
+        ridx = shard_indices(R, r, world, tile).to(rays.device)
+        out.index_copy_(0, ridx, gathered[r * cap:r * cap + ridx.numel()])
+    return out[:, :3].contiguous(), out[:, 3].contiguous()

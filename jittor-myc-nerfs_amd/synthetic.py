@@ -1,0 +1,79 @@
+"""Seeded synthetic TensorVMSplit scenes — numpy only, no device code.
+
+The reference's own initialisation (0.1*randn with density_shift=-10, tensoRF.py:148-149) renders
+nothing (softplus(-10) ~ 4.5e-5), so benchmarks and parity tests use a soft opaque blob instead:
+    density plane_i[c] = |N(0,1)| * g(u) * g(v),  density line_i[c] = |N(0,1)| * g(w),
+    g(s) = exp(-s^2 / (2*0.35^2)) on normalised coordinates s in [-1,1]
+so sigma_feature ~ 30.6*exp(-r^2/(2*0.35^2)) (r = normalised radius): ~30 at the centre, < 5 outside
+r ~ 0.67.  Appearance factors are 0.1*N(0,1) (the reference's init scale), basis / MLP weights
+U(+-1/sqrt(fan_in)), b3 = 0 (tensorBase.py:74).  Parameter shapes follow tensoRF.py:154-164.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+MAT_MODE = ((0, 1), (0, 2), (1, 2))
+VEC_MODE = (2, 1, 0)
+SEED = 20211202          # tensorf-myc/train.py:396
+
+
+def _g(n: int, sigma: float) -> np.ndarray:
+    s = np.linspace(-1.0, 1.0, n)
+    return np.exp(-s * s / (2 * sigma * sigma))
+
+
+def make_scene_arrays(gridSize: Sequence[int], aabb, seed: int = SEED,
+                      density_n_comp=(16, 16, 16), appearance_n_comp=(48, 48, 48), app_dim: int = 27,
+                      featureC: int = 128, view_pe: int = 2, fea_pe: int = 2, blob_sigma: float = 0.35,
+                      alpha_grid: Optional[Sequence[int]] = None) -> Dict[str, np.ndarray]:
+    """Return a flat dict of fp32 arrays in the reference's parameter layout."""
+    rng = np.random.default_rng(seed)
+    g = [int(x) for x in gridSize]
+    out: Dict[str, np.ndarray] = {"aabb": np.asarray(aabb, np.float32).reshape(2, 3), "gridSize": np.asarray(g, np.int32)}
+    gs = [_g(n, blob_sigma) for n in g]
+    for i in range(3):
+        m0, m1 = MAT_MODE[i]
+        v = VEC_MODE[i]
+        c = density_n_comp[i]
+        pl = np.abs(rng.standard_normal((1, c, g[m1], g[m0]))) * gs[m1][None, None, :, None] * gs[m0][None, None, None, :]
+        ln = np.abs(rng.standard_normal((1, c, g[v], 1))) * gs[v][None, None, :, None]
+        out[f"density_plane.{i}"] = pl.astype(np.float32)
+        out[f"density_line.{i}"] = ln.astype(np.float32)
+    for i in range(3):
+        m0, m1 = MAT_MODE[i]
+        v = VEC_MODE[i]
+        c = appearance_n_comp[i]
+        out[f"app_plane.{i}"] = (0.1 * rng.standard_normal((1, c, g[m1], g[m0]))).astype(np.float32)
+        out[f"app_line.{i}"] = (0.1 * rng.standard_normal((1, c, g[v], 1))).astype(np.float32)
+
+    def U(shape, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        return rng.uniform(-b, b, size=shape).astype(np.float32)
+
+    K = int(sum(appearance_n_comp))
+    nin = app_dim + 3 + 2 * fea_pe * app_dim + 2 * view_pe * 3
+    out["basis_mat"] = U((app_dim, K), K)
+    # basis output feeds sin/cos(f*2^k): scale it up so the PE terms are exercised over a few radians
+    out["basis_mat"] *= np.float32(64.0)
+    out["W1"], out["b1"] = U((featureC, nin), nin), U((featureC,), nin)
+    out["W2"], out["b2"] = U((featureC, featureC), featureC), U((featureC,), featureC)
+    out["W3"], out["b3"] = U((3, featureC), featureC) * np.float32(4.0), np.zeros((3,), np.float32)
+    if alpha_grid is not None:
+        ag = [int(x) for x in alpha_grid]                      # (gx, gy, gz); volume stored (gz, gy, gx)
+        zs, ys, xs = [np.linspace(-1, 1, n) for n in (ag[2], ag[1], ag[0])]
+        r2 = zs[:, None, None] ** 2 + ys[None, :, None] ** 2 + xs[None, None, :] ** 2
+        sf = 30.6 * np.exp(-r2 / (2 * blob_sigma ** 2))
+        out["alpha_volume"] = (sf > 0.5).astype(np.float32)    # generous (dilated) occupancy of the blob
+        out["alpha_aabb"] = out["aabb"].copy()
+    return out
+
+
+# BASELINE.json configs: hyper-parameters that go with the arrays.
+SCENE_A = dict(gridSize=[300, 300, 300], aabb=[[-1.5] * 3, [1.5] * 3], near_far=[2.0, 6.0], step_ratio=0.5,
+               cam_radius=4.0, camera_angle_x=0.6911, N_samples=512, img_wh=(800, 800))
+SCENE_B = dict(gridSize=[128, 128, 128], aabb=[[-5.0] * 3, [5.0] * 3], near_far=[5.0, 40.0], step_ratio=0.5,
+               cam_radius=13.0, camera_angle_x=0.6911, N_samples=192, img_wh=(64, 64))
+HYPER = dict(density_shift=-10.0, distance_scale=25.0, rayMarch_weight_thres=1e-4, fea2denseAct="softplus",
+             view_pe=2, fea_pe=2)

@@ -1,0 +1,259 @@
+"""CPU oracle (a): op-for-op torch-CPU restatement of the TensoRF render path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it,
+and only as the checker / CPU baseline.  The shipped path is the HIP library.
+
+PARITY UNPINNED.  The reference (FREDZEL2020/jittor-MYC-NeRFs, tensorf-myc) is
+Python over Jittor; Jittor is not installed, not vendored and cannot be fetched,
+and the reference holds no tests / golden vectors for this path (SURVEY.md §4,
+§8c).  This file restates the reference arithmetic from the source text; it is
+cross-checked against an independent scalar-C restatement (oracle/tvr_oracle.c)
+and uses torch's grid_sample (align_corners=True, zeros padding), which has the
+semantics the reference's F.grid_sample calls rely on.
+
+Every function cites the reference lines (relative to /root/reference/) that it
+follows.  All arithmetic is fp32 on CPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MAT_MODE = ((0, 1), (0, 2), (1, 2))   # tensorf-myc/models/tensorBase.py:168
+VEC_MODE = (2, 1, 0)                  # tensorf-myc/models/tensorBase.py:169
+
+
+def _t(x, dtype=torch.float32):
+    if isinstance(x, torch.Tensor):
+        return x.detach().to("cpu", dtype)
+    return torch.as_tensor(np.asarray(x), dtype=dtype)
+
+
+class OracleScene:
+    """Plain container for everything TensorBase.__init__ / TensorVMSplit hold.
+
+    Parameter shapes follow tensorf-myc/models/tensoRF.py:154-164
+    (planes (1,C,grid[mat1],grid[mat0]), lines (1,C,grid[vec],1)) and the
+    hyper-parameter set of tensorf-myc/models/tensorBase.py:141-145.
+    """
+
+    def __init__(self, aabb, gridSize, density_plane, density_line, app_plane, app_line,
+                 basis_mat, mlp, near_far=(2.0, 6.0), step_ratio=0.5, density_shift=-10.0,
+                 distance_scale=25.0, rayMarch_weight_thres=1e-4, fea2denseAct="softplus",
+                 view_pe=2, fea_pe=2, alpha_volume=None, alpha_aabb=None):
+        self.aabb = _t(aabb).reshape(2, 3)
+        self.gridSize = [int(g) for g in gridSize]
+        self.density_plane = [_t(p) for p in density_plane]
+        self.density_line = [_t(p) for p in density_line]
+        self.app_plane = [_t(p) for p in app_plane]
+        self.app_line = [_t(p) for p in app_line]
+        self.basis_mat = _t(basis_mat)                      # [app_dim, sum(app_n_comp)]
+        self.mlp = {k: _t(v) for k, v in mlp.items()}       # W1,b1,W2,b2,W3,b3 (Linear: y = x W^T + b)
+        self.near_far = (float(near_far[0]), float(near_far[1]))
+        self.step_ratio = float(step_ratio)
+        self.density_shift = float(density_shift)
+        self.distance_scale = float(distance_scale)
+        self.thres = float(rayMarch_weight_thres)
+        self.fea2denseAct = fea2denseAct
+        self.view_pe = int(view_pe)
+        self.fea_pe = int(fea_pe)
+        self.alpha_volume = None if alpha_volume is None else _t(alpha_volume)
+        self.alpha_aabb = None if alpha_aabb is None else _t(alpha_aabb).reshape(2, 3)
+        self.update_stepSize()
+
+    # tensorf-myc/models/tensorBase.py:197-209
+    def update_stepSize(self):
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        g = torch.tensor(self.gridSize, dtype=torch.int32)
+        self.units = self.aabbSize / (g - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio            # fp32 scalar tensor
+        self.aabbDiag = torch.sqrt(torch.sum(torch.pow(self.aabbSize, 2)))
+        self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+
+
+# tensorf-myc/models/tensorBase.py:9-15
+def positional_encoding(positions, freqs):
+    freq_bands = (2 ** torch.arange(freqs).float())
+    pts = (positions[..., None] * freq_bands).reshape(positions.shape[:-1] + (freqs * positions.shape[-1],))
+    return torch.cat([torch.sin(pts), torch.cos(pts)], dim=-1)
+
+
+# tensorf-myc/models/tensorBase.py:17-24
+def raw2alpha(sigma, dist):
+    alpha = 1.0 - torch.exp(-sigma * dist)
+    T = torch.cumprod(torch.cat([torch.ones(alpha.shape[0], 1), 1.0 - alpha + 1e-10], -1), -1)
+    weights = alpha * T[:, :-1]
+    return alpha, weights, T[:, -1:]
+
+
+# tensorf-myc/models/tensorBase.py:223-224
+def normalize_coord(sc: OracleScene, xyz):
+    return (xyz - sc.aabb[0]) * sc.invaabbSize - 1
+
+
+# tensorf-myc/models/tensorBase.py:39-59 (AlphaGridMask)
+def alpha_sample(sc: OracleScene, xyz):
+    aabb = sc.alpha_aabb
+    inv = 1.0 / (aabb[1] - aabb[0]) * 2
+    q = (xyz - aabb[0]) * inv - 1
+    if q.shape[0] == 0:
+        return torch.zeros(0)
+    vol = sc.alpha_volume.view(1, 1, *sc.alpha_volume.shape[-3:])
+    return F.grid_sample(vol, q.view(1, -1, 1, 1, 3), align_corners=True).view(-1)
+
+
+# tensorf-myc/models/tensorBase.py:340-360
+def sample_ray(sc: OracleScene, rays_o, rays_d, N_samples=-1, jitter=None):
+    N_samples = N_samples if N_samples > 0 else sc.nSamples
+    near, far = sc.near_far
+    vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+    rate_a = (sc.aabb[1] - rays_o) / vec
+    rate_b = (sc.aabb[0] - rays_o) / vec
+    t_min = torch.minimum(rate_a, rate_b).max(-1).values.clamp(min=near, max=far)
+    rng = torch.arange(N_samples)[None].float()
+    if jitter is not None:                       # is_train: one u ~ U[0,1) per ray (:351-353), injected
+        rng = rng.repeat(rays_d.shape[-2], 1)
+        rng = rng + _t(jitter).view(-1, 1)
+    step = sc.stepSize * rng
+    interpx = t_min[..., None] + step
+    rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+    mask_outbbox = ((sc.aabb[0] > rays_pts) | (rays_pts > sc.aabb[1])).any(dim=-1)
+    return rays_pts, interpx, ~mask_outbbox, t_min
+
+
+def _coords(xyz):
+    # tensorf-myc/models/tensoRF.py:212-214
+    plane = torch.stack((xyz[..., MAT_MODE[0]], xyz[..., MAT_MODE[1]], xyz[..., MAT_MODE[2]])).detach().view(3, -1, 1, 2)
+    line = torch.stack((xyz[..., VEC_MODE[0]], xyz[..., VEC_MODE[1]], xyz[..., VEC_MODE[2]]))
+    line = torch.stack((torch.zeros_like(line), line), dim=-1).detach().view(3, -1, 1, 2)
+    return plane, line
+
+
+# tensorf-myc/models/tensoRF.py:209-225
+def compute_densityfeature(sc: OracleScene, xyz):
+    plane, line = _coords(xyz)
+    sigma_feature = torch.zeros((xyz.shape[0],))
+    for i in range(3):
+        p = F.grid_sample(sc.density_plane[i], plane[[i]], align_corners=True).view(-1, xyz.shape[0])
+        l = F.grid_sample(sc.density_line[i], line[[i]], align_corners=True).view(-1, xyz.shape[0])
+        sigma_feature = sigma_feature + torch.sum(p * l, dim=0)
+    return sigma_feature
+
+
+# tensorf-myc/models/tensoRF.py:228-244
+def compute_appfeature(sc: OracleScene, xyz, return_h=False):
+    plane, line = _coords(xyz)
+    ps, ls = [], []
+    for i in range(3):
+        ps.append(F.grid_sample(sc.app_plane[i], plane[[i]], align_corners=True).view(-1, xyz.shape[0]))
+        ls.append(F.grid_sample(sc.app_line[i], line[[i]], align_corners=True).view(-1, xyz.shape[0]))
+    h = (torch.cat(ps) * torch.cat(ls)).T
+    f = h @ sc.basis_mat.T
+    return (f, h) if return_h else f
+
+
+# tensorf-myc/models/tensorBase.py:444-448
+def feature2density(sc: OracleScene, x):
+    if sc.fea2denseAct == "softplus":
+        return F.softplus(x + sc.density_shift)
+    return F.relu(x)
+
+
+# tensorf-myc/models/tensorBase.py:62-86 (MLPRender_Fea.execute)
+def mlp_render_fea(sc: OracleScene, viewdirs, features, return_in=False):
+    indata = [features, viewdirs]
+    if sc.fea_pe > 0:
+        indata += [positional_encoding(features, sc.fea_pe)]
+    if sc.view_pe > 0:
+        indata += [positional_encoding(viewdirs, sc.view_pe)]
+    mlp_in = torch.cat(indata, dim=-1)
+    m = sc.mlp
+    h1 = torch.relu(mlp_in @ m["W1"].T + m["b1"])
+    h2 = torch.relu(h1 @ m["W2"].T + m["b2"])
+    rgb = torch.sigmoid(h2 @ m["W3"].T + m["b3"])
+    return (rgb, mlp_in) if return_in else rgb
+
+
+# tensorf-myc/models/tensorBase.py:476-536 (ndc_ray=False branch)
+def execute(sc: OracleScene, rays_chunk, white_bg=True, N_samples=-1, jitter=None, dump=False):
+    rays_chunk = _t(rays_chunk)
+    viewdirs = rays_chunk[:, 3:6]
+    xyz, z_vals, ray_valid, t_min = sample_ray(sc, rays_chunk[:, :3], viewdirs, N_samples, jitter)
+    bbox_valid = ray_valid.clone()
+    dists = torch.cat((z_vals[:, 1:] - z_vals[:, :-1], torch.zeros_like(z_vals[:, :1])), dim=-1)
+    if dists.shape[0] != xyz.shape[0]:              # is_train=False: z_vals is [1,S] + [N,1] broadcast already
+        dists = dists.expand(xyz.shape[0], -1)
+    viewdirs_e = viewdirs.view(-1, 1, 3).expand(xyz.shape)
+
+    if sc.alpha_volume is not None:                 # :491-496
+        alphas = alpha_sample(sc, xyz[ray_valid])
+        alpha_mask = alphas > 0
+        ray_invalid = ~ray_valid
+        ray_invalid[ray_valid] |= (~alpha_mask)
+        ray_valid = ~ray_invalid
+
+    sigma = torch.zeros(xyz.shape[:-1])
+    rgb = torch.zeros((*xyz.shape[:2], 3))
+    sigma_feature_full = torch.zeros(xyz.shape[:-1])
+    xyz_n = normalize_coord(sc, xyz)                # :503 (done unconditionally here; values unused if none valid)
+    if ray_valid.any():
+        sf = compute_densityfeature(sc, xyz_n[ray_valid])
+        sigma[ray_valid] = feature2density(sc, sf)
+        sigma_feature_full[ray_valid] = sf
+
+    alpha, weight, bg_weight = raw2alpha(sigma, dists * sc.distance_scale)
+    app_mask = weight > sc.thres
+    if app_mask.any():
+        app_features = compute_appfeature(sc, xyz_n[app_mask])
+        rgb[app_mask] = mlp_render_fea(sc, viewdirs_e[app_mask], app_features)
+
+    acc_map = torch.sum(weight, -1)
+    rgb_map = torch.sum(weight[..., None] * rgb, -2)
+    if white_bg:
+        rgb_map = rgb_map + (1.0 - acc_map[..., None])
+    rgb_map = rgb_map.clamp(0, 1)
+    depth_map = torch.sum(weight * z_vals, -1)
+    depth_map = depth_map + (1.0 - acc_map) * rays_chunk[..., -1]   # :531 — last ray column (d_z), kept as is
+
+    if not dump:
+        return rgb_map, depth_map
+    g = torch.tensor(sc.gridSize, dtype=torch.float32)
+    fidx = ((xyz_n + 1) / 2) * (g - 1)             # grid_sample align_corners=True un-normalisation, per axis
+    return dict(rgb_map=rgb_map, depth_map=depth_map, acc_map=acc_map, t_min=t_min,
+                z_vals=z_vals.expand(xyz.shape[0], -1).contiguous(), xyz=xyz, xyz_norm=xyz_n,
+                bbox_valid=bbox_valid, valid=ray_valid, cell=torch.floor(fidx).to(torch.int32),
+                sigma_feature=sigma_feature_full, sigma=sigma, alpha=alpha, weight=weight,
+                bg_weight=bg_weight, app_mask=app_mask, rgb=rgb)
+
+
+# tensorf-myc/renderer.py:12-27
+def OctreeRender_trilinear_fast(rays, sc: OracleScene, chunk=4096, N_samples=-1, white_bg=True, jitter=None):
+    rays = _t(rays)
+    rgbs, depths = [], []
+    n = rays.shape[0]
+    for ci in range(n // chunk + int(n % chunk > 0)):
+        sl = slice(ci * chunk, (ci + 1) * chunk)
+        r, d = execute(sc, rays[sl], white_bg=white_bg, N_samples=N_samples,
+                       jitter=None if jitter is None else _t(jitter)[sl])
+        rgbs.append(r)
+        depths.append(d)
+    return torch.cat(rgbs), None, torch.cat(depths), None, None
+
+
+def scene_from_arrays(arrs: Dict[str, np.ndarray], **hyper) -> OracleScene:
+    """Build an OracleScene from the flat array dict jittor_myc_nerfs_amd.synthetic produces."""
+    mlp = {k: arrs[k] for k in ("W1", "b1", "W2", "b2", "W3", "b3")}
+    return OracleScene(
+        aabb=arrs["aabb"], gridSize=arrs["gridSize"],
+        density_plane=[arrs[f"density_plane.{i}"] for i in range(3)],
+        density_line=[arrs[f"density_line.{i}"] for i in range(3)],
+        app_plane=[arrs[f"app_plane.{i}"] for i in range(3)],
+        app_line=[arrs[f"app_line.{i}"] for i in range(3)],
+        basis_mat=arrs["basis_mat"], mlp=mlp,
+        alpha_volume=arrs.get("alpha_volume"), alpha_aabb=arrs.get("alpha_aabb"), **hyper)

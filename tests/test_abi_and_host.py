@@ -1,0 +1,115 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tvr.h declares; host-side logic (field
+constructor, step size / sample count, ray generation, shard maths) — no compute call needs a GPU here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, TINY, make_model
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "tvr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tvr_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from jittor_myc_nerfs_amd import _lib
+    names = _header_symbols()
+    assert len(names) >= 17
+    l = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(l, n), f"libtvr.so does not export {n}"
+    assert set(names) == set(_lib.SYMBOLS), "ctypes table and include/tvr.h disagree"
+    assert _lib.lib().tvr_version() == 100
+
+
+def test_abi_argument_errors_without_gpu():
+    from jittor_myc_nerfs_amd import _lib as L
+    lib = L.lib()
+    d = L.SceneDesc()
+    assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0                 # all-zero desc is invalid
+    assert b"grid" in lib.tvr_last_error()
+    d.grid[:] = [300, 300, 300]
+    d.aabb[:] = [-1.5] * 3 + [1.5] * 3
+    d.density_n_comp[:] = [8, 8, 8]
+    d.app_n_comp[:] = [48] * 3
+    assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"density_n_comp" in lib.tvr_last_error()
+    d.density_n_comp[:] = [16] * 3
+    d.app_dim, d.featureC, d.view_pe, d.fea_pe, d.step_size = 27, 128, 2, 2, 0.005
+    nbytes = lib.tvr_scene_packed_bytes(C.byref(d))
+    # 3 planes x 301x301 x (16+48) ch + lines + MLP, fp32, 256-B aligned blocks (DESIGN.md "data layout")
+    assert 69.5e6 < nbytes < 70.5e6
+    h = C.c_void_p()
+    assert lib.tvr_scene_create(C.byref(d), None, 0, C.byref(h)) == -3  # TVR_ERR_SCRATCH
+    assert lib.tvr_render(None, None, 0, 0, 0, None, 0.0, None, None, None, 0, None, None, None, None) == -1
+    assert lib.tvr_render_scratch_bytes(None, 4096, 512) > 4096 * 512 * 20
+
+
+def test_field_host_logic_matches_reference_sizes(tiny_arrays, hyper_tiny):
+    from jittor_myc_nerfs_amd import synthetic
+    A = synthetic.SCENE_A
+    arrs = {"aabb": np.asarray(A["aabb"], np.float32), "gridSize": np.asarray(A["gridSize"])}
+    from jittor_myc_nerfs_amd import TensorVMSplit
+    m = TensorVMSplit(arrs["aabb"], A["gridSize"], "cpu", density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, app_dim=27,
+                      near_far=A["near_far"], shadingMode="MLP_Fea", view_pe=2, fea_pe=2, featureC=128, step_ratio=0.5)
+    assert m.nSamples == 1036 and abs(float(m.stepSize) - 5.0167e-3) < 1e-6
+    assert tuple(m.density_plane[1].shape) == (1, 16, 300, 300) and tuple(m.app_line[0].shape) == (1, 48, 300, 1)
+    assert m.renderModule.in_mlpC == 150
+    kw = m.get_kwargs()
+    assert kw["gridSize"] == [300, 300, 300] and kw["shadingMode"] == "MLP_Fea"
+    sd = m.state_dict()
+    assert "density_plane.0" in sd and "basis_mat.weight" in sd and "renderModule.mlp.4.bias" in sd
+    n_par = sum(p.numel() for p in m.parameters())
+    assert abs(n_par * 4 / 1e6 - 69.35) < 0.3                                       # 69.35 MB fp32 (Appendix C)
+
+
+def test_product_path_fails_loudly_without_gpu(tiny_arrays, hyper_tiny, tiny_dump):
+    """No CPU fallback: on a CPU device every compute entry point raises."""
+    from jittor_myc_nerfs_amd import _lib as L
+    m = make_model(tiny_arrays, hyper_tiny, device="cpu")
+    rays = torch.tensor(tiny_dump["rays"])
+    with pytest.raises(L.TvrError):
+        m(rays, is_train=False, white_bg=True, N_samples=48)
+    with pytest.raises(L.TvrError):
+        m.compute_densityfeature(torch.zeros(4, 3))
+    with pytest.raises(NotImplementedError):
+        m(rays, ndc_ray=True)
+
+
+def test_unsupported_shading_mode_raises():
+    from jittor_myc_nerfs_amd import TensorVMSplit
+    with pytest.raises(NotImplementedError):
+        TensorVMSplit([[-1] * 3, [1] * 3], [8, 8, 8], "cpu", density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, shadingMode="SH")
+
+
+def test_ray_generation_blender_convention():
+    from jittor_myc_nerfs_amd import rays as R
+    H = W = 8
+    M = R.sphere_poses(8, 4.0)[3]
+    rays = R.frame_rays(M, H, W, 0.6911).numpy()
+    assert rays.shape == (64, 6) and rays.dtype == np.float32
+    assert np.allclose(np.linalg.norm(rays[:, 3:], axis=1), 1.0, atol=1e-6)       # blender.py:75 normalises
+    assert np.allclose(rays[:, :3], M[:3, 3], atol=1e-6)
+    # independent restatement of ray_utils.py:91-101 + blender.py:91 for one pixel
+    f = 0.5 * 800 / np.tan(0.5 * 0.6911) * (W / 800)
+    i, j = 5, 2
+    dcam = np.array([-(i + 0.5 - W / 2) / f, (j + 0.5 - H / 2) / f, -1.0])
+    dcam /= np.linalg.norm(dcam)
+    c2w = M @ R.BLENDER2OPENCV
+    assert np.allclose(rays[j * W + i, 3:], c2w[:3, :3] @ dcam, atol=1e-6)
+    # the centre of the image looks at the origin
+    centre = rays[[27, 28, 35, 36], 3:].mean(0)
+    assert np.dot(centre / np.linalg.norm(centre), -M[:3, 3] / np.linalg.norm(M[:3, 3])) > 0.999
+
+
+def test_shard_indices_partition():
+    from jittor_myc_nerfs_amd import shard_indices, shard_capacity
+    for R_, w, t in ((10000, 2, 4096), (640000, 8, 4096), (5, 4, 4), (4096, 3, 1024), (0, 2, 16)):
+        allidx = torch.cat([shard_indices(R_, r, w, t) for r in range(w)])
+        assert sorted(allidx.tolist()) == list(range(R_))
+        assert all(shard_indices(R_, r, w, t).numel() <= shard_capacity(R_, w, t) for r in range(w))

@@ -1,0 +1,143 @@
+"""CPU: the two oracle restatements against each other, against the committed golden vectors and against
+known-answer cases.  No GPU, no product code under test here except the shared scene generator."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as CO
+from oracle import tensorf_oracle as TO
+
+from conftest import TINY
+
+
+def _scenes(arrs, hyper):
+    sc = TO.scene_from_arrays(arrs, **hyper)
+    return sc, CO.COracle(arrs, step=float(sc.stepSize), **hyper)
+
+
+def test_torch_oracle_reproduces_golden(tiny_dump, tiny_arrays, hyper_tiny):
+    sc, _ = _scenes(tiny_arrays, hyper_tiny)
+    assert np.float32(sc.stepSize.item()) == tiny_dump["step"]
+    d = TO.execute(sc, torch.tensor(tiny_dump["rays"]), white_bg=True, N_samples=TINY["N_samples"], dump=True)
+    assert np.array_equal(d["z_vals"].numpy(), tiny_dump["out.z_vals"])
+    assert np.array_equal(d["valid"].numpy().astype(np.uint8), tiny_dump["out.valid"])
+    assert np.array_equal(d["cell"].numpy(), tiny_dump["out.cell"])
+    assert np.allclose(d["rgb_map"].numpy(), tiny_dump["out.rgb_map"], atol=1e-6)
+    assert np.allclose(d["weight"].numpy(), tiny_dump["out.weight"], atol=1e-6)
+
+
+def test_c_oracle_matches_golden_bit_exact_indices(tiny_dump, tiny_arrays, hyper_tiny):
+    _, co = _scenes(tiny_arrays, hyper_tiny)
+    c = co.render(tiny_dump["rays"], TINY["N_samples"], white_bg=True, dump=True)
+    v = tiny_dump["out.valid"].astype(bool)
+    assert np.array_equal(c["tmin"], tiny_dump["out.t_min"])
+    assert np.array_equal(c["z"], tiny_dump["out.z_vals"])                      # bit-exact sample positions
+    assert np.array_equal(c["valid"], tiny_dump["out.valid"])                   # bit-exact masks
+    assert np.array_equal(c["cell"][v], tiny_dump["out.cell"][v])               # bit-exact cell indices
+    assert np.abs(c["sf"] - tiny_dump["out.sigma_feature"]).max() < 2e-5
+    assert np.abs(c["weight"] - tiny_dump["out.weight"]).max() < 1e-6
+    assert np.abs(c["rgb_map"] - tiny_dump["out.rgb_map"]).max() < 1e-5         # tolerance: fp32 rgb
+    assert np.abs(c["depth_map"] - tiny_dump["out.depth_map"]).max() < 1e-4
+    assert (c["app"] != tiny_dump["out.app_mask"]).sum() <= 2                   # threshold flips at 1 ulp only
+
+
+@pytest.mark.parametrize("name,wb,am,jit", [("wb1_am0", True, False, False), ("wb0_am0", False, False, False),
+                                            ("wb1_am1", True, True, False), ("wb0_am1_jit", False, True, True)])
+def test_c_oracle_edge_cases(tiny_edge, tiny_arrays, hyper_tiny, name, wb, am, jit):
+    arrs = dict(tiny_arrays)
+    if am:
+        arrs["alpha_volume"], arrs["alpha_aabb"] = tiny_edge["alpha_volume"], tiny_edge["alpha_aabb"]
+    _, co = _scenes(arrs, hyper_tiny)
+    c = co.render(tiny_edge["rays"], TINY["N_samples"], white_bg=wb, jitter=tiny_edge["jitter"] if jit else None, dump=True)
+    g = lambda k: tiny_edge[f"{name}.{k}"]
+    assert np.array_equal(c["tmin"], g("t_min"))
+    assert np.array_equal(c["z"], g("z_vals"))
+    assert np.array_equal(c["bbox_valid"], g("bbox_valid"))
+    assert np.array_equal(c["valid"], g("valid"))
+    v = g("valid").astype(bool)
+    assert np.array_equal(c["cell"][v], g("cell")[v])
+    assert np.abs(c["rgb_map"] - g("rgb_map")).max() < 1e-5
+    assert np.abs(c["depth_map"] - g("depth_map")).max() < 1e-4
+    # the ray that misses the box: everything invalid, rgb = background, depth = d_z (tensorBase.py:531)
+    assert not c["valid"][3].any()
+    assert np.allclose(c["rgb_map"][3], 1.0 if wb else 0.0)
+    assert c["depth_map"][3] == tiny_edge["rays"][3, 5]
+
+
+def test_c_oracle_config1_against_golden(config1_golden):
+    """BASELINE.json configs[0]: 128^3 grid, 64x64 rays, 192 samples (scene regenerated from the seed)."""
+    import hashlib
+    from jittor_myc_nerfs_amd import rays as R, synthetic
+    B = synthetic.SCENE_B
+    arrs = synthetic.make_scene_arrays(B["gridSize"], B["aabb"])
+    shas = dict(s.split(":") for s in config1_golden["scene_sha"])
+    for k, v in arrs.items():
+        assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() == shas[k], f"synthetic scene drifted: {k}"
+    hyper = dict(synthetic.HYPER, near_far=B["near_far"], step_ratio=B["step_ratio"])
+    sc = TO.scene_from_arrays(arrs, **hyper)
+    assert sc.nSamples == int(config1_golden["nSamples"]) == 440
+    rays = R.frame_rays(R.sphere_poses(8, B["cam_radius"])[0], 64, 64, B["camera_angle_x"])
+    co = CO.COracle(arrs, step=float(sc.stepSize), **hyper)
+    c = co.render(rays.numpy(), B["N_samples"], white_bg=True, dump=True, nthreads=8)
+    assert np.array_equal(np.packbits(c["valid"]), config1_golden["valid_bits"])
+    assert (np.unpackbits(np.packbits(c["app"])) != np.unpackbits(config1_golden["app_bits"])).sum() <= 8
+    # a 1-ulp weight difference may flip `weight > 1e-4` for a sample: RGB then moves by <= weight ~ 1e-4 (SURVEY §7 hard part 4)
+    assert np.abs(c["rgb_map"] - config1_golden["rgb_map"]).max() < 2e-4
+    assert np.abs(c["acc"] - config1_golden["acc_map"]).max() < 2e-5
+
+
+# ---- known-answer tests (no data needed) ----
+def _const_scene(p, l, g=(6, 7, 8)):
+    arrs = {"aabb": np.array([[-1, -1, -1], [1, 1, 1]], np.float32), "gridSize": np.array(g, np.int32)}
+    from jittor_myc_nerfs_amd.synthetic import MAT_MODE, VEC_MODE
+    for i in range(3):
+        m0, m1 = MAT_MODE[i]
+        arrs[f"density_plane.{i}"] = np.full((1, 16, g[m1], g[m0]), p, np.float32)
+        arrs[f"density_line.{i}"] = np.full((1, 16, g[VEC_MODE[i]], 1), l, np.float32)
+        arrs[f"app_plane.{i}"] = np.full((1, 48, g[m1], g[m0]), 0.1, np.float32)
+        arrs[f"app_line.{i}"] = np.full((1, 48, g[VEC_MODE[i]], 1), 0.1, np.float32)
+    arrs["basis_mat"] = np.zeros((27, 144), np.float32)
+    for k, s in (("W1", (128, 150)), ("b1", (128,)), ("W2", (128, 128)), ("b2", (128,)), ("W3", (3, 128)), ("b3", (3,))):
+        arrs[k] = np.zeros(s, np.float32)
+    return arrs
+
+
+def test_known_answer_constant_factors():
+    arrs = _const_scene(0.5, 0.25)
+    hyper = dict(near_far=[0.1, 10.0], step_ratio=0.5)
+    sc, co = _scenes(arrs, hyper)
+    xyz = np.random.default_rng(0).uniform(-0.999, 0.999, (200, 3)).astype(np.float32)
+    expect = 3 * 16 * 0.5 * 0.25                                   # sigma_feature = 3*16*p*l exactly
+    assert np.allclose(co.density_features(xyz), expect, rtol=1e-6)
+    assert np.allclose(TO.compute_densityfeature(sc, torch.tensor(xyz)).numpy(), expect, rtol=1e-6)
+    # outside [-1,1]: zeros padding -> feature decays to 0 one cell outside
+    far = np.array([[3.0, 0, 0], [0, -3.0, 0]], np.float32)
+    assert np.allclose(co.density_features(far), TO.compute_densityfeature(sc, torch.tensor(far)).numpy(), atol=1e-6)
+
+
+def test_known_answer_empty_and_opaque():
+    rays = np.array([[0, 0, 3, 0, 0, -1], [0.2, 0.1, 3, 0, 0, -1]], np.float32)
+    # sigma = relu(0) = 0 everywhere -> rgb = white exactly, depth = d_z (tensorBase.py:531), no appearance sample
+    _, co = _scenes(_const_scene(0.0, 0.0), dict(near_far=[0.1, 10.0], step_ratio=0.5, fea2denseAct="relu"))
+    c = co.render(rays, 32, white_bg=True, dump=True)
+    assert c["acc"].max() == 0 and np.array_equal(c["rgb_map"], np.ones((2, 3), np.float32)) and c["app"].sum() == 0
+    assert np.array_equal(c["depth_map"], rays[:, 5])
+    # softplus(0 - 10) ~ 4.5e-5 is NOT empty at this step size: alpha ~ 1.9e-4 > thres, rgb = sigmoid(0) = 0.5 -> 1 - acc/2
+    _, co = _scenes(_const_scene(0.0, 0.0), dict(near_far=[0.1, 10.0], step_ratio=0.5))
+    c = co.render(rays, 32, white_bg=True, dump=True)
+    assert np.allclose(c["rgb_map"], 1.0 - c["acc"][:, None] / 2, atol=1e-6)
+    # opaque slab: sigma_feature = 48 -> alpha ~ 1 at the first in-box sample, acc ~ 1, rgb = sigmoid(0) = 0.5
+    _, co = _scenes(_const_scene(1.0, 1.0), dict(near_far=[0.1, 10.0], step_ratio=0.5))
+    c = co.render(rays, 32, white_bg=True, dump=True)
+    first = c["valid"].argmax(1)
+    assert np.all(c["weight"][np.arange(2), first] > 0.999) and np.allclose(c["acc"], 1.0, atol=1e-5)
+    assert np.allclose(c["rgb_map"], 0.5, atol=1e-5)
+
+
+def test_single_texel_impulse_bilinear_weights():
+    arrs = _const_scene(0.0, 1.0)
+    arrs["density_plane.0"][0, 3, 2, 4] = 1.0                       # plane0 = (x: W=6, y: H=7), channel 3, texel (x=4, y=2)
+    _, co = _scenes(arrs, dict(near_far=[0.1, 10.0], step_ratio=0.5))
+    fx, fy = 4.25, 1.5                                              # un-normalised -> weights (1-.25)*(.5)
+    n = np.array([[fx / 5 * 2 - 1, fy / 6 * 2 - 1, 0.3]], np.float32)
+    assert abs(co.density_features(n)[0] - 0.75 * 0.5) < 1e-5
