@@ -23,21 +23,27 @@ def focal_from_angle(camera_angle_x: float, width: int) -> float:
     return 0.5 * 800 / math.tan(0.5 * camera_angle_x) * (width / 800)
 
 
-def get_ray_directions(H: int, W: int, focal: Sequence[float], center=None) -> torch.Tensor:
-    """(H,W,3) camera-space directions [-(i+.5-cx)/fx, (j+.5-cy)/fy, -1]  (ray_utils.py:91-101)."""
-    xs = torch.linspace(0, W - 1, W)
-    ys = torch.linspace(0, H - 1, H)
-    j, i = torch.meshgrid(ys, xs, indexing="ij")
-    i = i + 0.5
-    j = j + 0.5
+def get_ray_directions(H: int, W: int, focal: Sequence[float], center=None) -> np.ndarray:
+    """(H,W,3) camera-space directions [-(i+.5-cx)/fx, (j+.5-cy)/fy, -1]  (ray_utils.py:91-101).
+
+    fp32 element-wise numpy arithmetic only (no BLAS, no transcendental): IEEE add/mul/div/sqrt give the same
+    bits on every host, so golden vectors generated in one container hold on the GPU box's CPU too."""
+    i = (np.arange(W, dtype=np.float32) + np.float32(0.5))[None, :].repeat(H, 0)
+    j = (np.arange(H, dtype=np.float32) + np.float32(0.5))[:, None].repeat(W, 1)
     cent = center if center is not None else [W / 2, H / 2]
-    return torch.stack([-(i - cent[0]) / focal[0], (j - cent[1]) / focal[1], -torch.ones_like(i)], -1)
+    x = -(i - np.float32(cent[0])) / np.float32(focal[0])
+    y = (j - np.float32(cent[1])) / np.float32(focal[1])
+    return np.stack([x, y, -np.ones_like(x)], -1)
 
 
-def get_rays(directions: torch.Tensor, c2w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """ray_utils.py:132-153: rays_d = directions @ c2w[:3,:3]^T, rays_o = c2w[:3,3] broadcast."""
-    rays_d = directions @ c2w[:3, :3].T
-    rays_o = c2w[:3, 3].expand(rays_d.shape)
+def get_rays(directions: np.ndarray, c2w: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """ray_utils.py:132-153: rays_d = directions @ c2w[:3,:3]^T (written as three fp32 multiply-adds, in k order),
+    rays_o = c2w[:3,3] broadcast."""
+    Rm = np.asarray(c2w, dtype=np.float32)[:3, :3]
+    d = directions.astype(np.float32)
+    rays_d = d[..., 0:1] * Rm[:, 0] + d[..., 1:2] * Rm[:, 1]
+    rays_d = rays_d + d[..., 2:3] * Rm[:, 2]
+    rays_o = np.broadcast_to(np.asarray(c2w, dtype=np.float32)[:3, 3], rays_d.shape)
     return rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
 
 
@@ -45,11 +51,11 @@ def frame_rays(transform_matrix, H: int, W: int, camera_angle_x: float) -> torch
     """One frame of a transforms_*.json -> rays [H*W,6] fp32 (blender.py:69-76,91,116-117)."""
     focal = focal_from_angle(camera_angle_x, W)
     dirs = get_ray_directions(H, W, [focal, focal])
-    dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)                 # blender.py:75
-    pose = np.asarray(transform_matrix, dtype=np.float64) @ BLENDER2OPENCV  # blender.py:91
-    c2w = torch.tensor(pose, dtype=torch.float32)
-    o, d = get_rays(dirs, c2w)
-    return torch.cat([o, d], 1).contiguous()
+    nrm = np.sqrt(dirs[..., 0] * dirs[..., 0] + dirs[..., 1] * dirs[..., 1] + dirs[..., 2] * dirs[..., 2])
+    dirs = dirs / nrm[..., None]                                            # blender.py:75
+    pose = np.asarray(transform_matrix, dtype=np.float64) @ BLENDER2OPENCV  # blender.py:91 (4x4, exact sign flips)
+    o, d = get_rays(dirs, pose.astype(np.float32))
+    return torch.from_numpy(np.ascontiguousarray(np.concatenate([o, d], 1), dtype=np.float32))
 
 
 def load_transforms(path: str):

@@ -104,7 +104,7 @@ def main():
     M = R.sphere_poses(8, B["cam_radius"])[0]
     rays1 = R.frame_rays(M, B["img_wh"][1], B["img_wh"][0], B["camera_angle_x"])
     d1 = dump_to_np(TO.execute(sc1, rays1, white_bg=True, N_samples=B["N_samples"], dump=True))
-    np.savez_compressed(os.path.join(HERE, "config1.npz"), rays_sha=sha(rays1.numpy()),
+    np.savez_compressed(os.path.join(HERE, "config1.npz"), rays=rays1.numpy(),
                         scene_sha=np.array([f"{k}:{sha(v)}" for k, v in sorted(arrs1.items())]),
                         step=np.float32(sc1.stepSize.item()), nSamples=sc1.nSamples,
                         rgb_map=d1["rgb_map"], depth_map=d1["depth_map"], acc_map=d1["acc_map"],

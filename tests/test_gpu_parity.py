@@ -73,7 +73,7 @@ def test_config1_against_golden(config1_golden):
     arrs = synthetic.make_scene_arrays(B["gridSize"], B["aabb"])
     hyper = dict(synthetic.HYPER, near_far=B["near_far"], step_ratio=B["step_ratio"])
     m = make_model(arrs, hyper)
-    rays = R.frame_rays(R.sphere_poses(8, B["cam_radius"])[0], 64, 64, B["camera_angle_x"]).cuda()
+    rays = torch.tensor(config1_golden["rays"], device="cuda")      # the fixture carries its inputs
     rgb0, depth0, d = m.render_rays(rays, white_bg=True, N_samples=B["N_samples"], eps_T=0.0, dense=True)
     assert np.array_equal(np.packbits(_np(d["valid"])), config1_golden["valid_bits"])                  # bit-exact mask
     app = (_np(d["weight"]) > 1e-4).astype(np.uint8)
@@ -144,8 +144,8 @@ def test_parameter_update_repacks(tiny_dump, tiny_arrays, hyper_tiny):
         m.density_plane[0].mul_(0.0)
         m.density_plane[1].mul_(0.0)
         m.density_plane[2].mul_(0.0)
-    rgb_b, _ = m(rays, N_samples=48)                                # in-place edit is picked up: scene now empty
-    assert float((rgb_b - 1.0).abs().max()) < 2e-3 and float((rgb_a - rgb_b).abs().max()) > 0.1
+    rgb_b, _ = m(rays, N_samples=48)                                # in-place edit is picked up: only softplus(-10) haze left
+    assert float((rgb_b - 1.0).abs().max()) < 1e-2 and float((rgb_a - rgb_b).abs().max()) > 0.1
 
 
 def test_full_size_properties_config2():
