@@ -33,7 +33,7 @@ static const int kVecH[3] = {2, 1, 0};
 
 struct PackedLayout {
     size_t dplane[3], dline[3], aplane[3], aline[3];
-    size_t basisT, W1T, W2T, W3T, b1, b2, b3, total;
+    size_t mlp_image, basis_frag, w3_frag, b3, total;
 };
 
 static PackedLayout packed_layout(const tvr_scene_desc &d)
@@ -48,12 +48,9 @@ static PackedLayout packed_layout(const tvr_scene_desc &d)
         L.aplane[i] = take((H + 1) * (W + 1) * TVR_CA);
         L.aline[i] = take((Ln + 1) * TVR_CA);
     }
-    L.basisT = take(TVR_KAPP * 32);
-    L.W1T = take(TVR_NIN * TVR_FEATC);
-    L.W2T = take(TVR_FEATC * TVR_FEATC);
-    L.W3T = take(TVR_FEATC * 16);
-    L.b1 = take(TVR_FEATC);
-    L.b2 = take(TVR_FEATC);
+    L.mlp_image = take(TVR_MLP_IMAGE_BYTES / 4);
+    L.basis_frag = take(TVR_BASIS_FRAG_BYTES / 4);
+    L.w3_frag = take(TVR_W3_FRAG_BYTES / 4);
     L.b3 = take(16);
     L.total = off;
     return L;
@@ -128,12 +125,9 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
         v.aplane[k] = (const float4 *)(s->packed + L.aplane[k]);
         v.aline[k] = (const float4 *)(s->packed + L.aline[k]);
     }
-    v.basisT = (const float *)(s->packed + L.basisT);
-    v.W1T = (const float *)(s->packed + L.W1T);
-    v.W2T = (const float *)(s->packed + L.W2T);
-    v.W3T = (const float *)(s->packed + L.W3T);
-    v.b1 = (const float *)(s->packed + L.b1);
-    v.b2 = (const float *)(s->packed + L.b2);
+    v.mlp_image = s->packed + L.mlp_image;
+    v.basis_frag = s->packed + L.basis_frag;
+    v.w3_frag = s->packed + L.w3_frag;
     v.b3 = (const float *)(s->packed + L.b3);
     v.near_ = desc->near_;
     v.far_ = desc->far_;
@@ -162,14 +156,14 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
         HIP_TRY(launch_pack_plane(p->app_line[i], (float *)(s->packed + s->lay.aline[i]), TVR_CA, Ln, 1, stream));
     }
     if (!p->basis_mat || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3) return fail(TVR_ERR_INVALID, "MLP pointer is NULL");
-    HIP_TRY(launch_transpose_pad(p->basis_mat, (float *)(s->packed + s->lay.basisT), TVR_APPDIM, TVR_KAPP, 32, stream));
-    HIP_TRY(launch_transpose_pad(p->W1, (float *)(s->packed + s->lay.W1T), TVR_FEATC, TVR_NIN, TVR_FEATC, stream));
-    HIP_TRY(launch_transpose_pad(p->W2, (float *)(s->packed + s->lay.W2T), TVR_FEATC, TVR_FEATC, TVR_FEATC, stream));
-    HIP_TRY(launch_transpose_pad(p->W3, (float *)(s->packed + s->lay.W3T), 3, TVR_FEATC, 16, stream));
-    // biases are [n][K=1] -> [1][n_out]
-    HIP_TRY(launch_transpose_pad(p->b1, (float *)(s->packed + s->lay.b1), TVR_FEATC, 1, TVR_FEATC, stream));
-    HIP_TRY(launch_transpose_pad(p->b2, (float *)(s->packed + s->lay.b2), TVR_FEATC, 1, TVR_FEATC, stream));
-    HIP_TRY(launch_transpose_pad(p->b3, (float *)(s->packed + s->lay.b3), 3, 1, 16, stream));
+    char *img = s->packed + s->lay.mlp_image;
+    HIP_TRY(launch_pack_mlp(p->W1, img + TVR_IMG_W1H, img + TVR_IMG_W1L, 0, stream));
+    HIP_TRY(launch_pack_mlp(p->W2, img + TVR_IMG_W2H, img + TVR_IMG_W2L, 1, stream));
+    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B1, p->b1, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B2, p->b2, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(launch_pack_mlp(p->basis_mat, s->packed + s->lay.basis_frag, nullptr, 2, stream));
+    HIP_TRY(launch_pack_mlp(p->W3, s->packed + s->lay.w3_frag, nullptr, 3, stream));
+    HIP_TRY(hipMemcpyAsync(s->packed + s->lay.b3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     s->params_set = true;
     return TVR_OK;
 }

@@ -6,8 +6,9 @@
 //   density line  i : [L_i+1][16]
 //   app plane     i : [H_i+1][W_i+1][48]       (192 B texel = 12 x float4)
 //   app line      i : [L_i+1][48]
-//   basisT [144][32] (cols >= 27 zero), W1T [150][128], W2T [128][128], W3T [128][16] (cols >= 3 zero),
-//   b1[128], b2[128], b3[16]   — K-major so MFMA B operands are coalesced 128-B rows.
+//   MLP LDS image (TVR_MLP_IMAGE_BYTES): W1 / W2 as fp16 hi and lo parts, row-major [128 hidden][k position] with padded
+//                      rows (conflict-free ds_read_b128 A-operand reads) and permuted k columns (see tvr_shade.hip), b1, b2
+//   basis / W3 fragments: [k-step][lane half][row 32][hi 8 | lo 8] fp16 — one 32-B A-operand pair per lane, coalesced
 // Compiled with -ffp-contract=off: every a*b+c below is two rounded ops unless written as fmaf, so the
 // position / mask / cell-index arithmetic reproduces SURVEY.md Appendix A steps 1-7 bit for bit.
 #pragma once
@@ -21,6 +22,19 @@
 #define TVR_NIN 150    // 27 + 3 + 2*2*27 + 2*2*3
 #define TVR_KAPP 144
 
+// byte offsets inside the MLP LDS image
+#define TVR_IMG_W1_ROW 336                 // 160 k positions * 2 B + 16 B pad: row r lands on 16-B slot 5r mod 16
+#define TVR_IMG_W2_ROW 272                 // 128 * 2 B + 16 B pad
+#define TVR_IMG_W1H 0
+#define TVR_IMG_W1L (128 * TVR_IMG_W1_ROW)
+#define TVR_IMG_W2H (2 * 128 * TVR_IMG_W1_ROW)
+#define TVR_IMG_W2L (TVR_IMG_W2H + 128 * TVR_IMG_W2_ROW)
+#define TVR_IMG_B1 (TVR_IMG_W2H + 2 * 128 * TVR_IMG_W2_ROW)
+#define TVR_IMG_B2 (TVR_IMG_B1 + 512)
+#define TVR_MLP_IMAGE_BYTES (TVR_IMG_B2 + 512)     // 156 672 B of the 163 840 B LDS
+#define TVR_BASIS_FRAG_BYTES (9 * 2 * 32 * 16 * 2)
+#define TVR_W3_FRAG_BYTES (8 * 2 * 32 * 16 * 2)
+
 struct SceneDev {
     float lo[3], hi[3], inv[3];
     float gm1[3];                 // float(grid-1)
@@ -29,7 +43,10 @@ struct SceneDev {
     const float4 *dline[3];
     const float4 *aplane[3];
     const float4 *aline[3];
-    const float *basisT, *W1T, *W2T, *W3T, *b1, *b2, *b3;
+    const void *mlp_image;        // TVR_MLP_IMAGE_BYTES, copied to LDS by the shade kernel
+    const void *basis_frag;       // [9][2][32][16] fp16
+    const void *w3_frag;          // [8][2][32][16] fp16
+    const float *b3;              // [3]
     float near_, far_, step, shift, scale, thres;
     int act;
     const float *avol;            // (gz,gy,gx) or nullptr

@@ -43,4 +43,4 @@ hipError_t launch_density_feature(const SceneDev &sc, const float *xyz, long lon
 hipError_t launch_alpha_sample(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream);
 hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream);
 hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, hipStream_t stream);
-hipError_t launch_transpose_pad(const float *in, float *out, int n_in, int K, int n_out, hipStream_t stream);
+hipError_t launch_pack_mlp(const float *W, void *out_hi, void *out_lo, int mode, hipStream_t stream);

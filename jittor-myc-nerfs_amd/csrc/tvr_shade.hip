@@ -4,216 +4,330 @@
 //   models/tensoRF.py:228-244 compute_appfeature (6 grid_samples + Linear(144->27, no bias)),
 //   models/tensorBase.py:9-15 positional_encoding, :76-86 MLPRender_Fea.execute (150->128->128->3, sigmoid).
 //
-// One workgroup (4 waves) processes tiles of 64 queue entries:
-//   gather : 12 lanes x float4 = one 192-B appearance texel per tap -> h[144] = plane*line, staged K-major in LDS
-//   basis  : f[64x27]  = h[64x144] · basisT            v_mfma_f32_16x16x4_f32
-//   PE     : in[150]   = [f, d, sin/cos(f 2^k), sin/cos(d 2^k)] written K-major to LDS straight from the accumulators
-//   L1, L2 : 150->128, 128->128 (+bias, relu)          v_mfma_f32_32x32x2_f32, wave w owns output columns 32w..32w+31
-//   L3     : 128->3 (+bias, sigmoid)                   v_mfma_f32_16x16x4_f32
-// fp32-input MFMA is bit-identical to a k-ordered fmaf chain (MI355X_MICROARCH §Matrix cores), so the MLP carries no
-// reduced-precision error against the 1e-3 RGB parity bar.  Activations live K-major ([k][entry], row stride 65) so
-// MFMA A-operand reads and accumulator write-backs are bank-conflict-free; weights stream K-major from L2.
+// Design (CDNA4): every wave is an independent pipeline over 32 queue entries, entry = MFMA column (lane & 31), and the
+// whole chain stays in registers — no LDS round trip, no barrier in the tile loop:
+//   gather   lane (e, h) fetches 8 channels (2 x float4) of each tap of entry e per k-step; the interpolated plane*line
+//            products ARE the B fragment of the basis product
+//   basis    F^T[32 x 32e]   = Bas[32 x 144] · h^T          A (basis) from L1-cached global fragments
+//   PE       lane (e, h) owns 16 base values (its accumulator rows); [v, sin v, sin 2v, cos v, cos 2v] of them, in that
+//            order, are the B fragments of layer 1 (W1's columns are permuted to this order at pack time)
+//   L1, L2   H^T[128 x 32e]  = W[128 x K] · X^T             A (weights) from LDS (resident for the workgroup's lifetime),
+//            B = previous accumulators converted in place ("accumulator tile as the next MFMA's operand": the k order
+//            inside a step is a fixed permutation, folded into the packed weight columns)
+//   L3       rgb^T[32(3) x 32e] = W3 · H2^T, sigmoid, 3 floats written back into the entry's queue slot
+// Arithmetic: v_mfma_f32_32x32x16_f16 with every fp32 operand split into fp16 hi + lo and three products per step
+// (hi·hi + hi·lo + lo·hi, fp32 accumulate): ~2^-22 relative error per product — fp32-class accuracy at 16/3 the rate of
+// the fp32-input MFMA.  Biases are the initial accumulators.
 #include "tvr_device.h"
 #include "tvr_kernels.h"
 
-#define SH_THREADS 256
-#define SH_TM 64
-#define SH_LD 65
-#define SH_X_FLOATS (TVR_KAPP * SH_LD)   // 9360: h (144 rows) / act1 (128 rows)
-#define SH_Y_FLOATS (152 * SH_LD)        // 9880: mlp_in (150 rows) / act2 (128 rows)
-#define SH_LDS_BYTES ((SH_X_FLOATS + SH_Y_FLOATS + 2 * SH_TM * 4) * 4)
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SH_THREADS 512
+#define SH_WAVES 8
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// positional-encoding rows of feature channel c with value v, entry column e  (tensorBase.py:9-15: index c*F+k)
-__device__ __forceinline__ void pe_rows_feat(float *Y, int c, int e, float v)
+// fp32 pair -> packed fp16 hi and lo words (x = hi + lo up to ~2^-22 |x|; round-toward-zero never overflows to inf)
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
 {
-    Y[c * SH_LD + e] = v;
-    const float v2 = v * 2.0f;
-    Y[(30 + 2 * c) * SH_LD + e] = sinf(v);
-    Y[(31 + 2 * c) * SH_LD + e] = sinf(v2);
-    Y[(84 + 2 * c) * SH_LD + e] = cosf(v);
-    Y[(85 + 2 * c) * SH_LD + e] = cosf(v2);
+    const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const float ra = a - (float)h[0], rb = b - (float)h[1];
+    const auto l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
 }
 
-// one 128-wide hidden layer on a 64-entry tile: out[n][e] = relu(sum_k in[k][e] * WT[k][n] + b[n]);  wave w -> n in [32w, 32w+32)
-template <int K>
-__device__ __forceinline__ void hidden_layer(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ WT,
-                                             const float *__restrict__ bias, int wave, int lane)
+struct Frag {   // one 8-element fp16 operand fragment, hi and lo parts
+    uint4 hi, lo;
+};
+
+__device__ __forceinline__ Frag split8(const float v[8])
 {
-    f32x16 c0 = {0}, c1 = {0};
-    const int half = lane >> 5, l31 = lane & 31;
-    const float *wp = WT + half * TVR_FEATC + wave * 32 + l31;
-    const float *ap = in + half * SH_LD + l31;
-#pragma unroll 5
-    for (int kk = 0; kk < K / 2; ++kk) {
-        const float b = wp[(size_t)kk * 2 * TVR_FEATC];
-        const float a0 = ap[kk * 2 * SH_LD];
-        const float a1 = ap[kk * 2 * SH_LD + 32];
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, c1, 0, 0, 0);
+    Frag f;
+    split2(v[0], v[1], f.hi.x, f.lo.x);
+    split2(v[2], v[3], f.hi.y, f.lo.y);
+    split2(v[4], v[5], f.hi.z, f.lo.z);
+    split2(v[6], v[7], f.hi.w, f.lo.w);
+    return f;
+}
+
+__device__ __forceinline__ f32x16 mfma3(const uint4 ah, const uint4 al, const Frag &b, f32x16 c)
+{
+    const h8 Ah = __builtin_bit_cast(h8, ah), Al = __builtin_bit_cast(h8, al);
+    const h8 Bh = __builtin_bit_cast(h8, b.hi), Bl = __builtin_bit_cast(h8, b.lo);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, c, 0, 0, 0);
+    return c;
+}
+
+// the 6 taps (4 plane texels, 2 line texels) x 8 channels of one entry for one k-step, plus the interpolation weights
+struct Taps {
+    float4 t[4][2], lv[2][2];
+    float w00, w01, w10, w11, ul, wl;
+};
+
+template <bool CHECK>
+__device__ __forceinline__ void load_taps(Taps &T, const float4 *__restrict__ P, const float4 *__restrict__ Ln, int W, int H, int L,
+                                          float fx, float fy, float fl, int q0)
+{
+    float x0f, y0f, l0f;
+    if (CHECK) {
+        x0f = floorf(fminf(fmaxf(fx, -2.0f), (float)W + 1.0f));
+        y0f = floorf(fminf(fmaxf(fy, -2.0f), (float)H + 1.0f));
+        l0f = floorf(fminf(fmaxf(fl, -2.0f), (float)L + 1.0f));
+    } else {
+        x0f = floorf(fx); y0f = floorf(fy); l0f = floorf(fl);
     }
-    const int n = wave * 32 + l31;
-    const float bb = bias[n];
+    const int x0 = (int)x0f, y0 = (int)y0f, l0 = (int)l0f;
+    const float wx = fx - x0f, wy = fy - y0f, wl = fl - l0f;
+    const float ux = 1.0f - wx, uy = 1.0f - wy;
+    T.w00 = ux * uy; T.w01 = wx * uy; T.w10 = ux * wy; T.w11 = wx * wy;
+    T.ul = 1.0f - wl; T.wl = wl;
+    const int Wp = W + 1;
+    if (!CHECK) {
+        const float4 *p = P + ((size_t)y0 * Wp + x0) * 12 + q0;
+        T.t[0][0] = p[0]; T.t[0][1] = p[1];
+        T.t[1][0] = p[12]; T.t[1][1] = p[13];
+        T.t[2][0] = p[(size_t)Wp * 12]; T.t[2][1] = p[(size_t)Wp * 12 + 1];
+        T.t[3][0] = p[(size_t)Wp * 12 + 12]; T.t[3][1] = p[(size_t)Wp * 12 + 13];
+        const float4 *q = Ln + (size_t)l0 * 12 + q0;
+        T.lv[0][0] = q[0]; T.lv[0][1] = q[1];
+        T.lv[1][0] = q[12]; T.lv[1][1] = q[13];
+    } else {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool xi[2] = {(x0 >= 0) && (x0 < W), (x0 + 1 >= 0) && (x0 + 1 < W)};
+        const bool yi[2] = {(y0 >= 0) && (y0 < H), (y0 + 1 >= 0) && (y0 + 1 < H)};
+        const bool li[2] = {(l0 >= 0) && (l0 < L), (l0 + 1 >= 0) && (l0 + 1 < L)};
+        const int xc[2] = {min(max(x0, 0), W - 1), min(max(x0 + 1, 0), W - 1)};
+        const int yc[2] = {min(max(y0, 0), H - 1), min(max(y0 + 1, 0), H - 1)};
+        const int lc[2] = {min(max(l0, 0), L - 1), min(max(l0 + 1, 0), L - 1)};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        out[n * SH_LD + row] = fmaxf(c0[r] + bb, 0.0f);
-        out[n * SH_LD + 32 + row] = fmaxf(c1[r] + bb, 0.0f);
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx) {
+                const float4 *p = P + ((size_t)yc[ty] * Wp + xc[tx]) * 12 + q0;
+                const bool in = xi[tx] && yi[ty];
+                T.t[ty * 2 + tx][0] = in ? p[0] : z;
+                T.t[ty * 2 + tx][1] = in ? p[1] : z;
+            }
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const float4 *q = Ln + (size_t)lc[tl] * 12 + q0;
+            T.lv[tl][0] = li[tl] ? q[0] : z;
+            T.lv[tl][1] = li[tl] ? q[1] : z;
+        }
     }
+}
+
+// bilinear(plane) * linear(line) for the 8 channels held in T
+__device__ __forceinline__ void taps_eval(const Taps &T, float out[8])
+{
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float4 p4 = f4_mul(T.w00, T.t[0][g]);
+        p4 = f4_fma(T.w01, T.t[1][g], p4);
+        p4 = f4_fma(T.w10, T.t[2][g], p4);
+        p4 = f4_fma(T.w11, T.t[3][g], p4);
+        float4 q4 = f4_mul(T.ul, T.lv[0][g]);
+        q4 = f4_fma(T.wl, T.lv[1][g], q4);
+        out[g * 4 + 0] = p4.x * q4.x;
+        out[g * 4 + 1] = p4.y * q4.y;
+        out[g * 4 + 2] = p4.z * q4.z;
+        out[g * 4 + 3] = p4.w * q4.w;
+    }
+}
+
+// accumulator register r of lane half h  <->  row of the 32x32 tile
+__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// sin/cos with a 3-term Cody-Waite reduction and short minimax polynomials (|err| < ~2e-7 for |x| < ~1e4)
+__device__ __forceinline__ void sincos_fast(float x, float &s, float &c)
+{
+    const float k = rintf(x * 0.636619772367581343f);          // x / (pi/2)
+    float r = __builtin_fmaf(k, -1.5707962512969971f, x);
+    r = __builtin_fmaf(k, -7.5497894158615964e-8f, r);
+    r = __builtin_fmaf(k, -5.3903029534742384e-15f, r);
+    const float r2 = r * r;
+    float sp = __builtin_fmaf(r2, 2.7183114939898219e-6f, -1.9839334836096632e-4f);
+    sp = __builtin_fmaf(sp, r2, 8.3333095484102479e-3f);
+    sp = __builtin_fmaf(sp, r2, -1.6666665461976921e-1f);
+    sp = __builtin_fmaf(sp * r2, r, r);
+    float cp = __builtin_fmaf(r2, 2.4433157656e-5f, -1.3887316255e-3f);
+    cp = __builtin_fmaf(cp, r2, 4.1666645683e-2f);
+    cp = __builtin_fmaf(cp, r2, -0.5f);
+    cp = __builtin_fmaf(cp, r2, 1.0f);
+    const int q = (int)k;
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
 }
 
 template <int SRC, int DST>
 __global__ __launch_bounds__(SH_THREADS, 2) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
-    extern __shared__ float lds[];
-    float *X = lds;
-    float *Y = lds + SH_X_FLOATS;
-    float *en = Y + SH_Y_FLOATS;          // [64][4] xyz_norm
-    float *ed = en + SH_TM * 4;           // [64][4] view dir
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
-    const long long n_tiles = (n_total + SH_TM - 1) / SH_TM;
-
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long long e0 = tile * SH_TM;
-        // ---- phase 0: entry positions / view directions ----
-        if (tid < SH_TM) {
-            const long long e = e0 + tid;
-            float4 pn = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < n_total) {
-                if (SRC == SH_SRC_QUEUE) {
-                    pn = a.q_pos[e];
-                    const float *rp = a.rays + (size_t)a.q_ray[e] * 6 + 3;
-                    dv = make_float4(rp[0], rp[1], rp[2], 0.f);
-                } else if (SRC == SH_SRC_XYZ) {
-                    pn = make_float4(a.xyz[e * 3], a.xyz[e * 3 + 1], a.xyz[e * 3 + 2], 0.f);
-                } else {
-                    dv = make_float4(a.viewdirs[e * 3], a.viewdirs[e * 3 + 1], a.viewdirs[e * 3 + 2], 0.f);
-                }
-            }
-            *(float4 *)(en + tid * 4) = pn;
-            *(float4 *)(ed + tid * 4) = dv;
-        }
+    const int e = lane & 31, h = lane >> 5;
+    if (DST != SH_DST_FEAT) {                     // MLP weights -> LDS once per workgroup
+        const uint4 *src = (const uint4 *)sc.mlp_image;
+        for (int i = tid; i < TVR_MLP_IMAGE_BYTES / 16; i += SH_THREADS) ((uint4 *)smem)[i] = src[i];
         __syncthreads();
+    }
+    const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
+    const long long n_tiles = (n_total + 31) / 32;
+
+    for (long long tile = (long long)blockIdx.x * SH_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * SH_WAVES) {
+        const long long ent = tile * 32 + e;
+        const bool live = ent < n_total;
+        float F[16];                               // base values: row c = acc_row(r, h) of the feature tile, column = entry
+        float dir[3] = {0.f, 0.f, 0.f};
 
         if (SRC != SH_SRC_FEAT) {
-            // ---- phase 1: gather 64 entries x 3 planes x 12 float4-quads ----
-#pragma unroll 3
-            for (int it = 0; it < (SH_TM * 36) / SH_THREADS; ++it) {
-                const int item = tid + SH_THREADS * it;
-                const int ent = item / 36, rem = item - ent * 36;
-                const int pl = rem / 12, q = rem - pl * 12;
-                const int ax = kMat[pl][0], bx = kMat[pl][1], vx = kVec[pl];
-                const float fx = unnorm(en[ent * 4 + ax], sc.gm1[ax]);
-                const float fy = unnorm(en[ent * 4 + bx], sc.gm1[bx]);
-                const float fl = unnorm(en[ent * 4 + vx], sc.gm1[vx]);
-                float4 h;
+            float pn[3] = {0.f, 0.f, 0.f};
+            if (live) {
                 if (SRC == SH_SRC_QUEUE) {
-                    const float x0 = floorf(fx), y0 = floorf(fy), l0 = floorf(fl);
-                    h = vm_term<12, false>(sc.aplane[pl], sc.aline[pl], sc.grid[ax], sc.grid[bx], sc.grid[vx], (int)x0, (int)y0, (int)l0,
-                                           fx - x0, fy - y0, fl - l0, q);
+                    const float4 q = a.q_pos[ent];
+                    pn[0] = q.x; pn[1] = q.y; pn[2] = q.z;
+                    const float *rp = a.rays + (size_t)a.q_ray[ent] * 6 + 3;
+                    dir[0] = rp[0]; dir[1] = rp[1]; dir[2] = rp[2];
                 } else {
-                    const float x0 = floorf(fminf(fmaxf(fx, -2.0f), sc.gm1[ax] + 2.0f));
-                    const float y0 = floorf(fminf(fmaxf(fy, -2.0f), sc.gm1[bx] + 2.0f));
-                    const float l0 = floorf(fminf(fmaxf(fl, -2.0f), sc.gm1[vx] + 2.0f));
-                    h = vm_term<12, true>(sc.aplane[pl], sc.aline[pl], sc.grid[ax], sc.grid[bx], sc.grid[vx], (int)x0, (int)y0, (int)l0,
-                                          fx - x0, fy - y0, fl - l0, q);
-                }
-                float *xp = X + (pl * TVR_CA + q * 4) * SH_LD + ent;
-                xp[0] = h.x;
-                xp[SH_LD] = h.y;
-                xp[2 * SH_LD] = h.z;
-                xp[3 * SH_LD] = h.w;
-            }
-            __syncthreads();
-
-            // ---- phase 2: basis  f[16 entries of wave w][32] = h · basisT  (two 16x16 N-tiles) ----
-            f32x4 f0 = {0}, f1 = {0};
-            {
-                const int kq = lane >> 4, l15 = lane & 15;
-                const float *ap = X + kq * SH_LD + wave * 16 + l15;
-                const float *bp = sc.basisT + kq * 32 + l15;
-#pragma unroll 6
-                for (int kk = 0; kk < TVR_KAPP / 4; ++kk) {
-                    const float av = ap[kk * 4 * SH_LD];
-                    const float b0 = bp[kk * 4 * 32], b1 = bp[kk * 4 * 32 + 16];
-                    f0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, f0, 0, 0, 0);
-                    f1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, f1, 0, 0, 0);
+                    pn[0] = a.xyz[ent * 3]; pn[1] = a.xyz[ent * 3 + 1]; pn[2] = a.xyz[ent * 3 + 2];
                 }
             }
-            const int col = lane & 15, rbase = wave * 16 + (lane >> 4) * 4;
-            if (DST == SH_DST_FEAT) {
+            float fc[3];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long long e = e0 + rbase + r;
-                    if (e < n_total) {
-                        a.out[e * TVR_APPDIM + col] = f0[r];
-                        if (col + 16 < TVR_APPDIM) a.out[e * TVR_APPDIM + col + 16] = f1[r];
-                    }
-                }
-                __syncthreads();
-                continue;
-            }
-            // ---- phase 3a: PE of the features straight from the accumulators ----
+            for (int k = 0; k < 3; ++k) fc[k] = unnorm(pn[k], sc.gm1[k]);
+            // ---- gather + basis: 9 k-steps of 16 channels (plane p = s/3, channels 16(s%3) + 8h .. +7 of this lane) ----
+            f32x16 accF = {0};
+            Taps cur, nxt;
+            load_taps<SRC != SH_SRC_QUEUE>(cur, sc.aplane[0], sc.aline[0], sc.grid[0], sc.grid[1], sc.grid[2], fc[0], fc[1], fc[2], 2 * h);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pe_rows_feat(Y, col, rbase + r, f0[r]);
-                if (col + 16 < TVR_APPDIM) pe_rows_feat(Y, col + 16, rbase + r, f1[r]);
+            for (int s = 0; s < 9; ++s) {
+                if (s < 8) {                                       // taps of k-step s+1 are in flight while step s computes
+                    const int s1 = s + 1, p = s1 / 3;
+                    const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
+                    load_taps<SRC != SH_SRC_QUEUE>(nxt, sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx],
+                                                   fc[vx], 4 * (s1 % 3) + 2 * h);
+                }
+                float hv[8];
+                taps_eval(cur, hv);
+                const Frag b = split8(hv);
+                const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
+                accF = mfma3(ap[0], ap[1], b, accF);
+                if (s < 8) cur = nxt;
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) F[r] = accF[r];
         } else {
-            for (int idx = tid; idx < SH_TM * TVR_APPDIM; idx += SH_THREADS) {
-                const int ent = idx / TVR_APPDIM, c = idx - ent * TVR_APPDIM;
-                const long long e = e0 + ent;
-                pe_rows_feat(Y, c, ent, e < n_total ? a.feats[e * TVR_APPDIM + c] : 0.0f);
-            }
-        }
-        // ---- phase 3b: view direction rows 27..29 and its PE rows 138..149 ----
-        if (tid < SH_TM * 3) {
-            const int ent = tid / 3, c = tid - ent * 3;
-            const float v = ed[ent * 4 + c], v2 = v * 2.0f;
-            Y[(27 + c) * SH_LD + ent] = v;
-            Y[(138 + 2 * c) * SH_LD + ent] = sinf(v);
-            Y[(139 + 2 * c) * SH_LD + ent] = sinf(v2);
-            Y[(144 + 2 * c) * SH_LD + ent] = cosf(v);
-            Y[(145 + 2 * c) * SH_LD + ent] = cosf(v2);
-        }
-        __syncthreads();
-
-        // ---- phase 4/5: hidden layers ----
-        hidden_layer<TVR_NIN>(Y, X, sc.W1T, sc.b1, wave, lane);
-        __syncthreads();
-        hidden_layer<TVR_FEATC>(X, Y, sc.W2T, sc.b2, wave, lane);
-        __syncthreads();
-
-        // ---- phase 6: output layer, 16 entries per wave ----
-        {
-            f32x4 o = {0};
-            const int kq = lane >> 4, l15 = lane & 15;
-            const float *ap = Y + kq * SH_LD + wave * 16 + l15;
-            const float *bp = sc.W3T + kq * 16 + l15;
-#pragma unroll 8
-            for (int kk = 0; kk < TVR_FEATC / 4; ++kk)
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * SH_LD], bp[kk * 4 * 16], o, 0, 0, 0);
-            const int col = l15, rbase = wave * 16 + kq * 4;
-            if (col < 3) {
-                const float bb = sc.b3[col];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long long e = e0 + rbase + r;
-                    if (e < n_total) {
-                        const float v = sigmoid_f(o[r] + bb);
-                        if (DST == SH_DST_QUEUE) ((float *)a.q_pos)[e * 4 + col] = v;
-                        else a.out[e * 3 + col] = v;
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int c = acc_row(r, h);
+                F[r] = (live && c < TVR_APPDIM) ? a.feats[ent * TVR_APPDIM + c] : 0.0f;
+            }
+            if (live) { dir[0] = a.viewdirs[ent * 3]; dir[1] = a.viewdirs[ent * 3 + 1]; dir[2] = a.viewdirs[ent * 3 + 2]; }
+        }
+
+        if (DST == SH_DST_FEAT) {
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = acc_row(r, h);
+                    if (c < TVR_APPDIM) a.out[ent * TVR_APPDIM + c] = F[r];
                 }
             }
+            continue;
         }
-        __syncthreads();
+
+        // view direction occupies base rows 27 (h=0, r=15), 28, 29 (h=1, r=12, 13); rows 30, 31 stay zero (zero weights)
+        if (h == 0) F[15] = dir[0];
+        else { F[12] = dir[1]; F[13] = dir[2]; F[14] = 0.f; F[15] = 0.f; }
+
+        // ---- layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5 ----
+        const unsigned char *W1H = smem + TVR_IMG_W1H, *W1L = smem + TVR_IMG_W1L;
+        const unsigned char *W2H = smem + TVR_IMG_W2H, *W2L = smem + TVR_IMG_W2L;
+        f32x16 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *(const float4 *)(smem + TVR_IMG_B1 + (32 * rb + 8 * q + 4 * h) * 4);
+                acc[rb][4 * q] = bv.x; acc[rb][4 * q + 1] = bv.y; acc[rb][4 * q + 2] = bv.z; acc[rb][4 * q + 3] = bv.w;
+            }
+        {
+            float S1[16], C1[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sincos_fast(F[r], S1[r], C1[r]);
+            const int rowoff = e * TVR_IMG_W1_ROW + h * 16;
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * s + j, r = i / 5, t = i % 5;
+                    v[j] = t == 0 ? F[r] : (t == 1 ? S1[r] : (t == 2 ? 2.0f * S1[r] * C1[r]                 // sin 2v
+                                  : (t == 3 ? C1[r] : __builtin_fmaf(-2.0f * S1[r], S1[r], 1.0f))));      // cos 2v
+                }
+                const Frag b = split8(v);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const int off = rb * 32 * TVR_IMG_W1_ROW + rowoff + s * 32;
+                    acc[rb] = mfma3(*(const uint4 *)(W1H + off), *(const uint4 *)(W1L + off), b, acc[rb]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- layer 2: B fragments are the relu'd layer-1 accumulators, 8 registers per k-step ----
+        f32x16 acc2[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * rb + 8 * q + 4 * h) * 4);
+                acc2[rb][4 * q] = bv.x; acc2[rb][4 * q + 1] = bv.y; acc2[rb][4 * q + 2] = bv.z; acc2[rb][4 * q + 3] = bv.w;
+            }
+        {
+            const int rowoff = e * TVR_IMG_W2_ROW + h * 16;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[s >> 1][8 * (s & 1) + j], 0.0f);
+                const Frag b = split8(v);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const int off = rb * 32 * TVR_IMG_W2_ROW + rowoff + s * 32;
+                    acc2[rb] = mfma3(*(const uint4 *)(W2H + off), *(const uint4 *)(W2L + off), b, acc2[rb]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- layer 3: rows 0..2 of W3 (fragments streamed from L1-cached global), bias b3 as the initial accumulator ----
+        f32x16 acc3 = {0};
+        if (h == 0) { acc3[0] = sc.b3[0]; acc3[1] = sc.b3[1]; acc3[2] = sc.b3[2]; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[s >> 1][8 * (s & 1) + j], 0.0f);
+            const Frag b = split8(v);
+            const uint4 *ap = (const uint4 *)sc.w3_frag + ((s * 2 + h) * 32 + e) * 2;
+            acc3 = mfma3(ap[0], ap[1], b, acc3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (live && h == 0) {
+            const float r0 = sigmoid_f(acc3[0]), r1 = sigmoid_f(acc3[1]), r2 = sigmoid_f(acc3[2]);
+            if (DST == SH_DST_QUEUE) {
+                float *qp = (float *)(a.q_pos + ent);
+                qp[0] = r0; qp[1] = r1; qp[2] = r2;               // .w (the weight) stays
+            } else {
+                a.out[ent * 3] = r0; a.out[ent * 3 + 1] = r1; a.out[ent * 3 + 2] = r2;
+            }
+        }
     }
     if (a.stats && SRC == SH_SRC_QUEUE && blockIdx.x == 0 && tid == 0)
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
@@ -222,13 +336,14 @@ __global__ __launch_bounds__(SH_THREADS, 2) void shade_kernel(const SceneDev sc,
 template <int SRC, int DST>
 static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
-    (void)hipFuncSetAttribute((const void *)shade_kernel<SRC, DST>, hipFuncAttributeMaxDynamicSharedMemorySize, SH_LDS_BYTES);
-    unsigned grid = 512;       // 2 workgroups per CU (LDS-limited), persistent over tiles
+    const int lds = (DST == SH_DST_FEAT) ? 0 : TVR_MLP_IMAGE_BYTES;
+    (void)hipFuncSetAttribute((const void *)shade_kernel<SRC, DST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    unsigned grid = 256;       // one 8-wave workgroup per CU (LDS holds the MLP weights), persistent over 32-entry tiles
     if (SRC != SH_SRC_QUEUE) {
-        const long long tiles = (a.n + SH_TM - 1) / SH_TM;
-        if (tiles < grid) grid = (unsigned)(tiles > 0 ? tiles : 1);
+        const long long groups = (a.n + 32 * SH_WAVES - 1) / (32 * SH_WAVES);
+        if (groups < grid) grid = (unsigned)(groups > 0 ? groups : 1);
     }
-    hipLaunchKernelGGL((shade_kernel<SRC, DST>), dim3(grid), dim3(SH_THREADS), SH_LDS_BYTES, stream, sc, a);
+    hipLaunchKernelGGL((shade_kernel<SRC, DST>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
     return hipGetLastError();
 }
 
@@ -241,7 +356,7 @@ hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a
 }
 
 // ---- scene packing (reference layout -> channels-last, zero-padded) ----
-// in (C,H,W) -> out [H+1][W+1][C]; a line is the W == 1 case written as [H+1][C] by passing W = 0 pad off.
+// in (C,H,W) -> out [H+1][W+1][C]; a line (W == 1) packs to [H+1][C]
 __global__ __launch_bounds__(256) void pack_plane_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int H, int W, int Wp)
 {
     const long long total = (long long)(H + 1) * Wp * C;
@@ -253,17 +368,6 @@ __global__ __launch_bounds__(256) void pack_plane_kernel(const float *__restrict
     }
 }
 
-// in [n_in][K] row-major -> out [K][n_out], zero for n >= n_in
-__global__ __launch_bounds__(256) void transpose_pad_kernel(const float *__restrict__ in, float *__restrict__ out, int n_in, int K, int n_out)
-{
-    const int total = K * n_out;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int n = i % n_out, k = i / n_out;
-        out[i] = n < n_in ? in[(size_t)n * K + k] : 0.0f;
-    }
-}
-
-// planes: W>1 -> padded row length W+1; lines (W == 1): packed [H+1][C], no x padding
 hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, hipStream_t stream)
 {
     const int Wp = (W == 1) ? 1 : W + 1;
@@ -274,9 +378,61 @@ hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, h
     return hipGetLastError();
 }
 
-hipError_t launch_transpose_pad(const float *in, float *out, int n_in, int K, int n_out, hipStream_t stream)
+// reference input index (tensorBase.py:77-82 concat order) of derived value t of base value c; -1 = zero weight
+__device__ __forceinline__ int ref_in_index(int c, int t)
 {
-    unsigned grid = (unsigned)((K * n_out + 255) / 256);
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3(grid), dim3(256), 0, stream, in, out, n_in, K, n_out);
+    if (c < TVR_APPDIM) return t == 0 ? c : (t == 1 ? 30 + 2 * c : (t == 2 ? 31 + 2 * c : (t == 3 ? 84 + 2 * c : 85 + 2 * c)));
+    if (c < TVR_APPDIM + 3) {
+        const int d = c - TVR_APPDIM;
+        return t == 0 ? 27 + d : (t == 1 ? 138 + 2 * d : (t == 2 ? 139 + 2 * d : (t == 3 ? 144 + 2 * d : 145 + 2 * d)));
+    }
+    return -1;
+}
+
+// MLP weights -> fp16 hi/lo operand images.  One thread per (row, k position).
+//  mode 0: W1 LDS image  [128][W1_ROW/2 halfs]: kpos = 16s + 8h + j  <->  derived (i%5) of base acc_row(i/5, h), i = 8s + j
+//  mode 1: W2 LDS image  [128][W2_ROW/2 halfs]: kpos = 16s + 8h + j  <->  hidden unit 16s + 8(j>>2) + 4h + (j&3)
+//  mode 2: basis fragments [9][2][32][hi 8 | lo 8]: row r < 27, k = 16s + 8h + j (natural)
+//  mode 3: W3 fragments    [8][2][32][hi 8 | lo 8]: row r < 3,  k as mode 1
+__global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__ W, unsigned short *__restrict__ out_hi,
+                                                       unsigned short *__restrict__ out_lo, int mode)
+{
+    const int nrows = (mode <= 1) ? 128 : 32;
+    const int K = (mode == 0) ? 160 : (mode == 2 ? 144 : 128);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * K) return;
+    const int row = i / K, kpos = i - row * K;
+    const int s = kpos >> 4, hh = (kpos >> 3) & 1, j = kpos & 7;
+    float w = 0.0f;
+    if (mode == 0) {
+        const int ii = 8 * s + j;
+        const int idx = ref_in_index(acc_row(ii / 5, hh), ii % 5);
+        if (idx >= 0) w = W[(size_t)row * TVR_NIN + idx];
+    } else if (mode == 1) {
+        w = W[(size_t)row * TVR_FEATC + (16 * s + 8 * (j >> 2) + 4 * hh + (j & 3))];
+    } else if (mode == 2) {
+        if (row < TVR_APPDIM) w = W[(size_t)row * TVR_KAPP + kpos];
+    } else {
+        if (row < 3) w = W[(size_t)row * TVR_FEATC + (16 * s + 8 * (j >> 2) + 4 * hh + (j & 3))];
+    }
+    unsigned hi, lo;
+    split2(w, 0.0f, hi, lo);
+    if (mode == 0) {
+        out_hi[row * (TVR_IMG_W1_ROW / 2) + kpos] = (unsigned short)hi;
+        out_lo[row * (TVR_IMG_W1_ROW / 2) + kpos] = (unsigned short)lo;
+    } else if (mode == 1) {
+        out_hi[row * (TVR_IMG_W2_ROW / 2) + kpos] = (unsigned short)hi;
+        out_lo[row * (TVR_IMG_W2_ROW / 2) + kpos] = (unsigned short)lo;
+    } else {
+        unsigned short *o = out_hi + ((size_t)((s * 2 + hh) * 32 + row)) * 16;   // [hi 8 | lo 8] per (s, h, row)
+        o[j] = (unsigned short)hi;
+        o[8 + j] = (unsigned short)lo;
+    }
+}
+
+hipError_t launch_pack_mlp(const float *W, void *out_hi, void *out_lo, int mode, hipStream_t stream)
+{
+    const int n = ((mode <= 1) ? 128 : 32) * ((mode == 0) ? 160 : (mode == 2 ? 144 : 128));
+    hipLaunchKernelGGL(pack_mlp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, (unsigned short *)out_hi, (unsigned short *)out_lo, mode);
     return hipGetLastError();
 }
