@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtvr.so")
+LIB_PATH = os.environ.get("TVR_LIB_PATH") or os.path.join(_HERE, "lib", "libtvr.so")   # env override: A/B builds of the same ABI
 
 _FP = C.POINTER(C.c_float)
 

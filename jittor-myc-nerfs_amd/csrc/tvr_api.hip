@@ -33,7 +33,7 @@ static const int kVecH[3] = {2, 1, 0};
 
 struct PackedLayout {
     size_t dplane[3], dline[3], aplane[3], aline[3];
-    size_t mlp_image, basis_frag, w3_frag, b3, total;
+    size_t mlp_image, basis_frag, b3, total;
 };
 
 static PackedLayout packed_layout(const tvr_scene_desc &d)
@@ -50,7 +50,6 @@ static PackedLayout packed_layout(const tvr_scene_desc &d)
     }
     L.mlp_image = take(TVR_MLP_IMAGE_BYTES / 4);
     L.basis_frag = take(TVR_BASIS_FRAG_BYTES / 4);
-    L.w3_frag = take(TVR_W3_FRAG_BYTES / 4);
     L.b3 = take(16);
     L.total = off;
     return L;
@@ -127,7 +126,6 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
     }
     v.mlp_image = s->packed + L.mlp_image;
     v.basis_frag = s->packed + L.basis_frag;
-    v.w3_frag = s->packed + L.w3_frag;
     v.b3 = (const float *)(s->packed + L.b3);
     v.near_ = desc->near_;
     v.far_ = desc->far_;
@@ -162,7 +160,7 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
     HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B1, p->b1, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B2, p->b2, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(launch_pack_mlp(p->basis_mat, s->packed + s->lay.basis_frag, nullptr, 2, stream));
-    HIP_TRY(launch_pack_mlp(p->W3, s->packed + s->lay.w3_frag, nullptr, 3, stream));
+    HIP_TRY(launch_pack_mlp(p->W3, img + TVR_IMG_W3, nullptr, 3, stream));
     HIP_TRY(hipMemcpyAsync(s->packed + s->lay.b3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     s->params_set = true;
     return TVR_OK;
@@ -191,7 +189,7 @@ int tvr_scene_destroy(tvr_scene *s)
 }
 
 // scratch carving shared by the size query and tvr_render
-struct ScratchLayout { size_t counter, ray_off, ray_cnt, acc, q_pos, q_ray, q_j, total; };
+struct ScratchLayout { size_t counter, ray_off, ray_cnt, acc, q_pos, q_out, q_ray, q_j, total; };
 static ScratchLayout scratch_layout(int64_t n_rays, int32_t S)
 {
     ScratchLayout L;
@@ -203,6 +201,7 @@ static ScratchLayout scratch_layout(int64_t n_rays, int32_t S)
     L.ray_cnt = take(n_rays * 4);
     L.acc = take(n_rays * 4);
     L.q_pos = take(cap * 16);
+    L.q_out = take(cap * 16);
     L.q_ray = take(cap * 4);
     L.q_j = take(cap * 4);
     L.total = off;
@@ -240,6 +239,7 @@ int tvr_render(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32
     mo.acc = (float *)(b + L.acc);
     mo.depth = depth_out;
     mo.q_pos = (float4 *)(b + L.q_pos);
+    mo.q_out = (float4 *)(b + L.q_out);
     mo.q_ray = (unsigned *)(b + L.q_ray);
     mo.q_j = (dense && dense->rgb) ? (unsigned *)(b + L.q_j) : nullptr;
     mo.stats = (unsigned long long *)stats;
@@ -253,6 +253,7 @@ int tvr_render(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32
     memset(&sa, 0, sizeof(sa));
     sa.counter = mo.counter;
     sa.q_pos = mo.q_pos;
+    sa.q_out = mo.q_out;
     sa.q_ray = mo.q_ray;
     sa.rays = rays;
     sa.stats = mo.stats;

@@ -8,7 +8,7 @@
 //   app line      i : [L_i+1][48]
 //   MLP LDS image (TVR_MLP_IMAGE_BYTES): W1 / W2 as fp16 hi and lo parts, row-major [128 hidden][k position] with padded
 //                      rows (conflict-free ds_read_b128 A-operand reads) and permuted k columns (see tvr_shade.hip), b1, b2
-//   basis / W3 fragments: [k-step][lane half][row 32][hi 8 | lo 8] fp16 — one 32-B A-operand pair per lane, coalesced
+//   basis fragments: [k-step][lane half][row 32][hi 8 | lo 8] fp16 — one 32-B A-operand pair per lane, coalesced
 // Compiled with -ffp-contract=off: every a*b+c below is two rounded ops unless written as fmaf, so the
 // position / mask / cell-index arithmetic reproduces SURVEY.md Appendix A steps 1-7 bit for bit.
 #pragma once
@@ -31,9 +31,10 @@
 #define TVR_IMG_W2L (TVR_IMG_W2H + 128 * TVR_IMG_W2_ROW)
 #define TVR_IMG_B1 (TVR_IMG_W2H + 2 * 128 * TVR_IMG_W2_ROW)
 #define TVR_IMG_B2 (TVR_IMG_B1 + 512)
-#define TVR_MLP_IMAGE_BYTES (TVR_IMG_B2 + 512)     // 156 672 B of the 163 840 B LDS
+#define TVR_IMG_W3 (TVR_IMG_B2 + 512)              // [4 rows: W3 rows 0..2 + one zero row][8 k-steps][2 halves][hi 8 | lo 8] fp16
+#define TVR_IMG_W3_ROW 512
+#define TVR_MLP_IMAGE_BYTES (TVR_IMG_W3 + 4 * TVR_IMG_W3_ROW)     // 158 720 B of the 163 840 B LDS
 #define TVR_BASIS_FRAG_BYTES (9 * 2 * 32 * 16 * 2)
-#define TVR_W3_FRAG_BYTES (8 * 2 * 32 * 16 * 2)
 
 struct SceneDev {
     float lo[3], hi[3], inv[3];
@@ -45,7 +46,6 @@ struct SceneDev {
     const float4 *aline[3];
     const void *mlp_image;        // TVR_MLP_IMAGE_BYTES, copied to LDS by the shade kernel
     const void *basis_frag;       // [9][2][32][16] fp16
-    const void *w3_frag;          // [8][2][32][16] fp16
     const float *b3;              // [3]
     float near_, far_, step, shift, scale, thres;
     int act;

@@ -13,7 +13,8 @@ struct MarchOut {
     unsigned *ray_cnt;        // [n_rays] entries of the ray
     float *acc;               // [n_rays] sum of ALL weights (tensorBase.py:520)
     float *depth;             // [n_rays] final depth_map (written by the march kernel)
-    float4 *q_pos;            // [cap] {xyz_norm, weight}; the shade kernel overwrites xyz with rgb
+    float4 *q_pos;            // [cap] {xyz_norm, weight}
+    float4 *q_out;            // [cap] {rgb, weight} written by the shade kernel (may alias q_pos)
     unsigned *q_ray;          // [cap] ray index (for the view direction)
     unsigned *q_j;            // [cap] sample index, or nullptr
     unsigned long long *stats;// TVR_STAT_* counters or nullptr
@@ -26,6 +27,7 @@ struct ShadeArgs {
     const unsigned *counter;   // SRC_QUEUE: entry count lives on the device
     long long n;               // other modes: entry count
     float4 *q_pos;
+    float4 *q_out;
     const unsigned *q_ray;
     const float *rays;         // [n_rays,6]
     const float *xyz;          // SRC_XYZ: xyz_norm [n,3]

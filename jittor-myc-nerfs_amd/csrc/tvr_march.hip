@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const MarchOut mo, const
     const unsigned base = mo.ray_off[r], cnt = mo.ray_cnt[r];
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     for (unsigned i = 0; i < cnt; ++i) {
-        const float4 e = mo.q_pos[base + i];     // {r,g,b,w} after the shade kernel
+        const float4 e = mo.q_out[base + i];     // {r,g,b,w} written by the shade kernel
         c0 = c0 + e.w * e.x;
         c1 = c1 + e.w * e.y;
         c2 = c2 + e.w * e.z;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void scatter_rgb_kernel(const MarchOut mo, con
 {
     const unsigned n = *mo.counter;
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const float4 v = mo.q_pos[e];
+        const float4 v = mo.q_out[e];
         const size_t q = ((size_t)mo.q_ray[e] * S + mo.q_j[e]) * 3;
         rgb_dense[q] = v.x; rgb_dense[q + 1] = v.y; rgb_dense[q + 2] = v.z;
     }

@@ -24,8 +24,19 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define SH_THREADS 512
-#define SH_WAVES 8
+#define TVR_SB __builtin_amdgcn_sched_barrier(0)
+#ifndef TVR_PF
+#define TVR_PF 2          // gather prefetch distance in k-steps (ring of TVR_PF + 1 tap sets)
+#endif
+#define TVR_CHK (SRC != SH_SRC_QUEUE)
+// ONE wave per SIMD (4 waves per workgroup, one workgroup per CU).  Measured on gfx950 / ROCm 7.2: with two MFMA-issuing
+// waves per SIMD an MFMA can sit queued behind the partner wave's MFMAs and read its A/B VGPRs late; a global load issued
+// behind it into those registers (the register allocator reuses them) then lands first and corrupts the operands one
+// 16-lane quarter at a time (16 queue entries wrong by ~1e-2, different ones each run).  With one wave per SIMD an MFMA
+// starts when it issues and the kernel is bit-reproducible (tests/test_gpu_parity.py::test_run_to_run_determinism).
+#define SH_THREADS 256
+#define SH_WAVES 4
+#define SH_MINW 1
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -53,20 +64,40 @@ __device__ __forceinline__ Frag split8(const float v[8])
     return f;
 }
 
-__device__ __forceinline__ f32x16 mfma3(const uint4 ah, const uint4 al, const Frag &b, f32x16 c)
+// The three products of a k-step go to independent accumulators (Acc3, summed once at the end) or are interleaved across
+// the four row blocks (mfma3x4), so no MFMA directly follows an MFMA it depends on.
+struct Acc3 { f32x16 a, b, c; };
+
+__device__ __forceinline__ void mfma3(const uint4 ah, const uint4 al, const Frag &b, Acc3 &acc)
 {
     const h8 Ah = __builtin_bit_cast(h8, ah), Al = __builtin_bit_cast(h8, al);
     const h8 Bh = __builtin_bit_cast(h8, b.hi), Bl = __builtin_bit_cast(h8, b.lo);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, c, 0, 0, 0);
-    return c;
+    acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc.a, 0, 0, 0);
+    acc.b = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc.b, 0, 0, 0);
+    acc.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc.c, 0, 0, 0);
+}
+
+// one k-step of a 128-row layer: A fragments of the four 32-row blocks from the LDS image, products interleaved across blocks
+__device__ __forceinline__ void mfma3x4(const unsigned char *WH, const unsigned char *WL, int off0, int rb_stride, const Frag &b, f32x16 acc[4])
+{
+    uint4 ah[4], al[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        ah[rb] = *(const uint4 *)(WH + off0 + rb * rb_stride);
+        al[rb] = *(const uint4 *)(WL + off0 + rb * rb_stride);
+    }
+    const h8 Bh = __builtin_bit_cast(h8, b.hi), Bl = __builtin_bit_cast(h8, b.lo);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, al[rb]), Bh, acc[rb], 0, 0, 0);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah[rb]), Bl, acc[rb], 0, 0, 0);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah[rb]), Bh, acc[rb], 0, 0, 0);
 }
 
 // the 6 taps (4 plane texels, 2 line texels) x 8 channels of one entry for one k-step, plus the interpolation weights
 struct Taps {
     float4 t[4][2], lv[2][2];
-    float w00, w01, w10, w11, ul, wl;
 };
 
 template <bool CHECK>
@@ -82,10 +113,6 @@ __device__ __forceinline__ void load_taps(Taps &T, const float4 *__restrict__ P,
         x0f = floorf(fx); y0f = floorf(fy); l0f = floorf(fl);
     }
     const int x0 = (int)x0f, y0 = (int)y0f, l0 = (int)l0f;
-    const float wx = fx - x0f, wy = fy - y0f, wl = fl - l0f;
-    const float ux = 1.0f - wx, uy = 1.0f - wy;
-    T.w00 = ux * uy; T.w01 = wx * uy; T.w10 = ux * wy; T.w11 = wx * wy;
-    T.ul = 1.0f - wl; T.wl = wl;
     const int Wp = W + 1;
     if (!CHECK) {
         const float4 *p = P + ((size_t)y0 * Wp + x0) * 12 + q0;
@@ -122,21 +149,46 @@ __device__ __forceinline__ void load_taps(Taps &T, const float4 *__restrict__ P,
     }
 }
 
-// bilinear(plane) * linear(line) for the 8 channels held in T
-__device__ __forceinline__ void taps_eval(const Taps &T, float out[8])
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+
+// bilinear(plane) * linear(line) for the 8 channels held in T (packed fp32 math: two channels per VALU op)
+template <bool CHECK>
+__device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, float fx, float fy, float fl, float out[8])
 {
+    float x0f, y0f, l0f;
+    if (CHECK) {
+        x0f = floorf(fminf(fmaxf(fx, -2.0f), (float)W + 1.0f));
+        y0f = floorf(fminf(fmaxf(fy, -2.0f), (float)H + 1.0f));
+        l0f = floorf(fminf(fmaxf(fl, -2.0f), (float)L + 1.0f));
+    } else {
+        x0f = floorf(fx); y0f = floorf(fy); l0f = floorf(fl);
+    }
+    const float wx = fx - x0f, wy = fy - y0f, wlf = fl - l0f;
+    const float ux = 1.0f - wx, uy = 1.0f - wy, ulf = 1.0f - wlf;
+    const float a00 = ux * uy, a01 = wx * uy, a10 = ux * wy, a11 = wx * wy;
+    const f32x2 w00 = {a00, a00}, w01 = {a01, a01}, w10 = {a10, a10}, w11 = {a11, a11};
+    const f32x2 ul = {ulf, ulf}, wl = {wlf, wlf};
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        float4 p4 = f4_mul(T.w00, T.t[0][g]);
-        p4 = f4_fma(T.w01, T.t[1][g], p4);
-        p4 = f4_fma(T.w10, T.t[2][g], p4);
-        p4 = f4_fma(T.w11, T.t[3][g], p4);
-        float4 q4 = f4_mul(T.ul, T.lv[0][g]);
-        q4 = f4_fma(T.wl, T.lv[1][g], q4);
-        out[g * 4 + 0] = p4.x * q4.x;
-        out[g * 4 + 1] = p4.y * q4.y;
-        out[g * 4 + 2] = p4.z * q4.z;
-        out[g * 4 + 3] = p4.w * q4.w;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x2 t0 = hh ? f32x2{T.t[0][g].z, T.t[0][g].w} : f32x2{T.t[0][g].x, T.t[0][g].y};
+            const f32x2 t1 = hh ? f32x2{T.t[1][g].z, T.t[1][g].w} : f32x2{T.t[1][g].x, T.t[1][g].y};
+            const f32x2 t2 = hh ? f32x2{T.t[2][g].z, T.t[2][g].w} : f32x2{T.t[2][g].x, T.t[2][g].y};
+            const f32x2 t3 = hh ? f32x2{T.t[3][g].z, T.t[3][g].w} : f32x2{T.t[3][g].x, T.t[3][g].y};
+            const f32x2 l0 = hh ? f32x2{T.lv[0][g].z, T.lv[0][g].w} : f32x2{T.lv[0][g].x, T.lv[0][g].y};
+            const f32x2 l1 = hh ? f32x2{T.lv[1][g].z, T.lv[1][g].w} : f32x2{T.lv[1][g].x, T.lv[1][g].y};
+            f32x2 p = w00 * t0;
+            p = pk_fma(w01, t1, p);
+            p = pk_fma(w10, t2, p);
+            p = pk_fma(w11, t3, p);
+            f32x2 q = ul * l0;
+            q = pk_fma(wl, l1, q);
+            const f32x2 r = p * q;
+            out[g * 4 + hh * 2] = r.x;
+            out[g * 4 + hh * 2 + 1] = r.y;
+        }
     }
 }
 
@@ -166,7 +218,7 @@ __device__ __forceinline__ void sincos_fast(float x, float &s, float &c)
 }
 
 template <int SRC, int DST>
-__global__ __launch_bounds__(SH_THREADS, 2) void shade_kernel(const SceneDev sc, const ShadeArgs a)
+__global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -185,13 +237,14 @@ __global__ __launch_bounds__(SH_THREADS, 2) void shade_kernel(const SceneDev sc,
         const bool live = ent < n_total;
         float F[16];                               // base values: row c = acc_row(r, h) of the feature tile, column = entry
         float dir[3] = {0.f, 0.f, 0.f};
+        float wq = 0.f;                            // the entry's compositing weight, carried to the output record
 
         if (SRC != SH_SRC_FEAT) {
             float pn[3] = {0.f, 0.f, 0.f};
             if (live) {
                 if (SRC == SH_SRC_QUEUE) {
                     const float4 q = a.q_pos[ent];
-                    pn[0] = q.x; pn[1] = q.y; pn[2] = q.z;
+                    pn[0] = q.x; pn[1] = q.y; pn[2] = q.z; wq = q.w;
                     const float *rp = a.rays + (size_t)a.q_ray[ent] * 6 + 3;
                     dir[0] = rp[0]; dir[1] = rp[1]; dir[2] = rp[2];
                 } else {
@@ -201,28 +254,40 @@ __global__ __launch_bounds__(SH_THREADS, 2) void shade_kernel(const SceneDev sc,
             float fc[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) fc[k] = unnorm(pn[k], sc.gm1[k]);
+            {
             // ---- gather + basis: 9 k-steps of 16 channels (plane p = s/3, channels 16(s%3) + 8h .. +7 of this lane) ----
-            f32x16 accF = {0};
-            Taps cur, nxt;
-            load_taps<SRC != SH_SRC_QUEUE>(cur, sc.aplane[0], sc.aline[0], sc.grid[0], sc.grid[1], sc.grid[2], fc[0], fc[1], fc[2], 2 * h);
+            Acc3 accF;
+            accF.a = f32x16{0}; accF.b = f32x16{0}; accF.c = f32x16{0};
+            Taps T[TVR_PF + 1];                                    // ring: taps of k-steps s .. s+TVR_PF in flight
 #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                if (s < 8) {                                       // taps of k-step s+1 are in flight while step s computes
-                    const int s1 = s + 1, p = s1 / 3;
-                    const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
-                    load_taps<SRC != SH_SRC_QUEUE>(nxt, sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx],
-                                                   fc[vx], 4 * (s1 % 3) + 2 * h);
-                }
-                float hv[8];
-                taps_eval(cur, hv);
-                const Frag b = split8(hv);
-                const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
-                accF = mfma3(ap[0], ap[1], b, accF);
-                if (s < 8) cur = nxt;
-                __builtin_amdgcn_sched_barrier(0);
+            for (int s0 = 0; s0 < TVR_PF; ++s0) {
+                const int p = s0 / 3;
+                const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
+                load_taps<TVR_CHK>(T[s0], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx],
+                                               fc[vx], 4 * (s0 % 3) + 2 * h);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) F[r] = accF[r];
+            for (int s = 0; s < 9; ++s) {
+                if (s + TVR_PF < 9) {
+                    const int s2 = s + TVR_PF, p = s2 / 3;
+                    const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
+                    load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx],
+                                                   fc[ax], fc[bx], fc[vx], 4 * (s2 % 3) + 2 * h);
+                }
+                float hv[8];
+                {
+                    const int p = s / 3;
+                    const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
+                    taps_eval<TVR_CHK>(T[s % (TVR_PF + 1)], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], hv);
+                }
+                const Frag b = split8(hv);
+                const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
+                mfma3(ap[0], ap[1], b, accF);
+                TVR_SB;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) F[r] = (accF.a[r] + accF.b[r]) + accF.c[r];
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -273,12 +338,8 @@ __global__ __launch_bounds__(SH_THREADS, 2) void shade_kernel(const SceneDev sc,
                                   : (t == 3 ? C1[r] : __builtin_fmaf(-2.0f * S1[r], S1[r], 1.0f))));      // cos 2v
                 }
                 const Frag b = split8(v);
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    const int off = rb * 32 * TVR_IMG_W1_ROW + rowoff + s * 32;
-                    acc[rb] = mfma3(*(const uint4 *)(W1H + off), *(const uint4 *)(W1L + off), b, acc[rb]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                mfma3x4(W1H, W1L, rowoff + s * 32, 32 * TVR_IMG_W1_ROW, b, acc);
+                TVR_SB;
             }
         }
         // ---- layer 2: B fragments are the relu'd layer-1 accumulators, 8 registers per k-step ----
@@ -298,32 +359,34 @@ __global__ __launch_bounds__(SH_THREADS, 2) void shade_kernel(const SceneDev sc,
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[s >> 1][8 * (s & 1) + j], 0.0f);
                 const Frag b = split8(v);
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    const int off = rb * 32 * TVR_IMG_W2_ROW + rowoff + s * 32;
-                    acc2[rb] = mfma3(*(const uint4 *)(W2H + off), *(const uint4 *)(W2L + off), b, acc2[rb]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                mfma3x4(W2H, W2L, rowoff + s * 32, 32 * TVR_IMG_W2_ROW, b, acc2);
+                TVR_SB;
             }
         }
         // ---- layer 3: rows 0..2 of W3 (fragments streamed from L1-cached global), bias b3 as the initial accumulator ----
-        f32x16 acc3 = {0};
-        if (h == 0) { acc3[0] = sc.b3[0]; acc3[1] = sc.b3[1]; acc3[2] = sc.b3[2]; }
+        Acc3 acc3;
+        acc3.a = f32x16{0}; acc3.b = f32x16{0}; acc3.c = f32x16{0};
+        {
+            const float b30 = sc.b3[0], b31 = sc.b3[1], b32 = sc.b3[2];
+            acc3.a[0] = h == 0 ? b30 : 0.0f; acc3.a[1] = h == 0 ? b31 : 0.0f; acc3.a[2] = h == 0 ? b32 : 0.0f;
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[s >> 1][8 * (s & 1) + j], 0.0f);
             const Frag b = split8(v);
-            const uint4 *ap = (const uint4 *)sc.w3_frag + ((s * 2 + h) * 32 + e) * 2;
-            acc3 = mfma3(ap[0], ap[1], b, acc3);
-            __builtin_amdgcn_sched_barrier(0);
+            // rows >= 3 of W3 are zero: every such lane reads the shared zero row (address select)
+            const uint4 *ap = (const uint4 *)(smem + TVR_IMG_W3 + (e < 3 ? e : 3) * TVR_IMG_W3_ROW + (s * 2 + h) * 32);
+            const uint4 a3h = ap[0], a3l = ap[1];
+            mfma3(a3h, a3l, b, acc3);
+            TVR_SB;
         }
         if (live && h == 0) {
-            const float r0 = sigmoid_f(acc3[0]), r1 = sigmoid_f(acc3[1]), r2 = sigmoid_f(acc3[2]);
+            const float r0 = sigmoid_f((acc3.a[0] + acc3.b[0]) + acc3.c[0]), r1 = sigmoid_f((acc3.a[1] + acc3.b[1]) + acc3.c[1]),
+                        r2 = sigmoid_f((acc3.a[2] + acc3.b[2]) + acc3.c[2]);
             if (DST == SH_DST_QUEUE) {
-                float *qp = (float *)(a.q_pos + ent);
-                qp[0] = r0; qp[1] = r1; qp[2] = r2;               // .w (the weight) stays
+                a.q_out[ent] = make_float4(r0, r1, r2, wq);
             } else {
                 a.out[ent * 3] = r0; a.out[ent * 3 + 1] = r1; a.out[ent * 3 + 2] = r2;
             }
@@ -393,11 +456,11 @@ __device__ __forceinline__ int ref_in_index(int c, int t)
 //  mode 0: W1 LDS image  [128][W1_ROW/2 halfs]: kpos = 16s + 8h + j  <->  derived (i%5) of base acc_row(i/5, h), i = 8s + j
 //  mode 1: W2 LDS image  [128][W2_ROW/2 halfs]: kpos = 16s + 8h + j  <->  hidden unit 16s + 8(j>>2) + 4h + (j&3)
 //  mode 2: basis fragments [9][2][32][hi 8 | lo 8]: row r < 27, k = 16s + 8h + j (natural)
-//  mode 3: W3 fragments    [8][2][32][hi 8 | lo 8]: row r < 3,  k as mode 1
+//  mode 3: W3 LDS block    [4][8][2][hi 8 | lo 8]: rows 0..2 of W3 + one zero row, k as mode 1
 __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__ W, unsigned short *__restrict__ out_hi,
                                                        unsigned short *__restrict__ out_lo, int mode)
 {
-    const int nrows = (mode <= 1) ? 128 : 32;
+    const int nrows = (mode <= 1) ? 128 : (mode == 2 ? 32 : 4);
     const int K = (mode == 0) ? 160 : (mode == 2 ? 144 : 128);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrows * K) return;
@@ -423,8 +486,12 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
     } else if (mode == 1) {
         out_hi[row * (TVR_IMG_W2_ROW / 2) + kpos] = (unsigned short)hi;
         out_lo[row * (TVR_IMG_W2_ROW / 2) + kpos] = (unsigned short)lo;
-    } else {
+    } else if (mode == 2) {
         unsigned short *o = out_hi + ((size_t)((s * 2 + hh) * 32 + row)) * 16;   // [hi 8 | lo 8] per (s, h, row)
+        o[j] = (unsigned short)hi;
+        o[8 + j] = (unsigned short)lo;
+    } else {
+        unsigned short *o = out_hi + ((size_t)((row * 8 + s) * 2 + hh)) * 16;    // [hi 8 | lo 8] per (row, s, h)
         o[j] = (unsigned short)hi;
         o[8 + j] = (unsigned short)lo;
     }
@@ -432,7 +499,7 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
 
 hipError_t launch_pack_mlp(const float *W, void *out_hi, void *out_lo, int mode, hipStream_t stream)
 {
-    const int n = ((mode <= 1) ? 128 : 32) * ((mode == 0) ? 160 : (mode == 2 ? 144 : 128));
+    const int n = ((mode <= 1) ? 128 : (mode == 2 ? 32 : 4)) * ((mode == 0) ? 160 : (mode == 2 ? 144 : 128));
     hipLaunchKernelGGL(pack_mlp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, (unsigned short *)out_hi, (unsigned short *)out_lo, mode);
     return hipGetLastError();
 }

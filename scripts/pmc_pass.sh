@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage: scripts/pmc_pass.sh <tag> <counter> [<counter> ...]   — one rocprofv3 PMC pass over a short bench run (GPU box)
+set -e
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+tag=$1; shift
+cd /tmp
+timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$tag.log 2>&1
+echo "pass $tag rc=$?"
