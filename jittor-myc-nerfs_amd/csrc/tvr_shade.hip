@@ -37,6 +37,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SH_THREADS 256
 #define SH_WAVES 4
 #define SH_MINW 1
+#ifndef SH_NCB
+#define SH_NCB 1            // column blocks (32 entries each) a wave processes together (2 measured no faster: 20.4 vs 20.1 ms)
+#endif
+#define SH_TILE (32 * SH_NCB)
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -64,21 +68,23 @@ __device__ __forceinline__ Frag split8(const float v[8])
     return f;
 }
 
-// The three products of a k-step go to independent accumulators (Acc3, summed once at the end) or are interleaved across
-// the four row blocks (mfma3x4), so no MFMA directly follows an MFMA it depends on.
-struct Acc3 { f32x16 a, b, c; };
-
-__device__ __forceinline__ void mfma3(const uint4 ah, const uint4 al, const Frag &b, Acc3 &acc)
+// One k-step of a single-row-block product (basis, layer 3) for all column blocks: the three hi/lo products are interleaved
+// across the column blocks, so no MFMA directly follows an MFMA it depends on.
+__device__ __forceinline__ void mfma3cb(const uint4 ah, const uint4 al, const Frag b[SH_NCB], f32x16 acc[SH_NCB])
 {
     const h8 Ah = __builtin_bit_cast(h8, ah), Al = __builtin_bit_cast(h8, al);
-    const h8 Bh = __builtin_bit_cast(h8, b.hi), Bl = __builtin_bit_cast(h8, b.lo);
-    acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc.a, 0, 0, 0);
-    acc.b = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc.b, 0, 0, 0);
-    acc.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc.c, 0, 0, 0);
+#pragma unroll
+    for (int cb = 0; cb < SH_NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, b[cb].hi), acc[cb], 0, 0, 0);
+#pragma unroll
+    for (int cb = 0; cb < SH_NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, b[cb].lo), acc[cb], 0, 0, 0);
+#pragma unroll
+    for (int cb = 0; cb < SH_NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, b[cb].hi), acc[cb], 0, 0, 0);
 }
 
-// one k-step of a 128-row layer: A fragments of the four 32-row blocks from the LDS image, products interleaved across blocks
-__device__ __forceinline__ void mfma3x4(const unsigned char *WH, const unsigned char *WL, int off0, int rb_stride, const Frag &b, f32x16 acc[4])
+// one k-step of a 128-row layer: A fragments of the four 32-row blocks from the LDS image (read once, used by every column
+// block), products interleaved across row and column blocks
+__device__ __forceinline__ void mfma3x4(const unsigned char *WH, const unsigned char *WL, int off0, int rb_stride, const Frag b[SH_NCB],
+                                        f32x16 acc[SH_NCB][4])
 {
     uint4 ah[4], al[4];
 #pragma unroll
@@ -86,13 +92,21 @@ __device__ __forceinline__ void mfma3x4(const unsigned char *WH, const unsigned 
         ah[rb] = *(const uint4 *)(WH + off0 + rb * rb_stride);
         al[rb] = *(const uint4 *)(WL + off0 + rb * rb_stride);
     }
-    const h8 Bh = __builtin_bit_cast(h8, b.hi), Bl = __builtin_bit_cast(h8, b.lo);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, al[rb]), Bh, acc[rb], 0, 0, 0);
+    for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah[rb]), Bl, acc[rb], 0, 0, 0);
+        for (int cb = 0; cb < SH_NCB; ++cb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, al[rb]), __builtin_bit_cast(h8, b[cb].hi), acc[cb][rb], 0, 0, 0);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah[rb]), Bh, acc[rb], 0, 0, 0);
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < SH_NCB; ++cb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah[rb]), __builtin_bit_cast(h8, b[cb].lo), acc[cb][rb], 0, 0, 0);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < SH_NCB; ++cb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah[rb]), __builtin_bit_cast(h8, b[cb].hi), acc[cb][rb], 0, 0, 0);
 }
 
 // the 6 taps (4 plane texels, 2 line texels) x 8 channels of one entry for one k-step, plus the interpolation weights
@@ -230,167 +244,220 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         __syncthreads();
     }
     const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
-    const long long n_tiles = (n_total + 31) / 32;
+    const long long n_tiles = (n_total + SH_TILE - 1) / SH_TILE;
 
+    // A wave owns SH_NCB column blocks of 32 entries at a time (entry = MFMA column).  The blocks are independent chains, so the
+    // VALU work of one overlaps the MFMAs of the other, and every weight fragment read from LDS feeds SH_NCB MFMAs.
     for (long long tile = (long long)blockIdx.x * SH_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * SH_WAVES) {
-        const long long ent = tile * 32 + e;
-        const bool live = ent < n_total;
-        float F[16];                               // base values: row c = acc_row(r, h) of the feature tile, column = entry
-        float dir[3] = {0.f, 0.f, 0.f};
-        float wq = 0.f;                            // the entry's compositing weight, carried to the output record
+        long long ent[SH_NCB];
+        bool live[SH_NCB];
+        float F[SH_NCB][16];                       // base values: row c = acc_row(r, h) of the feature tile, column = entry
+        float dir[SH_NCB][3], wq[SH_NCB];
+#pragma unroll
+        for (int cb = 0; cb < SH_NCB; ++cb) {
+            ent[cb] = tile * SH_TILE + cb * 32 + e;
+            live[cb] = ent[cb] < n_total;
+            dir[cb][0] = dir[cb][1] = dir[cb][2] = 0.f;
+            wq[cb] = 0.f;
+        }
 
         if (SRC != SH_SRC_FEAT) {
-            float pn[3] = {0.f, 0.f, 0.f};
-            if (live) {
-                if (SRC == SH_SRC_QUEUE) {
-                    const float4 q = a.q_pos[ent];
-                    pn[0] = q.x; pn[1] = q.y; pn[2] = q.z; wq = q.w;
-                    const float *rp = a.rays + (size_t)a.q_ray[ent] * 6 + 3;
-                    dir[0] = rp[0]; dir[1] = rp[1]; dir[2] = rp[2];
-                } else {
-                    pn[0] = a.xyz[ent * 3]; pn[1] = a.xyz[ent * 3 + 1]; pn[2] = a.xyz[ent * 3 + 2];
-                }
-            }
-            float fc[3];
+            float fc[SH_NCB][3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) fc[k] = unnorm(pn[k], sc.gm1[k]);
-            {
+            for (int cb = 0; cb < SH_NCB; ++cb) {
+                float pn[3] = {0.f, 0.f, 0.f};
+                if (live[cb]) {
+                    if (SRC == SH_SRC_QUEUE) {
+                        const float4 q = a.q_pos[ent[cb]];
+                        pn[0] = q.x; pn[1] = q.y; pn[2] = q.z; wq[cb] = q.w;
+                        const float *rp = a.rays + (size_t)a.q_ray[ent[cb]] * 6 + 3;
+                        dir[cb][0] = rp[0]; dir[cb][1] = rp[1]; dir[cb][2] = rp[2];
+                    } else {
+                        pn[0] = a.xyz[ent[cb] * 3]; pn[1] = a.xyz[ent[cb] * 3 + 1]; pn[2] = a.xyz[ent[cb] * 3 + 2];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fc[cb][k] = unnorm(pn[k], sc.gm1[k]);
+            }
             // ---- gather + basis: 9 k-steps of 16 channels (plane p = s/3, channels 16(s%3) + 8h .. +7 of this lane) ----
-            Acc3 accF;
-            accF.a = f32x16{0}; accF.b = f32x16{0}; accF.c = f32x16{0};
-            Taps T[TVR_PF + 1];                                    // ring: taps of k-steps s .. s+TVR_PF in flight
+            f32x16 accF[SH_NCB];
+#pragma unroll
+            for (int cb = 0; cb < SH_NCB; ++cb) accF[cb] = f32x16{0};
+            Taps T[TVR_PF + 1][SH_NCB];                            // ring: taps of k-steps s .. s+TVR_PF in flight
 #pragma unroll
             for (int s0 = 0; s0 < TVR_PF; ++s0) {
                 const int p = s0 / 3;
                 const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
-                load_taps<TVR_CHK>(T[s0], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx],
-                                               fc[vx], 4 * (s0 % 3) + 2 * h);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb)
+                    load_taps<TVR_CHK>(T[s0][cb], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[cb][ax], fc[cb][bx],
+                                       fc[cb][vx], 4 * (s0 % 3) + 2 * h);
             }
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
                 if (s + TVR_PF < 9) {
                     const int s2 = s + TVR_PF, p = s2 / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
-                    load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx],
-                                                   fc[ax], fc[bx], fc[vx], 4 * (s2 % 3) + 2 * h);
+#pragma unroll
+                    for (int cb = 0; cb < SH_NCB; ++cb)
+                        load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)][cb], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx],
+                                           fc[cb][ax], fc[cb][bx], fc[cb][vx], 4 * (s2 % 3) + 2 * h);
                 }
-                float hv[8];
-                {
-                    const int p = s / 3;
-                    const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
-                    taps_eval<TVR_CHK>(T[s % (TVR_PF + 1)], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], hv);
-                }
-                const Frag b = split8(hv);
                 const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
-                mfma3(ap[0], ap[1], b, accF);
+                const uint4 bah = ap[0], bal = ap[1];
+                const int p = s / 3;
+                const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
+                Frag bf[SH_NCB];
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) {
+                    float hv[8];
+                    taps_eval<TVR_CHK>(T[s % (TVR_PF + 1)][cb], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[cb][ax], fc[cb][bx], fc[cb][vx], hv);
+                    bf[cb] = split8(hv);
+                }
+                mfma3cb(bah, bal, bf, accF);
                 TVR_SB;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) F[r] = (accF.a[r] + accF.b[r]) + accF.c[r];
-            }
+            for (int cb = 0; cb < SH_NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) F[cb][r] = accF[cb][r];
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = acc_row(r, h);
-                F[r] = (live && c < TVR_APPDIM) ? a.feats[ent * TVR_APPDIM + c] : 0.0f;
-            }
-            if (live) { dir[0] = a.viewdirs[ent * 3]; dir[1] = a.viewdirs[ent * 3 + 1]; dir[2] = a.viewdirs[ent * 3 + 2]; }
-        }
-
-        if (DST == SH_DST_FEAT) {
-            if (live) {
+            for (int cb = 0; cb < SH_NCB; ++cb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c = acc_row(r, h);
-                    if (c < TVR_APPDIM) a.out[ent * TVR_APPDIM + c] = F[r];
+                    F[cb][r] = (live[cb] && c < TVR_APPDIM) ? a.feats[ent[cb] * TVR_APPDIM + c] : 0.0f;
+                }
+                if (live[cb]) {
+                    dir[cb][0] = a.viewdirs[ent[cb] * 3]; dir[cb][1] = a.viewdirs[ent[cb] * 3 + 1]; dir[cb][2] = a.viewdirs[ent[cb] * 3 + 2];
                 }
             }
+        }
+
+        if (DST == SH_DST_FEAT) {
+#pragma unroll
+            for (int cb = 0; cb < SH_NCB; ++cb)
+                if (live[cb]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = acc_row(r, h);
+                        if (c < TVR_APPDIM) a.out[ent[cb] * TVR_APPDIM + c] = F[cb][r];
+                    }
+                }
             continue;
         }
 
         // view direction occupies base rows 27 (h=0, r=15), 28, 29 (h=1, r=12, 13); rows 30, 31 stay zero (zero weights)
-        if (h == 0) F[15] = dir[0];
-        else { F[12] = dir[1]; F[13] = dir[2]; F[14] = 0.f; F[15] = 0.f; }
+#pragma unroll
+        for (int cb = 0; cb < SH_NCB; ++cb) {
+            if (h == 0) F[cb][15] = dir[cb][0];
+            else { F[cb][12] = dir[cb][1]; F[cb][13] = dir[cb][2]; F[cb][14] = 0.f; F[cb][15] = 0.f; }
+        }
 
         // ---- layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5 ----
         const unsigned char *W1H = smem + TVR_IMG_W1H, *W1L = smem + TVR_IMG_W1L;
         const unsigned char *W2H = smem + TVR_IMG_W2H, *W2L = smem + TVR_IMG_W2L;
-        f32x16 acc[4];
+        f32x16 acc[SH_NCB][4];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bv = *(const float4 *)(smem + TVR_IMG_B1 + (32 * rb + 8 * q + 4 * h) * 4);
-                acc[rb][4 * q] = bv.x; acc[rb][4 * q + 1] = bv.y; acc[rb][4 * q + 2] = bv.z; acc[rb][4 * q + 3] = bv.w;
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) {
+                    acc[cb][rb][4 * q] = bv.x; acc[cb][rb][4 * q + 1] = bv.y; acc[cb][rb][4 * q + 2] = bv.z; acc[cb][rb][4 * q + 3] = bv.w;
+                }
             }
         {
-            float S1[16], C1[16];
+            float S1[SH_NCB][16], C1[SH_NCB][16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sincos_fast(F[r], S1[r], C1[r]);
+            for (int cb = 0; cb < SH_NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sincos_fast(F[cb][r], S1[cb][r], C1[cb][r]);
             const int rowoff = e * TVR_IMG_W1_ROW + h * 16;
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
-                float v[8];
+                Frag b[SH_NCB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = 8 * s + j, r = i / 5, t = i % 5;
-                    v[j] = t == 0 ? F[r] : (t == 1 ? S1[r] : (t == 2 ? 2.0f * S1[r] * C1[r]                 // sin 2v
-                                  : (t == 3 ? C1[r] : __builtin_fmaf(-2.0f * S1[r], S1[r], 1.0f))));      // cos 2v
+                for (int cb = 0; cb < SH_NCB; ++cb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 8 * s + j, r = i / 5, t = i % 5;
+                        v[j] = t == 0 ? F[cb][r] : (t == 1 ? S1[cb][r] : (t == 2 ? 2.0f * S1[cb][r] * C1[cb][r]                 // sin 2v
+                                      : (t == 3 ? C1[cb][r] : __builtin_fmaf(-2.0f * S1[cb][r], S1[cb][r], 1.0f))));          // cos 2v
+                    }
+                    b[cb] = split8(v);
                 }
-                const Frag b = split8(v);
                 mfma3x4(W1H, W1L, rowoff + s * 32, 32 * TVR_IMG_W1_ROW, b, acc);
                 TVR_SB;
             }
         }
         // ---- layer 2: B fragments are the relu'd layer-1 accumulators, 8 registers per k-step ----
-        f32x16 acc2[4];
+        f32x16 acc2[SH_NCB][4];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * rb + 8 * q + 4 * h) * 4);
-                acc2[rb][4 * q] = bv.x; acc2[rb][4 * q + 1] = bv.y; acc2[rb][4 * q + 2] = bv.z; acc2[rb][4 * q + 3] = bv.w;
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) {
+                    acc2[cb][rb][4 * q] = bv.x; acc2[cb][rb][4 * q + 1] = bv.y; acc2[cb][rb][4 * q + 2] = bv.z; acc2[cb][rb][4 * q + 3] = bv.w;
+                }
             }
         {
             const int rowoff = e * TVR_IMG_W2_ROW + h * 16;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                float v[8];
+                Frag b[SH_NCB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[s >> 1][8 * (s & 1) + j], 0.0f);
-                const Frag b = split8(v);
+                for (int cb = 0; cb < SH_NCB; ++cb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[cb][s >> 1][8 * (s & 1) + j], 0.0f);
+                    b[cb] = split8(v);
+                }
                 mfma3x4(W2H, W2L, rowoff + s * 32, 32 * TVR_IMG_W2_ROW, b, acc2);
                 TVR_SB;
             }
         }
-        // ---- layer 3: rows 0..2 of W3 (fragments streamed from L1-cached global), bias b3 as the initial accumulator ----
-        Acc3 acc3;
-        acc3.a = f32x16{0}; acc3.b = f32x16{0}; acc3.c = f32x16{0};
+        // ---- layer 3: rows 0..2 of W3 (+ a shared zero row) from LDS, bias b3 as the initial accumulator ----
+        f32x16 acc3[SH_NCB];
         {
             const float b30 = sc.b3[0], b31 = sc.b3[1], b32 = sc.b3[2];
-            acc3.a[0] = h == 0 ? b30 : 0.0f; acc3.a[1] = h == 0 ? b31 : 0.0f; acc3.a[2] = h == 0 ? b32 : 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < SH_NCB; ++cb) {
+                acc3[cb] = f32x16{0};
+                acc3[cb][0] = h == 0 ? b30 : 0.0f; acc3[cb][1] = h == 0 ? b31 : 0.0f; acc3[cb][2] = h == 0 ? b32 : 0.0f;
+            }
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[s >> 1][8 * (s & 1) + j], 0.0f);
-            const Frag b = split8(v);
             // rows >= 3 of W3 are zero: every such lane reads the shared zero row (address select)
             const uint4 *ap = (const uint4 *)(smem + TVR_IMG_W3 + (e < 3 ? e : 3) * TVR_IMG_W3_ROW + (s * 2 + h) * 32);
             const uint4 a3h = ap[0], a3l = ap[1];
-            mfma3(a3h, a3l, b, acc3);
+            Frag b3f[SH_NCB];
+#pragma unroll
+            for (int cb = 0; cb < SH_NCB; ++cb) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[cb][s >> 1][8 * (s & 1) + j], 0.0f);
+                b3f[cb] = split8(v);
+            }
+            mfma3cb(a3h, a3l, b3f, acc3);
             TVR_SB;
         }
-        if (live && h == 0) {
-            const float r0 = sigmoid_f((acc3.a[0] + acc3.b[0]) + acc3.c[0]), r1 = sigmoid_f((acc3.a[1] + acc3.b[1]) + acc3.c[1]),
-                        r2 = sigmoid_f((acc3.a[2] + acc3.b[2]) + acc3.c[2]);
-            if (DST == SH_DST_QUEUE) {
-                a.q_out[ent] = make_float4(r0, r1, r2, wq);
-            } else {
-                a.out[ent * 3] = r0; a.out[ent * 3 + 1] = r1; a.out[ent * 3 + 2] = r2;
+#pragma unroll
+        for (int cb = 0; cb < SH_NCB; ++cb)
+            if (live[cb] && h == 0) {
+                const float r0 = sigmoid_f(acc3[cb][0]), r1 = sigmoid_f(acc3[cb][1]), r2 = sigmoid_f(acc3[cb][2]);
+                if (DST == SH_DST_QUEUE) {
+                    a.q_out[ent[cb]] = make_float4(r0, r1, r2, wq[cb]);
+                } else {
+                    a.out[ent[cb] * 3] = r0; a.out[ent[cb] * 3 + 1] = r1; a.out[ent[cb] * 3 + 2] = r2;
+                }
             }
-        }
     }
     if (a.stats && SRC == SH_SRC_QUEUE && blockIdx.x == 0 && tid == 0)
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
@@ -401,9 +468,9 @@ static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStre
 {
     const int lds = (DST == SH_DST_FEAT) ? 0 : TVR_MLP_IMAGE_BYTES;
     (void)hipFuncSetAttribute((const void *)shade_kernel<SRC, DST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    unsigned grid = 256;       // one 8-wave workgroup per CU (LDS holds the MLP weights), persistent over 32-entry tiles
+    unsigned grid = 256;       // one 8-wave workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
     if (SRC != SH_SRC_QUEUE) {
-        const long long groups = (a.n + 32 * SH_WAVES - 1) / (32 * SH_WAVES);
+        const long long groups = (a.n + SH_TILE * SH_WAVES - 1) / (SH_TILE * SH_WAVES);
         if (groups < grid) grid = (unsigned)(groups > 0 ? groups : 1);
     }
     hipLaunchKernelGGL((shade_kernel<SRC, DST>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
