@@ -115,12 +115,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()              # (rehearsals may put several ranks on one card)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)          # "nccl" IS RCCL on ROCm
+        backend = os.environ.get("TVR_BENCH_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm; "gloo" only for 1-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from jittor_myc_nerfs_amd import _lib as L, shard_capacity, shard_indices
     import ctypes as C
@@ -153,7 +158,12 @@ def main():
         if world > 1:
             mine[:n_mine, :3] = rgb
             mine[:n_mine, 3] = depth
-            dist.all_gather_into_tensor(gathered, mine)
+            if dist.get_backend() == "gloo":                        # rehearsal path only
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                gathered.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(gathered, mine)
             for r in range(world):                                  # undo the tile interleave: index permutation only
                 out_img.index_copy_(0, all_idx[r], gathered[r * cap:r * cap + all_idx[r].numel()])
             return out_img

@@ -24,7 +24,11 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef TVR_NOSB
+#define TVR_SB
+#else
 #define TVR_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef TVR_PF
 #define TVR_PF 2          // gather prefetch distance in k-steps (ring of TVR_PF + 1 tap sets)
 #endif
@@ -293,9 +297,25 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     load_taps<TVR_CHK>(T[s0][cb], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[cb][ax], fc[cb][bx],
                                        fc[cb][vx], 4 * (s0 % 3) + 2 * h);
             }
+            // software pipeline: the VALU work that builds k-step s+1's B fragment sits in the same scheduling region as
+            // k-step s's MFMAs (independent), so one wave keeps its SIMD's vector and matrix pipes busy together
+            auto gather_frag = [&](int s, Frag bf[SH_NCB]) {
+                const int p = s / 3;
+                const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) {
+                    float hv[8];
+                    taps_eval<TVR_CHK>(T[s % (TVR_PF + 1)][cb], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[cb][ax], fc[cb][bx], fc[cb][vx], hv);
+                    bf[cb] = split8(hv);
+                }
+            };
+            Frag bcur[SH_NCB], bnxt[SH_NCB];
+            gather_frag(0, bcur);
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
-                if (s + TVR_PF < 9) {
+                const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
+                const uint4 bah = ap[0], bal = ap[1];
+                if (s + 1 + TVR_PF - 1 < 9 && TVR_PF >= 1) {       // taps of k-step s+TVR_PF (its ring slot was consumed by gather_frag(s))
                     const int s2 = s + TVR_PF, p = s2 / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
 #pragma unroll
@@ -303,18 +323,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)][cb], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx],
                                            fc[cb][ax], fc[cb][bx], fc[cb][vx], 4 * (s2 % 3) + 2 * h);
                 }
-                const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
-                const uint4 bah = ap[0], bal = ap[1];
-                const int p = s / 3;
-                const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
-                Frag bf[SH_NCB];
+                if (s + 1 < 9) gather_frag(s + 1, bnxt);
+                mfma3cb(bah, bal, bcur, accF);
 #pragma unroll
-                for (int cb = 0; cb < SH_NCB; ++cb) {
-                    float hv[8];
-                    taps_eval<TVR_CHK>(T[s % (TVR_PF + 1)][cb], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[cb][ax], fc[cb][bx], fc[cb][vx], hv);
-                    bf[cb] = split8(hv);
-                }
-                mfma3cb(bah, bal, bf, accF);
+                for (int cb = 0; cb < SH_NCB; ++cb) bcur[cb] = bnxt[cb];
                 TVR_SB;
             }
 #pragma unroll
@@ -376,9 +388,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sincos_fast(F[cb][r], S1[cb][r], C1[cb][r]);
             const int rowoff = e * TVR_IMG_W1_ROW + h * 16;
-#pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                Frag b[SH_NCB];
+            auto l1_frag = [&](int s, Frag b[SH_NCB]) {
 #pragma unroll
                 for (int cb = 0; cb < SH_NCB; ++cb) {
                     float v[8];
@@ -390,7 +400,15 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     }
                     b[cb] = split8(v);
                 }
-                mfma3x4(W1H, W1L, rowoff + s * 32, 32 * TVR_IMG_W1_ROW, b, acc);
+            };
+            Frag bcur[SH_NCB], bnxt[SH_NCB];
+            l1_frag(0, bcur);
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                if (s + 1 < 10) l1_frag(s + 1, bnxt);
+                mfma3x4(W1H, W1L, rowoff + s * 32, 32 * TVR_IMG_W1_ROW, bcur, acc);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) bcur[cb] = bnxt[cb];
                 TVR_SB;
             }
         }
@@ -408,17 +426,23 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             }
         {
             const int rowoff = e * TVR_IMG_W2_ROW + h * 16;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                Frag b[SH_NCB];
+            auto relu_frag = [&](f32x16 (&src)[SH_NCB][4], int s, Frag b[SH_NCB]) {
 #pragma unroll
                 for (int cb = 0; cb < SH_NCB; ++cb) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[cb][s >> 1][8 * (s & 1) + j], 0.0f);
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(src[cb][s >> 1][8 * (s & 1) + j], 0.0f);
                     b[cb] = split8(v);
                 }
-                mfma3x4(W2H, W2L, rowoff + s * 32, 32 * TVR_IMG_W2_ROW, b, acc2);
+            };
+            Frag bcur[SH_NCB], bnxt[SH_NCB];
+            relu_frag(acc, 0, bcur);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8) relu_frag(acc, s + 1, bnxt);
+                mfma3x4(W2H, W2L, rowoff + s * 32, 32 * TVR_IMG_W2_ROW, bcur, acc2);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) bcur[cb] = bnxt[cb];
                 TVR_SB;
             }
         }
