@@ -309,6 +309,77 @@ class TensorBase(torch.nn.Module):
         length = float(length) if not torch.is_tensor(length) else length.to(self.device)
         return (1 - torch.exp(-sigma * length)).view(xyz_locs.shape[:-1])
 
+    # ---- scene-maintenance ops that feed the render path: host-side torch over the HIP lookups ----------
+    def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1):                        # :340-360 (host form for filtering_rays)
+        N_samples = N_samples if N_samples > 0 else self.nSamples
+        near, far = self.near_far
+        aabb = self.aabb.to(rays_o.device)
+        vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+        rate_a = (aabb[1] - rays_o) / vec
+        rate_b = (aabb[0] - rays_o) / vec
+        t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
+        rng = torch.arange(N_samples, device=rays_o.device)[None].float()
+        if is_train:
+            rng = rng.repeat(rays_d.shape[-2], 1)
+            rng = rng + torch.rand_like(rng[:, [0]])
+        step = self.stepSize.to(rays_o.device) * rng
+        interpx = t_min[..., None] + step
+        rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+        mask_outbbox = ((aabb[0] > rays_pts) | (rays_pts > aabb[1])).any(dim=-1)
+        return rays_pts, interpx, ~mask_outbbox
+
+    @torch.no_grad()
+    def getDenseAlpha(self, gridSize=None):                                                   # :366-383
+        gridSize = self.gridSize if gridSize is None else gridSize
+        gridSize = [int(g) for g in gridSize]
+        dev = self.device
+        samples = torch.stack(torch.meshgrid(torch.linspace(0, 1, gridSize[0], device=dev), torch.linspace(0, 1, gridSize[1], device=dev),
+                                             torch.linspace(0, 1, gridSize[2], device=dev), indexing="ij"), -1)
+        aabb = self.aabb.to(dev)
+        dense_xyz = aabb[0] * (1 - samples) + aabb[1] * samples
+        alpha = torch.zeros_like(dense_xyz[..., 0])
+        step = float(self.stepSize)
+        for i in range(gridSize[0]):
+            alpha[i] = self.compute_alpha(dense_xyz[i].view(-1, 3), step).view((gridSize[1], gridSize[2]))
+        return alpha, dense_xyz
+
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=(200, 200, 200)):                                      # :385-409
+        gridSize = [int(g) for g in gridSize]
+        alpha, dense_xyz = self.getDenseAlpha(gridSize)
+        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
+        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        ks = 3
+        alpha = torch.nn.functional.max_pool3d(alpha, kernel_size=ks, padding=ks // 2, stride=1).view(gridSize[::-1])
+        alpha = (alpha >= self.alphaMask_thres).float()                                       # :395-396
+        self.alphaMask = AlphaGridMask(self.device, self.aabb, alpha)
+        valid_xyz = dense_xyz[alpha > 0.5]
+        new_aabb = torch.stack((valid_xyz.amin(0), valid_xyz.amax(0)))
+        return new_aabb
+
+    @torch.no_grad()
+    def filtering_rays(self, all_rays, all_rgbs, N_samples=256, chunk=10240 * 5, bbox_only=False):   # :411-441
+        N = int(np.prod(all_rays.shape[:-1]))
+        flat = all_rays.reshape(N, all_rays.shape[-1])
+        aabb = self.aabb.to(self.device)
+        masks = []
+        for idx_chunk in torch.split(torch.arange(N), chunk):
+            rays_chunk = flat[idx_chunk].to(self.device)
+            rays_o, rays_d = rays_chunk[..., :3], rays_chunk[..., 3:6]
+            if bbox_only:
+                vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+                rate_a = (aabb[1] - rays_o) / vec
+                rate_b = (aabb[0] - rays_o) / vec
+                t_min = torch.minimum(rate_a, rate_b).amax(-1)
+                t_max = torch.maximum(rate_a, rate_b).amin(-1)
+                mask_inbbox = t_max > t_min
+            else:
+                xyz_sampled, _, _ = self.sample_ray(rays_o, rays_d, N_samples=N_samples, is_train=False)
+                mask_inbbox = (self.alphaMask.sample_alpha(xyz_sampled).view(xyz_sampled.shape[:-1]) > 0).any(-1)
+            masks.append(mask_inbbox.cpu())
+        mask_filtered = torch.cat(masks).view(all_rgbs.shape[:-1])
+        return all_rays[mask_filtered], all_rgbs[mask_filtered]
+
     def render_rays(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None, eps_T=None, dense=False,
                     stats: Optional[torch.Tensor] = None, profile=None):
         """One tvr_render call.  Returns (rgb_map [N,3], depth_map [N]) or, with dense=True, additionally a dict
@@ -396,6 +467,50 @@ class TensorVMSplit(TensorBase):
                      {'params': self.basis_mat.parameters(), 'lr': lr_init_network}]
         grad_vars += [{'params': self.renderModule.parameters(), 'lr': lr_init_network}]
         return grad_vars
+
+    @torch.no_grad()
+    def up_sampling_VM(self, plane_coef, line_coef, res_target):                              # tensoRF.py:249-263
+        F = torch.nn.functional
+        for i in range(len(self.vecMode)):
+            vec_id = self.vecMode[i]
+            mat_id_0, mat_id_1 = self.matMode[i]
+            plane_coef[i] = torch.nn.Parameter(F.interpolate(plane_coef[i].data, size=(int(res_target[mat_id_1]), int(res_target[mat_id_0])),
+                                                             mode='bilinear', align_corners=True))
+            line_coef[i] = torch.nn.Parameter(F.interpolate(line_coef[i].data, size=(int(res_target[vec_id]), 1), mode='bilinear',
+                                                            align_corners=True))
+        return plane_coef, line_coef
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):                                               # tensoRF.py:265-271
+        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane, self.density_line, res_target)
+        self.update_stepSize(res_target)
+
+    @torch.no_grad()
+    def shrink(self, new_aabb):                                                               # tensoRF.py:273-314
+        new_aabb = torch.as_tensor(new_aabb, dtype=torch.float32).cpu()
+        xyz_min, xyz_max = new_aabb
+        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize.long()]).amin(0)
+        for i in range(len(self.vecMode)):
+            mode0 = self.vecMode[i]
+            self.density_line[i] = torch.nn.Parameter(self.density_line[i].data[..., int(t_l[mode0]):int(b_r[mode0]), :].contiguous())
+            self.app_line[i] = torch.nn.Parameter(self.app_line[i].data[..., int(t_l[mode0]):int(b_r[mode0]), :].contiguous())
+            mode0, mode1 = self.matMode[i]
+            self.density_plane[i] = torch.nn.Parameter(
+                self.density_plane[i].data[..., int(t_l[mode1]):int(b_r[mode1]), int(t_l[mode0]):int(b_r[mode0])].contiguous())
+            self.app_plane[i] = torch.nn.Parameter(
+                self.app_plane[i].data[..., int(t_l[mode1]):int(b_r[mode1]), int(t_l[mode0]):int(b_r[mode0])].contiguous())
+        if not torch.all(self.alphaMask.gridSize == self.gridSize):
+            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
+            correct_aabb = torch.zeros_like(new_aabb)
+            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct_aabb
+        newSize = b_r - t_l
+        self.aabb = new_aabb
+        self.update_stepSize((int(newSize[0]), int(newSize[1]), int(newSize[2])))
 
     def load_arrays(self, arrs):
         """Copy a flat array dict (synthetic.make_scene_arrays / oracle layout) into the parameters."""

@@ -204,3 +204,68 @@ def test_full_size_properties_config2():
     m._drop_scene()
     rgb_e, depth_e = m.render_rays(rays, white_bg=True, N_samples=A["N_samples"])
     assert bool((rgb_e == 1.0).all()) and torch.equal(depth_e, rays[:, 5])
+
+
+def test_scene_maintenance_ops(tiny_arrays, hyper_tiny, tiny_dump):
+    """getDenseAlpha / updateAlphaMask / filtering_rays / upsample_volume_grid / shrink feed the render path."""
+    from oracle import c_oracle as CO, tensorf_oracle as TO
+    m = make_model(tiny_arrays, hyper_tiny)
+    sc = TO.scene_from_arrays(tiny_arrays, **hyper_tiny)
+    g = [9, 8, 7]
+    alpha, dense = m.getDenseAlpha(g)
+    ref_alpha, ref_dense = TO.getDenseAlpha(sc, g)
+    assert alpha.shape == (9, 8, 7) and np.array_equal(_np(dense), ref_dense.numpy())
+    assert np.abs(_np(alpha) - ref_alpha.numpy()).max() < 1e-5
+    new_aabb = m.updateAlphaMask(g)
+    ref_vol, ref_aabb = TO.updateAlphaMask(sc, g, m.alphaMask_thres)
+    assert tuple(m.alphaMask.alpha_volume.shape) == (1, 1, 7, 8, 9)
+    assert (_np(m.alphaMask.alpha_volume).reshape(7, 8, 9) != ref_vol.numpy()).sum() <= 1        # threshold at 1e-4: <= 1 borderline cell
+    assert np.allclose(_np(new_aabb), ref_aabb.numpy(), atol=1e-6)
+    # rendering with the freshly built mask == oracle rendering with the same mask
+    arrs = dict(tiny_arrays, alpha_volume=_np(m.alphaMask.alpha_volume).reshape(7, 8, 9), alpha_aabb=tiny_arrays["aabb"])
+    sca = TO.scene_from_arrays(arrs, **hyper_tiny)
+    ref = CO.COracle(arrs, step=float(sca.stepSize), **hyper_tiny).render(tiny_dump["rays"], TINY["N_samples"], white_bg=True)
+    rays = torch.tensor(tiny_dump["rays"], device="cuda")
+    rgb, depth = m(rays, N_samples=TINY["N_samples"])
+    assert np.abs(_np(rgb) - ref["rgb_map"]).max() < RGB_TIGHT
+    # filtering_rays: bbox-only and alpha-mask variants keep exactly the rays the host formulas say
+    rr = torch.tensor(np.concatenate([tiny_dump["rays"], [[5, 5, 5, 0, 0, 1]]]).astype(np.float32))
+    kept, kept_rgb = m.filtering_rays(rr, torch.zeros(rr.shape[0], 3), bbox_only=True)
+    o, d = rr[:, :3].numpy(), rr[:, 3:6].numpy()
+    v = np.where(d == 0, np.float32(1e-6), d)
+    ra, rb = (tiny_arrays["aabb"][1] - o) / v, (tiny_arrays["aabb"][0] - o) / v
+    hit = np.maximum(ra, rb).min(1) > np.minimum(ra, rb).max(1)                # tensorBase.py:428-430
+    assert kept.shape[0] == int(hit.sum()) < rr.shape[0] and not hit[-1]      # the appended ray misses the box
+    kept2, _ = m.filtering_rays(rr, torch.zeros(rr.shape[0], 3), N_samples=48)
+    xyz, _, _ = m.sample_ray(rr[:, :3].cuda(), rr[:, 3:6].cuda(), is_train=False, N_samples=48)
+    expect = (torch.tensor(CO.COracle(arrs, step=float(sca.stepSize), **hyper_tiny).alpha_samples(_np(xyz).reshape(-1, 3))).view(rr.shape[0], 48) > 0).any(1)
+    assert kept2.shape[0] == int(expect.sum())
+    # upsample_volume_grid (bilinear, align_corners) then render == oracle on the same upsampled factors
+    m2 = make_model(tiny_arrays, hyper_tiny)
+    m2.upsample_volume_grid([20, 24, 28])
+    assert tuple(m2.density_plane[0].shape) == (1, 16, 24, 20) and tuple(m2.app_line[0].shape) == (1, 48, 28, 1)
+    up = dict(tiny_arrays, gridSize=np.array([20, 24, 28]))
+    for i in range(3):
+        for k in ("density_plane", "density_line", "app_plane", "app_line"):
+            up[f"{k}.{i}"] = _np(getattr(m2, k)[i])
+    scu = TO.scene_from_arrays(up, **hyper_tiny)
+    assert abs(float(scu.stepSize) - float(m2.stepSize)) == 0 and scu.nSamples == m2.nSamples
+    refu = CO.COracle(up, step=float(scu.stepSize), **hyper_tiny).render(tiny_dump["rays"], TINY["N_samples"], white_bg=True)
+    rgbu, _ = m2(rays, N_samples=TINY["N_samples"])
+    assert np.abs(_np(rgbu) - refu["rgb_map"]).max() < RGB_TIGHT
+    # shrink to the mask's box: parameter slices + new aabb / step size, still renders against the oracle
+    m3 = make_model(tiny_arrays, hyper_tiny)
+    na = m3.updateAlphaMask([16, 20, 24])
+    m3.shrink(na)
+    sh = {"aabb": m3.aabb.numpy(), "gridSize": m3.gridSize.numpy()}
+    for i in range(3):
+        for k in ("density_plane", "density_line", "app_plane", "app_line"):
+            sh[f"{k}.{i}"] = _np(getattr(m3, k)[i])
+    for k in ("basis_mat", "W1", "b1", "W2", "b2", "W3", "b3"):
+        sh[k] = tiny_arrays[k]
+    sh["alpha_volume"] = _np(m3.alphaMask.alpha_volume).reshape(24, 20, 16)
+    sh["alpha_aabb"] = m3.alphaMask.aabb.numpy()
+    scs = TO.scene_from_arrays(sh, **hyper_tiny)
+    refs = CO.COracle(sh, step=float(scs.stepSize), **hyper_tiny).render(tiny_dump["rays"], TINY["N_samples"], white_bg=True)
+    rgbs, _ = m3(rays, N_samples=TINY["N_samples"])
+    assert np.abs(_np(rgbs) - refs["rgb_map"]).max() < RGB_TIGHT
