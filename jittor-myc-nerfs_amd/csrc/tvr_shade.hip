@@ -30,17 +30,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TVR_SB __builtin_amdgcn_sched_barrier(0)
 #endif
 #ifndef TVR_PF
-#define TVR_PF 2          // gather prefetch distance in k-steps (ring of TVR_PF + 1 tap sets)
+#define TVR_PF 1          // gather prefetch distance in k-steps (ring of TVR_PF + 1 tap sets); 2 spills at 256 VGPRs
 #endif
 #define TVR_CHK (SRC != SH_SRC_QUEUE)
-// ONE wave per SIMD (4 waves per workgroup, one workgroup per CU).  Measured on gfx950 / ROCm 7.2: with two MFMA-issuing
-// waves per SIMD an MFMA can sit queued behind the partner wave's MFMAs and read its A/B VGPRs late; a global load issued
-// behind it into those registers (the register allocator reuses them) then lands first and corrupts the operands one
-// 16-lane quarter at a time (16 queue entries wrong by ~1e-2, different ones each run).  With one wave per SIMD an MFMA
-// starts when it issues and the kernel is bit-reproducible (tests/test_gpu_parity.py::test_run_to_run_determinism).
-#define SH_THREADS 256
-#define SH_WAVES 4
-#define SH_MINW 1
+// gfx950 / ROCm 7.2 hazard (measured): with two MFMA-issuing waves per SIMD an MFMA can sit queued behind
+// the partner wave's MFMAs and read its A/B VGPRs late; a *global* load issued behind it into those registers (the register
+// allocator reuses them) lands first and corrupts the operands one 16-lane quarter at a time (16 queue entries wrong by ~1e-2,
+// different ones each run).  LDS loads that reuse MFMA source registers showed no such effect.  The kernel is therefore phased
+// per tile: a GATHER phase (global loads + VALU, no MFMA) and a MATRIX phase (MFMA + LDS + VALU, no global load: the basis
+// fragments are fetched before its first MFMA), and the epilogue's read of the last accumulator drains the wave's MFMAs before
+// the next tile's loads.  SH_WAVES = 8 gives two waves per SIMD (one gathers while the other multiplies).
+#ifndef SH_WAVES
+#define SH_WAVES 8
+#endif
+#define SH_THREADS (64 * SH_WAVES)
+#define SH_MINW (SH_WAVES / 4)
 #ifndef SH_NCB
 #define SH_NCB 1            // column blocks (32 entries each) a wave processes together (2 measured no faster: 20.4 vs 20.1 ms)
 #endif
@@ -284,10 +288,9 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 for (int k = 0; k < 3; ++k) fc[cb][k] = unnorm(pn[k], sc.gm1[k]);
             }
             // ---- gather + basis: 9 k-steps of 16 channels (plane p = s/3, channels 16(s%3) + 8h .. +7 of this lane) ----
-            f32x16 accF[SH_NCB];
-#pragma unroll
-            for (int cb = 0; cb < SH_NCB; ++cb) accF[cb] = f32x16{0};
+            // GATHER phase: global loads + VALU only.  The 9 k-steps' B fragments (plane*line products, fp16 hi/lo) stay in registers.
             Taps T[TVR_PF + 1][SH_NCB];                            // ring: taps of k-steps s .. s+TVR_PF in flight
+            Frag hf[9][SH_NCB];
 #pragma unroll
             for (int s0 = 0; s0 < TVR_PF; ++s0) {
                 const int p = s0 / 3;
@@ -297,25 +300,9 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     load_taps<TVR_CHK>(T[s0][cb], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[cb][ax], fc[cb][bx],
                                        fc[cb][vx], 4 * (s0 % 3) + 2 * h);
             }
-            // software pipeline: the VALU work that builds k-step s+1's B fragment sits in the same scheduling region as
-            // k-step s's MFMAs (independent), so one wave keeps its SIMD's vector and matrix pipes busy together
-            auto gather_frag = [&](int s, Frag bf[SH_NCB]) {
-                const int p = s / 3;
-                const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
-#pragma unroll
-                for (int cb = 0; cb < SH_NCB; ++cb) {
-                    float hv[8];
-                    taps_eval<TVR_CHK>(T[s % (TVR_PF + 1)][cb], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[cb][ax], fc[cb][bx], fc[cb][vx], hv);
-                    bf[cb] = split8(hv);
-                }
-            };
-            Frag bcur[SH_NCB], bnxt[SH_NCB];
-            gather_frag(0, bcur);
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
-                const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
-                const uint4 bah = ap[0], bal = ap[1];
-                if (s + 1 + TVR_PF - 1 < 9 && TVR_PF >= 1) {       // taps of k-step s+TVR_PF (its ring slot was consumed by gather_frag(s))
+                if (s + TVR_PF < 9) {
                     const int s2 = s + TVR_PF, p = s2 / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
 #pragma unroll
@@ -323,16 +310,43 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)][cb], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx],
                                            fc[cb][ax], fc[cb][bx], fc[cb][vx], 4 * (s2 % 3) + 2 * h);
                 }
-                if (s + 1 < 9) gather_frag(s + 1, bnxt);
-                mfma3cb(bah, bal, bcur, accF);
+                const int p = s / 3;
+                const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
 #pragma unroll
-                for (int cb = 0; cb < SH_NCB; ++cb) bcur[cb] = bnxt[cb];
+                for (int cb = 0; cb < SH_NCB; ++cb) {
+                    float hv[8];
+                    taps_eval<TVR_CHK>(T[s % (TVR_PF + 1)][cb], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[cb][ax], fc[cb][bx], fc[cb][vx], hv);
+                    hf[s][cb] = split8(hv);
+                }
                 TVR_SB;
+            }
+            // MATRIX phase starts: the basis A fragments are the last global loads of this tile, fetched before its first MFMA
+            uint4 bah[9], bal[9];
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
+                bah[s] = ap[0];
+                bal[s] = ap[1];
+            }
+            TVR_SB;
+            // three independent accumulation chains (hi*lo products) summed at the end: no MFMA directly follows its producer
+            f32x16 accA[SH_NCB], accB[SH_NCB], accC[SH_NCB];
+#pragma unroll
+            for (int cb = 0; cb < SH_NCB; ++cb) { accA[cb] = f32x16{0}; accB[cb] = f32x16{0}; accC[cb] = f32x16{0}; }
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const h8 Ah = __builtin_bit_cast(h8, bah[s]), Al = __builtin_bit_cast(h8, bal[s]);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) accA[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s][cb].hi), accA[cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) accB[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s][cb].lo), accB[cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) accC[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s][cb].hi), accC[cb], 0, 0, 0);
             }
 #pragma unroll
             for (int cb = 0; cb < SH_NCB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) F[cb][r] = accF[cb][r];
+                for (int r = 0; r < 16; ++r) F[cb][r] = (accA[cb][r] + accB[cb][r]) + accC[cb][r];
         } else {
 #pragma unroll
             for (int cb = 0; cb < SH_NCB; ++cb) {
@@ -473,15 +487,18 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             TVR_SB;
         }
 #pragma unroll
-        for (int cb = 0; cb < SH_NCB; ++cb)
+        for (int cb = 0; cb < SH_NCB; ++cb) {
+            // every lane reads the last accumulator (drains this wave's MFMAs before the next tile's global loads)
+            const float r0 = sigmoid_f(acc3[cb][0]), r1 = sigmoid_f(acc3[cb][1]), r2 = sigmoid_f(acc3[cb][2]);
             if (live[cb] && h == 0) {
-                const float r0 = sigmoid_f(acc3[cb][0]), r1 = sigmoid_f(acc3[cb][1]), r2 = sigmoid_f(acc3[cb][2]);
                 if (DST == SH_DST_QUEUE) {
                     a.q_out[ent[cb]] = make_float4(r0, r1, r2, wq[cb]);
                 } else {
                     a.out[ent[cb] * 3] = r0; a.out[ent[cb] * 3 + 1] = r1; a.out[ent[cb] * 3 + 2] = r2;
                 }
             }
+        }
+        TVR_SB;
     }
     if (a.stats && SRC == SH_SRC_QUEUE && blockIdx.x == 0 && tid == 0)
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
@@ -492,7 +509,7 @@ static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStre
 {
     const int lds = (DST == SH_DST_FEAT) ? 0 : TVR_MLP_IMAGE_BYTES;
     (void)hipFuncSetAttribute((const void *)shade_kernel<SRC, DST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    unsigned grid = 256;       // one 8-wave workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
+    unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
     if (SRC != SH_SRC_QUEUE) {
         const long long groups = (a.n + SH_TILE * SH_WAVES - 1) / (SH_TILE * SH_WAVES);
         if (groups < grid) grid = (unsigned)(groups > 0 ? groups : 1);

@@ -14,7 +14,7 @@ mode = sys.argv[1]
 keep = []
 ref = None
 nbad = 0
-for rep in range(12):
+for rep in range(int(os.environ.get("REPS", "12"))):
     if mode == "fresh":
         keep.append(m._scratch); m._scratch = None          # never reuse scratch memory
     if mode == "sync":
@@ -26,4 +26,4 @@ for rep in range(12):
     else:
         bad = int((rgb != ref).any(1).sum()); nbad += bad > 0
         print(mode, "rep", rep, "rays differing", bad)
-print(mode, "runs differing from run 0:", nbad, "of 11")
+print(mode, "runs differing from run 0:", nbad, "of", int(os.environ.get("REPS", "12")) - 1)
