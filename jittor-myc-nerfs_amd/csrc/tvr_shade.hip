@@ -33,6 +33,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TVR_PF 1          // gather prefetch distance in k-steps (ring of TVR_PF + 1 tap sets); 2 spills at 256 VGPRs
 #endif
 #define TVR_CHK (SRC != SH_SRC_QUEUE)
+#ifndef TVR_COAL
+#define TVR_COAL 0        // 1: coalesced gather (4 lanes per 64-B segment + v_permlane16_swap): halves the L1 tag lookups of the
+#endif                    //    gather but measured slower (17.8 vs 16.1 ms) — the kernel is not L1-lookup-bound, the swaps cost VALU
 // gfx950 / ROCm 7.2 hazard (measured): with two MFMA-issuing waves per SIMD an MFMA can sit queued behind
 // the partner wave's MFMAs and read its A/B VGPRs late; a *global* load issued behind it into those registers (the register
 // allocator reuses them) lands first and corrupts the operands one 16-lane quarter at a time (16 queue entries wrong by ~1e-2,
@@ -214,6 +217,84 @@ __device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, fl
     }
 }
 
+// ---- coalesced gather (queue path) -------------------------------------------------------------------------------------
+// A lane (e, h) needs two float4 pieces (2h, 2h+1) of each tap's 64-B channel segment.  Loading them directly makes every
+// wave-level load touch 32 cache lines (two lanes per line).  Instead lane L loads piece (L >> 4) of the segment of entry
+// (L & 15) [X] and of entry 16 + (L & 15) [Y]: 4 lanes x 16 B cover one 64-B segment, 16 lines per load (half the L1 tag
+// lookups), and ONE v_permlane16_swap per dword (a' = [a0, b0, a2, b2], b' = [a1, b1, a3, b3] by 16-lane rows — probed on
+// gfx950, scripts/hwprobe/permlane.hip) hands every lane exactly its two pieces: X' = piece 2h, Y' = piece 2h + 1.
+struct TapOff { unsigned p1, p2, l1, l2; };      // float4-unit offsets of the (x0, y0) texel / l0 texel of entry c and entry 16 + c
+
+__device__ __forceinline__ TapOff tap_offsets(int W, float fx, float fy, float fl)
+{
+    const int x0 = (int)floorf(fx), y0 = (int)floorf(fy), l0 = (int)floorf(fl);
+    const unsigned op = (unsigned)((y0 * (W + 1) + x0) * 12), ol = (unsigned)(l0 * 12);
+    const auto sp = __builtin_amdgcn_permlane16_swap(op, op, false, false);
+    const auto sl = __builtin_amdgcn_permlane16_swap(ol, ol, false, false);
+    TapOff o;
+    o.p1 = sp[0]; o.p2 = sp[1]; o.l1 = sl[0]; o.l2 = sl[1];
+    return o;
+}
+
+struct TapsXY { float4 x[6], y[6]; };            // taps 0..3 plane (x0y0, x1y0, x0y1, x1y1), 4..5 line; X = entry c, Y = entry 16 + c
+
+__device__ __forceinline__ void load_taps_coal(TapsXY &T, const float4 *__restrict__ P, const float4 *__restrict__ Ln, int W, const TapOff &o,
+                                               int seg_row)                       // seg_row = 4 * (s % 3) + (lane >> 4)
+{
+    const size_t ys = (size_t)(W + 1) * 12;
+    const float4 *a1 = P + o.p1 + seg_row, *a2 = P + o.p2 + seg_row;
+    const float4 *b1 = Ln + o.l1 + seg_row, *b2 = Ln + o.l2 + seg_row;
+    T.x[0] = a1[0]; T.x[1] = a1[12]; T.x[2] = a1[ys]; T.x[3] = a1[ys + 12]; T.x[4] = b1[0]; T.x[5] = b1[12];
+    T.y[0] = a2[0]; T.y[1] = a2[12]; T.y[2] = a2[ys]; T.y[3] = a2[ys + 12]; T.y[4] = b2[0]; T.y[5] = b2[12];
+}
+
+__device__ __forceinline__ void swap_rows(float4 &x, float4 &y)
+{
+#define TVR_SWAP1(c)                                                                                                          \
+    {                                                                                                                         \
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x.c), __float_as_uint(y.c), false, false);             \
+        x.c = __uint_as_float(r[0]);                                                                                          \
+        y.c = __uint_as_float(r[1]);                                                                                          \
+    }
+    TVR_SWAP1(x) TVR_SWAP1(y) TVR_SWAP1(z) TVR_SWAP1(w)
+#undef TVR_SWAP1
+}
+
+// swap the rows into place, then bilinear(plane) * linear(line) for this lane's 8 channels
+__device__ __forceinline__ void taps_eval_coal(TapsXY &T, float fx, float fy, float fl, float out[8])
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i) swap_rows(T.x[i], T.y[i]);
+    const float x0f = floorf(fx), y0f = floorf(fy), l0f = floorf(fl);
+    const float wx = fx - x0f, wy = fy - y0f, wlf = fl - l0f;
+    const float ux = 1.0f - wx, uy = 1.0f - wy, ulf = 1.0f - wlf;
+    const float a00 = ux * uy, a01 = wx * uy, a10 = ux * wy, a11 = wx * wy;
+    const f32x2 w00 = {a00, a00}, w01 = {a01, a01}, w10 = {a10, a10}, w11 = {a11, a11};
+    const f32x2 ul = {ulf, ulf}, wl = {wlf, wlf};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float4 *t = g ? T.y : T.x;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x2 t0 = hh ? f32x2{t[0].z, t[0].w} : f32x2{t[0].x, t[0].y};
+            const f32x2 t1 = hh ? f32x2{t[1].z, t[1].w} : f32x2{t[1].x, t[1].y};
+            const f32x2 t2 = hh ? f32x2{t[2].z, t[2].w} : f32x2{t[2].x, t[2].y};
+            const f32x2 t3 = hh ? f32x2{t[3].z, t[3].w} : f32x2{t[3].x, t[3].y};
+            const f32x2 l0 = hh ? f32x2{t[4].z, t[4].w} : f32x2{t[4].x, t[4].y};
+            const f32x2 l1 = hh ? f32x2{t[5].z, t[5].w} : f32x2{t[5].x, t[5].y};
+            f32x2 p = w00 * t0;
+            p = pk_fma(w01, t1, p);
+            p = pk_fma(w10, t2, p);
+            p = pk_fma(w11, t3, p);
+            f32x2 q = ul * l0;
+            q = pk_fma(wl, l1, q);
+            const f32x2 r = p * q;
+            out[g * 4 + hh * 2] = r.x;
+            out[g * 4 + hh * 2 + 1] = r.y;
+        }
+    }
+}
+
 // accumulator register r of lane half h  <->  row of the 32x32 tile
 __device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -289,8 +370,36 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             }
             // ---- gather + basis: 9 k-steps of 16 channels (plane p = s/3, channels 16(s%3) + 8h .. +7 of this lane) ----
             // GATHER phase: global loads + VALU only.  The 9 k-steps' B fragments (plane*line products, fp16 hi/lo) stay in registers.
-            Taps T[TVR_PF + 1][SH_NCB];                            // ring: taps of k-steps s .. s+TVR_PF in flight
             Frag hf[9][SH_NCB];
+            if (TVR_COAL && SRC == SH_SRC_QUEUE && SH_NCB == 1) {
+                TapsXY T[TVR_PF + 1];
+                TapOff off[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
+                    off[p] = tap_offsets(sc.grid[ax], fc[0][ax], fc[0][bx], fc[0][vx]);
+                }
+                const int row = lane >> 4;
+#pragma unroll
+                for (int s0 = 0; s0 < TVR_PF; ++s0) {
+                    const int p = s0 / 3;
+                    load_taps_coal(T[s0], sc.aplane[p], sc.aline[p], sc.grid[(p == 2) ? 1 : 0], off[p], 4 * (s0 % 3) + row);
+                }
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    if (s + TVR_PF < 9) {
+                        const int s2 = s + TVR_PF, p = s2 / 3;
+                        load_taps_coal(T[s2 % (TVR_PF + 1)], sc.aplane[p], sc.aline[p], sc.grid[(p == 2) ? 1 : 0], off[p], 4 * (s2 % 3) + row);
+                    }
+                    const int p = s / 3;
+                    const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
+                    float hv[8];
+                    taps_eval_coal(T[s % (TVR_PF + 1)], fc[0][ax], fc[0][bx], fc[0][vx], hv);
+                    hf[s][0] = split8(hv);
+                    TVR_SB;
+                }
+            } else {
+            Taps T[TVR_PF + 1][SH_NCB];                            // ring: taps of k-steps s .. s+TVR_PF in flight
 #pragma unroll
             for (int s0 = 0; s0 < TVR_PF; ++s0) {
                 const int p = s0 / 3;
@@ -319,6 +428,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     hf[s][cb] = split8(hv);
                 }
                 TVR_SB;
+            }
             }
             // MATRIX phase starts: the basis A fragments are the last global loads of this tile, fetched before its first MFMA
             uint4 bah[9], bal[9];
