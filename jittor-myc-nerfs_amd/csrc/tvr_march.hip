@@ -21,6 +21,25 @@
 #define MARCH_THREADS 256
 #define MARCH_WAVES 4
 
+// quad-level data movement as DPP VALU ops (quad_perm) instead of ds_bpermute: no LDS hop in front of the gather addresses
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float quad_perm_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+// broadcast lane k of each quad (quad_perm:[k,k,k,k]); k is a constant after unrolling, the switch folds away
+__device__ __forceinline__ int quad_bcast_i(int v, int k)
+{
+    switch (k) {
+    case 0: return quad_perm_i<0x00>(v);
+    case 1: return quad_perm_i<0x55>(v);
+    case 2: return quad_perm_i<0xAA>(v);
+    default: return quad_perm_i<0xFF>(v);
+    }
+}
+__device__ __forceinline__ float quad_bcast_f(float v, int k) { return __int_as_float(quad_bcast_i(__float_as_int(v), k)); }
+#define QUAD_XOR1 0xB1                    // quad_perm:[1,0,3,2]
+#define QUAD_XOR2 0x4E                    // quad_perm:[2,3,0,1]
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -40,7 +59,6 @@ __global__ __launch_bounds__(MARCH_THREADS) void march_kernel(const SceneDev sc,
     uint2 *buf = lds_buf + (size_t)wave * s_cap;
     const unsigned blk = xcd_remap(blockIdx.x, gridDim.x);
     const int sub = lane & 3;
-    const int qbase = lane & ~3;
 
     unsigned long long st_eval = 0, st_bbox = 0, st_term = 0;
 
@@ -119,11 +137,10 @@ __global__ __launch_bounds__(MARCH_THREADS) void march_kernel(const SceneDev sc,
             float sf = 0.0f;
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
-                const int src = qbase | k4;
-                const bool v = __shfl((int)valid, src) != 0;
+                const bool v = quad_bcast_i((int)valid, k4) != 0;
                 if (__ballot(v) == 0ull) continue;
-                const int ix = __shfl(i0[0], src), iy = __shfl(i0[1], src), iz = __shfl(i0[2], src);
-                const float wx = __shfl(w[0], src), wy = __shfl(w[1], src), wz = __shfl(w[2], src);
+                const int ix = quad_bcast_i(i0[0], k4), iy = quad_bcast_i(i0[1], k4), iz = quad_bcast_i(i0[2], k4);
+                const float wx = quad_bcast_f(w[0], k4), wy = quad_bcast_f(w[1], k4), wz = quad_bcast_f(w[2], k4);
                 float part = 0.0f;
                 if (v) {
                     // plane0 (x,y)·line0(z) ; plane1 (x,z)·line1(y) ; plane2 (y,z)·line2(x)   (matMode / vecMode)
@@ -132,8 +149,8 @@ __global__ __launch_bounds__(MARCH_THREADS) void march_kernel(const SceneDev sc,
                     const float4 cc = vm_term<4, false>(sc.dplane[2], sc.dline[2], sc.grid[1], sc.grid[2], sc.grid[0], iy, iz, ix, wy, wz, wx, sub);
                     part = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((cc.x + cc.y) + (cc.z + cc.w));
                 }
-                part += __shfl_xor(part, 1);
-                part += __shfl_xor(part, 2);
+                part += quad_perm_f<QUAD_XOR1>(part);
+                part += quad_perm_f<QUAD_XOR2>(part);
                 if (sub == k4) sf = part;
             }
 

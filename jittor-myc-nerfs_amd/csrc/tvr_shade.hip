@@ -33,6 +33,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TVR_PF 1          // gather prefetch distance in k-steps (ring of TVR_PF + 1 tap sets); 2 spills at 256 VGPRs
 #endif
 #define TVR_CHK (SRC != SH_SRC_QUEUE)
+#ifndef TVR_TIMING
+#define TVR_TIMING 0      // diagnostic build: per-phase s_memtime sums into stats[4..7] (gather, basis, hidden layers, L3 + epilogue)
+#endif
+#if TVR_TIMING
+#define TVR_STAMP(x) { __builtin_amdgcn_sched_barrier(0); x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TVR_STAMP(x)
+#endif
+#ifndef TVR_STAGGER
+#define TVR_STAGGER 1
+#endif
+#ifndef TVR_SGB
+#define TVR_SGB 0         // >0: sched_group_barrier recipe in the hidden-layer k-steps, TVR_SGB VALU ops behind every MFMA
+#endif
+#ifndef TVR_PRIO
+#define TVR_PRIO 0
+#endif
 #ifndef TVR_COAL
 #define TVR_COAL 0        // 1: coalesced gather (4 lanes per 64-B segment + v_permlane16_swap): halves the L1 tag lookups of the
 #endif                    //    gather but measured slower (17.8 vs 16.1 ms) — the kernel is not L1-lookup-bound, the swaps cost VALU
@@ -59,9 +76,14 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
 {
     const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const float ra = a - (float)h[0], rb = b - (float)h[1];
+    // x - hi as fma(hi, -1, x): one v_fma_mix_f32 reading the packed half in place (exact: the product by -1 is exact); hipcc
+    // does not select the mixed-precision form by itself (it emits v_cvt_f32_f16 + v_sub), hence the asm
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hb), "v"(b));
     const auto l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
-    hi = __builtin_bit_cast(unsigned, h);
+    hi = hb;
     lo = __builtin_bit_cast(unsigned, l);
 }
 
@@ -92,32 +114,51 @@ __device__ __forceinline__ void mfma3cb(const uint4 ah, const uint4 al, const Fr
     for (int cb = 0; cb < SH_NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, b[cb].hi), acc[cb], 0, 0, 0);
 }
 
-// one k-step of a 128-row layer: A fragments of the four 32-row blocks from the LDS image (read once, used by every column
-// block), products interleaved across row and column blocks
-__device__ __forceinline__ void mfma3x4(const unsigned char *WH, const unsigned char *WL, int off0, int rb_stride, const Frag b[SH_NCB],
-                                        f32x16 acc[SH_NCB][4])
+// A fragments (hi, lo) of the four 32-row blocks of one k-step, from the LDS weight image
+struct AFrag4 { uint4 h[4], l[4]; };
+
+__device__ __forceinline__ void load_afrag4(AFrag4 &A, const unsigned char *WH, const unsigned char *WL, int off0, int rb_stride)
 {
-    uint4 ah[4], al[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-        ah[rb] = *(const uint4 *)(WH + off0 + rb * rb_stride);
-        al[rb] = *(const uint4 *)(WL + off0 + rb * rb_stride);
+        A.h[rb] = *(const uint4 *)(WH + off0 + rb * rb_stride);
+        A.l[rb] = *(const uint4 *)(WL + off0 + rb * rb_stride);
     }
+}
+
+// one k-step of a 128-row layer: the three hi/lo products interleaved across row and column blocks (no MFMA directly follows
+// an MFMA it depends on)
+__device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag b[SH_NCB], f32x16 acc[SH_NCB][4])
+{
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < SH_NCB; ++cb)
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, al[rb]), __builtin_bit_cast(h8, b[cb].hi), acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.l[rb]), __builtin_bit_cast(h8, b[cb].hi), acc[cb][rb], 0, 0, 0);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < SH_NCB; ++cb)
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah[rb]), __builtin_bit_cast(h8, b[cb].lo), acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h[rb]), __builtin_bit_cast(h8, b[cb].lo), acc[cb][rb], 0, 0, 0);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < SH_NCB; ++cb)
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah[rb]), __builtin_bit_cast(h8, b[cb].hi), acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h[rb]), __builtin_bit_cast(h8, b[cb].hi), acc[cb][rb], 0, 0, 0);
+}
+
+// scheduling recipe for one hidden-layer k-step region: LDS reads of the NEXT step's weights first, then one MFMA followed by
+// five VALU ops (the next step's B-fragment conversion), twelve times — keeps one wave's vector and matrix pipes busy together
+__device__ __forceinline__ void sched_layer_step()
+{
+#if TVR_SGB
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int i = 0; i < 12 * SH_NCB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, TVR_SGB, 0);
+    }
+#endif
 }
 
 // the 6 taps (4 plane texels, 2 line texels) x 8 channels of one entry for one k-step, plus the interpolation weights
@@ -334,7 +375,16 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     }
     const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
     const long long n_tiles = (n_total + SH_TILE - 1) / SH_TILE;
+#if TVR_TIMING
+    unsigned long long tsum[4] = {0, 0, 0, 0};
+#endif
 
+#if TVR_STAGGER
+    // the two waves of a SIMD (w and w + 4) run the same program: start the second half a tile late so that one gathers while
+    // the other multiplies (MI355X_MICROARCH 'Two waves per SIMD', item 9)
+    if (wave >= 4)
+        for (int i = 0; i < TVR_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     // A wave owns SH_NCB column blocks of 32 entries at a time (entry = MFMA column).  The blocks are independent chains, so the
     // VALU work of one overlaps the MFMAs of the other, and every weight fragment read from LDS feeds SH_NCB MFMAs.
     for (long long tile = (long long)blockIdx.x * SH_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * SH_WAVES) {
@@ -350,6 +400,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             wq[cb] = 0.f;
         }
 
+#if TVR_TIMING
+        unsigned long long tg0 = 0, tg1 = 0, tg2 = 0, tg3 = 0, tg4 = 0;
+#endif
+        TVR_STAMP(tg0);
         if (SRC != SH_SRC_FEAT) {
             float fc[SH_NCB][3];
 #pragma unroll
@@ -430,6 +484,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 TVR_SB;
             }
             }
+#if TVR_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
+            TVR_STAMP(tg1);
             // MATRIX phase starts: the basis A fragments are the last global loads of this tile, fetched before its first MFMA
             uint4 bah[9], bal[9];
 #pragma unroll
@@ -484,6 +542,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             continue;
         }
 
+        TVR_STAMP(tg2);
         // view direction occupies base rows 27 (h=0, r=15), 28, 29 (h=1, r=12, 13); rows 30, 31 stay zero (zero weights)
 #pragma unroll
         for (int cb = 0; cb < SH_NCB; ++cb) {
@@ -526,11 +585,18 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 }
             };
             Frag bcur[SH_NCB], bnxt[SH_NCB];
+            AFrag4 acur, anxt;
             l1_frag(0, bcur);
+            load_afrag4(acur, W1H, W1L, rowoff, 32 * TVR_IMG_W1_ROW);
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
-                if (s + 1 < 10) l1_frag(s + 1, bnxt);
-                mfma3x4(W1H, W1L, rowoff + s * 32, 32 * TVR_IMG_W1_ROW, bcur, acc);
+                if (s + 1 < 10) {
+                    load_afrag4(anxt, W1H, W1L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W1_ROW);
+                    l1_frag(s + 1, bnxt);
+                }
+                mfma3x4(acur, bcur, acc);
+                if (s + 1 < 10) sched_layer_step();
+                acur = anxt;
 #pragma unroll
                 for (int cb = 0; cb < SH_NCB; ++cb) bcur[cb] = bnxt[cb];
                 TVR_SB;
@@ -560,41 +626,68 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 }
             };
             Frag bcur[SH_NCB], bnxt[SH_NCB];
+            AFrag4 acur, anxt;
             relu_frag(acc, 0, bcur);
+            load_afrag4(acur, W2H, W2L, rowoff, 32 * TVR_IMG_W2_ROW);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                if (s + 1 < 8) relu_frag(acc, s + 1, bnxt);
-                mfma3x4(W2H, W2L, rowoff + s * 32, 32 * TVR_IMG_W2_ROW, bcur, acc2);
+                if (s + 1 < 8) {
+                    load_afrag4(anxt, W2H, W2L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W2_ROW);
+                    relu_frag(acc, s + 1, bnxt);
+                }
+                mfma3x4(acur, bcur, acc2);
+                if (s + 1 < 8) sched_layer_step();
+                acur = anxt;
 #pragma unroll
                 for (int cb = 0; cb < SH_NCB; ++cb) bcur[cb] = bnxt[cb];
                 TVR_SB;
             }
         }
+        TVR_STAMP(tg3);
         // ---- layer 3: rows 0..2 of W3 (+ a shared zero row) from LDS, bias b3 as the initial accumulator ----
-        f32x16 acc3[SH_NCB];
+        // three independent accumulation chains (as in the basis product): with one column block the hi/lo products of a k-step
+        // would otherwise be 24 MFMAs each waiting for its predecessor
+        f32x16 acc3[SH_NCB], acc3b[SH_NCB], acc3c[SH_NCB];
         {
             const float b30 = sc.b3[0], b31 = sc.b3[1], b32 = sc.b3[2];
 #pragma unroll
             for (int cb = 0; cb < SH_NCB; ++cb) {
-                acc3[cb] = f32x16{0};
+                acc3[cb] = f32x16{0}; acc3b[cb] = f32x16{0}; acc3c[cb] = f32x16{0};
                 acc3[cb][0] = h == 0 ? b30 : 0.0f; acc3[cb][1] = h == 0 ? b31 : 0.0f; acc3[cb][2] = h == 0 ? b32 : 0.0f;
             }
         }
+        {
+            Frag bcur[SH_NCB], bnxt[SH_NCB];
+            auto relu2_frag = [&](int s, Frag b[SH_NCB]) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            // rows >= 3 of W3 are zero: every such lane reads the shared zero row (address select)
-            const uint4 *ap = (const uint4 *)(smem + TVR_IMG_W3 + (e < 3 ? e : 3) * TVR_IMG_W3_ROW + (s * 2 + h) * 32);
-            const uint4 a3h = ap[0], a3l = ap[1];
-            Frag b3f[SH_NCB];
+                for (int cb = 0; cb < SH_NCB; ++cb) {
+                    float v[8];
 #pragma unroll
-            for (int cb = 0; cb < SH_NCB; ++cb) {
-                float v[8];
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[cb][s >> 1][8 * (s & 1) + j], 0.0f);
+                    b[cb] = split8(v);
+                }
+            };
+            relu2_frag(0, bcur);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[cb][s >> 1][8 * (s & 1) + j], 0.0f);
-                b3f[cb] = split8(v);
+            for (int s = 0; s < 8; ++s) {
+                // rows >= 3 of W3 are zero: every such lane reads the shared zero row (address select)
+                const uint4 *ap = (const uint4 *)(smem + TVR_IMG_W3 + (e < 3 ? e : 3) * TVR_IMG_W3_ROW + (s * 2 + h) * 32);
+                const h8 Ah = __builtin_bit_cast(h8, ap[0]), Al = __builtin_bit_cast(h8, ap[1]);
+                if (s + 1 < 8) relu2_frag(s + 1, bnxt);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) acc3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, bcur[cb].hi), acc3[cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) acc3b[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, bcur[cb].lo), acc3b[cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) acc3c[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, bcur[cb].hi), acc3c[cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) bcur[cb] = bnxt[cb];
+                TVR_SB;
             }
-            mfma3cb(a3h, a3l, b3f, acc3);
-            TVR_SB;
+#pragma unroll
+            for (int cb = 0; cb < SH_NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) acc3[cb][r] = (acc3[cb][r] + acc3b[cb][r]) + acc3c[cb][r];
         }
 #pragma unroll
         for (int cb = 0; cb < SH_NCB; ++cb) {
@@ -609,7 +702,18 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             }
         }
         TVR_SB;
+#if TVR_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#if TVR_TIMING
+        TVR_STAMP(tg4);
+        tsum[0] += tg1 - tg0; tsum[1] += tg2 - tg1; tsum[2] += tg3 - tg2; tsum[3] += tg4 - tg3;
+#endif
     }
+#if TVR_TIMING
+    if (a.stats && lane == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd((unsigned long long *)&a.stats[4 + i], tsum[i]);
+#endif
     if (a.stats && SRC == SH_SRC_QUEUE && blockIdx.x == 0 && tid == 0)
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
 }
