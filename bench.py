@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eps-T", type=float, default=None, help="early-termination threshold (default = weight thres 1e-4; 0 = exact)")
+    ap.add_argument("--chunk", type=int, default=0, help="rays per tvr_render call (0 = the rank's whole batch in one call; 4096 = BASELINE "
+                                                          "configs[3] / train.py batch size)")
+    ap.add_argument("--alpha-mask", type=int, default=0, help="build an AlphaGridMask of this resolution with updateAlphaMask first "
+                                                               "(the reference does so at iteration 2000/4000); 0 = none")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,6 +135,8 @@ def main():
     import ctypes as C
     model, arrs, A = build_model(device)
     S = A["N_samples"]
+    if args.alpha_mask > 0:
+        model.updateAlphaMask((args.alpha_mask,) * 3)
     fr = frames(A)                                                  # 8 poses x [640000,6] on the host
     R1 = fr[0].shape[0]
 
@@ -154,7 +160,12 @@ def main():
 
     def step(s, profile=None, stats=None):
         rays = step_rays[s % n_patterns]
-        rgb, depth = model.render_rays(rays, white_bg=True, N_samples=S, eps_T=args.eps_T, stats=stats, profile=profile)
+        if args.chunk > 0:                                          # renderer.py:16-25 chunk loop, one tvr_render per chunk, no host sync
+            outs = [model.render_rays(rays[c0:c0 + args.chunk], white_bg=True, N_samples=S, eps_T=args.eps_T, stats=stats)
+                    for c0 in range(0, rays.shape[0], args.chunk)]
+            rgb, depth = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        else:
+            rgb, depth = model.render_rays(rays, white_bg=True, N_samples=S, eps_T=args.eps_T, stats=stats, profile=profile)
         if world > 1:
             mine[:n_mine, :3] = rgb
             mine[:n_mine, 3] = depth
@@ -192,6 +203,8 @@ def main():
     n_calls = L.lib().tvr_profile_read(prof, C.byref(ms))
     L.check(n_calls, "tvr_profile_read")
     k_ms = [ms[i] / max(n_calls, 1) for i in range(3)]
+    if n_calls == 0:                                               # chunked mode records no per-kernel events
+        k_ms = [0.0, 0.0, 0.0]
 
     # occupancy statistics of exactly the timed steps (untimed pass with counters on)
     stats = torch.zeros(8, dtype=torch.int64, device=device)
@@ -240,7 +253,8 @@ def main():
                                "(BASELINE configs[1]; N>1: configs[2] as N frames, 4096-ray tiles round-robin, one RCCL all_gather "
                                "of [rays,4] fp32)", "scene": "synthetic scene A (SURVEY 8d), no alpha mask, white_bg",
                    "rays_per_step": total_rays, "samples_per_ray": S,
-                   "eps_T": float(model.rayMarch_weight_thres) if args.eps_T is None else args.eps_T, "tile": TILE},
+                   "eps_T": float(model.rayMarch_weight_thres) if args.eps_T is None else args.eps_T, "tile": TILE,
+                   "chunk": args.chunk if args.chunk > 0 else n_mine, "alpha_mask": args.alpha_mask},
         "rays_per_sec": total_rays * args.steps / dt,
         "effective": {"density_samples_evaluated_per_sec": m_eval * world * args.steps / dt,
                       "appearance_samples_per_sec": m_app * world * args.steps / dt,

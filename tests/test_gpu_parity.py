@@ -269,3 +269,48 @@ def test_scene_maintenance_ops(tiny_arrays, hyper_tiny, tiny_dump):
     refs = CO.COracle(sh, step=float(scs.stepSize), **hyper_tiny).render(tiny_dump["rays"], TINY["N_samples"], white_bg=True)
     rgbs, _ = m3(rays, N_samples=TINY["N_samples"])
     assert np.abs(_np(rgbs) - refs["rgb_map"]).max() < RGB_TIGHT
+
+
+def test_render_is_hip_graph_capturable(config1_golden):
+    """The C-ABI never allocates or synchronises, so a whole tvr_render (memset + 3 kernels) can be captured into a hipGraph and
+    replayed; the replay is bit-identical to the eager call."""
+    from jittor_myc_nerfs_amd import synthetic
+    B = synthetic.SCENE_B
+    arrs = synthetic.make_scene_arrays(B["gridSize"], B["aabb"])
+    m = make_model(arrs, dict(synthetic.HYPER, near_far=B["near_far"], step_ratio=B["step_ratio"]))
+    rays = torch.tensor(config1_golden["rays"], device="cuda")
+    eager_rgb, eager_depth = m.render_rays(rays, white_bg=True, N_samples=B["N_samples"])      # also builds scene + scratch
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.render_rays(rays, white_bg=True, N_samples=B["N_samples"])                            # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap_rgb, cap_depth = m.render_rays(rays, white_bg=True, N_samples=B["N_samples"])
+    cap_rgb.zero_(); cap_depth.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cap_rgb, eager_rgb) and torch.equal(cap_depth, eager_depth)
+
+
+def test_evaluation_loop_on_gpu(tmp_path, tiny_arrays, hyper_tiny):
+    """renderer.py:29-91 driven end to end: transforms json -> rays -> OctreeRender_trilinear_fast (chunk 1024) -> PNG + PSNR."""
+    import json
+    from PIL import Image
+    from jittor_myc_nerfs_amd import BlenderRays, OctreeRender_trilinear_fast, evaluation, rays as R
+    from oracle import c_oracle as CO, tensorf_oracle as TO
+    m = make_model(tiny_arrays, hyper_tiny)
+    poses = R.sphere_poses(2, 4.0)
+    meta = {"camera_angle_x": 0.6911, "frames": [{"file_path": f"./test/r_{i}", "transform_matrix": M.tolist()} for i, M in enumerate(poses)]}
+    with open(tmp_path / "transforms_test.json", "w") as f:
+        json.dump(meta, f)
+    ds = BlenderRays(str(tmp_path), split="test", downsample=25.0, near=2.0, far=6.0)     # 32x32
+    class A: expname = "tiny"
+    evaluation(ds, m, A, OctreeRender_trilinear_fast, savePath=str(tmp_path / "o"), N_vis=-1, N_samples=48, white_bg=True, device="cuda")
+    img = np.asarray(Image.open(tmp_path / "o" / "tiny_r_1.png")).astype(np.float32) / 255.0
+    sc = TO.scene_from_arrays(tiny_arrays, **hyper_tiny)
+    ref = CO.COracle(tiny_arrays, step=float(sc.stepSize), **hyper_tiny).render(ds.all_rays[1].numpy(), 48, white_bg=True)
+    assert np.abs(img.reshape(-1, 3) - ref["rgb_map"]).max() < 1.0 / 255 + 1e-3         # 8-bit quantisation + parity bar
