@@ -113,3 +113,25 @@ def test_shard_indices_partition():
         allidx = torch.cat([shard_indices(R_, r, w, t) for r in range(w)])
         assert sorted(allidx.tolist()) == list(range(R_))
         assert all(shard_indices(R_, r, w, t).numel() <= shard_capacity(R_, w, t) for r in range(w))
+
+
+def test_checkpoint_save_load_roundtrip(tmp_path, tiny_arrays, hyper_tiny):
+    """TensorBase.save / load (tensorBase.py:253-272): kwargs + state_dict + bit-packed alpha mask survive a round trip and
+    rebuild an identical field through the reference's `eval(model_name)(**kwargs); load(ckpt)` sequence (train.py:75-87)."""
+    from jittor_myc_nerfs_amd import AlphaGridMask, TensorVMSplit
+    m = make_model(tiny_arrays, hyper_tiny, device="cpu")
+    vol = (np.random.default_rng(0).random((6, 5, 4)) > 0.5).astype(np.float32)
+    m.alphaMask = AlphaGridMask("cpu", tiny_arrays["aabb"], torch.tensor(vol))
+    path = str(tmp_path / "tiny.th")
+    m.save(path, global_kwargs={"global_step": 7})
+    ckpt = torch.load(path, weights_only=False)
+    assert ckpt["global_step"] == 7 and tuple(ckpt["alphaMask.shape"]) == (1, 1, 6, 5, 4)
+    kwargs = ckpt["kwargs"]
+    kwargs.update({"device": "cpu"})
+    m2 = TensorVMSplit(**kwargs)
+    m2.load(ckpt)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert np.array_equal(m2.alphaMask.alpha_volume.numpy().reshape(6, 5, 4), vol)
+    assert m2.nSamples == m.nSamples and float(m2.stepSize) == float(m.stepSize)
+    assert m2.get_kwargs()["gridSize"] == m.get_kwargs()["gridSize"]
