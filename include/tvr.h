@@ -123,6 +123,36 @@ int tvr_mlp_render(tvr_scene *scene, const float *viewdirs, const float *feature
 int tvr_alpha_sample(const float *alpha_volume_dev, const int32_t agrid_xyz[3], const float alpha_aabb[6],
                      const float alpha_inv_size[3], const float *xyz, int64_t m, float *out, void *stream);
 
+/* ---- training step (caller: tensorf-myc/train.py:225-261) ------------------------------------------------
+ * The TensoRF-specific halves of forward and backward are HIP kernels; the 144->27 basis, the positional encoding and the
+ * three Linears run as library GEMMs under the host's autograd between them. */
+
+/* Byte offsets of the regions of a tvr_render / tvr_march_forward scratch buffer, for hosts that consume the queue:
+ * counter u32; ray_off/ray_cnt u32[n]; acc f32[n]; q_pos float4[cap] {xyz_norm, weight}; q_out float4[cap] {rgb, weight};
+ * q_ray u32[cap]; q_j u32[cap]; cap = n_rays * n_samples.  Each ray's entries are contiguous and in sample order. */
+typedef struct { size_t counter, ray_off, ray_cnt, acc, q_pos, q_out, q_ray, q_j, total; } tvr_scratch_layout;
+int tvr_scratch_describe(int64_t n_rays, int32_t n_samples, tvr_scratch_layout *out);
+
+/* The march alone (sample_ray .. raw2alpha, tensorBase.py:487-513): fills the queue (q_pos, q_ray, ray_off, ray_cnt, counter),
+ * acc [n] and depth_out [n].  Same arithmetic as tvr_render. */
+int tvr_march_forward(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *jitter, float eps_T,
+                      float *depth_out, void *scratch, size_t scratch_bytes, void *stream);
+
+/* Gradient outputs in the REFERENCE parameter layout ((1,C,H,W) planes, (1,C,L,1) lines); each call overwrites its six. */
+typedef struct { float *density_plane[3], *density_line[3], *app_plane[3], *app_line[3]; } tvr_vm_grads;
+size_t tvr_grad_scratch_bytes(const tvr_scene *scene);      /* packed gradient images used internally by the two backward calls */
+
+/* d loss / d density factors from grad_w [queue length] (d loss / d weight of each appearance sample, queue order) and
+ * grad_acc [n] (d loss / d acc_map).  fwd_scratch is the untouched scratch of the matching tvr_march_forward call. */
+int tvr_march_backward(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *jitter, float eps_T,
+                       const void *fwd_scratch, size_t fwd_scratch_bytes, const float *grad_w, const float *grad_acc,
+                       void *grad_scratch, size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream);
+
+/* h [m,144] = bilinear(app_plane) * linear(app_line), plane-major (tensoRF.py:235-241, before basis_mat), and its backward. */
+int tvr_app_h_forward(tvr_scene *scene, const float *xyz_norm, int64_t m, float *h_out, void *stream);
+int tvr_app_h_backward(tvr_scene *scene, const float *xyz_norm, int64_t m, const float *dh, void *grad_scratch,
+                       size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream);
+
 /* Per-kernel HIP-event timing of tvr_render calls (march / shade / composite), for bench.py's roofline. */
 int tvr_profile_create(int32_t max_calls, tvr_profile **out);
 int tvr_profile_reset(tvr_profile *prof);

@@ -6,4 +6,5 @@ hand-written HIP kernels for gfx950 behind the C-ABI in include/tvr.h (csrc/, bu
 from .field import AlphaGridMask, MLPRender_Fea, TensorBase, TensorVMSplit  # noqa: F401
 from .render import OctreeRender_trilinear_fast, render_sharded, shard_indices, shard_capacity  # noqa: F401
 from .evaluation import BlenderRays, evaluation, evaluation_path, rgb_ssim  # noqa: F401
+from .losses import TVLoss  # noqa: F401
 from . import rays, synthetic  # noqa: F401

@@ -26,6 +26,14 @@ class SceneParams(C.Structure):
                 ("W3", C.c_void_p), ("b3", C.c_void_p)]
 
 
+class ScratchLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("counter", "ray_off", "ray_cnt", "acc", "q_pos", "q_out", "q_ray", "q_j", "total")]
+
+
+class VmGrads(C.Structure):
+    _fields_ = [("density_plane", C.c_void_p * 3), ("density_line", C.c_void_p * 3), ("app_plane", C.c_void_p * 3), ("app_line", C.c_void_p * 3)]
+
+
 class DenseOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("z", "valid", "bbox_valid", "cell", "sigma_feature", "sigma", "alpha",
                                           "weight", "rgb", "bg_weight", "acc", "t_min")]
@@ -50,6 +58,14 @@ SYMBOLS = {
     "tvr_mlp_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tvr_alpha_sample": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_float * 6), C.POINTER(C.c_float * 3),
                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_scratch_describe": (C.c_int, [C.c_int64, C.c_int32, C.POINTER(ScratchLayout)]),
+    "tvr_march_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
+    "tvr_grad_scratch_bytes": (C.c_size_t, [C.c_void_p]),
+    "tvr_march_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.c_void_p]),
+    "tvr_app_h_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_app_h_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.c_void_p]),
     "tvr_profile_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
     "tvr_profile_reset": (C.c_int, [C.c_void_p]),
     "tvr_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3)]),

@@ -271,6 +271,139 @@ int tvr_render(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32
     return TVR_OK;
 }
 
+
+static int scene_ready(const tvr_scene *s)
+{
+    if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
+    return TVR_OK;
+}
+
+static MarchOut carve_scratch(char *b, const ScratchLayout &L, float *depth_out)
+{
+    MarchOut mo;
+    mo.counter = (unsigned *)(b + L.counter);
+    mo.ray_off = (unsigned *)(b + L.ray_off);
+    mo.ray_cnt = (unsigned *)(b + L.ray_cnt);
+    mo.acc = (float *)(b + L.acc);
+    mo.depth = depth_out;
+    mo.q_pos = (float4 *)(b + L.q_pos);
+    mo.q_out = (float4 *)(b + L.q_out);
+    mo.q_ray = (unsigned *)(b + L.q_ray);
+    mo.q_j = nullptr;
+    mo.stats = nullptr;
+    return mo;
+}
+
+int tvr_scratch_describe(int64_t n_rays, int32_t n_samples, tvr_scratch_layout *out)
+{
+    if (!out || n_rays <= 0 || n_samples <= 0) return fail(TVR_ERR_INVALID, "bad arguments");
+    ScratchLayout L = scratch_layout(n_rays, n_samples);
+    out->counter = L.counter; out->ray_off = L.ray_off; out->ray_cnt = L.ray_cnt; out->acc = L.acc;
+    out->q_pos = L.q_pos; out->q_out = L.q_out; out->q_ray = L.q_ray; out->q_j = L.q_j; out->total = L.total;
+    return TVR_OK;
+}
+
+int tvr_march_forward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *jitter, float eps_T, float *depth_out,
+                      void *scratch, size_t scratch_bytes, void *stream_)
+{
+    int rc = scene_ready(s);
+    if (rc != TVR_OK) return rc;
+    if (!rays || !depth_out || n_rays <= 0) return fail(TVR_ERR_INVALID, "rays/depth_out NULL or n_rays <= 0");
+    if (S <= 0 || S > 4096) return fail(TVR_ERR_INVALID, "n_samples=%d out of [1,4096]", S);
+    if ((size_t)n_rays * (size_t)S >= (1ull << 32)) return fail(TVR_ERR_INVALID, "n_rays*n_samples must be < 2^32 per call");
+    if (!(eps_T >= 0.0f) || eps_T > s->desc.weight_thres) return fail(TVR_ERR_INVALID, "eps_T=%g must be in [0, weight_thres]", eps_T);
+    ScratchLayout L = scratch_layout(n_rays, S);
+    if (!scratch || scratch_bytes < L.total || (uintptr_t)scratch % 256) return fail(TVR_ERR_SCRATCH, "scratch too small (%zu < %zu) or misaligned", scratch_bytes, L.total);
+    hipStream_t stream = (hipStream_t)stream_;
+    MarchOut mo = carve_scratch((char *)scratch, L, depth_out);
+    HIP_TRY(hipMemsetAsync(mo.counter, 0, 4, stream));
+    HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, jitter, eps_T, mo, nullptr, stream));
+    return TVR_OK;
+}
+
+size_t tvr_grad_scratch_bytes(const tvr_scene *s)
+{
+    if (!s) return 0;
+    return s->lay.mlp_image;      // the VM blocks come first in the packed layout; the gradient images mirror them
+}
+
+static TrainGrads carve_grads(const tvr_scene *s, char *g)
+{
+    TrainGrads tg;
+    for (int i = 0; i < 3; ++i) {
+        tg.dplane[i] = (float *)(g + s->lay.dplane[i]);
+        tg.dline[i] = (float *)(g + s->lay.dline[i]);
+        tg.aplane[i] = (float *)(g + s->lay.aplane[i]);
+        tg.aline[i] = (float *)(g + s->lay.aline[i]);
+    }
+    return tg;
+}
+
+int tvr_march_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *jitter, float eps_T, const void *fwd_scratch,
+                       size_t fwd_scratch_bytes, const float *grad_w, const float *grad_acc, void *grad_scratch, size_t grad_scratch_bytes,
+                       const tvr_vm_grads *out, void *stream_)
+{
+    int rc = scene_ready(s);
+    if (rc != TVR_OK) return rc;
+    if (!rays || !fwd_scratch || !grad_w || !grad_acc || !grad_scratch || !out || n_rays <= 0) return fail(TVR_ERR_INVALID, "NULL argument");
+    ScratchLayout L = scratch_layout(n_rays, S);
+    if (fwd_scratch_bytes < L.total) return fail(TVR_ERR_SCRATCH, "forward scratch %zu B < %zu B", fwd_scratch_bytes, L.total);
+    if (grad_scratch_bytes < s->lay.mlp_image || (uintptr_t)grad_scratch % 256) return fail(TVR_ERR_SCRATCH, "gradient scratch too small or misaligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const tvr_scene_desc &d = s->desc;
+    char *g = (char *)grad_scratch;
+    TrainGrads tg = carve_grads(s, g);
+    for (int i = 0; i < 3; ++i) {
+        const size_t W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
+        HIP_TRY(hipMemsetAsync(tg.dplane[i], 0, (H + 1) * (W + 1) * TVR_CD * sizeof(float), stream));
+        HIP_TRY(hipMemsetAsync(tg.dline[i], 0, (Ln + 1) * TVR_CD * sizeof(float), stream));
+    }
+    MarchOut mo = carve_scratch((char *)fwd_scratch, L, nullptr);
+    HIP_TRY(launch_march_backward(s->dev, rays, (int)n_rays, S, jitter, eps_T, mo, grad_w, grad_acc, tg, stream));
+    for (int i = 0; i < 3; ++i) {
+        if (!out->density_plane[i] || !out->density_line[i]) return fail(TVR_ERR_INVALID, "density gradient pointer %d is NULL", i);
+        const int W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
+        HIP_TRY(launch_unpack_grad(tg.dplane[i], out->density_plane[i], TVR_CD, H, W, stream));
+        HIP_TRY(launch_unpack_grad(tg.dline[i], out->density_line[i], TVR_CD, Ln, 1, stream));
+    }
+    return TVR_OK;
+}
+
+int tvr_app_h_forward(tvr_scene *s, const float *xyz, int64_t m, float *h_out, void *stream)
+{
+    int rc = scene_ready(s);
+    if (rc != TVR_OK) return rc;
+    if (m == 0) return TVR_OK;
+    if (!xyz || !h_out || m < 0) return fail(TVR_ERR_INVALID, "xyz/h_out NULL or m < 0");
+    HIP_TRY(launch_app_h_forward(s->dev, xyz, m, h_out, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *dh, void *grad_scratch, size_t grad_scratch_bytes,
+                       const tvr_vm_grads *out, void *stream_)
+{
+    int rc = scene_ready(s);
+    if (rc != TVR_OK) return rc;
+    if (!grad_scratch || !out || m < 0 || (m > 0 && (!xyz || !dh))) return fail(TVR_ERR_INVALID, "NULL argument");
+    if (grad_scratch_bytes < s->lay.mlp_image || (uintptr_t)grad_scratch % 256) return fail(TVR_ERR_SCRATCH, "gradient scratch too small or misaligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const tvr_scene_desc &d = s->desc;
+    TrainGrads tg = carve_grads(s, (char *)grad_scratch);
+    for (int i = 0; i < 3; ++i) {
+        const size_t W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
+        HIP_TRY(hipMemsetAsync(tg.aplane[i], 0, (H + 1) * (W + 1) * TVR_CA * sizeof(float), stream));
+        HIP_TRY(hipMemsetAsync(tg.aline[i], 0, (Ln + 1) * TVR_CA * sizeof(float), stream));
+    }
+    if (m > 0) HIP_TRY(launch_app_h_backward(s->dev, xyz, m, dh, tg, stream));
+    for (int i = 0; i < 3; ++i) {
+        if (!out->app_plane[i] || !out->app_line[i]) return fail(TVR_ERR_INVALID, "appearance gradient pointer %d is NULL", i);
+        const int W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
+        HIP_TRY(launch_unpack_grad(tg.aplane[i], out->app_plane[i], TVR_CA, H, W, stream));
+        HIP_TRY(launch_unpack_grad(tg.aline[i], out->app_line[i], TVR_CA, Ln, 1, stream));
+    }
+    return TVR_OK;
+}
+
 int tvr_density_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, void *stream)
 {
     if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");

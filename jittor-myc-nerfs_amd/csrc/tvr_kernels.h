@@ -20,6 +20,11 @@ struct MarchOut {
     unsigned long long *stats;// TVR_STAT_* counters or nullptr
 };
 
+// packed (channels-last, zero-padded) gradient images of the VM factors, same geometry as the packed scene
+struct TrainGrads {
+    float *dplane[3], *dline[3], *aplane[3], *aline[3];
+};
+
 enum { SH_SRC_QUEUE = 0, SH_SRC_XYZ = 1, SH_SRC_FEAT = 2 };
 enum { SH_DST_QUEUE = 0, SH_DST_FEAT = 1, SH_DST_RGB = 2 };
 
@@ -46,3 +51,8 @@ hipError_t launch_alpha_sample(const SceneDev &sc, const float *xyz, long long m
 hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream);
 hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, hipStream_t stream);
 hipError_t launch_pack_mlp(const float *W, void *out_hi, void *out_lo, int mode, hipStream_t stream);
+hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T, const MarchOut &mo,
+                                 const float *grad_w, const float *grad_acc, const TrainGrads &tg, hipStream_t stream);
+hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream);
+hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream);
+hipError_t launch_unpack_grad(const float *in, float *out, int C, int H, int W, hipStream_t stream);

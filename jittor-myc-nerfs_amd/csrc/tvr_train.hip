@@ -1,0 +1,314 @@
+// tvr_train.hip — backward kernels for the training step (the caller is tensorf-myc/train.py:225-261).
+//
+//   march_backward_kernel : d loss / d density planes+lines, given d loss / d w_e (per appearance sample) and d loss / d acc (per ray)
+//   app_h_forward_kernel  : h[m,144] = bilinear(app_plane)·linear(app_line) for queue positions (tensoRF.py:235-241; the 144->27 basis,
+//                           the PE and the three Linears then run as plain rocBLAS GEMMs under torch autograd in training)
+//   app_h_backward_kernel : scatter-add of d loss / d h into the appearance planes+lines
+//   unpack_grad_kernel    : packed channels-last gradient image -> the reference parameter layout (1,C,H,W)
+//
+// Compositing gradient in FORWARD order (no reverse scan): with w_k = alpha_k T_k and T_k = prod_{i<k} (1 - alpha_i + 1e-10),
+//   dL/dalpha_j = T_j dL/dw_j - (sum_{k>j} dL/dw_k w_k) / (1 - alpha_j + 1e-10),
+// and the suffix sum is (total - inclusive prefix), where total = sum_e grad_w_e w_e + grad_acc * acc is known from the forward
+// pass.  dL/dw_j = grad_acc (every sample feeds acc, tensorBase.py:520) + grad_w_e if the sample is an appearance sample.
+// The kernel recomputes the forward march bit for bit (same code, same eps_T), so "k-th sample with w > thres" is queue entry
+// ray_off + k again.
+#include "tvr_device.h"
+#include "tvr_kernels.h"
+
+#define TB_THREADS 256
+#define TB_WAVES 4
+
+template <int CTRL>
+__device__ __forceinline__ int qperm_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int qbcast_i(int v, int k)
+{
+    switch (k) {
+    case 0: return qperm_i<0x00>(v);
+    case 1: return qperm_i<0x55>(v);
+    case 2: return qperm_i<0xAA>(v);
+    default: return qperm_i<0xFF>(v);
+    }
+}
+__device__ __forceinline__ float qbcast_f(float v, int k) { return __int_as_float(qbcast_i(__float_as_int(v), k)); }
+__device__ __forceinline__ float qxor_sum(float v)
+{
+    v += __int_as_float(qperm_i<0xB1>(__float_as_int(v)));
+    v += __int_as_float(qperm_i<0x4E>(__float_as_int(v)));
+    return v;
+}
+
+__device__ __forceinline__ void atomic_add4(float *p, float4 v)
+{
+    atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+
+// texels + interpolated values of one (plane, line) pair for this lane's 4 channels; optionally scatters gradients
+struct VmTerm {
+    float4 P, Q;          // bilinear(plane)[4ch], linear(line)[4ch]
+};
+
+template <int TPT>
+__device__ __forceinline__ VmTerm vm_eval(const float4 *__restrict__ Pl, const float4 *__restrict__ Ln, int W, int x0, int y0, int l0, float wx,
+                                          float wy, float wl, int sub)
+{
+    const float ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
+    const int Wp = W + 1;
+    const float4 *p = Pl + ((size_t)y0 * Wp + x0) * TPT + sub;
+    const float4 t00 = p[0], t01 = p[TPT], t10 = p[(size_t)Wp * TPT], t11 = p[(size_t)Wp * TPT + TPT];
+    const float4 *q = Ln + (size_t)l0 * TPT + sub;
+    const float4 l0v = q[0], l1v = q[TPT];
+    VmTerm r;
+    r.P = f4_mul(ux * uy, t00);
+    r.P = f4_fma(wx * uy, t01, r.P);
+    r.P = f4_fma(ux * wy, t10, r.P);
+    r.P = f4_fma(wx * wy, t11, r.P);
+    r.Q = f4_mul(ul, l0v);
+    r.Q = f4_fma(wl, l1v, r.Q);
+    return r;
+}
+
+// d(plane taps) += gP * w_tap, d(line taps) += gQ * w_l   (gP = dL/dP[4ch], gQ = dL/dQ[4ch]); packed gradient images
+template <int TPT>
+__device__ __forceinline__ void vm_scatter(float *__restrict__ gPl, float *__restrict__ gLn, int W, int x0, int y0, int l0, float wx, float wy,
+                                           float wl, int sub, float4 gP, float4 gQ)
+{
+    const float ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
+    const int Wp = W + 1;
+    float *p = gPl + (((size_t)y0 * Wp + x0) * TPT + sub) * 4;
+    atomic_add4(p, f4_mul(ux * uy, gP));
+    atomic_add4(p + TPT * 4, f4_mul(wx * uy, gP));
+    atomic_add4(p + (size_t)Wp * TPT * 4, f4_mul(ux * wy, gP));
+    atomic_add4(p + (size_t)Wp * TPT * 4 + TPT * 4, f4_mul(wx * wy, gP));
+    float *q = gLn + ((size_t)l0 * TPT + sub) * 4;
+    atomic_add4(q, f4_mul(ul, gQ));
+    atomic_add4(q + TPT * 4, f4_mul(wl, gQ));
+}
+
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneDev sc, const float *__restrict__ rays, const int n_rays, const int S,
+                                                                    const float *__restrict__ jitter, const float eps_T, const int rays_per_block,
+                                                                    const MarchOut mo, const float *__restrict__ grad_w,
+                                                                    const float *__restrict__ grad_acc, TrainGrads tg)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane & 3;
+    for (int it = wave; it < rays_per_block; it += TB_WAVES) {
+        const int ray = blockIdx.x * rays_per_block + it;
+        if (ray >= n_rays) break;
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = rays[(size_t)ray * 6 + k];
+            d[k] = rays[(size_t)ray * 6 + 3 + k];
+        }
+        const float tmin = ray_tmin(sc, o, d);
+        const bool has_jit = jitter != nullptr;
+        const float u = has_jit ? jitter[ray] : 0.0f;
+        const unsigned base = mo.ray_off[ray], cnt = mo.ray_cnt[ray];
+        const float gacc = grad_acc[ray];
+        // total = sum_k dL/dw_k w_k over the whole (possibly early-terminated) ray
+        float tot_l = 0.0f;
+        for (unsigned i = lane; i < cnt; i += 64) tot_l += grad_w[base + i] * mo.q_pos[base + i].w;
+        const float total = wave_sum_f(tot_l) + gacc * mo.acc[ray];
+
+        float T = 1.0f, prefix = 0.0f;
+        unsigned napp = 0;
+        bool seen = false;
+        for (int c = 0; c * 64 < S; ++c) {
+            const int j = c * 64 + lane;
+            const bool inr = j < S;
+            float fj = (float)j, fj1 = (float)(j + 1);
+            if (has_jit) { fj = fj + u; fj1 = fj1 + u; }
+            const float z = tmin + sc.step * fj;
+            const float z1 = tmin + sc.step * fj1;
+            float p[3], n[3], f[3];
+            bool bbox = inr;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                p[k] = o[k] + d[k] * z;
+                bbox = bbox & !((sc.lo[k] > p[k]) | (p[k] > sc.hi[k]));
+            }
+            bool valid = bbox;
+            if (sc.avol != nullptr) {
+                if (bbox) valid = alpha_lookup(sc, p) > 0.0f;
+            }
+            int i0[3];
+            float w[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                n[k] = (p[k] - sc.lo[k]) * sc.inv[k] - 1.0f;
+                f[k] = unnorm(n[k], sc.gm1[k]);
+                const float fl = floorf(f[k]);
+                i0[k] = (int)fl;
+                w[k] = f[k] - fl;
+            }
+            const unsigned long long mb = __ballot(bbox), mv = __ballot(valid);
+            if (mv == 0ull) {
+                if (mb == 0ull && seen) break;
+                continue;
+            }
+            seen = true;
+            // ---- phase 1: forward recomputation of sigma_feature (identical arithmetic to march_kernel) ----
+            float sf = 0.0f;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const bool v = qbcast_i((int)valid, k4) != 0;
+                if (__ballot(v) == 0ull) continue;
+                const int ix = qbcast_i(i0[0], k4), iy = qbcast_i(i0[1], k4), iz = qbcast_i(i0[2], k4);
+                const float wx = qbcast_f(w[0], k4), wy = qbcast_f(w[1], k4), wz = qbcast_f(w[2], k4);
+                float part = 0.0f;
+                if (v) {
+                    const float4 a = vm_term<4, false>(sc.dplane[0], sc.dline[0], sc.grid[0], sc.grid[1], sc.grid[2], ix, iy, iz, wx, wy, wz, sub);
+                    const float4 b = vm_term<4, false>(sc.dplane[1], sc.dline[1], sc.grid[0], sc.grid[2], sc.grid[1], ix, iz, iy, wx, wz, wy, sub);
+                    const float4 cc = vm_term<4, false>(sc.dplane[2], sc.dline[2], sc.grid[1], sc.grid[2], sc.grid[0], iy, iz, ix, wy, wz, wx, sub);
+                    part = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((cc.x + cc.y) + (cc.z + cc.w));
+                }
+                part = qxor_sum(part);
+                if (sub == k4) sf = part;
+            }
+            float sigma = 0.0f, dsig_dsf = 0.0f;
+            if (valid) {
+                if (sc.act == 0) {
+                    const float x = sf + sc.shift;
+                    sigma = softplus_f(x);
+                    dsig_dsf = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
+                } else {
+                    sigma = fmaxf(sf, 0.0f);
+                    dsig_dsf = sf > 0.0f ? 1.0f : 0.0f;
+                }
+            }
+            float dist = (j < S - 1) ? (z1 - z) : 0.0f;
+            dist = dist * sc.scale;
+            const float alpha = 1.0f - expf(-sigma * dist);
+            const float fT = (1.0f - alpha) + 1e-10f;
+            float incl = fT;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float t = __shfl_up(incl, off);
+                if (lane >= off) incl = incl * t;
+            }
+            float excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 1.0f;
+            const float Tj = T * excl;
+            const float wgt = alpha * Tj;
+            const bool app = wgt > sc.thres;
+            const unsigned long long ma = __ballot(app);
+            float dLdw = gacc;
+            if (app) dLdw += grad_w[base + napp + __popcll(ma & ((1ull << lane) - 1ull))];
+            napp += __popcll(ma);
+            // inclusive prefix of dL/dw_k w_k
+            float pin = dLdw * wgt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float t = __shfl_up(pin, off);
+                if (lane >= off) pin += t;
+            }
+            const float suffix = total - (prefix + pin);
+            prefix += __shfl(pin, 63);
+            const float dLda = Tj * dLdw - suffix / fT;
+            const float dLdsf = valid ? dLda * dist * (1.0f - alpha) * dsig_dsf : 0.0f;
+            T = T * __shfl(incl, 63);
+
+            // ---- phase 2: scatter dL/dsf into the density planes / lines (re-gather: the texels are L1/L2 hot) ----
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const bool v = qbcast_i((int)valid, k4) != 0;
+                const float gs = qbcast_f(dLdsf, k4);
+                if (__ballot(v && gs != 0.0f) == 0ull) continue;
+                const int ix = qbcast_i(i0[0], k4), iy = qbcast_i(i0[1], k4), iz = qbcast_i(i0[2], k4);
+                const float wx = qbcast_f(w[0], k4), wy = qbcast_f(w[1], k4), wz = qbcast_f(w[2], k4);
+                if (v && gs != 0.0f) {
+                    // sf = sum_i sum_c P_i[c] Q_i[c]  ->  dP_i[c] = gs Q_i[c], dQ_i[c] = gs P_i[c]
+                    const VmTerm t0 = vm_eval<4>(sc.dplane[0], sc.dline[0], sc.grid[0], ix, iy, iz, wx, wy, wz, sub);
+                    vm_scatter<4>(tg.dplane[0], tg.dline[0], sc.grid[0], ix, iy, iz, wx, wy, wz, sub, f4_mul(gs, t0.Q), f4_mul(gs, t0.P));
+                    const VmTerm t1 = vm_eval<4>(sc.dplane[1], sc.dline[1], sc.grid[0], ix, iz, iy, wx, wz, wy, sub);
+                    vm_scatter<4>(tg.dplane[1], tg.dline[1], sc.grid[0], ix, iz, iy, wx, wz, wy, sub, f4_mul(gs, t1.Q), f4_mul(gs, t1.P));
+                    const VmTerm t2 = vm_eval<4>(sc.dplane[2], sc.dline[2], sc.grid[1], iy, iz, ix, wy, wz, wx, sub);
+                    vm_scatter<4>(tg.dplane[2], tg.dline[2], sc.grid[1], iy, iz, ix, wy, wz, wx, sub, f4_mul(gs, t2.Q), f4_mul(gs, t2.P));
+                }
+            }
+            if (T < eps_T) break;
+        }
+    }
+}
+
+// one thread per (entry, plane, float4 channel group): h[entry][48*plane + 4*q .. +3]
+__global__ __launch_bounds__(256) void app_h_forward_kernel(const SceneDev sc, const float *__restrict__ xyz, const long long m, float *__restrict__ h)
+{
+    const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= m * 36) return;
+    const long long ent = item / 36;
+    const int rem = (int)(item - ent * 36), pl = rem / 12, q = rem - pl * 12;
+    const int ax = kMat[pl][0], bx = kMat[pl][1], vx = kVec[pl];
+    const float fx = unnorm(xyz[ent * 3 + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * 3 + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * 3 + vx], sc.gm1[vx]);
+    const float x0 = floorf(fx), y0 = floorf(fy), l0 = floorf(fl);
+    const VmTerm t = vm_eval<12>(sc.aplane[pl], sc.aline[pl], sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q);
+    *(float4 *)(h + ent * TVR_KAPP + pl * TVR_CA + q * 4) = make_float4(t.P.x * t.Q.x, t.P.y * t.Q.y, t.P.z * t.Q.z, t.P.w * t.Q.w);
+}
+
+__global__ __launch_bounds__(256) void app_h_backward_kernel(const SceneDev sc, const float *__restrict__ xyz, const long long m,
+                                                             const float *__restrict__ dh, TrainGrads tg)
+{
+    const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= m * 36) return;
+    const long long ent = item / 36;
+    const int rem = (int)(item - ent * 36), pl = rem / 12, q = rem - pl * 12;
+    const int ax = kMat[pl][0], bx = kMat[pl][1], vx = kVec[pl];
+    const float fx = unnorm(xyz[ent * 3 + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * 3 + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * 3 + vx], sc.gm1[vx]);
+    const float x0 = floorf(fx), y0 = floorf(fy), l0 = floorf(fl);
+    const VmTerm t = vm_eval<12>(sc.aplane[pl], sc.aline[pl], sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q);
+    const float4 g = *(const float4 *)(dh + ent * TVR_KAPP + pl * TVR_CA + q * 4);
+    // h = P*Q  ->  dP = g*Q, dQ = g*P
+    vm_scatter<12>(tg.aplane[pl], tg.aline[pl], sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q,
+                   make_float4(g.x * t.Q.x, g.y * t.Q.y, g.z * t.Q.z, g.w * t.Q.w), make_float4(g.x * t.P.x, g.y * t.P.y, g.z * t.P.z, g.w * t.P.w));
+}
+
+// packed [H+1][Wp][C] gradient image -> reference (C,H,W) (a line: W == 1, Wp == 1)
+__global__ __launch_bounds__(256) void unpack_grad_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int H, int W, int Wp)
+{
+    const long long total = (long long)C * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const long long t = i / W;
+        const int y = (int)(t % H), c = (int)(t / H);
+        out[i] = in[((size_t)y * Wp + x) * C + c];
+    }
+}
+
+hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T, const MarchOut &mo,
+                                 const float *grad_w, const float *grad_acc, const TrainGrads &tg, hipStream_t stream)
+{
+    const int rpb = 16;
+    hipLaunchKernelGGL(march_backward_kernel, dim3((n_rays + rpb - 1) / rpb), dim3(TB_THREADS), 0, stream, sc, rays, n_rays, S, jitter, eps_T, rpb, mo,
+                       grad_w, grad_acc, tg);
+    return hipGetLastError();
+}
+
+hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream)
+{
+    hipLaunchKernelGGL(app_h_forward_kernel, dim3((unsigned)((m * 36 + 255) / 256)), dim3(256), 0, stream, sc, xyz, m, h);
+    return hipGetLastError();
+}
+
+hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream)
+{
+    hipLaunchKernelGGL(app_h_backward_kernel, dim3((unsigned)((m * 36 + 255) / 256)), dim3(256), 0, stream, sc, xyz, m, dh, tg);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_grad(const float *in, float *out, int C, int H, int W, hipStream_t stream)
+{
+    const int Wp = (W == 1) ? 1 : W + 1;
+    const long long total = (long long)C * H * W;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(unpack_grad_kernel, dim3(grid), dim3(256), 0, stream, in, out, C, H, W, Wp);
+    return hipGetLastError();
+}

@@ -10,7 +10,8 @@ place of jt.Var.  Parameters stay in the reference layout ((1,C,H,W) planes, (1,
 the Python-visible truth; a packed channels-last device copy is refreshed automatically when they change.
 
 There is NO CPU fallback: every compute call goes through the C-ABI and raises if the HIP library is missing.
-Scope this round: inference (no autograd through the kernels), shadingMode 'MLP_Fea', ndc_ray=False.
+Scope this round: shadingMode 'MLP_Fea', ndc_ray=False.  Inference runs entirely in the fused HIP kernels; under autograd
+(training, train.py:225-261) the march and the VM gathers run as HIP kernels forward and backward and the small MLP as library GEMMs.
 """
 from __future__ import annotations
 
@@ -82,7 +83,92 @@ class MLPRender_Fea(torch.nn.Module):
     def forward(self, pts, viewdirs, features):
         if self._owner is None:
             raise L.TvrError("MLPRender_Fea is not attached to a TensorVMSplit field (no packed weights on the device)")
+        if torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.forward_autograd(viewdirs, features)
         return self._owner()._mlp_render(viewdirs, features)
+
+    def forward_autograd(self, viewdirs, features):
+        """tensorBase.py:76-86 as library GEMMs under autograd (training): PE, concat, Linear-ReLU-Linear-ReLU-Linear, sigmoid."""
+        def pe(x, freqs):                                                                       # tensorBase.py:9-15
+            fb = 2 ** torch.arange(freqs, device=x.device, dtype=torch.float32)
+            pts = (x[..., None] * fb).reshape(x.shape[:-1] + (freqs * x.shape[-1],))
+            return torch.cat([torch.sin(pts), torch.cos(pts)], dim=-1)
+        indata = [features, viewdirs]
+        if self.feape > 0:
+            indata += [pe(features, self.feape)]
+        if self.viewpe > 0:
+            indata += [pe(viewdirs, self.viewpe)]
+        return torch.sigmoid(self.mlp(torch.cat(indata, dim=-1)))
+
+
+class _MarchFn(torch.autograd.Function):
+    """Training forward/backward of the march (tvr_march_forward / tvr_march_backward).  Differentiable outputs: the weights of
+    the appearance samples (queue order) and acc_map, w.r.t. the six density factors."""
+
+    @staticmethod
+    def forward(ctx, model, rays, jitter, S, eps_T, *density_params):
+        lib = L.lib()
+        sc = model._ensure_scene()
+        n = rays.shape[0]
+        lay = L.ScratchLayout()
+        L.check(lib.tvr_scratch_describe(n, S, C.byref(lay)), "tvr_scratch_describe")
+        scratch = torch.empty(lay.total, dtype=torch.uint8, device=model.device)      # owned by this call: backward needs it intact
+        depth = torch.empty(n, dtype=torch.float32, device=model.device)
+        L.check(lib.tvr_march_forward(sc, rays.data_ptr(), n, S, None if jitter is None else jitter.data_ptr(), float(eps_T),
+                                      depth.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream_ptr(model.device)), "tvr_march_forward")
+        M = int(scratch[lay.counter:lay.counter + 4].view(torch.int32).item())           # host sync: the queue length sizes what follows
+        q_pos = scratch[lay.q_pos:lay.q_pos + M * 16].view(torch.float32).view(M, 4)
+        w = q_pos[:, 3].clone()
+        xyz = q_pos[:, :3].contiguous()
+        ray_id = scratch[lay.q_ray:lay.q_ray + M * 4].view(torch.int32).long()
+        acc = scratch[lay.acc:lay.acc + n * 4].view(torch.float32).clone()
+        ctx.model, ctx.rays, ctx.jitter, ctx.S, ctx.eps_T, ctx.scratch, ctx.M = model, rays, jitter, S, eps_T, scratch, M
+        ctx.shapes = [p.shape for p in density_params]
+        ctx.mark_non_differentiable(xyz, ray_id, depth)
+        return w, acc, xyz, ray_id, depth
+
+    @staticmethod
+    def backward(ctx, gw, gacc, *_unused):
+        model, lib = ctx.model, L.lib()
+        sc = model._ensure_scene()
+        grads = [torch.empty(sh, dtype=torch.float32, device=model.device) for sh in ctx.shapes]
+        out = L.VmGrads()
+        for i in range(3):
+            out.density_plane[i], out.density_line[i] = grads[i].data_ptr(), grads[3 + i].data_ptr()
+        gs = model._get_grad_scratch()
+        gw = torch.zeros(max(ctx.M, 1), device=model.device) if gw is None else gw.contiguous().float()
+        gacc = torch.zeros(ctx.rays.shape[0], device=model.device) if gacc is None else gacc.contiguous().float()
+        L.check(lib.tvr_march_backward(sc, ctx.rays.data_ptr(), ctx.rays.shape[0], ctx.S, None if ctx.jitter is None else ctx.jitter.data_ptr(),
+                                       float(ctx.eps_T), ctx.scratch.data_ptr(), ctx.scratch.numel(), gw.data_ptr(), gacc.data_ptr(),
+                                       gs.data_ptr(), gs.numel(), C.byref(out), _stream_ptr(model.device)), "tvr_march_backward")
+        return (None, None, None, None, None, *grads)
+
+
+class _AppHFn(torch.autograd.Function):
+    """h [M,144] = bilinear(app_plane)*linear(app_line) at the queue positions, and the scatter-add backward."""
+
+    @staticmethod
+    def forward(ctx, model, xyz, *app_params):
+        sc = model._ensure_scene()
+        h = torch.empty((xyz.shape[0], sum(model.app_n_comp)), dtype=torch.float32, device=model.device)
+        L.check(L.lib().tvr_app_h_forward(sc, xyz.data_ptr(), xyz.shape[0], h.data_ptr(), _stream_ptr(model.device)), "tvr_app_h_forward")
+        ctx.model, ctx.xyz = model, xyz
+        ctx.shapes = [p.shape for p in app_params]
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        model = ctx.model
+        sc = model._ensure_scene()
+        grads = [torch.empty(sh, dtype=torch.float32, device=model.device) for sh in ctx.shapes]
+        out = L.VmGrads()
+        for i in range(3):
+            out.app_plane[i], out.app_line[i] = grads[i].data_ptr(), grads[3 + i].data_ptr()
+        gs = model._get_grad_scratch()
+        dh = dh.contiguous().float()
+        L.check(L.lib().tvr_app_h_backward(sc, ctx.xyz.data_ptr(), ctx.xyz.shape[0], dh.data_ptr(), gs.data_ptr(), gs.numel(), C.byref(out),
+                                           _stream_ptr(model.device)), "tvr_app_h_backward")
+        return (None, None, *grads)
 
 
 class TensorBase(torch.nn.Module):
@@ -194,6 +280,7 @@ class TensorBase(torch.nn.Module):
         if getattr(self, "_scene", None):
             L.lib().tvr_scene_destroy(self._scene)
         self._scene, self._packed, self._sig = None, None, None
+        self._grad_scratch = None
         self._alpha_dirty = True
 
     def __del__(self):
@@ -262,6 +349,27 @@ class TensorBase(torch.nn.Module):
                         "tvr_scene_set_alpha")
             self._alpha_dirty = False
         return self._scene
+
+    def _get_grad_scratch(self) -> torch.Tensor:
+        nbytes = L.lib().tvr_grad_scratch_bytes(self._ensure_scene())
+        if getattr(self, "_grad_scratch", None) is None or self._grad_scratch.numel() < nbytes:
+            self._grad_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._grad_scratch
+
+    def render_rays_autograd(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None):
+        """TensorBase.execute with gradients (train.py:225-261): HIP march / VM-gather kernels forward and backward, the 144->27
+        basis + PE + MLP as library GEMMs under torch autograd, compositing as an index_add over the appearance-sample queue."""
+        rays = _f32c(rays_chunk, self.device)
+        S = int(N_samples) if N_samples > 0 else self.nSamples
+        eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
+        w, acc, xyz, ray_id, depth = _MarchFn.apply(self, rays, jitter, S, eps_T, *self.density_plane, *self.density_line)
+        h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
+        feats = self.basis_mat(h)                                                             # tensoRF.py:244
+        rgb = self.renderModule.forward_autograd(rays[ray_id, 3:6], feats)                    # tensorBase.py:517
+        rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)   # :521
+        if white_bg:
+            rgb_map = rgb_map + (1.0 - acc[:, None])                                          # :524
+        return rgb_map.clamp(0, 1), depth                                                     # :527 (depth under no_grad, :529-531)
 
     def _get_scratch(self, nbytes: int) -> torch.Tensor:
         if self._scratch is None or self._scratch.numel() < nbytes:
@@ -428,10 +536,13 @@ class TensorBase(torch.nn.Module):
                                       "configs render Blender-format scenes with ndc_ray=0")
         jitter = None
         if is_train:
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                raise NotImplementedError("training through the HIP kernels (autograd) is not built yet; call under "
-                                          "torch.no_grad() or with is_train=False")
             jitter = torch.rand(rays_chunk.shape[0], device=self.device)                      # :351-353
+        if is_train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # the training call of train.py:225-226; evaluation calls (is_train=False, renderer.py under no_grad) stay on the
+            # fused inference kernels whatever the grad mode.  render_rays_autograd() gives gradients without jitter.
+            if additional_output:
+                raise NotImplementedError("additional_output=True is an inference-only (no_grad) feature of this build")
+            return self.render_rays_autograd(rays_chunk, white_bg, N_samples, jitter)
         if additional_output:
             rgb_map, depth_map, d = self.render_rays(rays_chunk, white_bg, N_samples, jitter, dense=True)
             return rgb_map, depth_map, d["rgb"], d["sigma"], d["alpha"], d["weight"], d["bg_weight"].view(-1, 1)
@@ -511,6 +622,38 @@ class TensorVMSplit(TensorBase):
         newSize = b_r - t_l
         self.aabb = new_aabb
         self.update_stepSize((int(newSize[0]), int(newSize[1]), int(newSize[2])))
+
+    # ---- regularisers of the training loss (tensoRF.py:177-207), plain torch on the parameters --------------------------
+    def vectorDiffs(self, vector_comps):
+        total = 0
+        for idx in range(len(vector_comps)):
+            n_comp, n_size = vector_comps[idx].shape[1:-1]
+            v = vector_comps[idx].view(n_comp, n_size)
+            dotp = torch.matmul(v, v.transpose(-1, -2))
+            non_diagonal = dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]
+            total = total + torch.mean(torch.abs(non_diagonal))
+        return total
+
+    def vector_comp_diffs(self):
+        return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
+
+    def density_L1(self):
+        total = 0
+        for idx in range(len(self.density_plane)):
+            total = total + torch.mean(torch.abs(self.density_plane[idx])) + torch.mean(torch.abs(self.density_line[idx]))
+        return total
+
+    def TV_loss_density(self, reg):
+        total = 0
+        for idx in range(len(self.density_plane)):
+            total = total + reg(self.density_plane[idx]) * 1e-2
+        return total
+
+    def TV_loss_app(self, reg):
+        total = 0
+        for idx in range(len(self.app_plane)):
+            total = total + reg(self.app_plane[idx]) * 1e-2
+        return total
 
     def load_arrays(self, arrs):
         """Copy a flat array dict (synthetic.make_scene_arrays / oracle layout) into the parameters."""

@@ -1,0 +1,37 @@
+"""Times the training step (forward + backward + Adam) at the reference's settings: TensorVMSplit 300^3, batch 4096 rays,
+nSamples = min(1e6, cal_n_samples(reso, 0.5)) = 1039 (train.py:143-144, utils.py:61-62), MSE + regularisers (train.py:228-251)."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench
+from jittor_myc_nerfs_amd import OctreeRender_trilinear_fast, TVLoss
+m, arrs, A = bench.build_model(torch.device("cuda"))
+with torch.no_grad():                                  # start from a perturbed copy so that gradients are non-trivial
+    for p in m.parameters():
+        p.mul_(0.9)
+fr = bench.frames(A)
+allrays = torch.cat(fr[:4]).cuda()
+with torch.no_grad():
+    teacher, _, _ = bench.build_model(torch.device("cuda"))
+    allrgbs = torch.cat([teacher.render_rays(allrays[i:i + 640000], N_samples=512)[0] for i in range(0, allrays.shape[0], 640000)])
+    del teacher
+nS = int(np.linalg.norm(A["gridSize"]) / 0.5)
+opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
+tv = TVLoss()
+g = torch.Generator(device="cuda").manual_seed(0)
+def step():
+    idx = torch.randint(0, allrays.shape[0], (4096,), device="cuda", generator=g)
+    opt.zero_grad()
+    rgb_map, _, _, _, _ = OctreeRender_trilinear_fast(allrays[idx], m, chunk=4096, N_samples=nS, white_bg=True, is_train=True)
+    loss = torch.mean((rgb_map - allrgbs[idx]) ** 2)
+    total = loss + 1e-4 * m.vector_comp_diffs() + 8e-5 * m.density_L1() + 0.1 * m.TV_loss_density(tv) + 0.01 * m.TV_loss_app(tv)
+    total.backward()
+    opt.step()
+    return loss
+for _ in range(3): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+N = 20
+for _ in range(N): l = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
+print(f"train step: {dt * 1e3:.2f} ms  ({1 / dt:.1f} it/s), batch 4096 rays x {nS} samples, loss {float(l.detach()):.3e}")
