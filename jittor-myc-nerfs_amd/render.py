@@ -15,16 +15,42 @@ from typing import Callable, Optional, Tuple
 import torch
 
 
+_INFER_SCRATCH_BUDGET = 16 << 30        # bytes of queue scratch an inference call may use (40 B per ray-sample, worst case)
+
+
 def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray=False, white_bg=True, is_train=False,
                                 device='cuda'):
-    rgbs, depth_maps = [], []
+    """tensorf-myc/renderer.py:12-27.  `chunk` bounds memory in the reference (every chunk materialises [chunk,S,3] tensors and
+    is followed by a host sync, :23-25).  Here a chunk is one enqueue of three kernels with no host sync, and per-ray results
+    do not depend on how rays are batched (tested bit for bit), so inference merges chunks up to a scratch budget — the
+    reference's evaluation() passes chunk=1024 (625 calls per 800x800 frame), which would otherwise be host-bound.  Training
+    calls (is_train under autograd) keep the caller's chunk: there it is the optimisation batch."""
     N_rays_all = rays.shape[0]
+    if not (is_train and torch.is_grad_enabled()) and N_rays_all > chunk:
+        S = N_samples if N_samples > 0 else getattr(tensorf, "nSamples", 1024)
+        cap = min(_INFER_SCRATCH_BUDGET // (40 * S), ((1 << 32) - 1) // S)
+        chunk = max(chunk, min(N_rays_all, (cap // 4096) * 4096 if cap >= 4096 else cap))
+    rgbs, depth_maps = [], []
     for chunk_idx in range(N_rays_all // chunk + int(N_rays_all % chunk > 0)):
         rays_chunk = rays[chunk_idx * chunk:(chunk_idx + 1) * chunk]
         rgb_map, depth_map = tensorf(rays_chunk, is_train=is_train, white_bg=white_bg, ndc_ray=ndc_ray, N_samples=N_samples)
         rgbs.append(rgb_map)
         depth_maps.append(depth_map)
     return torch.cat(rgbs), None, torch.cat(depth_maps), None, None
+
+
+def N_to_reso(n_voxels, bbox):
+    """tensorf-myc/utils.py:56-59: grid resolution for a voxel budget inside an aabb."""
+    xyz_min, xyz_max = bbox
+    xyz_min, xyz_max = torch.as_tensor(xyz_min, dtype=torch.float32), torch.as_tensor(xyz_max, dtype=torch.float32)
+    voxel_size = ((xyz_max - xyz_min).prod() / n_voxels).pow(1 / 3)
+    return ((xyz_max - xyz_min) / voxel_size).long().tolist()
+
+
+def cal_n_samples(reso, step_ratio=0.5):
+    """tensorf-myc/utils.py:61-62."""
+    import numpy as np
+    return int(np.linalg.norm(reso) / step_ratio)
 
 
 def shard_indices(n_rays: int, rank: int, world: int, tile: int = 4096) -> torch.Tensor:

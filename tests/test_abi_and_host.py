@@ -135,3 +135,33 @@ def test_checkpoint_save_load_roundtrip(tmp_path, tiny_arrays, hyper_tiny):
     assert np.array_equal(m2.alphaMask.alpha_volume.numpy().reshape(6, 5, 4), vol)
     assert m2.nSamples == m.nSamples and float(m2.stepSize) == float(m.stepSize)
     assert m2.get_kwargs()["gridSize"] == m.get_kwargs()["gridSize"]
+
+
+def test_grid_sizing_helpers_match_survey_appendix_c():
+    from jittor_myc_nerfs_amd import N_to_reso, cal_n_samples
+    assert N_to_reso(2097156, ([-5.0] * 3, [5.0] * 3)) == [128, 128, 128]
+    assert N_to_reso(27000000, ([-1.5] * 3, [1.5] * 3)) == [300, 300, 300]
+    assert cal_n_samples([128, 128, 128], 0.5) == 443 and cal_n_samples([300, 300, 300], 0.5) == 1039
+
+
+def test_renderer_merges_inference_chunks_but_not_training_batches():
+    """OctreeRender_trilinear_fast: evaluation()'s chunk=1024 must not turn into 625 host-bound calls; training keeps its batch."""
+    from jittor_myc_nerfs_amd import OctreeRender_trilinear_fast
+    calls = []
+
+    class Fake:
+        nSamples = 512
+        def __call__(self, rays_chunk, is_train=False, white_bg=True, ndc_ray=False, N_samples=-1):
+            calls.append(rays_chunk.shape[0])
+            return rays_chunk[:, :3], rays_chunk[:, 0]
+    rays = torch.zeros(10000, 6)
+    with torch.no_grad():
+        rgb, _, depth, _, _ = OctreeRender_trilinear_fast(rays, Fake(), chunk=1024, N_samples=512, device="cpu")
+    assert calls == [10000] and rgb.shape == (10000, 3) and depth.shape == (10000,)
+    calls.clear()
+    OctreeRender_trilinear_fast(rays, Fake(), chunk=4096, N_samples=512, is_train=True, device="cpu")      # grad enabled: training batch
+    assert calls == [4096, 4096, 1808]
+    calls.clear()
+    with torch.no_grad():
+        OctreeRender_trilinear_fast(torch.zeros(3_000_000, 6), Fake(), chunk=1024, N_samples=1036, device="cpu")
+    assert len(calls) > 1 and max(calls) * 1036 * 40 <= 16 << 30 and sum(calls) == 3_000_000
