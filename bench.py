@@ -30,12 +30,12 @@ N_POSES = 8
 TILE = 4096
 
 
-def build_model(device):
-    from jittor_myc_nerfs_amd import TensorVMSplit, synthetic
+def build_model(device, name="TensorVMSplit"):
+    from jittor_myc_nerfs_amd import REFTensoRF, TensorVMSplit, synthetic
     A = synthetic.SCENE_A
-    arrs = synthetic.make_scene_arrays(A["gridSize"], A["aabb"])
+    arrs = synthetic.make_scene_arrays(A["gridSize"], A["aabb"], ref=(name == "REFTensoRF"))
     H = synthetic.HYPER
-    m = TensorVMSplit(arrs["aabb"], A["gridSize"], device, density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, app_dim=27,
+    m = (REFTensoRF if name == "REFTensoRF" else TensorVMSplit)(arrs["aabb"], A["gridSize"], device, density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, app_dim=27,
                       near_far=A["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=H["density_shift"],
                       distance_scale=H["distance_scale"], rayMarch_weight_thres=H["rayMarch_weight_thres"], pos_pe=6,
                       view_pe=2, fea_pe=2, featureC=128, step_ratio=A["step_ratio"], fea2denseAct=H["fea2denseAct"])
@@ -62,7 +62,7 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("TVR_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(arrs, A, rays_cpu, budget_s=15.0):
+def cpu_baseline(arrs, A, rays_cpu, budget_s=15.0, with_c=True):
     """Restated CPU path (oracle (a): the reference's op sequence on torch CPU, chunk 1024 as renderer.py:50), timed on
     a bounded strided sample of the same frame; plus the scalar-C oracle (b) with OpenMP for a second figure."""
     from jittor_myc_nerfs_amd import synthetic
@@ -86,6 +86,8 @@ def cpu_baseline(arrs, A, rays_cpu, budget_s=15.0):
            "sample": f"every {stride}th ray of pose 0: {n} rays x {S} samples in {t:.1f} s; restated CPU path = the reference's "
                      f"op sequence (tensorBase.py:476-536) on torch-CPU fp32, chunk 1024 (oracle/tensorf_oracle.py); "
                      f"Jittor itself cannot run here"}
+    if not with_c:                     # the scalar-C restatement covers TensorVMSplit only
+        return out
     co = CO.COracle(arrs, step=float(sc.stepSize), **hyper)
     n2 = min(n, 8192)
     sample2 = rays_cpu[:: rays_cpu.shape[0] // n2][:n2].numpy()
@@ -108,6 +110,8 @@ def main():
                                                           "configs[3] / train.py batch size)")
     ap.add_argument("--alpha-mask", type=int, default=0, help="build an AlphaGridMask of this resolution with updateAlphaMask first "
                                                                "(the reference does so at iteration 2000/4000); 0 = none")
+    ap.add_argument("--model", choices=["TensorVMSplit", "REFTensoRF"], default="TensorVMSplit",
+                    help="model_name (opt.py:44): TensorVMSplit is the BASELINE workload; REFTensoRF is the variant configs/Scar.txt trains")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,7 +137,7 @@ def main():
 
     from jittor_myc_nerfs_amd import _lib as L, shard_capacity, shard_indices
     import ctypes as C
-    model, arrs, A = build_model(device)
+    model, arrs, A = build_model(device, args.model)
     S = A["N_samples"]
     if args.alpha_mask > 0:
         model.updateAlphaMask((args.alpha_mask,) * 3)
@@ -223,7 +227,7 @@ def main():
     # correction + WRITE_SIZE, KB -> B); only valid for the workload it was collected on (this one)
     pmc = {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and args.model == "TensorVMSplit" and args.alpha_mask == 0:
         try:
             pmc = json.load(open(pmc_path))
         except Exception:
@@ -231,17 +235,20 @@ def main():
     t_march, t_shade = k_ms[0] * 1e-3, k_ms[1] * 1e-3
     FLOP_APP = 8.0e4            # algorithmic FLOP per appearance sample (basis 7 776 + MLP 71 936 + PE)
     FLOP_APP_EXEC = 3 * 2 * (32 * 144 + 128 * 160 + 128 * 128 + 32 * 128)   # executed on the matrix cores: 3 fp16 products, padded
+    if args.model == "REFTensoRF":                                         # + four 144 -> {3,3,1,1} heads, 151-input layer 1
+        FLOP_APP += 2 * 8 * 144 + 2 * 128
+        FLOP_APP_EXEC += 3 * 2 * 32 * 144
     roof_march = {"kernel": "march_kernel<false>", "bound": "hbm", "achieved": march_bytes / t_march / 1e9 if t_march > 0 else None,
                   "peak": 8000.0, "unit": "GB/s", "frac": march_bytes / t_march / 1e9 / 8000.0 if t_march > 0 else None,
                   "traffic": pmc.get("march_hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": march_bytes, "ms": k_ms[0],
                   "note": "40 B/ray + 1152 B per density sample actually evaluated (+32 B per alpha-mask lookup); the 17 MB of density "
                           "factors are L2/Infinity-Cache resident (frac > 1 against HBM): the kernel runs at the L1 (TA) rate"}
-    roof_shade = {"kernel": "shade_kernel<0,0>", "bound": "mfma", "achieved": FLOP_APP * m_app / t_shade / 1e12 if t_shade > 0 else None,
+    roof_shade = {"kernel": "shade_kernel<0,0,%s>" % ("true" if args.model == "REFTensoRF" else "false"), "bound": "mfma", "achieved": FLOP_APP * m_app / t_shade / 1e12 if t_shade > 0 else None,
                   "peak": 2500.0, "unit": "TFLOP/s", "frac": FLOP_APP * m_app / t_shade / 1e12 / 2500.0 if t_shade > 0 else None,
                   "traffic": pmc.get("shade_hbm_bytes_per_launch"), "algorithmic_flops_per_launch": FLOP_APP * m_app, "ms": k_ms[1],
                   "executed_mfma_TFLOPs": FLOP_APP_EXEC * m_app / t_shade / 1e12 if t_shade > 0 else None,
                   "gather_algorithmic_GBps": shade_bytes / t_shade / 1e9 if t_shade > 0 else None,
-                  "note": "80 kFLOP per appearance sample (algorithmic, fp32 semantics) against the dense f16 MFMA peak; the kernel "
+                  "note": f"{FLOP_APP / 1e3:.1f} kFLOP per appearance sample (algorithmic, fp32 semantics) against the dense f16 MFMA peak; the kernel "
                           "executes 3 fp16 products per fp32 product (hi/lo split, fp32-class accuracy) on padded tiles = "
                           f"{FLOP_APP_EXEC} FLOP per sample, and gathers 3456 B per sample through L1"}
     dominant = roof_shade if k_ms[1] >= k_ms[0] else roof_march
@@ -249,7 +256,9 @@ def main():
         "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "TensorVMSplit 300^3 (16/48 comps, MLP_Fea 150-128-128-3), 800x800 rays x 512 samples/ray per GPU "
+        "config": {"workload": ("TensorVMSplit 300^3 (16/48 comps, MLP_Fea 150-128-128-3)" if args.model == "TensorVMSplit" else
+                                "REFTensoRF 300^3 (16/48 comps, 4 heads on h, MLP_Fea_Ref 151-128-128-3)") +
+                               ", 800x800 rays x 512 samples/ray per GPU "
                                "(BASELINE configs[1]; N>1: configs[2] as N frames, 4096-ray tiles round-robin, one RCCL all_gather "
                                "of [rays,4] fp32)", "scene": "synthetic scene A (SURVEY 8d), no alpha mask, white_bg",
                    "rays_per_step": total_rays, "samples_per_ray": S,
@@ -265,7 +274,7 @@ def main():
         "roofline_all": {"march": roof_march, "shade": roof_shade},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(arrs, A, fr[0])
+        result["cpu_baseline"] = cpu_baseline(arrs, A, fr[0], with_c=(args.model == "TensorVMSplit"))
     elif rank == 0:
         result["cpu_baseline"] = None
     L.lib().tvr_profile_destroy(prof)

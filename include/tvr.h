@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 100
+#define TVR_VERSION 101
 
 typedef enum {
     TVR_OK = 0,
@@ -53,6 +53,7 @@ typedef struct {
     float distance_scale;          /* 25 */
     float weight_thres;            /* rayMarch_weight_thres 1e-4 */
     int32_t fea2dense_act;         /* 0 softplus, 1 relu (:444-448) */
+    int32_t variant;               /* 0 TensorVMSplit (models/tensoRF.py:141), 1 REFTensoRF (models/REFTensoRF.py:64) */
 } tvr_scene_desc;
 
 /* Device pointers to the parameters in the REFERENCE layout (tensoRF.py:154-164, tensorBase.py:69-71):
@@ -61,7 +62,10 @@ typedef struct {
     const float *density_plane[3], *density_line[3];
     const float *app_plane[3], *app_line[3];
     const float *basis_mat;              /* [app_dim, 144] */
-    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    const float *W1, *b1, *W2, *b2, *W3, *b3;   /* W1 [128,150]; variant 1: [128,151] (MLPRender_Fea_Ref, REFTensoRF.py:9-16) */
+    /* variant 1 only (REFTensoRF.init_svd_volume, REFTensoRF.py:86-96): normal_linear [3,144], diffuse_linear [3,144],
+     * specular_linear [1,144], rho_linear [1,144] and their biases, in that order */
+    const float *ref_W[4], *ref_b[4];
 } tvr_scene_params;
 
 /* Optional per-sample outputs (additional_output=True of TensorBase.execute, tensorBase.py:533-534,
@@ -101,7 +105,8 @@ int tvr_scene_set_alpha(tvr_scene *scene, const float *alpha_volume_dev, const i
                         const float alpha_aabb[6], const float alpha_inv_size[3]);
 int tvr_scene_destroy(tvr_scene *scene);
 
-/* TensorBase.execute over a ray batch (tensorBase.py:476-536, ndc_ray=False) as called by
+/* TensorBase.execute over a ray batch (tensorBase.py:476-536, ndc_ray=False; variant 1: REFTensoRF.execute,
+ * models/REFTensoRF.py:174-256, without the training-only normal penalty) as called by
  * OctreeRender_trilinear_fast (tensorf-myc/renderer.py:12-27).
  *   rays [n,6] (o,d); jitter [n] or NULL (is_train: one u per ray, tensorBase.py:351-353);
  *   eps_T: stop a ray once transmittance < eps_T (0 = exact, never stop); must be <= weight_thres;
@@ -118,6 +123,13 @@ int tvr_density_feature(tvr_scene *scene, const float *xyz_norm, int64_t m, floa
 int tvr_app_feature(tvr_scene *scene, const float *xyz_norm, int64_t m, float *out, void *stream);
 /* MLPRender_Fea.execute (tensorBase.py:76-86): viewdirs [m,3], features [m,app_dim] -> rgb [m,3]. */
 int tvr_mlp_render(tvr_scene *scene, const float *viewdirs, const float *features, int64_t m, float *rgb, void *stream);
+/* REFTensoRF.compute_appfeature (models/REFTensoRF.py:107-133), variant-1 scenes: xyz_norm [m,3] -> features [m,app_dim] and
+ * extra [m,8] = {normal_vector 3 (not normalised), rgb_d 3, relu(specular_tint), relu(rho)}. */
+int tvr_app_feature_ref(tvr_scene *scene, const float *xyz_norm, int64_t m, float *features, float *extra, void *stream);
+/* MLPRender_Fea_Ref.execute (models/REFTensoRF.py:18-28), variant-1 scenes: viewdirs [m,3] (the reflection directions),
+ * features [m,app_dim], dot_product [m] -> sigmoid rgb [m,3]. */
+int tvr_mlp_render_ref(tvr_scene *scene, const float *viewdirs, const float *features, const float *dot_product, int64_t m,
+                       float *rgb, void *stream);
 /* AlphaGridMask.sample_alpha (tensorBase.py:50-56): xyz [m,3] (world) -> out [m].  Stand-alone (the reference's
  * AlphaGridMask is its own module): volume (gz,gy,gx) fp32, grid (gx,gy,gz), aabb, invgridSize = 1/size*2 (:46). */
 int tvr_alpha_sample(const float *alpha_volume_dev, const int32_t agrid_xyz[3], const float alpha_aabb[6],

@@ -16,14 +16,15 @@ class SceneDesc(C.Structure):
                 ("app_n_comp", C.c_int32 * 3), ("app_dim", C.c_int32), ("featureC", C.c_int32),
                 ("view_pe", C.c_int32), ("fea_pe", C.c_int32), ("near_", C.c_float), ("far_", C.c_float),
                 ("step_size", C.c_float), ("inv_aabb_size", C.c_float * 3), ("density_shift", C.c_float),
-                ("distance_scale", C.c_float), ("weight_thres", C.c_float), ("fea2dense_act", C.c_int32)]
+                ("distance_scale", C.c_float), ("weight_thres", C.c_float), ("fea2dense_act", C.c_int32),
+                ("variant", C.c_int32)]
 
 
 class SceneParams(C.Structure):
     _fields_ = [("density_plane", C.c_void_p * 3), ("density_line", C.c_void_p * 3),
                 ("app_plane", C.c_void_p * 3), ("app_line", C.c_void_p * 3), ("basis_mat", C.c_void_p),
                 ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
-                ("W3", C.c_void_p), ("b3", C.c_void_p)]
+                ("W3", C.c_void_p), ("b3", C.c_void_p), ("ref_W", C.c_void_p * 4), ("ref_b", C.c_void_p * 4)]
 
 
 class ScratchLayout(C.Structure):
@@ -56,6 +57,8 @@ SYMBOLS = {
     "tvr_density_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tvr_app_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tvr_mlp_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_app_feature_ref": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvr_mlp_render_ref": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tvr_alpha_sample": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_float * 6), C.POINTER(C.c_float * 3),
                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tvr_scratch_describe": (C.c_int, [C.c_int64, C.c_int32, C.POINTER(ScratchLayout)]),

@@ -48,7 +48,7 @@ static PackedLayout packed_layout(const tvr_scene_desc &d)
         L.aplane[i] = take((H + 1) * (W + 1) * TVR_CA);
         L.aline[i] = take((Ln + 1) * TVR_CA);
     }
-    L.mlp_image = take(TVR_MLP_IMAGE_BYTES / 4);
+    L.mlp_image = take(TVR_MLP_IMAGE_BYTES_REF / 4);
     L.basis_frag = take(TVR_BASIS_FRAG_BYTES / 4);
     L.b3 = take(16);
     L.total = off;
@@ -81,6 +81,7 @@ static int check_desc(const tvr_scene_desc *d)
         return fail(TVR_ERR_UNSUPPORTED, "MLP_Fea shape app_dim=%d featureC=%d view_pe=%d fea_pe=%d; this build supports 27/128/2/2",
                     d->app_dim, d->featureC, d->view_pe, d->fea_pe);
     if (d->fea2dense_act != 0 && d->fea2dense_act != 1) return fail(TVR_ERR_INVALID, "fea2dense_act must be 0 or 1");
+    if (d->variant != 0 && d->variant != 1) return fail(TVR_ERR_INVALID, "variant must be 0 (TensorVMSplit) or 1 (REFTensoRF)");
     if (!(d->step_size > 0.0f)) return fail(TVR_ERR_INVALID, "step_size must be > 0");
     return TVR_OK;
 }
@@ -134,6 +135,7 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
     v.scale = desc->distance_scale;
     v.thres = desc->weight_thres;
     v.act = desc->fea2dense_act;
+    v.variant = desc->variant;
     v.avol = nullptr;
     *out = s;
     return TVR_OK;
@@ -155,13 +157,19 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
     }
     if (!p->basis_mat || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3) return fail(TVR_ERR_INVALID, "MLP pointer is NULL");
     char *img = s->packed + s->lay.mlp_image;
-    HIP_TRY(launch_pack_mlp(p->W1, img + TVR_IMG_W1H, img + TVR_IMG_W1L, 0, stream));
+    HIP_TRY(launch_pack_mlp(p->W1, img + TVR_IMG_W1H, img + TVR_IMG_W1L, d.variant == 1 ? 4 : 0, stream));
     HIP_TRY(launch_pack_mlp(p->W2, img + TVR_IMG_W2H, img + TVR_IMG_W2L, 1, stream));
     HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B1, p->b1, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B2, p->b2, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(launch_pack_mlp(p->basis_mat, s->packed + s->lay.basis_frag, nullptr, 2, stream));
     HIP_TRY(launch_pack_mlp(p->W3, img + TVR_IMG_W3, nullptr, 3, stream));
     HIP_TRY(hipMemcpyAsync(s->packed + s->lay.b3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemsetAsync(img + TVR_MLP_IMAGE_BYTES, 0, TVR_MLP_IMAGE_BYTES_REF - TVR_MLP_IMAGE_BYTES, stream));
+    if (d.variant == 1) {
+        for (int i = 0; i < 4; ++i)
+            if (!p->ref_W[i] || !p->ref_b[i]) return fail(TVR_ERR_INVALID, "REFTensoRF linear %d (normal, diffuse, specular, rho) is NULL", i);
+        HIP_TRY(launch_pack_ref(p->ref_W, p->ref_b, img + TVR_IMG_REFW, (float *)(img + TVR_IMG_REFB), stream));
+    }
     s->params_set = true;
     return TVR_OK;
 }
@@ -427,9 +435,46 @@ int tvr_app_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, void 
     return TVR_OK;
 }
 
+int tvr_app_feature_ref(tvr_scene *s, const float *xyz, int64_t m, float *features, float *extra, void *stream)
+{
+    int rc = scene_ready(s);
+    if (rc != TVR_OK) return rc;
+    if (s->desc.variant != 1) return fail(TVR_ERR_INVALID, "tvr_app_feature_ref needs a REFTensoRF (variant 1) scene");
+    if (m == 0) return TVR_OK;
+    if (!xyz || !features || !extra || m < 0) return fail(TVR_ERR_INVALID, "xyz/features/extra NULL or m < 0");
+    ShadeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.n = m;
+    sa.xyz = xyz;
+    sa.out = features;
+    sa.out2 = extra;
+    HIP_TRY(launch_shade(s->dev, SH_SRC_XYZ, SH_DST_FEAT, sa, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_mlp_render_ref(tvr_scene *s, const float *viewdirs, const float *features, const float *dot_product, int64_t m, float *rgb,
+                       void *stream)
+{
+    int rc = scene_ready(s);
+    if (rc != TVR_OK) return rc;
+    if (s->desc.variant != 1) return fail(TVR_ERR_INVALID, "tvr_mlp_render_ref needs a REFTensoRF (variant 1) scene");
+    if (m == 0) return TVR_OK;
+    if (!viewdirs || !features || !dot_product || !rgb || m < 0) return fail(TVR_ERR_INVALID, "viewdirs/features/dot_product/rgb NULL or m < 0");
+    ShadeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.n = m;
+    sa.viewdirs = viewdirs;
+    sa.feats = features;
+    sa.dots = dot_product;
+    sa.out = rgb;
+    HIP_TRY(launch_shade(s->dev, SH_SRC_FEAT, SH_DST_RGB, sa, (hipStream_t)stream));
+    return TVR_OK;
+}
+
 int tvr_mlp_render(tvr_scene *s, const float *viewdirs, const float *features, int64_t m, float *rgb, void *stream)
 {
     if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
+    if (s->desc.variant != 0) return fail(TVR_ERR_INVALID, "tvr_mlp_render is MLPRender_Fea; a REFTensoRF scene takes tvr_mlp_render_ref");
     if (m == 0) return TVR_OK;
     if (!viewdirs || !features || !rgb || m < 0) return fail(TVR_ERR_INVALID, "viewdirs/features/rgb NULL or m < 0");
     ShadeArgs sa;

@@ -34,6 +34,15 @@
 #define TVR_IMG_W3 (TVR_IMG_B2 + 512)              // [4 rows: W3 rows 0..2 + one zero row][8 k-steps][2 halves][hi 8 | lo 8] fp16
 #define TVR_IMG_W3_ROW 512
 #define TVR_MLP_IMAGE_BYTES (TVR_IMG_W3 + 4 * TVR_IMG_W3_ROW)     // 158 720 B of the 163 840 B LDS
+// REFTensoRF (variant 1) appends the four 144 -> {3,3,1,1} linears of REFTensoRF.compute_appfeature (models/REFTensoRF.py:126-132):
+//   64 zero bytes (they extend W3's zero row to the 576 B of a 9-k-step row), 8 rows [9 k-steps][2 halves][hi 8 | lo 8] fp16
+//   (normal 0..2, specular 3, diffuse 4..6, rho 7) and 16 fp32 biases in accumulator-row order.
+#define TVR_IMG_REF_ZROW (TVR_IMG_W3 + 3 * TVR_IMG_W3_ROW)
+#define TVR_IMG_REFW (TVR_MLP_IMAGE_BYTES + 64)
+#define TVR_IMG_REF_ROW 576
+#define TVR_IMG_REFB (TVR_IMG_REFW + 8 * TVR_IMG_REF_ROW)
+#define TVR_MLP_IMAGE_BYTES_REF (TVR_IMG_REFB + 64)               // 163 456 B
+#define TVR_NIN_REF 151  // 1 + 27 + 3 + 2*2*27 + 2*2*3 (MLPRender_Fea_Ref, models/REFTensoRF.py:9)
 #define TVR_BASIS_FRAG_BYTES (9 * 2 * 32 * 16 * 2)
 
 struct SceneDev {
@@ -44,11 +53,12 @@ struct SceneDev {
     const float4 *dline[3];
     const float4 *aplane[3];
     const float4 *aline[3];
-    const void *mlp_image;        // TVR_MLP_IMAGE_BYTES, copied to LDS by the shade kernel
+    const void *mlp_image;        // TVR_MLP_IMAGE_BYTES(_REF), copied to LDS by the shade kernel
     const void *basis_frag;       // [9][2][32][16] fp16
     const float *b3;              // [3]
     float near_, far_, step, shift, scale, thres;
     int act;
+    int variant;                  // 0 TensorVMSplit, 1 REFTensoRF
     const float *avol;            // (gz,gy,gx) or nullptr
     int ag[3];
     float alo[3], ainv[3], agm1[3];

@@ -39,6 +39,8 @@ struct ShadeArgs {
     const float *viewdirs;     // SRC_FEAT: [n,3]
     const float *feats;        // SRC_FEAT: [n,27]
     float *out;                // DST_FEAT [n,27] / DST_RGB [n,3]
+    const float *dots;         // REFTensoRF, SRC_FEAT: the dot_product input of MLPRender_Fea_Ref [n]
+    float *out2;               // REFTensoRF, DST_FEAT: [n,8] {normal 3, rgb_d 3, specular_tint, rho}
     unsigned long long *stats;
 };
 
@@ -51,6 +53,7 @@ hipError_t launch_alpha_sample(const SceneDev &sc, const float *xyz, long long m
 hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream);
 hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, hipStream_t stream);
 hipError_t launch_pack_mlp(const float *W, void *out_hi, void *out_lo, int mode, hipStream_t stream);
+hipError_t launch_pack_ref(const float *const W[4], const float *const b[4], void *rows, float *bias, hipStream_t stream);
 hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T, const MarchOut &mo,
                                  const float *grad_w, const float *grad_acc, const TrainGrads &tg, hipStream_t stream);
 hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream);

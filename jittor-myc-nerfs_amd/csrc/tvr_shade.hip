@@ -361,16 +361,19 @@ __device__ __forceinline__ void sincos_fast(float x, float &s, float &c)
     c = ((q + 1) & 2) ? -cc : cc;
 }
 
-template <int SRC, int DST>
+// REF = REFTensoRF (models/REFTensoRF.py:107-133, 174-256): a second basis row block gives normal / diffuse / specular / rho from the
+// same h, the view direction is replaced by the reflection about the normalised normal, layer 1 takes one more input (-dot) and the
+// colour is  specular_tint * rgb_s + rgb_d.
+template <int SRC, int DST, bool REF>
 __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e = lane & 31, h = lane >> 5;
-    if (DST != SH_DST_FEAT) {                     // MLP weights -> LDS once per workgroup
+    if (DST != SH_DST_FEAT || REF) {              // MLP weights -> LDS once per workgroup
         const uint4 *src = (const uint4 *)sc.mlp_image;
-        for (int i = tid; i < TVR_MLP_IMAGE_BYTES / 16; i += SH_THREADS) ((uint4 *)smem)[i] = src[i];
+        for (int i = tid; i < (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES) / 16; i += SH_THREADS) ((uint4 *)smem)[i] = src[i];
         __syncthreads();
     }
     const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
@@ -392,8 +395,11 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         bool live[SH_NCB];
         float F[SH_NCB][16];                       // base values: row c = acc_row(r, h) of the feature tile, column = entry
         float dir[SH_NCB][3], wq[SH_NCB];
+        float G[SH_NCB][8];                        // REF: rows acc_row(r, h) of the second block (h=0: normal, tint, rgb_d, rho; h=1: normal)
 #pragma unroll
         for (int cb = 0; cb < SH_NCB; ++cb) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) G[cb][r] = 0.f;
             ent[cb] = tile * SH_TILE + cb * 32 + e;
             live[cb] = ent[cb] < n_total;
             dir[cb][0] = dir[cb][1] = dir[cb][2] = 0.f;
@@ -515,6 +521,34 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             for (int cb = 0; cb < SH_NCB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) F[cb][r] = (accA[cb][r] + accB[cb][r]) + accC[cb][r];
+            if (REF) {
+                // second row block: A from the LDS image (8 weight rows; lanes 4..6 re-read the normal rows so that both lane halves
+                // hold the normal, every other lane reads the zero row), biases as the initial accumulator
+                const int rr = e < 4 ? e : (e < 7 ? e - 4 : ((e >= 8 && e < 12) ? e - 4 : -1));
+                const unsigned char *rowp = rr >= 0 ? smem + TVR_IMG_REFW + rr * TVR_IMG_REF_ROW : smem + TVR_IMG_REF_ZROW;
+                const float4 g0 = *(const float4 *)(smem + TVR_IMG_REFB + 16 * h), g1 = *(const float4 *)(smem + TVR_IMG_REFB + 32 + 16 * h);
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb) {
+                    accA[cb] = f32x16{0}; accB[cb] = f32x16{0}; accC[cb] = f32x16{0};
+                    accA[cb][0] = g0.x; accA[cb][1] = g0.y; accA[cb][2] = g0.z; accA[cb][3] = g0.w;
+                    accA[cb][4] = g1.x; accA[cb][5] = g1.y; accA[cb][6] = g1.z; accA[cb][7] = g1.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    const uint4 *ap = (const uint4 *)(rowp + (s * 2 + h) * 32);
+                    const h8 Ah = __builtin_bit_cast(h8, ap[0]), Al = __builtin_bit_cast(h8, ap[1]);
+#pragma unroll
+                    for (int cb = 0; cb < SH_NCB; ++cb) accA[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s][cb].hi), accA[cb], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < SH_NCB; ++cb) accB[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s][cb].lo), accB[cb], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < SH_NCB; ++cb) accC[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s][cb].hi), accC[cb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int cb = 0; cb < SH_NCB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) G[cb][r] = (accA[cb][r] + accB[cb][r]) + accC[cb][r];
+            }
         } else {
 #pragma unroll
             for (int cb = 0; cb < SH_NCB; ++cb) {
@@ -538,16 +572,38 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         const int c = acc_row(r, h);
                         if (c < TVR_APPDIM) a.out[ent[cb] * TVR_APPDIM + c] = F[cb][r];
                     }
+                    if (REF && h == 0 && a.out2) {       // REFTensoRF.compute_appfeature :126-133 {normal, rgb_d, relu(tint), relu(rho)}
+                        float *o = a.out2 + ent[cb] * 8;
+                        o[0] = G[cb][0]; o[1] = G[cb][1]; o[2] = G[cb][2];
+                        o[3] = G[cb][4]; o[4] = G[cb][5]; o[5] = G[cb][6];
+                        o[6] = fmaxf(G[cb][3], 0.0f); o[7] = fmaxf(G[cb][7], 0.0f);
+                    }
                 }
             continue;
         }
 
         TVR_STAMP(tg2);
         // view direction occupies base rows 27 (h=0, r=15), 28, 29 (h=1, r=12, 13); rows 30, 31 stay zero (zero weights)
+        float dotin[SH_NCB];
 #pragma unroll
         for (int cb = 0; cb < SH_NCB; ++cb) {
+            dotin[cb] = 0.f;
+            if (REF) {
+                if (SRC != SH_SRC_FEAT) {
+                    // REFTensoRF.execute :215-227: normalise the normal, d = -view, dot = d.n, reflection = 2 dot n - d; the MLP
+                    // takes the reflection as its direction and -dot as input 0 (row 30: only its t=0 slot has a weight)
+                    const float nrm = sqrtf(fmaxf((G[cb][0] * G[cb][0] + G[cb][1] * G[cb][1]) + G[cb][2] * G[cb][2], 1e-30f));
+                    const float nx = G[cb][0] / nrm, ny = G[cb][1] / nrm, nz = G[cb][2] / nrm;
+                    const float dx = -dir[cb][0], dy = -dir[cb][1], dz = -dir[cb][2];
+                    const float dot = (dx * nx + dy * ny) + dz * nz;
+                    dir[cb][0] = 2.0f * dot * nx - dx; dir[cb][1] = 2.0f * dot * ny - dy; dir[cb][2] = 2.0f * dot * nz - dz;
+                    dotin[cb] = -dot;
+                } else if (live[cb]) {
+                    dotin[cb] = a.dots[ent[cb]];
+                }
+            }
             if (h == 0) F[cb][15] = dir[cb][0];
-            else { F[cb][12] = dir[cb][1]; F[cb][13] = dir[cb][2]; F[cb][14] = 0.f; F[cb][15] = 0.f; }
+            else { F[cb][12] = dir[cb][1]; F[cb][13] = dir[cb][2]; F[cb][14] = dotin[cb]; F[cb][15] = 0.f; }
         }
 
         // ---- layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5 ----
@@ -692,7 +748,11 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
         for (int cb = 0; cb < SH_NCB; ++cb) {
             // every lane reads the last accumulator (drains this wave's MFMAs before the next tile's global loads)
-            const float r0 = sigmoid_f(acc3[cb][0]), r1 = sigmoid_f(acc3[cb][1]), r2 = sigmoid_f(acc3[cb][2]);
+            float r0 = sigmoid_f(acc3[cb][0]), r1 = sigmoid_f(acc3[cb][1]), r2 = sigmoid_f(acc3[cb][2]);
+            if (REF && SRC != SH_SRC_FEAT) {           // :232  specular_tint * clamp(rgb_s, 0) + rgb_d
+                const float tint = fmaxf(G[cb][3], 0.0f);
+                r0 = tint * fmaxf(r0, 0.0f) + G[cb][4]; r1 = tint * fmaxf(r1, 0.0f) + G[cb][5]; r2 = tint * fmaxf(r2, 0.0f) + G[cb][6];
+            }
             if (live[cb] && h == 0) {
                 if (DST == SH_DST_QUEUE) {
                     a.q_out[ent[cb]] = make_float4(r0, r1, r2, wq[cb]);
@@ -718,25 +778,32 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
 }
 
-template <int SRC, int DST>
+template <int SRC, int DST, bool REF>
 static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
-    const int lds = (DST == SH_DST_FEAT) ? 0 : TVR_MLP_IMAGE_BYTES;
-    (void)hipFuncSetAttribute((const void *)shade_kernel<SRC, DST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int lds = REF ? TVR_MLP_IMAGE_BYTES_REF : ((DST == SH_DST_FEAT) ? 0 : TVR_MLP_IMAGE_BYTES);
+    hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (rc != hipSuccess) return rc;
     unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
     if (SRC != SH_SRC_QUEUE) {
         const long long groups = (a.n + SH_TILE * SH_WAVES - 1) / (SH_TILE * SH_WAVES);
         if (groups < grid) grid = (unsigned)(groups > 0 ? groups : 1);
     }
-    hipLaunchKernelGGL((shade_kernel<SRC, DST>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
+    hipLaunchKernelGGL((shade_kernel<SRC, DST, REF>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
     return hipGetLastError();
 }
 
 hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream)
 {
-    if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE>(sc, a, stream);
-    if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT>(sc, a, stream);
-    if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return launch_shade_t<SH_SRC_FEAT, SH_DST_RGB>(sc, a, stream);
+    if (sc.variant == 1) {
+        if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, true>(sc, a, stream);
+        if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, true>(sc, a, stream);
+        if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, true>(sc, a, stream);
+        return hipErrorInvalidValue;
+    }
+    if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false>(sc, a, stream);
+    if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, false>(sc, a, stream);
+    if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false>(sc, a, stream);
     return hipErrorInvalidValue;
 }
 
@@ -779,11 +846,13 @@ __device__ __forceinline__ int ref_in_index(int c, int t)
 //  mode 1: W2 LDS image  [128][W2_ROW/2 halfs]: kpos = 16s + 8h + j  <->  hidden unit 16s + 8(j>>2) + 4h + (j&3)
 //  mode 2: basis fragments [9][2][32][hi 8 | lo 8]: row r < 27, k = 16s + 8h + j (natural)
 //  mode 3: W3 LDS block    [4][8][2][hi 8 | lo 8]: rows 0..2 of W3 + one zero row, k as mode 1
+//  mode 4: mode 0 for MLPRender_Fea_Ref (REFTensoRF.py:19-24: [dot, features, viewdirs, PE(features), PE(viewdirs)], 151 inputs):
+//          every index moves up by one and base row 30's plain slot carries input 0 (dot)
 __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__ W, unsigned short *__restrict__ out_hi,
                                                        unsigned short *__restrict__ out_lo, int mode)
 {
-    const int nrows = (mode <= 1) ? 128 : (mode == 2 ? 32 : 4);
-    const int K = (mode == 0) ? 160 : (mode == 2 ? 144 : 128);
+    const int nrows = (mode <= 1 || mode == 4) ? 128 : (mode == 2 ? 32 : 4);
+    const int K = (mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : 128);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrows * K) return;
     const int row = i / K, kpos = i - row * K;
@@ -793,6 +862,10 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
         const int ii = 8 * s + j;
         const int idx = ref_in_index(acc_row(ii / 5, hh), ii % 5);
         if (idx >= 0) w = W[(size_t)row * TVR_NIN + idx];
+    } else if (mode == 4) {
+        const int ii = 8 * s + j, c = acc_row(ii / 5, hh), t = ii % 5;
+        const int idx = (c == TVR_APPDIM + 3) ? (t == 0 ? 0 : -1) : (ref_in_index(c, t) >= 0 ? ref_in_index(c, t) + 1 : -1);
+        if (idx >= 0) w = W[(size_t)row * TVR_NIN_REF + idx];
     } else if (mode == 1) {
         w = W[(size_t)row * TVR_FEATC + (16 * s + 8 * (j >> 2) + 4 * hh + (j & 3))];
     } else if (mode == 2) {
@@ -802,7 +875,7 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
     }
     unsigned hi, lo;
     split2(w, 0.0f, hi, lo);
-    if (mode == 0) {
+    if (mode == 0 || mode == 4) {
         out_hi[row * (TVR_IMG_W1_ROW / 2) + kpos] = (unsigned short)hi;
         out_lo[row * (TVR_IMG_W1_ROW / 2) + kpos] = (unsigned short)lo;
     } else if (mode == 1) {
@@ -821,7 +894,41 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
 
 hipError_t launch_pack_mlp(const float *W, void *out_hi, void *out_lo, int mode, hipStream_t stream)
 {
-    const int n = ((mode <= 1) ? 128 : (mode == 2 ? 32 : 4)) * ((mode == 0) ? 160 : (mode == 2 ? 144 : 128));
+    const int n = ((mode <= 1 || mode == 4) ? 128 : (mode == 2 ? 32 : 4)) * ((mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : 128));
     hipLaunchKernelGGL(pack_mlp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, (unsigned short *)out_hi, (unsigned short *)out_lo, mode);
+    return hipGetLastError();
+}
+
+// REFTensoRF's four 144 -> {3,3,1,1} linears -> the 8 LDS rows (normal 0..2, specular 3, diffuse 4..6, rho 7; k natural as mode 2)
+// and the 16 biases in accumulator-row order {n, tint | n, 0 | rgb_d, rho | 0}
+struct RefPtrs { const float *W[4], *b[4]; };      // normal, diffuse, specular, rho
+__global__ __launch_bounds__(256) void pack_ref_kernel(const RefPtrs p, unsigned short *__restrict__ rows, float *__restrict__ bias)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16) {
+        float b = 0.0f;
+        if (i < 3) b = p.b[0][i];
+        else if (i == 3) b = p.b[2][0];
+        else if (i < 7) b = p.b[0][i - 4];
+        else if (i >= 8 && i < 11) b = p.b[1][i - 8];
+        else if (i == 11) b = p.b[3][0];
+        bias[i] = b;
+    }
+    if (i >= 8 * TVR_KAPP) return;
+    const int row = i / TVR_KAPP, kpos = i - row * TVR_KAPP;
+    const int s = kpos >> 4, hh = (kpos >> 3) & 1, j = kpos & 7;
+    const float *src = row < 3 ? p.W[0] + row * TVR_KAPP : (row == 3 ? p.W[2] : (row < 7 ? p.W[1] + (row - 4) * TVR_KAPP : p.W[3]));
+    unsigned hi, lo;
+    split2(src[kpos], 0.0f, hi, lo);
+    unsigned short *o = rows + (size_t)row * (TVR_IMG_REF_ROW / 2) + (s * 2 + hh) * 16;
+    o[j] = (unsigned short)hi;
+    o[8 + j] = (unsigned short)lo;
+}
+
+hipError_t launch_pack_ref(const float *const W[4], const float *const b[4], void *rows, float *bias, hipStream_t stream)
+{
+    RefPtrs p;
+    for (int i = 0; i < 4; ++i) { p.W[i] = W[i]; p.b[i] = b[i]; }
+    hipLaunchKernelGGL(pack_ref_kernel, dim3((8 * TVR_KAPP + 255) / 256), dim3(256), 0, stream, p, (unsigned short *)rows, bias);
     return hipGetLastError();
 }

@@ -89,15 +89,49 @@ class MLPRender_Fea(torch.nn.Module):
 
     def forward_autograd(self, viewdirs, features):
         """tensorBase.py:76-86 as library GEMMs under autograd (training): PE, concat, Linear-ReLU-Linear-ReLU-Linear, sigmoid."""
-        def pe(x, freqs):                                                                       # tensorBase.py:9-15
-            fb = 2 ** torch.arange(freqs, device=x.device, dtype=torch.float32)
-            pts = (x[..., None] * fb).reshape(x.shape[:-1] + (freqs * x.shape[-1],))
-            return torch.cat([torch.sin(pts), torch.cos(pts)], dim=-1)
         indata = [features, viewdirs]
         if self.feape > 0:
-            indata += [pe(features, self.feape)]
+            indata += [_pe(features, self.feape)]
         if self.viewpe > 0:
-            indata += [pe(viewdirs, self.viewpe)]
+            indata += [_pe(viewdirs, self.viewpe)]
+        return torch.sigmoid(self.mlp(torch.cat(indata, dim=-1)))
+
+
+def _pe(x, freqs):                                                                            # tensorBase.py:9-15
+    fb = 2 ** torch.arange(freqs, device=x.device, dtype=torch.float32)
+    pts = (x[..., None] * fb).reshape(x.shape[:-1] + (freqs * x.shape[-1],))
+    return torch.cat([torch.sin(pts), torch.cos(pts)], dim=-1)
+
+
+class MLPRender_Fea_Ref(torch.nn.Module):
+    """REFTensoRF.py:5-28: [dot_product, features, viewdirs, PE(features), PE(viewdirs)] -> Linear-ReLU-Linear-ReLU-Linear -> sigmoid.
+    Parameters only; the arithmetic runs in the shade kernel of the owning REFTensoRF (k, the 1/rho argument, is unused there too)."""
+
+    def __init__(self, inChanel, viewpe=6, feape=6, featureC=128):
+        super().__init__()
+        self.in_mlpC = 2 * viewpe * 3 + 2 * feape * inChanel + 1 + 3 + inChanel
+        self.viewpe, self.feape = viewpe, feape
+        layer1 = torch.nn.Linear(self.in_mlpC, featureC)
+        layer2 = torch.nn.Linear(featureC, featureC)
+        layer3 = torch.nn.Linear(featureC, 3)
+        self.mlp = torch.nn.Sequential(layer1, torch.nn.ReLU(), layer2, torch.nn.ReLU(), layer3)
+        torch.nn.init.constant_(self.mlp[-1].bias, 0)
+        self._owner = None
+
+    def forward(self, pts, viewdirs, features, dot_product, k=None):
+        if self._owner is None:
+            raise L.TvrError("MLPRender_Fea_Ref is not attached to a REFTensoRF field (no packed weights on the device)")
+        if torch.is_grad_enabled() and (features.requires_grad or viewdirs.requires_grad or dot_product.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            return self.forward_autograd(viewdirs, features, dot_product)
+        return self._owner()._mlp_render_ref(viewdirs, features, dot_product)
+
+    def forward_autograd(self, viewdirs, features, dot_product):
+        indata = [dot_product.view(-1, 1), features, viewdirs]
+        if self.feape > 0:
+            indata += [_pe(features, self.feape)]
+        if self.viewpe > 0:
+            indata += [_pe(viewdirs, self.viewpe)]
         return torch.sigmoid(self.mlp(torch.cat(indata, dim=-1)))
 
 
@@ -289,10 +323,17 @@ class TensorBase(torch.nn.Module):
         except Exception:
             pass
 
+    _variant = 0                  # tvr_scene_desc.variant
+    def _extra_linears(self):     # variant 1: (normal, diffuse, specular, rho) Linear modules
+        return []
+
     def _param_list(self):
         m = self.renderModule.mlp
-        return (list(self.density_plane) + list(self.density_line) + list(self.app_plane) + list(self.app_line)
-                + [self.basis_mat.weight, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias])
+        ps = (list(self.density_plane) + list(self.density_line) + list(self.app_plane) + list(self.app_line)
+              + [self.basis_mat.weight, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias])
+        for lin in self._extra_linears():
+            ps += [lin.weight, lin.bias]
+        return ps
 
     def _ensure_scene(self):
         """Create the tvr_scene on first use and re-pack whenever a parameter tensor was replaced or written in place."""
@@ -315,6 +356,7 @@ class TensorBase(torch.nn.Module):
             d.density_shift, d.distance_scale = float(self.density_shift), float(self.distance_scale)
             d.weight_thres = float(self.rayMarch_weight_thres)
             d.fea2dense_act = 0 if self.fea2denseAct == "softplus" else 1
+            d.variant = self._variant
             nbytes = lib.tvr_scene_packed_bytes(C.byref(d))
             if nbytes == 0:
                 raise L.TvrError("unsupported field configuration: " + lib.tvr_last_error().decode())
@@ -337,6 +379,8 @@ class TensorBase(torch.nn.Module):
             sp.W1, sp.b1 = m[0].weight.data_ptr(), m[0].bias.data_ptr()
             sp.W2, sp.b2 = m[2].weight.data_ptr(), m[2].bias.data_ptr()
             sp.W3, sp.b3 = m[4].weight.data_ptr(), m[4].bias.data_ptr()
+            for i, lin in enumerate(self._extra_linears()):
+                sp.ref_W[i], sp.ref_b[i] = lin.weight.data_ptr(), lin.bias.data_ptr()
             L.check(lib.tvr_scene_update(self._scene, C.byref(sp), _stream_ptr(self.device)), "tvr_scene_update")
             self._sig = sig
         if self._alpha_dirty:
@@ -670,4 +714,110 @@ class TensorVMSplit(TensorBase):
                 m[idx].bias.copy_(torch.as_tensor(arrs[b]))
         if "alpha_volume" in arrs:
             self.alphaMask = AlphaGridMask(self.device, arrs["alpha_aabb"], torch.as_tensor(arrs["alpha_volume"]))
+        return self
+
+
+class REFTensoRF(TensorVMSplit):
+    """models/REFTensoRF.py:64-256 — the Ref-NeRF-style variant configs/Scar.txt trains: four extra Linears on the 144-wide plane*line
+    product give a normal, a diffuse colour, a specular tint and a roughness; the MLP sees the reflection direction and -dot.
+    Inference runs in the same fused HIP kernels (tvr_scene_desc.variant = 1); training as TensorVMSplit's (HIP march / gather
+    kernels forward + backward, the small dense algebra under torch autograd)."""
+
+    _variant = 1
+
+    def __init__(self, aabb, gridSize, device, **kargs):
+        super().__init__(aabb, gridSize, device, **kargs)
+        self.norm_n_comp = self.density_n_comp                                                # :67
+        self.penalty = torch.zeros((), device=self.device)                                    # :68
+
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):      # :70-77
+        if shadingMode != 'MLP_Fea':
+            raise NotImplementedError(f"shadingMode {shadingMode!r}: only 'MLP_Fea' (MLPRender_Fea_Ref; what configs/Scar.txt uses) "
+                                      "is on the accelerated render path")
+        self.renderModule = MLPRender_Fea_Ref(self.app_dim, view_pe, fea_pe, featureC)
+        import weakref
+        self.renderModule._owner = weakref.ref(self)
+
+    def init_svd_volume(self, res, device):                                                   # :80-96
+        super().init_svd_volume(res, device)
+        k = sum(self.app_n_comp)
+        self.normal_linear = torch.nn.Linear(k, 3)
+        self.diffuse_linear = torch.nn.Linear(k, 3)
+        self.specular_linear = torch.nn.Linear(k, 1)
+        self.rho_linear = torch.nn.Linear(k, 1)
+
+    def _extra_linears(self):
+        return [self.normal_linear, self.diffuse_linear, self.specular_linear, self.rho_linear]
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):            # :99-106
+        grad_vars = super().get_optparam_groups(lr_init_spatialxyz, lr_init_network)
+        grad_vars += [{'params': self.normal_linear.parameters(), 'lr': lr_init_network},
+                      {'params': self.diffuse_linear.parameters(), 'lr': lr_init_network},
+                      {'params': self.rho_linear.parameters(), 'lr': lr_init_network},
+                      {'params': self.specular_linear.parameters(), 'lr': lr_init_network}]
+        return grad_vars
+
+    def _heads(self, h):                                                                      # :125-133
+        return (self.basis_mat(h), self.diffuse_linear(h), torch.relu(self.specular_linear(h)), self.normal_linear(h),
+                torch.relu(self.rho_linear(h)))
+
+    def compute_appfeature(self, xyz_sampled):                                                # :107-133
+        """-> (appfeatures [M,27], rgb_d [M,3], specular_tint [M,1], normal_vector [M,3], rho [M,1])"""
+        sc = self._ensure_scene()
+        x = _f32c(xyz_sampled, self.device).view(-1, 3)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._heads(_AppHFn.apply(self, x, *self.app_plane, *self.app_line))
+        feats = torch.empty((x.shape[0], self.app_dim), dtype=torch.float32, device=self.device)
+        extra = torch.empty((x.shape[0], 8), dtype=torch.float32, device=self.device)
+        L.check(L.lib().tvr_app_feature_ref(sc, x.data_ptr(), x.shape[0], feats.data_ptr(), extra.data_ptr(), _stream_ptr(self.device)),
+                "tvr_app_feature_ref")
+        return feats, extra[:, 3:6], extra[:, 6:7], extra[:, 0:3], extra[:, 7:8]
+
+    def _mlp_render(self, viewdirs, features):
+        raise L.TvrError("REFTensoRF shades with MLPRender_Fea_Ref: call renderModule(pts, reflection, features, dot_product, k)")
+
+    def _mlp_render_ref(self, viewdirs, features, dot_product):
+        sc = self._ensure_scene()
+        v = _f32c(viewdirs, self.device).view(-1, 3)
+        f = _f32c(features, self.device).view(-1, self.app_dim)
+        d = _f32c(dot_product, self.device).view(-1)
+        if d.shape[0] != v.shape[0] or f.shape[0] != v.shape[0]:
+            raise ValueError("viewdirs, features and dot_product must describe the same samples")
+        out = torch.empty((v.shape[0], 3), dtype=torch.float32, device=self.device)
+        L.check(L.lib().tvr_mlp_render_ref(sc, v.data_ptr(), f.data_ptr(), d.data_ptr(), v.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+                "tvr_mlp_render_ref")
+        return out
+
+    @staticmethod
+    def _normalize(x):
+        """jt.normalize(x, dim=-1) (Jittor misc.py: x / sqrt(max(sum x^2, eps)), eps = 1e-30)"""
+        return x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-30))
+
+    def render_rays_autograd(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None):
+        """REFTensoRF.execute with gradients (:174-256); also sets self.penalty (:240-243) for train.py:253-257."""
+        rays = _f32c(rays_chunk, self.device)
+        S = int(N_samples) if N_samples > 0 else self.nSamples
+        eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
+        w, acc, xyz, ray_id, depth = _MarchFn.apply(self, rays, jitter, S, eps_T, *self.density_plane, *self.density_line)
+        h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
+        app_features, rgb_d, specular_tint, normal_vector, rho = self._heads(h)
+        normal_vector = self._normalize(normal_vector)                                        # :217
+        d = -rays[ray_id, 3:6]                                                                # :219
+        dot_product = (d * normal_vector).sum(dim=1, keepdim=True)                            # :221-223
+        reflection = 2 * dot_product * normal_vector - d                                      # :225
+        rgb_s = self.renderModule.forward_autograd(reflection, app_features, -dot_product)    # :229
+        rgb = specular_tint * rgb_s.clamp(min=0) + rgb_d                                      # :232
+        penalty = torch.relu(-dot_product).square().squeeze(-1)                               # :237-238
+        self.penalty = torch.sum(w * penalty, -1)                                             # :239
+        rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)
+        if white_bg:
+            rgb_map = rgb_map + (1.0 - acc[:, None])
+        return rgb_map.clamp(0, 1), depth
+
+    def load_arrays(self, arrs):
+        super().load_arrays(arrs)
+        with torch.no_grad():
+            for name, lin in zip(("normal", "diffuse", "specular", "rho"), self._extra_linears()):
+                lin.weight.copy_(torch.as_tensor(arrs[f"{name}_W"]))
+                lin.bias.copy_(torch.as_tensor(arrs[f"{name}_b"]))
         return self

@@ -27,8 +27,10 @@ def _g(n: int, sigma: float) -> np.ndarray:
 def make_scene_arrays(gridSize: Sequence[int], aabb, seed: int = SEED,
                       density_n_comp=(16, 16, 16), appearance_n_comp=(48, 48, 48), app_dim: int = 27,
                       featureC: int = 128, view_pe: int = 2, fea_pe: int = 2, blob_sigma: float = 0.35,
-                      alpha_grid: Optional[Sequence[int]] = None) -> Dict[str, np.ndarray]:
-    """Return a flat dict of fp32 arrays in the reference's parameter layout."""
+                      alpha_grid: Optional[Sequence[int]] = None, ref: bool = False) -> Dict[str, np.ndarray]:
+    """Return a flat dict of fp32 arrays in the reference's parameter layout.  ref=True adds REFTensoRF's parameters
+    (models/REFTensoRF.py:86-96 and the 151-input W1 of MLPRender_Fea_Ref) from a second generator, so that the arrays shared
+    with the TensorVMSplit scene of the same seed are identical."""
     rng = np.random.default_rng(seed)
     g = [int(x) for x in gridSize]
     out: Dict[str, np.ndarray] = {"aabb": np.asarray(aabb, np.float32).reshape(2, 3), "gridSize": np.asarray(g, np.int32)}
@@ -60,6 +62,18 @@ def make_scene_arrays(gridSize: Sequence[int], aabb, seed: int = SEED,
     out["W1"], out["b1"] = U((featureC, nin), nin), U((featureC,), nin)
     out["W2"], out["b2"] = U((featureC, featureC), featureC), U((featureC,), featureC)
     out["W3"], out["b3"] = U((3, featureC), featureC) * np.float32(4.0), np.zeros((3,), np.float32)
+    if ref:
+        r2 = np.random.default_rng(seed + 1)
+
+        def U2(shape, fan_in, scale=1.0):
+            b = 1.0 / np.sqrt(fan_in)
+            return (r2.uniform(-b, b, size=shape) * scale).astype(np.float32)
+        out["W1"], out["b1"] = U2((featureC, nin + 1), nin + 1), U2((featureC,), nin + 1)
+        # h = plane*line is O(1e-2): scale the heads like the basis so that normal / colour / tint vary over the scene
+        out["normal_W"], out["normal_b"] = U2((3, K), K, 64.0), U2((3,), K)
+        out["diffuse_W"], out["diffuse_b"] = U2((3, K), K, 16.0), U2((3,), K) + np.float32(0.3)
+        out["specular_W"], out["specular_b"] = U2((1, K), K, 64.0), U2((1,), K) + np.float32(0.5)
+        out["rho_W"], out["rho_b"] = U2((1, K), K, 64.0), U2((1,), K) + np.float32(0.5)
     if alpha_grid is not None:
         ag = [int(x) for x in alpha_grid]                      # (gx, gy, gz); volume stored (gz, gy, gx)
         zs, ys, xs = [np.linspace(-1, 1, n) for n in (ag[2], ag[1], ag[0])]

@@ -58,10 +58,25 @@ def tiny_arrays(tiny_dump):
     return {k[len("scene."):]: v for k, v in tiny_dump.items() if k.startswith("scene.")}
 
 
+@pytest.fixture(scope="session")
+def tiny_ref():
+    return dict(np.load(os.path.join(GOLDEN, "tiny_ref.npz")))
+
+
+@pytest.fixture(scope="session")
+def tiny_ref_arrays(tiny_arrays, tiny_ref):
+    """REFTensoRF parameters: the tiny scene's VM factors / basis / W2 / W3 plus the arrays tiny_ref.npz adds or replaces."""
+    a = dict(tiny_arrays)
+    a.update({k[len("scene."):]: v for k, v in tiny_ref.items() if k.startswith("scene.")})
+    return a
+
+
 def make_model(arrs, hyper, device="cuda", gridSize=None, aabb=None):
-    """TensorVMSplit on `device` holding the given arrays (reference constructor signature, train.py:167-172)."""
-    from jittor_myc_nerfs_amd import TensorVMSplit
-    m = TensorVMSplit(arrs["aabb"] if aabb is None else aabb, [int(x) for x in (arrs["gridSize"] if gridSize is None else gridSize)],
+    """TensorVMSplit (REFTensoRF when the arrays hold its extra linears) on `device` holding the given arrays (reference
+    constructor signature, train.py:167-172)."""
+    from jittor_myc_nerfs_amd import REFTensoRF, TensorVMSplit
+    cls = REFTensoRF if "normal_W" in arrs else TensorVMSplit
+    m = cls(arrs["aabb"] if aabb is None else aabb, [int(x) for x in (arrs["gridSize"] if gridSize is None else gridSize)],
                       device, density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
                       near_far=hyper["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4,
                       density_shift=hyper["density_shift"], distance_scale=hyper["distance_scale"],

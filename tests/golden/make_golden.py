@@ -29,9 +29,42 @@ def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def tiny_scene(alpha=False):
+def tiny_scene(alpha=False, ref=False):
     return synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=TINY["seed"],
-                                       alpha_grid=[12, 10, 14] if alpha else None)
+                                       alpha_grid=[12, 10, 14] if alpha else None, ref=ref)
+
+REF_KEYS = ("W1", "b1") + tuple(f"{n}_{s}" for n in ("normal", "diffuse", "specular", "rho") for s in ("W", "b"))
+
+
+def main_ref(hyper):
+    """(iv) REFTensoRF (models/REFTensoRF.py) on the tiny scene: the arrays it adds to tiny_dump's scene, the full render,
+    the appearance-branch intermediates at the shaded samples, and one masked + jittered + black-background variant."""
+    arrs = tiny_scene(ref=True)
+    sc = TO.scene_from_arrays(arrs, **hyper)
+    rays = tiny_rays()
+    d = dump_to_np(TO.execute(sc, rays, white_bg=True, N_samples=TINY["N_samples"], dump=True))
+    am = torch.tensor(d["app_mask"].astype(bool))
+    xyz_n = torch.tensor(d["xyz_norm"])[am]
+    dirs = rays[:, None, 3:6].expand(-1, TINY["N_samples"], -1)[am]
+    f, rgb_d, tint, normal, rho = TO.compute_appfeature_ref(sc, xyz_n)
+    nn = TO.jt_normalize(normal)
+    dot = ((-dirs) * nn).sum(1, keepdim=True)
+    refl = 2 * dot * nn - (-dirs)
+    rgb_s, mlp_in = TO.mlp_render_fea_ref(sc, refl, f, -dot, return_in=True)
+    out = dict(rays=rays.numpy(), rgb_map=d["rgb_map"], depth_map=d["depth_map"], acc_map=d["acc_map"], app_mask=d["app_mask"],
+               rgb=d["rgb"], weight=d["weight"], penalty=np.float32(sc.penalty.item()),
+               app_xyz_norm=xyz_n.numpy(), app_dirs=dirs.numpy(), app_feature=f.numpy(), rgb_d=rgb_d.numpy(), specular_tint=tint.numpy(),
+               normal_vector=normal.numpy(), rho=rho.numpy(), reflection=refl.numpy(), dot_product=dot.numpy(), mlp_in=mlp_in.numpy(),
+               rgb_s=rgb_s.numpy(), **{f"scene.{k}": arrs[k] for k in REF_KEYS})
+    arrs_a = tiny_scene(alpha=True, ref=True)
+    jit = np.random.default_rng(5).random(rays.shape[0]).astype(np.float32)
+    sca = TO.scene_from_arrays(arrs_a, **hyper)
+    da = dump_to_np(TO.execute(sca, rays, white_bg=False, N_samples=TINY["N_samples"], jitter=jit, dump=True))
+    out.update({"wb0_am1_jit.jitter": jit, "wb0_am1_jit.rgb_map": da["rgb_map"], "wb0_am1_jit.depth_map": da["depth_map"],
+                "wb0_am1_jit.app_mask": da["app_mask"]})
+    np.savez_compressed(os.path.join(HERE, "tiny_ref.npz"), **out)
+    print("tiny_ref.npz", os.path.getsize(os.path.join(HERE, "tiny_ref.npz")) // 1024, "KiB; app", int(d["app_mask"].sum()),
+          "rgb range", float(d["rgb"].min()), float(d["rgb"].max()), "penalty", float(sc.penalty))
 
 
 def tiny_rays():
@@ -67,6 +100,8 @@ def dump_to_np(d):
 def main():
     torch.manual_seed(0)
     hyper = dict(synthetic.HYPER, near_far=TINY["near_far"], step_ratio=TINY["step_ratio"])
+    if "--only-ref" in sys.argv:
+        return main_ref(hyper)
 
     # (i) tiny scene, full per-sample dump, white_bg on, no alpha mask
     arrs = tiny_scene()
@@ -110,6 +145,7 @@ def main():
                         rgb_map=d1["rgb_map"], depth_map=d1["depth_map"], acc_map=d1["acc_map"],
                         valid_bits=np.packbits(d1["valid"]), app_bits=np.packbits(d1["app_mask"]),
                         n_valid=int(d1["valid"].sum()), n_app=int(d1["app_mask"].sum()))
+    main_ref(hyper)
     for fn in ("tiny_dump.npz", "tiny_edge.npz", "config1.npz"):
         print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
     print("tiny: valid", d["valid"].sum(), "app", d["app_mask"].sum(), "acc range", d["acc_map"].min(), d["acc_map"].max())

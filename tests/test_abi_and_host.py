@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(l, n), f"libtvr.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and include/tvr.h disagree"
-    assert _lib.lib().tvr_version() == 100
+    assert _lib.lib().tvr_version() == 101
 
 
 def test_abi_argument_errors_without_gpu():
@@ -48,6 +48,29 @@ def test_abi_argument_errors_without_gpu():
     assert lib.tvr_scene_create(C.byref(d), None, 0, C.byref(h)) == -3  # TVR_ERR_SCRATCH
     assert lib.tvr_render(None, None, 0, 0, 0, None, 0.0, None, None, None, 0, None, None, None, None) == -1
     assert lib.tvr_render_scratch_bytes(None, 4096, 512) > 4096 * 512 * 20
+    d.variant = 2
+    assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"variant" in lib.tvr_last_error()
+    d.variant = 1                                                       # REFTensoRF: same packed size (the LDS image has room for both)
+    assert lib.tvr_scene_packed_bytes(C.byref(d)) == nbytes
+    assert lib.tvr_app_feature_ref(None, None, 0, None, None, None) == -1
+    assert lib.tvr_mlp_render_ref(None, None, None, None, 0, None, None) == -1
+
+
+def test_ref_field_host_logic():
+    """REFTensoRF's host surface (models/REFTensoRF.py:64-106) without a GPU: parameters, optimizer groups, state dict."""
+    from jittor_myc_nerfs_amd import REFTensoRF, MLPRender_Fea_Ref
+    m = REFTensoRF(np.asarray(TINY["aabb"], np.float32), TINY["gridSize"], "cpu", density_n_comp=[16] * 3, appearance_n_comp=[48] * 3,
+                   app_dim=27, near_far=TINY["near_far"], shadingMode="MLP_Fea", view_pe=2, fea_pe=2, featureC=128, step_ratio=0.5)
+    assert isinstance(m.renderModule, MLPRender_Fea_Ref) and m.renderModule.in_mlpC == 151
+    assert m.normal_linear.weight.shape == (3, 144) and m.rho_linear.weight.shape == (1, 144)
+    assert len(m.get_optparam_groups()) == 10 and float(m.penalty) == 0.0
+    assert {"normal_linear.weight", "diffuse_linear.bias", "specular_linear.weight", "rho_linear.bias"} <= set(m.state_dict())
+    with pytest.raises(NotImplementedError):
+        REFTensoRF(np.asarray(TINY["aabb"], np.float32), TINY["gridSize"], "cpu", density_n_comp=[16] * 3, appearance_n_comp=[48] * 3,
+                   shadingMode="SH")
+    from jittor_myc_nerfs_amd._lib import TvrError
+    with pytest.raises(TvrError):                                       # no CPU fallback
+        m.render_rays(torch.zeros(4, 6))
 
 
 def test_field_host_logic_matches_reference_sizes(tiny_arrays, hyper_tiny):

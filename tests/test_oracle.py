@@ -142,3 +142,43 @@ def test_single_texel_impulse_bilinear_weights():
     fx, fy = 4.25, 1.5                                              # un-normalised -> weights (1-.25)*(.5)
     n = np.array([[fx / 5 * 2 - 1, fy / 6 * 2 - 1, 0.3]], np.float32)
     assert abs(co.density_features(n)[0] - 0.75 * 0.5) < 1e-5
+
+
+# ---- REFTensoRF (models/REFTensoRF.py) ------------------------------------------------------------------------
+def test_ref_oracle_reproduces_golden(tiny_ref, tiny_ref_arrays, hyper_tiny):
+    sc = TO.scene_from_arrays(tiny_ref_arrays, **hyper_tiny)
+    d = TO.execute(sc, tiny_ref["rays"], white_bg=True, N_samples=TINY["N_samples"], dump=True)
+    assert np.array_equal(d["app_mask"].numpy().astype(np.uint8), tiny_ref["app_mask"])
+    assert np.abs(d["rgb_map"].numpy() - tiny_ref["rgb_map"]).max() < 1e-5
+    assert np.abs(d["rgb"].numpy() - tiny_ref["rgb"]).max() < 1e-5
+    assert abs(float(sc.penalty) - float(tiny_ref["penalty"])) < 1e-4
+    sca = TO.scene_from_arrays(dict(tiny_ref_arrays, alpha_volume=None), **hyper_tiny)
+    assert sca.ref is not None and sca.mlp["W1"].shape == (128, 151)
+
+
+def test_ref_known_answers(tiny_ref_arrays, hyper_tiny):
+    """Hand-checkable REFTensoRF.execute arithmetic (:212-239): a constant normal n = +z seen along -z gives d = +z, dot = 1,
+    reflection = 2n - d = +z, MLP input 0 = -1, no penalty; seen along +z gives d = -z, dot = -1, reflection = -2z + z = -z,
+    penalty = relu(1)^2 = 1 per unit weight.  With W3 = 0 the specular colour is sigmoid(0) = 0.5, so rgb = 0.5 * tint + rgb_d."""
+    a = dict(tiny_ref_arrays)
+    a["normal_W"] = np.zeros_like(a["normal_W"]); a["normal_b"] = np.array([0, 0, 2.0], np.float32)       # |n| = 2 -> normalised to z
+    a["specular_W"] = np.zeros_like(a["specular_W"]); a["specular_b"] = np.array([0.4], np.float32)
+    a["diffuse_W"] = np.zeros_like(a["diffuse_W"]); a["diffuse_b"] = np.array([0.1, 0.2, 0.3], np.float32)
+    a["W3"] = np.zeros_like(a["W3"]); a["b3"] = np.zeros_like(a["b3"])
+    sc = TO.scene_from_arrays(a, **hyper_tiny)
+    xyz = torch.zeros((2, 3))
+    views = torch.tensor([[0.0, 0.0, -1.0], [0.0, 0.0, 1.0]])
+    w = torch.tensor([0.25, 0.5])
+    rgb = TO.shade_ref(sc, xyz, views, w)
+    assert torch.allclose(rgb, torch.tensor([[0.3, 0.4, 0.5]] * 2), atol=1e-6)
+    assert abs(float(sc.penalty) - 0.5) < 1e-6                    # only the back-facing sample (dot = -1) is penalised: 0.5 * 1
+    f, rgb_d, tint, normal, rho = TO.compute_appfeature_ref(sc, xyz)
+    nn = TO.jt_normalize(normal)
+    dot = ((-views) * nn).sum(1, keepdim=True)
+    refl = 2 * dot * nn - (-views)
+    assert torch.allclose(dot.view(-1), torch.tensor([1.0, -1.0])) and torch.allclose(refl, torch.tensor([[0, 0, 1.0], [0, 0, -1.0]]))
+    _, mlp_in = TO.mlp_render_fea_ref(sc, refl, f, -dot, return_in=True)
+    assert mlp_in.shape == (2, 151) and torch.allclose(mlp_in[:, 0], torch.tensor([-1.0, 1.0]))
+    assert torch.equal(mlp_in[:, 1:28], f) and torch.equal(mlp_in[:, 28:31], refl)
+    # a zero normal stays zero (eps floor of jt.normalize), never NaN
+    assert torch.equal(TO.jt_normalize(torch.zeros(1, 3)), torch.zeros(1, 3))
