@@ -6,6 +6,11 @@
 //   models/tensoRF.py:209-225 compute_densityfeature, tensorBase.py:444-448 feature2density,
 //   :17-24 raw2alpha, :513 app_mask, :520 acc_map, :530-531 depth_map.
 //
+// Launch shape: persistent workgroups, one per CU (up to 16 waves), each owning every (gridDim)-th 16-ray tile of its XCD's contiguous
+// tile range; the waves of a group take rays from an LDS cursor, so the 16 rays of a tile are marched concurrently (shared texels
+// in L1) and no wave idles while the group has rays left.  The three density LINES (3 x (L+1) x 64 B, 58 KB at 300^3) are copied
+// into LDS once per group: a third of the gather's 64-B requests then go to LDS instead of the L1/TA path that bounds this kernel.
+//
 // Mapping (wave64): one wave marches one ray, 64 consecutive samples per chunk.  Position / mask / index math is
 // lane-per-sample.  The density gather is quad-per-sample: 4 lanes each fetch one float4 (4 of the 16 channels) of
 // every texel, so a wave-level dwordx4 load covers 16 samples x 64 contiguous bytes (one texel per quad) — coalesced
@@ -18,8 +23,8 @@
 #include "tvr_device.h"
 #include "tvr_kernels.h"
 
-#define MARCH_THREADS 256
-#define MARCH_WAVES 4
+#define MARCH_MAX_WAVES 16
+#define MARCH_TILE 16                     // rays per tile
 
 // quad-level data movement as DPP VALU ops (quad_perm) instead of ds_bpermute: no LDS hop in front of the gather addresses
 template <int CTRL>
@@ -47,24 +52,68 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <bool DENSE>
-__global__ __launch_bounds__(MARCH_THREADS) void march_kernel(const SceneDev sc, const float *__restrict__ rays,
-                                                              const int n_rays, const int S, const int s_cap,
-                                                              const float *__restrict__ jitter, const float eps_T,
-                                                              const int rays_per_block, MarchOut mo, const tvr_dense_out dn)
+// vm_term<4, false> with the line taps taken from the LDS copy (same arithmetic, same order)
+__device__ __forceinline__ float4 vm_term_lds(const float4 *__restrict__ P, const float4 *Ls, int W, int x0, int y0, int l0,
+                                              float wx, float wy, float wl, int sub)
 {
-    extern __shared__ uint2 lds_buf[];
+    const float ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
+    const int Wp = W + 1;
+    const float4 *p = P + ((size_t)y0 * Wp + x0) * 4 + sub;
+    const float4 t00 = p[0], t01 = p[4], t10 = p[(size_t)Wp * 4], t11 = p[(size_t)Wp * 4 + 4];
+    const float4 *q = Ls + l0 * 4 + sub;
+    const float4 l0v = q[0], l1v = q[4];
+    float4 p4 = f4_mul(ux * uy, t00);
+    p4 = f4_fma(wx * uy, t01, p4);
+    p4 = f4_fma(ux * wy, t10, p4);
+    p4 = f4_fma(wx * wy, t11, p4);
+    float4 q4 = f4_mul(ul, l0v);
+    q4 = f4_fma(wl, l1v, q4);
+    return make_float4(p4.x * q4.x, p4.y * q4.y, p4.z * q4.z, p4.w * q4.w);
+}
+
+template <bool DENSE, bool LDSL>
+__global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const SceneDev sc, const float *__restrict__ rays,
+                                                                     const int n_rays, const int S, const int s_cap,
+                                                                     const float *__restrict__ jitter, const float eps_T,
+                                                                     MarchOut mo, const tvr_dense_out dn)
+{
+    // LDS: [cursor 16 B][lines: 3 x (L+1) x 4 float4, LDSL only][per-wave weight lists f32 s_cap][per-wave sample lists u16 s_cap]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint2 *buf = lds_buf + (size_t)wave * s_cap;
-    const unsigned blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_waves = blockDim.x >> 6;
+    unsigned *cursor = (unsigned *)lds_raw;
+    const float4 *ls0 = (const float4 *)(lds_raw + 16);
+    const int ln0 = LDSL ? (sc.grid[2] + 1) * 4 : 0, ln1 = LDSL ? (sc.grid[1] + 1) * 4 : 0, ln2 = LDSL ? (sc.grid[0] + 1) * 4 : 0;
+    const float4 *ls1 = ls0 + ln0, *ls2 = ls1 + ln1;                     // line i runs along axis vecMode[i] = 2 - i
+    float *bufw = (float *)(ls2 + ln2) + (size_t)wave * s_cap;
+    unsigned short *bufj = (unsigned short *)((float *)(ls2 + ln2) + (size_t)n_waves * s_cap) + (size_t)wave * s_cap;
+    if (threadIdx.x == 0) *cursor = 0u;
+    if (LDSL) {
+        float4 *dst = (float4 *)(lds_raw + 16);
+        for (int i = threadIdx.x; i < ln0; i += blockDim.x) dst[i] = sc.dline[0][i];
+        for (int i = threadIdx.x; i < ln1; i += blockDim.x) dst[ln0 + i] = sc.dline[1][i];
+        for (int i = threadIdx.x; i < ln2; i += blockDim.x) dst[ln0 + ln1 + i] = sc.dline[2][i];
+    }
+    __syncthreads();
     const int sub = lane & 3;
+
+    // this group's tiles: XCD x (groups x, x+8, ...: observed round-robin dispatch) owns a contiguous tile range; speed only
+    const int n_tiles = (n_rays + MARCH_TILE - 1) / MARCH_TILE;
+    const int nx = gridDim.x < 8u ? (int)gridDim.x : 8;
+    const int xcd = blockIdx.x % nx, bi = blockIdx.x / nx, nbx = ((int)gridDim.x - xcd + nx - 1) / nx;
+    const int t0 = (int)((long long)n_tiles * xcd / nx), t1 = (int)((long long)n_tiles * (xcd + 1) / nx);
 
     unsigned long long st_eval = 0, st_bbox = 0, st_term = 0;
 
-    for (int it = wave; it < rays_per_block; it += MARCH_WAVES) {
-        const int ray = blk * rays_per_block + it;
-        if (ray >= n_rays) break;
+    for (;;) {
+        unsigned ci = 0;
+        if (lane == 0) ci = atomicAdd(cursor, 1u);
+        ci = __builtin_amdgcn_readfirstlane(ci);
+        const int tile = t0 + (int)(ci / MARCH_TILE) * nbx + bi;
+        if (tile >= t1) break;
+        const int ray = tile * MARCH_TILE + (int)(ci % MARCH_TILE);
+        if (ray >= n_rays) continue;
         float o[3], d[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -142,7 +191,12 @@ __global__ __launch_bounds__(MARCH_THREADS) void march_kernel(const SceneDev sc,
                 const int ix = quad_bcast_i(i0[0], k4), iy = quad_bcast_i(i0[1], k4), iz = quad_bcast_i(i0[2], k4);
                 const float wx = quad_bcast_f(w[0], k4), wy = quad_bcast_f(w[1], k4), wz = quad_bcast_f(w[2], k4);
                 float part = 0.0f;
-                if (v) {
+                if (v && LDSL) {
+                    const float4 a = vm_term_lds(sc.dplane[0], ls0, sc.grid[0], ix, iy, iz, wx, wy, wz, sub);
+                    const float4 b = vm_term_lds(sc.dplane[1], ls1, sc.grid[0], ix, iz, iy, wx, wz, wy, sub);
+                    const float4 cc = vm_term_lds(sc.dplane[2], ls2, sc.grid[1], iy, iz, ix, wy, wz, wx, sub);
+                    part = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((cc.x + cc.y) + (cc.z + cc.w));
+                } else if (v) {
                     // plane0 (x,y)·line0(z) ; plane1 (x,z)·line1(y) ; plane2 (y,z)·line2(x)   (matMode / vecMode)
                     const float4 a = vm_term<4, false>(sc.dplane[0], sc.dline[0], sc.grid[0], sc.grid[1], sc.grid[2], ix, iy, iz, wx, wy, wz, sub);
                     const float4 b = vm_term<4, false>(sc.dplane[1], sc.dline[1], sc.grid[0], sc.grid[2], sc.grid[1], ix, iz, iy, wx, wz, wy, sub);
@@ -176,7 +230,7 @@ __global__ __launch_bounds__(MARCH_THREADS) void march_kernel(const SceneDev sc,
             const unsigned long long ma = __ballot(app);
             if (ma) {
                 const int pos = napp + __popcll(ma & ((1ull << lane) - 1ull));
-                if (app) buf[pos] = make_uint2((unsigned)j, __float_as_uint(wgt));
+                if (app) { bufw[pos] = wgt; bufj[pos] = (unsigned short)j; }
                 napp += __popcll(ma);
             }
             T = T * __shfl(incl, 63);
@@ -227,18 +281,18 @@ __global__ __launch_bounds__(MARCH_THREADS) void march_kernel(const SceneDev sc,
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int i = lane; i < napp; i += 64) {
-            const uint2 e = buf[i];
-            float fj = (float)e.x;
+            const unsigned ej = bufj[i];
+            float fj = (float)ej;
             if (has_jit) fj = fj + u;
             const float z = tmin + sc.step * fj;
             float4 qv;
             qv.x = ((o[0] + d[0] * z) - sc.lo[0]) * sc.inv[0] - 1.0f;
             qv.y = ((o[1] + d[1] * z) - sc.lo[1]) * sc.inv[1] - 1.0f;
             qv.z = ((o[2] + d[2] * z) - sc.lo[2]) * sc.inv[2] - 1.0f;
-            qv.w = __uint_as_float(e.y);
+            qv.w = bufw[i];
             mo.q_pos[base + i] = qv;
             mo.q_ray[base + i] = (unsigned)ray;
-            if (mo.q_j) mo.q_j[base + i] = e.x;
+            if (mo.q_j) mo.q_j[base + i] = ej;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -325,24 +379,48 @@ __global__ __launch_bounds__(256) void alpha_sample_kernel(const SceneDev sc, co
 }
 
 // ---- host launchers ----
+template <bool DENSE, bool LDSL>
+static hipError_t launch_march_t(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T, const MarchOut &mo,
+                                 const tvr_dense_out &dn, int waves, size_t lds, unsigned grid, hipStream_t stream)
+{
+    hipError_t rc = hipFuncSetAttribute((const void *)march_kernel<DENSE, LDSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc != hipSuccess) return rc;
+    hipLaunchKernelGGL((march_kernel<DENSE, LDSL>), dim3(grid), dim3(64 * waves), lds, stream, sc, rays, n_rays, S, S, jitter, eps_T, mo, dn);
+    return hipGetLastError();
+}
+
+static int device_cu_count()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+
 hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T,
                         const MarchOut &mo, const tvr_dense_out *dense, hipStream_t stream)
 {
-    const int rpb = 16;
-    const int s_cap = S;
-    const size_t lds = (size_t)MARCH_WAVES * s_cap * sizeof(uint2);
-    const unsigned nblk = (unsigned)((n_rays + rpb - 1) / rpb);
-    if (dense) {
-        (void)hipFuncSetAttribute((const void *)march_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(march_kernel<true>, dim3(nblk), dim3(MARCH_THREADS), lds, stream, sc, rays, n_rays, S, s_cap, jitter,
-                           eps_T, rpb, mo, *dense);
-    } else {
-        tvr_dense_out none = {};
-        (void)hipFuncSetAttribute((const void *)march_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(march_kernel<false>, dim3(nblk), dim3(MARCH_THREADS), lds, stream, sc, rays, n_rays, S, s_cap, jitter,
-                           eps_T, rpb, mo, none);
-    }
-    return hipGetLastError();
+    // LDS budget: the density lines (if they fit next to at least 4 waves' lists) + 6 B per sample and wave for the appearance lists
+    const size_t kLds = 160 * 1024, line_bytes = ((size_t)sc.grid[0] + sc.grid[1] + sc.grid[2] + 3) * 64, per_wave = (size_t)S * 6;
+    bool ldsl = 16 + line_bytes + 4 * per_wave + 64 <= kLds;
+    const size_t fixed = 16 + (ldsl ? line_bytes : 0) + 64;
+    int waves = (int)((kLds - fixed) / per_wave);
+    waves = waves >= 16 ? 16 : (waves >= 12 ? 12 : (waves >= 8 ? 8 : (waves >= 4 ? 4 : (waves >= 2 ? 2 : 1))));
+    const size_t lds = fixed + (size_t)waves * per_wave;
+    const int n_tiles = (n_rays + MARCH_TILE - 1) / MARCH_TILE;
+    // one group per CU when it holds 16 waves; proportionally more groups when the lists force smaller ones
+    long long grid = (long long)device_cu_count() * (16 / waves > 0 ? 16 / waves : 1);
+    if (grid > n_tiles) grid = n_tiles;
+    if (grid < 1) grid = 1;
+    tvr_dense_out none = {};
+    const tvr_dense_out &dn = dense ? *dense : none;
+    if (dense) return ldsl ? launch_march_t<true, true>(sc, rays, n_rays, S, jitter, eps_T, mo, dn, waves, lds, (unsigned)grid, stream)
+                           : launch_march_t<true, false>(sc, rays, n_rays, S, jitter, eps_T, mo, dn, waves, lds, (unsigned)grid, stream);
+    return ldsl ? launch_march_t<false, true>(sc, rays, n_rays, S, jitter, eps_T, mo, dn, waves, lds, (unsigned)grid, stream)
+                : launch_march_t<false, false>(sc, rays, n_rays, S, jitter, eps_T, mo, dn, waves, lds, (unsigned)grid, stream);
 }
 
 hipError_t launch_composite(const MarchOut &mo, int n_rays, int white_bg, float *rgb, hipStream_t stream)
