@@ -71,13 +71,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SH_TILE (32 * SH_NCB)
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// relu as ONE VALU op: integer max on the bit pattern (negative floats, -0.0 included, are negative integers).  fmaxf(x, 0) costs
+// two v_max_f32 (hipcc canonicalises the operand first), and an inline-asm v_max_f32 would bypass the compiler's MFMA-result
+// wait states (the accumulator read hazard is software-managed) — that variant rendered non-reproducibly.
+__device__ __forceinline__ float relu_f(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 // fp32 pair -> packed fp16 hi and lo words (x = hi + lo up to ~2^-22 |x|; round-toward-zero never overflows to inf)
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
 {
     const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
     // x - hi as fma(hi, -1, x): one v_fma_mix_f32 reading the packed half in place (exact: the product by -1 is exact); hipcc
-    // does not select the mixed-precision form by itself (it emits v_cvt_f32_f16 + v_sub), hence the asm
+    // does not select the mixed-precision form by itself (it emits v_cvt_f32_f16 + v_sub), hence the asm.  (v_fma_mixlo/mixhi_f16
+    // would fuse the final conversion too — 3 ops per pair — but their partial-register writes from inline asm, which the
+    // compiler's MFMA hazard recogniser cannot see, rendered non-reproducibly, and 15 % fewer VALU ops bought no time: measured.)
     const unsigned hb = __builtin_bit_cast(unsigned, h);
     float ra, rb;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 for (int cb = 0; cb < SH_NCB; ++cb) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(src[cb][s >> 1][8 * (s & 1) + j], 0.0f);
+                    for (int j = 0; j < 8; ++j) v[j] = relu_f(src[cb][s >> 1][8 * (s & 1) + j]);
                     b[cb] = split8(v);
                 }
             };
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 for (int cb = 0; cb < SH_NCB; ++cb) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc2[cb][s >> 1][8 * (s & 1) + j], 0.0f);
+                    for (int j = 0; j < 8; ++j) v[j] = relu_f(acc2[cb][s >> 1][8 * (s & 1) + j]);
                     b[cb] = split8(v);
                 }
             };
