@@ -34,13 +34,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #define TVR_CHK (SRC != SH_SRC_QUEUE)
 #ifndef TVR_TIMING
-#define TVR_TIMING 0      // diagnostic build: per-phase s_memtime sums into stats[4..7] (gather, basis, hidden layers, L3 + epilogue)
+#define TVR_TIMING 0      // diagnostic build: per-phase s_memtime sums into stats[8..14] (scripts/phase_timing.py passes 16 slots)
 #endif
 #if TVR_TIMING
 #define TVR_STAMP(x) { __builtin_amdgcn_sched_barrier(0); x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define TVR_STAMP(x)
 #endif
+#ifndef TVR_TOKEN
+#define TVR_TOKEN 0       // 1: the two waves of a SIMD (w, w + 4) pass a token and only its holder runs the hidden layers, so one
+#endif                    //    wave's gather always sits beside the other's MFMAs.  Measured 15.7 vs 15.5 ms (stagger only): the
+                          //    layers run faster alone (8.7k vs 10.1k cycles per tile) but the waits eat it (scripts/phase_timing.py)
 #ifndef TVR_STAGGER
 #define TVR_STAGGER 1
 #endif
@@ -380,15 +384,20 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     if (DST != SH_DST_FEAT || REF) {              // MLP weights -> LDS once per workgroup
         const uint4 *src = (const uint4 *)sc.mlp_image;
         for (int i = tid; i < (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES) / 16; i += SH_THREADS) ((uint4 *)smem)[i] = src[i];
+        if (tid < 4) ((volatile unsigned *)(smem + (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES)))[tid] = 0u;
         __syncthreads();
     }
     const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
     const long long n_tiles = (n_total + SH_TILE - 1) / SH_TILE;
 #if TVR_TIMING
-    unsigned long long tsum[4] = {0, 0, 0, 0};
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
-#if TVR_STAGGER
+    // matrix-phase token of this wave's SIMD pair: value = the half (wave >> 2) allowed in, 2 = partner has left (free for all)
+    unsigned *const turn = (unsigned *)(smem + (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES)) + (wave & 3);
+    const unsigned my_half = (unsigned)(wave >> 2);
+    const bool use_token = TVR_TOKEN && SH_WAVES == 8 && DST != SH_DST_FEAT;
+#if TVR_STAGGER && !TVR_TOKEN
     // the two waves of a SIMD (w and w + 4) run the same program: start the second half a tile late so that one gathers while
     // the other multiplies (MI355X_MICROARCH 'Two waves per SIMD', item 9)
     if (wave >= 4)
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         }
 
 #if TVR_TIMING
-        unsigned long long tg0 = 0, tg1 = 0, tg2 = 0, tg3 = 0, tg4 = 0;
+        unsigned long long tg0 = 0, tg1 = 0, tg2 = 0, tg3 = 0, tg4 = 0, tgA = 0, tgB = 0, tgC = 0;
 #endif
         TVR_STAMP(tg0);
         if (SRC != SH_SRC_FEAT) {
@@ -632,6 +641,19 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             for (int cb = 0; cb < SH_NCB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sincos_fast(F[cb][r], S1[cb][r], C1[cb][r]);
+            // the hidden layers (240 of the tile's 267 MFMAs) run under the SIMD pair's token; gather, basis product and the
+            // positional encoding above are the part that overlaps the partner's turn
+            TVR_SB;
+            TVR_STAMP(tgA);
+            if (use_token) {
+                for (;;) {
+                    const unsigned t = *(volatile unsigned *)turn;
+                    if (t == my_half || t == 2u) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            TVR_STAMP(tgB);
+            TVR_SB;
             const int rowoff = e * TVR_IMG_W1_ROW + h * 16;
             auto l1_frag = [&](int s, Frag b[SH_NCB]) {
 #pragma unroll
@@ -746,6 +768,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 for (int cb = 0; cb < SH_NCB; ++cb) bcur[cb] = bnxt[cb];
                 TVR_SB;
             }
+            // the last MFMA of this tile is issued: hand the token over (unless the partner has left); the epilogue is VALU only
+            TVR_STAMP(tgC);
+            if (use_token && lane == 0) atomicCAS(turn, my_half, 1u - my_half);
+            TVR_SB;
 #pragma unroll
             for (int cb = 0; cb < SH_NCB; ++cb)
 #pragma unroll
@@ -773,12 +799,13 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #endif
 #if TVR_TIMING
         TVR_STAMP(tg4);
-        tsum[0] += tg1 - tg0; tsum[1] += tg2 - tg1; tsum[2] += tg3 - tg2; tsum[3] += tg4 - tg3;
+        tsum[0] += tg1 - tg0; tsum[1] += tg2 - tg1; tsum[2] += tgA - tg2; tsum[3] += tgB - tgA; tsum[4] += tg3 - tgB; tsum[5] += tgC - tg3; tsum[6] += tg4 - tgC;
 #endif
     }
+    if (use_token && lane == 0) atomicExch(turn, 2u);                             // no more tiles here: the partner runs freely
 #if TVR_TIMING
     if (a.stats && lane == 0)
-        for (int i = 0; i < 4; ++i) atomicAdd((unsigned long long *)&a.stats[4 + i], tsum[i]);
+        for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // diagnostic build: 16-slot stats
 #endif
     if (a.stats && SRC == SH_SRC_QUEUE && blockIdx.x == 0 && tid == 0)
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
@@ -787,7 +814,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 template <int SRC, int DST, bool REF>
 static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
-    const int lds = REF ? TVR_MLP_IMAGE_BYTES_REF : ((DST == SH_DST_FEAT) ? 0 : TVR_MLP_IMAGE_BYTES);
+    const int lds = (REF ? TVR_MLP_IMAGE_BYTES_REF : ((DST == SH_DST_FEAT) ? 0 : TVR_MLP_IMAGE_BYTES)) + 16;    // + the token words
     hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
     unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles

@@ -5,14 +5,14 @@ import torch, numpy as np
 import bench
 m, arrs, A = bench.build_model(torch.device("cuda"))
 rays = bench.frames(A)[0].cuda()
-stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+stats = torch.zeros(16, dtype=torch.int64, device="cuda")
 for _ in range(2): m.render_rays(rays, N_samples=512)
 stats.zero_()
 m.render_rays(rays, N_samples=512, stats=stats)
 torch.cuda.synchronize()
 st = stats.cpu().numpy().astype(float)
-tot = st[4:8].sum()
+tot = st[8:15].sum()
 print("entries", st[2], "tiles", st[2] / 32)
-for n, v in zip(("gather", "basis", "PE+L1+L2", "L3+epilogue"), st[4:8]):
+for n, v in zip(("gather", "basis", "PE", "token wait", "L1+L2", "L3", "epilogue"), st[8:15]):
     print(f"{n:12s} {v / (st[2] / 32):9.0f} cycles/tile  {100 * v / tot:5.1f} %")
 print("sum cycles/tile", tot / (st[2] / 32))
