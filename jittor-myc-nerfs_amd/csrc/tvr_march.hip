@@ -103,9 +103,11 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
 
     // this group's tiles: XCD x (groups x, x+8, ...: observed round-robin dispatch) owns a contiguous tile range; speed only
     const int n_tiles = (n_rays + MARCH_TILE - 1) / MARCH_TILE;
+#if !TVR_MARCH_RASTER
     const int nx = gridDim.x < 8u ? (int)gridDim.x : 8;
     const int xcd = blockIdx.x % nx, bi = blockIdx.x / nx, nbx = ((int)gridDim.x - xcd + nx - 1) / nx;
     const int t0 = (int)((long long)n_tiles * xcd / nx), t1 = (int)((long long)n_tiles * (xcd + 1) / nx);
+#endif
 
     unsigned long long st_eval = 0, st_bbox = 0, st_term = 0;
 

@@ -41,6 +41,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #else
 #define TVR_STAMP(x)
 #endif
+#ifndef TVR_QPF
+#define TVR_QPF 0         // 1: prefetch the next tile's queue positions one tile ahead (measured: no gain, 15.3 vs 15.0-15.3 ms; +6 VGPRs)
+#endif
+#ifndef TVR_SHADE_XCD
+#define TVR_SHADE_XCD 0
+#endif
 #ifndef TVR_TOKEN
 #define TVR_TOKEN 0       // 1: the two waves of a SIMD (w, w + 4) pass a token and only its holder runs the hidden layers, so one
 #endif                    //    wave's gather always sits beside the other's MFMAs.  Measured 15.7 vs 15.5 ms (stagger only): the
@@ -405,7 +411,23 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #endif
     // A wave owns SH_NCB column blocks of 32 entries at a time (entry = MFMA column).  The blocks are independent chains, so the
     // VALU work of one overlaps the MFMAs of the other, and every weight fragment read from LDS feeds SH_NCB MFMAs.
-    for (long long tile = (long long)blockIdx.x * SH_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * SH_WAVES) {
+#if TVR_SHADE_XCD
+    const unsigned lblk = xcd_remap(blockIdx.x, gridDim.x);       // each XCD takes a contiguous eighth of every window of tiles
+#else
+    const unsigned lblk = blockIdx.x;
+#endif
+    // the queue position of the NEXT tile is fetched one tile ahead (it heads the dependent chain position -> tap address -> tap)
+    const long long tile_stride = (long long)gridDim.x * SH_WAVES;
+    float4 qnext[SH_NCB];
+#pragma unroll
+    for (int cb = 0; cb < SH_NCB; ++cb) {
+        qnext[cb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (TVR_QPF && SRC == SH_SRC_QUEUE) {
+            const long long en = ((long long)lblk * SH_WAVES + wave) * SH_TILE + cb * 32 + e;
+            if (en < n_total) qnext[cb] = a.q_pos[en];
+        }
+    }
+    for (long long tile = (long long)lblk * SH_WAVES + wave; tile < n_tiles; tile += tile_stride) {
         long long ent[SH_NCB];
         bool live[SH_NCB];
         float F[SH_NCB][16];                       // base values: row c = acc_row(r, h) of the feature tile, column = entry
@@ -432,7 +454,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 float pn[3] = {0.f, 0.f, 0.f};
                 if (live[cb]) {
                     if (SRC == SH_SRC_QUEUE) {
-                        const float4 q = a.q_pos[ent[cb]];
+                        const float4 q = TVR_QPF ? qnext[cb] : a.q_pos[ent[cb]];
                         pn[0] = q.x; pn[1] = q.y; pn[2] = q.z; wq[cb] = q.w;
                         const float *rp = a.rays + (size_t)a.q_ray[ent[cb]] * 6 + 3;
                         dir[cb][0] = rp[0]; dir[cb][1] = rp[1]; dir[cb][2] = rp[2];
@@ -442,6 +464,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) fc[cb][k] = unnorm(pn[k], sc.gm1[k]);
+                if (TVR_QPF && SRC == SH_SRC_QUEUE) {
+                    const long long en = ent[cb] + tile_stride * SH_TILE;
+                    if (en < n_total) qnext[cb] = a.q_pos[en];
+                }
             }
             // ---- gather + basis: 9 k-steps of 16 channels (plane p = s/3, channels 16(s%3) + 8h .. +7 of this lane) ----
             // GATHER phase: global loads + VALU only.  The 9 k-steps' B fragments (plane*line products, fp16 hi/lo) stay in registers.

@@ -15,8 +15,10 @@
 #include "tvr_device.h"
 #include "tvr_kernels.h"
 
-#define TB_THREADS 256
-#define TB_WAVES 4
+#define TB_WAVES 16                      // march_backward: one ray per wave, 16 rays per workgroup
+#define TB_THREADS (64 * TB_WAVES)
+#define AHB_THREADS 256
+#define AHB_ENTRIES 2048                 // app_h_backward: queue entries per workgroup (per plane)
 
 template <int CTRL>
 __device__ __forceinline__ int qperm_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
@@ -84,6 +86,25 @@ __device__ __forceinline__ void vm_scatter(float *__restrict__ gPl, float *__res
     atomic_add4(q + TPT * 4, f4_mul(wl, gQ));
 }
 
+// Line gradients are accumulated in LDS and flushed once per workgroup: every sample of every ray at the same height adds into the
+// same (L+1) x C line texels, and same-address global atomics serialise in L2 (measured: 10.1 -> see DESIGN.md ms per 4096-ray step).
+// LINE_LDS = false (the three lines do not fit the LDS) keeps the global atomics.
+template <int TPT, bool LINE_LDS>
+__device__ __forceinline__ void vm_scatter_l(float *__restrict__ gPl, float *__restrict__ gLn, float *gLds, int W, int x0, int y0, int l0,
+                                             float wx, float wy, float wl, int sub, float4 gP, float4 gQ)
+{
+    const float ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
+    const int Wp = W + 1;
+    float *p = gPl + (((size_t)y0 * Wp + x0) * TPT + sub) * 4;
+    atomic_add4(p, f4_mul(ux * uy, gP));
+    atomic_add4(p + TPT * 4, f4_mul(wx * uy, gP));
+    atomic_add4(p + (size_t)Wp * TPT * 4, f4_mul(ux * wy, gP));
+    atomic_add4(p + (size_t)Wp * TPT * 4 + TPT * 4, f4_mul(wx * wy, gP));
+    float *q = (LINE_LDS ? gLds : gLn) + ((size_t)l0 * TPT + sub) * 4;
+    atomic_add4(q, f4_mul(ul, gQ));
+    atomic_add4(q + TPT * 4, f4_mul(wl, gQ));
+}
+
 __device__ __forceinline__ float wave_sum_f(float v)
 {
 #pragma unroll
@@ -91,14 +112,22 @@ __device__ __forceinline__ float wave_sum_f(float v)
     return v;
 }
 
+template <bool LINE_LDS>
 __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneDev sc, const float *__restrict__ rays, const int n_rays, const int S,
                                                                     const float *__restrict__ jitter, const float eps_T, const int rays_per_block,
                                                                     const MarchOut mo, const float *__restrict__ grad_w,
                                                                     const float *__restrict__ grad_acc, TrainGrads tg)
 {
+    extern __shared__ __attribute__((aligned(16))) float glds[];      // [line 0 | line 1 | line 2] gradient accumulators, (L+1) x 16 each
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane & 3;
+    const int ln0 = (sc.grid[2] + 1) * TVR_CD, ln1 = (sc.grid[1] + 1) * TVR_CD, ln2 = (sc.grid[0] + 1) * TVR_CD;
+    float *const gl0 = glds, *const gl1 = glds + ln0, *const gl2 = glds + ln0 + ln1;
+    if (LINE_LDS) {
+        for (int i = threadIdx.x; i < ln0 + ln1 + ln2; i += TB_THREADS) glds[i] = 0.0f;
+        __syncthreads();
+    }
     for (int it = wave; it < rays_per_block; it += TB_WAVES) {
         const int ray = blockIdx.x * rays_per_block + it;
         if (ray >= n_rays) break;
@@ -227,15 +256,21 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
                 if (v && gs != 0.0f) {
                     // sf = sum_i sum_c P_i[c] Q_i[c]  ->  dP_i[c] = gs Q_i[c], dQ_i[c] = gs P_i[c]
                     const VmTerm t0 = vm_eval<4>(sc.dplane[0], sc.dline[0], sc.grid[0], ix, iy, iz, wx, wy, wz, sub);
-                    vm_scatter<4>(tg.dplane[0], tg.dline[0], sc.grid[0], ix, iy, iz, wx, wy, wz, sub, f4_mul(gs, t0.Q), f4_mul(gs, t0.P));
+                    vm_scatter_l<4, LINE_LDS>(tg.dplane[0], tg.dline[0], gl0, sc.grid[0], ix, iy, iz, wx, wy, wz, sub, f4_mul(gs, t0.Q), f4_mul(gs, t0.P));
                     const VmTerm t1 = vm_eval<4>(sc.dplane[1], sc.dline[1], sc.grid[0], ix, iz, iy, wx, wz, wy, sub);
-                    vm_scatter<4>(tg.dplane[1], tg.dline[1], sc.grid[0], ix, iz, iy, wx, wz, wy, sub, f4_mul(gs, t1.Q), f4_mul(gs, t1.P));
+                    vm_scatter_l<4, LINE_LDS>(tg.dplane[1], tg.dline[1], gl1, sc.grid[0], ix, iz, iy, wx, wz, wy, sub, f4_mul(gs, t1.Q), f4_mul(gs, t1.P));
                     const VmTerm t2 = vm_eval<4>(sc.dplane[2], sc.dline[2], sc.grid[1], iy, iz, ix, wy, wz, wx, sub);
-                    vm_scatter<4>(tg.dplane[2], tg.dline[2], sc.grid[1], iy, iz, ix, wy, wz, wx, sub, f4_mul(gs, t2.Q), f4_mul(gs, t2.P));
+                    vm_scatter_l<4, LINE_LDS>(tg.dplane[2], tg.dline[2], gl2, sc.grid[1], iy, iz, ix, wy, wz, wx, sub, f4_mul(gs, t2.Q), f4_mul(gs, t2.P));
                 }
             }
             if (T < eps_T) break;
         }
+    }
+    if (LINE_LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ln0; i += TB_THREADS) { const float v = gl0[i]; if (v != 0.0f) atomicAdd(tg.dline[0] + i, v); }
+        for (int i = threadIdx.x; i < ln1; i += TB_THREADS) { const float v = gl1[i]; if (v != 0.0f) atomicAdd(tg.dline[1] + i, v); }
+        for (int i = threadIdx.x; i < ln2; i += TB_THREADS) { const float v = gl2[i]; if (v != 0.0f) atomicAdd(tg.dline[2] + i, v); }
     }
 }
 
@@ -253,21 +288,37 @@ __global__ __launch_bounds__(256) void app_h_forward_kernel(const SceneDev sc, c
     *(float4 *)(h + ent * TVR_KAPP + pl * TVR_CA + q * 4) = make_float4(t.P.x * t.Q.x, t.P.y * t.Q.y, t.P.z * t.Q.z, t.P.w * t.Q.w);
 }
 
-__global__ __launch_bounds__(256) void app_h_backward_kernel(const SceneDev sc, const float *__restrict__ xyz, const long long m,
-                                                             const float *__restrict__ dh, TrainGrads tg)
+// grid = (entry chunks, 3 planes): a workgroup owns AHB_ENTRIES entries of ONE plane/line pair and keeps that line's gradient in LDS
+template <bool LINE_LDS>
+__global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const SceneDev sc, const float *__restrict__ xyz, const long long m,
+                                                                     const float *__restrict__ dh, TrainGrads tg)
 {
-    const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= m * 36) return;
-    const long long ent = item / 36;
-    const int rem = (int)(item - ent * 36), pl = rem / 12, q = rem - pl * 12;
+    extern __shared__ __attribute__((aligned(16))) float glds[];
+    const int pl = blockIdx.y;
     const int ax = kMat[pl][0], bx = kMat[pl][1], vx = kVec[pl];
-    const float fx = unnorm(xyz[ent * 3 + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * 3 + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * 3 + vx], sc.gm1[vx]);
-    const float x0 = floorf(fx), y0 = floorf(fy), l0 = floorf(fl);
-    const VmTerm t = vm_eval<12>(sc.aplane[pl], sc.aline[pl], sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q);
-    const float4 g = *(const float4 *)(dh + ent * TVR_KAPP + pl * TVR_CA + q * 4);
-    // h = P*Q  ->  dP = g*Q, dQ = g*P
-    vm_scatter<12>(tg.aplane[pl], tg.aline[pl], sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q,
-                   make_float4(g.x * t.Q.x, g.y * t.Q.y, g.z * t.Q.z, g.w * t.Q.w), make_float4(g.x * t.P.x, g.y * t.P.y, g.z * t.P.z, g.w * t.P.w));
+    const int ln = (sc.grid[vx] + 1) * TVR_CA;
+    if (LINE_LDS) {
+        for (int i = threadIdx.x; i < ln; i += AHB_THREADS) glds[i] = 0.0f;
+        __syncthreads();
+    }
+    const long long e0 = (long long)blockIdx.x * AHB_ENTRIES;
+    const long long e1 = e0 + AHB_ENTRIES < m ? e0 + AHB_ENTRIES : m;
+    for (long long item = e0 * 12 + threadIdx.x; item < e1 * 12; item += AHB_THREADS) {
+        const long long ent = item / 12;
+        const int q = (int)(item - ent * 12);
+        const float fx = unnorm(xyz[ent * 3 + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * 3 + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * 3 + vx], sc.gm1[vx]);
+        const float x0 = floorf(fx), y0 = floorf(fy), l0 = floorf(fl);
+        const VmTerm t = vm_eval<12>(sc.aplane[pl], sc.aline[pl], sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q);
+        const float4 g = *(const float4 *)(dh + ent * TVR_KAPP + pl * TVR_CA + q * 4);
+        // h = P*Q  ->  dP = g*Q, dQ = g*P
+        vm_scatter_l<12, LINE_LDS>(tg.aplane[pl], tg.aline[pl], glds, sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q,
+                                   make_float4(g.x * t.Q.x, g.y * t.Q.y, g.z * t.Q.z, g.w * t.Q.w),
+                                   make_float4(g.x * t.P.x, g.y * t.P.y, g.z * t.P.z, g.w * t.P.w));
+    }
+    if (LINE_LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ln; i += AHB_THREADS) { const float v = glds[i]; if (v != 0.0f) atomicAdd(tg.aline[pl] + i, v); }
+    }
 }
 
 // packed [H+1][Wp][C] gradient image -> reference (C,H,W) (a line: W == 1, Wp == 1)
@@ -285,9 +336,18 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(const float *__restric
 hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T, const MarchOut &mo,
                                  const float *grad_w, const float *grad_acc, const TrainGrads &tg, hipStream_t stream)
 {
-    const int rpb = 16;
-    hipLaunchKernelGGL(march_backward_kernel, dim3((n_rays + rpb - 1) / rpb), dim3(TB_THREADS), 0, stream, sc, rays, n_rays, S, jitter, eps_T, rpb, mo,
-                       grad_w, grad_acc, tg);
+    const int rpb = TB_WAVES;
+    const size_t lds = ((size_t)sc.grid[0] + sc.grid[1] + sc.grid[2] + 3) * TVR_CD * sizeof(float);
+    const unsigned grid = (unsigned)((n_rays + rpb - 1) / rpb);
+    if (lds <= 150 * 1024) {
+        hipError_t rc = hipFuncSetAttribute((const void *)march_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rc != hipSuccess) return rc;
+        hipLaunchKernelGGL(march_backward_kernel<true>, dim3(grid), dim3(TB_THREADS), lds, stream, sc, rays, n_rays, S, jitter, eps_T, rpb, mo,
+                           grad_w, grad_acc, tg);
+    } else {
+        hipLaunchKernelGGL(march_backward_kernel<false>, dim3(grid), dim3(TB_THREADS), 0, stream, sc, rays, n_rays, S, jitter, eps_T, rpb, mo,
+                           grad_w, grad_acc, tg);
+    }
     return hipGetLastError();
 }
 
@@ -299,7 +359,17 @@ hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long 
 
 hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream)
 {
-    hipLaunchKernelGGL(app_h_backward_kernel, dim3((unsigned)((m * 36 + 255) / 256)), dim3(256), 0, stream, sc, xyz, m, dh, tg);
+    int gmax = sc.grid[0] > sc.grid[1] ? sc.grid[0] : sc.grid[1];
+    gmax = gmax > sc.grid[2] ? gmax : sc.grid[2];
+    const size_t lds = ((size_t)gmax + 1) * TVR_CA * sizeof(float);
+    const dim3 grid((unsigned)((m + AHB_ENTRIES - 1) / AHB_ENTRIES), 3);
+    if (lds <= 150 * 1024) {
+        hipError_t rc = hipFuncSetAttribute((const void *)app_h_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rc != hipSuccess) return rc;
+        hipLaunchKernelGGL(app_h_backward_kernel<true>, grid, dim3(AHB_THREADS), lds, stream, sc, xyz, m, dh, tg);
+    } else {
+        hipLaunchKernelGGL(app_h_backward_kernel<false>, grid, dim3(AHB_THREADS), 0, stream, sc, xyz, m, dh, tg);
+    }
     return hipGetLastError();
 }
 
