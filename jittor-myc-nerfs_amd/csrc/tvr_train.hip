@@ -17,7 +17,7 @@
 
 #define TB_WAVES 16                      // march_backward: one ray per wave, 16 rays per workgroup
 #define TB_THREADS (64 * TB_WAVES)
-#define AHB_THREADS 256
+#define AHB_THREADS 192                  // 4 entries x 48 channels per pass
 #define AHB_ENTRIES 2048                 // app_h_backward: queue entries per workgroup (per plane)
 
 template <int CTRL>
@@ -103,6 +103,32 @@ __device__ __forceinline__ void vm_scatter_l(float *__restrict__ gPl, float *__r
     float *q = (LINE_LDS ? gLds : gLn) + ((size_t)l0 * TPT + sub) * 4;
     atomic_add4(q, f4_mul(ul, gQ));
     atomic_add4(q + TPT * 4, f4_mul(wl, gQ));
+}
+
+// one density channel of one (plane, line) pair: re-evaluate P, Q and scatter gs*Q into the 4 plane taps, gs*P into the 2 line taps
+template <bool LINE_LDS>
+__device__ __forceinline__ void scatter_ch(const float *__restrict__ Pl, const float *__restrict__ Ln, float *__restrict__ gPl,
+                                           float *__restrict__ gLn, float *gLds, int W, int x0, int y0, int l0, float wx, float wy, float wl,
+                                           int c, float gs)
+{
+    const float ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
+    const int Wp = W + 1;
+    const size_t t00 = ((size_t)y0 * Wp + x0) * TVR_CD + c, t10 = t00 + (size_t)Wp * TVR_CD;
+    const size_t q0 = (size_t)l0 * TVR_CD + c;
+    float P = (ux * uy) * Pl[t00];
+    P = __builtin_fmaf(wx * uy, Pl[t00 + TVR_CD], P);
+    P = __builtin_fmaf(ux * wy, Pl[t10], P);
+    P = __builtin_fmaf(wx * wy, Pl[t10 + TVR_CD], P);
+    float Q = ul * Ln[q0];
+    Q = __builtin_fmaf(wl, Ln[q0 + TVR_CD], Q);
+    const float gP = gs * Q, gQ = gs * P;
+    atomicAdd(gPl + t00, (ux * uy) * gP);
+    atomicAdd(gPl + t00 + TVR_CD, (wx * uy) * gP);
+    atomicAdd(gPl + t10, (ux * wy) * gP);
+    atomicAdd(gPl + t10 + TVR_CD, (wx * wy) * gP);
+    float *q = (LINE_LDS ? gLds : gLn) + q0;
+    atomicAdd(q, ul * gQ);
+    atomicAdd(q + TVR_CD, wl * gQ);
 }
 
 __device__ __forceinline__ float wave_sum_f(float v)
@@ -246,21 +272,21 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
             T = T * __shfl(incl, 63);
 
             // ---- phase 2: scatter dL/dsf into the density planes / lines (re-gather: the texels are L1/L2 hot) ----
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const bool v = qbcast_i((int)valid, k4) != 0;
-                const float gs = qbcast_f(dLdsf, k4);
-                if (__ballot(v && gs != 0.0f) == 0ull) continue;
-                const int ix = qbcast_i(i0[0], k4), iy = qbcast_i(i0[1], k4), iz = qbcast_i(i0[2], k4);
-                const float wx = qbcast_f(w[0], k4), wy = qbcast_f(w[1], k4), wz = qbcast_f(w[2], k4);
-                if (v && gs != 0.0f) {
+            // one lane per CHANNEL, four samples per step: each atomic instruction then covers whole 64-B texels (16 dwords per
+            // L2 request; with the quad-per-sample layout of phase 1 a request carried 4 scattered dwords)
+            const int ch = lane & 15;
+#pragma unroll 2
+            for (int t = 0; t < 16; ++t) {
+                const int src = 4 * t + (lane >> 4);
+                const float gs = __shfl(dLdsf, src);
+                if (__ballot(gs != 0.0f) == 0ull) continue;
+                const int ix = __shfl(i0[0], src), iy = __shfl(i0[1], src), iz = __shfl(i0[2], src);
+                const float wx = __shfl(w[0], src), wy = __shfl(w[1], src), wz = __shfl(w[2], src);
+                if (gs != 0.0f) {
                     // sf = sum_i sum_c P_i[c] Q_i[c]  ->  dP_i[c] = gs Q_i[c], dQ_i[c] = gs P_i[c]
-                    const VmTerm t0 = vm_eval<4>(sc.dplane[0], sc.dline[0], sc.grid[0], ix, iy, iz, wx, wy, wz, sub);
-                    vm_scatter_l<4, LINE_LDS>(tg.dplane[0], tg.dline[0], gl0, sc.grid[0], ix, iy, iz, wx, wy, wz, sub, f4_mul(gs, t0.Q), f4_mul(gs, t0.P));
-                    const VmTerm t1 = vm_eval<4>(sc.dplane[1], sc.dline[1], sc.grid[0], ix, iz, iy, wx, wz, wy, sub);
-                    vm_scatter_l<4, LINE_LDS>(tg.dplane[1], tg.dline[1], gl1, sc.grid[0], ix, iz, iy, wx, wz, wy, sub, f4_mul(gs, t1.Q), f4_mul(gs, t1.P));
-                    const VmTerm t2 = vm_eval<4>(sc.dplane[2], sc.dline[2], sc.grid[1], iy, iz, ix, wy, wz, wx, sub);
-                    vm_scatter_l<4, LINE_LDS>(tg.dplane[2], tg.dline[2], gl2, sc.grid[1], iy, iz, ix, wy, wz, wx, sub, f4_mul(gs, t2.Q), f4_mul(gs, t2.P));
+                    scatter_ch<LINE_LDS>((const float *)sc.dplane[0], (const float *)sc.dline[0], tg.dplane[0], tg.dline[0], gl0, sc.grid[0], ix, iy, iz, wx, wy, wz, ch, gs);
+                    scatter_ch<LINE_LDS>((const float *)sc.dplane[1], (const float *)sc.dline[1], tg.dplane[1], tg.dline[1], gl1, sc.grid[0], ix, iz, iy, wx, wz, wy, ch, gs);
+                    scatter_ch<LINE_LDS>((const float *)sc.dplane[2], (const float *)sc.dline[2], tg.dplane[2], tg.dline[2], gl2, sc.grid[1], iy, iz, ix, wy, wz, wx, ch, gs);
                 }
             }
             if (T < eps_T) break;
@@ -288,7 +314,9 @@ __global__ __launch_bounds__(256) void app_h_forward_kernel(const SceneDev sc, c
     *(float4 *)(h + ent * TVR_KAPP + pl * TVR_CA + q * 4) = make_float4(t.P.x * t.Q.x, t.P.y * t.Q.y, t.P.z * t.Q.z, t.P.w * t.Q.w);
 }
 
-// grid = (entry chunks, 3 planes): a workgroup owns AHB_ENTRIES entries of ONE plane/line pair and keeps that line's gradient in LDS
+// grid = (entry chunks, 3 planes): a workgroup owns AHB_ENTRIES entries of ONE plane/line pair and keeps that line's gradient in LDS.
+// One lane per CHANNEL (48 consecutive lanes = one entry): a wave's atomic instruction then covers whole 64-B lines of a texel
+// (16 dwords per L2 request) instead of 4 scattered dwords per line with a lane per float4.
 template <bool LINE_LDS>
 __global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const SceneDev sc, const float *__restrict__ xyz, const long long m,
                                                                      const float *__restrict__ dh, TrainGrads tg)
@@ -303,17 +331,33 @@ __global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const Scene
     }
     const long long e0 = (long long)blockIdx.x * AHB_ENTRIES;
     const long long e1 = e0 + AHB_ENTRIES < m ? e0 + AHB_ENTRIES : m;
-    for (long long item = e0 * 12 + threadIdx.x; item < e1 * 12; item += AHB_THREADS) {
-        const long long ent = item / 12;
-        const int q = (int)(item - ent * 12);
+    const float *__restrict__ Pl = (const float *)sc.aplane[pl];
+    const float *__restrict__ Ln = (const float *)sc.aline[pl];
+    float *__restrict__ gPl = tg.aplane[pl];
+    float *gLn = LINE_LDS ? glds : tg.aline[pl];
+    const int Wp = sc.grid[ax] + 1;
+    for (long long item = e0 * TVR_CA + threadIdx.x; item < e1 * TVR_CA; item += AHB_THREADS) {
+        const long long ent = item / TVR_CA;
+        const int c = (int)(item - ent * TVR_CA);
         const float fx = unnorm(xyz[ent * 3 + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * 3 + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * 3 + vx], sc.gm1[vx]);
-        const float x0 = floorf(fx), y0 = floorf(fy), l0 = floorf(fl);
-        const VmTerm t = vm_eval<12>(sc.aplane[pl], sc.aline[pl], sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q);
-        const float4 g = *(const float4 *)(dh + ent * TVR_KAPP + pl * TVR_CA + q * 4);
-        // h = P*Q  ->  dP = g*Q, dQ = g*P
-        vm_scatter_l<12, LINE_LDS>(tg.aplane[pl], tg.aline[pl], glds, sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q,
-                                   make_float4(g.x * t.Q.x, g.y * t.Q.y, g.z * t.Q.z, g.w * t.Q.w),
-                                   make_float4(g.x * t.P.x, g.y * t.P.y, g.z * t.P.z, g.w * t.P.w));
+        const float x0f = floorf(fx), y0f = floorf(fy), l0f = floorf(fl);
+        const float wx = fx - x0f, wy = fy - y0f, wl = fl - l0f, ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
+        const size_t t00 = (((size_t)(int)y0f * Wp + (int)x0f)) * TVR_CA + c, t10 = t00 + (size_t)Wp * TVR_CA;
+        const size_t q0 = (size_t)(int)l0f * TVR_CA + c;
+        float P = (ux * uy) * Pl[t00];
+        P = __builtin_fmaf(wx * uy, Pl[t00 + TVR_CA], P);
+        P = __builtin_fmaf(ux * wy, Pl[t10], P);
+        P = __builtin_fmaf(wx * wy, Pl[t10 + TVR_CA], P);
+        float Q = ul * Ln[q0];
+        Q = __builtin_fmaf(wl, Ln[q0 + TVR_CA], Q);
+        const float g = dh[ent * TVR_KAPP + pl * TVR_CA + c];
+        const float gP = g * Q, gQ = g * P;                       // h = P*Q  ->  dP = g*Q, dQ = g*P
+        atomicAdd(gPl + t00, (ux * uy) * gP);
+        atomicAdd(gPl + t00 + TVR_CA, (wx * uy) * gP);
+        atomicAdd(gPl + t10, (ux * wy) * gP);
+        atomicAdd(gPl + t10 + TVR_CA, (wx * wy) * gP);
+        atomicAdd(gLn + q0, ul * gQ);
+        atomicAdd(gLn + q0 + TVR_CA, wl * gQ);
     }
     if (LINE_LDS) {
         __syncthreads();
