@@ -316,20 +316,30 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
 }
 
 // composite tail (tensorBase.py:520-527): rgb_map = sum_j w_j*rgb_j (+ 1-acc if white_bg), clamp(0,1).
-// One thread per ray walks the ray's contiguous, sample-ordered queue segment: fixed summation order.
+// Eight lanes per ray read the ray's contiguous, sample-ordered queue segment 128 B at a time (lane l sums entries l, l+8, ...),
+// then a fixed butterfly adds the eight partial sums: the summation order depends on nothing but the ray -> deterministic.
+#define COMP_LANES 8
 __global__ __launch_bounds__(256) void composite_kernel(const MarchOut mo, const int n_rays, const int white_bg,
                                                         float *__restrict__ rgb_out)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rays) return;
-    const unsigned base = mo.ray_off[r], cnt = mo.ray_cnt[r];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = t / COMP_LANES, l = t % COMP_LANES;
+    const bool live = r < n_rays;
+    const unsigned base = live ? mo.ray_off[r] : 0u, cnt = live ? mo.ray_cnt[r] : 0u;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    for (unsigned i = 0; i < cnt; ++i) {
+    for (unsigned i = l; i < cnt; i += COMP_LANES) {
         const float4 e = mo.q_out[base + i];     // {r,g,b,w} written by the shade kernel
         c0 = c0 + e.w * e.x;
         c1 = c1 + e.w * e.y;
         c2 = c2 + e.w * e.z;
     }
+#pragma unroll
+    for (int off = 1; off < COMP_LANES; off <<= 1) {
+        c0 = c0 + __shfl_xor(c0, off);
+        c1 = c1 + __shfl_xor(c1, off);
+        c2 = c2 + __shfl_xor(c2, off);
+    }
+    if (!live || l != 0) return;
     const float acc = mo.acc[r];
     if (white_bg) {
         const float bg = 1.0f - acc;
@@ -435,7 +445,8 @@ hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S
 
 hipError_t launch_composite(const MarchOut &mo, int n_rays, int white_bg, float *rgb, hipStream_t stream)
 {
-    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, stream, mo, n_rays, white_bg, rgb);
+    const long long threads = (long long)n_rays * COMP_LANES;
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, mo, n_rays, white_bg, rgb);
     return hipGetLastError();
 }
 
