@@ -41,6 +41,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #else
 #define TVR_STAMP(x)
 #endif
+#ifndef TVR_HWSIN
+#define TVR_HWSIN 1       // positional encoding by v_sin_f32 / v_cos_f32 (4 instructions per value instead of ~25 for the polynomial
+                          // sincos_fast): shade 15.2 -> 14.4 ms, RGB error against the oracle unchanged (scripts/accuracy_report.py)
+#endif
 #ifndef TVR_QPF
 #define TVR_QPF 0         // 1: prefetch the next tile's queue positions one tile ahead (measured: no gain, 15.3 vs 15.0-15.3 ms; +6 VGPRs)
 #endif
@@ -380,6 +384,14 @@ __device__ __forceinline__ void sincos_fast(float x, float &s, float &c)
 // REF = REFTensoRF (models/REFTensoRF.py:107-133, 174-256): a second basis row block gives normal / diffuse / specular / rho from the
 // same h, the view direction is replaced by the reflection about the normalised normal, layer 1 takes one more input (-dot) and the
 // colour is  specular_tint * rgb_s + rgb_d.
+// hardware sine / cosine (v_sin_f32 / v_cos_f32 take revolutions): 3 instructions per pair instead of ~25
+__device__ __forceinline__ void sincos_hw(float x, float &s, float &c)
+{
+    const float r = __builtin_amdgcn_fractf(x * 0.15915494309189535f);     // keeps the argument inside the instructions' +-256 domain
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
+}
+
 template <int SRC, int DST, bool REF>
 __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
@@ -666,7 +678,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
             for (int cb = 0; cb < SH_NCB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sincos_fast(F[cb][r], S1[cb][r], C1[cb][r]);
+                for (int r = 0; r < 16; ++r) {
+                    if (TVR_HWSIN) sincos_hw(F[cb][r], S1[cb][r], C1[cb][r]);
+                    else sincos_fast(F[cb][r], S1[cb][r], C1[cb][r]);
+                }
             // the hidden layers (240 of the tile's 267 MFMAs) run under the SIMD pair's token; gather, basis product and the
             // positional encoding above are the part that overlaps the partner's turn
             TVR_SB;
