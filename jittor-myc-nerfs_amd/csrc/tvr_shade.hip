@@ -41,6 +41,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #else
 #define TVR_STAMP(x)
 #endif
+#ifndef TVR_BPF
+#define TVR_BPF 0         // 1: issue the basis-fragment loads inside gather k-step TVR_BPF_AT (measured: 14.47 vs 14.38 ms at step 8; step 7 spills)
+#endif
+#ifndef TVR_BPF_AT
+#define TVR_BPF_AT 8
+#endif
 #ifndef TVR_HWSIN
 #define TVR_HWSIN 1       // positional encoding by v_sin_f32 / v_cos_f32 (4 instructions per value instead of ~25 for the polynomial
                           // sincos_fast): shade 15.2 -> 14.4 ms, RGB error against the oracle unchanged (scripts/accuracy_report.py)
@@ -484,6 +490,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             // ---- gather + basis: 9 k-steps of 16 channels (plane p = s/3, channels 16(s%3) + 8h .. +7 of this lane) ----
             // GATHER phase: global loads + VALU only.  The 9 k-steps' B fragments (plane*line products, fp16 hi/lo) stay in registers.
             Frag hf[9][SH_NCB];
+            uint4 bah[9], bal[9];
             if (TVR_COAL && SRC == SH_SRC_QUEUE && SH_NCB == 1) {
                 TapsXY T[TVR_PF + 1];
                 TapOff off[3];
@@ -532,6 +539,15 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)][cb], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx],
                                            fc[cb][ax], fc[cb][bx], fc[cb][vx], 4 * (s2 % 3) + 2 * h);
                 }
+                if (TVR_BPF && s == TVR_BPF_AT) {
+                    // the basis A fragments (the tile's last global loads) ride behind the last taps instead of stalling the first MFMA
+#pragma unroll
+                    for (int s3 = 0; s3 < 9; ++s3) {
+                        const uint4 *ap = (const uint4 *)sc.basis_frag + ((s3 * 2 + h) * 32 + e) * 2;
+                        bah[s3] = ap[0];
+                        bal[s3] = ap[1];
+                    }
+                }
                 const int p = s / 3;
                 const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
 #pragma unroll
@@ -548,12 +564,13 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #endif
             TVR_STAMP(tg1);
             // MATRIX phase starts: the basis A fragments are the last global loads of this tile, fetched before its first MFMA
-            uint4 bah[9], bal[9];
+            if (!(TVR_BPF && !(TVR_COAL && SRC == SH_SRC_QUEUE && SH_NCB == 1))) {
 #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
-                bah[s] = ap[0];
-                bal[s] = ap[1];
+                for (int s = 0; s < 9; ++s) {
+                    const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
+                    bah[s] = ap[0];
+                    bal[s] = ap[1];
+                }
             }
             TVR_SB;
             // three independent accumulation chains (hi*lo products) summed at the end: no MFMA directly follows its producer
