@@ -66,6 +66,19 @@ class AlphaGridMask:
         return (xyz_sampled - self.aabb[0].to(xyz_sampled.device)) * self.invgridSize.to(xyz_sampled.device) - 1
 
 
+def load_checkpoint(path):
+    """jt.load for the reference's `.th` checkpoints (train.py:43,75,148; written by tensorBase.py:253-264 through jt.save).  Jittor
+    (third-party, absent here) pickles the dict with every jt.Var turned into a numpy array, so plain `pickle` reads the file;
+    files written by this package's `save` (torch.save, a zip archive) are read with torch.load.  Returns the dict as stored."""
+    import pickle
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    if magic == b"PK":
+        return torch.load(path, map_location="cpu", weights_only=False)
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
 class MLPRender_Fea(torch.nn.Module):
     """tensorBase.py:62-86: parameters only; the arithmetic runs in the shade kernel of the owning field."""
 
@@ -293,12 +306,27 @@ class TensorBase(torch.nn.Module):
             ckpt.update({'alphaMask.aabb': self.alphaMask.aabb})
         torch.save(ckpt, path)
 
-    def load(self, ckpt):                                                                     # :266-272
+    def load(self, ckpt):                                                                     # :266-272 (+ load_parameterlist :273-322)
+        """Accepts our own checkpoints and the dict `load_checkpoint` reads from a reference `.th` file: values may be numpy arrays,
+        and a Jittor state_dict also lists every non-parameter Var of the module (aabb, units, stepSize, ...), which is ignored."""
         if 'alphaMask.aabb' in ckpt.keys():
             length = int(np.prod(ckpt['alphaMask.shape']))
-            vol = torch.from_numpy(np.unpackbits(ckpt['alphaMask.mask'])[:length].reshape(ckpt['alphaMask.shape']))
-            self.alphaMask = AlphaGridMask(self.device, ckpt['alphaMask.aabb'], vol.float())
-        self.load_state_dict(ckpt['state_dict'])
+            vol = torch.from_numpy(np.unpackbits(np.asarray(ckpt['alphaMask.mask']))[:length].reshape(tuple(ckpt['alphaMask.shape'])))
+            self.alphaMask = AlphaGridMask(self.device, np.asarray(ckpt['alphaMask.aabb'], np.float32), vol.float())
+        own = self.state_dict()
+        sd, missing = {}, []
+        for k, cur in own.items():
+            if k not in ckpt['state_dict']:
+                missing.append(k)
+                continue
+            v = torch.as_tensor(np.asarray(ckpt['state_dict'][k]) if not torch.is_tensor(ckpt['state_dict'][k]) else ckpt['state_dict'][k])
+            if tuple(v.shape) != tuple(cur.shape):
+                raise ValueError(f"checkpoint parameter {k}: shape {tuple(v.shape)}, model expects {tuple(cur.shape)} "
+                                 "(construct the model from the checkpoint's kwargs)")
+            sd[k] = v.to(torch.float32)
+        if missing:
+            raise KeyError(f"checkpoint lacks parameters {missing}")
+        self.load_state_dict(sd)
 
     @property
     def alphaMask(self) -> Optional[AlphaGridMask]:

@@ -160,6 +160,41 @@ def test_checkpoint_save_load_roundtrip(tmp_path, tiny_arrays, hyper_tiny):
     assert m2.get_kwargs()["gridSize"] == m.get_kwargs()["gridSize"]
 
 
+def test_reads_reference_th_checkpoint_layout(tmp_path, tiny_arrays, hyper_tiny):
+    """A `.th` file as the reference writes it (tensorBase.py:253-264 via jt.save: a pickled dict whose jt.Vars became numpy arrays; Jittor's
+    state_dict also lists the module's non-parameter Vars) loads through load_checkpoint + the reference's rebuild sequence (train.py:75-87)."""
+    import pickle
+    from jittor_myc_nerfs_amd import TensorVMSplit, load_checkpoint
+    m = make_model(tiny_arrays, hyper_tiny, device="cpu")
+    sd = {k: v.numpy().copy() for k, v in m.state_dict().items()}
+    sd.update({"aabb": tiny_arrays["aabb"], "units": np.ones(3, np.float32), "stepSize": np.float32(0.1), "alphaMask.alpha_volume": np.zeros((1, 1, 2, 2, 2), np.float32)})
+    vol = (np.random.default_rng(1).random((1, 1, 5, 4, 3)) > 0.5)
+    kwargs = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in m.get_kwargs().items()}
+    ckpt = {"kwargs": kwargs, "state_dict": sd, "alphaMask.shape": vol.shape, "alphaMask.mask": np.packbits(vol.reshape(-1)),
+            "alphaMask.aabb": np.asarray(tiny_arrays["aabb"], np.float32)}
+    path = str(tmp_path / "Scar.th")
+    with open(path, "wb") as f:
+        pickle.dump(ckpt, f)
+    got = load_checkpoint(path)
+    kw = got["kwargs"]
+    kw.update({"device": "cpu"})
+    m2 = TensorVMSplit(**kw)
+    m2.load(got)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert np.array_equal(m2.alphaMask.alpha_volume.numpy().reshape(5, 4, 3) > 0.5, vol.reshape(5, 4, 3))
+    # our own (torch.save) files go through the same reader
+    p2 = str(tmp_path / "own.th")
+    m.save(p2)
+    assert set(load_checkpoint(p2)["state_dict"]) == set(m.state_dict())
+    # a checkpoint of another shape is refused with a clear message, a missing parameter too
+    bad = dict(got, state_dict=dict(sd, **{"basis_mat.weight": np.zeros((27, 100), np.float32)}))
+    with pytest.raises(ValueError):
+        m2.load(bad)
+    with pytest.raises(KeyError):
+        m2.load(dict(got, state_dict={k: v for k, v in sd.items() if k != "basis_mat.weight"}))
+
+
 def test_grid_sizing_helpers_match_survey_appendix_c():
     from jittor_myc_nerfs_amd import N_to_reso, cal_n_samples
     assert N_to_reso(2097156, ([-5.0] * 3, [5.0] * 3)) == [128, 128, 128]
