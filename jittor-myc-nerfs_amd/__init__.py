@@ -7,4 +7,5 @@ from .field import AlphaGridMask, MLPRender_Fea, MLPRender_Fea_Ref, REFTensoRF, 
 from .render import OctreeRender_trilinear_fast, N_to_reso, cal_n_samples, render_sharded, shard_indices, shard_capacity  # noqa: F401
 from .evaluation import BlenderRays, evaluation, evaluation_path, rgb_ssim  # noqa: F401
 from .losses import TVLoss  # noqa: F401
+from .training import GradBucket, shard_batch  # noqa: F401
 from . import rays, synthetic  # noqa: F401

@@ -5,7 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench
-from jittor_myc_nerfs_amd import OctreeRender_trilinear_fast, TVLoss
+import torch.distributed as dist
+from jittor_myc_nerfs_amd import GradBucket, OctreeRender_trilinear_fast, TVLoss, shard_batch
+# data-parallel: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 scripts/train_step_timing.py
+world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+if world > 1:
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    dist.init_process_group(os.environ.get("TVR_BENCH_BACKEND", "nccl"))
 m, arrs, A = bench.build_model(torch.device("cuda"))
 with torch.no_grad():                                  # start from a perturbed copy so that gradients are non-trivial
     for p in m.parameters():
@@ -20,13 +26,15 @@ nS = int(np.linalg.norm(A["gridSize"]) / 0.5)
 opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
 tv = TVLoss()
 g = torch.Generator(device="cuda").manual_seed(0)
+bucket = GradBucket(m)                                 # all gradients in one 70 MB buffer: one all-reduce per step
 def step():
-    idx = torch.randint(0, allrays.shape[0], (4096,), device="cuda", generator=g)
-    opt.zero_grad()
+    idx = torch.randint(0, allrays.shape[0], (4096,), device="cuda", generator=g)[shard_batch(4096, rank, world)]
+    bucket.zero()
     rgb_map, _, _, _, _ = OctreeRender_trilinear_fast(allrays[idx], m, chunk=4096, N_samples=nS, white_bg=True, is_train=True)
     loss = torch.mean((rgb_map - allrgbs[idx]) ** 2)
     total = loss + 1e-4 * m.vector_comp_diffs() + 8e-5 * m.density_L1() + 0.1 * m.TV_loss_density(tv) + 0.01 * m.TV_loss_app(tv)
     total.backward()
+    bucket.all_reduce_mean()
     opt.step()
     return loss
 for _ in range(3): step()
@@ -34,4 +42,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 N = 20
 for _ in range(N): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
-print(f"train step: {dt * 1e3:.2f} ms  ({1 / dt:.1f} it/s), batch 4096 rays x {nS} samples, loss {float(l.detach()):.3e}")
+if rank == 0: print(f"train step ({world} rank(s), {4096 // world} rays each): {dt * 1e3:.2f} ms  ({1 / dt:.1f} it/s), batch 4096 rays x {nS} samples, loss {float(l.detach()):.3e}")
