@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 101
+#define TVR_VERSION 102
 
 typedef enum {
     TVR_OK = 0,
@@ -117,6 +117,14 @@ int tvr_render(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_sa
                void *scratch, size_t scratch_bytes, const tvr_dense_out *dense, uint64_t *stats,
                tvr_profile *prof, void *stream);
 
+/* The same with EXPLICIT sample depths z_vals [n,S] (ascending per ray) instead of uniform steps from the box entry: the foreground of
+ * NerfPlusPlus.execute (tensorf-myc/models/nerfplusplus.py:272-276), whose sample_ray (:239-269) spaces the samples between `near`
+ * and the bounding sphere and perturbs every one.  dists[j] = z[j+1]-z[j], 0 for the last (tensorBase.py:488).
+ * t_last_tiny_out [n] or NULL: prod_j (1 - alpha_j + 1e-6), the `bg_lambda` of nerfplusplus.py:277-278. */
+int tvr_render_z(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, int32_t white_bg,
+                 const float *z_vals, float eps_T, float *rgb_out, float *depth_out, float *t_last_tiny_out,
+                 void *scratch, size_t scratch_bytes, const tvr_dense_out *dense, uint64_t *stats, void *stream);
+
 /* TensorVMSplit.compute_densityfeature (tensoRF.py:209-225): xyz_norm [m,3] -> out [m]. */
 int tvr_density_feature(tvr_scene *scene, const float *xyz_norm, int64_t m, float *out, void *stream);
 /* TensorVMSplit.compute_appfeature (tensoRF.py:228-244): xyz_norm [m,3] -> out [m,app_dim]. */
@@ -150,6 +158,10 @@ int tvr_scratch_describe(int64_t n_rays, int32_t n_samples, tvr_scratch_layout *
 int tvr_march_forward(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *jitter, float eps_T,
                       float *depth_out, void *scratch, size_t scratch_bytes, void *stream);
 
+/* Explicit-depth variant (NerfPlusPlus foreground under autograd); t_last_tiny_out [n] or NULL as in tvr_render_z. */
+int tvr_march_forward_z(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *z_vals, float eps_T,
+                        float *depth_out, float *t_last_tiny_out, void *scratch, size_t scratch_bytes, void *stream);
+
 /* Gradient outputs in the REFERENCE parameter layout ((1,C,H,W) planes, (1,C,L,1) lines); each call overwrites its six. */
 typedef struct { float *density_plane[3], *density_line[3], *app_plane[3], *app_line[3]; } tvr_vm_grads;
 size_t tvr_grad_scratch_bytes(const tvr_scene *scene);      /* packed gradient images used internally by the two backward calls */
@@ -159,6 +171,12 @@ size_t tvr_grad_scratch_bytes(const tvr_scene *scene);      /* packed gradient i
 int tvr_march_backward(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *jitter, float eps_T,
                        const void *fwd_scratch, size_t fwd_scratch_bytes, const float *grad_w, const float *grad_acc,
                        void *grad_scratch, size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream);
+
+/* Explicit-depth variant; t_last_tiny [n] (forward values) with grad_t_last_tiny [n] = d loss / d t_last_tiny, or both NULL. */
+int tvr_march_backward_z(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *z_vals, float eps_T,
+                         const void *fwd_scratch, size_t fwd_scratch_bytes, const float *grad_w, const float *grad_acc,
+                         const float *t_last_tiny, const float *grad_t_last_tiny, void *grad_scratch, size_t grad_scratch_bytes,
+                         const tvr_vm_grads *out, void *stream);
 
 /* h [m,144] = bilinear(app_plane) * linear(app_line), plane-major (tensoRF.py:235-241, before basis_mat), and its backward. */
 int tvr_app_h_forward(tvr_scene *scene, const float *xyz_norm, int64_t m, float *h_out, void *stream);

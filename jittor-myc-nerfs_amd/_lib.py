@@ -54,6 +54,12 @@ SYMBOLS = {
     "tvr_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DenseOut), C.c_void_p,
                              C.c_void_p, C.c_void_p]),
+    "tvr_render_z": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DenseOut), C.c_void_p, C.c_void_p]),
+    "tvr_march_forward_z": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    "tvr_march_backward_z": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.c_void_p]),
     "tvr_density_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tvr_app_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tvr_mlp_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -223,9 +223,11 @@ size_t tvr_render_scratch_bytes(const tvr_scene *s, int64_t n_rays, int32_t n_sa
     return scratch_layout(n_rays, n_samples).total;
 }
 
-int tvr_render(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, const float *jitter, float eps_T,
-               float *rgb_out, float *depth_out, void *scratch, size_t scratch_bytes, const tvr_dense_out *dense,
-               uint64_t *stats, tvr_profile *prof, void *stream_)
+}  // extern "C"
+
+static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, const MarchSampling &sm, float eps_T,
+                       float *rgb_out, float *depth_out, float *lam6_out, void *scratch, size_t scratch_bytes, const tvr_dense_out *dense,
+                       uint64_t *stats, tvr_profile *prof, void *stream_)
 {
     if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
     if (n_rays == 0) return TVR_OK;
@@ -251,11 +253,12 @@ int tvr_render(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32
     mo.q_ray = (unsigned *)(b + L.q_ray);
     mo.q_j = (dense && dense->rgb) ? (unsigned *)(b + L.q_j) : nullptr;
     mo.stats = (unsigned long long *)stats;
+    mo.lam6 = lam6_out;
 
     hipEvent_t *ev = prof ? &prof->ev[(size_t)prof->n_calls * 4] : nullptr;
     HIP_TRY(hipMemsetAsync(mo.counter, 0, 4, stream));
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
-    HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, jitter, eps_T, mo, dense, stream));
+    HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, dense, stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
     ShadeArgs sa;
     memset(&sa, 0, sizeof(sa));
@@ -279,6 +282,26 @@ int tvr_render(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32
     return TVR_OK;
 }
 
+extern "C" {
+
+int tvr_render(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, const float *jitter, float eps_T,
+               float *rgb_out, float *depth_out, void *scratch, size_t scratch_bytes, const tvr_dense_out *dense,
+               uint64_t *stats, tvr_profile *prof, void *stream)
+{
+    const MarchSampling sm = {jitter, nullptr};
+    return render_impl(s, rays, n_rays, S, white_bg, sm, eps_T, rgb_out, depth_out, nullptr, scratch, scratch_bytes, dense, stats, prof, stream);
+}
+
+int tvr_render_z(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, const float *z_vals, float eps_T,
+                 float *rgb_out, float *depth_out, float *t_last_tiny_out, void *scratch, size_t scratch_bytes, const tvr_dense_out *dense,
+                 uint64_t *stats, void *stream)
+{
+    if (!z_vals) return fail(TVR_ERR_INVALID, "z_vals is NULL");
+    const MarchSampling sm = {nullptr, z_vals};
+    return render_impl(s, rays, n_rays, S, white_bg, sm, eps_T, rgb_out, depth_out, t_last_tiny_out, scratch, scratch_bytes, dense, stats, nullptr, stream);
+}
+
+}  // extern "C"
 
 static int scene_ready(const tvr_scene *s)
 {
@@ -299,8 +322,11 @@ static MarchOut carve_scratch(char *b, const ScratchLayout &L, float *depth_out)
     mo.q_ray = (unsigned *)(b + L.q_ray);
     mo.q_j = nullptr;
     mo.stats = nullptr;
+    mo.lam6 = nullptr;
     return mo;
 }
+
+extern "C" {
 
 int tvr_scratch_describe(int64_t n_rays, int32_t n_samples, tvr_scratch_layout *out)
 {
@@ -311,8 +337,10 @@ int tvr_scratch_describe(int64_t n_rays, int32_t n_samples, tvr_scratch_layout *
     return TVR_OK;
 }
 
-int tvr_march_forward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *jitter, float eps_T, float *depth_out,
-                      void *scratch, size_t scratch_bytes, void *stream_)
+}  // extern "C"
+
+static int march_forward_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const MarchSampling &sm, float eps_T, float *depth_out,
+                              float *lam6_out, void *scratch, size_t scratch_bytes, void *stream_)
 {
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
@@ -324,9 +352,27 @@ int tvr_march_forward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S
     if (!scratch || scratch_bytes < L.total || (uintptr_t)scratch % 256) return fail(TVR_ERR_SCRATCH, "scratch too small (%zu < %zu) or misaligned", scratch_bytes, L.total);
     hipStream_t stream = (hipStream_t)stream_;
     MarchOut mo = carve_scratch((char *)scratch, L, depth_out);
+    mo.lam6 = lam6_out;
     HIP_TRY(hipMemsetAsync(mo.counter, 0, 4, stream));
-    HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, jitter, eps_T, mo, nullptr, stream));
+    HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, nullptr, stream));
     return TVR_OK;
+}
+
+extern "C" {
+
+int tvr_march_forward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *jitter, float eps_T, float *depth_out,
+                      void *scratch, size_t scratch_bytes, void *stream)
+{
+    const MarchSampling sm = {jitter, nullptr};
+    return march_forward_impl(s, rays, n_rays, S, sm, eps_T, depth_out, nullptr, scratch, scratch_bytes, stream);
+}
+
+int tvr_march_forward_z(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *z_vals, float eps_T, float *depth_out,
+                        float *t_last_tiny_out, void *scratch, size_t scratch_bytes, void *stream)
+{
+    if (!z_vals) return fail(TVR_ERR_INVALID, "z_vals is NULL");
+    const MarchSampling sm = {nullptr, z_vals};
+    return march_forward_impl(s, rays, n_rays, S, sm, eps_T, depth_out, t_last_tiny_out, scratch, scratch_bytes, stream);
 }
 
 size_t tvr_grad_scratch_bytes(const tvr_scene *s)
@@ -347,9 +393,11 @@ static TrainGrads carve_grads(const tvr_scene *s, char *g)
     return tg;
 }
 
-int tvr_march_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *jitter, float eps_T, const void *fwd_scratch,
-                       size_t fwd_scratch_bytes, const float *grad_w, const float *grad_acc, void *grad_scratch, size_t grad_scratch_bytes,
-                       const tvr_vm_grads *out, void *stream_)
+}  // extern "C"
+
+static int march_backward_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const MarchSampling &sm, float eps_T, const void *fwd_scratch,
+                               size_t fwd_scratch_bytes, const float *grad_w, const float *grad_acc, const float *lam6, const float *grad_lam6,
+                               void *grad_scratch, size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream_)
 {
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
@@ -367,7 +415,7 @@ int tvr_march_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
         HIP_TRY(hipMemsetAsync(tg.dline[i], 0, (Ln + 1) * TVR_CD * sizeof(float), stream));
     }
     MarchOut mo = carve_scratch((char *)fwd_scratch, L, nullptr);
-    HIP_TRY(launch_march_backward(s->dev, rays, (int)n_rays, S, jitter, eps_T, mo, grad_w, grad_acc, tg, stream));
+    HIP_TRY(launch_march_backward(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, grad_w, grad_acc, lam6, grad_lam6, tg, stream));
     for (int i = 0; i < 3; ++i) {
         if (!out->density_plane[i] || !out->density_line[i]) return fail(TVR_ERR_INVALID, "density gradient pointer %d is NULL", i);
         const int W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
@@ -375,6 +423,28 @@ int tvr_march_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
         HIP_TRY(launch_unpack_grad(tg.dline[i], out->density_line[i], TVR_CD, Ln, 1, stream));
     }
     return TVR_OK;
+}
+
+extern "C" {
+
+int tvr_march_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *jitter, float eps_T, const void *fwd_scratch,
+                       size_t fwd_scratch_bytes, const float *grad_w, const float *grad_acc, void *grad_scratch, size_t grad_scratch_bytes,
+                       const tvr_vm_grads *out, void *stream)
+{
+    const MarchSampling sm = {jitter, nullptr};
+    return march_backward_impl(s, rays, n_rays, S, sm, eps_T, fwd_scratch, fwd_scratch_bytes, grad_w, grad_acc, nullptr, nullptr, grad_scratch,
+                               grad_scratch_bytes, out, stream);
+}
+
+int tvr_march_backward_z(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *z_vals, float eps_T, const void *fwd_scratch,
+                         size_t fwd_scratch_bytes, const float *grad_w, const float *grad_acc, const float *t_last_tiny,
+                         const float *grad_t_last_tiny, void *grad_scratch, size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream)
+{
+    if (!z_vals) return fail(TVR_ERR_INVALID, "z_vals is NULL");
+    if ((t_last_tiny == nullptr) != (grad_t_last_tiny == nullptr)) return fail(TVR_ERR_INVALID, "t_last_tiny and its gradient go together");
+    const MarchSampling sm = {nullptr, z_vals};
+    return march_backward_impl(s, rays, n_rays, S, sm, eps_T, fwd_scratch, fwd_scratch_bytes, grad_w, grad_acc, t_last_tiny, grad_t_last_tiny,
+                               grad_scratch, grad_scratch_bytes, out, stream);
 }
 
 int tvr_app_h_forward(tvr_scene *s, const float *xyz, int64_t m, float *h_out, void *stream)

@@ -18,6 +18,13 @@ struct MarchOut {
     unsigned *q_ray;          // [cap] ray index (for the view direction)
     unsigned *q_j;            // [cap] sample index, or nullptr
     unsigned long long *stats;// TVR_STAT_* counters or nullptr
+    float *lam6;              // [n_rays] prod_j (1 - alpha_j + 1e-6) (NerfPlusPlus bg_lambda, nerfplusplus.py:277-278) or nullptr
+};
+
+// how the samples of a ray are placed: uniform steps from the box entry (+ one jitter per ray), or explicit depths [n,S]
+struct MarchSampling {
+    const float *jitter;      // [n_rays] or nullptr
+    const float *zv;          // [n_rays,S] or nullptr (NerfPlusPlus.sample_ray, nerfplusplus.py:239-269)
 };
 
 // packed (channels-last, zero-padded) gradient images of the VM factors, same geometry as the packed scene
@@ -44,7 +51,7 @@ struct ShadeArgs {
     unsigned long long *stats;
 };
 
-hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T,
+hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T,
                         const MarchOut &mo, const tvr_dense_out *dense, hipStream_t stream);
 hipError_t launch_composite(const MarchOut &mo, int n_rays, int white_bg, float *rgb, hipStream_t stream);
 hipError_t launch_scatter_rgb(const MarchOut &mo, int S, float *rgb_dense, hipStream_t stream);
@@ -54,8 +61,9 @@ hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a
 hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, hipStream_t stream);
 hipError_t launch_pack_mlp(const float *W, void *out_hi, void *out_lo, int mode, hipStream_t stream);
 hipError_t launch_pack_ref(const float *const W[4], const float *const b[4], void *rows, float *bias, hipStream_t stream);
-hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T, const MarchOut &mo,
-                                 const float *grad_w, const float *grad_acc, const TrainGrads &tg, hipStream_t stream);
+hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T, const MarchOut &mo,
+                                 const float *grad_w, const float *grad_acc, const float *lam6, const float *grad_lam6, const TrainGrads &tg,
+                                 hipStream_t stream);
 hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream);
 hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream);
 hipError_t launch_unpack_grad(const float *in, float *out, int C, int H, int W, hipStream_t stream);

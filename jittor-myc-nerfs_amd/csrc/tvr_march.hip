@@ -77,7 +77,7 @@ __device__ __forceinline__ float4 vm_term_lds(const float4 *__restrict__ P, cons
 template <bool DENSE, bool LDSL>
 __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const SceneDev sc, const float *__restrict__ rays,
                                                                      const int n_rays, const int S, const int s_cap,
-                                                                     const float *__restrict__ jitter, const float eps_T,
+                                                                     const MarchSampling sm, const float eps_T,
                                                                      MarchOut mo, const tvr_dense_out dn)
 {
     // LDS: [cursor 16 B][lines: 3 x (L+1) x 4 float4, LDSL only][per-wave weight lists f32 s_cap][per-wave sample lists u16 s_cap]
@@ -131,8 +131,11 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
             d[k] = rays[(size_t)ray * 6 + 3 + k];
         }
         const float tmin = ray_tmin(sc, o, d);
-        const bool has_jit = jitter != nullptr;
-        const float u = has_jit ? jitter[ray] : 0.0f;
+        const bool has_jit = sm.jitter != nullptr;
+        const float u = has_jit ? sm.jitter[ray] : 0.0f;
+        const float *__restrict__ zrow = sm.zv ? sm.zv + (size_t)ray * S : nullptr;     // explicit depths (wave-uniform choice)
+        float lam6 = 1.0f;
+        int n6 = 0;                                        // samples whose (1 - alpha + 1e-6) factor lam6 already holds
 
         float T = 1.0f, acc_l = 0.0f, dep_l = 0.0f;
         int napp = 0;
@@ -143,8 +146,12 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
             const bool inr = j < S;
             float fj = (float)j, fj1 = (float)(j + 1);
             if (has_jit) { fj = fj + u; fj1 = fj1 + u; }
-            const float z = tmin + sc.step * fj;               // tensorBase.py:354-355
-            const float z1 = tmin + sc.step * fj1;
+            float z = tmin + sc.step * fj;                     // tensorBase.py:354-355
+            float z1 = tmin + sc.step * fj1;
+            if (zrow) {
+                z = inr ? zrow[j] : 0.0f;
+                z1 = (j < S - 1) ? zrow[j + 1] : z;
+            }
             float p[3], n[3], f[3];
             bool bbox = inr;
 #pragma unroll
@@ -224,6 +231,13 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
             dist = dist * sc.scale;                               // :511
             const float alpha = 1.0f - expf(-sigma * dist);       // :19
             const float fT = (1.0f - alpha) + 1e-10f;             // :21
+            if (mo.lam6) {                                        // nerfplusplus.py:277: cumprod(1 - alpha + TINY_NUMBER), TINY_NUMBER = 1e-6
+                float f6 = inr ? (1.0f - alpha) + 1e-6f : 1.0f;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) f6 = f6 * __shfl_xor(f6, off);
+                lam6 = lam6 * f6;
+                n6 += min(64, S - c * 64);
+            }
             float incl = fT;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
                 if (j < S) {
                     const size_t q = (size_t)ray * S + j;
                     const float fjj = has_jit ? ((float)j + u) : (float)j;
-                    if (dn.z) dn.z[q] = tmin + sc.step * fjj;
+                    if (dn.z) dn.z[q] = zrow ? zrow[j] : tmin + sc.step * fjj;
                     if (dn.valid) dn.valid[q] = 0;
                     if (dn.bbox_valid) dn.bbox_valid[q] = 0;
                     if (dn.cell) { dn.cell[q * 3] = 0; dn.cell[q * 3 + 1] = 0; dn.cell[q * 3 + 2] = 0; }
@@ -283,6 +297,8 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
             mo.ray_cnt[ray] = (unsigned)napp;
             mo.acc[ray] = acc;
             mo.depth[ray] = dep + (1.0f - acc) * d[2];            // :531 (rays[..., -1] is d_z)
+            // samples of skipped chunks / behind an early exit have alpha = 0: each factor is fp32(1 + 1e-6) = 1 + 8 ulp, log = 9.5367386e-7
+            if (mo.lam6) mo.lam6[ray] = lam6 * expf((float)(S - n6) * 9.5367386e-7f);
             if (DENSE) {
                 if (dn.bg_weight) dn.bg_weight[ray] = T;
                 if (dn.acc) dn.acc[ray] = acc;
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
             const unsigned ej = bufj[i];
             float fj = (float)ej;
             if (has_jit) fj = fj + u;
-            const float z = tmin + sc.step * fj;
+            const float z = zrow ? zrow[ej] : tmin + sc.step * fj;
             float4 qv;
             qv.x = ((o[0] + d[0] * z) - sc.lo[0]) * sc.inv[0] - 1.0f;
             qv.y = ((o[1] + d[1] * z) - sc.lo[1]) * sc.inv[1] - 1.0f;
@@ -400,12 +416,12 @@ __global__ __launch_bounds__(256) void alpha_sample_kernel(const SceneDev sc, co
 
 // ---- host launchers ----
 template <bool DENSE, bool LDSL>
-static hipError_t launch_march_t(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T, const MarchOut &mo,
+static hipError_t launch_march_t(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T, const MarchOut &mo,
                                  const tvr_dense_out &dn, int waves, size_t lds, unsigned grid, hipStream_t stream)
 {
     hipError_t rc = hipFuncSetAttribute((const void *)march_kernel<DENSE, LDSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL((march_kernel<DENSE, LDSL>), dim3(grid), dim3(64 * waves), lds, stream, sc, rays, n_rays, S, S, jitter, eps_T, mo, dn);
+    hipLaunchKernelGGL((march_kernel<DENSE, LDSL>), dim3(grid), dim3(64 * waves), lds, stream, sc, rays, n_rays, S, S, sm, eps_T, mo, dn);
     return hipGetLastError();
 }
 
@@ -420,7 +436,7 @@ static int device_cu_count()
     return cus;
 }
 
-hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T,
+hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T,
                         const MarchOut &mo, const tvr_dense_out *dense, hipStream_t stream)
 {
     // LDS budget: the density lines (if they fit next to at least 4 waves' lists) + 6 B per sample and wave for the appearance lists
@@ -437,10 +453,10 @@ hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S
     if (grid < 1) grid = 1;
     tvr_dense_out none = {};
     const tvr_dense_out &dn = dense ? *dense : none;
-    if (dense) return ldsl ? launch_march_t<true, true>(sc, rays, n_rays, S, jitter, eps_T, mo, dn, waves, lds, (unsigned)grid, stream)
-                           : launch_march_t<true, false>(sc, rays, n_rays, S, jitter, eps_T, mo, dn, waves, lds, (unsigned)grid, stream);
-    return ldsl ? launch_march_t<false, true>(sc, rays, n_rays, S, jitter, eps_T, mo, dn, waves, lds, (unsigned)grid, stream)
-                : launch_march_t<false, false>(sc, rays, n_rays, S, jitter, eps_T, mo, dn, waves, lds, (unsigned)grid, stream);
+    if (dense) return ldsl ? launch_march_t<true, true>(sc, rays, n_rays, S, sm, eps_T, mo, dn, waves, lds, (unsigned)grid, stream)
+                           : launch_march_t<true, false>(sc, rays, n_rays, S, sm, eps_T, mo, dn, waves, lds, (unsigned)grid, stream);
+    return ldsl ? launch_march_t<false, true>(sc, rays, n_rays, S, sm, eps_T, mo, dn, waves, lds, (unsigned)grid, stream)
+                : launch_march_t<false, false>(sc, rays, n_rays, S, sm, eps_T, mo, dn, waves, lds, (unsigned)grid, stream);
 }
 
 hipError_t launch_composite(const MarchOut &mo, int n_rays, int white_bg, float *rgb, hipStream_t stream)

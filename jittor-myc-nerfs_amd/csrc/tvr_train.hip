@@ -140,9 +140,10 @@ __device__ __forceinline__ float wave_sum_f(float v)
 
 template <bool LINE_LDS>
 __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneDev sc, const float *__restrict__ rays, const int n_rays, const int S,
-                                                                    const float *__restrict__ jitter, const float eps_T, const int rays_per_block,
+                                                                    const MarchSampling sm, const float eps_T, const int rays_per_block,
                                                                     const MarchOut mo, const float *__restrict__ grad_w,
-                                                                    const float *__restrict__ grad_acc, TrainGrads tg)
+                                                                    const float *__restrict__ grad_acc, const float *__restrict__ lam6,
+                                                                    const float *__restrict__ grad_lam6, TrainGrads tg)
 {
     extern __shared__ __attribute__((aligned(16))) float glds[];      // [line 0 | line 1 | line 2] gradient accumulators, (L+1) x 16 each
     const int lane = threadIdx.x & 63;
@@ -164,8 +165,11 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
             d[k] = rays[(size_t)ray * 6 + 3 + k];
         }
         const float tmin = ray_tmin(sc, o, d);
-        const bool has_jit = jitter != nullptr;
-        const float u = has_jit ? jitter[ray] : 0.0f;
+        const bool has_jit = sm.jitter != nullptr;
+        const float u = has_jit ? sm.jitter[ray] : 0.0f;
+        const float *__restrict__ zrow = sm.zv ? sm.zv + (size_t)ray * S : nullptr;
+        // d lam6 / d alpha_k = -lam6 / (1 - alpha_k + 1e-6)   (lam6 = prod_j (1 - alpha_j + 1e-6), nerfplusplus.py:277-278)
+        const float g6 = grad_lam6 ? grad_lam6[ray] * lam6[ray] : 0.0f;
         const unsigned base = mo.ray_off[ray], cnt = mo.ray_cnt[ray];
         const float gacc = grad_acc[ray];
         // total = sum_k dL/dw_k w_k over the whole (possibly early-terminated) ray
@@ -181,8 +185,12 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
             const bool inr = j < S;
             float fj = (float)j, fj1 = (float)(j + 1);
             if (has_jit) { fj = fj + u; fj1 = fj1 + u; }
-            const float z = tmin + sc.step * fj;
-            const float z1 = tmin + sc.step * fj1;
+            float z = tmin + sc.step * fj;
+            float z1 = tmin + sc.step * fj1;
+            if (zrow) {
+                z = inr ? zrow[j] : 0.0f;
+                z1 = (j < S - 1) ? zrow[j + 1] : z;
+            }
             float p[3], n[3], f[3];
             bool bbox = inr;
 #pragma unroll
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
             }
             const float suffix = total - (prefix + pin);
             prefix += __shfl(pin, 63);
-            const float dLda = Tj * dLdw - suffix / fT;
+            const float dLda = Tj * dLdw - suffix / fT - g6 / ((1.0f - alpha) + 1e-6f);
             const float dLdsf = valid ? dLda * dist * (1.0f - alpha) * dsig_dsf : 0.0f;
             T = T * __shfl(incl, 63);
 
@@ -377,8 +385,9 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(const float *__restric
     }
 }
 
-hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const float *jitter, float eps_T, const MarchOut &mo,
-                                 const float *grad_w, const float *grad_acc, const TrainGrads &tg, hipStream_t stream)
+hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T, const MarchOut &mo,
+                                 const float *grad_w, const float *grad_acc, const float *lam6, const float *grad_lam6, const TrainGrads &tg,
+                                 hipStream_t stream)
 {
     const int rpb = TB_WAVES;
     const size_t lds = ((size_t)sc.grid[0] + sc.grid[1] + sc.grid[2] + 3) * TVR_CD * sizeof(float);
@@ -386,11 +395,11 @@ hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_ra
     if (lds <= 150 * 1024) {
         hipError_t rc = hipFuncSetAttribute((const void *)march_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (rc != hipSuccess) return rc;
-        hipLaunchKernelGGL(march_backward_kernel<true>, dim3(grid), dim3(TB_THREADS), lds, stream, sc, rays, n_rays, S, jitter, eps_T, rpb, mo,
-                           grad_w, grad_acc, tg);
+        hipLaunchKernelGGL(march_backward_kernel<true>, dim3(grid), dim3(TB_THREADS), lds, stream, sc, rays, n_rays, S, sm, eps_T, rpb, mo,
+                           grad_w, grad_acc, lam6, grad_lam6, tg);
     } else {
-        hipLaunchKernelGGL(march_backward_kernel<false>, dim3(grid), dim3(TB_THREADS), 0, stream, sc, rays, n_rays, S, jitter, eps_T, rpb, mo,
-                           grad_w, grad_acc, tg);
+        hipLaunchKernelGGL(march_backward_kernel<false>, dim3(grid), dim3(TB_THREADS), 0, stream, sc, rays, n_rays, S, sm, eps_T, rpb, mo,
+                           grad_w, grad_acc, lam6, grad_lam6, tg);
     }
     return hipGetLastError();
 }

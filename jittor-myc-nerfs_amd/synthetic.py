@@ -27,10 +27,11 @@ def _g(n: int, sigma: float) -> np.ndarray:
 def make_scene_arrays(gridSize: Sequence[int], aabb, seed: int = SEED,
                       density_n_comp=(16, 16, 16), appearance_n_comp=(48, 48, 48), app_dim: int = 27,
                       featureC: int = 128, view_pe: int = 2, fea_pe: int = 2, blob_sigma: float = 0.35,
-                      alpha_grid: Optional[Sequence[int]] = None, ref: bool = False) -> Dict[str, np.ndarray]:
+                      alpha_grid: Optional[Sequence[int]] = None, ref: bool = False, npp: Optional[float] = None) -> Dict[str, np.ndarray]:
     """Return a flat dict of fp32 arrays in the reference's parameter layout.  ref=True adds REFTensoRF's parameters
     (models/REFTensoRF.py:86-96 and the 151-input W1 of MLPRender_Fea_Ref) from a second generator, so that the arrays shared
-    with the TensorVMSplit scene of the same seed are identical."""
+    with the TensorVMSplit scene of the same seed are identical.  npp=<radii> adds NerfPlusPlus's background network
+    (models/nerfplusplus.py:147-163: bg_freq 4, bg_view_freq 2, bg_D 4, W 128) from a third generator."""
     rng = np.random.default_rng(seed)
     g = [int(x) for x in gridSize]
     out: Dict[str, np.ndarray] = {"aabb": np.asarray(aabb, np.float32).reshape(2, 3), "gridSize": np.asarray(g, np.int32)}
@@ -74,6 +75,23 @@ def make_scene_arrays(gridSize: Sequence[int], aabb, seed: int = SEED,
         out["diffuse_W"], out["diffuse_b"] = U2((3, K), K, 16.0), U2((3,), K) + np.float32(0.3)
         out["specular_W"], out["specular_b"] = U2((1, K), K, 64.0), U2((1,), K) + np.float32(0.5)
         out["rho_W"], out["rho_b"] = U2((1, K), K, 64.0), U2((1,), K) + np.float32(0.5)
+    if npp is not None:
+        r3 = np.random.default_rng(seed + 2)
+
+        def U3(shape, fan_in, scale=1.0):
+            b = 1.0 / np.sqrt(fan_in)
+            return (r3.uniform(-b, b, size=shape) * scale).astype(np.float32)
+        bg_freq, bg_view_freq, bg_D, W = 4, 2, 4, 128
+        ch_p, ch_v = 4 + 4 * 2 * bg_freq, 3 + 3 * 2 * bg_view_freq
+        out.update({"bg.radii": np.float32(npp), "bg.bg_freq": np.int32(bg_freq), "bg.bg_view_freq": np.int32(bg_view_freq), "bg.bg_D": np.int32(bg_D)})
+        dim = ch_p
+        for i in range(bg_D):
+            out[f"bg_net.base_layers.{i}.0.weight"], out[f"bg_net.base_layers.{i}.0.bias"] = U3((W, dim), dim), U3((W,), dim)
+            dim = W + (ch_p if (i == int(bg_D / 2) and i != bg_D - 1) else 0)
+        out["bg_net.sigma_layers.0.weight"], out["bg_net.sigma_layers.0.bias"] = U3((1, dim), dim, 20.0), U3((1,), dim)   # visible background density
+        out["bg_net.base_remap_layers.0.weight"], out["bg_net.base_remap_layers.0.bias"] = U3((256, dim), dim), U3((256,), dim)
+        out["bg_net.rgb_layers.0.weight"], out["bg_net.rgb_layers.0.bias"] = U3((W // 2, 256 + ch_v), 256 + ch_v), U3((W // 2,), 256 + ch_v)
+        out["bg_net.rgb_layers.2.weight"], out["bg_net.rgb_layers.2.bias"] = U3((3, W // 2), W // 2, 4.0), U3((3,), W // 2)
     if alpha_grid is not None:
         ag = [int(x) for x in alpha_grid]                      # (gx, gy, gz); volume stored (gz, gy, gx)
         zs, ys, xs = [np.linspace(-1, 1, n) for n in (ag[2], ag[1], ag[0])]

@@ -45,7 +45,7 @@ class OracleScene:
     def __init__(self, aabb, gridSize, density_plane, density_line, app_plane, app_line,
                  basis_mat, mlp, near_far=(2.0, 6.0), step_ratio=0.5, density_shift=-10.0,
                  distance_scale=25.0, rayMarch_weight_thres=1e-4, fea2denseAct="softplus",
-                 view_pe=2, fea_pe=2, alpha_volume=None, alpha_aabb=None, ref=None):
+                 view_pe=2, fea_pe=2, alpha_volume=None, alpha_aabb=None, ref=None, npp=None):
         self.aabb = _t(aabb).reshape(2, 3)
         self.gridSize = [int(g) for g in gridSize]
         self.density_plane = [_t(p) for p in density_plane]
@@ -67,6 +67,11 @@ class OracleScene:
         # REFTensoRF (tensorf-myc/models/REFTensoRF.py:86-96): {normal,diffuse,specular,rho}_{W,b}; mlp["W1"] is then [128,151]
         self.ref = None if ref is None else {k: _t(v) for k, v in ref.items()}
         self.penalty = torch.zeros(())
+        # NerfPlusPlus (tensorf-myc/models/nerfplusplus.py:147-163): {"radii", "bg_freq", "bg_view_freq", "bg_D", "net": {name: array}} with
+        # the MLPNet parameters under their module names (base_layers.i.0.weight, sigma_layers.0.weight, base_remap_layers.0.weight, rgb_layers.0/2.*)
+        self.npp = None
+        if npp is not None:
+            self.npp = dict(npp, net={k: _t(v) for k, v in npp["net"].items()})
         self.update_stepSize()
 
     # tensorf-myc/models/tensorBase.py:197-209
@@ -235,10 +240,14 @@ def shade_ref(sc: OracleScene, xyz_n_sel, views_sel, weight_sel):
 
 # tensorf-myc/models/tensorBase.py:476-536 (ndc_ray=False branch); with sc.ref set, tensorf-myc/models/REFTensoRF.py:174-256,
 # which differs only in the appearance branch (shade_ref)
-def execute(sc: OracleScene, rays_chunk, white_bg=True, N_samples=-1, jitter=None, dump=False):
+def execute(sc: OracleScene, rays_chunk, white_bg=True, N_samples=-1, jitter=None, dump=False, sampler=None):
     rays_chunk = _t(rays_chunk)
     viewdirs = rays_chunk[:, 3:6]
-    xyz, z_vals, ray_valid, t_min = sample_ray(sc, rays_chunk[:, :3], viewdirs, N_samples, jitter)
+    if sampler is not None:                         # a subclass's sample_ray override (NerfPlusPlus, nerfplusplus.py:239-269)
+        xyz, z_vals, ray_valid = sampler(rays_chunk[:, :3], viewdirs)
+        t_min = torch.zeros(rays_chunk.shape[0])
+    else:
+        xyz, z_vals, ray_valid, t_min = sample_ray(sc, rays_chunk[:, :3], viewdirs, N_samples, jitter)
     bbox_valid = ray_valid.clone()
     dists = torch.cat((z_vals[:, 1:] - z_vals[:, :-1], torch.zeros_like(z_vals[:, :1])), dim=-1)
     if dists.shape[0] != xyz.shape[0]:              # is_train=False: z_vals is [1,S] + [N,1] broadcast already
@@ -287,6 +296,135 @@ def execute(sc: OracleScene, rays_chunk, white_bg=True, N_samples=-1, jitter=Non
                 bbox_valid=bbox_valid, valid=ray_valid, cell=torch.floor(fidx).to(torch.int32),
                 sigma_feature=sigma_feature_full, sigma=sigma, alpha=alpha, weight=weight,
                 bg_weight=bg_weight, app_mask=app_mask, rgb=rgb)
+
+
+# ---- NerfPlusPlus (tensorf-myc/models/nerfplusplus.py) -------------------------------------------------------------------------
+HUGE_NUMBER = 1e10      # nerfplusplus.py:4
+TINY_NUMBER = 1e-6      # nerfplusplus.py:5
+
+
+# nerfplusplus.py:7-56 (Embedder, log_sampling=True, include_input=True, periodic_fns=(sin, cos))
+def embed(x, max_freq_log2, n_freqs):
+    freq_bands = (2.0 ** torch.linspace(0.0, float(max_freq_log2), n_freqs)).tolist()
+    out = [x]
+    for f in freq_bands:
+        out += [torch.sin(x * f), torch.cos(x * f)]
+    return torch.cat(out, dim=-1)
+
+
+# nerfplusplus.py:66-140 (MLPNet with W=128, skips=[int(D/2)], use_viewdirs=True as set_nerfplusplus builds it, :158-161)
+def mlpnet(net, D, skips, inp, input_ch, input_ch_viewdirs):
+    lin = lambda name, x: x @ net[name + ".weight"].T + net[name + ".bias"]
+    input_pts = inp[..., :input_ch]
+    base = torch.relu(lin("base_layers.0.0", input_pts))
+    for i in range(D - 1):
+        if i in skips:
+            base = torch.cat((input_pts, base), dim=-1)
+        base = torch.relu(lin(f"base_layers.{i + 1}.0", base))
+    sigma = torch.abs(lin("sigma_layers.0", base))
+    base_remap = lin("base_remap_layers.0", base)
+    input_viewdirs = inp[..., -input_ch_viewdirs:]
+    h = torch.relu(lin("rgb_layers.0", torch.cat((base_remap, input_viewdirs), dim=-1)))
+    rgb = torch.sigmoid(lin("rgb_layers.2", h))
+    return rgb, sigma.squeeze(-1)
+
+
+# nerfplusplus.py:178-194
+def intersect_sphere(ray_o, ray_d, radii):
+    d1 = -torch.sum(ray_d * ray_o, dim=-1) / torch.sum(ray_d * ray_d, dim=-1)
+    p = ray_o + d1.unsqueeze(-1) * ray_d
+    ray_d_cos = 1.0 / torch.norm(ray_d, dim=-1)
+    p_norm_sq = torch.sum(p * p, dim=-1)
+    if (p_norm_sq >= radii).any():
+        raise Exception("Not all your cameras are bounded by the unit sphere; please make sure the cameras are normalized properly!")
+    d2 = torch.sqrt(radii - p_norm_sq) * ray_d_cos
+    return d1 + d2
+
+
+# nerfplusplus.py:196-205; t_rand = jt.rand_like(z_vals), injected
+def perturb_samples(z_vals, t_rand):
+    mids = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    upper = torch.cat([mids, z_vals[..., -1:]], dim=-1)
+    lower = torch.cat([z_vals[..., 0:1], mids], dim=-1)
+    return lower + (upper - lower) * t_rand
+
+
+# nerfplusplus.py:207-237
+def depth2pts_outside(ray_o, ray_d, depth, radii):
+    d1 = -torch.sum(ray_d * ray_o, dim=-1) / torch.sum(ray_d * ray_d, dim=-1)
+    p_mid = ray_o + d1.unsqueeze(-1) * ray_d
+    p_mid_norm = torch.norm(p_mid, dim=-1)
+    ray_d_cos = 1.0 / torch.norm(ray_d, dim=-1)
+    d2 = torch.sqrt(radii * radii - p_mid_norm * p_mid_norm) * ray_d_cos
+    p_sphere = ray_o + (d1 + d2).unsqueeze(-1) * ray_d
+    rot_axis = torch.cross(ray_o, p_sphere, dim=-1)
+    rot_axis = rot_axis / torch.norm(rot_axis, dim=-1, keepdim=True)
+    phi = torch.asin(p_mid_norm / radii)
+    theta = torch.asin(p_mid_norm * depth / (radii * radii))
+    rot_angle = (phi - theta).unsqueeze(-1)
+    p_sphere_new = p_sphere * torch.cos(rot_angle) + torch.cross(rot_axis, p_sphere, dim=-1) * torch.sin(rot_angle) + \
+        rot_axis * torch.sum(rot_axis * p_sphere, dim=-1, keepdim=True) * (1.0 - torch.cos(rot_angle))
+    pts = torch.cat((p_sphere_new, depth.unsqueeze(-1)), dim=-1)
+    depth_real = radii / (depth + TINY_NUMBER) * torch.cos(theta) * ray_d_cos + d1
+    return pts, depth_real
+
+
+# nerfplusplus.py:239-269 (NerfPlusPlus.sample_ray): N samples between `near` and the sphere of radius `radii`, every one perturbed
+def sample_ray_npp(sc: OracleScene, rays_o, rays_d, N_samples, t_rand):
+    radii = float(sc.npp["radii"])
+    fg_far_depth = intersect_sphere(rays_o, rays_d, radii * radii)
+    near, far = sc.near_far
+    step = (fg_far_depth - near) / (N_samples - 1)
+    fg_depth = torch.stack([near + i * step for i in range(N_samples)], dim=-1)
+    interpx = perturb_samples(fg_depth, _t(t_rand))
+    rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+    mask_outbbox = ((sc.aabb[0] > rays_pts) | (rays_pts > sc.aabb[1])).any(dim=-1)
+    return rays_pts, interpx, ~mask_outbbox
+
+
+# nerfplusplus.py:272-318 (NerfPlusPlus.execute).  rand_fg [N,S] and rand_bg [N,bg_samples] are the two jt.rand_like draws;
+# bg_samples is the literal 512 of :284.
+def execute_npp(sc: OracleScene, rays_chunk, N_samples=-1, rand_fg=None, rand_bg=None, bg_samples=512, dump=False):
+    rays_chunk = _t(rays_chunk)
+    N_samples = N_samples if N_samples > 0 else sc.nSamples
+    P = sc.npp
+    radii = float(P["radii"])
+    d = execute(sc, rays_chunk, white_bg=False, N_samples=N_samples, dump=True,
+                sampler=lambda o, v: sample_ray_npp(sc, o, v, N_samples, rand_fg))          # :276 super().execute(rays_chunk, False, ...)
+    rgb_map, depth_map, alpha = d["rgb_map"], d["depth_map"], d["alpha"]
+    T = torch.cumprod(1.0 - alpha + TINY_NUMBER, dim=-1)
+    bg_lambda = T[..., -1]
+    ray_o, ray_d = rays_chunk[:, :3], rays_chunk[:, 3:6]
+    ray_d_norm = torch.norm(ray_d, dim=-1, keepdim=True)
+    viewdirs = ray_d / ray_d_norm
+    n = ray_d.shape[0]
+    bg_z_vals = torch.linspace(0.0, radii, bg_samples).view(1, bg_samples).expand(n, bg_samples)
+    bg_z_vals = perturb_samples(bg_z_vals, _t(rand_bg))
+    bg_ray_o = ray_o.unsqueeze(-2).expand(n, bg_samples, 3)
+    bg_ray_d = ray_d.unsqueeze(-2).expand(n, bg_samples, 3)
+    bg_viewdirs = viewdirs.unsqueeze(-2).expand(n, bg_samples, 3)
+    bg_pts, _ = depth2pts_outside(bg_ray_o, bg_ray_d, bg_z_vals, radii)
+    inp = torch.cat((embed(bg_pts, P["bg_freq"] - 1, P["bg_freq"]), embed(bg_viewdirs, P["bg_view_freq"] - 1, P["bg_view_freq"])), dim=-1)
+    inp = torch.flip(inp, dims=[-2])
+    bg_z_vals = torch.flip(bg_z_vals, dims=[-1])
+    bg_dists = bg_z_vals[..., :-1] - bg_z_vals[..., 1:]
+    bg_dists = torch.cat((bg_dists, HUGE_NUMBER * torch.ones_like(bg_dists[..., 0:1])), dim=-1)
+    ch_p, ch_v = 4 + 4 * 2 * P["bg_freq"], 3 + 3 * 2 * P["bg_view_freq"]
+    bg_rgb, bg_sigma = mlpnet(P["net"], P["bg_D"], [int(P["bg_D"] / 2)], inp, ch_p, ch_v)
+    bg_alpha = 1.0 - torch.exp(-bg_sigma * bg_dists)
+    T = torch.cumprod(1.0 - bg_alpha + TINY_NUMBER, dim=-1)[..., :-1]
+    T = torch.cat((torch.ones_like(T[..., 0:1]), T), dim=-1)
+    bg_weights = bg_alpha * T
+    bg_rgb_map = torch.sum(bg_weights.unsqueeze(-1) * bg_rgb, dim=-2)
+    bg_depth_map = torch.sum(bg_weights * bg_z_vals, dim=-1)
+    bg_lambda = torch.where(bg_lambda > 0.1, bg_lambda, torch.zeros_like(bg_lambda))
+    bg_rgb_map = bg_lambda.unsqueeze(-1) * bg_rgb_map
+    bg_depth_map = bg_lambda * bg_depth_map
+    rgb_map = rgb_map + bg_rgb_map
+    if dump:
+        return dict(rgb_map=rgb_map, depth_map=depth_map, fg_rgb_map=d["rgb_map"], bg_rgb_map=bg_rgb_map, bg_lambda=bg_lambda, z_vals=d["z_vals"],
+                    valid=d["valid"], app_mask=d["app_mask"], weight=d["weight"], bg_pts=bg_pts)
+    return rgb_map, depth_map
 
 
 # tensorf-myc/renderer.py:12-27
@@ -343,7 +481,11 @@ def scene_from_arrays(arrs: Dict[str, np.ndarray], **hyper) -> OracleScene:
     ref = None
     if "normal_W" in arrs:
         ref = {f"{n}_{s}": arrs[f"{n}_{s}"] for n in ("normal", "diffuse", "specular", "rho") for s in ("W", "b")}
-    return OracleScene(ref=ref,
+    npp = None
+    if "bg.radii" in arrs:
+        npp = dict(radii=float(arrs["bg.radii"]), bg_freq=int(arrs["bg.bg_freq"]), bg_view_freq=int(arrs["bg.bg_view_freq"]), bg_D=int(arrs["bg.bg_D"]),
+                   net={k[len("bg_net."):]: v for k, v in arrs.items() if k.startswith("bg_net.")})
+    return OracleScene(ref=ref, npp=npp,
         aabb=arrs["aabb"], gridSize=arrs["gridSize"],
         density_plane=[arrs[f"density_plane.{i}"] for i in range(3)],
         density_line=[arrs[f"density_line.{i}"] for i in range(3)],

@@ -71,11 +71,24 @@ def tiny_ref_arrays(tiny_arrays, tiny_ref):
     return a
 
 
+@pytest.fixture(scope="session")
+def tiny_npp():
+    return dict(np.load(os.path.join(GOLDEN, "tiny_npp.npz")))
+
+
+@pytest.fixture(scope="session")
+def tiny_npp_arrays(tiny_arrays, tiny_npp):
+    """NerfPlusPlus parameters: the tiny TensorVMSplit scene plus the background network of tiny_npp.npz."""
+    a = dict(tiny_arrays)
+    a.update({k[len("scene."):]: v for k, v in tiny_npp.items() if k.startswith("scene.")})
+    return a
+
+
 def make_model(arrs, hyper, device="cuda", gridSize=None, aabb=None):
     """TensorVMSplit (REFTensoRF when the arrays hold its extra linears) on `device` holding the given arrays (reference
     constructor signature, train.py:167-172)."""
-    from jittor_myc_nerfs_amd import REFTensoRF, TensorVMSplit
-    cls = REFTensoRF if "normal_W" in arrs else TensorVMSplit
+    from jittor_myc_nerfs_amd import NerfPlusPlus, REFTensoRF, TensorVMSplit
+    cls = REFTensoRF if "normal_W" in arrs else (NerfPlusPlus if "bg.radii" in arrs else TensorVMSplit)
     m = cls(arrs["aabb"] if aabb is None else aabb, [int(x) for x in (arrs["gridSize"] if gridSize is None else gridSize)],
                       device, density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
                       near_far=hyper["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4,

@@ -29,9 +29,27 @@ def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def tiny_scene(alpha=False, ref=False):
+def tiny_scene(alpha=False, ref=False, npp=None):
     return synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=TINY["seed"],
-                                       alpha_grid=[12, 10, 14] if alpha else None, ref=ref)
+                                       alpha_grid=[12, 10, 14] if alpha else None, ref=ref, npp=npp)
+
+
+def main_npp(hyper):
+    """(v) NerfPlusPlus (models/nerfplusplus.py) on the tiny scene, bounding sphere radius 6: the background network's arrays, the two
+    random draws the reference takes per call (injected), and the render with its foreground / background parts."""
+    arrs = tiny_scene(npp=6.0)
+    sc = TO.scene_from_arrays(arrs, **hyper)
+    rays = tiny_rays()
+    g = np.random.default_rng(17)
+    rf = g.random((rays.shape[0], TINY["N_samples"])).astype(np.float32)
+    rb = g.random((rays.shape[0], 512)).astype(np.float32)
+    d = dump_to_np(TO.execute_npp(sc, rays, N_samples=TINY["N_samples"], rand_fg=rf, rand_bg=rb, dump=True))
+    out = dict(rays=rays.numpy(), rand_fg=rf, rand_bg=rb, **{f"out.{k}": d[k] for k in ("rgb_map", "depth_map", "fg_rgb_map", "bg_rgb_map", "bg_lambda",
+                                                                                       "z_vals", "valid", "app_mask", "weight")},
+               **{f"scene.{k}": v for k, v in arrs.items() if k.startswith("bg")})
+    np.savez_compressed(os.path.join(HERE, "tiny_npp.npz"), **out)
+    print("tiny_npp.npz", os.path.getsize(os.path.join(HERE, "tiny_npp.npz")) // 1024, "KiB; valid/ray", float(d["valid"].sum(1).mean()),
+          "app", int(d["app_mask"].sum()), "bg_lambda>0:", int((d["bg_lambda"] > 0).sum()), "of", rays.shape[0])
 
 REF_KEYS = ("W1", "b1") + tuple(f"{n}_{s}" for n in ("normal", "diffuse", "specular", "rho") for s in ("W", "b"))
 
@@ -102,6 +120,8 @@ def main():
     hyper = dict(synthetic.HYPER, near_far=TINY["near_far"], step_ratio=TINY["step_ratio"])
     if "--only-ref" in sys.argv:
         return main_ref(hyper)
+    if "--only-npp" in sys.argv:
+        return main_npp(hyper)
 
     # (i) tiny scene, full per-sample dump, white_bg on, no alpha mask
     arrs = tiny_scene()
@@ -146,6 +166,7 @@ def main():
                         valid_bits=np.packbits(d1["valid"]), app_bits=np.packbits(d1["app_mask"]),
                         n_valid=int(d1["valid"].sum()), n_app=int(d1["app_mask"].sum()))
     main_ref(hyper)
+    main_npp(hyper)
     for fn in ("tiny_dump.npz", "tiny_edge.npz", "config1.npz"):
         print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
     print("tiny: valid", d["valid"].sum(), "app", d["app_mask"].sum(), "acc range", d["acc_map"].min(), d["acc_map"].max())

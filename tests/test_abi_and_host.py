@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(l, n), f"libtvr.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and include/tvr.h disagree"
-    assert _lib.lib().tvr_version() == 101
+    assert _lib.lib().tvr_version() == 102
 
 
 def test_abi_argument_errors_without_gpu():
@@ -193,6 +193,30 @@ def test_reads_reference_th_checkpoint_layout(tmp_path, tiny_arrays, hyper_tiny)
         m2.load(bad)
     with pytest.raises(KeyError):
         m2.load(dict(got, state_dict={k: v for k, v in sd.items() if k != "basis_mat.weight"}))
+
+
+def test_npp_host_logic_on_cpu(tiny_npp, tiny_npp_arrays, hyper_tiny):
+    """NerfPlusPlus's host side (models/nerfplusplus.py:143-269, 280-308) is plain torch: sampling and background agree with the golden
+    vectors without a GPU; the foreground render needs the HIP library and says so."""
+    from jittor_myc_nerfs_amd import NerfPlusPlus
+    from jittor_myc_nerfs_amd._lib import TvrError
+    m = make_model(tiny_npp_arrays, hyper_tiny, device="cpu")
+    assert isinstance(m, NerfPlusPlus) and m.radii == 6.0 and m.bg_embedder_position.out_dim == 36 and m.bg_embedder_viewdir.out_dim == 15
+    rays = torch.tensor(tiny_npp["rays"])
+    pts, z, mask = m.sample_ray(rays[:, :3], rays[:, 3:6], N_samples=TINY["N_samples"], t_rand=torch.tensor(tiny_npp["rand_fg"]))
+    assert np.array_equal(z.numpy(), tiny_npp["out.z_vals"]) and pts.shape == (64, TINY["N_samples"], 3)
+    lam = torch.tensor(tiny_npp["out.bg_lambda"])
+    with torch.no_grad():
+        bg = m._background(rays[:, :3], rays[:, 3:6], torch.tensor(tiny_npp["rand_bg"]))
+    assert np.abs((lam[:, None] * bg).numpy() - tiny_npp["out.bg_rgb_map"]).max() < 2e-5
+    assert len(m.get_optparam_groups()) == 7 and {"bg_freq", "bg_view_freq", "bg_D", "radii"} <= set(m.get_kwargs())
+    assert any(k.startswith("bg_net.base_layers.3.0") for k in m.state_dict())
+    with pytest.raises(TvrError):
+        m(rays, N_samples=TINY["N_samples"])                          # no CPU fallback for the foreground
+    m2 = NerfPlusPlus(tiny_npp_arrays["aabb"], TINY["gridSize"], "cpu", density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, shadingMode="MLP_Fea",
+                      view_pe=2, fea_pe=2)
+    with pytest.raises(TvrError):
+        m2(rays)                                                       # set_nerfplusplus() not called
 
 
 def test_grid_sizing_helpers_match_survey_appendix_c():

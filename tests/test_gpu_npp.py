@@ -1,0 +1,139 @@
+"""GPU (-m gpu): NerfPlusPlus (models/nerfplusplus.py) — TensorVMSplit foreground with explicit sample depths through the fused HIP
+kernels (tvr_render_z / tvr_march_*_z) + the torch background network, against the oracle's restatement with the random draws injected."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TINY, make_model
+
+pytestmark = pytest.mark.gpu
+RGB_TOL = 1e-3
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_npp_render_against_golden(tiny_npp, tiny_npp_arrays, hyper_tiny):
+    m = make_model(tiny_npp_arrays, hyper_tiny)
+    rays = torch.tensor(tiny_npp["rays"], device="cuda")
+    rf, rb = torch.tensor(tiny_npp["rand_fg"], device="cuda"), torch.tensor(tiny_npp["rand_bg"], device="cuda")
+    m.eps_T = 0.0
+    with torch.no_grad():
+        rgb, depth = m(rays, is_train=False, N_samples=TINY["N_samples"], rand_fg=rf, rand_bg=rb)
+    e = np.abs(_np(rgb) - tiny_npp["out.rgb_map"]).max()
+    print(f"NerfPlusPlus rgb_map Linf {e:.2e}")
+    assert e < 1e-4 < RGB_TOL
+    assert np.abs(_np(depth) - tiny_npp["out.depth_map"]).max() < 1e-4
+    # the foreground alone through the C-ABI: explicit depths, dense outputs, bg_lambda
+    z = m._fg_depths(rays[:, :3], rays[:, 3:6], TINY["N_samples"], rf)
+    # the depths come from torch on the device (sqrt, sums): equal to the CPU oracle's to an ulp (bit-identical on a CPU device,
+    # tests/test_abi_and_host.py::test_npp_host_logic_on_cpu); the kernels are then checked on exactly the oracle's depths
+    assert np.allclose(_np(z), tiny_npp["out.z_vals"], rtol=3e-7, atol=0)
+    z = torch.tensor(tiny_npp["out.z_vals"], device="cuda")
+    fg, _, lam = m._render_z(rays, z, TINY["N_samples"], 0.0)
+    assert np.abs(_np(fg) - tiny_npp["out.fg_rgb_map"]).max() < 1e-4
+    lam_t = torch.where(lam > 0.1, lam, torch.zeros_like(lam))
+    assert np.abs(_np(lam_t) - tiny_npp["out.bg_lambda"]).max() < 1e-5
+    # default early termination stays inside the bar; results do not depend on the batch order
+    m.eps_T = None
+    with torch.no_grad():
+        rgb2, _ = m(rays, N_samples=TINY["N_samples"], rand_fg=rf, rand_bg=rb)
+        perm = torch.randperm(rays.shape[0], device="cuda")
+        rgb3, _ = m(rays[perm], N_samples=TINY["N_samples"], rand_fg=rf[perm], rand_bg=rb[perm])
+    assert np.abs(_np(rgb2) - tiny_npp["out.rgb_map"]).max() < 3e-4 and torch.allclose(rgb3, rgb2[perm], atol=1e-6)
+    # without injected draws the call still works (fresh random perturbation, as in the reference)
+    with torch.no_grad():
+        rgb4, _ = m(rays, N_samples=TINY["N_samples"])
+    assert bool(torch.isfinite(rgb4).all()) and float((rgb4 - rgb2).abs().max()) > 0
+
+
+def _oracle_with_grads(arrs, hyper):
+    from oracle import tensorf_oracle as TO
+    sc = TO.scene_from_arrays(arrs, **hyper)
+    leaves = {}
+    for name in ("density_plane", "density_line", "app_plane", "app_line"):
+        for i, t in enumerate(getattr(sc, name)):
+            leaves[f"{name}.{i}"] = t.requires_grad_(True)
+    leaves["basis_mat"] = sc.basis_mat.requires_grad_(True)
+    for k, t in sc.mlp.items():
+        leaves[k] = t.requires_grad_(True)
+    for k, t in sc.npp["net"].items():
+        leaves["bg_net." + k] = t.requires_grad_(True)
+    return sc, leaves
+
+
+def test_npp_gradients_match_oracle_autograd(tiny_npp, tiny_npp_arrays, hyper_tiny):
+    from oracle import tensorf_oracle as TO
+    rays_np, S = tiny_npp["rays"], TINY["N_samples"]
+    cw = torch.tensor(np.random.default_rng(21).standard_normal((rays_np.shape[0], 3)).astype(np.float32))
+    sc, leaves = _oracle_with_grads(tiny_npp_arrays, hyper_tiny)
+    rgb_o, _ = TO.execute_npp(sc, torch.tensor(rays_np), N_samples=S, rand_fg=tiny_npp["rand_fg"], rand_bg=tiny_npp["rand_bg"])
+    (rgb_o * cw).sum().backward()
+    m = make_model(tiny_npp_arrays, hyper_tiny)
+    m.eps_T = 0.0
+    rgb, _ = m(torch.tensor(rays_np, device="cuda"), is_train=True, N_samples=S, rand_fg=torch.tensor(tiny_npp["rand_fg"], device="cuda"),
+               rand_bg=torch.tensor(tiny_npp["rand_bg"], device="cuda"))
+    assert np.abs(_np(rgb) - rgb_o.detach().numpy()).max() < 2e-4
+    (rgb * cw.cuda()).sum().backward()
+    mlp = m.renderModule.mlp
+    got = {"basis_mat": m.basis_mat.weight.grad, "W1": mlp[0].weight.grad, "b1": mlp[0].bias.grad, "W2": mlp[2].weight.grad,
+           "b2": mlp[2].bias.grad, "W3": mlp[4].weight.grad, "b3": mlp[4].bias.grad}
+    for i in range(3):
+        got[f"density_plane.{i}"], got[f"density_line.{i}"] = m.density_plane[i].grad, m.density_line[i].grad
+        got[f"app_plane.{i}"], got[f"app_line.{i}"] = m.app_plane[i].grad, m.app_line[i].grad
+    for k, p in m.bg_net.named_parameters():
+        got["bg_net." + k] = p.grad
+    worst = 0.0
+    for k, ref in leaves.items():
+        g, r = got[k].cpu().numpy(), ref.grad.numpy()
+        scale = max(np.abs(r).max(), 1e-6)
+        err = np.abs(g - r).max() / scale
+        worst = max(worst, err)
+        # the background network is torch on both sides; its CPU-vs-GPU gradients alone differ by up to 8e-4 of the largest entry
+        # (scripts/debug_npp_bg.py: cancellation behind the 1e10 last interval), so those tensors get a looser bound; everything that
+        # passes through the HIP kernels keeps the 5e-4 of test_gpu_training
+        tol = 3e-3 if k.startswith("bg_net.") else 5e-4
+        assert err < tol, f"{k}: max |grad diff| / max |grad| = {err:.2e}"
+        assert np.abs(r).max() > 0, f"{k}: oracle gradient is identically zero"
+    print(f"NerfPlusPlus gradients: {len(leaves)} tensors, worst rel-max-err {worst:.2e}")
+    # the density gradient really contains the bg_lambda path: without it (background detached) it differs
+    m2 = make_model(tiny_npp_arrays, hyper_tiny)
+    m2.eps_T = 0.0
+    rays = torch.tensor(rays_np, device="cuda")
+    z = m2._fg_depths(rays[:, :3], rays[:, 3:6], S, torch.tensor(tiny_npp["rand_fg"], device="cuda"))
+    fg, _, lam = m2._render_z_autograd(rays, z, S, 0.0)
+    (fg * cw.cuda()).sum().backward()
+    assert float((m2.density_plane[0].grad - m.density_plane[0].grad).abs().max()) > 1e-6
+
+
+def test_npp_training_loop_and_checkpoint(tmp_path, tiny_npp, tiny_npp_arrays, hyper_tiny):
+    from jittor_myc_nerfs_amd import NerfPlusPlus, OctreeRender_trilinear_fast, load_checkpoint
+    rays = torch.tensor(tiny_npp["rays"], device="cuda")
+    gt = torch.tensor(tiny_npp["out.rgb_map"], device="cuda").roll(1, dims=1)
+    m = make_model(tiny_npp_arrays, hyper_tiny)
+    opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
+    losses = []
+    for it in range(20):
+        opt.zero_grad()
+        rgb_map, _, _, _, _ = OctreeRender_trilinear_fast(rays, m, chunk=4096, N_samples=TINY["N_samples"], white_bg=False, is_train=True)
+        loss = torch.mean((rgb_map - gt) ** 2)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    print("NerfPlusPlus training loss", losses[0], "->", losses[-1])
+    assert losses[-1] < 0.7 * losses[0]
+    path = str(tmp_path / "npp.th")
+    m.save(path)
+    ckpt = load_checkpoint(path)
+    kwargs = ckpt["kwargs"]
+    bg = {k: kwargs.pop(k) for k in ("bg_D", "bg_freq", "radii", "bg_view_freq")}                # train.py:45-54
+    kwargs.update({"device": "cuda"})
+    m2 = NerfPlusPlus(**kwargs)
+    m2.set_nerfplusplus(bg["bg_freq"], bg["bg_view_freq"], bg["bg_D"], bg["radii"])
+    m2.load(ckpt)
+    rf, rb = torch.tensor(tiny_npp["rand_fg"], device="cuda"), torch.tensor(tiny_npp["rand_bg"], device="cuda")
+    with torch.no_grad():
+        a, _ = m(rays, N_samples=TINY["N_samples"], rand_fg=rf, rand_bg=rb)
+        b, _ = m2(rays, N_samples=TINY["N_samples"], rand_fg=rf, rand_bg=rb)
+    assert torch.equal(a, b)

@@ -182,3 +182,31 @@ def test_ref_known_answers(tiny_ref_arrays, hyper_tiny):
     assert torch.equal(mlp_in[:, 1:28], f) and torch.equal(mlp_in[:, 28:31], refl)
     # a zero normal stays zero (eps floor of jt.normalize), never NaN
     assert torch.equal(TO.jt_normalize(torch.zeros(1, 3)), torch.zeros(1, 3))
+
+
+# ---- NerfPlusPlus (second half; models/nerfplusplus.py) ----------------------------------------------------------------
+def test_npp_oracle_reproduces_golden_and_known_answers(tiny_npp, tiny_npp_arrays, hyper_tiny):
+    sc = TO.scene_from_arrays(tiny_npp_arrays, **hyper_tiny)
+    d = TO.execute_npp(sc, tiny_npp["rays"], N_samples=TINY["N_samples"], rand_fg=tiny_npp["rand_fg"], rand_bg=tiny_npp["rand_bg"], dump=True)
+    assert np.array_equal(d["z_vals"].numpy(), tiny_npp["out.z_vals"])
+    assert np.array_equal(d["app_mask"].numpy().astype(np.uint8), tiny_npp["out.app_mask"])
+    assert np.abs(d["rgb_map"].numpy() - tiny_npp["out.rgb_map"]).max() < 1e-5
+    # sampling (nerfplusplus.py:239-256): ascending, first sample inside [near, near + half a step], last one on or inside the sphere
+    rays = torch.tensor(tiny_npp["rays"])
+    z = d["z_vals"]
+    assert bool((z[:, 1:] > z[:, :-1]).all()) and bool((z[:, 0] >= hyper_tiny["near_far"][0]).all())
+    end = rays[:, :3] + rays[:, 3:6] * z[:, -1:]
+    assert bool((end.norm(dim=-1) <= 6.0 + 1e-4).all())
+    far = TO.intersect_sphere(rays[:, :3], rays[:, 3:6], 36.0)
+    assert torch.allclose((rays[:, :3] + rays[:, 3:6] * far[:, None]).norm(dim=-1), torch.full((rays.shape[0],), 6.0), atol=1e-4)
+    # inverted-sphere points (:207-237) lie on the unit... on the radius-`radii` sphere, 4th coordinate = the depth parameter
+    pts, _ = TO.depth2pts_outside(rays[:, None, :3].expand(-1, 5, -1), rays[:, None, 3:6].expand(-1, 5, -1), torch.linspace(0.5, 5.5, 5).expand(rays.shape[0], 5), 6.0)
+    assert torch.allclose(pts[..., :3].norm(dim=-1), torch.full(pts.shape[:-1], 6.0), atol=1e-3) and torch.equal(pts[0, :, 3], torch.linspace(0.5, 5.5, 5))
+    # composition (:311-314): background enters only where more than 10 % of the light passes the foreground
+    lam = d["bg_lambda"]
+    assert bool(((lam == 0) | (lam > 0.1)).all())
+    assert torch.allclose(d["rgb_map"], d["fg_rgb_map"] + d["bg_rgb_map"])
+    assert bool((d["bg_rgb_map"][lam == 0] == 0).all())
+    # embedder / network shapes (:7-56, :147-163)
+    assert TO.embed(torch.zeros(2, 4), 3, 4).shape == (2, 36) and TO.embed(torch.zeros(2, 3), 1, 2).shape == (2, 15)
+    assert sc.npp["net"]["base_layers.3.0.weight"].shape == (128, 164) and sc.npp["net"]["rgb_layers.0.weight"].shape == (64, 271)
