@@ -317,3 +317,29 @@ def test_evaluation_loop_on_gpu(tmp_path, tiny_arrays, hyper_tiny):
     sc = TO.scene_from_arrays(tiny_arrays, **hyper_tiny)
     ref = CO.COracle(tiny_arrays, step=float(sc.stepSize), **hyper_tiny).render(ds.all_rays[1].numpy(), 48, white_bg=True)
     assert np.abs(img.reshape(-1, 3) - ref["rgb_map"]).max() < 1.0 / 255 + 1e-3         # 8-bit quantisation + parity bar
+
+
+@pytest.mark.parametrize("grid,S", [([16, 20, 24], 2000), ([16, 20, 24], 4096), ([2500, 4, 5], 96), ([700, 6, 300], 64)])
+def test_march_launch_shapes(hyper_tiny, grid, S):
+    """The march launcher's other shapes: long sample lists shrink the workgroup (16 -> 12/8/4 waves so that lines + lists fit the 160 KB
+    LDS), and grids whose three density lines do not fit fall back to global line reads.  Same parity as the default shape: bit-exact masks /
+    cells against the scalar oracle, RGB within the tight bar."""
+    from jittor_myc_nerfs_amd import rays as R, synthetic
+    from oracle import c_oracle as CO, tensorf_oracle as TO
+    aabb = TINY["aabb"]
+    arrs = synthetic.make_scene_arrays(grid, aabb, seed=5)
+    hyper = dict(hyper_tiny)
+    m = make_model(arrs, hyper)
+    rays = R.frame_rays(R.sphere_poses(4, 4.0)[2], 12, 12, 0.6911)
+    sc = TO.scene_from_arrays(arrs, **hyper)
+    ref = CO.COracle(arrs, step=float(sc.stepSize), **hyper).render(rays.numpy(), S, white_bg=True, dump=True, nthreads=8)
+    rgb, depth, d = m.render_rays(rays.cuda(), white_bg=True, N_samples=S, eps_T=0.0, dense=True)
+    assert np.array_equal(_np(d["valid"]), ref["valid"]) and np.array_equal(_np(d["cell"])[ref["valid"] > 0], ref["cell"][ref["valid"] > 0])
+    assert np.abs(_np(rgb) - ref["rgb_map"]).max() < RGB_TIGHT
+    rgb2, depth2 = m.render_rays(rays.cuda(), white_bg=True, N_samples=S)           # the non-dense instantiation, default eps_T
+    assert np.abs(_np(rgb2) - ref["rgb_map"]).max() < 3e-4
+    # and the training march (forward + backward launch shapes) runs on the same scene
+    m.eps_T = 0.0
+    out, _ = m.render_rays_autograd(rays.cuda(), white_bg=True, N_samples=S)
+    out.sum().backward()
+    assert np.abs(_np(out) - ref["rgb_map"]).max() < 3e-4 and bool(torch.isfinite(m.density_line[0].grad).all())
