@@ -482,6 +482,15 @@ int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *d
     return TVR_OK;
 }
 
+int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C, void *stream)
+{
+    if (!C || M < 0 || (M > 0 && (!A || !B))) return fail(TVR_ERR_INVALID, "A/B/C NULL or M < 0");
+    if (Ka < 1 || Kb < 1 || lda < Ka || ldb < Kb) return fail(TVR_ERR_INVALID, "bad Ka/Kb/lda/ldb");
+    if (((Ka + 31) / 32) * ((Kb + 31) / 32) > 20) return fail(TVR_ERR_UNSUPPORTED, "Ka x Kb = %d x %d exceeds the 20 32x32 tiles of a workgroup", Ka, Kb);
+    HIP_TRY(launch_gemm_tn(A, lda, Ka, B, ldb, Kb, M, C, (hipStream_t)stream));
+    return TVR_OK;
+}
+
 int tvr_density_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, void *stream)
 {
     if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");

@@ -107,7 +107,44 @@ class MLPRender_Fea(torch.nn.Module):
             indata += [_pe(features, self.feape)]
         if self.viewpe > 0:
             indata += [_pe(viewdirs, self.viewpe)]
-        return torch.sigmoid(self.mlp(torch.cat(indata, dim=-1)))
+        return torch.sigmoid(_mlp3(self.mlp, torch.cat(indata, dim=-1)))
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b over the M appearance samples of a batch.  Forward and dX are library GEMMs; the weight gradient dW = dY^T X is the
+    tall-skinny reduction tvr_gemm_tn (M ~ 3.5e5 rows, <= 160 columns) that the library runs at ~15 TFLOP/s."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            Ka, Kb, M = weight.shape[0], weight.shape[1], x.shape[0]
+            if x.is_cuda and M >= 4096 and ((Ka + 31) // 32) * ((Kb + 31) // 32) <= 20 and x.dtype == torch.float32:
+                xc = x.contiguous()
+                gw = torch.empty((Ka, Kb), dtype=torch.float32, device=x.device)
+                L.check(L.lib().tvr_gemm_tn(gy.data_ptr(), Ka, Ka, xc.data_ptr(), Kb, Kb, M, gw.data_ptr(), _stream_ptr(x.device)), "tvr_gemm_tn")
+            else:
+                gw = gy.t() @ x
+        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def _linear(lin: torch.nn.Linear, x):
+    return _LinearFn.apply(x, lin.weight, lin.bias)
+
+
+def _mlp3(mlp: torch.nn.Sequential, x):
+    """Linear-ReLU-Linear-ReLU-Linear of MLPRender_Fea / MLPRender_Fea_Ref (tensorBase.py:69-73) through _LinearFn."""
+    return _linear(mlp[4], torch.relu(_linear(mlp[2], torch.relu(_linear(mlp[0], x)))))
 
 
 def _pe(x, freqs):                                                                            # tensorBase.py:9-15
@@ -145,7 +182,7 @@ class MLPRender_Fea_Ref(torch.nn.Module):
             indata += [_pe(features, self.feape)]
         if self.viewpe > 0:
             indata += [_pe(viewdirs, self.viewpe)]
-        return torch.sigmoid(self.mlp(torch.cat(indata, dim=-1)))
+        return torch.sigmoid(_mlp3(self.mlp, torch.cat(indata, dim=-1)))
 
 
 class _MarchFn(torch.autograd.Function):
@@ -450,7 +487,7 @@ class TensorBase(torch.nn.Module):
         eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
         w, acc, xyz, ray_id, depth, _ = _MarchFn.apply(self, rays, jitter, S, eps_T, None, *self.density_plane, *self.density_line)
         h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
-        feats = self.basis_mat(h)                                                             # tensoRF.py:244
+        feats = _linear(self.basis_mat, h)                                                    # tensoRF.py:244
         rgb = self.renderModule.forward_autograd(rays[ray_id, 3:6], feats)                    # tensorBase.py:517
         rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)   # :521
         if white_bg:
@@ -800,8 +837,8 @@ class REFTensoRF(TensorVMSplit):
         return grad_vars
 
     def _heads(self, h):                                                                      # :125-133
-        return (self.basis_mat(h), self.diffuse_linear(h), torch.relu(self.specular_linear(h)), self.normal_linear(h),
-                torch.relu(self.rho_linear(h)))
+        return (_linear(self.basis_mat, h), _linear(self.diffuse_linear, h), torch.relu(_linear(self.specular_linear, h)),
+                _linear(self.normal_linear, h), torch.relu(_linear(self.rho_linear, h)))
 
     def compute_appfeature(self, xyz_sampled):                                                # :107-133
         """-> (appfeatures [M,27], rgb_d [M,3], specular_tint [M,1], normal_vector [M,3], rho [M,1])"""
@@ -1010,7 +1047,7 @@ class NerfPlusPlus(TensorVMSplit):
     def _render_z_autograd(self, rays, z_vals, S, eps_T):
         w, acc, xyz, ray_id, depth, lam = _MarchFn.apply(self, rays, None, S, eps_T, z_vals, *self.density_plane, *self.density_line)
         h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
-        rgb = self.renderModule.forward_autograd(rays[ray_id, 3:6], self.basis_mat(h))
+        rgb = self.renderModule.forward_autograd(rays[ray_id, 3:6], _linear(self.basis_mat, h))
         rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)
         return rgb_map.clamp(0, 1), depth, lam                                                # white_bg=False (:276), tensorBase.py:527
 

@@ -1,0 +1,28 @@
+"""One 800x800 frame of NerfPlusPlus (TensorVMSplit 300^3 foreground with explicit depths + the 512-sample background network), timed."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from jittor_myc_nerfs_amd import NerfPlusPlus, OctreeRender_trilinear_fast, synthetic
+A, H = synthetic.SCENE_A, synthetic.HYPER
+arrs = synthetic.make_scene_arrays(A["gridSize"], A["aabb"], npp=6.0)
+m = NerfPlusPlus(arrs["aabb"], A["gridSize"], "cuda", density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, app_dim=27, near_far=A["near_far"],
+                 shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=H["density_shift"], distance_scale=H["distance_scale"],
+                 rayMarch_weight_thres=H["rayMarch_weight_thres"], pos_pe=6, view_pe=2, fea_pe=2, featureC=128, step_ratio=A["step_ratio"],
+                 fea2denseAct=H["fea2denseAct"])
+m.load_arrays(arrs)
+rays = bench.frames(A)[0].cuda()
+S = A["N_samples"]
+with torch.no_grad():
+    OctreeRender_trilinear_fast(rays[:65536], m, chunk=4096, N_samples=S, white_bg=False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    rgb, _, _, _, _ = OctreeRender_trilinear_fast(rays, m, chunk=4096, N_samples=S, white_bg=False)
+    torch.cuda.synchronize(); t_all = time.perf_counter() - t0
+    # the foreground alone (same call sequence without the background network)
+    z = m._fg_depths(rays[:, :3], rays[:, 3:6], S)
+    m._render_z(rays, z, S, 1e-4); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): m._render_z(rays, z, S, 1e-4)
+    torch.cuda.synchronize(); t_fg = (time.perf_counter() - t0) / 5
+print(f"NerfPlusPlus 800x800 x {S} fg samples + 512 bg samples: {t_all * 1e3:.0f} ms / frame ({rays.shape[0] * S / t_all:.3e} fg ray-samples/s); "
+      f"foreground kernels alone (tvr_render_z, one call) {t_fg * 1e3:.1f} ms; rgb range {float(rgb.min()):.3f}..{float(rgb.max()):.3f}")

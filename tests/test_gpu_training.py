@@ -85,3 +85,22 @@ def test_training_loop_reduces_loss(tiny_arrays, hyper_tiny, tiny_dump):
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.5 * losses[0], f"loss did not drop: {losses[0]:.4e} -> {losses[-1]:.4e}"
     assert all(np.isfinite(losses))
+
+
+@pytest.mark.parametrize("M,Ka,Kb", [(356_123, 128, 150), (50_001, 128, 128), (9_999, 3, 128), (70_000, 27, 144), (4_097, 1, 144), (100, 5, 7), (0, 4, 4)])
+def test_gemm_tn_matches_fp64(M, Ka, Kb):
+    """tvr_gemm_tn (the weight-gradient reduction dW = dY^T X) against a float64 product: fp32-class accuracy, ragged edges, empty input."""
+    import ctypes as C
+    from jittor_myc_nerfs_amd import _lib as L
+    g = torch.Generator(device="cuda").manual_seed(M + Ka)
+    A = torch.randn((M, Ka), device="cuda", generator=g)
+    B = torch.randn((M, Kb), device="cuda", generator=g)
+    out = torch.full((Ka, Kb), float("nan"), device="cuda")
+    L.check(L.lib().tvr_gemm_tn(A.data_ptr(), Ka, Ka, B.data_ptr(), Kb, Kb, M, out.data_ptr(), None), "tvr_gemm_tn")
+    ref = (A.double().t() @ B.double())
+    err = float((out.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    lib = float(((A.t() @ B).double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    print(f"gemm_tn {M}x{Ka}x{Kb}: rel err {err:.2e} (library fp32 GEMM {lib:.2e})")
+    assert err < 2e-6
+    assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, Ka, B.data_ptr(), Kb, Kb, -1, out.data_ptr(), None) < 0
+    assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, 161, B.data_ptr(), Kb, 161, 10, out.data_ptr(), None) < 0      # 6 x 6 tiles: refused
