@@ -185,8 +185,11 @@ int tvr_app_h_backward(tvr_scene *scene, const float *xyz_norm, int64_t m, const
 
 /* C [Ka,Kb] = A^T B for tall-skinny fp32 operands A [M,Ka] (row stride lda), B [M,Kb] (row stride ldb): the weight gradients dW = dY^T X of
  * the training step's Linears (MLPRender_Fea's three layers tensorBase.py:69-71, basis_mat tensoRF.py:150) over the M appearance samples of
- * a batch.  fp32 semantics (fp32-input MFMA); C is overwritten; (Ka/32 rounded up) * (Kb/32 rounded up) <= 20. */
-int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C, void *stream);
+ * a batch.  fp32 semantics (fp32-input MFMA), fixed summation order (bit-reproducible); C is overwritten;
+ * (Ka/32 rounded up) * (Kb/32 rounded up) <= 20.  scratch: tvr_gemm_tn_scratch_bytes() of device memory (per-workgroup partial sums). */
+size_t tvr_gemm_tn_scratch_bytes(int32_t Ka, int32_t Kb, int64_t M);
+int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C,
+                void *scratch, size_t scratch_bytes, void *stream);
 
 /* Per-kernel HIP-event timing of tvr_render calls (march / shade / composite), for bench.py's roofline. */
 int tvr_profile_create(int32_t max_calls, tvr_profile **out);

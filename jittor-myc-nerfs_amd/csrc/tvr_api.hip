@@ -482,12 +482,28 @@ int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *d
     return TVR_OK;
 }
 
-int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C, void *stream)
+static int gemm_tn_check(int32_t Ka, int32_t Kb, int64_t M)
 {
-    if (!C || M < 0 || (M > 0 && (!A || !B))) return fail(TVR_ERR_INVALID, "A/B/C NULL or M < 0");
-    if (Ka < 1 || Kb < 1 || lda < Ka || ldb < Kb) return fail(TVR_ERR_INVALID, "bad Ka/Kb/lda/ldb");
+    if (M < 0 || Ka < 1 || Kb < 1) return fail(TVR_ERR_INVALID, "bad Ka/Kb/M");
     if (((Ka + 31) / 32) * ((Kb + 31) / 32) > 20) return fail(TVR_ERR_UNSUPPORTED, "Ka x Kb = %d x %d exceeds the 20 32x32 tiles of a workgroup", Ka, Kb);
-    HIP_TRY(launch_gemm_tn(A, lda, Ka, B, ldb, Kb, M, C, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+size_t tvr_gemm_tn_scratch_bytes(int32_t Ka, int32_t Kb, int64_t M)
+{
+    if (gemm_tn_check(Ka, Kb, M) != TVR_OK) return 0;
+    return gemm_tn_scratch_bytes(Ka, Kb, M);
+}
+
+int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C, void *scratch,
+                size_t scratch_bytes, void *stream)
+{
+    int rc = gemm_tn_check(Ka, Kb, M);
+    if (rc != TVR_OK) return rc;
+    if (!C || (M > 0 && (!A || !B))) return fail(TVR_ERR_INVALID, "A/B/C NULL");
+    if (lda < Ka || ldb < Kb) return fail(TVR_ERR_INVALID, "lda/ldb smaller than the row length");
+    if (M > 0 && (!scratch || scratch_bytes < gemm_tn_scratch_bytes(Ka, Kb, M))) return fail(TVR_ERR_SCRATCH, "scratch too small (tvr_gemm_tn_scratch_bytes)");
+    HIP_TRY(launch_gemm_tn(A, lda, Ka, B, ldb, Kb, M, C, (float *)scratch, (hipStream_t)stream));
     return TVR_OK;
 }
 

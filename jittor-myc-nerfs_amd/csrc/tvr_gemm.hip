@@ -2,10 +2,13 @@
 // Ka, Kb <= 160): the weight gradients dW = dY^T X of the training step's Linears (tensorBase.py:69-71, tensoRF.py:150, train.py:258).
 // The library GEMM picks 32x32 macro tiles with stream-K for these shapes and runs at ~15 TFLOP/s (0.9 ms per gradient, three per step);
 // here every workgroup reduces its own slab of rows with fp32-input MFMAs (v_mfma_f32_32x32x2_f32, fp32 semantics, no splitting needed:
-// the kernel is bound by the fp32 matrix rate, 0.1 ms for the largest of them) and adds its Ka x Kb partial into C with fp32 atomics.
+// no atomics) and writes its Ka x Kb partial to a scratch slab; a second kernel sums the slabs in a fixed order, so the result is
+// bit-reproducible.  (Adding the partials into C with atomics instead costs 0.3 ms: 256 workgroups hit the same 19 k addresses at once.)
 //
-// One workgroup per CU, one wave per SIMD (the requested LDS keeps a second workgroup off the CU): the MFMA operands come straight from
-// global loads, and with a single MFMA-issuing wave per SIMD the load-behind-MFMA hazard described in tvr_shade.hip cannot occur.
+// Two workgroups per CU (two waves per SIMD; the requested LDS caps it there).  The MFMA operands come straight from global loads, so the
+// load-behind-MFMA hazard described in tvr_shade.hip is designed out the same way: within an iteration the loads (into the NEXT buffers)
+// are issued before the MFMAs (which read the CURRENT buffers, live until their last use), and every iteration ends with a
+// compiler-visible read of the last accumulator, which drains the wave's MFMAs before the next iteration's loads can reuse a register.
 #include <hip/hip_runtime.h>
 #include "tvr_kernels.h"
 
@@ -17,7 +20,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__restrict__ A, const int lda, const int Ka,
                                                                  const float *__restrict__ B, const int ldb, const int Kb,
-                                                                 const long long M, float *__restrict__ C, const long long rows_per_block)
+                                                                 const long long M, float *__restrict__ P, const long long rows_per_block)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, k = lane >> 5;
@@ -35,23 +38,41 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
     }
     const long long m0 = (long long)blockIdx.x * rows_per_block;
     const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
-    for (long long m = m0; m < m1; m += 2 * TG_UNROLL) {
-        float a[TG_UNROLL][TG_MAXT], b[TG_UNROLL][TG_MAXT];
+    // software pipeline: the operands of the next 8 rows are in flight while the MFMAs of the current 8 run
+    float a[TG_UNROLL][TG_MAXT], b[TG_UNROLL][TG_MAXT];
+    auto fetch = [&](long long m, float (&fa)[TG_UNROLL][TG_MAXT], float (&fb)[TG_UNROLL][TG_MAXT]) {
 #pragma unroll
         for (int u = 0; u < TG_UNROLL; ++u) {
             const long long row = m + 2 * u + k;
             const bool in = row < m1;
-#pragma unroll
+            const long long rr = in ? row : m1 - 1;            // every load is unconditional (clamped address, value selected afterwards):
+#pragma unroll                                                   // a predicated load is a branch, and its join waits for the data
             for (int q = 0; q < TG_MAXT; ++q) {
-                a[u][q] = (in && offA[q] >= 0) ? A[row * lda + offA[q]] : 0.0f;
-                b[u][q] = (in && offB[q] >= 0) ? B[row * ldb + offB[q]] : 0.0f;
+                const float va = A[rr * lda + (offA[q] >= 0 ? offA[q] : 0)];
+                const float vb = B[rr * ldb + (offB[q] >= 0 ? offB[q] : 0)];
+                fa[u][q] = (in && offA[q] >= 0) ? va : 0.0f;
+                fb[u][q] = (in && offB[q] >= 0) ? vb : 0.0f;
             }
         }
+    };
+    fetch(m0, a, b);
+    float drain = 0.0f;
+    for (long long m = m0; m < m1; m += 2 * TG_UNROLL) {
+        float an[TG_UNROLL][TG_MAXT], bn[TG_UNROLL][TG_MAXT];
+        fetch(m + 2 * TG_UNROLL, an, bn);                      // rows >= m1 read as zero
 #pragma unroll
         for (int u = 0; u < TG_UNROLL; ++u)
 #pragma unroll
             for (int q = 0; q < TG_MAXT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], b[u][q], acc[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        drain += acc[TG_MAXT - 1][15];                          // written by the last MFMA issued: all of them have completed
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < TG_UNROLL; ++u)
+#pragma unroll
+            for (int q = 0; q < TG_MAXT; ++q) { a[u][q] = an[u][q]; b[u][q] = bn[u][q]; }
     }
+    if (drain == 1.2345e-30f && P == nullptr) P[0] = drain;     // keeps `drain` alive; never true
 #pragma unroll
     for (int q = 0; q < TG_MAXT; ++q) {
         const int t = wave + q * TG_WAVES;
@@ -61,27 +82,59 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * k;
-            if (row < Ka && col < Kb) atomicAdd(C + (size_t)row * Kb + col, acc[q][r]);
+            if (row < Ka && col < Kb) P[((size_t)blockIdx.x * Ka + row) * Kb + col] = acc[q][r];
         }
     }
 }
 
-hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, hipStream_t stream)
+// C[e] = sum over the slabs in a fixed order: 16 lanes per element (lane l adds slabs l, l+16, ... in order), then a fixed butterfly
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__restrict__ P, const int n_slabs, const int n, float *__restrict__ C)
 {
-    hipError_t rc = hipMemsetAsync(C, 0, (size_t)Ka * Kb * sizeof(float), stream);
-    if (rc != hipSuccess || M <= 0) return rc;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t >> 4, l = t & 15;
+    float s = 0.0f;
+    if (e < n)
+        for (int b = l; b < n_slabs; b += 16) s = s + P[(size_t)b * n + e];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) s = s + __shfl_xor(s, off);
+    if (e < n && l == 0) C[e] = s;
+}
+
+static int cu_count()
+{
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, n = 0;
         cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }
-    long long grid = cus;
-    long long rpb = ((M + grid - 1) / grid + 7) / 8 * 8;           // multiple of the 8-row unrolled step
+    return cus;
+}
+
+static void gemm_tn_shape(long long M, long long &grid, long long &rpb)
+{
+    grid = 2 * cu_count();
+    rpb = ((M + grid - 1) / grid + 7) / 8 * 8;                     // multiple of the 8-row unrolled step
     if (rpb < 64) rpb = 64;
-    grid = (M + rpb - 1) / rpb;
-    const int lds = 96 * 1024;                                     // unused; keeps the CU to one workgroup (see header)
-    rc = hipFuncSetAttribute((const void *)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    grid = M > 0 ? (M + rpb - 1) / rpb : 0;
+}
+
+size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M)
+{
+    long long grid, rpb;
+    gemm_tn_shape(M, grid, rpb);
+    return (size_t)(grid > 0 ? grid : 1) * Ka * Kb * sizeof(float);
+}
+
+hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream)
+{
+    long long grid, rpb;
+    gemm_tn_shape(M, grid, rpb);
+    if (grid == 0) return hipMemsetAsync(C, 0, (size_t)Ka * Kb * sizeof(float), stream);
+    const int lds = 64 * 1024;                                     // unused; caps the CU at two workgroups (see header)
+    hipError_t rc = hipFuncSetAttribute((const void *)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, C, rpb);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb);
+    const int n = Ka * Kb;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, scratch, (int)grid, n, C);
     return hipGetLastError();
 }

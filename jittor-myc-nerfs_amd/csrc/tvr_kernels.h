@@ -67,4 +67,5 @@ hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_ra
 hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream);
 hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream);
 hipError_t launch_unpack_grad(const float *in, float *out, int C, int H, int W, hipStream_t stream);
-hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, hipStream_t stream);
+hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream);
+size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M);

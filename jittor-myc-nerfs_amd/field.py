@@ -131,7 +131,9 @@ class _LinearFn(torch.autograd.Function):
             if x.is_cuda and M >= 4096 and ((Ka + 31) // 32) * ((Kb + 31) // 32) <= 20 and x.dtype == torch.float32:
                 xc = x.contiguous()
                 gw = torch.empty((Ka, Kb), dtype=torch.float32, device=x.device)
-                L.check(L.lib().tvr_gemm_tn(gy.data_ptr(), Ka, Ka, xc.data_ptr(), Kb, Kb, M, gw.data_ptr(), _stream_ptr(x.device)), "tvr_gemm_tn")
+                scratch = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb, M), dtype=torch.uint8, device=x.device)
+                L.check(L.lib().tvr_gemm_tn(gy.data_ptr(), Ka, Ka, xc.data_ptr(), Kb, Kb, M, gw.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                            _stream_ptr(x.device)), "tvr_gemm_tn")
             else:
                 gw = gy.t() @ x
         gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None

@@ -96,11 +96,14 @@ def test_gemm_tn_matches_fp64(M, Ka, Kb):
     A = torch.randn((M, Ka), device="cuda", generator=g)
     B = torch.randn((M, Kb), device="cuda", generator=g)
     out = torch.full((Ka, Kb), float("nan"), device="cuda")
-    L.check(L.lib().tvr_gemm_tn(A.data_ptr(), Ka, Ka, B.data_ptr(), Kb, Kb, M, out.data_ptr(), None), "tvr_gemm_tn")
+    sc = torch.empty(max(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb, M), 1), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().tvr_gemm_tn(A.data_ptr(), Ka, Ka, B.data_ptr(), Kb, Kb, M, out.data_ptr(), sc.data_ptr(), sc.numel(), None), "tvr_gemm_tn")
     ref = (A.double().t() @ B.double())
     err = float((out.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
     lib = float(((A.t() @ B).double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
     print(f"gemm_tn {M}x{Ka}x{Kb}: rel err {err:.2e} (library fp32 GEMM {lib:.2e})")
     assert err < 2e-6
-    assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, Ka, B.data_ptr(), Kb, Kb, -1, out.data_ptr(), None) < 0
-    assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, 161, B.data_ptr(), Kb, 161, 10, out.data_ptr(), None) < 0      # 6 x 6 tiles: refused
+    assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, Ka, B.data_ptr(), Kb, Kb, -1, out.data_ptr(), sc.data_ptr(), sc.numel(), None) < 0
+    assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, 161, B.data_ptr(), Kb, 161, 10, out.data_ptr(), sc.data_ptr(), sc.numel(), None) < 0      # 6 x 6 tiles: refused
+    if M > 0:
+        assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, Ka, B.data_ptr(), Kb, Kb, M, out.data_ptr(), sc.data_ptr(), 16, None) == -3          # scratch too small
