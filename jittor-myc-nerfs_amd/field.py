@@ -195,7 +195,7 @@ class _MarchFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, jitter, S, eps_T, z_vals, *density_params):
         lib = L.lib()
-        sc = model._ensure_scene()
+        sc = model._ensure_scene(force=True)          # a training step: the optimizer has just written the parameters (0.1 ms for 70 MB)
         n = rays.shape[0]
         lay = L.ScratchLayout()
         L.check(lib.tvr_scratch_describe(n, S, C.byref(lay)), "tvr_scratch_describe")
@@ -241,6 +241,7 @@ class _MarchFn(torch.autograd.Function):
             L.check(lib.tvr_march_backward_z(sc, ctx.rays.data_ptr(), n, ctx.S, ctx.z_vals.data_ptr(), float(ctx.eps_T), ctx.scratch.data_ptr(),
                                              ctx.scratch.numel(), gw.data_ptr(), gacc.data_ptr(), ctx.lam.data_ptr(), glam.data_ptr(),
                                              gs.data_ptr(), gs.numel(), C.byref(out), _stream_ptr(model.device)), "tvr_march_backward_z")
+        model._sig = None       # an optimizer step follows; whatever renders next (training or evaluation) re-packs the scene first
         return (None, None, None, None, None, None, *grads)
 
 
@@ -416,8 +417,10 @@ class TensorBase(torch.nn.Module):
             ps += [lin.weight, lin.bias]
         return ps
 
-    def _ensure_scene(self):
-        """Create the tvr_scene on first use and re-pack whenever a parameter tensor was replaced or written in place."""
+    def _ensure_scene(self, force=False):
+        """Create the tvr_scene on first use and re-pack whenever a parameter tensor was replaced or written in place (detected by
+        storage pointer + version counter).  force=True re-packs regardless: the training forward does so every step, because a fused
+        optimizer kernel (torch.optim.Adam(fused=True)) updates the parameters without bumping their version counters."""
         lib = L.lib()
         if self.device.type != "cuda":
             raise L.TvrError(f"the render path runs on an MI355X (HIP) device only; model device is {self.device}. "
@@ -447,7 +450,7 @@ class TensorBase(torch.nn.Module):
             self._scene = h
             self._sig = None
             self._alpha_dirty = True
-        if sig != self._sig:
+        if force or sig != self._sig:
             for p in ps:
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.device != self._packed.device:
                     raise L.TvrError("field parameters must be contiguous fp32 tensors on the model's device")

@@ -23,18 +23,18 @@ with torch.no_grad():
     allrgbs = torch.cat([teacher.render_rays(allrays[i:i + 640000], N_samples=512)[0] for i in range(0, allrays.shape[0], 640000)])
     del teacher
 nS = int(np.linalg.norm(A["gridSize"]) / 0.5)
-opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
+opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99), fused=bool(int(os.environ.get("TVR_FUSED_ADAM", "1"))))
 tv = TVLoss()
 g = torch.Generator(device="cuda").manual_seed(0)
-bucket = GradBucket(m)                                 # all gradients in one 70 MB buffer: one all-reduce per step
+bucket = GradBucket(m) if (world > 1 or os.environ.get("TVR_BUCKET")) else None    # all gradients in one 70 MB buffer: one all-reduce per step
 def step():
     idx = torch.randint(0, allrays.shape[0], (4096,), device="cuda", generator=g)[shard_batch(4096, rank, world)]
-    bucket.zero()
+    bucket.zero() if bucket else opt.zero_grad()
     rgb_map, _, _, _, _ = OctreeRender_trilinear_fast(allrays[idx], m, chunk=4096, N_samples=nS, white_bg=True, is_train=True)
     loss = torch.mean((rgb_map - allrgbs[idx]) ** 2)
     total = loss + 1e-4 * m.vector_comp_diffs() + 8e-5 * m.density_L1() + 0.1 * m.TV_loss_density(tv) + 0.01 * m.TV_loss_app(tv)
     total.backward()
-    bucket.all_reduce_mean()
+    if bucket: bucket.all_reduce_mean()
     opt.step()
     return loss
 for _ in range(3): step()

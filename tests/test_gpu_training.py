@@ -107,3 +107,25 @@ def test_gemm_tn_matches_fp64(M, Ka, Kb):
     assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, 161, B.data_ptr(), Kb, 161, 10, out.data_ptr(), sc.data_ptr(), sc.numel(), None) < 0      # 6 x 6 tiles: refused
     if M > 0:
         assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, Ka, B.data_ptr(), Kb, Kb, M, out.data_ptr(), sc.data_ptr(), 16, None) == -3          # scratch too small
+
+
+def test_fused_adam_updates_reach_the_packed_scene(tiny_arrays, hyper_tiny, tiny_dump):
+    """torch.optim.Adam(fused=True) writes the parameters without bumping their version counters; the packed device scene must follow
+    anyway (the training forward re-packs, and a backward invalidates the pack for whatever renders next)."""
+    from jittor_myc_nerfs_amd import TensorVMSplit
+    rays = torch.tensor(tiny_dump["rays"], device="cuda")
+    m = make_model(tiny_arrays, hyper_tiny)
+    opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99), fused=True)
+    gt = torch.rand((rays.shape[0], 3), device="cuda")
+    for _ in range(3):
+        opt.zero_grad()
+        rgb, _ = m(rays, is_train=True, white_bg=True, N_samples=TINY["N_samples"])
+        torch.mean((rgb - gt) ** 2).backward()
+        opt.step()
+    with torch.no_grad():
+        after, _ = m(rays, is_train=False, white_bg=True, N_samples=TINY["N_samples"])          # evaluation right after the last step
+    fresh = TensorVMSplit(**dict(m.get_kwargs(), device="cuda"))
+    fresh.load({"state_dict": m.state_dict()})
+    with torch.no_grad():
+        want, _ = fresh(rays, is_train=False, white_bg=True, N_samples=TINY["N_samples"])
+    assert torch.equal(after, want)
