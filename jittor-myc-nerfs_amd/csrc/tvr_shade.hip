@@ -41,6 +41,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #else
 #define TVR_STAMP(x)
 #endif
+#ifndef TVR_PIPE
+#define TVR_PIPE 0        // 1: the queue path runs shade_pipe_kernel (one wave per SIMD, two tiles software-pipelined per wave)
+#endif
 #ifndef TVR_BPF
 #define TVR_BPF 0         // 1: issue the basis-fragment loads inside gather k-step TVR_BPF_AT (measured: 14.47 vs 14.38 ms at step 8; step 7 spills)
 #endif
@@ -869,6 +872,280 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
 }
 
+// ---- software-pipelined variant (build with -DTVR_PIPE=1): ONE wave per SIMD, two tiles in flight per wave -------------------------
+// The two-waves-per-SIMD kernel above runs each wave's gather and matrix phases back to back (~25 k cycles per tile and wave), so a
+// SIMD needs ~13 k cycles per tile however its two waves interleave.  Here a wave computes the MATRIX part of tile i while it issues
+// the loads and the interpolation arithmetic of tile i+1's GATHER between the MFMAs of the hidden layers (one gather k-step per two
+// layer k-steps), with the queue entry and the basis fragments of the following stage prefetched.  With a single MFMA-issuing wave per
+// SIMD the load-behind-MFMA hazard cannot occur.  Parity-green (tests/test_gpu_parity.py with this build), measured 15.0 ms against
+// 14.2 ms for the kernel above: phase stamps give 16.8 k cycles per tile — basis 1.2 k, entry + PE 0.8 k, L1 6.1 k and L2 5.0 k (6.9 k of
+// MFMA pipe between them, stalled on the tap loads issued two layer steps earlier), L3 2.6 k, epilogue 1.1 k — and nothing fills the
+// MFMA-idle stages.  A deeper tap ring or earlier basis prefetch spills: a 512-register wave still has only 256 registers the VALU can
+// address (the other 256 are accumulator registers), and ring + fragments + weights already need ~330.  Kept as a build switch.
+#if TVR_PIPE
+#define PW_WAVES 4
+#ifndef PW_RING
+#define PW_RING 2
+#endif
+#ifndef PW_SGB
+#define PW_SGB 0          // >0: sched_group_barrier recipe, PW_SGB VALU operations behind every hidden-layer MFMA
+#endif
+#ifndef PW_SGX
+#define PW_SGX 3          // extra VALU operations per MFMA in the k-steps that carry a gather step
+#endif
+// order inside one hidden-layer k-step: the next step's 8 weight reads (and a gather step's 12 tap loads) first, then each of the 12
+// MFMAs followed by NV VALU operations
+template <int NV, bool LOADS>
+__device__ __forceinline__ void sched_pipe_step()
+{
+#if PW_SGB
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    if (LOADS) __builtin_amdgcn_sched_group_barrier(0x020, 12, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    }
+#endif
+}
+
+struct PipeTile {
+    long long ent;
+    bool live;
+    float fc[3], dir[3], wq;
+    Frag hf[9];
+};
+
+__global__ __launch_bounds__(64 * PW_WAVES, 1) void shade_pipe_kernel(const SceneDev sc, const ShadeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e = lane & 31, h = lane >> 5;
+    {
+        const uint4 *src = (const uint4 *)sc.mlp_image;
+        for (int i = tid; i < TVR_MLP_IMAGE_BYTES / 16; i += 64 * PW_WAVES) ((uint4 *)smem)[i] = src[i];
+        __syncthreads();
+    }
+    const long long n_total = (long long)(*a.counter);
+    const long long n_tiles = (n_total + 31) / 32;
+    const long long stride = (long long)gridDim.x * PW_WAVES;
+    const long long first = (long long)blockIdx.x * PW_WAVES + wave;
+    if (first >= n_tiles) return;
+    const unsigned char *W1H = smem + TVR_IMG_W1H, *W1L = smem + TVR_IMG_W1L;
+    const unsigned char *W2H = smem + TVR_IMG_W2H, *W2L = smem + TVR_IMG_W2L;
+
+    Taps T[PW_RING];                                     // tap ring: gather steps k .. k + PW_RING - 1 in flight
+    auto plane_args = [&](int s, int &p, int &ax, int &bx, int &vx) { p = s / 3; ax = (p == 2) ? 1 : 0; bx = (p == 0) ? 1 : 2; vx = 2 - p; };
+    auto issue_taps = [&](PipeTile &g, int s) {
+        int p, ax, bx, vx;
+        plane_args(s, p, ax, bx, vx);
+        load_taps<false>(T[s % PW_RING], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], g.fc[ax], g.fc[bx], g.fc[vx], 4 * (s % 3) + 2 * h);
+    };
+    // the queue entry of a tile is fetched a whole stage ahead (it heads the dependent chain entry -> coordinates -> tap address -> tap)
+    long long qn_ent = 0;
+    bool qn_live = false;
+    float4 qn_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned qn_ray = 0;
+    auto fetch_entry = [&](long long tile) {
+        long long en = tile * 32 + e;
+        qn_live = (tile < n_tiles) && (en < n_total);
+        if (en >= n_total) en = n_total - 1;                // a dead entry gathers a valid address; nothing of it is stored
+        qn_ent = en;
+        qn_q = a.q_pos[en];
+        qn_ray = a.q_ray[en];
+    };
+    // gather step 0': prefetched entry -> coordinates, view direction and the first tap sets in flight
+    auto gather_begin = [&](PipeTile &g) {
+        g.ent = qn_ent; g.live = qn_live; g.wq = qn_q.w;
+        const float *rp = a.rays + (size_t)qn_ray * 6 + 3;
+        g.dir[0] = rp[0]; g.dir[1] = rp[1]; g.dir[2] = rp[2];
+        g.fc[0] = unnorm(qn_q.x, sc.gm1[0]); g.fc[1] = unnorm(qn_q.y, sc.gm1[1]); g.fc[2] = unnorm(qn_q.z, sc.gm1[2]);
+#pragma unroll
+        for (int s = 0; s < PW_RING - 1; ++s) issue_taps(g, s);
+    };
+    // the basis A fragments (the same 18 x 16 B for every tile, but 72 VGPRs the hidden layers cannot spare) are re-read during
+    // layer 3 of the previous stage, a few thousand cycles before the basis product needs them
+    uint4 bh[9], bl[9];
+    auto fetch_basis = [&]() {
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const uint4 *ap = (const uint4 *)sc.basis_frag + ((s * 2 + h) * 32 + e) * 2;
+            bh[s] = ap[0]; bl[s] = ap[1];
+        }
+    };
+    auto gather_step = [&](PipeTile &g, int s) {            // s = 0..8: issue step s + PW_RING - 1, evaluate step s
+        if (s + PW_RING - 1 < 9) issue_taps(g, s + PW_RING - 1);
+        int p, ax, bx, vx;
+        plane_args(s, p, ax, bx, vx);
+        float hv[8];
+        taps_eval<false>(T[s % PW_RING], sc.grid[ax], sc.grid[bx], sc.grid[vx], g.fc[ax], g.fc[bx], g.fc[vx], hv);
+        g.hf[s] = split8(hv);
+    };
+    // matrix part of tile M with the gather of tile N (for `next_tile`) threaded through the hidden layers
+#if TVR_TIMING
+    unsigned long long psum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    auto stage = [&](PipeTile &M, PipeTile &N, long long following_tile) {
+#if TVR_TIMING
+        unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0;
+#endif
+        TVR_SB; TVR_STAMP(p0);
+        float F[16];
+        {   // basis: A fragments prefetched by the previous stage
+            f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const h8 Ah = __builtin_bit_cast(h8, bh[s]), Al = __builtin_bit_cast(h8, bl[s]);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, M.hf[s].hi), accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, M.hf[s].lo), accB, 0, 0, 0);
+                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, M.hf[s].hi), accC, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) F[r] = (accA[r] + accB[r]) + accC[r];
+        }
+        TVR_SB; TVR_STAMP(p1);
+        gather_begin(N);
+        if (h == 0) F[15] = M.dir[0];
+        else { F[12] = M.dir[1]; F[13] = M.dir[2]; F[14] = 0.f; F[15] = 0.f; }
+        f32x16 acc[1][4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *(const float4 *)(smem + TVR_IMG_B1 + (32 * rb + 8 * q + 4 * h) * 4);
+                acc[0][rb][4 * q] = bv.x; acc[0][rb][4 * q + 1] = bv.y; acc[0][rb][4 * q + 2] = bv.z; acc[0][rb][4 * q + 3] = bv.w;
+            }
+        {
+            const int rowoff = e * TVR_IMG_W1_ROW + h * 16;
+            // sin / cos are re-derived where a k-step needs them (2-3 base values per step, 3 instructions each) instead of being
+            // held in 32 registers across the layer
+            auto l1_frag = [&](int s, Frag b[1]) {
+                float v[8];
+                float S1[3], C1[3];
+                const int r0 = (8 * s) / 5;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (r0 + q < 16) sincos_hw(F[r0 + q], S1[q], C1[q]);
+                    else { S1[q] = 0.f; C1[q] = 1.f; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * s + j, r = i / 5, t = i % 5, q = r - r0;
+                    v[j] = t == 0 ? F[r] : (t == 1 ? S1[q] : (t == 2 ? 2.0f * S1[q] * C1[q] : (t == 3 ? C1[q] : __builtin_fmaf(-2.0f * S1[q], S1[q], 1.0f))));
+                }
+                b[0] = split8(v);
+            };
+            Frag bcur[1], bnxt[1];
+            AFrag4 acur, anxt;
+            l1_frag(0, bcur);
+            load_afrag4(acur, W1H, W1L, rowoff, 32 * TVR_IMG_W1_ROW);
+            TVR_SB; TVR_STAMP(p2);
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                if (s + 1 < 10) {
+                    load_afrag4(anxt, W1H, W1L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W1_ROW);
+                    l1_frag(s + 1, bnxt);
+                }
+                mfma3x4(acur, bcur, acc);
+                if ((s & 1) == 0) gather_step(N, s >> 1);          // gather steps 0..4
+                if (s + 1 < 10) { if ((s & 1) == 0) sched_pipe_step<PW_SGB + PW_SGX, true>(); else sched_pipe_step<PW_SGB, false>(); }
+                acur = anxt;
+                bcur[0] = bnxt[0];
+                TVR_SB;
+            }
+        }
+        TVR_SB; TVR_STAMP(p3);
+        f32x16 acc2[1][4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * rb + 8 * q + 4 * h) * 4);
+                acc2[0][rb][4 * q] = bv.x; acc2[0][rb][4 * q + 1] = bv.y; acc2[0][rb][4 * q + 2] = bv.z; acc2[0][rb][4 * q + 3] = bv.w;
+            }
+        {
+            const int rowoff = e * TVR_IMG_W2_ROW + h * 16;
+            auto relu_frag = [&](int s, Frag b[1]) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = relu_f(acc[0][s >> 1][8 * (s & 1) + j]);
+                b[0] = split8(v);
+            };
+            Frag bcur[1], bnxt[1];
+            AFrag4 acur, anxt;
+            relu_frag(0, bcur);
+            load_afrag4(acur, W2H, W2L, rowoff, 32 * TVR_IMG_W2_ROW);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8) {
+                    load_afrag4(anxt, W2H, W2L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W2_ROW);
+                    relu_frag(s + 1, bnxt);
+                }
+                mfma3x4(acur, bcur, acc2);
+                if ((s & 1) == 0) gather_step(N, 5 + (s >> 1));   // gather steps 5..8
+                if (s + 1 < 8) { if ((s & 1) == 0) sched_pipe_step<PW_SGB + PW_SGX, true>(); else sched_pipe_step<PW_SGB, false>(); }
+                acur = anxt;
+                bcur[0] = bnxt[0];
+                TVR_SB;
+            }
+        }
+        TVR_SB; TVR_STAMP(p4);
+        fetch_entry(following_tile);                            // the tile after N
+        f32x16 acc3 = f32x16{0}, acc3b = f32x16{0}, acc3c = f32x16{0};
+        {
+            const float b30 = sc.b3[0], b31 = sc.b3[1], b32 = sc.b3[2];
+            acc3[0] = h == 0 ? b30 : 0.0f; acc3[1] = h == 0 ? b31 : 0.0f; acc3[2] = h == 0 ? b32 : 0.0f;
+            Frag bcur, bnxt;
+            auto relu2_frag = [&](int s, Frag &b) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = relu_f(acc2[0][s >> 1][8 * (s & 1) + j]);
+                b = split8(v);
+            };
+            relu2_frag(0, bcur);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const uint4 *ap = (const uint4 *)(smem + TVR_IMG_W3 + (e < 3 ? e : 3) * TVR_IMG_W3_ROW + (s * 2 + h) * 32);
+                const h8 Ah = __builtin_bit_cast(h8, ap[0]), Al = __builtin_bit_cast(h8, ap[1]);
+                if (s + 1 < 8) relu2_frag(s + 1, bnxt);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, bcur.hi), acc3, 0, 0, 0);
+                acc3b = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, bcur.lo), acc3b, 0, 0, 0);
+                acc3c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, bcur.hi), acc3c, 0, 0, 0);
+                bcur = bnxt;
+                TVR_SB;
+            }
+        }
+        TVR_SB; TVR_STAMP(p5);
+        const float r0 = sigmoid_f((acc3[0] + acc3b[0]) + acc3c[0]), r1 = sigmoid_f((acc3[1] + acc3b[1]) + acc3c[1]),
+                    r2 = sigmoid_f((acc3[2] + acc3b[2]) + acc3c[2]);
+        if (M.live && h == 0) a.q_out[M.ent] = make_float4(r0, r1, r2, M.wq);
+        fetch_basis();                                          // for the next stage (issued any earlier, the 72 registers spill)
+        TVR_SB; TVR_STAMP(p6);
+#if TVR_TIMING
+        psum[0] += p1 - p0; psum[1] += p2 - p1; psum[2] += p3 - p2; psum[3] += p4 - p3; psum[4] += p5 - p4; psum[5] += p6 - p5;
+#endif
+    };
+
+    PipeTile ga, gb;
+    fetch_entry(first);
+    gather_begin(ga);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) gather_step(ga, s);           // prologue: the first tile's gather runs alone
+    fetch_basis();
+    fetch_entry(first + stride);
+    for (long long tile = first; tile < n_tiles; tile += 2 * stride) {
+        stage(ga, gb, tile + 2 * stride);                     // matrix(tile), gather(tile + stride), entry prefetch(tile + 2 stride)
+        if (tile + stride < n_tiles) stage(gb, ga, tile + 3 * stride);
+    }
+#if TVR_TIMING
+    if (a.stats && lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], psum[i]);     // basis, gather begin + PE, L1, L2, L3, epilogue
+#endif
+    if (a.stats && blockIdx.x == 0 && tid == 0) atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
+}
+
+#endif  // TVR_PIPE
+
 template <int SRC, int DST, bool REF>
 static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
@@ -892,6 +1169,14 @@ hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a
         if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, true>(sc, a, stream);
         return hipErrorInvalidValue;
     }
+#if TVR_PIPE
+    if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) {
+        hipError_t rc = hipFuncSetAttribute((const void *)shade_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TVR_MLP_IMAGE_BYTES);
+        if (rc != hipSuccess) return rc;
+        hipLaunchKernelGGL(shade_pipe_kernel, dim3(256), dim3(64 * PW_WAVES), TVR_MLP_IMAGE_BYTES, stream, sc, a);
+        return hipGetLastError();
+    }
+#endif
     if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false>(sc, a, stream);
     if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, false>(sc, a, stream);
     if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false>(sc, a, stream);

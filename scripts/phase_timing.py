@@ -13,6 +13,7 @@ torch.cuda.synchronize()
 st = stats.cpu().numpy().astype(float)
 tot = st[8:15].sum()
 print("entries", st[2], "tiles", st[2] / 32)
-for n, v in zip(("gather", "basis", "PE", "token wait", "L1+L2", "L3", "epilogue"), st[8:15]):
+names = ("basis", "gather begin + PE", "L1 (+gather 0..4)", "L2 (+gather 5..8)", "L3", "epilogue", "-") if os.environ.get("TVR_PIPE_NAMES") else ("gather", "basis", "PE", "token wait", "L1+L2", "L3", "epilogue")
+for n, v in zip(names, st[8:15]):
     print(f"{n:12s} {v / (st[2] / 32):9.0f} cycles/tile  {100 * v / tot:5.1f} %")
 print("sum cycles/tile", tot / (st[2] / 32))
