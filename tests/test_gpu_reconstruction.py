@@ -1,0 +1,89 @@
+"""GPU (-m gpu): the reference's reconstruction schedule in miniature (tensorf-myc/train.py:133-360) — coarse-to-fine training with ray
+filtering, per-group Adam + exponential lr decay, TV / L1 / ortho regularisers, an alpha-mask update with shrink, a second mask update with
+filtering_rays, two grid upsamplings (each with a fresh optimizer), a checkpoint, and the evaluation loop at the end.  Every piece is
+parity-tested on its own elsewhere; this drives them together the way train.py does and checks that the result is a better image."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TINY, make_model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reconstruction_schedule(tmp_path, hyper_tiny):
+    from jittor_myc_nerfs_amd import (N_to_reso, OctreeRender_trilinear_fast, TVLoss, TensorVMSplit, cal_n_samples, load_checkpoint, rays as R,
+                                      synthetic)
+    torch.manual_seed(0)
+    aabb = torch.tensor(TINY["aabb"], dtype=torch.float32)
+    # "dataset": a teacher scene rendered from 12 poses at 24x24 (the reference reads Blender frames; tests/test_evaluation_io.py covers the reader)
+    teacher = make_model(synthetic.make_scene_arrays([40, 40, 40], TINY["aabb"], seed=3), hyper_tiny)
+    poses = R.sphere_poses(12, 4.0)
+    allrays = torch.cat([R.frame_rays(M, 24, 24, 0.6911) for M in poses]).cuda()
+    with torch.no_grad():
+        allrgbs, _ = teacher(allrays, is_train=False, white_bg=True, N_samples=96)
+    test_rays, test_rgbs = allrays[:576], allrgbs[:576]
+
+    n_iters, batch = 120, 1024
+    upsamp_list, update_AlphaMask_list = [40, 80], [30, 60]
+    N_voxel_list = [int(v) for v in np.round(np.exp(np.linspace(np.log(16 ** 3), np.log(40 ** 3), len(upsamp_list) + 1)))][1:]      # train.py:136
+    reso_cur = N_to_reso(16 ** 3, aabb)
+    nSamples = min(96, cal_n_samples(reso_cur, 0.5))
+    m = TensorVMSplit(aabb, reso_cur, "cuda", density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, app_dim=27, near_far=TINY["near_far"],
+                      shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=-10, distance_scale=25, pos_pe=6, view_pe=2, fea_pe=2,
+                      featureC=128, step_ratio=0.5, fea2denseAct="softplus")
+    allrays_f, allrgbs_f = m.filtering_rays(allrays, allrgbs, bbox_only=True)                       # train.py:198-199
+    assert 0 < allrays_f.shape[0] <= allrays.shape[0]
+    lr_factor = 0.1 ** (1 / n_iters)                                                                # train.py:185
+    opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
+    tv = TVLoss()
+
+    def psnr(model, S):
+        with torch.no_grad():
+            out, _, _, _, _ = OctreeRender_trilinear_fast(test_rays, model, chunk=4096, N_samples=S, white_bg=True)
+        return float(-10 * torch.log10(torch.mean((out - test_rgbs) ** 2)))
+
+    psnr0 = psnr(m, nSamples)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    L1_w = 8e-5
+    for it in range(n_iters):
+        idx = torch.randint(0, allrays_f.shape[0], (batch,), device="cuda", generator=g)
+        opt.zero_grad()
+        rgb_map, _, _, _, _ = OctreeRender_trilinear_fast(allrays_f[idx], m, chunk=batch, N_samples=nSamples, white_bg=True, is_train=True)
+        loss = torch.mean((rgb_map - allrgbs_f[idx]) ** 2)
+        total = loss + 1e-4 * m.vector_comp_diffs() + L1_w * m.density_L1() + 0.1 * m.TV_loss_density(tv) + 0.01 * m.TV_loss_app(tv)
+        total.backward()
+        opt.step()
+        for pg in opt.param_groups:
+            pg["lr"] = pg["lr"] * lr_factor                                                         # train.py:270-271
+        if it in update_AlphaMask_list:                                                             # train.py:292-313
+            new_aabb = m.updateAlphaMask(tuple(reso_cur))
+            if it == update_AlphaMask_list[0]:
+                m.shrink(new_aabb)
+                L1_w = 4e-5
+            if it == update_AlphaMask_list[1]:
+                allrays_f, allrgbs_f = m.filtering_rays(allrays_f, allrgbs_f)
+                assert allrays_f.shape[0] > 0
+        if it in upsamp_list:                                                                       # train.py:316-330
+            reso_cur = N_to_reso(N_voxel_list.pop(0), m.aabb)
+            nSamples = min(96, cal_n_samples(reso_cur, 0.5))
+            m.upsample_volume_grid(reso_cur)
+            lr_scale = 0.1 ** (it / n_iters)
+            opt = torch.optim.Adam(m.get_optparam_groups(0.02 * lr_scale, 0.001 * lr_scale), betas=(0.9, 0.99))
+    psnr1 = psnr(m, nSamples)
+    print(f"reconstruction schedule: test PSNR {psnr0:.2f} -> {psnr1:.2f} dB, final grid {m.gridSize.tolist()}, nSamples {nSamples}, "
+          f"alpha mask {tuple(m.alphaMask.alpha_volume.shape[-3:])}, {allrays_f.shape[0]} of {allrays.shape[0]} rays kept")
+    assert psnr1 > psnr0 + 6.0 and psnr1 > 20.0
+    assert m.alphaMask is not None and max(m.gridSize.tolist()) > 16
+    # checkpoint -> rebuild -> same pixels (train.py:75-87)
+    path = str(tmp_path / "recon.th")
+    m.save(path, global_kwargs={"global_step": n_iters})
+    ckpt = load_checkpoint(path)
+    kw = ckpt["kwargs"]
+    kw.update({"device": "cuda"})
+    m2 = TensorVMSplit(**kw)
+    m2.load(ckpt)
+    with torch.no_grad():
+        a, _ = m(test_rays, is_train=False, white_bg=True, N_samples=nSamples)
+        b, _ = m2(test_rays, is_train=False, white_bg=True, N_samples=nSamples)
+    assert torch.equal(a, b)
