@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 103
+#define TVR_VERSION 104
 
 typedef enum {
     TVR_OK = 0,
@@ -190,6 +190,18 @@ int tvr_app_h_backward(tvr_scene *scene, const float *xyz_norm, int64_t m, const
 size_t tvr_gemm_tn_scratch_bytes(int32_t Ka, int32_t Kb, int64_t M);
 int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C,
                 void *scratch, size_t scratch_bytes, void *stream);
+
+/* The MLP input of the training step in one pass: X [m,150] = [features 27, viewdirs 3, PE(features), PE(viewdirs)] (MLPRender_Fea.execute,
+ * tensorBase.py:76-82; positional_encoding :9-15), or X [m,151] with dot_product [m] in front (MLPRender_Fea_Ref, REFTensoRF.py:19-24) when
+ * dot_product is non-NULL; and its backward (grad_viewdirs / grad_dot may be NULL). */
+int tvr_pe_concat(const float *features, const float *viewdirs, const float *dot_product, int64_t m, float *X, void *stream);
+int tvr_pe_concat_backward(const float *features, const float *viewdirs, const float *grad_X, int64_t m, int32_t with_dot,
+                           float *grad_features, float *grad_viewdirs, float *grad_dot, void *stream);
+
+/* TVLoss.forward (tensorf-myc/utils.py:123-142) of one plane x (C,H,W), batch 1: value [1] = weight * 2 (h_tv/count_h + w_tv/count_w) and
+ * grad (C,H,W) = d value / d x in the same pass; fixed summation order.  scratch: 2048 bytes. */
+int tvr_tv_loss(const float *x, int32_t C, int32_t H, int32_t W, float weight, float *value, float *grad, void *scratch, size_t scratch_bytes,
+                void *stream);
 
 /* Per-kernel HIP-event timing of tvr_render calls (march / shade / composite), for bench.py's roofline. */
 int tvr_profile_create(int32_t max_calls, tvr_profile **out);

@@ -482,6 +482,32 @@ int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *d
     return TVR_OK;
 }
 
+int tvr_pe_concat(const float *features, const float *viewdirs, const float *dot_product, int64_t m, float *X, void *stream)
+{
+    if (m == 0) return TVR_OK;
+    if (!features || !viewdirs || !X || m < 0) return fail(TVR_ERR_INVALID, "features/viewdirs/X NULL or m < 0");
+    HIP_TRY(launch_pe_concat(features, viewdirs, dot_product, m, X, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_pe_concat_backward(const float *features, const float *viewdirs, const float *grad_X, int64_t m, int32_t with_dot, float *grad_features,
+                           float *grad_viewdirs, float *grad_dot, void *stream)
+{
+    if (m == 0) return TVR_OK;
+    if (!features || !viewdirs || !grad_X || !grad_features || m < 0) return fail(TVR_ERR_INVALID, "NULL argument or m < 0");
+    HIP_TRY(launch_pe_concat_backward(features, viewdirs, grad_X, m, with_dot ? 1 : 0, grad_features, grad_viewdirs, grad_dot, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_tv_loss(const float *x, int32_t C, int32_t H, int32_t W, float weight, float *value, float *grad, void *scratch, size_t scratch_bytes,
+                void *stream)
+{
+    if (!x || !value || !grad || C < 1 || H < 1 || W < 1) return fail(TVR_ERR_INVALID, "x/value/grad NULL or bad shape");
+    if (!scratch || scratch_bytes < 2048) return fail(TVR_ERR_SCRATCH, "tvr_tv_loss needs 2048 bytes of scratch");
+    HIP_TRY(launch_tv_loss(x, C, H, W, weight, value, grad, (float *)scratch, (hipStream_t)stream));
+    return TVR_OK;
+}
+
 static int gemm_tn_check(int32_t Ka, int32_t Kb, int64_t M)
 {
     if (M < 0 || Ka < 1 || Kb < 1) return fail(TVR_ERR_INVALID, "bad Ka/Kb/M");

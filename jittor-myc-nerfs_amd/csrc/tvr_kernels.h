@@ -69,3 +69,7 @@ hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long
 hipError_t launch_unpack_grad(const float *in, float *out, int C, int H, int W, hipStream_t stream);
 hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream);
 size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M);
+hipError_t launch_pe_concat(const float *feat, const float *dir, const float *dot, long long m, float *X, hipStream_t stream);
+hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const float *gX, long long m, int with_dot, float *gfeat, float *gdir,
+                                     float *gdot, hipStream_t stream);
+hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, float *value, float *grad, float *part, hipStream_t stream);

@@ -435,3 +435,117 @@ hipError_t launch_unpack_grad(const float *in, float *out, int C, int H, int W, 
     hipLaunchKernelGGL(unpack_grad_kernel, dim3(grid), dim3(256), 0, stream, in, out, C, H, W, Wp);
     return hipGetLastError();
 }
+
+// ---- fused training helpers: the MLP input assembly and the TV regulariser (each replaces a dozen elementwise library launches) ----------
+// MLPRender_Fea's input (tensorBase.py:76-82): X = [f (27), d (3), sin(f 2^k), cos(f 2^k) (k < 2, index 2c + k), sin(d 2^k), cos(d 2^k)];
+// MLPRender_Fea_Ref (REFTensoRF.py:19-24) puts dot_product in front (with_dot = 1, 151 columns).  One thread per (entry, base value).
+__global__ __launch_bounds__(256) void pe_concat_forward_kernel(const float *__restrict__ feat, const float *__restrict__ dir,
+                                                                const float *__restrict__ dot, const long long m, const int with_dot,
+                                                                float *__restrict__ X)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * 30) return;
+    const long long ent = t / 30;
+    const int c = (int)(t - ent * 30);
+    const int n = 150 + with_dot;
+    float *x = X + ent * n + with_dot;
+    const float v = c < 27 ? feat[ent * 27 + c] : dir[ent * 3 + (c - 27)];
+    float s1, c1, s2, c2;
+    sincosf(v, &s1, &c1);
+    sincosf(v * 2.0f, &s2, &c2);
+    x[c] = v;
+    if (c < 27) {
+        x[30 + 2 * c] = s1; x[31 + 2 * c] = s2; x[84 + 2 * c] = c1; x[85 + 2 * c] = c2;
+    } else {
+        const int j = c - 27;
+        x[138 + 2 * j] = s1; x[139 + 2 * j] = s2; x[144 + 2 * j] = c1; x[145 + 2 * j] = c2;
+    }
+    if (with_dot && c == 0) X[ent * n] = dot[ent];
+}
+
+// d/dv of the five columns a base value feeds: gX[v] + sum_k 2^k (gX[sin] cos(v 2^k) - gX[cos] sin(v 2^k))
+__global__ __launch_bounds__(256) void pe_concat_backward_kernel(const float *__restrict__ feat, const float *__restrict__ dir,
+                                                                 const float *__restrict__ gX, const long long m, const int with_dot,
+                                                                 float *__restrict__ gfeat, float *__restrict__ gdir, float *__restrict__ gdot)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * 30) return;
+    const long long ent = t / 30;
+    const int c = (int)(t - ent * 30);
+    const int n = 150 + with_dot;
+    const float *g = gX + ent * n + with_dot;
+    const float v = c < 27 ? feat[ent * 27 + c] : dir[ent * 3 + (c - 27)];
+    float s1, c1, s2, c2;
+    sincosf(v, &s1, &c1);
+    sincosf(v * 2.0f, &s2, &c2);
+    const int is = c < 27 ? 30 + 2 * c : 138 + 2 * (c - 27), ic = c < 27 ? 84 + 2 * c : 144 + 2 * (c - 27);
+    const float r = g[c] + (g[is] * c1 - g[ic] * s1) + 2.0f * (g[is + 1] * c2 - g[ic + 1] * s2);
+    if (c < 27) gfeat[ent * 27 + c] = r;
+    else if (gdir) gdir[ent * 3 + (c - 27)] = r;
+    if (with_dot && c == 0 && gdot) gdot[ent] = gX[ent * n];
+}
+
+hipError_t launch_pe_concat(const float *feat, const float *dir, const float *dot, long long m, float *X, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pe_concat_forward_kernel, dim3((unsigned)((m * 30 + 255) / 256)), dim3(256), 0, stream, feat, dir, dot, m, dot ? 1 : 0, X);
+    return hipGetLastError();
+}
+
+hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const float *gX, long long m, int with_dot, float *gfeat, float *gdir,
+                                     float *gdot, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pe_concat_backward_kernel, dim3((unsigned)((m * 30 + 255) / 256)), dim3(256), 0, stream, feat, dir, gX, m, with_dot, gfeat,
+                       gdir, gdot);
+    return hipGetLastError();
+}
+
+// TVLoss (tensorf-myc/utils.py:123-142) of one plane x (C,H,W): value = 2 (h_tv / count_h + w_tv / count_w) with h_tv = sum (x[.,y+1,.] - x[.,y,.])^2,
+// w_tv likewise along x, count_h = C (H-1) W, count_w = C H (W-1); and its gradient, in one pass.  Partial sums go to `part` (one float per
+// workgroup, summed in order by tv_finish_kernel): deterministic.
+#define TV_THREADS 256
+__global__ __launch_bounds__(TV_THREADS) void tv_loss_kernel(const float *__restrict__ x, const int C, const int H, const int W,
+                                                             const float ch, const float cw, float *__restrict__ grad, float *__restrict__ part)
+{
+    __shared__ float red[TV_THREADS / 64];
+    const long long total = (long long)C * H * W;
+    float acc = 0.0f;
+    for (long long i = (long long)blockIdx.x * TV_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * TV_THREADS) {
+        const int xx = (int)(i % W);
+        const int yy = (int)((i / W) % H);
+        const float v = x[i];
+        float g = 0.0f;
+        if (yy + 1 < H) { const float d = x[i + W] - v; acc += ch * d * d; g -= 2.0f * ch * d; }
+        if (yy > 0) g += 2.0f * ch * (v - x[i - W]);
+        if (xx + 1 < W) { const float d = x[i + 1] - v; acc += cw * d * d; g -= 2.0f * cw * d; }
+        if (xx > 0) g += 2.0f * cw * (v - x[i - 1]);
+        grad[i] = g;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+        for (int w = 0; w < TV_THREADS / 64; ++w) s += red[w];
+        part[blockIdx.x] = s;
+    }
+}
+
+__global__ void tv_finish_kernel(const float *__restrict__ part, const int n, float *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.0f;
+        for (int i = 0; i < n; ++i) s += part[i];
+        out[0] = s;
+    }
+}
+
+#define TV_BLOCKS 512
+hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, float *value, float *grad, float *part, hipStream_t stream)
+{
+    const float count_h = (float)C * (float)(H - 1) * (float)W, count_w = (float)C * (float)H * (float)(W - 1);
+    const float ch = (H > 1) ? weight * 2.0f / count_h : 0.0f, cw = (W > 1) ? weight * 2.0f / count_w : 0.0f;
+    hipLaunchKernelGGL(tv_loss_kernel, dim3(TV_BLOCKS), dim3(TV_THREADS), 0, stream, x, C, H, W, ch, cw, grad, part);
+    hipLaunchKernelGGL(tv_finish_kernel, dim3(1), dim3(64), 0, stream, part, TV_BLOCKS, value);
+    return hipGetLastError();
+}

@@ -102,12 +102,7 @@ class MLPRender_Fea(torch.nn.Module):
 
     def forward_autograd(self, viewdirs, features):
         """tensorBase.py:76-86 as library GEMMs under autograd (training): PE, concat, Linear-ReLU-Linear-ReLU-Linear, sigmoid."""
-        indata = [features, viewdirs]
-        if self.feape > 0:
-            indata += [_pe(features, self.feape)]
-        if self.viewpe > 0:
-            indata += [_pe(viewdirs, self.viewpe)]
-        return torch.sigmoid(_mlp3(self.mlp, torch.cat(indata, dim=-1)))
+        return torch.sigmoid(_mlp3(self.mlp, _mlp_input(features, viewdirs, self.feape, self.viewpe)))
 
 
 class _LinearFn(torch.autograd.Function):
@@ -149,6 +144,49 @@ def _mlp3(mlp: torch.nn.Sequential, x):
     return _linear(mlp[4], torch.relu(_linear(mlp[2], torch.relu(_linear(mlp[0], x)))))
 
 
+class _PEConcatFn(torch.autograd.Function):
+    """[ (dot,) features, viewdirs, PE(features), PE(viewdirs) ] in one kernel each way (tvr_pe_concat): the torch formulation is four
+    elementwise launches plus a concat forward and a dozen backward, each streaming the [M,150] matrix."""
+
+    @staticmethod
+    def forward(ctx, features, viewdirs, dot):
+        f, v = features.contiguous(), viewdirs.contiguous()
+        d = None if dot is None else dot.contiguous().view(-1)
+        m = f.shape[0]
+        X = torch.empty((m, 150 + (0 if d is None else 1)), dtype=torch.float32, device=f.device)
+        L.check(L.lib().tvr_pe_concat(f.data_ptr(), v.data_ptr(), None if d is None else d.data_ptr(), m, X.data_ptr(), _stream_ptr(f.device)),
+                "tvr_pe_concat")
+        ctx.save_for_backward(f, v)
+        ctx.with_dot = d is not None
+        ctx.dot_shape = None if dot is None else dot.shape
+        return X
+
+    @staticmethod
+    def backward(ctx, gX):
+        f, v = ctx.saved_tensors
+        gX = gX.contiguous()
+        m = f.shape[0]
+        gf = torch.empty_like(f)
+        gv = torch.empty_like(v) if ctx.needs_input_grad[1] else None
+        gd = torch.empty(m, dtype=torch.float32, device=f.device) if (ctx.with_dot and ctx.needs_input_grad[2]) else None
+        L.check(L.lib().tvr_pe_concat_backward(f.data_ptr(), v.data_ptr(), gX.data_ptr(), m, int(ctx.with_dot), gf.data_ptr(),
+                                               None if gv is None else gv.data_ptr(), None if gd is None else gd.data_ptr(), _stream_ptr(f.device)),
+                "tvr_pe_concat_backward")
+        return gf, gv, (None if gd is None else gd.view(ctx.dot_shape))
+
+
+def _mlp_input(features, viewdirs, feape, viewpe, dot=None):
+    """The MLP input of MLPRender_Fea (tensorBase.py:76-82) / MLPRender_Fea_Ref (REFTensoRF.py:19-24)."""
+    if features.is_cuda and feape == 2 and viewpe == 2 and features.shape[-1] == 27 and features.dtype == torch.float32:
+        return _PEConcatFn.apply(features, viewdirs, dot)
+    indata = ([] if dot is None else [dot.view(-1, 1)]) + [features, viewdirs]
+    if feape > 0:
+        indata += [_pe(features, feape)]
+    if viewpe > 0:
+        indata += [_pe(viewdirs, viewpe)]
+    return torch.cat(indata, dim=-1)
+
+
 def _pe(x, freqs):                                                                            # tensorBase.py:9-15
     fb = 2 ** torch.arange(freqs, device=x.device, dtype=torch.float32)
     pts = (x[..., None] * fb).reshape(x.shape[:-1] + (freqs * x.shape[-1],))
@@ -179,12 +217,7 @@ class MLPRender_Fea_Ref(torch.nn.Module):
         return self._owner()._mlp_render_ref(viewdirs, features, dot_product)
 
     def forward_autograd(self, viewdirs, features, dot_product):
-        indata = [dot_product.view(-1, 1), features, viewdirs]
-        if self.feape > 0:
-            indata += [_pe(features, self.feape)]
-        if self.viewpe > 0:
-            indata += [_pe(viewdirs, self.viewpe)]
-        return torch.sigmoid(_mlp3(self.mlp, torch.cat(indata, dim=-1)))
+        return torch.sigmoid(_mlp3(self.mlp, _mlp_input(features, viewdirs, self.feape, self.viewpe, dot_product)))
 
 
 class _MarchFn(torch.autograd.Function):

@@ -129,3 +129,32 @@ def test_fused_adam_updates_reach_the_packed_scene(tiny_arrays, hyper_tiny, tiny
     with torch.no_grad():
         want, _ = fresh(rays, is_train=False, white_bg=True, N_samples=TINY["N_samples"])
     assert torch.equal(after, want)
+
+
+def test_fused_pe_concat_and_tv_loss_match_torch():
+    """tvr_pe_concat / tvr_tv_loss against the torch formulations they replace in the training step (values and gradients)."""
+    from jittor_myc_nerfs_amd import TVLoss
+    from jittor_myc_nerfs_amd.field import _mlp_input, _pe
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for with_dot in (False, True):
+        f = (torch.randn((5003, 27), device="cuda", generator=g) * 3).requires_grad_(True)
+        v = torch.randn((5003, 3), device="cuda", generator=g).requires_grad_(True)
+        d = torch.randn((5003, 1), device="cuda", generator=g).requires_grad_(True) if with_dot else None
+        X = _mlp_input(f, v, 2, 2, d)
+        ref = torch.cat(([d] if with_dot else []) + [f, v, _pe(f, 2), _pe(v, 2)], dim=-1)
+        assert X.shape == ref.shape == (5003, 151 if with_dot else 150) and float((X - ref).abs().max()) < 1e-6
+        cw = torch.randn(X.shape, device="cuda", generator=g)
+        got = torch.autograd.grad((X * cw).sum(), [f, v] + ([d] if with_dot else []))
+        want = torch.autograd.grad((ref * cw).sum(), [f, v] + ([d] if with_dot else []))
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and float((a - b).abs().max()) < 2e-5
+    tv = TVLoss(0.7)
+    for shape in ((1, 16, 33, 47), (1, 48, 5, 1), (1, 3, 2, 9)):
+        x = torch.randn(shape, device="cuda", generator=g).requires_grad_(True)
+        val = tv(x)
+        xr = x.detach().cpu().double().requires_grad_(True)
+        ref = tv(xr)                                                   # the reference's torch formulation (CPU, float64)
+        assert abs(float(val) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+        (gx,) = torch.autograd.grad(val * 3.0, x)
+        (gr,) = torch.autograd.grad(ref * 3.0, xr)
+        assert float((gx.cpu().double() - gr).abs().max()) < 1e-6
