@@ -131,6 +131,56 @@ __device__ __forceinline__ void scatter_ch(const float *__restrict__ Pl, const f
     atomicAdd(q + TVR_CD, wl * gQ);
 }
 
+// Run-length accumulation of the plane gradients: consecutive samples of a ray (half a voxel apart) mostly fall into the same cell of
+// a plane, so their four tap contributions are summed in registers and written with ONE set of atomics when the cell changes.
+struct TapRun {
+    long long key;               // element offset of the (x0, y0) texel's channel, -1 = empty
+    float a00, a01, a10, a11;
+};
+
+__device__ __forceinline__ void run_flush(TapRun &r, float *__restrict__ gPl, int Wp)
+{
+    if (r.key >= 0) {
+        float *p = gPl + r.key;
+        atomicAdd(p, r.a00);
+        atomicAdd(p + TVR_CD, r.a01);
+        atomicAdd(p + (size_t)Wp * TVR_CD, r.a10);
+        atomicAdd(p + (size_t)Wp * TVR_CD + TVR_CD, r.a11);
+    }
+    r.key = -1;
+    r.a00 = r.a01 = r.a10 = r.a11 = 0.0f;
+}
+
+// one density channel of one (plane, line) pair: re-evaluate P, Q; gs*Q joins the plane's run, gs*P goes to the 2 line taps
+template <bool LINE_LDS>
+__device__ __forceinline__ void scatter_run(TapRun &run, const float *__restrict__ Pl, const float *__restrict__ Ln, float *__restrict__ gPl,
+                                            float *__restrict__ gLn, float *gLds, int W, int x0, int y0, int l0, float wx, float wy, float wl,
+                                            int c, float gs)
+{
+    const float ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
+    const int Wp = W + 1;
+    const long long t00 = ((long long)y0 * Wp + x0) * TVR_CD + c, t10 = t00 + (long long)Wp * TVR_CD;
+    const size_t q0 = (size_t)l0 * TVR_CD + c;
+    float P = (ux * uy) * Pl[t00];
+    P = __builtin_fmaf(wx * uy, Pl[t00 + TVR_CD], P);
+    P = __builtin_fmaf(ux * wy, Pl[t10], P);
+    P = __builtin_fmaf(wx * wy, Pl[t10 + TVR_CD], P);
+    float Q = ul * Ln[q0];
+    Q = __builtin_fmaf(wl, Ln[q0 + TVR_CD], Q);
+    const float gP = gs * Q, gQ = gs * P;
+    if (t00 != run.key) {
+        run_flush(run, gPl, Wp);
+        run.key = t00;
+    }
+    run.a00 += (ux * uy) * gP;
+    run.a01 += (wx * uy) * gP;
+    run.a10 += (ux * wy) * gP;
+    run.a11 += (wx * wy) * gP;
+    float *q = (LINE_LDS ? gLds : gLn) + q0;
+    atomicAdd(q, ul * gQ);
+    atomicAdd(q + TVR_CD, wl * gQ);
+}
+
 __device__ __forceinline__ float wave_sum_f(float v)
 {
 #pragma unroll
@@ -280,23 +330,31 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
             T = T * __shfl(incl, 63);
 
             // ---- phase 2: scatter dL/dsf into the density planes / lines (re-gather: the texels are L1/L2 hot) ----
-            // one lane per CHANNEL, four samples per step: each atomic instruction then covers whole 64-B texels (16 dwords per
-            // L2 request; with the quad-per-sample layout of phase 1 a request carried 4 scattered dwords)
+            // one lane per CHANNEL: an atomic instruction covers whole 64-B texels (16 dwords per L2 request; with the quad-per-sample
+            // layout of phase 1 a request carried 4 scattered dwords).  Each 16-lane group walks 16 CONSECUTIVE samples of the chunk, so
+            // that the contributions to a plane's cell accumulate in registers until the ray leaves the cell (TapRun).
             const int ch = lane & 15;
+            TapRun run0, run1, run2;
+            run0.key = run1.key = run2.key = -1;
+            run0.a00 = run0.a01 = run0.a10 = run0.a11 = 0.0f;
+            run1 = run0; run2 = run0;
 #pragma unroll 2
             for (int t = 0; t < 16; ++t) {
-                const int src = 4 * t + (lane >> 4);
+                const int src = 16 * (lane >> 4) + t;
                 const float gs = __shfl(dLdsf, src);
                 if (__ballot(gs != 0.0f) == 0ull) continue;
                 const int ix = __shfl(i0[0], src), iy = __shfl(i0[1], src), iz = __shfl(i0[2], src);
                 const float wx = __shfl(w[0], src), wy = __shfl(w[1], src), wz = __shfl(w[2], src);
                 if (gs != 0.0f) {
                     // sf = sum_i sum_c P_i[c] Q_i[c]  ->  dP_i[c] = gs Q_i[c], dQ_i[c] = gs P_i[c]
-                    scatter_ch<LINE_LDS>((const float *)sc.dplane[0], (const float *)sc.dline[0], tg.dplane[0], tg.dline[0], gl0, sc.grid[0], ix, iy, iz, wx, wy, wz, ch, gs);
-                    scatter_ch<LINE_LDS>((const float *)sc.dplane[1], (const float *)sc.dline[1], tg.dplane[1], tg.dline[1], gl1, sc.grid[0], ix, iz, iy, wx, wz, wy, ch, gs);
-                    scatter_ch<LINE_LDS>((const float *)sc.dplane[2], (const float *)sc.dline[2], tg.dplane[2], tg.dline[2], gl2, sc.grid[1], iy, iz, ix, wy, wz, wx, ch, gs);
+                    scatter_run<LINE_LDS>(run0, (const float *)sc.dplane[0], (const float *)sc.dline[0], tg.dplane[0], tg.dline[0], gl0, sc.grid[0], ix, iy, iz, wx, wy, wz, ch, gs);
+                    scatter_run<LINE_LDS>(run1, (const float *)sc.dplane[1], (const float *)sc.dline[1], tg.dplane[1], tg.dline[1], gl1, sc.grid[0], ix, iz, iy, wx, wz, wy, ch, gs);
+                    scatter_run<LINE_LDS>(run2, (const float *)sc.dplane[2], (const float *)sc.dline[2], tg.dplane[2], tg.dline[2], gl2, sc.grid[1], iy, iz, ix, wy, wz, wx, ch, gs);
                 }
             }
+            run_flush(run0, tg.dplane[0], sc.grid[0] + 1);
+            run_flush(run1, tg.dplane[1], sc.grid[0] + 1);
+            run_flush(run2, tg.dplane[2], sc.grid[1] + 1);
             if (T < eps_T) break;
         }
     }
