@@ -402,13 +402,18 @@ __global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const Scene
     float *__restrict__ gPl = tg.aplane[pl];
     float *gLn = LINE_LDS ? glds : tg.aline[pl];
     const int Wp = sc.grid[ax] + 1;
-    for (long long item = e0 * TVR_CA + threadIdx.x; item < e1 * TVR_CA; item += AHB_THREADS) {
-        const long long ent = item / TVR_CA;
-        const int c = (int)(item - ent * TVR_CA);
+    // each 48-lane group walks a contiguous run of queue entries (consecutive appearance samples of a ray: mostly the same cell), and
+    // the four tap contributions accumulate in registers until the cell changes (as in march_backward)
+    const int grp = threadIdx.x / TVR_CA, c = threadIdx.x - grp * TVR_CA;
+    const long long per = (AHB_ENTRIES + AHB_THREADS / TVR_CA - 1) / (AHB_THREADS / TVR_CA);
+    const long long g0 = e0 + grp * per, g1 = (g0 + per < e1) ? g0 + per : e1;
+    long long key = -1;
+    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+    for (long long ent = g0; ent < g1; ++ent) {
         const float fx = unnorm(xyz[ent * 3 + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * 3 + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * 3 + vx], sc.gm1[vx]);
         const float x0f = floorf(fx), y0f = floorf(fy), l0f = floorf(fl);
         const float wx = fx - x0f, wy = fy - y0f, wl = fl - l0f, ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
-        const size_t t00 = (((size_t)(int)y0f * Wp + (int)x0f)) * TVR_CA + c, t10 = t00 + (size_t)Wp * TVR_CA;
+        const long long t00 = (((long long)(int)y0f * Wp + (int)x0f)) * TVR_CA + c, t10 = t00 + (long long)Wp * TVR_CA;
         const size_t q0 = (size_t)(int)l0f * TVR_CA + c;
         float P = (ux * uy) * Pl[t00];
         P = __builtin_fmaf(wx * uy, Pl[t00 + TVR_CA], P);
@@ -418,12 +423,28 @@ __global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const Scene
         Q = __builtin_fmaf(wl, Ln[q0 + TVR_CA], Q);
         const float g = dh[ent * TVR_KAPP + pl * TVR_CA + c];
         const float gP = g * Q, gQ = g * P;                       // h = P*Q  ->  dP = g*Q, dQ = g*P
-        atomicAdd(gPl + t00, (ux * uy) * gP);
-        atomicAdd(gPl + t00 + TVR_CA, (wx * uy) * gP);
-        atomicAdd(gPl + t10, (ux * wy) * gP);
-        atomicAdd(gPl + t10 + TVR_CA, (wx * wy) * gP);
+        if (t00 != key) {
+            if (key >= 0) {
+                atomicAdd(gPl + key, a00);
+                atomicAdd(gPl + key + TVR_CA, a01);
+                atomicAdd(gPl + key + (long long)Wp * TVR_CA, a10);
+                atomicAdd(gPl + key + (long long)Wp * TVR_CA + TVR_CA, a11);
+            }
+            key = t00;
+            a00 = a01 = a10 = a11 = 0.f;
+        }
+        a00 += (ux * uy) * gP;
+        a01 += (wx * uy) * gP;
+        a10 += (ux * wy) * gP;
+        a11 += (wx * wy) * gP;
         atomicAdd(gLn + q0, ul * gQ);
         atomicAdd(gLn + q0 + TVR_CA, wl * gQ);
+    }
+    if (key >= 0) {
+        atomicAdd(gPl + key, a00);
+        atomicAdd(gPl + key + TVR_CA, a01);
+        atomicAdd(gPl + key + (long long)Wp * TVR_CA, a10);
+        atomicAdd(gPl + key + (long long)Wp * TVR_CA + TVR_CA, a11);
     }
     if (LINE_LDS) {
         __syncthreads();
