@@ -610,13 +610,14 @@ __global__ __launch_bounds__(TV_THREADS) void tv_loss_kernel(const float *__rest
     }
 }
 
-__global__ void tv_finish_kernel(const float *__restrict__ part, const int n, float *__restrict__ out)
+// one wave: lane l adds partials l, l+64, ... in order, then a fixed butterfly
+__global__ __launch_bounds__(64) void tv_finish_kernel(const float *__restrict__ part, const int n, float *__restrict__ out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float s = 0.0f;
-        for (int i = 0; i < n; ++i) s += part[i];
-        out[0] = s;
-    }
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 #define TV_BLOCKS 512
