@@ -158,3 +158,27 @@ def test_fused_pe_concat_and_tv_loss_match_torch():
         (gx,) = torch.autograd.grad(val * 3.0, x)
         (gr,) = torch.autograd.grad(ref * 3.0, xr)
         assert float((gx.cpu().double() - gr).abs().max()) < 1e-6
+
+
+def test_fixed_order_reductions_are_bit_reproducible():
+    """tvr_gemm_tn and tvr_tv_loss sum in a fixed order: repeated calls return identical bits (the scatter kernels use fp32 atomics and do not)."""
+    from jittor_myc_nerfs_amd import TVLoss, _lib as L
+    g = torch.Generator(device="cuda").manual_seed(9)
+    A, B = torch.randn((200_003, 128), device="cuda", generator=g), torch.randn((200_003, 150), device="cuda", generator=g)
+    outs = []
+    for _ in range(3):
+        junk = torch.full((8 << 20,), 0x7F, dtype=torch.uint8, device="cuda")        # perturb what the allocator hands out next
+        out = torch.empty((128, 150), device="cuda")
+        sc = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(128, 150, A.shape[0]), dtype=torch.uint8, device="cuda")
+        L.check(L.lib().tvr_gemm_tn(A.data_ptr(), 128, 128, B.data_ptr(), 150, 150, A.shape[0], out.data_ptr(), sc.data_ptr(), sc.numel(), None), "gemm")
+        outs.append(out.clone())
+        del junk
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    x = torch.randn((1, 48, 301, 301), device="cuda", generator=g).requires_grad_(True)
+    tv = TVLoss()
+    vals, grads = [], []
+    for _ in range(3):
+        v = tv(x)
+        (gx,) = torch.autograd.grad(v, x)
+        vals.append(v.detach().clone()); grads.append(gx.clone())
+    assert torch.equal(vals[0], vals[1]) and torch.equal(vals[0], vals[2]) and torch.equal(grads[0], grads[2])
