@@ -59,7 +59,7 @@ hipError_t launch_density_feature(const SceneDev &sc, const float *xyz, long lon
 hipError_t launch_alpha_sample(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream);
 hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream);
 hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, hipStream_t stream);
-hipError_t launch_pack_mlp(const float *W, void *out_hi, void *out_lo, int mode, hipStream_t stream);
+hipError_t launch_pack_mlp(const float *W, const float *bias, void *out_hi, void *out_lo, int mode, hipStream_t stream);
 hipError_t launch_pack_ref(const float *const W[4], const float *const b[4], void *rows, float *bias, hipStream_t stream);
 hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T, const MarchOut &mo,
                                  const float *grad_w, const float *grad_acc, const float *lam6, const float *grad_lam6, const TrainGrads &tg,

@@ -675,8 +675,9 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     dotin[cb] = a.dots[ent[cb]];
                 }
             }
+            // base row 31's plain slot is the constant 1: its W1 column holds b1, so layer 1 starts from zero accumulators (no bias reads, no moves)
             if (h == 0) F[cb][15] = dir[cb][0];
-            else { F[cb][12] = dir[cb][1]; F[cb][13] = dir[cb][2]; F[cb][14] = dotin[cb]; F[cb][15] = 0.f; }
+            else { F[cb][12] = dir[cb][1]; F[cb][13] = dir[cb][2]; F[cb][14] = dotin[cb]; F[cb][15] = 1.0f; }
         }
 
         // ---- layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5 ----
@@ -686,13 +687,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bv = *(const float4 *)(smem + TVR_IMG_B1 + (32 * rb + 8 * q + 4 * h) * 4);
-#pragma unroll
-                for (int cb = 0; cb < SH_NCB; ++cb) {
-                    acc[cb][rb][4 * q] = bv.x; acc[cb][rb][4 * q + 1] = bv.y; acc[cb][rb][4 * q + 2] = bv.z; acc[cb][rb][4 * q + 3] = bv.w;
-                }
-            }
+            for (int cb = 0; cb < SH_NCB; ++cb) acc[cb][rb] = f32x16{0};
         {
             float S1[SH_NCB][16], C1[SH_NCB][16];
 #pragma unroll
@@ -1007,15 +1002,10 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void shade_pipe_kernel(const Scen
         TVR_SB; TVR_STAMP(p1);
         gather_begin(N);
         if (h == 0) F[15] = M.dir[0];
-        else { F[12] = M.dir[1]; F[13] = M.dir[2]; F[14] = 0.f; F[15] = 0.f; }
+        else { F[12] = M.dir[1]; F[13] = M.dir[2]; F[14] = 0.f; F[15] = 1.0f; }      // row 31 = 1: W1's bias column
         f32x16 acc[1][4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bv = *(const float4 *)(smem + TVR_IMG_B1 + (32 * rb + 8 * q + 4 * h) * 4);
-                acc[0][rb][4 * q] = bv.x; acc[0][rb][4 * q + 1] = bv.y; acc[0][rb][4 * q + 2] = bv.z; acc[0][rb][4 * q + 3] = bv.w;
-            }
+        for (int rb = 0; rb < 4; ++rb) acc[0][rb] = f32x16{0};
         {
             const int rowoff = e * TVR_IMG_W1_ROW + h * 16;
             // sin / cos are re-derived where a k-step needs them (2-3 base values per step, 3 instructions each) instead of being
@@ -1218,14 +1208,15 @@ __device__ __forceinline__ int ref_in_index(int c, int t)
 }
 
 // MLP weights -> fp16 hi/lo operand images.  One thread per (row, k position).
-//  mode 0: W1 LDS image  [128][W1_ROW/2 halfs]: kpos = 16s + 8h + j  <->  derived (i%5) of base acc_row(i/5, h), i = 8s + j
+//  mode 0: W1 LDS image  [128][W1_ROW/2 halfs]: kpos = 16s + 8h + j  <->  derived (i%5) of base acc_row(i/5, h), i = 8s + j;
+//          base row 31's plain slot (the constant-1 input) carries b1
 //  mode 1: W2 LDS image  [128][W2_ROW/2 halfs]: kpos = 16s + 8h + j  <->  hidden unit 16s + 8(j>>2) + 4h + (j&3)
 //  mode 2: basis fragments [9][2][32][hi 8 | lo 8]: row r < 27, k = 16s + 8h + j (natural)
 //  mode 3: W3 LDS block    [4][8][2][hi 8 | lo 8]: rows 0..2 of W3 + one zero row, k as mode 1
 //  mode 4: mode 0 for MLPRender_Fea_Ref (REFTensoRF.py:19-24: [dot, features, viewdirs, PE(features), PE(viewdirs)], 151 inputs):
 //          every index moves up by one and base row 30's plain slot carries input 0 (dot)
-__global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__ W, unsigned short *__restrict__ out_hi,
-                                                       unsigned short *__restrict__ out_lo, int mode)
+__global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__ W, const float *__restrict__ bias,
+                                                       unsigned short *__restrict__ out_hi, unsigned short *__restrict__ out_lo, int mode)
 {
     const int nrows = (mode <= 1 || mode == 4) ? 128 : (mode == 2 ? 32 : 4);
     const int K = (mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : 128);
@@ -1236,12 +1227,14 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
     float w = 0.0f;
     if (mode == 0) {
         const int ii = 8 * s + j;
-        const int idx = ref_in_index(acc_row(ii / 5, hh), ii % 5);
+        const int c = acc_row(ii / 5, hh), idx = ref_in_index(c, ii % 5);
         if (idx >= 0) w = W[(size_t)row * TVR_NIN + idx];
+        if (c == 31 && ii % 5 == 0) w = bias[row];                 // the constant-1 input (base row 31): b1 rides in the weight image
     } else if (mode == 4) {
         const int ii = 8 * s + j, c = acc_row(ii / 5, hh), t = ii % 5;
         const int idx = (c == TVR_APPDIM + 3) ? (t == 0 ? 0 : -1) : (ref_in_index(c, t) >= 0 ? ref_in_index(c, t) + 1 : -1);
         if (idx >= 0) w = W[(size_t)row * TVR_NIN_REF + idx];
+        if (c == 31 && t == 0) w = bias[row];
     } else if (mode == 1) {
         w = W[(size_t)row * TVR_FEATC + (16 * s + 8 * (j >> 2) + 4 * hh + (j & 3))];
     } else if (mode == 2) {
@@ -1268,10 +1261,10 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
     }
 }
 
-hipError_t launch_pack_mlp(const float *W, void *out_hi, void *out_lo, int mode, hipStream_t stream)
+hipError_t launch_pack_mlp(const float *W, const float *bias, void *out_hi, void *out_lo, int mode, hipStream_t stream)
 {
     const int n = ((mode <= 1 || mode == 4) ? 128 : (mode == 2 ? 32 : 4)) * ((mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : 128));
-    hipLaunchKernelGGL(pack_mlp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, (unsigned short *)out_hi, (unsigned short *)out_lo, mode);
+    hipLaunchKernelGGL(pack_mlp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, bias, (unsigned short *)out_hi, (unsigned short *)out_lo, mode);
     return hipGetLastError();
 }
 
