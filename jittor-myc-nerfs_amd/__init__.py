@@ -1,9 +1,10 @@
 """MI355X-native TensoRF volume renderer (package dir: jittor-myc-nerfs_amd; import as jittor_myc_nerfs_amd).
 
 Drop-in surface of the reference's render path (tensorf-myc): TensorVMSplit / AlphaGridMask / MLPRender_Fea
-(field.py), OctreeRender_trilinear_fast (render.py), Blender-format ray generation (rays.py), backed by
+(field.py), REFTensoRF / NerfPlusPlus (variants.py), OctreeRender_trilinear_fast (render.py), Blender-format ray generation (rays.py), backed by
 hand-written HIP kernels for gfx950 behind the C-ABI in include/tvr.h (csrc/, built into lib/libtvr.so)."""
-from .field import AlphaGridMask, MLPRender_Fea, MLPRender_Fea_Ref, NerfPlusPlus, REFTensoRF, TensorBase, TensorVMSplit, load_checkpoint  # noqa: F401
+from .field import AlphaGridMask, MLPRender_Fea, TensorBase, TensorVMSplit, load_checkpoint  # noqa: F401
+from .variants import Embedder, MLPNet, MLPRender_Fea_Ref, NerfPlusPlus, REFTensoRF  # noqa: F401
 from .render import OctreeRender_trilinear_fast, N_to_reso, cal_n_samples, render_sharded, shard_indices, shard_capacity  # noqa: F401
 from .evaluation import BlenderRays, evaluation, evaluation_path, rgb_ssim  # noqa: F401
 from .losses import TVLoss  # noqa: F401

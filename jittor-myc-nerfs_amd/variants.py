@@ -1,0 +1,345 @@
+"""The reference's model variants that override the render path, on the same kernels as TensorVMSplit:
+
+  * MLPRender_Fea_Ref, REFTensoRF      tensorf-myc/models/REFTensoRF.py:5-28, 64-256   (what configs/Scar.txt:28 trains)
+  * Embedder, MLPNet, NerfPlusPlus     tensorf-myc/models/nerfplusplus.py:7-56, 66-140, 143-318
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .autograd_ops import _AppHFn, _MarchFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
+from .field import TensorVMSplit
+
+
+class MLPRender_Fea_Ref(torch.nn.Module):
+    """REFTensoRF.py:5-28: [dot_product, features, viewdirs, PE(features), PE(viewdirs)] -> Linear-ReLU-Linear-ReLU-Linear -> sigmoid.
+    Parameters only; the arithmetic runs in the shade kernel of the owning REFTensoRF (k, the 1/rho argument, is unused there too)."""
+
+    def __init__(self, inChanel, viewpe=6, feape=6, featureC=128):
+        super().__init__()
+        self.in_mlpC = 2 * viewpe * 3 + 2 * feape * inChanel + 1 + 3 + inChanel
+        self.viewpe, self.feape = viewpe, feape
+        layer1 = torch.nn.Linear(self.in_mlpC, featureC)
+        layer2 = torch.nn.Linear(featureC, featureC)
+        layer3 = torch.nn.Linear(featureC, 3)
+        self.mlp = torch.nn.Sequential(layer1, torch.nn.ReLU(), layer2, torch.nn.ReLU(), layer3)
+        torch.nn.init.constant_(self.mlp[-1].bias, 0)
+        self._owner = None
+
+    def forward(self, pts, viewdirs, features, dot_product, k=None):
+        if self._owner is None:
+            raise L.TvrError("MLPRender_Fea_Ref is not attached to a REFTensoRF field (no packed weights on the device)")
+        if torch.is_grad_enabled() and (features.requires_grad or viewdirs.requires_grad or dot_product.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            return self.forward_autograd(viewdirs, features, dot_product)
+        return self._owner()._mlp_render_ref(viewdirs, features, dot_product)
+
+    def forward_autograd(self, viewdirs, features, dot_product):
+        return torch.sigmoid(_mlp3(self.mlp, _mlp_input(features, viewdirs, self.feape, self.viewpe, dot_product)))
+
+
+class REFTensoRF(TensorVMSplit):
+    """models/REFTensoRF.py:64-256 — the Ref-NeRF-style variant configs/Scar.txt trains: four extra Linears on the 144-wide plane*line
+    product give a normal, a diffuse colour, a specular tint and a roughness; the MLP sees the reflection direction and -dot.
+    Inference runs in the same fused HIP kernels (tvr_scene_desc.variant = 1); training as TensorVMSplit's (HIP march / gather
+    kernels forward + backward, the small dense algebra under torch autograd)."""
+
+    _variant = 1
+
+    def __init__(self, aabb, gridSize, device, **kargs):
+        super().__init__(aabb, gridSize, device, **kargs)
+        self.norm_n_comp = self.density_n_comp                                                # :67
+        self.penalty = torch.zeros((), device=self.device)                                    # :68
+
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):      # :70-77
+        if shadingMode != 'MLP_Fea':
+            raise NotImplementedError(f"shadingMode {shadingMode!r}: only 'MLP_Fea' (MLPRender_Fea_Ref; what configs/Scar.txt uses) "
+                                      "is on the accelerated render path")
+        self.renderModule = MLPRender_Fea_Ref(self.app_dim, view_pe, fea_pe, featureC)
+        import weakref
+        self.renderModule._owner = weakref.ref(self)
+
+    def init_svd_volume(self, res, device):                                                   # :80-96
+        super().init_svd_volume(res, device)
+        k = sum(self.app_n_comp)
+        self.normal_linear = torch.nn.Linear(k, 3)
+        self.diffuse_linear = torch.nn.Linear(k, 3)
+        self.specular_linear = torch.nn.Linear(k, 1)
+        self.rho_linear = torch.nn.Linear(k, 1)
+
+    def _extra_linears(self):
+        return [self.normal_linear, self.diffuse_linear, self.specular_linear, self.rho_linear]
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):            # :99-106
+        grad_vars = super().get_optparam_groups(lr_init_spatialxyz, lr_init_network)
+        grad_vars += [{'params': self.normal_linear.parameters(), 'lr': lr_init_network},
+                      {'params': self.diffuse_linear.parameters(), 'lr': lr_init_network},
+                      {'params': self.rho_linear.parameters(), 'lr': lr_init_network},
+                      {'params': self.specular_linear.parameters(), 'lr': lr_init_network}]
+        return grad_vars
+
+    def _heads(self, h):                                                                      # :125-133
+        return (_linear(self.basis_mat, h), _linear(self.diffuse_linear, h), torch.relu(_linear(self.specular_linear, h)),
+                _linear(self.normal_linear, h), torch.relu(_linear(self.rho_linear, h)))
+
+    def compute_appfeature(self, xyz_sampled):                                                # :107-133
+        """-> (appfeatures [M,27], rgb_d [M,3], specular_tint [M,1], normal_vector [M,3], rho [M,1])"""
+        sc = self._ensure_scene()
+        x = _f32c(xyz_sampled, self.device).view(-1, 3)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._heads(_AppHFn.apply(self, x, *self.app_plane, *self.app_line))
+        feats = torch.empty((x.shape[0], self.app_dim), dtype=torch.float32, device=self.device)
+        extra = torch.empty((x.shape[0], 8), dtype=torch.float32, device=self.device)
+        L.check(L.lib().tvr_app_feature_ref(sc, x.data_ptr(), x.shape[0], feats.data_ptr(), extra.data_ptr(), _stream_ptr(self.device)),
+                "tvr_app_feature_ref")
+        return feats, extra[:, 3:6], extra[:, 6:7], extra[:, 0:3], extra[:, 7:8]
+
+    def _mlp_render(self, viewdirs, features):
+        raise L.TvrError("REFTensoRF shades with MLPRender_Fea_Ref: call renderModule(pts, reflection, features, dot_product, k)")
+
+    def _mlp_render_ref(self, viewdirs, features, dot_product):
+        sc = self._ensure_scene()
+        v = _f32c(viewdirs, self.device).view(-1, 3)
+        f = _f32c(features, self.device).view(-1, self.app_dim)
+        d = _f32c(dot_product, self.device).view(-1)
+        if d.shape[0] != v.shape[0] or f.shape[0] != v.shape[0]:
+            raise ValueError("viewdirs, features and dot_product must describe the same samples")
+        out = torch.empty((v.shape[0], 3), dtype=torch.float32, device=self.device)
+        L.check(L.lib().tvr_mlp_render_ref(sc, v.data_ptr(), f.data_ptr(), d.data_ptr(), v.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+                "tvr_mlp_render_ref")
+        return out
+
+    @staticmethod
+    def _normalize(x):
+        """jt.normalize(x, dim=-1) (Jittor misc.py: x / sqrt(max(sum x^2, eps)), eps = 1e-30)"""
+        return x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-30))
+
+    def render_rays_autograd(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None):
+        """REFTensoRF.execute with gradients (:174-256); also sets self.penalty (:240-243) for train.py:253-257."""
+        rays = _f32c(rays_chunk, self.device)
+        S = int(N_samples) if N_samples > 0 else self.nSamples
+        eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
+        w, acc, xyz, ray_id, depth, _ = _MarchFn.apply(self, rays, jitter, S, eps_T, None, *self.density_plane, *self.density_line)
+        h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
+        app_features, rgb_d, specular_tint, normal_vector, rho = self._heads(h)
+        normal_vector = self._normalize(normal_vector)                                        # :217
+        d = -rays[ray_id, 3:6]                                                                # :219
+        dot_product = (d * normal_vector).sum(dim=1, keepdim=True)                            # :221-223
+        reflection = 2 * dot_product * normal_vector - d                                      # :225
+        rgb_s = self.renderModule.forward_autograd(reflection, app_features, -dot_product)    # :229
+        rgb = specular_tint * rgb_s.clamp(min=0) + rgb_d                                      # :232
+        penalty = torch.relu(-dot_product).square().squeeze(-1)                               # :237-238
+        self.penalty = torch.sum(w * penalty, -1)                                             # :239
+        rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)
+        if white_bg:
+            rgb_map = rgb_map + (1.0 - acc[:, None])
+        return rgb_map.clamp(0, 1), depth
+
+    def load_arrays(self, arrs):
+        super().load_arrays(arrs)
+        with torch.no_grad():
+            for name, lin in zip(("normal", "diffuse", "specular", "rho"), self._extra_linears()):
+                lin.weight.copy_(torch.as_tensor(arrs[f"{name}_W"]))
+                lin.bias.copy_(torch.as_tensor(arrs[f"{name}_b"]))
+        return self
+
+
+class Embedder(torch.nn.Module):
+    """nerfplusplus.py:7-56 with its defaults (log_sampling, include_input, (sin, cos))."""
+
+    def __init__(self, input_dim, max_freq_log2, N_freqs):
+        super().__init__()
+        self.input_dim = input_dim
+        self.out_dim = input_dim + input_dim * N_freqs * 2
+        self.freq_bands = (2.0 ** torch.linspace(0.0, float(max_freq_log2), N_freqs)).tolist()
+
+    def forward(self, input):
+        out = [input]
+        for freq in self.freq_bands:
+            out += [torch.sin(input * freq), torch.cos(input * freq)]
+        return torch.cat(out, dim=-1)
+
+
+class MLPNet(torch.nn.Module):
+    """nerfplusplus.py:66-140: the NeRF++ background network (library GEMMs; it is not on the TensoRF gather path)."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_viewdirs=3, skips=(4,), use_viewdirs=False):
+        super().__init__()
+        self.input_ch, self.input_ch_viewdirs, self.use_viewdirs, self.skips = input_ch, input_ch_viewdirs, use_viewdirs, list(skips)
+        layers, dim = [], input_ch
+        for i in range(D):
+            layers.append(torch.nn.Sequential(torch.nn.Linear(dim, W), torch.nn.ReLU()))
+            dim = W
+            if i in self.skips and i != (D - 1):
+                dim += input_ch
+        self.base_layers = torch.nn.ModuleList(layers)
+        self.sigma_layers = torch.nn.Sequential(torch.nn.Linear(dim, 1))
+        self.base_remap_layers = torch.nn.Sequential(torch.nn.Linear(dim, 256))
+        self.rgb_layers = torch.nn.Sequential(torch.nn.Linear(256 + input_ch_viewdirs, W // 2), torch.nn.ReLU(), torch.nn.Linear(W // 2, 3),
+                                              torch.nn.Sigmoid())
+
+    def forward(self, input):
+        input_pts = input[..., :self.input_ch]
+        base = self.base_layers[0](input_pts)
+        for i in range(len(self.base_layers) - 1):
+            if i in self.skips:
+                base = torch.cat((input_pts, base), dim=-1)
+            base = self.base_layers[i + 1](base)
+        sigma = torch.abs(self.sigma_layers(base))
+        base_remap = self.base_remap_layers(base)
+        input_viewdirs = input[..., -self.input_ch_viewdirs:]
+        rgb = self.rgb_layers(torch.cat((base_remap, input_viewdirs), dim=-1))
+        return {'rgb': rgb, 'sigma': sigma.squeeze(-1)}
+
+
+class NerfPlusPlus(TensorVMSplit):
+    """models/nerfplusplus.py:143-318 — TensorVMSplit foreground inside a bounding sphere + a NeRF++ inverted-sphere background MLP.
+    The foreground is the fused HIP path with EXPLICIT sample depths (tvr_render_z / tvr_march_*_z): NerfPlusPlus.sample_ray spaces the
+    samples between `near` and the sphere and perturbs every one of them (also at evaluation: the reference's own behaviour).  The
+    background (Embedder + MLPNet over 512 samples per ray) is plain torch.  `rand_fg` / `rand_bg` inject the two jt.rand_like draws."""
+
+    HUGE_NUMBER, TINY_NUMBER, BG_SAMPLES = 1e10, 1e-6, 512                                    # :4-5, :284
+    max_render_chunk = 8192       # rays per merged inference call (renderer): the background holds [rays, 512, <=420] fp32 activations
+
+    def __init__(self, aabb, gridSize, device, **kargs):
+        super().__init__(aabb, gridSize, device, **kargs)
+        self.bg_net = None
+
+    def set_nerfplusplus(self, bg_freq=4, bg_view_freq=2, bg_D=4, radii=20):                  # :147-163
+        self.bg_freq, self.bg_view_freq, self.radii, self.bg_D = bg_freq, bg_view_freq, radii, bg_D
+        self.bg_embedder_position = Embedder(input_dim=4, max_freq_log2=bg_freq - 1, N_freqs=bg_freq)
+        self.bg_embedder_viewdir = Embedder(input_dim=3, max_freq_log2=bg_view_freq - 1, N_freqs=bg_view_freq)
+        self.bg_net = MLPNet(D=bg_D, W=128, skips=[int(bg_D / 2)], input_ch=self.bg_embedder_position.out_dim,
+                             input_ch_viewdirs=self.bg_embedder_viewdir.out_dim, use_viewdirs=True).to(self.device)
+
+    def get_kwargs(self):                                                                     # :165-171
+        kwargs = super().get_kwargs()
+        kwargs.update({'bg_freq': self.bg_freq, 'bg_view_freq': self.bg_view_freq, 'bg_D': self.bg_D, 'radii': self.radii})
+        return kwargs
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):            # :173-176
+        grad_vars = super().get_optparam_groups(lr_init_spatialxyz, lr_init_network)
+        grad_vars += [{'params': self.bg_net.parameters(), 'lr': lr_init_network}]
+        return grad_vars
+
+    def _param_list(self):                      # the bg network is not part of the packed scene
+        return super()._param_list()
+
+    def intersect_sphere(self, ray_o, ray_d, radii):                                          # :178-194
+        d1 = -torch.sum(ray_d * ray_o, dim=-1) / torch.sum(ray_d * ray_d, dim=-1)
+        p = ray_o + d1.unsqueeze(-1) * ray_d
+        ray_d_cos = 1. / torch.norm(ray_d, dim=-1)
+        p_norm_sq = torch.sum(p * p, dim=-1)
+        if (p_norm_sq >= radii).any():
+            raise Exception('Not all your cameras are bounded by the unit sphere; please make sure the cameras are normalized properly!')
+        d2 = torch.sqrt(radii - p_norm_sq) * ray_d_cos
+        return d1 + d2
+
+    def perturb_samples(self, z_vals, t_rand=None):                                           # :196-205
+        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        upper = torch.cat([mids, z_vals[..., -1:]], dim=-1)
+        lower = torch.cat([z_vals[..., 0:1], mids], dim=-1)
+        t_rand = torch.rand_like(z_vals) if t_rand is None else t_rand.to(z_vals)
+        return lower + (upper - lower) * t_rand
+
+    def depth2pts_outside(self, ray_o, ray_d, depth, radii):                                  # :207-237
+        d1 = -torch.sum(ray_d * ray_o, dim=-1) / torch.sum(ray_d * ray_d, dim=-1)
+        p_mid = ray_o + d1.unsqueeze(-1) * ray_d
+        p_mid_norm = torch.norm(p_mid, dim=-1)
+        ray_d_cos = 1. / torch.norm(ray_d, dim=-1)
+        d2 = torch.sqrt(radii * radii - p_mid_norm * p_mid_norm) * ray_d_cos
+        p_sphere = ray_o + (d1 + d2).unsqueeze(-1) * ray_d
+        rot_axis = torch.cross(ray_o, p_sphere, dim=-1)
+        rot_axis = rot_axis / torch.norm(rot_axis, dim=-1, keepdim=True)
+        phi = torch.asin(p_mid_norm / radii)
+        theta = torch.asin(p_mid_norm * depth / (radii * radii))
+        rot_angle = (phi - theta).unsqueeze(-1)
+        p_sphere_new = p_sphere * torch.cos(rot_angle) + torch.cross(rot_axis, p_sphere, dim=-1) * torch.sin(rot_angle) + \
+            rot_axis * torch.sum(rot_axis * p_sphere, dim=-1, keepdim=True) * (1. - torch.cos(rot_angle))
+        pts = torch.cat((p_sphere_new, depth.unsqueeze(-1)), dim=-1)
+        depth_real = radii / (depth + self.TINY_NUMBER) * torch.cos(theta) * ray_d_cos + d1
+        return pts, depth_real
+
+    def _fg_depths(self, rays_o, rays_d, N_samples, t_rand=None):                             # :239-256
+        fg_far_depth = self.intersect_sphere(rays_o, rays_d, radii=self.radii * self.radii)
+        near, far = self.near_far
+        step = (fg_far_depth - near) / (N_samples - 1)
+        fg_depth = torch.stack([near + i * step for i in range(N_samples)], dim=-1)
+        return self.perturb_samples(fg_depth, t_rand).contiguous()
+
+    def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1, t_rand=None):           # :239-269 (host form)
+        N_samples = N_samples if N_samples > 0 else self.nSamples
+        interpx = self._fg_depths(rays_o, rays_d, N_samples, t_rand)
+        rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+        aabb = self.aabb.to(rays_o.device)
+        mask_outbbox = ((aabb[0] > rays_pts) | (rays_pts > aabb[1])).any(dim=-1)
+        return rays_pts, interpx, ~mask_outbbox
+
+    def _render_z(self, rays, z_vals, S, eps_T):
+        sc, lib = self._ensure_scene(), L.lib()
+        n = rays.shape[0]
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        depth = torch.empty((n,), dtype=torch.float32, device=self.device)
+        lam = torch.empty((n,), dtype=torch.float32, device=self.device)
+        scratch = self._get_scratch(lib.tvr_render_scratch_bytes(sc, n, S))
+        L.check(lib.tvr_render_z(sc, rays.data_ptr(), n, S, 0, z_vals.data_ptr(), float(eps_T), rgb.data_ptr(), depth.data_ptr(), lam.data_ptr(),
+                                 scratch.data_ptr(), scratch.numel(), None, None, _stream_ptr(self.device)), "tvr_render_z")
+        return rgb, depth, lam
+
+    def _render_z_autograd(self, rays, z_vals, S, eps_T):
+        w, acc, xyz, ray_id, depth, lam = _MarchFn.apply(self, rays, None, S, eps_T, z_vals, *self.density_plane, *self.density_line)
+        h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
+        rgb = self.renderModule.forward_autograd(rays[ray_id, 3:6], _linear(self.basis_mat, h))
+        rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)
+        return rgb_map.clamp(0, 1), depth, lam                                                # white_bg=False (:276), tensorBase.py:527
+
+    def _background(self, ray_o, ray_d, rand_bg=None):                                        # :280-308
+        n, N = ray_d.shape[0], self.BG_SAMPLES
+        viewdirs = ray_d / torch.norm(ray_d, dim=-1, keepdim=True)
+        bg_z_vals = torch.linspace(0., self.radii, N, device=self.device).view(1, N).expand(n, N)
+        bg_z_vals = self.perturb_samples(bg_z_vals, rand_bg)
+        bg_ray_o = ray_o.unsqueeze(-2).expand(n, N, 3)
+        bg_ray_d = ray_d.unsqueeze(-2).expand(n, N, 3)
+        bg_viewdirs = viewdirs.unsqueeze(-2).expand(n, N, 3)
+        bg_pts, _ = self.depth2pts_outside(bg_ray_o, bg_ray_d, bg_z_vals, radii=self.radii)
+        input = torch.cat((self.bg_embedder_position(bg_pts), self.bg_embedder_viewdir(bg_viewdirs)), dim=-1)
+        input = torch.flip(input, dims=[-2])
+        bg_z_vals = torch.flip(bg_z_vals, dims=[-1])
+        bg_dists = bg_z_vals[..., :-1] - bg_z_vals[..., 1:]
+        bg_dists = torch.cat((bg_dists, self.HUGE_NUMBER * torch.ones_like(bg_dists[..., 0:1])), dim=-1)
+        bg_raw = self.bg_net(input)
+        bg_alpha = 1. - torch.exp(-bg_raw['sigma'] * bg_dists)
+        T = torch.cumprod(1. - bg_alpha + self.TINY_NUMBER, dim=-1)[..., :-1]
+        T = torch.cat((torch.ones_like(T[..., 0:1]), T), dim=-1)
+        bg_weights = bg_alpha * T
+        return torch.sum(bg_weights.unsqueeze(-1) * bg_raw['rgb'], dim=-2)
+
+    def forward(self, rays_chunk, white_bg=False, is_train=False, ndc_ray=False, N_samples=-1, additional_output=True,
+                rand_fg=None, rand_bg=None):                                                  # :272-318
+        if self.bg_net is None:
+            raise L.TvrError("call set_nerfplusplus() first (train.py:45-54 does so right after constructing the model)")
+        if ndc_ray:
+            raise NotImplementedError("ndc_ray=True is outside the accelerated path")
+        rays = _f32c(rays_chunk, self.device)
+        S = int(N_samples) if N_samples > 0 else self.nSamples
+        eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
+        with torch.no_grad():
+            z_vals = self._fg_depths(rays[:, :3], rays[:, 3:6], S, rand_fg)
+        if is_train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            rgb_map, depth_map, bg_lambda = self._render_z_autograd(rays, z_vals, S, eps_T)
+        else:
+            rgb_map, depth_map, bg_lambda = self._render_z(rays, z_vals, S, eps_T)
+        bg_rgb_map = self._background(rays[:, :3], rays[:, 3:6], rand_bg)
+        bg_lambda = torch.where(bg_lambda > 0.1, bg_lambda, torch.zeros_like(bg_lambda))     # :311
+        rgb_map = rgb_map + bg_lambda.unsqueeze(-1) * bg_rgb_map                              # :312-314
+        return rgb_map, depth_map
+
+    execute = forward
+
+    def load_arrays(self, arrs):
+        super().load_arrays(arrs)
+        self.set_nerfplusplus(int(arrs["bg.bg_freq"]), int(arrs["bg.bg_view_freq"]), int(arrs["bg.bg_D"]), float(arrs["bg.radii"]))
+        sd = {k[len("bg_net."):]: torch.as_tensor(v) for k, v in arrs.items() if k.startswith("bg_net.")}
+        self.bg_net.load_state_dict(sd)
+        return self

@@ -134,7 +134,7 @@ def test_fused_adam_updates_reach_the_packed_scene(tiny_arrays, hyper_tiny, tiny
 def test_fused_pe_concat_and_tv_loss_match_torch():
     """tvr_pe_concat / tvr_tv_loss against the torch formulations they replace in the training step (values and gradients)."""
     from jittor_myc_nerfs_amd import TVLoss
-    from jittor_myc_nerfs_amd.field import _mlp_input, _pe
+    from jittor_myc_nerfs_amd.autograd_ops import _mlp_input, _pe
     g = torch.Generator(device="cuda").manual_seed(5)
     for with_dot in (False, True):
         f = (torch.randn((5003, 27), device="cuda", generator=g) * 3).requires_grad_(True)
