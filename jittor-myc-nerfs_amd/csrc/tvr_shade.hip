@@ -104,9 +104,11 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 {
     const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
     // x - hi as fma(hi, -1, x): one v_fma_mix_f32 reading the packed half in place (exact: the product by -1 is exact); hipcc
-    // does not select the mixed-precision form by itself (it emits v_cvt_f32_f16 + v_sub), hence the asm.  (v_fma_mixlo/mixhi_f16
-    // would fuse the final conversion too — 3 ops per pair — but their partial-register writes from inline asm, which the
-    // compiler's MFMA hazard recogniser cannot see, rendered non-reproducibly, and 15 % fewer VALU ops bought no time: measured.)
+    // does not select the mixed-precision form by itself (it emits v_cvt_f32_f16 + v_sub), hence the asm.  Its results feed the
+    // compiler-visible v_cvt_pkrtz below, never an MFMA directly: VALU-write -> MFMA-read needs software wait states on gfx950
+    // (scripts/hwprobe/mfma_raw.hip) and the compiler cannot pad inline asm.  (v_fma_mixlo/mixhi_f16 would fuse the final conversion
+    // too — 3 ops per pair — but then asm results ARE the MFMA operands: that variant rendered non-reproducibly, and 15 % fewer VALU
+    // ops bought no time anyway: measured.)
     const unsigned hb = __builtin_bit_cast(unsigned, h);
     float ra, rb;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
