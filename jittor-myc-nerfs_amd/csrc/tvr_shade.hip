@@ -696,7 +696,9 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             for (int cb = 0; cb < SH_NCB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (TVR_HWSIN) sincos_hw(F[cb][r], S1[cb][r], C1[cb][r]);
+                    // hardware sin / cos while |v| is moderate (their error is the fp32 reduction to revolutions, |v| * 6e-8 rad);
+                    // a wave in which any lane holds a large value takes the Cody-Waite polynomial for that base row
+                    if (TVR_HWSIN && __ballot(fabsf(F[cb][r]) > 256.0f) == 0ull) sincos_hw(F[cb][r], S1[cb][r], C1[cb][r]);
                     else sincos_fast(F[cb][r], S1[cb][r], C1[cb][r]);
                 }
             // the hidden layers (240 of the tile's 267 MFMAs) run under the SIMD pair's token; gather, basis product and the

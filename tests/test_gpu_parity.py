@@ -343,3 +343,23 @@ def test_march_launch_shapes(hyper_tiny, grid, S):
     out, _ = m.render_rays_autograd(rays.cuda(), white_bg=True, N_samples=S)
     out.sum().backward()
     assert np.abs(_np(out) - ref["rgb_map"]).max() < 3e-4 and bool(torch.isfinite(m.density_line[0].grad).all())
+
+
+@pytest.mark.parametrize("scale", [20.0, 200.0, 1000.0])
+def test_large_feature_magnitudes(tiny_dump, tiny_arrays, hyper_tiny, scale):
+    """The positional encoding takes sin / cos of the appearance features; the kernel evaluates them with v_sin_f32 / v_cos_f32 after an
+    fp32 reduction to revolutions, whose error grows like |v| * 6e-8 rad.  Features 20x and 200x larger than the synthetic scene's
+    (|v| up to ~1100) must still render within the parity bar; beyond |v| = 256 the kernel switches to its Cody-Waite polynomial.  (At |v| in
+    the thousands sin(v) is ill-conditioned for ANY fp32 evaluation: the features' own rounding, 1e-7 relative, is already 1e-3 rad.)"""
+    from oracle import tensorf_oracle as TO
+    arrs = dict(tiny_arrays)
+    arrs["basis_mat"] = tiny_arrays["basis_mat"] * np.float32(scale)
+    sc = TO.scene_from_arrays(arrs, **hyper_tiny)
+    d = TO.execute(sc, torch.tensor(tiny_dump["rays"]), white_bg=True, N_samples=TINY["N_samples"], dump=True)
+    fmax = float(TO.compute_appfeature(sc, d["xyz_norm"][d["app_mask"]]).abs().max())
+    m = make_model(arrs, hyper_tiny)
+    rgb, depth, dd = m.render_rays(torch.tensor(tiny_dump["rays"], device="cuda"), white_bg=True, N_samples=TINY["N_samples"], eps_T=0.0, dense=True)
+    e_s = np.abs(_np(dd["rgb"]) - d["rgb"].numpy()).max()
+    e_m = np.abs(_np(rgb) - d["rgb_map"].numpy()).max()
+    print(f"basis x{scale:g}: max |feature| {fmax:.0f}, per-sample rgb Linf {e_s:.2e}, rgb_map Linf {e_m:.2e}")
+    assert e_m < RGB_TOL and e_s < RGB_TOL
