@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 104
+#define TVR_VERSION 105
 
 typedef enum {
     TVR_OK = 0,
@@ -100,9 +100,12 @@ const char *tvr_last_error(void);
 size_t tvr_scene_packed_bytes(const tvr_scene_desc *desc);
 int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed_bytes, tvr_scene **out);
 int tvr_scene_update(tvr_scene *scene, const tvr_scene_params *params, void *stream);
-/* AlphaGridMask (tensorBase.py:39-59): volume (gz,gy,gx) fp32 in device memory, kept by reference; NULL clears. */
+/* AlphaGridMask (tensorBase.py:39-59): volume (gz,gy,gx) fp32 (non-negative) in device memory, kept by reference; NULL clears.
+ * bits (optional, tvr_alpha_bits_bytes() of device memory, kept by reference): the march then tests `sample_alpha(p) > 0` (:491-496) on a
+ * bit volume built here from the float one — same result, 1/32 of the footprint; NULL keeps the 8-tap float lookup. */
+size_t tvr_alpha_bits_bytes(const int32_t agrid_xyz[3]);
 int tvr_scene_set_alpha(tvr_scene *scene, const float *alpha_volume_dev, const int32_t agrid_xyz[3],
-                        const float alpha_aabb[6], const float alpha_inv_size[3]);
+                        const float alpha_aabb[6], const float alpha_inv_size[3], void *bits, size_t bits_bytes, void *stream);
 int tvr_scene_destroy(tvr_scene *scene);
 
 /* TensorBase.execute over a ray batch (tensorBase.py:476-536, ndc_ray=False; variant 1: REFTensoRF.execute,

@@ -47,8 +47,9 @@ SYMBOLS = {
     "tvr_scene_packed_bytes": (C.c_size_t, [C.POINTER(SceneDesc)]),
     "tvr_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "tvr_scene_update": (C.c_int, [C.c_void_p, C.POINTER(SceneParams), C.c_void_p]),
+    "tvr_alpha_bits_bytes": (C.c_size_t, [C.POINTER(C.c_int32 * 3)]),
     "tvr_scene_set_alpha": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_float * 6),
-                                      C.POINTER(C.c_float * 3)]),
+                                      C.POINTER(C.c_float * 3), C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_scene_destroy": (C.c_int, [C.c_void_p]),
     "tvr_render_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "tvr_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float,

@@ -174,10 +174,17 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
     return TVR_OK;
 }
 
-int tvr_scene_set_alpha(tvr_scene *s, const float *vol, const int32_t ag[3], const float aabb[6], const float inv[3])
+size_t tvr_alpha_bits_bytes(const int32_t ag[3])
+{
+    if (!ag || ag[0] < 1 || ag[1] < 1 || ag[2] < 1) return 0;
+    return (size_t)(((long long)ag[0] * ag[1] * ag[2] + 31) / 32) * 4;
+}
+
+int tvr_scene_set_alpha(tvr_scene *s, const float *vol, const int32_t ag[3], const float aabb[6], const float inv[3], void *bits, size_t bits_bytes,
+                        void *stream)
 {
     if (!s) return fail(TVR_ERR_INVALID, "scene is NULL");
-    if (!vol) { s->dev.avol = nullptr; return TVR_OK; }
+    if (!vol) { s->dev.avol = nullptr; s->dev.abits = nullptr; return TVR_OK; }
     if (!ag || !aabb || !inv) return fail(TVR_ERR_INVALID, "alpha grid/aabb/inv is NULL");
     for (int k = 0; k < 3; ++k) {
         if (ag[k] < 1) return fail(TVR_ERR_INVALID, "alpha grid[%d]=%d", k, ag[k]);
@@ -187,6 +194,12 @@ int tvr_scene_set_alpha(tvr_scene *s, const float *vol, const int32_t ag[3], con
         s->dev.agm1[k] = (float)(ag[k] - 1);
     }
     s->dev.avol = vol;
+    s->dev.abits = nullptr;
+    if (bits) {
+        if (bits_bytes < tvr_alpha_bits_bytes(ag) || (uintptr_t)bits % 4) return fail(TVR_ERR_SCRATCH, "alpha bit buffer too small or misaligned");
+        HIP_TRY(launch_alpha_bits(vol, (long long)ag[0] * ag[1] * ag[2], (unsigned *)bits, (hipStream_t)stream));
+        s->dev.abits = (const unsigned *)bits;
+    }
     return TVR_OK;
 }
 

@@ -73,3 +73,4 @@ hipError_t launch_pe_concat(const float *feat, const float *dir, const float *do
 hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const float *gX, long long m, int with_dot, float *gfeat, float *gdir,
                                      float *gdot, hipStream_t stream);
 hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, float *value, float *grad, float *part, hipStream_t stream);
+hipError_t launch_alpha_bits(const float *vol, long long n, unsigned *bits, hipStream_t stream);

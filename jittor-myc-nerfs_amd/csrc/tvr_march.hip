@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
             }
             bool valid = bbox;
             if (sc.avol != nullptr) {
-                if (bbox) valid = alpha_lookup(sc, p) > 0.0f;  // :491-496
+                if (bbox) valid = sc.abits ? alpha_positive(sc, p) : (alpha_lookup(sc, p) > 0.0f);  // :491-496
             }
             int i0[3];
             float w[3];
@@ -412,6 +412,26 @@ __global__ __launch_bounds__(256) void alpha_sample_kernel(const SceneDev sc, co
     if (s >= m) return;
     const float p[3] = {xyz[s * 3], xyz[s * 3 + 1], xyz[s * 3 + 2]};
     out[s] = alpha_lookup(sc, p);
+}
+
+// alpha volume -> bit volume (one thread per 32-voxel word)
+__global__ __launch_bounds__(256) void alpha_bits_kernel(const float *__restrict__ vol, const long long n, unsigned *__restrict__ bits)
+{
+    const long long wd = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wd * 32 >= n) return;
+    unsigned v = 0u;
+    for (int b = 0; b < 32; ++b) {
+        const long long i = wd * 32 + b;
+        if (i < n && vol[i] > 0.0f) v |= 1u << b;
+    }
+    bits[wd] = v;
+}
+
+hipError_t launch_alpha_bits(const float *vol, long long n, unsigned *bits, hipStream_t stream)
+{
+    const long long words = (n + 31) / 32;
+    hipLaunchKernelGGL(alpha_bits_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, vol, n, bits);
+    return hipGetLastError();
 }
 
 // ---- host launchers ----

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
             }
             bool valid = bbox;
             if (sc.avol != nullptr) {
-                if (bbox) valid = alpha_lookup(sc, p) > 0.0f;
+                if (bbox) valid = sc.abits ? alpha_positive(sc, p) : (alpha_lookup(sc, p) > 0.0f);
             }
             int i0[3];
             float w[3];

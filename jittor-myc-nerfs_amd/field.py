@@ -296,11 +296,13 @@ class TensorBase(torch.nn.Module):
         if self._alpha_dirty:
             am = self._alphaMask
             if am is None:
-                L.check(lib.tvr_scene_set_alpha(self._scene, None, None, None, None), "tvr_scene_set_alpha")
+                L.check(lib.tvr_scene_set_alpha(self._scene, None, None, None, None, None, 0, None), "tvr_scene_set_alpha")
+                self._alpha_bits = None
             else:
                 ag, ab, inv = am._c_args()
-                L.check(lib.tvr_scene_set_alpha(self._scene, am.alpha_volume.data_ptr(), C.byref(ag), C.byref(ab), C.byref(inv)),
-                        "tvr_scene_set_alpha")
+                self._alpha_bits = torch.empty(lib.tvr_alpha_bits_bytes(C.byref(ag)), dtype=torch.uint8, device=self.device)
+                L.check(lib.tvr_scene_set_alpha(self._scene, am.alpha_volume.data_ptr(), C.byref(ag), C.byref(ab), C.byref(inv),
+                                                self._alpha_bits.data_ptr(), self._alpha_bits.numel(), _stream_ptr(self.device)), "tvr_scene_set_alpha")
             self._alpha_dirty = False
         return self._scene
 
