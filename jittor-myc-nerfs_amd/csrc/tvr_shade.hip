@@ -17,7 +17,7 @@
 //   L3       rgb^T[32(3) x 32e] = W3 · H2^T, sigmoid, 3 floats written back into the entry's queue slot
 // Arithmetic: v_mfma_f32_32x32x16_f16 with every fp32 operand split into fp16 hi + lo and three products per step
 // (hi·hi + hi·lo + lo·hi, fp32 accumulate): ~2^-22 relative error per product — fp32-class accuracy at 16/3 the rate of
-// the fp32-input MFMA.  Biases are the initial accumulators.
+// the fp32-input MFMA.  b1 rides in W1's image as the column of a constant-1 input (base row 31); b2, b3 are the initial accumulators.
 #include "tvr_device.h"
 #include "tvr_kernels.h"
 
@@ -52,7 +52,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #ifndef TVR_HWSIN
 #define TVR_HWSIN 1       // positional encoding by v_sin_f32 / v_cos_f32 (4 instructions per value instead of ~25 for the polynomial
-                          // sincos_fast): shade 15.2 -> 14.4 ms, RGB error against the oracle unchanged (scripts/accuracy_report.py)
+                          // sincos_fast, which still serves |v| > 256): shade 15.2 -> 14.2 ms, RGB error against the oracle unchanged (scripts/accuracy_report.py)
 #endif
 #ifndef TVR_QPF
 #define TVR_QPF 0         // 1: prefetch the next tile's queue positions one tile ahead (measured: no gain, 15.3 vs 15.0-15.3 ms; +6 VGPRs)
@@ -76,13 +76,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef TVR_COAL
 #define TVR_COAL 0        // 1: coalesced gather (4 lanes per 64-B segment + v_permlane16_swap): halves the L1 tag lookups of the
 #endif                    //    gather but measured slower (17.8 vs 16.1 ms) — the kernel is not L1-lookup-bound, the swaps cost VALU
-// gfx950 / ROCm 7.2 hazard (measured): with two MFMA-issuing waves per SIMD an MFMA can sit queued behind
-// the partner wave's MFMAs and read its A/B VGPRs late; a *global* load issued behind it into those registers (the register
-// allocator reuses them) lands first and corrupts the operands one 16-lane quarter at a time (16 queue entries wrong by ~1e-2,
-// different ones each run).  LDS loads that reuse MFMA source registers showed no such effect.  The kernel is therefore phased
-// per tile: a GATHER phase (global loads + VALU, no MFMA) and a MATRIX phase (MFMA + LDS + VALU, no global load: the basis
-// fragments are fetched before its first MFMA), and the epilogue's read of the last accumulator drains the wave's MFMAs before
-// the next tile's loads.  SH_WAVES = 8 gives two waves per SIMD (one gathers while the other multiplies).
+// Phase rule (empirical): an earlier version of this kernel that issued global loads between the MFMAs of a tile, with
+// two MFMA-issuing waves per SIMD, returned 16 queue entries wrong by ~1e-2, different ones each run; one wave per SIMD was clean.  The
+// kernel is therefore phased per tile: a GATHER phase (global loads + VALU, no MFMA) and a MATRIX phase (MFMA + LDS + VALU, no global
+// load: the basis fragments are fetched before its first MFMA), and the epilogue's read of the last accumulator drains the wave's
+// MFMAs before the next tile's loads.  A stand-alone probe of "global load into the operand registers of just-issued MFMAs" does NOT
+// reproduce the corruption (scripts/hwprobe/mfma_war.hip), so the root cause is unconfirmed and the rule is kept as validated practice
+// (bit-reproducibility tests); what IS confirmed is that a VALU write directly in front of an MFMA reading it needs software wait
+// states (scripts/hwprobe/mfma_raw.hip) — never feed an MFMA from inline asm.  SH_WAVES = 8 gives two waves per SIMD.
 #ifndef SH_WAVES
 #define SH_WAVES 8
 #endif
