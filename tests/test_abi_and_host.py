@@ -219,6 +219,53 @@ def test_npp_host_logic_on_cpu(tiny_npp, tiny_npp_arrays, hyper_tiny):
         m2(rays)                                                       # set_nerfplusplus() not called
 
 
+def test_config_parser_reads_the_reference_config_format(tmp_path):
+    """opt.py's options over a configs/Scar.txt-style file (written here: `key = value`, `[..]` lists, comments, booleans), command line on top."""
+    from jittor_myc_nerfs_amd.reconstruct import SimpleSampler, config_parser
+    cfg = tmp_path / "Scene.txt"
+    cfg.write_text("""
+dataset_name = blender
+datadir = ../data/Scene
+expname =  Scene
+basedir = ./log
+
+normal_vector_penalty_weight = 0.5
+bbox = [-5.0, -5.0, -5.0, 5.0, 5.0, 5.0]
+near = 5
+far = 40
+white_bkgd=True
+
+n_iters = 400000
+batch_size = 4096
+N_voxel_init = 2097156 # 128**3
+N_voxel_final = 27000000 # 300**3
+upsamp_list = [2000,3000,4000,5500,7000]
+update_AlphaMask_list = [2000,4000]
+n_lamb_sigma = [16,16,16]
+n_lamb_sh = [48,48,48]
+model_name = REFTensoRF
+shadingMode = MLP_Fea
+fea2denseAct = softplus
+view_pe = 2
+fea_pe = 2
+TV_weight_density = 2.
+# L1_weight_inital = 1e-5
+rm_weight_mask_thre = 1e-6
+""")
+    a = config_parser(["--config", str(cfg), "--n_iters", "100", "--render_test", "1"])
+    assert a.model_name == "REFTensoRF" and a.shadingMode == "MLP_Fea" and a.white_bkgd is True and a.expname == "Scene"
+    assert a.bbox == [-5.0, -5.0, -5.0, 5.0, 5.0, 5.0] and a.near == 5.0 and a.far == 40.0 and a.normal_vector_penalty_weight == 0.5
+    assert a.n_lamb_sigma == [16, 16, 16] and a.n_lamb_sh == [48, 48, 48] and a.upsamp_list == [2000, 3000, 4000, 5500, 7000]
+    assert a.N_voxel_init == 2097156 and a.N_voxel_final == 27000000 and a.TV_weight_density == 2.0 and a.L1_weight_inital == 0.0
+    assert a.n_iters == 100 and a.render_test == 1 and a.batch_size == 4096 and a.rm_weight_mask_thre == 1e-6       # command line wins
+    d = config_parser([])
+    assert d.model_name == "TensorVMSplit" and d.nSamples == 1e6 and d.N_voxel_final == 300 ** 3 and d.lr_init == 0.02 and d.white_bkgd is False
+    s = SimpleSampler(10, 4)
+    torch.manual_seed(0)
+    ids = torch.cat([s.nextids() for _ in range(4)])
+    assert ids.numel() == 16 and set(ids[:8].tolist()) <= set(range(10)) and len(set(ids[:8].tolist())) == 8       # two batches of one permutation
+
+
 def test_grid_sizing_helpers_match_survey_appendix_c():
     from jittor_myc_nerfs_amd import N_to_reso, cal_n_samples
     assert N_to_reso(2097156, ([-5.0] * 3, [5.0] * 3)) == [128, 128, 128]

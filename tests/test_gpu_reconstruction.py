@@ -87,3 +87,72 @@ def test_reconstruction_schedule(tmp_path, hyper_tiny):
         a, _ = m(test_rays, is_train=False, white_bg=True, N_samples=nSamples)
         b, _ = m2(test_rays, is_train=False, white_bg=True, N_samples=nSamples)
     assert torch.equal(a, b)
+
+
+def test_reconstruct_driver_on_a_blender_format_dataset(tmp_path, hyper_tiny):
+    """`reconstruct.reconstruction` / `render_test` (train.py:113-371, 62-110) from a config file over a Blender-format dataset on disk
+    (transforms_{train,test}.json + PNGs written here from a teacher scene): trains, checkpoints, evaluates, re-renders from the checkpoint."""
+    import json
+    import os
+    from PIL import Image
+    from jittor_myc_nerfs_amd import rays as R, synthetic
+    from jittor_myc_nerfs_amd.reconstruct import config_parser, reconstruction, render_test
+    teacher = make_model(synthetic.make_scene_arrays([40, 40, 40], TINY["aabb"], seed=3), hyper_tiny)
+    wh = 24
+    for split, n in (("train", 14), ("test", 3)):
+        poses = R.sphere_poses(n, 4.0) if split == "train" else R.sphere_poses(9, 4.0)[1::3]
+        os.makedirs(tmp_path / "data" / split, exist_ok=True)
+        meta = {"camera_angle_x": 0.6911, "frames": []}
+        for i, M in enumerate(poses):
+            with torch.no_grad():
+                rgb, _ = teacher(R.frame_rays(M, wh, wh, 0.6911).cuda(), is_train=False, white_bg=True, N_samples=96)
+            img = (rgb.clamp(0, 1).cpu().numpy().reshape(wh, wh, 3) * 255 + 0.5).astype(np.uint8)
+            Image.fromarray(img).save(tmp_path / "data" / split / f"r_{i}.png")
+            meta["frames"].append({"file_path": f"./{split}/r_{i}", "transform_matrix": np.asarray(M).tolist()})
+        with open(tmp_path / "data" / f"transforms_{split}.json", "w") as f:
+            json.dump(meta, f)
+    cfg = tmp_path / "tiny.txt"
+    a = TINY["aabb"]
+    cfg.write_text(f"""
+dataset_name = blender
+datadir = {tmp_path / 'data'}
+expname = tiny
+basedir = {tmp_path / 'log'}
+bbox = [{a[0][0]}, {a[0][1]}, {a[0][2]}, {a[1][0]}, {a[1][1]}, {a[1][2]}]
+near = 2.0
+far = 6.0
+white_bkgd=True
+downsample_train = {800 / wh}
+n_iters = 100
+batch_size = 1024
+N_voxel_init = 4096 # 16**3
+N_voxel_final = 32768 # 32**3
+upsamp_list = [35,60]
+update_AlphaMask_list = [30,55]
+N_vis = 2
+vis_every = 50
+progress_refresh_rate = 25
+render_test = 1
+n_lamb_sigma = [16,16,16]
+n_lamb_sh = [48,48,48]
+model_name = TensorVMSplit
+shadingMode = MLP_Fea
+fea2denseAct = softplus
+view_pe = 2
+fea_pe = 2
+TV_weight_density = 0.1
+TV_weight_app = 0.01
+L1_weight_inital = 8e-5
+L1_weight_rest = 4e-5
+""")
+    args = config_parser(["--config", str(cfg)])
+    lines = []
+    tensorf, logfolder, psnrs = reconstruction(args, log=lines.append)
+    print("\n".join(lines[-3:]))
+    assert os.path.exists(f"{logfolder}/tiny.th") and os.path.exists(f"{logfolder}/imgs_test_all/tiny_r_0.png")
+    assert len(psnrs) == 3 and float(np.mean(psnrs)) > 20.0, psnrs
+    assert os.path.exists(f"{logfolder}/imgs_vis/000049_000.png") or len(os.listdir(f"{logfolder}/imgs_vis")) > 0
+    # render_only from the checkpoint reproduces the test images' PSNR
+    args2 = config_parser(["--config", str(cfg), "--ckpt", f"{logfolder}/tiny.th", "--render_only", "1", "--render_test", "1"])
+    out = render_test(args2)
+    assert np.allclose(out["test"], psnrs, atol=1e-4)
