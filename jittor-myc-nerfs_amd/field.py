@@ -418,6 +418,9 @@ class TensorBase(torch.nn.Module):
         alpha = (alpha >= self.alphaMask_thres).float()                                       # :395-396
         self.alphaMask = AlphaGridMask(self.device, self.aabb, alpha)
         valid_xyz = dense_xyz[alpha > 0.5]
+        if valid_xyz.shape[0] == 0:                # the reference fails here with an empty-reduction error (tensorBase.py:400-404)
+            raise RuntimeError("updateAlphaMask: no voxel reaches alphaMask_thres — the density field is still empty; update the mask later "
+                               "in the schedule (update_AlphaMask_list)")
         new_aabb = torch.stack((valid_xyz.amin(0), valid_xyz.amax(0)))
         return new_aabb
 

@@ -89,9 +89,12 @@ def test_reconstruction_schedule(tmp_path, hyper_tiny):
     assert torch.equal(a, b)
 
 
-def test_reconstruct_driver_on_a_blender_format_dataset(tmp_path, hyper_tiny):
+@pytest.mark.parametrize("model_name,min_psnr", [("TensorVMSplit", 20.0), ("REFTensoRF", 20.0), ("NerfPlusPlus", 15.0)])
+def test_reconstruct_driver_on_a_blender_format_dataset(tmp_path, hyper_tiny, model_name, min_psnr):
     """`reconstruct.reconstruction` / `render_test` (train.py:113-371, 62-110) from a config file over a Blender-format dataset on disk
-    (transforms_{train,test}.json + PNGs written here from a teacher scene): trains, checkpoints, evaluates, re-renders from the checkpoint."""
+    (transforms_{train,test}.json + PNGs written here from a teacher scene): trains, checkpoints, evaluates, re-renders from the checkpoint.
+    (NerfPlusPlus runs without alpha-mask updates: its background network can carry the whole image, so the foreground density of this tiny
+    scene may still be empty when the mask would be built — the reference's updateAlphaMask fails on an empty field just the same.)"""
     import json
     import os
     from PIL import Image
@@ -123,19 +126,21 @@ near = 2.0
 far = 6.0
 white_bkgd=True
 downsample_train = {800 / wh}
-n_iters = 100
+n_iters = 130
 batch_size = 1024
 N_voxel_init = 4096 # 16**3
 N_voxel_final = 32768 # 32**3
-upsamp_list = [35,60]
-update_AlphaMask_list = [30,55]
+upsamp_list = [55,90]
+{"" if model_name == "NerfPlusPlus" else "update_AlphaMask_list = [50,85]"}
 N_vis = 2
-vis_every = 50
+vis_every = 60
 progress_refresh_rate = 25
 render_test = 1
 n_lamb_sigma = [16,16,16]
 n_lamb_sh = [48,48,48]
-model_name = TensorVMSplit
+model_name = {model_name}
+normal_vector_penalty_weight = {1e-4 if model_name == "REFTensoRF" else 0.0}
+radii = 6
 shadingMode = MLP_Fea
 fea2denseAct = softplus
 view_pe = 2
@@ -150,9 +155,13 @@ L1_weight_rest = 4e-5
     tensorf, logfolder, psnrs = reconstruction(args, log=lines.append)
     print("\n".join(lines[-3:]))
     assert os.path.exists(f"{logfolder}/tiny.th") and os.path.exists(f"{logfolder}/imgs_test_all/tiny_r_0.png")
-    assert len(psnrs) == 3 and float(np.mean(psnrs)) > 20.0, psnrs
-    assert os.path.exists(f"{logfolder}/imgs_vis/000049_000.png") or len(os.listdir(f"{logfolder}/imgs_vis")) > 0
+    assert type(tensorf).__name__ == model_name
+    assert len(psnrs) == 3 and float(np.mean(psnrs)) > min_psnr, psnrs
+    assert len(os.listdir(f"{logfolder}/imgs_vis")) > 0
     # render_only from the checkpoint reproduces the test images' PSNR
     args2 = config_parser(["--config", str(cfg), "--ckpt", f"{logfolder}/tiny.th", "--render_only", "1", "--render_test", "1"])
     out = render_test(args2)
-    assert np.allclose(out["test"], psnrs, atol=1e-4)
+    if model_name != "NerfPlusPlus":                       # NerfPlusPlus perturbs its samples at evaluation too (fresh random draws)
+        assert np.allclose(out["test"], psnrs, atol=1e-4)
+    else:
+        assert abs(np.mean(out["test"]) - np.mean(psnrs)) < 1.0
