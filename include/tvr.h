@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 105
+#define TVR_VERSION 106
 
 typedef enum {
     TVR_OK = 0,

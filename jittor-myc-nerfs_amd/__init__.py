@@ -9,4 +9,4 @@ from .render import OctreeRender_trilinear_fast, N_to_reso, cal_n_samples, rende
 from .evaluation import BlenderRays, evaluation, evaluation_path, rgb_ssim  # noqa: F401
 from .losses import TVLoss  # noqa: F401
 from .training import GradBucket, shard_batch  # noqa: F401
-from . import rays, synthetic  # noqa: F401
+from . import ngp, rays, synthetic  # noqa: F401

@@ -40,7 +40,20 @@ class DenseOut(C.Structure):
                                           "weight", "rgb", "bg_weight", "acc", "t_min")]
 
 
-# name -> (restype, argtypes); every symbol include/tvr.h declares
+class NgpMarchCfg(C.Structure):          # tvr_ngp_march_cfg (include/tvr_ngp.h)
+    _fields_ = [("aabb_lo", C.c_float * 3), ("aabb_hi", C.c_float * 3), ("near_distance", C.c_float), ("cone_angle", C.c_float),
+                ("const_dt", C.c_int32), ("rng_state", C.c_uint64), ("rng_inc", C.c_uint64), ("slab_rays", C.c_uint32)]
+
+
+class NgpGridCfg(C.Structure):           # tvr_ngp_grid_cfg
+    _fields_ = [("offsets", C.c_uint32 * 17), ("scale", C.c_float * 16)]
+
+
+class NgpNetParams(C.Structure):         # tvr_ngp_net_params
+    _fields_ = [(n, C.c_void_p) for n in ("density0", "density1", "rgb0", "rgb1", "rgb2")]
+
+
+# name -> (restype, argtypes); every symbol include/tvr.h and include/tvr_ngp.h declare
 SYMBOLS = {
     "tvr_version": (C.c_int, []),
     "tvr_last_error": (C.c_char_p, []),
@@ -86,6 +99,18 @@ SYMBOLS = {
     "tvr_profile_reset": (C.c_int, [C.c_void_p]),
     "tvr_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3)]),
     "tvr_profile_destroy": (C.c_int, [C.c_void_p]),
+    # include/tvr_ngp.h
+    "tvr_ngp_update_bitfield": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_ngp_sample_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "tvr_ngp_sample": (C.c_int, [C.POINTER(NgpMarchCfg), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_ngp_hash_encode": (C.c_int, [C.POINTER(NgpGridCfg), C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_ngp_sh_encode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_ngp_net_packed_bytes": (C.c_size_t, []),
+    "tvr_ngp_net_pack": (C.c_int, [C.POINTER(NgpNetParams), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_ngp_network": (C.c_int, [C.POINTER(NgpGridCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "tvr_ngp_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float * 3), C.c_void_p, C.c_void_p]),
 }
 
 STAT_SAMPLES_EVAL, STAT_SAMPLES_BBOX, STAT_APP, STAT_RAYS_TERMINATED, STAT_COUNT = 0, 1, 2, 3, 8

@@ -11,7 +11,7 @@
 
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int tvr_set_error(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -19,6 +19,7 @@ static int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+#define fail tvr_set_error
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \

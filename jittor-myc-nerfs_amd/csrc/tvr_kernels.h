@@ -5,6 +5,9 @@
 
 struct SceneDev;
 
+// records the text tvr_last_error() returns (thread-local) and hands `code` back; defined in tvr_api.hip
+int tvr_set_error(int code, const char *fmt, ...);
+
 // Outputs of the march kernel / inputs of shade + composite.  The "queue" holds one entry per appearance sample
 // (weight > thres); each ray's entries are contiguous and in sample order.
 struct MarchOut {

@@ -109,3 +109,60 @@ SCENE_B = dict(gridSize=[128, 128, 128], aabb=[[-5.0] * 3, [5.0] * 3], near_far=
                cam_radius=13.0, camera_angle_x=0.6911, N_samples=192, img_wh=(64, 64))
 HYPER = dict(density_shift=-10.0, distance_scale=25.0, rayMarch_weight_thres=1e-4, fea2denseAct="softplus",
              view_pe=2, fea_pe=2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Alt path (BASELINE configs[4]): a seeded Instant-NGP scene in JNeRF's layout
+def _expand_bits(v: np.ndarray) -> np.ndarray:
+    v = v.astype(np.uint32)
+    v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+    v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+    v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+    v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+    return v
+
+
+def morton3d(x, y, z) -> np.ndarray:
+    """Morton code of integer cell coordinates < 1024 (the order JNeRF keeps its 128^3 density grid in)."""
+    with np.errstate(over="ignore"):
+        return _expand_bits(x) | (_expand_bits(y) << np.uint32(1)) | (_expand_bits(z) << np.uint32(2))
+
+
+def make_ngp_scene_arrays(level_offsets: Sequence[int], seed: int = SEED, shell=(0.12, 0.30), speckle: float = 0.02,
+                          density_gain: float = 24.0) -> Dict[str, np.ndarray]:
+    """fp32 arrays keyed like JNeRF's state dicts (`NGPNetworks` / `HashEncoder` / `DensityGridSampler`):
+    `grid` (= pos_encoder.m_grid, level-major, 2 features per entry; level_offsets[-1] entries), the five bias-free Linear weights,
+    and `density_grid` [5*128^3] (Morton order per cascade).  The reference's initialisation (grid U(+-1e-4)) renders nothing,
+    so: grid U(-1,1); Linear weights U(+-sqrt(6/(fan_in+fan_out))), the density head scaled by `density_gain` so that raw
+    densities spread over several e-folds; occupancy = a hollow ball around the scene centre (0.5,0.5,0.5), radii `shell` in
+    unit-cube units, plus a `speckle` fraction of random cells inside radius 0.45 (cascade 0; coarser cascades carry the same
+    geometry at their own cell size)."""
+    rng = np.random.default_rng(seed + 5)
+    out: Dict[str, np.ndarray] = {}
+    out["grid"] = rng.uniform(-1.0, 1.0, size=int(level_offsets[-1]) * 2).astype(np.float32)
+
+    def U(n_out, n_in, gain=1.0):
+        b = np.sqrt(6.0 / (n_in + n_out))
+        return (rng.uniform(-b, b, size=(n_out, n_in)) * gain).astype(np.float32)
+    out["density_mlp.0.weight"] = U(64, 32)
+    out["density_mlp.2.weight"] = U(16, 64, density_gain)
+    out["rgb_mlp.0.weight"] = U(64, 32, 0.25)
+    out["rgb_mlp.2.weight"] = U(64, 64)
+    out["rgb_mlp.4.weight"] = U(3, 64, 4.0)
+    G = 128
+    ax = np.arange(G, dtype=np.uint32)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    code = morton3d(X, Y, Z).reshape(-1)
+    dg = np.zeros(5 * G ** 3, np.float32)
+    for c in range(5):
+        size = float(1 << c)
+        ctr = [(A.astype(np.float32) + 0.5) / G * size + (0.5 - size / 2) for A in (X, Y, Z)]
+        r = np.sqrt((ctr[0] - 0.5) ** 2 + (ctr[1] - 0.5) ** 2 + (ctr[2] - 0.5) ** 2).reshape(-1)
+        occ = (r >= shell[0]) & (r <= shell[1])
+        if c == 0 and speckle > 0:
+            occ |= (r < 0.45) & (rng.random(G ** 3) < speckle)
+        lvl = np.zeros(G ** 3, np.float32)
+        lvl[code] = occ.astype(np.float32)
+        dg[c * G ** 3:(c + 1) * G ** 3] = lvl
+    out["density_grid"] = dg
+    return out

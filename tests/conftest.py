@@ -97,3 +97,37 @@ def make_model(arrs, hyper, device="cuda", gridSize=None, aabb=None):
                       step_ratio=hyper["step_ratio"], fea2denseAct=hyper["fea2denseAct"])
     m.load_arrays(arrs)
     return m
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# alt path: seeded Instant-NGP scene shared by the oracle tests and the GPU parity tests
+NGP_AABB_SCALE = 4
+
+
+@pytest.fixture(scope="session")
+def ngp_scene():
+    """(levels, arrays): synthetic.make_ngp_scene_arrays at aabb_scale 4 plus the oracle's bitfield of its density grid."""
+    from jittor_myc_nerfs_amd import synthetic
+    from oracle import ngp_oracle as N
+    levels = N.grid_levels(NGP_AABB_SCALE)
+    arrs = synthetic.make_ngp_scene_arrays(levels["offsets"])
+    arrs["density_grid_bitfield"], arrs["density_grid_mean"] = N.update_bitfield(arrs["density_grid"])
+    return levels, arrs
+
+
+def ngp_camera_rays(W, H, pose_index=0, radius=4.0):
+    """Blender-convention pose on a sphere -> NGP rays through the oracle's restatement of dataset.py."""
+    import math
+    from jittor_myc_nerfs_amd import rays as R
+    from oracle import ngp_oracle as N
+    pose = R.sphere_poses(8, radius)[pose_index]
+    focal = 0.5 * W / math.tan(0.5 * 0.6911)
+    return N.generate_rays(N.matrix_nerf2ngp(pose), W, H, (focal, focal))
+
+
+def ngp_edge_rays():
+    """Rays the reference's sampler treats specially: a zero direction component (division by zero in the slab test), an origin
+    inside the occupied shell, a ray that misses the box, the render loop's padding ray (o = d = 1), and an axis-aligned ray."""
+    o = np.array([[0.5, 0.5, -1.2], [0.5, 0.7, 0.5], [3.5, 3.5, 3.5], [1.0, 1.0, 1.0], [-1.4, 0.52, 0.49], [0.5, 0.5, 2.4]], np.float32)
+    d = np.array([[0.0, 0.0, 1.0], [0.6, 0.0, 0.8], [1.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, 0.0, 0.0], [0.0, 0.6, -0.8]], np.float32)
+    return o, d

@@ -12,7 +12,7 @@ from conftest import ROOT, TINY, make_model
 
 
 def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "tvr.h")).read()
+    src = open(os.path.join(ROOT, "include", "tvr.h")).read() + open(os.path.join(ROOT, "include", "tvr_ngp.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(tvr_[a-z_0-9]+)\s*\(", src)))
 
@@ -24,8 +24,8 @@ def test_library_exports_every_declared_symbol():
     l = C.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(l, n), f"libtvr.so does not export {n}"
-    assert set(names) == set(_lib.SYMBOLS), "ctypes table and include/tvr.h disagree"
-    assert _lib.lib().tvr_version() == 105
+    assert set(names) == set(_lib.SYMBOLS), "ctypes table and include/*.h disagree"
+    assert _lib.lib().tvr_version() == 106
 
 
 def test_abi_argument_errors_without_gpu():

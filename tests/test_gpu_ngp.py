@@ -1,0 +1,176 @@
+"""GPU parity of the alt path: csrc/tvr_ngp.hip through the C-ABI (include/tvr_ngp.h) against oracle/ngp_oracle.*.
+Bar: sample rows, step counts, bases and hash-grid features bit-exact (integer / index work and explicitly rounded fp32);
+network outputs within fp32 accumulation-order tolerance; RGB L-inf <= 1e-3 (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import NGP_AABB_SCALE, ngp_camera_rays, ngp_edge_rays
+
+pytestmark = pytest.mark.gpu
+RGB_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def setup(ngp_scene):
+    from jittor_myc_nerfs_amd import ngp
+    levels, arrs = ngp_scene
+    dev = torch.device("cuda:0")
+    model = ngp.NGPNetworks(NGP_AABB_SCALE).to(dev)
+    sampler = ngp.DensityGridSampler(model, NGP_AABB_SCALE, rng=ngp.Pcg32(1337)).to(dev)
+    a = {k: v for k, v in arrs.items() if k != "density_grid_bitfield"}          # the bitfield comes from the HIP update_bitfield
+    ngp.load_scene_arrays(model, sampler, a)
+    return model, sampler, levels, arrs, dev
+
+
+def test_level_table_matches_oracle(setup):
+    model, _, levels, _, _ = setup
+    assert np.array_equal(model.pos_encoder.offsets, levels["offsets"])
+    assert np.array_equal(model.pos_encoder.scale, levels["scale"])
+
+
+def test_update_bitfield_bit_exact(setup):
+    _, sampler, _, arrs, _ = setup
+    assert np.array_equal(sampler.density_grid_bitfield.cpu().numpy(), arrs["density_grid_bitfield"])
+    assert abs(float(sampler.density_grid_mean) - arrs["density_grid_mean"]) < 1e-6
+
+
+@pytest.mark.parametrize("const_dt", [True, False])
+def test_sampler_rows_bit_exact(setup, const_dt):
+    from jittor_myc_nerfs_amd import ngp
+    from oracle import ngp_oracle as N
+    model, sampler, _, arrs, dev = setup
+    o, d = ngp_camera_rays(48, 48)
+    eo, ed = ngp_edge_rays()
+    o, d = np.concatenate([o, eo]), np.concatenate([d, ed])
+    s2 = ngp.DensityGridSampler(model, NGP_AABB_SCALE, const_dt=const_dt, rng=ngp.Pcg32(1337)).to(dev)
+    s2.density_grid_bitfield.copy_(sampler.density_grid_bitfield)
+    rng = N.Pcg32(1337)
+    for call in range(2):                                              # the second call sees the advanced generator
+        want = N.sample(o, d, arrs["density_grid_bitfield"], NGP_AABB_SCALE, rng.state, const_dt=const_dt)
+        rng.advance()
+        pos, dirs = s2.sample(None, torch.from_numpy(o), torch.from_numpy(d))
+        coords, numsteps = s2._coords.cpu().numpy(), s2._rays_numsteps.cpu().numpy()
+        assert np.array_equal(numsteps, want[2]), f"call {call}: step counts / bases differ"
+        assert np.array_equal(s2._counter.cpu().numpy().astype(np.uint32), want[3])
+        assert np.array_equal(s2._rays_index.cpu().numpy(), want[1])
+        assert coords.shape == want[0].shape and coords.shape[0] > 20000
+        assert np.array_equal(coords.view(np.uint32), want[0].view(np.uint32)), f"call {call}: sample rows differ"
+        assert pos.shape[1] == 3 and dirs.shape[1] == 3 and pos.data_ptr() == s2._coords.data_ptr()
+    assert want[2][-6:, 0].tolist()[2:4] == [0, 0]                    # the missing ray and the padding ray have no samples
+
+
+def test_sampler_overflow_semantics(setup):
+    """`base + numsteps > max_samples` -> (0, base), later rays keep their bases (ray_sampler.h:69-75)."""
+    from oracle import ngp_oracle as N
+    _, sampler, _, arrs, _ = setup
+    o, d = ngp_camera_rays(24, 24)
+    st = (sampler.rng.state, sampler.rng.inc)
+    want = N.sample(o, d, arrs["density_grid_bitfield"], NGP_AABB_SCALE, st, max_samples=30000)
+    coords, _, numsteps, counter = sampler._sample_raw(torch.from_numpy(o), torch.from_numpy(d), 30000)
+    assert np.array_equal(numsteps.cpu().numpy(), want[2])
+    assert int(counter[1]) == int(want[3][1]) > 30000 and (want[2][:, 0] == 0).sum() > (N.sample(o, d, arrs["density_grid_bitfield"], NGP_AABB_SCALE, st)[2][:, 0] == 0).sum()
+    keep = want[2][want[2][:, 0] > 0]
+    for n, b in keep[:: max(1, len(keep) // 50)]:
+        assert np.array_equal(coords[b:b + n].cpu().numpy().view(np.uint32), want[0][b:b + n].view(np.uint32))
+
+
+def test_hash_and_sh_encoders(setup):
+    from oracle import ngp_oracle as N
+    model, _, levels, arrs, dev = setup
+    rng = np.random.default_rng(3)
+    pos = rng.random((5000, 3), dtype=np.float32)
+    pos[:8] = [[0, 0, 0], [1, 1, 1], [0, 1, 0.5], [0.5, 0.5, 0.5], [1, 0, 0], [0.999999, 0.25, 0.75], [1e-7, 0.5, 1], [0.375, 0.375, 0.375]]
+    want, cells = N.hash_encode_c(levels, arrs["grid"], pos, want_cells=True)
+    got = model.pos_encoder(torch.from_numpy(pos).to(dev)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "hash-grid features are not bit-exact"
+    assert np.abs(N.hash_encode(levels, arrs["grid"], pos) - want).max() < 2e-6          # oracle (a) vs (b)
+    # strided rows (the sampler's [n,7] layout)
+    rows = torch.zeros(5000, 7, device=dev)
+    rows[:, :3] = torch.from_numpy(pos).to(dev)
+    assert torch.equal(model.pos_encoder(rows[:, :3]).cpu(), torch.from_numpy(want))
+    d01 = rng.random((3000, 3), dtype=np.float32)
+    sh = model.dir_encoder(torch.from_numpy(d01).to(dev)).cpu().numpy()
+    assert np.abs(sh - N.sh_encode_c(d01)).max() < 2e-6 and np.abs(sh - N.sh_encode(d01)).max() < 2e-6
+
+
+def test_fused_network_matches_oracle(setup):
+    from oracle import ngp_oracle as N
+    model, sampler, levels, arrs, dev = setup
+    o, d = ngp_camera_rays(32, 32, pose_index=3)
+    coords = N.sample(o, d, arrs["density_grid_bitfield"], NGP_AABB_SCALE, (1, 3))[0][:30011]       # not a multiple of the tile
+    want = N.network_c(levels, arrs, coords)
+    c = torch.from_numpy(coords).to(dev)
+    got = model(c[:, :3], c[:, 4:]).cpu().numpy()
+    err = np.abs(got - want)
+    assert err.max() < 2e-4 * max(1.0, np.abs(want).max()), f"fused network differs: {err.max():.3e}"
+    # separate contiguous inputs give the same numbers; density() is column 3
+    got2 = model(c[:, :3].contiguous(), c[:, 4:].contiguous()).cpu().numpy()
+    assert np.array_equal(got, got2)
+    assert np.array_equal(model.density(c[:, :3]).cpu().numpy()[:, 0], got[:, 3])
+    # unfused composition through the stand-alone encoders and torch Linears agrees as well (the reference's op-by-op path)
+    enc = model.pos_encoder(c[:, :3])
+    den = model.density_mlp(enc)
+    rgb = model.rgb_mlp(torch.cat([den, model.dir_encoder(c[:, 4:])], -1))
+    ref = torch.cat([rgb, den[:, :1]], -1).detach().cpu().numpy()
+    assert np.abs(ref - got).max() < 2e-4 * max(1.0, np.abs(want).max())
+    # independent of how samples are grouped into tiles
+    got3 = model(c[7:, :3], c[7:, 4:]).cpu().numpy()
+    assert np.array_equal(got3, got[7:])
+    assert model(c[:0, :3], c[:0, 4:]).shape == (0, 4)
+
+
+def test_composite_matches_oracle(setup):
+    from oracle import ngp_oracle as N
+    _, sampler, levels, arrs, dev = setup
+    o, d = ngp_camera_rays(32, 32, pose_index=5)
+    coords, _, numsteps, _, _ = N.sample(o, d, arrs["density_grid_bitfield"], NGP_AABB_SCALE, (7, 5))
+    out = N.network_c(levels, arrs, coords)
+    want, T = N.composite_c(out, coords, numsteps)
+    got = sampler._composite(torch.from_numpy(out).to(dev), torch.from_numpy(coords).to(dev), torch.from_numpy(numsteps).to(dev), [1.0, 1.0, 1.0])
+    assert np.abs(got.cpu().numpy() - want).max() < 2e-5
+    assert (T < 1e-4).mean() > 0.2 and (T > 0.5).mean() > 0.1         # both terminated and nearly transparent rays occur
+    sub = slice(0, 64)
+    assert np.abs(N.composite(out, coords, numsteps[sub]) - want[sub]).max() < 2e-5      # oracle (a) vs (b)
+    bg = [0.2, 0.5, 0.9]
+    got = sampler._composite(torch.from_numpy(out).to(dev), torch.from_numpy(coords).to(dev), torch.from_numpy(numsteps).to(dev), bg)
+    assert np.abs(got.cpu().numpy() - N.composite_c(out, coords, numsteps, bg)[0]).max() < 2e-5
+
+
+def test_render_img_and_render_frame(setup):
+    """runner.py's slab loop through the drop-in surface == the one-pass frame path (bit for bit) == the oracle (<= 1e-3)."""
+    from jittor_myc_nerfs_amd import ngp
+    from oracle import ngp_oracle as N
+    model, sampler, levels, arrs, dev = setup
+    W = H = 100                                                        # 10 000 rays: two full slabs and a padded tail
+    o, d = ngp_camera_rays(W, H, pose_index=1)
+    to, td = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    sampler.rng = ngp.Pcg32(1337)
+    a = ngp.render_img(sampler, model, to, td)
+    after_loop = (sampler.rng.state, sampler.rng.inc)
+    sampler.rng = ngp.Pcg32(1337)
+    stats = {}
+    b = sampler.render_frame(to, td, samples_per_ray_hint=16, stats=stats)      # the hint is too small on purpose: exercises the retry
+    assert (sampler.rng.state, sampler.rng.inc) == after_loop
+    assert stats["samples"] > 16 * W * H * 0.5 and torch.equal(a, b)
+    want = N.render_img(arrs, levels, o, d, NGP_AABB_SCALE, N.Pcg32(1337))
+    err = np.abs(a.cpu().numpy() - want).max()
+    assert err < RGB_TOL, f"RGB L-inf vs oracle {err:.3e}"
+    assert want.std() > 0.05                                           # a picture, not a constant
+
+
+def test_ngp_errors_are_loud(setup):
+    import ctypes as C
+    from jittor_myc_nerfs_amd import _lib as L, ngp
+    model, sampler, _, _, dev = setup
+    with pytest.raises(L.TvrError):
+        ngp.NGPNetworks(NGP_AABB_SCALE)(torch.zeros(4, 3), torch.zeros(4, 3))              # CPU tensors: no fallback
+    cfg = L.NgpGridCfg()
+    assert L.lib().tvr_ngp_hash_encode(C.byref(cfg), None, None, 3, 4, None, None) == -1 and b"offsets" in L.lib().tvr_last_error()
+    g = model.pos_encoder.cfg
+    bad = L.NgpGridCfg()
+    C.memmove(C.byref(bad), C.byref(g), C.sizeof(g))
+    bad.offsets[16] = bad.offsets[15] + 300000                          # hashed level whose table is not a power of two
+    assert L.lib().tvr_ngp_hash_encode(C.byref(bad), None, None, 3, 4, None, None) == -4
+    with pytest.raises(NotImplementedError):
+        sampler.sample(None, torch.zeros(1, 3), torch.ones(1, 3), is_training=True)
