@@ -349,7 +349,8 @@ __device__ __forceinline__ uint32_t grid_entry(bool hashed, uint32_t size, uint3
 {
     const uint32_t dense = x + y * res + z * res * res;
     const uint32_t hash = x ^ (y * 19349663u) ^ (z * 83492791u);
-    return hashed ? (hash & (size - 1)) : (dense - (dense >= size ? size : 0u));
+    // min(): rows the sampler left unwritten (holes of rays that overflowed max_samples) hold arbitrary bits; never index outside the table
+    return hashed ? (hash & (size - 1)) : min(dense - (dense >= size ? size : 0u), size - 1);
 }
 
 // one level of kernel_grid for one position: the 8 corner entries are fetched first (independent loads), then blended in corner order
