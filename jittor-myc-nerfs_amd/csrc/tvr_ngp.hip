@@ -421,19 +421,33 @@ __global__ void __launch_bounds__(256) ngp_sh_encode_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------ fused field kernel
-// Packed weight image: five layers, each [m_blocks][steps][64 lanes] floats; lane l of step s, block mb holds
-// W[mb*32 + l%32][l < 32 ? ka(s) : kb(s)] (zero for rows past n_out).  k pairings per layer input:
-//   hash features   step s = 2p+f : ka = 4p+f (level 2p, feature f), kb = 4p+2+f (level 2p+1)          [lane half = level parity]
-//   previous layer  step s = mb*16+i : ka = mb*32 + (i/4)*8 + i%4, kb = ka+4                              [MFMA accumulator layout]
-//   rgb0 input      steps 0..7: density_mlp output, accumulator regs 0..7 (ka = (i/4)*8 + i%4, kb = ka+4);
-//                   steps 8..15: SH pair j = s-8: ka = 16+2j, kb = 17+2j
+// Two arithmetic variants of the five bias-free Linears, same gather, same register-resident chaining:
+//   F16 = true  (default) v_mfma_f32_32x32x16_f16 with every fp32 operand split into fp16 hi + lo and three products per k-step
+//                         (hi*lo, lo*hi, hi*hi; error ~2^-22 relative, i.e. fp32-grade) — 72 MFMAs x 32 cycles per 32 samples;
+//   F16 = false           v_mfma_f32_32x32x2_f32, exact fp32 — 192 MFMAs x 64 cycles per 32 samples (-DTVR_NGP_MLP_F32=1).
+// Chaining: the accumulator of a 32-neuron block holds, in lane (sample = lane%32, h = lane/32), register i, neuron
+// (i/4)*8 + 4h + i%4.  A k-step of the next layer reads registers straight from there as its B operand, and the k order that implies
+// is folded into the packed weight image (LDS), so no activation ever leaves the registers:
+//   fp32 image  [layer][m_block][step][64 lanes] floats; step s pairs k = (ka, kb) for the two lane halves
+//   fp16 image  [block][hi|lo][64 lanes] uint4 (8 halves); block = (layer, m_block, k-step of 16); lane half h, element j:
+//                 hash features (density0)   t: level 2*(4t + j/2) + h, feature j%2
+//                 previous accumulators      t: neuron (t/2)*32 + (2*(t%2) + j/4)*8 + 4h + j%4
+//                 rgb0 input                 t=0: density_mlp output (j/4)*8 + 4h + j%4;  t=1: SH 8h + j
+#ifndef TVR_NGP_MLP_F32
+#define TVR_NGP_MLP_F32 0
+#endif
 enum { NGP_L_D0 = 0, NGP_L_D1 = 2 * 16 * 64, NGP_L_C0 = NGP_L_D1 + 32 * 64, NGP_L_C1 = NGP_L_C0 + 2 * 16 * 64, NGP_L_C2 = NGP_L_C1 + 2 * 32 * 64,
        NGP_IMAGE_FLOATS = NGP_L_C2 + 32 * 64 };
+// fp16 image: first block of each layer (blocks are m_block-major, then k-step)
+enum { NGP_H_D0 = 0, NGP_H_D1 = 4, NGP_H_C0 = 8, NGP_H_C1 = 12, NGP_H_C2 = 20, NGP_H_BLOCKS = 24, NGP_HIMAGE_FLOATS = NGP_H_BLOCKS * 2 * 64 * 4 };
+static_assert(NGP_HIMAGE_FLOATS == NGP_IMAGE_FLOATS, "both images are 48 KiB");
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int acc_row(int i) { return (i / 4) * 8 + i % 4; }
 
-__global__ void __launch_bounds__(256) ngp_pack_kernel(const float *__restrict__ d0, const float *__restrict__ d1, const float *__restrict__ c0, const float *__restrict__ c1,
-                                                       const float *__restrict__ c2, float *__restrict__ image)
+__global__ void __launch_bounds__(256) ngp_pack_f32_kernel(const float *__restrict__ d0, const float *__restrict__ d1, const float *__restrict__ c0, const float *__restrict__ c1,
+                                                           const float *__restrict__ c2, float *__restrict__ image)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= NGP_IMAGE_FLOATS) return;
@@ -454,10 +468,93 @@ __global__ void __launch_bounds__(256) ngp_pack_kernel(const float *__restrict__
     image[e] = row < n_out ? W[row * n_in + k] : 0.f;
 }
 
+// fp32 pair -> packed fp16 hi and lo words (x = hi + lo up to ~2^-22 |x|; round-toward-zero never overflows to inf).  x - hi is one
+// v_fma_mix_f32 reading the packed half in place; its result goes through the compiler-visible v_cvt_pkrtz, never into an MFMA
+// directly (VALU-write -> MFMA-read wait states are software-managed on gfx950 and the compiler cannot pad inline asm; see tvr_shade.hip).
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hb), "v"(b));
+    hi = hb;
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+struct Frag {   // one 8-element fp16 operand fragment, hi and lo parts
+    uint4 hi, lo;
+};
+__device__ __forceinline__ Frag split8(const float v[8])
+{
+    Frag f;
+    split2(v[0], v[1], f.hi.x, f.lo.x);
+    split2(v[2], v[3], f.hi.y, f.lo.y);
+    split2(v[4], v[5], f.hi.z, f.lo.z);
+    split2(v[6], v[7], f.hi.w, f.lo.w);
+    return f;
+}
+
+// one thread per (block, lane): the 8 weights of that lane's A fragment, split into hi / lo
+__global__ void __launch_bounds__(256) ngp_pack_f16_kernel(const float *__restrict__ d0, const float *__restrict__ d1, const float *__restrict__ c0, const float *__restrict__ c1,
+                                                           const float *__restrict__ c2, uint4 *__restrict__ image)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NGP_H_BLOCKS * 64) return;
+    const int blk = e >> 6, l = e & 63, h = l >> 5;
+    const float *W;
+    int first, n_in, n_out, steps, kind;
+    if (blk < NGP_H_D1) { W = d0; first = NGP_H_D0; n_in = 32; n_out = 64; steps = 2; kind = 0; }
+    else if (blk < NGP_H_C0) { W = d1; first = NGP_H_D1; n_in = 64; n_out = 16; steps = 4; kind = 1; }
+    else if (blk < NGP_H_C1) { W = c0; first = NGP_H_C0; n_in = 32; n_out = 64; steps = 2; kind = 2; }
+    else if (blk < NGP_H_C2) { W = c1; first = NGP_H_C1; n_in = 64; n_out = 64; steps = 4; kind = 1; }
+    else { W = c2; first = NGP_H_C2; n_in = 64; n_out = 3; steps = 4; kind = 1; }
+    const int mb = (blk - first) / steps, t = (blk - first) % steps, row = mb * 32 + (l & 31);
+    float v[8];
+    for (int j = 0; j < 8; ++j) {
+        int k;
+        if (kind == 0) k = 2 * (2 * (4 * t + j / 2) + h) + (j & 1);
+        else if (kind == 1) k = (t / 2) * 32 + (2 * (t & 1) + j / 4) * 8 + 4 * h + (j & 3);
+        else k = t == 0 ? (j / 4) * 8 + 4 * h + (j & 3) : 16 + 8 * h + j;
+        v[j] = row < n_out ? W[row * n_in + k] : 0.f;
+    }
+    const Frag f = split8(v);
+    image[(blk * 2 + 0) * 64 + l] = f.hi;
+    image[(blk * 2 + 1) * 64 + l] = f.lo;
+}
+
 __device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
 
+// one k-step (16 inputs) into the two 32-neuron blocks of a 64-wide layer; the two blocks alternate so that no MFMA directly follows
+// the one it depends on
+__device__ __forceinline__ void step2(const uint4 *__restrict__ w4, int blk0, int blk1, const Frag &b, f32x16 &a0, f32x16 &a1)
+{
+    const uint4 h0 = w4[(blk0 * 2 + 0) * 64], l0 = w4[(blk0 * 2 + 1) * 64], h1 = w4[(blk1 * 2 + 0) * 64], l1 = w4[(blk1 * 2 + 1) * 64];
+    a0 = MFMAH(l0, b.hi, a0);
+    a1 = MFMAH(l1, b.hi, a1);
+    a0 = MFMAH(h0, b.lo, a0);
+    a1 = MFMAH(h1, b.lo, a1);
+    a0 = MFMAH(h0, b.hi, a0);
+    a1 = MFMAH(h1, b.hi, a1);
+}
+__device__ __forceinline__ void step1(const uint4 *__restrict__ w4, int blk, const Frag &b, f32x16 &a)
+{
+    const uint4 h0 = w4[(blk * 2 + 0) * 64], l0 = w4[(blk * 2 + 1) * 64];
+    a = MFMAH(l0, b.hi, a);
+    a = MFMAH(h0, b.lo, a);
+    a = MFMAH(h0, b.hi, a);
+}
+// B fragment of k-step t (0..3) of a 64-wide activation held in two accumulators
+__device__ __forceinline__ Frag relu_frag(const f32x16 &a0, const f32x16 &a1, int t)
+{
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = relu_f(t < 2 ? a0[8 * (t & 1) + j] : a1[8 * (t & 1) + j]);
+    return split8(v);
+}
+
+template <bool F16>
 __global__ void __launch_bounds__(256, 2) ngp_field_kernel(GridCfg g, const float *__restrict__ grid, const float *__restrict__ image,
                                                            const float *__restrict__ positions, int pos_stride, const float *__restrict__ dirs, int dir_stride,
                                                            long long n_max, const uint32_t *__restrict__ n_dev, float4 *__restrict__ out)
@@ -486,7 +583,7 @@ __global__ void __launch_bounds__(256, 2) ngp_field_kernel(GridCfg g, const floa
             float sh[16];
             sh16(qd[0], qd[1], qd[2], sh);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) shv[j] = hh ? sh[2 * j + 1] : sh[2 * j];
+            for (int j = 0; j < 8; ++j) shv[j] = F16 ? (hh ? sh[8 + j] : sh[j]) : (hh ? sh[2 * j + 1] : sh[2 * j]);
         }
         // two levels per lane at a time: 16 float2 loads in flight, no more (registers)
 #pragma unroll
@@ -501,41 +598,72 @@ __global__ void __launch_bounds__(256, 2) ngp_field_kernel(GridCfg g, const floa
             if (p & 1) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- MATRIX phase
-        const float *wl = lds + lane_off;
-        f32x16 a0 = {0}, a1 = {0};                                  // the two 32-neuron blocks of a 64-wide layer
-        // density_mlp.0: 32 -> 64, relu
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float bv = (s & 1) ? f1[s >> 1] : f0[s >> 1];
-            a0 = MFMA(wl[NGP_L_D0 + (0 * 16 + s) * 64], bv, a0);
-            a1 = MFMA(wl[NGP_L_D0 + (1 * 16 + s) * 64], bv, a1);
-        }
-        // density_mlp.2: 64 -> 16 (rows 16..31 of the block are zero weights)
-        f32x16 d = {0};
-#pragma unroll
-        for (int s = 0; s < 32; ++s) d = MFMA(wl[NGP_L_D1 + s * 64], relu_f(s < 16 ? a0[s & 15] : a1[s & 15]), d);
-        // rgb_mlp.0: [density(16), SH(16)] -> 64, relu
-        a0 = (f32x16){0};
-        a1 = (f32x16){0};
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float bv = s < 8 ? d[s & 7] : shv[s & 7];
-            a0 = MFMA(wl[NGP_L_C0 + (0 * 16 + s) * 64], bv, a0);
-            a1 = MFMA(wl[NGP_L_C0 + (1 * 16 + s) * 64], bv, a1);
-        }
-        const float density_raw = d[0];
-        // rgb_mlp.2: 64 -> 64, relu
-        f32x16 c0 = {0}, c1 = {0};
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const float bv = relu_f(s < 16 ? a0[s & 15] : a1[s & 15]);
-            c0 = MFMA(wl[NGP_L_C1 + (0 * 32 + s) * 64], bv, c0);
-            c1 = MFMA(wl[NGP_L_C1 + (1 * 32 + s) * 64], bv, c1);
-        }
-        // rgb_mlp.4: 64 -> 3
+        float density_raw;
         f32x16 e = {0};
+        if (F16) {
+            const uint4 *w4 = reinterpret_cast<const uint4 *>(lds) + lane_off;
+            f32x16 a0 = {0}, a1 = {0};
+            // density_mlp.0: 32 -> 64
 #pragma unroll
-        for (int s = 0; s < 32; ++s) e = MFMA(wl[NGP_L_C2 + s * 64], relu_f(s < 16 ? c0[s & 15] : c1[s & 15]), e);
+            for (int t = 0; t < 2; ++t) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (j & 1) ? f1[4 * t + j / 2] : f0[4 * t + j / 2];
+                step2(w4, NGP_H_D0 + t, NGP_H_D0 + 2 + t, split8(v), a0, a1);
+            }
+            // density_mlp.2: relu, 64 -> 16
+            f32x16 d = {0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) step1(w4, NGP_H_D1 + t, relu_frag(a0, a1, t), d);
+            density_raw = d[0];
+            // rgb_mlp.0: [density(16), SH(16)] -> 64
+            a0 = (f32x16){0};
+            a1 = (f32x16){0};
+            {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = d[j];
+                step2(w4, NGP_H_C0 + 0, NGP_H_C0 + 2, split8(v), a0, a1);
+                step2(w4, NGP_H_C0 + 1, NGP_H_C0 + 3, split8(shv), a0, a1);
+            }
+            // rgb_mlp.2: relu, 64 -> 64
+            f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) step2(w4, NGP_H_C1 + t, NGP_H_C1 + 4 + t, relu_frag(a0, a1, t), c0, c1);
+            // rgb_mlp.4: relu, 64 -> 3
+#pragma unroll
+            for (int t = 0; t < 4; ++t) step1(w4, NGP_H_C2 + t, relu_frag(c0, c1, t), e);
+        } else {
+            const float *wl = lds + lane_off;
+            f32x16 a0 = {0}, a1 = {0};                              // the two 32-neuron blocks of a 64-wide layer
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float bv = (s & 1) ? f1[s >> 1] : f0[s >> 1];
+                a0 = MFMA(wl[NGP_L_D0 + (0 * 16 + s) * 64], bv, a0);
+                a1 = MFMA(wl[NGP_L_D0 + (1 * 16 + s) * 64], bv, a1);
+            }
+            f32x16 d = {0};
+#pragma unroll
+            for (int s = 0; s < 32; ++s) d = MFMA(wl[NGP_L_D1 + s * 64], relu_f(s < 16 ? a0[s & 15] : a1[s & 15]), d);
+            a0 = (f32x16){0};
+            a1 = (f32x16){0};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float bv = s < 8 ? d[s & 7] : shv[s & 7];
+                a0 = MFMA(wl[NGP_L_C0 + (0 * 16 + s) * 64], bv, a0);
+                a1 = MFMA(wl[NGP_L_C0 + (1 * 16 + s) * 64], bv, a1);
+            }
+            density_raw = d[0];
+            f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const float bv = relu_f(s < 16 ? a0[s & 15] : a1[s & 15]);
+                c0 = MFMA(wl[NGP_L_C1 + (0 * 32 + s) * 64], bv, c0);
+                c1 = MFMA(wl[NGP_L_C1 + (1 * 32 + s) * 64], bv, c1);
+            }
+#pragma unroll
+            for (int s = 0; s < 32; ++s) e = MFMA(wl[NGP_L_C2 + s * 64], relu_f(s < 16 ? c0[s & 15] : c1[s & 15]), e);
+        }
         // rows 0..2 of the last layer and row 0 of the density head sit in accumulator regs 0..2 / 0 of the lower half-wave
         if (h == 0 && sidx < n) out[sidx] = make_float4(e[0], e[1], e[2], density_raw);
     }
@@ -718,15 +846,18 @@ int tvr_ngp_sh_encode(const void *dirs, int32_t dir_stride, int64_t n, void *out
     return TVR_OK;
 }
 
-size_t tvr_ngp_net_packed_bytes(void) { return (size_t)NGP_IMAGE_FLOATS * sizeof(float); }
+size_t tvr_ngp_net_packed_bytes(void) { return 2 * (size_t)NGP_IMAGE_FLOATS * sizeof(float); }      // fp32 image, then fp16 hi/lo image
 
 int tvr_ngp_net_pack(const tvr_ngp_net_params *p, void *packed, size_t packed_bytes, void *stream)
 {
     if (!p || !p->density0 || !p->density1 || !p->rgb0 || !p->rgb1 || !p->rgb2) return tvr_set_error(TVR_ERR_INVALID, "tvr_ngp_net_pack: NULL weights");
     if (!packed || misaligned(packed) || packed_bytes < tvr_ngp_net_packed_bytes()) return tvr_set_error(TVR_ERR_SCRATCH, "tvr_ngp_net_pack: packed buffer too small or misaligned");
-    hipLaunchKernelGGL(ngp_pack_kernel, dim3((NGP_IMAGE_FLOATS + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float *>(p->density0),
-                       static_cast<const float *>(p->density1), static_cast<const float *>(p->rgb0), static_cast<const float *>(p->rgb1),
-                       static_cast<const float *>(p->rgb2), static_cast<float *>(packed));
+    const float *d0 = static_cast<const float *>(p->density0), *d1 = static_cast<const float *>(p->density1), *c0 = static_cast<const float *>(p->rgb0),
+                *c1 = static_cast<const float *>(p->rgb1), *c2 = static_cast<const float *>(p->rgb2);
+    hipLaunchKernelGGL(ngp_pack_f32_kernel, dim3((NGP_IMAGE_FLOATS + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), d0, d1, c0, c1, c2,
+                       static_cast<float *>(packed));
+    hipLaunchKernelGGL(ngp_pack_f16_kernel, dim3((NGP_H_BLOCKS * 64 + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), d0, d1, c0, c1, c2,
+                       reinterpret_cast<uint4 *>(static_cast<float *>(packed) + NGP_IMAGE_FLOATS));
     HIP_TRY(hipGetLastError());
     return TVR_OK;
 }
@@ -742,9 +873,11 @@ int tvr_ngp_network(const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const vo
         return tvr_set_error(TVR_ERR_INVALID, "tvr_ngp_network: NULL or misaligned argument");
     const long long tiles = (n_max + 31) / 32;
     const unsigned blocks = (unsigned)(tiles < 4 * 2048 ? (tiles + 3) / 4 : 2048);
-    hipLaunchKernelGGL(ngp_field_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, static_cast<const float *>(grid),
-                       static_cast<const float *>(net_packed), static_cast<const float *>(positions), (int)pos_stride, static_cast<const float *>(dirs),
-                       (int)dir_stride, (long long)n_max, static_cast<const uint32_t *>(n_dev), static_cast<float4 *>(out));
+    const bool f16 = !TVR_NGP_MLP_F32;
+    hipLaunchKernelGGL(f16 ? ngp_field_kernel<true> : ngp_field_kernel<false>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g,
+                       static_cast<const float *>(grid), static_cast<const float *>(net_packed) + (f16 ? NGP_IMAGE_FLOATS : 0), static_cast<const float *>(positions),
+                       (int)pos_stride, static_cast<const float *>(dirs), (int)dir_stride, (long long)n_max, static_cast<const uint32_t *>(n_dev),
+                       static_cast<float4 *>(out));
     HIP_TRY(hipGetLastError());
     return TVR_OK;
 }
