@@ -159,6 +159,27 @@ def test_render_img_and_render_frame(setup):
     assert want.std() > 0.05                                           # a picture, not a constant
 
 
+def test_against_committed_golden(setup):
+    """tests/golden/ngp.npz (make_golden_ngp.py): sampler rows bit for bit (digest), network / picture to tolerance."""
+    import hashlib
+    import os
+    from conftest import GOLDEN
+    from jittor_myc_nerfs_amd import ngp
+    model, sampler, _, _, dev = setup
+    g = dict(np.load(os.path.join(GOLDEN, "ngp.npz")))
+    sampler.rng = ngp.Pcg32(1337)
+    sampler.rng.state, sampler.rng.inc = int(g["rng_state"][0]), int(g["rng_state"][1])
+    pos, dirs = sampler.sample(None, torch.from_numpy(g["rays_o"]), torch.from_numpy(g["rays_d"]))
+    assert np.array_equal(sampler._rays_numsteps.cpu().numpy(), g["numsteps"]) and np.array_equal(sampler._rays_index.cpu().numpy(), g["ray_index"])
+    coords = sampler._coords.cpu().numpy()
+    assert hashlib.sha256(coords.tobytes()).hexdigest() == str(g["sha.coords"])
+    assert np.array_equal(model.pos_encoder(pos[:512]).cpu().numpy(), g["enc_head"])
+    out = model(pos, dirs)
+    assert np.abs(out[:512].cpu().numpy() - g["net_head"]).max() < 2e-4 * max(1.0, np.abs(g["net_head"]).max())
+    rgb = sampler.rays2rgb(out, inference=True).cpu().numpy()
+    assert np.abs(rgb - g["rgb"]).max() < RGB_TOL
+
+
 def test_ngp_errors_are_loud(setup):
     import ctypes as C
     from jittor_myc_nerfs_amd import _lib as L, ngp
