@@ -1,7 +1,7 @@
 // tvr_ngp.hip — the alt path: JNeRF Instant-NGP inference on MI355X.  Kernels + the C-ABI of include/tvr_ngp.h.
 //
-//   ngp_march_kernel<WRITE>   one lane per ray: AABB slab test, jittered start (PCG32), occupancy-bitfield march.
-//                             Pass 1 counts; a 3-kernel exclusive scan hands out bases IN RAY ORDER; pass 2 writes the rows.
+//   ngp_march_kernel          one lane per ray: AABB slab test, jittered start (PCG32), occupancy-bitfield march ONCE, recording each
+//                             step's t; an exclusive scan hands out bases IN RAY ORDER; ngp_expand_kernel (one wave per ray) writes the rows.
 //   ngp_field_kernel          fused NGPNetworks.execute_: per wave 32 samples at a time; each half-wave gathers the even / odd hash
 //                             levels of its 32 samples (8 corners x float2), and the five bias-free Linears run as fp32 MFMAs
 //                             (v_mfma_f32_32x32x2_f32) with activations register-resident between layers: the accumulator layout
@@ -128,32 +128,19 @@ struct RayState {
     float o[3], d[3], idir[3];
 };
 
-// the body of rays_sampler's two while loops; WRITE selects pass 2
-template <bool WRITE>
-__device__ __forceinline__ uint32_t march_ray(const MarchCfg &c, const RayState &r, const uint8_t *__restrict__ bits, float startt,
-                                              uint32_t limit, float *__restrict__ rows)
+// rays_sampler's march (its two while loops are the same walk): every occupied step's t goes to the ray's slab; returns the step count
+__device__ __forceinline__ uint32_t march_ray(const MarchCfg &c, const RayState &r, const uint8_t *__restrict__ bits, float startt, float *__restrict__ tslab)
 {
     uint32_t j = 0;
     float t = startt;
-    const float w0 = (r.d[0] + 1.0f) * 0.5f, w1 = (r.d[1] + 1.0f) * 0.5f, w2 = (r.d[2] + 1.0f) * 0.5f;
     for (;;) {
         const float x = __builtin_fmaf(t, r.d[0], r.o[0]), y = __builtin_fmaf(t, r.d[1], r.o[1]), z = __builtin_fmaf(t, r.d[2], r.o[2]);
         const bool inside = x >= c.lo[0] && x <= c.hi[0] && y >= c.lo[1] && y <= c.hi[1] && z >= c.lo[2] && z <= c.hi[2];
-        if (!(inside && j < limit)) break;
+        if (!(inside && j < (uint32_t)TVR_NGP_STEPS)) break;
         const float dt = calc_dt(c, t);
         const uint32_t mip = (uint32_t)mip_from_dt(dt, x, y, z);
         if (occupied_at(x, y, z, bits, mip)) {
-            if (WRITE) {
-                float *q = rows + 7 * (size_t)j;
-                const float max_step = min_cone_step() * 16.0f;
-                q[0] = (x - c.lo[0]) / (c.hi[0] - c.lo[0]);
-                q[1] = (y - c.lo[1]) / (c.hi[1] - c.lo[1]);
-                q[2] = (z - c.lo[2]) / (c.hi[2] - c.lo[2]);
-                q[3] = (dt - min_cone_step()) / (max_step - min_cone_step());
-                q[4] = w0;
-                q[5] = w1;
-                q[6] = w2;
-            }
+            tslab[j] = t;
             ++j;
             t += dt;
         } else {
@@ -193,9 +180,9 @@ __device__ __forceinline__ void load_ray(const float *__restrict__ rays_o, const
     }
 }
 
-// pass 1: step count and start depth of every ray
-__global__ void __launch_bounds__(256) ngp_count_kernel(MarchCfg c, const float *__restrict__ rays_o, const float *__restrict__ rays_d, long long n_rays,
-                                                        const uint8_t *__restrict__ bits, uint32_t *__restrict__ counts, float *__restrict__ startt)
+// the march: step count of every ray, and the t of every step in the ray's 1024-float slab
+__global__ void __launch_bounds__(256) ngp_march_kernel(MarchCfg c, const float *__restrict__ rays_o, const float *__restrict__ rays_d, long long n_rays,
+                                                        const uint8_t *__restrict__ bits, uint32_t *__restrict__ counts, float *__restrict__ tslab)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rays) return;
@@ -207,8 +194,7 @@ __global__ void __launch_bounds__(256) ngp_count_kernel(MarchCfg c, const float 
     pcg_advance(rng, ((uint64_t)slab << 32) + (uint64_t)(uint32_t)(in_slab * 8u));
     float t0 = fmaxf(ray_entry(c, r), c.near_distance);
     t0 = __builtin_fmaf(calc_dt(c, t0), pcg_float(rng), t0);
-    startt[i] = t0;
-    counts[i] = march_ray<false>(c, r, bits, t0, TVR_NGP_STEPS, nullptr);
+    counts[i] = march_ray(c, r, bits, t0, tslab + (size_t)i * TVR_NGP_STEPS);
 }
 
 // exclusive scan of counts in ray order: (a) per 1024-ray block, (b) the block totals, (c) folded into pass 2
@@ -257,31 +243,42 @@ __global__ void __launch_bounds__(1024) ngp_scan_top_kernel(uint32_t *__restrict
     if (threadIdx.x == 0) *total = carry;
 }
 
-// pass 2: rows, numsteps, ray_index.  ray_index needs the rank among rays that got a slab: a second scan would do; the rank is
-// only informational (unused by inference), so it is computed from a per-ray flag with the same two scan kernels by the host
-// wrapper when ray_index != nullptr (flags = 1 for rays with a slab).
-__global__ void __launch_bounds__(256) ngp_write_kernel(MarchCfg c, const float *__restrict__ rays_o, const float *__restrict__ rays_d, long long n_rays,
-                                                        const uint8_t *__restrict__ bits, const uint32_t *__restrict__ counts, const float *__restrict__ startt,
-                                                        const uint32_t *__restrict__ local, const uint32_t *__restrict__ block_sum, long long max_samples,
-                                                        float *__restrict__ coords, int *__restrict__ numsteps, uint32_t *__restrict__ got_slab)
+// rows from the recorded t: one wave per ray, lane j writes row base+j (consecutive rows: the stores of a wave cover one contiguous
+// span).  Also numsteps and the "got a slab" flag whose scan gives ray_index (rank among rays with a slab; informational, unused by
+// inference).
+__global__ void __launch_bounds__(256) ngp_expand_kernel(MarchCfg c, const float *__restrict__ rays_o, const float *__restrict__ rays_d, long long n_rays,
+                                                         const uint32_t *__restrict__ counts, const float *__restrict__ tslab, const uint32_t *__restrict__ local,
+                                                         const uint32_t *__restrict__ block_sum, long long max_samples, float *__restrict__ coords,
+                                                         int *__restrict__ numsteps, uint32_t *__restrict__ got_slab)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= n_rays) return;
     const uint32_t n = counts[i];
     const uint32_t base = local[i] + block_sum[i >> 10];
-    if ((long long)base + n > max_samples) {
-        numsteps[2 * i] = 0;
+    const bool over = (long long)base + n > max_samples;
+    if (lane == 0) {
+        numsteps[2 * i] = over ? 0 : (int)n;
         numsteps[2 * i + 1] = (int)base;
-        if (got_slab) got_slab[i] = 0u;
-        return;
+        if (got_slab) got_slab[i] = over ? 0u : 1u;
     }
-    numsteps[2 * i] = (int)n;
-    numsteps[2 * i + 1] = (int)base;
-    if (got_slab) got_slab[i] = 1u;
-    if (n == 0) return;
-    RayState r;
-    load_ray(rays_o, rays_d, i, r);
-    march_ray<true>(c, r, bits, startt[i], n, coords + 7 * (size_t)base);
+    if (over || n == 0) return;
+    const float o0 = rays_o[3 * i], o1 = rays_o[3 * i + 1], o2 = rays_o[3 * i + 2], d0 = rays_d[3 * i], d1 = rays_d[3 * i + 1], d2 = rays_d[3 * i + 2];
+    const float w0 = (d0 + 1.0f) * 0.5f, w1 = (d1 + 1.0f) * 0.5f, w2 = (d2 + 1.0f) * 0.5f;
+    const float max_step = min_cone_step() * 16.0f;
+    const float *ts = tslab + (size_t)i * TVR_NGP_STEPS;
+    for (uint32_t j = lane; j < n; j += 64) {
+        const float t = ts[j];
+        const float x = __builtin_fmaf(t, d0, o0), y = __builtin_fmaf(t, d1, o1), z = __builtin_fmaf(t, d2, o2);
+        float *q = coords + 7 * ((size_t)base + j);
+        q[0] = (x - c.lo[0]) / (c.hi[0] - c.lo[0]);
+        q[1] = (y - c.lo[1]) / (c.hi[1] - c.lo[1]);
+        q[2] = (z - c.lo[2]) / (c.hi[2] - c.lo[2]);
+        q[3] = (calc_dt(c, t) - min_cone_step()) / (max_step - min_cone_step());
+        q[4] = w0;
+        q[5] = w1;
+        q[6] = w2;
+    }
 }
 __global__ void __launch_bounds__(256) ngp_ray_index_kernel(const uint32_t *__restrict__ got_slab, const uint32_t *__restrict__ local, const uint32_t *__restrict__ block_sum,
                                                             const uint32_t *__restrict__ counts, const uint32_t *__restrict__ slab_total,
@@ -765,13 +762,13 @@ int tvr_ngp_update_bitfield(const void *density_grid, void *bitfield, void *mean
     return TVR_OK;
 }
 
-// scratch: counts, startt, local, flags [n] each + two block-sum arrays + 2 totals
+// scratch: counts, local, flags, flag-local [n] each + two block-sum arrays + 2 totals + the t slabs [n, 1024]
 static size_t scan_blocks(int64_t n) { return (size_t)((n + 1023) / 1024); }
 size_t tvr_ngp_sample_scratch_bytes(int64_t n_rays)
 {
     if (n_rays < 0) return 0;
     const size_t n = align_up((size_t)n_rays * 4, 256), nb = align_up(scan_blocks(n_rays) * 4 + 4, 256);
-    return 5 * n + 2 * nb + 256;
+    return 4 * n + 2 * nb + 256 + (size_t)n_rays * TVR_NGP_STEPS * sizeof(float);
 }
 
 int tvr_ngp_sample(const tvr_ngp_march_cfg *cfg, const void *rays_o, const void *rays_d, int64_t n_rays, const void *bitfield,
@@ -794,21 +791,21 @@ int tvr_ngp_sample(const tvr_ngp_march_cfg *cfg, const void *rays_o, const void 
     const size_t n = align_up((size_t)n_rays * 4, 256), nbb = align_up(scan_blocks(n_rays) * 4 + 4, 256);
     char *p = static_cast<char *>(scratch);
     uint32_t *counts = reinterpret_cast<uint32_t *>(p);
-    float *startt = reinterpret_cast<float *>(p + n);
-    uint32_t *local = reinterpret_cast<uint32_t *>(p + 2 * n);
-    uint32_t *flags = reinterpret_cast<uint32_t *>(p + 3 * n);
-    uint32_t *flocal = reinterpret_cast<uint32_t *>(p + 4 * n);
-    uint32_t *bsum = reinterpret_cast<uint32_t *>(p + 5 * n);
-    uint32_t *fsum = reinterpret_cast<uint32_t *>(p + 5 * n + nbb);
-    uint32_t *totals = reinterpret_cast<uint32_t *>(p + 5 * n + 2 * nbb);          // [0] steps, [1] rays with a slab
+    uint32_t *local = reinterpret_cast<uint32_t *>(p + n);
+    uint32_t *flags = reinterpret_cast<uint32_t *>(p + 2 * n);
+    uint32_t *flocal = reinterpret_cast<uint32_t *>(p + 3 * n);
+    uint32_t *bsum = reinterpret_cast<uint32_t *>(p + 4 * n);
+    uint32_t *fsum = reinterpret_cast<uint32_t *>(p + 4 * n + nbb);
+    uint32_t *totals = reinterpret_cast<uint32_t *>(p + 4 * n + 2 * nbb);          // [0] steps, [1] rays with a slab
+    float *tslab = reinterpret_cast<float *>(p + 4 * n + 2 * nbb + 256);
     const int nb = (int)scan_blocks(n_rays);
-    const dim3 rg((unsigned)((n_rays + 255) / 256));
+    const dim3 rg((unsigned)((n_rays + 255) / 256)), wg((unsigned)((n_rays + 3) / 4));
     const float *o = static_cast<const float *>(rays_o), *d = static_cast<const float *>(rays_d);
     const uint8_t *bits = static_cast<const uint8_t *>(bitfield);
-    hipLaunchKernelGGL(ngp_count_kernel, rg, dim3(256), 0, st, c, o, d, (long long)n_rays, bits, counts, startt);
+    hipLaunchKernelGGL(ngp_march_kernel, rg, dim3(256), 0, st, c, o, d, (long long)n_rays, bits, counts, tslab);
     hipLaunchKernelGGL(ngp_scan_block_kernel, dim3(nb), dim3(1024), 0, st, counts, (long long)n_rays, local, bsum);
     hipLaunchKernelGGL(ngp_scan_top_kernel, dim3(1), dim3(1024), 0, st, bsum, nb, totals);
-    hipLaunchKernelGGL(ngp_write_kernel, rg, dim3(256), 0, st, c, o, d, (long long)n_rays, bits, counts, startt, local, bsum, (long long)max_samples,
+    hipLaunchKernelGGL(ngp_expand_kernel, wg, dim3(256), 0, st, c, o, d, (long long)n_rays, counts, tslab, local, bsum, (long long)max_samples,
                        static_cast<float *>(coords), static_cast<int *>(numsteps), ray_index ? flags : nullptr);
     if (ray_index) {
         hipLaunchKernelGGL(ngp_scan_block_kernel, dim3(nb), dim3(1024), 0, st, flags, (long long)n_rays, flocal, fsum);

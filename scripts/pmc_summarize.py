@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"),
         out[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
 for k, cs in out.items():
-    if not any(s in k for s in ("march", "shade", "composite")):
+    if not any(s in k for s in ("march", "shade", "composite", "ngp_")):
         continue
     res[k] = {c: sum(v) / len(v) for c, v in sorted(cs.items())}
     res[k]["_dispatches"] = max(len(v) for v in cs.values())
