@@ -93,6 +93,17 @@ int tvr_ngp_network(const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const vo
 int tvr_ngp_composite(const void *net_out, const void *coords, const void *numsteps, int64_t n_rays, const float background[3],
                       void *rgb, void *stream);
 
+/* One frame = what Runner.render_img (runner.py:195-228) returns for these rays, without rows, network outputs or slabs in between:
+ * the march records each step's t, then one kernel walks every ray's steps 32 at a time through the encoders and networks and
+ * composites them in order, stopping at the sample where compute_rgbs_inference breaks (T < 1e-4) — the samples behind it
+ * contribute nothing, so their gathers and networks are skipped.  cfg->slab_rays = n_rays_per_batch reproduces the slab loop's
+ * jitter.  rgb [n_rays,3]; stats (optional, device) uint64[2] = (samples evaluated, samples marched).
+ * scratch: tvr_ngp_render_scratch_bytes(n_rays). */
+size_t tvr_ngp_render_scratch_bytes(int64_t n_rays);
+int tvr_ngp_render(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const void *net_packed, const void *rays_o,
+                   const void *rays_d, int64_t n_rays, const void *bitfield, const float background[3], void *rgb, void *stats,
+                   void *scratch, size_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -433,6 +433,15 @@ __global__ void __launch_bounds__(256) ngp_sh_encode_kernel(const float *__restr
 #ifndef TVR_NGP_MLP_F32
 #define TVR_NGP_MLP_F32 0
 #endif
+#ifndef TVR_NGP_INFLIGHT          // hash levels per lane whose 8 corner loads are issued together (2 -> 16 float2 loads in flight)
+#define TVR_NGP_INFLIGHT 2
+#endif
+#ifndef TVR_NGP_WAVES             // waves per SIMD the field kernel is compiled for
+#define TVR_NGP_WAVES 2
+#endif
+#ifndef TVR_NGP_XCD               // 1: every XCD (blockIdx % 8) works through its own contiguous eighth of the tiles
+#define TVR_NGP_XCD 0
+#endif
 enum { NGP_L_D0 = 0, NGP_L_D1 = 2 * 16 * 64, NGP_L_C0 = NGP_L_D1 + 32 * 64, NGP_L_C1 = NGP_L_C0 + 2 * 16 * 64, NGP_L_C2 = NGP_L_C1 + 2 * 32 * 64,
        NGP_IMAGE_FLOATS = NGP_L_C2 + 32 * 64 };
 // fp16 image: first block of each layer (blocks are m_block-major, then k-step)
@@ -551,8 +560,104 @@ __device__ __forceinline__ Frag relu_frag(const f32x16 &a0, const f32x16 &a1, in
     return split8(v);
 }
 
+// One 32-sample column block through the encoders and both networks.  Lane (col = lane%32, hh = lane/32) holds sample col's
+// position and direction; returns (rgb raw, density raw) of sample col in the lanes with hh == 0.  `lds_lane` = LDS image + lane.
 template <bool F16>
-__global__ void __launch_bounds__(256, 2) ngp_field_kernel(GridCfg g, const float *__restrict__ grid, const float *__restrict__ image,
+__device__ __forceinline__ float4 field_tile(const GridCfg &g, const float2 *__restrict__ tab, const float *__restrict__ lds_lane, int hh, float px, float py, float pz,
+                                             float dx, float dy, float dz)
+{
+    // ---- GATHER phase: lane half hh takes the hash levels of parity hh (8 levels x 8 corners)
+    float f0[8], f1[8], shv[8];
+    {
+        float sh[16];
+        sh16(dx, dy, dz, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) shv[j] = F16 ? (hh ? sh[8 + j] : sh[j]) : (hh ? sh[2 * j + 1] : sh[2 * j]);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const uint32_t o0 = hh ? g.offsets[2 * p + 1] : g.offsets[2 * p];
+        const uint32_t o1 = hh ? g.offsets[2 * p + 2] : g.offsets[2 * p + 1];
+        const float sc = hh ? g.scale[2 * p + 1] : g.scale[2 * p];
+        const bool hashed = (g.hashed >> (2 * p + hh)) & 1u;
+        const float2 r = encode_level(tab + o0, hashed, o1 - o0, sc, px, py, pz);
+        f0[p] = r.x;
+        f1[p] = r.y;
+        if ((p + 1) % TVR_NGP_INFLIGHT == 0) __builtin_amdgcn_sched_barrier(0);      // bounds the loads in flight (registers)
+    }
+    // ---- MATRIX phase
+    float density_raw;
+    f32x16 e = {0};
+    if (F16) {
+        const uint4 *w4 = reinterpret_cast<const uint4 *>(lds_lane);
+        f32x16 a0 = {0}, a1 = {0};
+        // density_mlp.0: 32 -> 64
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (j & 1) ? f1[4 * t + j / 2] : f0[4 * t + j / 2];
+            step2(w4, NGP_H_D0 + t, NGP_H_D0 + 2 + t, split8(v), a0, a1);
+        }
+        // density_mlp.2: relu, 64 -> 16
+        f32x16 d = {0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) step1(w4, NGP_H_D1 + t, relu_frag(a0, a1, t), d);
+        density_raw = d[0];
+        // rgb_mlp.0: [density(16), SH(16)] -> 64
+        a0 = (f32x16){0};
+        a1 = (f32x16){0};
+        {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = d[j];
+            step2(w4, NGP_H_C0 + 0, NGP_H_C0 + 2, split8(v), a0, a1);
+            step2(w4, NGP_H_C0 + 1, NGP_H_C0 + 3, split8(shv), a0, a1);
+        }
+        // rgb_mlp.2: relu, 64 -> 64
+        f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) step2(w4, NGP_H_C1 + t, NGP_H_C1 + 4 + t, relu_frag(a0, a1, t), c0, c1);
+        // rgb_mlp.4: relu, 64 -> 3
+#pragma unroll
+        for (int t = 0; t < 4; ++t) step1(w4, NGP_H_C2 + t, relu_frag(c0, c1, t), e);
+    } else {
+        const float *wl = lds_lane;
+        f32x16 a0 = {0}, a1 = {0};                              // the two 32-neuron blocks of a 64-wide layer
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float bv = (s & 1) ? f1[s >> 1] : f0[s >> 1];
+            a0 = MFMA(wl[NGP_L_D0 + (0 * 16 + s) * 64], bv, a0);
+            a1 = MFMA(wl[NGP_L_D0 + (1 * 16 + s) * 64], bv, a1);
+        }
+        f32x16 d = {0};
+#pragma unroll
+        for (int s = 0; s < 32; ++s) d = MFMA(wl[NGP_L_D1 + s * 64], relu_f(s < 16 ? a0[s & 15] : a1[s & 15]), d);
+        a0 = (f32x16){0};
+        a1 = (f32x16){0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float bv = s < 8 ? d[s & 7] : shv[s & 7];
+            a0 = MFMA(wl[NGP_L_C0 + (0 * 16 + s) * 64], bv, a0);
+            a1 = MFMA(wl[NGP_L_C0 + (1 * 16 + s) * 64], bv, a1);
+        }
+        density_raw = d[0];
+        f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float bv = relu_f(s < 16 ? a0[s & 15] : a1[s & 15]);
+            c0 = MFMA(wl[NGP_L_C1 + (0 * 32 + s) * 64], bv, c0);
+            c1 = MFMA(wl[NGP_L_C1 + (1 * 32 + s) * 64], bv, c1);
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) e = MFMA(wl[NGP_L_C2 + s * 64], relu_f(s < 16 ? c0[s & 15] : c1[s & 15]), e);
+    }
+    // rows 0..2 of the last layer and row 0 of the density head sit in accumulator regs 0..2 / 0 of the lower half-wave
+    return make_float4(e[0], e[1], e[2], density_raw);
+}
+
+template <bool F16>
+__global__ void __launch_bounds__(256, TVR_NGP_WAVES) ngp_field_kernel(GridCfg g, const float *__restrict__ grid, const float *__restrict__ image,
                                                            const float *__restrict__ positions, int pos_stride, const float *__restrict__ dirs, int dir_stride,
                                                            long long n_max, const uint32_t *__restrict__ n_dev, float4 *__restrict__ out)
 {
@@ -567,102 +672,104 @@ __global__ void __launch_bounds__(256, 2) ngp_field_kernel(GridCfg g, const floa
     const long long n_tiles = (n + 31) / 32;
     const float2 *__restrict__ tab = reinterpret_cast<const float2 *>(grid);
 
+#if TVR_NGP_XCD
+    // blocks are dealt round-robin to the 8 XCDs: XCD x = blockIdx % 8 walks tiles [x*T/8, (x+1)*T/8) so that neighbouring rays share an L2
+    const long long per_xcd = (n_tiles + 7) / 8, xcd = blockIdx.x & 7, t_end = min(n_tiles, (xcd + 1) * per_xcd);
+    for (long long tile = xcd * per_xcd + (long long)(blockIdx.x >> 3) * 4 + wave; tile < t_end; tile += (long long)(gridDim.x >> 3) * 4) {
+#else
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
-        // ---- GATHER phase: one column block of 32 samples; lane half hh takes the levels of parity hh (8 levels x 8 corners)
+#endif
         int hh = h, lane_off = lane;
-        asm volatile("" : "+v"(hh), "+v"(lane_off));                // opaque per tile: nothing below may be hoisted out of the loop
+        asm volatile("" : "+v"(hh), "+v"(lane_off));                // opaque per tile: nothing below may be hoisted out of the loop (registers)
         const long long sidx = tile * 32 + col;
         const long long srow = min(sidx, n - 1);
         const float *q = positions + pos_stride * srow, *qd = dirs + dir_stride * srow;
-        const float px = q[0], py = q[1], pz = q[2];
-        float f0[8], f1[8], shv[8];
-        {
-            float sh[16];
-            sh16(qd[0], qd[1], qd[2], sh);
+        const float4 r = field_tile<F16>(g, tab, lds + (F16 ? 4 : 1) * lane_off, hh, q[0], q[1], q[2], qd[0], qd[1], qd[2]);
+        if (h == 0 && sidx < n) out[sidx] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused frame kernel
+// render_img's picture without rows, network outputs or slabs in between: a wave takes a ray (dynamic queue), walks its recorded
+// steps 32 at a time through field_tile, composites them in order, and STOPS at the sample where compute_rgbs_inference breaks
+// (T < 1e-4): the samples behind it never contribute, so skipping their gathers and networks changes nothing.
+// T is advanced serially in sample order (the same multiplications as the reference's loop, so the break lands on the same
+// sample); colour is accumulated per lane and reduced once per ray (a different summation order: ~1e-7).
+template <bool F16>
+__global__ void __launch_bounds__(256, TVR_NGP_WAVES) ngp_render_kernel(MarchCfg c, GridCfg g, const float *__restrict__ grid, const float *__restrict__ image,
+                                                            const float *__restrict__ rays_o, const float *__restrict__ rays_d, long long n_rays,
+                                                            const uint32_t *__restrict__ counts, const float *__restrict__ tslab, unsigned long long *__restrict__ queue,
+                                                            float bg0, float bg1, float bg2, float *__restrict__ rgb, unsigned long long *__restrict__ evaluated)
+{
+    __shared__ float lds[NGP_IMAGE_FLOATS];
+    for (int e = threadIdx.x; e < NGP_IMAGE_FLOATS / 4; e += 256) reinterpret_cast<float4 *>(lds)[e] = reinterpret_cast<const float4 *>(image)[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, h = lane >> 5, col = lane & 31;
+    const float2 *__restrict__ tab = reinterpret_cast<const float2 *>(grid);
+    const float max_step = min_cone_step() * 16.0f;
+    unsigned long long done_samples = 0, all_samples = 0;
+    for (;;) {
+        unsigned long long ticket = 0;
+        if (lane == 0) ticket = atomicAdd(queue, 1ull);
+        const long long i = (long long)__shfl(ticket, 0, 64);
+        if (i >= n_rays) break;
+        const uint32_t n = counts[i];
+        all_samples += n;
+        const float o0 = rays_o[3 * i], o1 = rays_o[3 * i + 1], o2 = rays_o[3 * i + 2], d0 = rays_d[3 * i], d1 = rays_d[3 * i + 1], d2 = rays_d[3 * i + 2];
+        const float w0 = (d0 + 1.0f) * 0.5f, w1 = (d1 + 1.0f) * 0.5f, w2 = (d2 + 1.0f) * 0.5f;
+        const float *ts = tslab + (size_t)i * TVR_NGP_STEPS;
+        float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        bool broke = false;
+        for (uint32_t s0 = 0; s0 < n && !broke; s0 += 32) {
+            int hh = h, lane_off = lane;
+            asm volatile("" : "+v"(hh), "+v"(lane_off));            // opaque per tile (see ngp_field_kernel)
+            const uint32_t valid = min(32u, n - s0);
+            const float t = ts[min(s0 + (uint32_t)col, n - 1)];
+            const float x = __builtin_fmaf(t, d0, o0), y = __builtin_fmaf(t, d1, o1), z = __builtin_fmaf(t, d2, o2);
+            const float px = (x - c.lo[0]) / (c.hi[0] - c.lo[0]), py = (y - c.lo[1]) / (c.hi[1] - c.lo[1]), pz = (z - c.lo[2]) / (c.hi[2] - c.lo[2]);
+            const float4 r = field_tile<F16>(g, tab, lds + (F16 ? 4 : 1) * lane_off, hh, px, py, pz, w0, w1, w2);
+            // the row's dt as compute_rgbs_inference sees it: warped by the sampler, unwarped by the compositor
+            const float dtw = (calc_dt(c, t) - min_cone_step()) / (max_step - min_cone_step());
+            const float dt = dtw * (max_step - min_cone_step()) + min_cone_step();
+            const float alpha = 1.f - __expf(-__expf(r.w) * dt);
+            const int oma_bits = __float_as_int(1.f - alpha);
+            float Tk = 0.f;
+            bool live = false;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) shv[j] = F16 ? (hh ? sh[8 + j] : sh[j]) : (hh ? sh[2 * j + 1] : sh[2 * j]);
+            for (int k = 0; k < 32; ++k) {                          // uniform, in sample order
+                if ((uint32_t)k < valid && !broke) {
+                    if (T < 1e-4f) {
+                        broke = true;
+                    } else {
+                        if (lane == k) { Tk = T; live = true; }
+                        T *= __int_as_float(__builtin_amdgcn_readlane(oma_bits, k));
+                    }
+                }
+            }
+            if (live) {
+                const float w = alpha * Tk;
+                c0 += w * (1.0f / (1.0f + __expf(-r.x)));
+                c1 += w * (1.0f / (1.0f + __expf(-r.y)));
+                c2 += w * (1.0f / (1.0f + __expf(-r.z)));
+            }
+            done_samples += valid;
         }
-        // two levels per lane at a time: 16 float2 loads in flight, no more (registers)
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const uint32_t o0 = hh ? g.offsets[2 * p + 1] : g.offsets[2 * p];
-            const uint32_t o1 = hh ? g.offsets[2 * p + 2] : g.offsets[2 * p + 1];
-            const float sc = hh ? g.scale[2 * p + 1] : g.scale[2 * p];
-            const bool hashed = (g.hashed >> (2 * p + hh)) & 1u;
-            const float2 r = encode_level(tab + o0, hashed, o1 - o0, sc, px, py, pz);
-            f0[p] = r.x;
-            f1[p] = r.y;
-            if (p & 1) __builtin_amdgcn_sched_barrier(0);
+        for (int m = 16; m >= 1; m >>= 1) {                         // lanes 0..31 hold the partial sums
+            c0 += __shfl_xor(c0, m, 64);
+            c1 += __shfl_xor(c1, m, 64);
+            c2 += __shfl_xor(c2, m, 64);
         }
-        // ---- MATRIX phase
-        float density_raw;
-        f32x16 e = {0};
-        if (F16) {
-            const uint4 *w4 = reinterpret_cast<const uint4 *>(lds) + lane_off;
-            f32x16 a0 = {0}, a1 = {0};
-            // density_mlp.0: 32 -> 64
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (j & 1) ? f1[4 * t + j / 2] : f0[4 * t + j / 2];
-                step2(w4, NGP_H_D0 + t, NGP_H_D0 + 2 + t, split8(v), a0, a1);
-            }
-            // density_mlp.2: relu, 64 -> 16
-            f32x16 d = {0};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) step1(w4, NGP_H_D1 + t, relu_frag(a0, a1, t), d);
-            density_raw = d[0];
-            // rgb_mlp.0: [density(16), SH(16)] -> 64
-            a0 = (f32x16){0};
-            a1 = (f32x16){0};
-            {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = d[j];
-                step2(w4, NGP_H_C0 + 0, NGP_H_C0 + 2, split8(v), a0, a1);
-                step2(w4, NGP_H_C0 + 1, NGP_H_C0 + 3, split8(shv), a0, a1);
-            }
-            // rgb_mlp.2: relu, 64 -> 64
-            f32x16 c0 = {0}, c1 = {0};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) step2(w4, NGP_H_C1 + t, NGP_H_C1 + 4 + t, relu_frag(a0, a1, t), c0, c1);
-            // rgb_mlp.4: relu, 64 -> 3
-#pragma unroll
-            for (int t = 0; t < 4; ++t) step1(w4, NGP_H_C2 + t, relu_frag(c0, c1, t), e);
-        } else {
-            const float *wl = lds + lane_off;
-            f32x16 a0 = {0}, a1 = {0};                              // the two 32-neuron blocks of a 64-wide layer
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float bv = (s & 1) ? f1[s >> 1] : f0[s >> 1];
-                a0 = MFMA(wl[NGP_L_D0 + (0 * 16 + s) * 64], bv, a0);
-                a1 = MFMA(wl[NGP_L_D0 + (1 * 16 + s) * 64], bv, a1);
-            }
-            f32x16 d = {0};
-#pragma unroll
-            for (int s = 0; s < 32; ++s) d = MFMA(wl[NGP_L_D1 + s * 64], relu_f(s < 16 ? a0[s & 15] : a1[s & 15]), d);
-            a0 = (f32x16){0};
-            a1 = (f32x16){0};
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float bv = s < 8 ? d[s & 7] : shv[s & 7];
-                a0 = MFMA(wl[NGP_L_C0 + (0 * 16 + s) * 64], bv, a0);
-                a1 = MFMA(wl[NGP_L_C0 + (1 * 16 + s) * 64], bv, a1);
-            }
-            density_raw = d[0];
-            f32x16 c0 = {0}, c1 = {0};
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const float bv = relu_f(s < 16 ? a0[s & 15] : a1[s & 15]);
-                c0 = MFMA(wl[NGP_L_C1 + (0 * 32 + s) * 64], bv, c0);
-                c1 = MFMA(wl[NGP_L_C1 + (1 * 32 + s) * 64], bv, c1);
-            }
-#pragma unroll
-            for (int s = 0; s < 32; ++s) e = MFMA(wl[NGP_L_C2 + s * 64], relu_f(s < 16 ? c0[s & 15] : c1[s & 15]), e);
+        if (lane == 0) {
+            if (!broke) { c0 += T * bg0; c1 += T * bg1; c2 += T * bg2; }
+            rgb[3 * i] = c0;
+            rgb[3 * i + 1] = c1;
+            rgb[3 * i + 2] = c2;
         }
-        // rows 0..2 of the last layer and row 0 of the density head sit in accumulator regs 0..2 / 0 of the lower half-wave
-        if (h == 0 && sidx < n) out[sidx] = make_float4(e[0], e[1], e[2], density_raw);
+    }
+    if (evaluated && lane == 0) {
+        if (done_samples) atomicAdd(evaluated, done_samples);
+        if (all_samples) atomicAdd(evaluated + 1, all_samples);
     }
 }
 
@@ -869,7 +976,8 @@ int tvr_ngp_network(const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const vo
     if (!grid || !net_packed || !positions || !dirs || !out || misaligned(out) || misaligned(net_packed))
         return tvr_set_error(TVR_ERR_INVALID, "tvr_ngp_network: NULL or misaligned argument");
     const long long tiles = (n_max + 31) / 32;
-    const unsigned blocks = (unsigned)(tiles < 4 * 2048 ? (tiles + 3) / 4 : 2048);
+    unsigned blocks = (unsigned)(tiles < 4 * 2048 ? (tiles + 3) / 4 : 2048);
+    if (TVR_NGP_XCD) blocks = (blocks + 7) / 8 * 8;
     const bool f16 = !TVR_NGP_MLP_F32;
     hipLaunchKernelGGL(f16 ? ngp_field_kernel<true> : ngp_field_kernel<false>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g,
                        static_cast<const float *>(grid), static_cast<const float *>(net_packed) + (f16 ? NGP_IMAGE_FLOATS : 0), static_cast<const float *>(positions),
@@ -887,6 +995,45 @@ int tvr_ngp_composite(const void *net_out, const void *coords, const void *numst
     hipLaunchKernelGGL(ngp_composite_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float4 *>(net_out),
                        static_cast<const float *>(coords), static_cast<const int *>(numsteps), (long long)n_rays, background[0], background[1], background[2],
                        static_cast<float *>(rgb));
+    HIP_TRY(hipGetLastError());
+    return TVR_OK;
+}
+
+// scratch of the fused frame call: step counts [n], the ray queue + 2 statistics words, the t slabs [n, 1024]
+size_t tvr_ngp_render_scratch_bytes(int64_t n_rays)
+{
+    if (n_rays < 0) return 0;
+    return align_up((size_t)n_rays * 4, 256) + 256 + (size_t)n_rays * TVR_NGP_STEPS * sizeof(float);
+}
+
+int tvr_ngp_render(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const void *net_packed, const void *rays_o,
+                   const void *rays_d, int64_t n_rays, const void *bitfield, const float background[3], void *rgb, void *stats,
+                   void *scratch, size_t scratch_bytes, void *stream)
+{
+    MarchCfg c;
+    GridCfg g;
+    if (int rc = to_cfg(cfg, c)) return rc;
+    if (int rc = to_grid(grid_cfg, g)) return rc;
+    if (n_rays < 0 || n_rays > (1ll << 31) || !background) return tvr_set_error(TVR_ERR_INVALID, "tvr_ngp_render: n_rays out of range or background NULL");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (stats) HIP_TRY(hipMemsetAsync(stats, 0, 16, st));
+    if (n_rays == 0) return TVR_OK;
+    if (!grid || !net_packed || !rays_o || !rays_d || !bitfield || !rgb || misaligned(net_packed)) return tvr_set_error(TVR_ERR_INVALID, "tvr_ngp_render: NULL or misaligned argument");
+    if (scratch_bytes < tvr_ngp_render_scratch_bytes(n_rays) || !scratch || misaligned(scratch))
+        return tvr_set_error(TVR_ERR_SCRATCH, "tvr_ngp_render: scratch too small or misaligned (%zu < %zu)", scratch_bytes, tvr_ngp_render_scratch_bytes(n_rays));
+    char *p = static_cast<char *>(scratch);
+    const size_t n = align_up((size_t)n_rays * 4, 256);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(p);
+    unsigned long long *queue = reinterpret_cast<unsigned long long *>(p + n);
+    float *tslab = reinterpret_cast<float *>(p + n + 256);
+    HIP_TRY(hipMemsetAsync(queue, 0, 8, st));
+    const float *o = static_cast<const float *>(rays_o), *d = static_cast<const float *>(rays_d);
+    hipLaunchKernelGGL(ngp_march_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, c, o, d, (long long)n_rays, static_cast<const uint8_t *>(bitfield), counts, tslab);
+    const bool f16 = !TVR_NGP_MLP_F32;
+    const unsigned blocks = (unsigned)(n_rays < 4 * 512 ? (n_rays + 3) / 4 : 512);         // 256 CUs x 2 blocks (LDS image + 2 waves / SIMD)
+    hipLaunchKernelGGL(f16 ? ngp_render_kernel<true> : ngp_render_kernel<false>, dim3(blocks), dim3(256), 0, st, c, g, static_cast<const float *>(grid),
+                       static_cast<const float *>(net_packed) + (f16 ? NGP_IMAGE_FLOATS : 0), o, d, (long long)n_rays, counts, tslab, queue, background[0],
+                       background[1], background[2], static_cast<float *>(rgb), static_cast<unsigned long long *>(stats));
     HIP_TRY(hipGetLastError());
     return TVR_OK;
 }

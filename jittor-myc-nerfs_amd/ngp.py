@@ -313,10 +313,38 @@ class DensityGridSampler(torch.nn.Module):
         return rgb
 
     # -- one frame without the slab loop
-    def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, samples_per_ray_hint: int = 256, stats: Optional[dict] = None) -> torch.Tensor:
-        """The image `render_img` produces, in one pass: one march over all rays (each ray draws the jitter it would get in its
-        4096-ray slab), one fused network launch over all samples (count read on the device), one compositing launch.  The only
-        host read is the total at the end, to detect that the sample buffer was too small (then it is re-rendered larger)."""
+    def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, stats: Optional[dict] = None) -> torch.Tensor:
+        """The image `render_img` produces, in two launches and no host read (`tvr_ngp_render`): the march over all rays (each ray draws
+        the jitter it would get in its 4096-ray slab), then one kernel that walks every ray's steps through the encoders and networks
+        and composites them in order, stopping where `compute_rgbs_inference` breaks (T < 1e-4).  Nothing in between is materialised."""
+        dev = self.density_grid_bitfield.device
+        _need_gpu(self.density_grid_bitfield, "DensityGridSampler")
+        o = rays_o.detach().to(dev, torch.float32).contiguous()
+        d = rays_d.detach().to(dev, torch.float32).contiguous()
+        R = o.shape[0]
+        rgb = torch.empty(R, 3, device=dev)
+        need = L.lib().tvr_ngp_render_scratch_bytes(R)
+        if self._scratch is None or self._scratch.numel() < need or self._scratch.device != dev:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        st = torch.zeros(2, dtype=torch.int64, device=dev) if stats is not None else None
+        cfg = self._cfg(self.n_rays_per_batch)
+        bgc = (C.c_float * 3)(*self.background_color)
+        m = self.model
+        L.check(L.lib().tvr_ngp_render(C.byref(cfg), C.byref(m.pos_encoder.cfg), m.pos_encoder.m_grid.data_ptr(), m.packed().data_ptr(), o.data_ptr(), d.data_ptr(),
+                                       R, self.density_grid_bitfield.data_ptr(), C.byref(bgc), rgb.data_ptr(), None if st is None else st.data_ptr(),
+                                       self._scratch.data_ptr(), self._scratch.numel(), _stream(dev)), "tvr_ngp_render")
+        for _ in range((R + self.n_rays_per_batch - 1) // self.n_rays_per_batch):
+            self.rng.advance()                                          # as many advances as the slab loop would make
+        if stats is not None:
+            ev, tot = (int(v) for v in st.tolist())
+            stats.update(evaluated=ev, samples=tot)
+        return rgb
+
+    def render_frame_rows(self, rays_o: torch.Tensor, rays_d: torch.Tensor, samples_per_ray_hint: int = 256, stats: Optional[dict] = None) -> torch.Tensor:
+        """The same image through the three stand-alone entry points over the whole frame (rows of every step, network outputs of every
+        row, compositing): what `render_img` does without the slabs.  The only host read is the total at the end, to detect that the row
+        buffer was too small (then it is re-rendered larger).  Kept as the cross-check of `render_frame` and as the bulk user of the
+        row-level ABI."""
         R = rays_o.shape[0]
         state0 = (self.rng.state, self.rng.inc)
         cap = max(1, min(R * self.MAX_STEP, R * samples_per_ray_hint))

@@ -29,18 +29,25 @@ def main():
     poses = R.sphere_poses(8, 4.0)
     frames = [ngp.generate_rays(ngp.matrix_nerf2ngp(p), W, H, (focal, focal), device=dev) for p in poses[:a.frames]]
     stats = {}
-    sampler.render_frame(*frames[0], stats=stats)                      # warm-up (also sizes the sample buffer hint)
-    hint = int(stats["samples"] / (W * H) * 1.3) + 8
+    sampler.render_frame(*frames[0], stats=stats)                      # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tot = 0
     for o, d in frames:
-        img = sampler.render_frame(o, d, samples_per_ray_hint=hint, stats=stats)
-        tot += stats["samples"]
+        img = sampler.render_frame(o, d)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / len(frames)
-    print(f"NGP {W}x{H} frame, one pass: {dt * 1e3:.1f} ms / frame, {tot / len(frames) / 1e6:.1f} M samples / frame "
-          f"({tot / len(frames) / dt / 1e9:.2f} G samples/s, {W * H / dt / 1e6:.2f} M rays/s); rgb range {float(img.min()):.3f}..{float(img.max()):.3f}")
+    tot, ev = stats["samples"], stats["evaluated"]
+    print(f"NGP {W}x{H} frame, fused (march + render kernel): {dt * 1e3:.1f} ms / frame, {tot / 1e6:.1f} M samples marched, {ev / 1e6:.1f} M evaluated "
+          f"({tot / dt / 1e9:.2f} G marched samples/s, {W * H / dt / 1e6:.2f} M rays/s); rgb range {float(img.min()):.3f}..{float(img.max()):.3f}")
+    hint = int(tot / (W * H) * 1.3) + 8
+    sampler.render_frame_rows(*frames[0], samples_per_ray_hint=hint)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for o, d in frames:
+        sampler.render_frame_rows(o, d, samples_per_ray_hint=hint)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / len(frames)
+    print(f"NGP {W}x{H} frame, row-level one pass (sample + network + composite over all rows): {dt * 1e3:.1f} ms / frame ({tot / dt / 1e9:.2f} G samples/s)")
     if a.loop:
         torch.cuda.synchronize()
         t0 = time.perf_counter()

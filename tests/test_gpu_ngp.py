@@ -138,7 +138,8 @@ def test_composite_matches_oracle(setup):
 
 
 def test_render_img_and_render_frame(setup):
-    """runner.py's slab loop through the drop-in surface == the one-pass frame path (bit for bit) == the oracle (<= 1e-3)."""
+    """runner.py's slab loop through the drop-in surface == the row-level frame path (bit for bit) == the fused frame kernel (to summation
+    order) == the oracle (<= 1e-3)."""
     from jittor_myc_nerfs_amd import ngp
     from oracle import ngp_oracle as N
     model, sampler, levels, arrs, dev = setup
@@ -150,9 +151,17 @@ def test_render_img_and_render_frame(setup):
     after_loop = (sampler.rng.state, sampler.rng.inc)
     sampler.rng = ngp.Pcg32(1337)
     stats = {}
-    b = sampler.render_frame(to, td, samples_per_ray_hint=16, stats=stats)      # the hint is too small on purpose: exercises the retry
+    b = sampler.render_frame_rows(to, td, samples_per_ray_hint=16, stats=stats)  # the hint is too small on purpose: exercises the retry
     assert (sampler.rng.state, sampler.rng.inc) == after_loop
     assert stats["samples"] > 16 * W * H * 0.5 and torch.equal(a, b)
+    sampler.rng = ngp.Pcg32(1337)
+    fs = {}
+    c = sampler.render_frame(to, td, stats=fs)                         # fused: stops each ray where the compositor breaks
+    assert (sampler.rng.state, sampler.rng.inc) == after_loop
+    assert fs["samples"] == stats["samples"] and 0.2 * fs["samples"] < fs["evaluated"] < 0.9 * fs["samples"]
+    assert (a - c).abs().max().item() < 2e-6, "fused frame differs from the slab loop beyond summation order"
+    sampler.rng = ngp.Pcg32(1337)
+    assert torch.equal(sampler.render_frame(to, td), c)                # deterministic despite the dynamic ray queue
     want = N.render_img(arrs, levels, o, d, NGP_AABB_SCALE, N.Pcg32(1337))
     err = np.abs(a.cpu().numpy() - want).max()
     assert err < RGB_TOL, f"RGB L-inf vs oracle {err:.3e}"
