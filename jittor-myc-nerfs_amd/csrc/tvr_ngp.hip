@@ -709,62 +709,75 @@ __global__ void __launch_bounds__(256, TVR_NGP_WAVES) ngp_render_kernel(MarchCfg
     const float max_step = min_cone_step() * 16.0f;
     unsigned long long done_samples = 0, all_samples = 0;
     for (;;) {
+        // a ticket covers 64 consecutive rays: one atomic and one coalesced read of their step counts per 64 rays; rays without
+        // steps (a third of a typical frame) are finished right here
         unsigned long long ticket = 0;
         if (lane == 0) ticket = atomicAdd(queue, 1ull);
-        const long long i = (long long)__shfl(ticket, 0, 64);
-        if (i >= n_rays) break;
-        const uint32_t n = counts[i];
-        all_samples += n;
-        const float o0 = rays_o[3 * i], o1 = rays_o[3 * i + 1], o2 = rays_o[3 * i + 2], d0 = rays_d[3 * i], d1 = rays_d[3 * i + 1], d2 = rays_d[3 * i + 2];
-        const float w0 = (d0 + 1.0f) * 0.5f, w1 = (d1 + 1.0f) * 0.5f, w2 = (d2 + 1.0f) * 0.5f;
-        const float *ts = tslab + (size_t)i * TVR_NGP_STEPS;
-        float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
-        bool broke = false;
-        for (uint32_t s0 = 0; s0 < n && !broke; s0 += 32) {
-            int hh = h, lane_off = lane;
-            asm volatile("" : "+v"(hh), "+v"(lane_off));            // opaque per tile (see ngp_field_kernel)
-            const uint32_t valid = min(32u, n - s0);
-            const float t = ts[min(s0 + (uint32_t)col, n - 1)];
-            const float x = __builtin_fmaf(t, d0, o0), y = __builtin_fmaf(t, d1, o1), z = __builtin_fmaf(t, d2, o2);
-            const float px = (x - c.lo[0]) / (c.hi[0] - c.lo[0]), py = (y - c.lo[1]) / (c.hi[1] - c.lo[1]), pz = (z - c.lo[2]) / (c.hi[2] - c.lo[2]);
-            const float4 r = field_tile<F16>(g, tab, lds + (F16 ? 4 : 1) * lane_off, hh, px, py, pz, w0, w1, w2);
-            // the row's dt as compute_rgbs_inference sees it: warped by the sampler, unwarped by the compositor
-            const float dtw = (calc_dt(c, t) - min_cone_step()) / (max_step - min_cone_step());
-            const float dt = dtw * (max_step - min_cone_step()) + min_cone_step();
-            const float alpha = 1.f - __expf(-__expf(r.w) * dt);
-            const int oma_bits = __float_as_int(1.f - alpha);
-            float Tk = 0.f;
-            bool live = false;
+        const long long first = (long long)__shfl(ticket, 0, 64) * 64;
+        if (first >= n_rays) break;
+        const long long mine = first + lane;
+        const uint32_t my_n = mine < n_rays ? counts[mine] : 0u;
+        if (mine < n_rays && my_n == 0) {
+            rgb[3 * mine] = bg0;
+            rgb[3 * mine + 1] = bg1;
+            rgb[3 * mine + 2] = bg2;
+        }
+        unsigned long long todo = __ballot(my_n != 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const long long i = first + src;
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)my_n, src);
+            all_samples += n;
+            const float o0 = rays_o[3 * i], o1 = rays_o[3 * i + 1], o2 = rays_o[3 * i + 2], d0 = rays_d[3 * i], d1 = rays_d[3 * i + 1], d2 = rays_d[3 * i + 2];
+            const float w0 = (d0 + 1.0f) * 0.5f, w1 = (d1 + 1.0f) * 0.5f, w2 = (d2 + 1.0f) * 0.5f;
+            const float *ts = tslab + (size_t)i * TVR_NGP_STEPS;
+            float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            bool broke = false;
+            for (uint32_t s0 = 0; s0 < n && !broke; s0 += 32) {
+                int hh = h, lane_off = lane;
+                asm volatile("" : "+v"(hh), "+v"(lane_off));        // opaque per tile (see ngp_field_kernel)
+                const uint32_t valid = min(32u, n - s0);
+                const float t = ts[min(s0 + (uint32_t)col, n - 1)];
+                const float x = __builtin_fmaf(t, d0, o0), y = __builtin_fmaf(t, d1, o1), z = __builtin_fmaf(t, d2, o2);
+                const float px = (x - c.lo[0]) / (c.hi[0] - c.lo[0]), py = (y - c.lo[1]) / (c.hi[1] - c.lo[1]), pz = (z - c.lo[2]) / (c.hi[2] - c.lo[2]);
+                const float4 r = field_tile<F16>(g, tab, lds + (F16 ? 4 : 1) * lane_off, hh, px, py, pz, w0, w1, w2);
+                // the row's dt as compute_rgbs_inference sees it: warped by the sampler, unwarped by the compositor
+                const float dtw = (calc_dt(c, t) - min_cone_step()) / (max_step - min_cone_step());
+                const float dt = dtw * (max_step - min_cone_step()) + min_cone_step();
+                const float alpha = 1.f - __expf(-__expf(r.w) * dt);
+                const int oma_bits = __float_as_int(1.f - alpha);
+                // T before each sample, multiplied up serially in sample order (the reference's products, so the break lands on the
+                // same sample); branch-free: the break is located afterwards
+                float Tk = 0.f;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {                          // uniform, in sample order
-                if ((uint32_t)k < valid && !broke) {
-                    if (T < 1e-4f) {
-                        broke = true;
-                    } else {
-                        if (lane == k) { Tk = T; live = true; }
-                        T *= __int_as_float(__builtin_amdgcn_readlane(oma_bits, k));
-                    }
+                for (int k = 0; k < 32; ++k) {
+                    Tk = lane == k ? T : Tk;
+                    T *= (uint32_t)k < valid ? __int_as_float(__builtin_amdgcn_readlane(oma_bits, k)) : 1.0f;   // lanes past the ray's end hold a repeat of its last step
                 }
+                const unsigned long long dead = __ballot(h == 0 && (uint32_t)col < valid && Tk < 1e-4f);   // T is non-increasing: a prefix survives
+                const uint32_t n_live = dead ? (uint32_t)(__ffsll((long long)dead) - 1) : valid;
+                broke = dead != 0;
+                if (h == 0 && (uint32_t)col < n_live) {
+                    const float w = alpha * Tk;
+                    c0 += w * (1.0f / (1.0f + __expf(-r.x)));
+                    c1 += w * (1.0f / (1.0f + __expf(-r.y)));
+                    c2 += w * (1.0f / (1.0f + __expf(-r.z)));
+                }
+                done_samples += valid;
             }
-            if (live) {
-                const float w = alpha * Tk;
-                c0 += w * (1.0f / (1.0f + __expf(-r.x)));
-                c1 += w * (1.0f / (1.0f + __expf(-r.y)));
-                c2 += w * (1.0f / (1.0f + __expf(-r.z)));
-            }
-            done_samples += valid;
-        }
 #pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) {                         // lanes 0..31 hold the partial sums
-            c0 += __shfl_xor(c0, m, 64);
-            c1 += __shfl_xor(c1, m, 64);
-            c2 += __shfl_xor(c2, m, 64);
-        }
-        if (lane == 0) {
-            if (!broke) { c0 += T * bg0; c1 += T * bg1; c2 += T * bg2; }
-            rgb[3 * i] = c0;
-            rgb[3 * i + 1] = c1;
-            rgb[3 * i + 2] = c2;
+            for (int m = 16; m >= 1; m >>= 1) {                     // lanes 0..31 hold the partial sums
+                c0 += __shfl_xor(c0, m, 64);
+                c1 += __shfl_xor(c1, m, 64);
+                c2 += __shfl_xor(c2, m, 64);
+            }
+            if (lane == 0) {
+                if (!broke) { c0 += T * bg0; c1 += T * bg1; c2 += T * bg2; }
+                rgb[3 * i] = c0;
+                rgb[3 * i + 1] = c1;
+                rgb[3 * i + 2] = c2;
+            }
         }
     }
     if (evaluated && lane == 0) {
