@@ -168,6 +168,45 @@ def test_render_img_and_render_frame(setup):
     assert want.std() > 0.05                                           # a picture, not a constant
 
 
+@pytest.mark.parametrize("aabb_scale", [1, 2, 16])
+def test_other_aabb_scales(aabb_scale):
+    """Other level tables (the dense / hashed boundary falls inside a lane pair at aabb_scale 1) and other boxes for the march."""
+    from jittor_myc_nerfs_amd import ngp
+    from oracle import ngp_oracle as N
+    dev = torch.device("cuda:0")
+    levels = N.grid_levels(aabb_scale)
+    rng = np.random.default_rng(aabb_scale)
+    model = ngp.NGPNetworks(aabb_scale).to(dev)
+    assert np.array_equal(model.pos_encoder.offsets, levels["offsets"]) and np.array_equal(model.pos_encoder.scale, levels["scale"])
+    grid = rng.uniform(-1, 1, int(levels["offsets"][-1]) * 2).astype(np.float32)
+    arrs = {"grid": grid}
+    for name, shape in (("density_mlp.0", (64, 32)), ("density_mlp.2", (16, 64)), ("rgb_mlp.0", (64, 32)), ("rgb_mlp.2", (64, 64)), ("rgb_mlp.4", (3, 64))):
+        arrs[name + ".weight"] = rng.uniform(-0.3, 0.3, shape).astype(np.float32)
+    ngp.load_scene_arrays(model, None, arrs)
+    pos = rng.random((4096, 3), dtype=np.float32)
+    pos[:3] = [[0, 0, 0], [1, 1, 1], [1, 0, 1]]
+    want = N.hash_encode_c(levels, grid, pos)
+    assert np.array_equal(model.pos_encoder(torch.from_numpy(pos).to(dev)).cpu().numpy().view(np.uint32), want.view(np.uint32))
+    coords = np.concatenate([pos, np.zeros((4096, 1), np.float32), rng.random((4096, 3), dtype=np.float32)], 1)
+    c = torch.from_numpy(coords).to(dev)
+    ref = N.network_c(levels, arrs, coords)
+    assert np.abs(model(c[:, :3], c[:, 4:]).cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    if aabb_scale == 16:
+        return                                                         # the sampler allows aabb_scale <= 16 and is covered at 1, 2, 4
+    # a random occupancy bitfield and rays from outside / inside the box
+    bits = rng.integers(0, 256, 5 * 128 ** 3 // 8, dtype=np.uint8) & rng.integers(0, 256, 5 * 128 ** 3 // 8, dtype=np.uint8) & rng.integers(0, 256, 5 * 128 ** 3 // 8, dtype=np.uint8)
+    sampler = ngp.DensityGridSampler(model, aabb_scale, rng=ngp.Pcg32(99)).to(dev)
+    sampler.density_grid_bitfield.copy_(torch.from_numpy(bits))
+    o = (rng.random((600, 3), dtype=np.float32) - 0.5) * (2.5 * aabb_scale) + 0.5
+    d = rng.standard_normal((600, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:300] = (0.5 - o[:300]) / np.linalg.norm(0.5 - o[:300], axis=1, keepdims=True)      # aimed at the centre
+    want = N.sample(o, d, bits, aabb_scale, N.Pcg32(99).state)
+    sampler.sample(None, torch.from_numpy(o), torch.from_numpy(d))
+    assert np.array_equal(sampler._rays_numsteps.cpu().numpy(), want[2]) and want[2][:, 0].max() > 100
+    assert np.array_equal(sampler._coords.cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+
+
 def test_against_committed_golden(setup):
     """tests/golden/ngp.npz (make_golden_ngp.py): sampler rows bit for bit (digest), network / picture to tolerance."""
     import hashlib
