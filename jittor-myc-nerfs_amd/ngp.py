@@ -423,3 +423,67 @@ def load_scene_arrays(model: NGPNetworks, sampler: Optional[DensityGridSampler],
                 sampler.density_grid_bitfield.copy_(torch.as_tensor(arrs["density_grid_bitfield"]))
             elif sampler.density_grid.is_cuda:
                 sampler.update_bitfield()
+
+
+# ------------------------------------------------------------------------------------------------------------------ formats either side
+def load_jnerf_checkpoint(path: str, model: NGPNetworks, sampler: Optional[DensityGridSampler] = None) -> int:
+    """`Runner.load_ckpt` (runner/runner.py:137-144) for inference: the file `Runner.save_ckpt` (:127-135) writes with `jt.save` is a pickle
+    of `{'global_step', 'model': state_dict, 'sampler': state_dict, optimizer states...}` with every jt.Var turned into a numpy array
+    (Jittor's published behaviour, restated; Jittor itself is absent here).  Fills `model` from `ckpt['model']` (`pos_encoder.m_grid`,
+    `density_mlp.{0,2}.weight`, `rgb_mlp.{0,2,4}.weight`) and `sampler` from `ckpt['sampler']` (`density_grid`, `density_grid_bitfield`,
+    `density_grid_mean`); fp16 checkpoints (`fp16 = True` configs) are widened to fp32.  Returns `global_step`."""
+    import pickle
+    with open(path, "rb") as f:
+        ckpt = pickle.load(f)
+    m = {k: np.asarray(v) for k, v in ckpt["model"].items()}
+    want = {"pos_encoder.m_grid": (model.pos_encoder.m_n_params,), "density_mlp.0.weight": (64, 32), "density_mlp.2.weight": (16, 64),
+            "rgb_mlp.0.weight": (64, 32), "rgb_mlp.2.weight": (64, 64), "rgb_mlp.4.weight": (3, 64)}
+    for k, shape in want.items():
+        if k not in m:
+            raise KeyError(f"{path}: 'model' has no '{k}' (FullyFusedMlp checkpoints keep their weights in `con_weights`; not supported)")
+        if tuple(m[k].shape) != shape:
+            raise ValueError(f"{path}: {k} has shape {tuple(m[k].shape)}, this model (aabb_scale {model.pos_encoder.aabb_scale}) needs {shape}")
+    load_scene_arrays(model, None, {k: m[k].astype(np.float32) for k in want})
+    if sampler is not None and "sampler" in ckpt:
+        s = {k: np.asarray(v) for k, v in ckpt["sampler"].items()}
+        with torch.no_grad():
+            for k in ("density_grid", "density_grid_bitfield", "density_grid_mean"):
+                if k in s:
+                    buf = getattr(sampler, k)
+                    buf.copy_(torch.as_tensor(s[k].reshape(-1)[:buf.numel()].astype(np.uint8 if k.endswith("bitfield") else np.float32)).reshape(buf.shape))
+    return int(ckpt.get("global_step", 0))
+
+
+class NerfRays:
+    """Test-set rays of a `NerfDataset` (dataset/dataset.py:82-228, mode 'test', `have_img=False`): `transforms_test.json` in the NeRF
+    synthetic format -> NGP-convention camera matrices (`matrix_nerf2ngp`: `correct_pose`, `scale`, `offset`, axis cycle) and focal
+    lengths (`fl_x` / `camera_angle_x`, :187-203); `rays(i)` is `generate_rays_total_test` for image i."""
+
+    def __init__(self, root_dir: str, mode: str = "test", H: int = 800, W: int = 800, correct_pose=(1, -1, -1), aabb_scale: Optional[int] = None,
+                 scale: Optional[float] = None, offset=None, device=None):
+        import json
+        import os
+        with open(os.path.join(root_dir, f"transforms_{mode}.json")) as f:
+            meta = json.load(f)
+        self.H, self.W, self.device = int(meta.get("h", H)), int(meta.get("w", W)), device
+        self.scale = NERF_SCALE if scale is None else scale
+        self.offset = [0.5, 0.5, 0.5] if offset is None else offset
+        self.aabb_scale = meta.get("aabb_scale", 1) if aabb_scale is None else aabb_scale
+        self.aabb_range = (0.5 - self.aabb_scale / 2, 0.5 + self.aabb_scale / 2)
+
+        def focal(res, axis):
+            if "fl_" + axis in meta:
+                return float(meta["fl_" + axis])
+            if "camera_angle_" + axis in meta:
+                return fov_to_focal_length(res, meta["camera_angle_" + axis] * 180 / math.pi)
+            return 0.0
+        fx, fy = focal(self.W, "x"), focal(self.H, "y")
+        if fx == 0 and fy == 0:
+            raise RuntimeError("Couldn't read fov.")
+        self.focal = (fx or fy, fy or fx)
+        self.principal = (meta.get("cx", self.W / 2) / self.W, meta.get("cy", self.H / 2) / self.H)
+        self.transforms = [matrix_nerf2ngp(np.asarray(fr["transform_matrix"], np.float32), self.scale, self.offset, correct_pose) for fr in meta["frames"]]
+        self.n_images = len(self.transforms)
+
+    def rays(self, img_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        return generate_rays(self.transforms[img_id], self.W, self.H, self.focal, self.principal, device=self.device)
