@@ -715,7 +715,12 @@ __global__ void __launch_bounds__(256, TVR_NGP_WAVES) ngp_render_kernel(MarchCfg
         if (lane == 0) ticket = atomicAdd(queue, 1ull);
         const long long first = (long long)__shfl(ticket, 0, 64) * 64;
         if (first >= n_rays) break;
+#ifdef TVR_NGP_TILE_W                 // experiment: a ticket is an 8x8 pixel tile of a TVR_NGP_TILE_W-wide image instead of 64 consecutive rays
+        const long long tk = first / 64, tpr = TVR_NGP_TILE_W / 8;
+        const long long mine = ((tk / tpr) * 8 + (lane >> 3)) * TVR_NGP_TILE_W + (tk % tpr) * 8 + (lane & 7);
+#else
         const long long mine = first + lane;
+#endif
         const uint32_t my_n = mine < n_rays ? counts[mine] : 0u;
         if (mine < n_rays && my_n == 0) {
             rgb[3 * mine] = bg0;
@@ -726,7 +731,7 @@ __global__ void __launch_bounds__(256, TVR_NGP_WAVES) ngp_render_kernel(MarchCfg
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const long long i = first + src;
+            const long long i = __shfl(mine, src, 64);
             const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)my_n, src);
             all_samples += n;
             const float o0 = rays_o[3 * i], o1 = rays_o[3 * i + 1], o2 = rays_o[3 * i + 2], d0 = rays_d[3 * i], d1 = rays_d[3 * i + 1], d2 = rays_d[3 * i + 2];
