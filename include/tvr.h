@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 106
+#define TVR_VERSION 107
 
 typedef enum {
     TVR_OK = 0,
@@ -212,6 +212,35 @@ int tvr_profile_reset(tvr_profile *prof);
 /* After the stream is synchronised: sums over recorded calls, ms[0..2] = march, shade, composite; returns #calls. */
 int tvr_profile_read(tvr_profile *prof, float ms[3]);
 int tvr_profile_destroy(tvr_profile *prof);
+
+/* ---- NerfPlusPlus background network: `Embedder` + `MLPNet.forward`, models/nerfplusplus.py:7-56, 66-140, as
+ * evaluated by `NerfPlusPlus.execute` on the background samples (:280-302).  W = 128, D base layers with one skip, sigma = |Linear|,
+ * rgb = sigmoid(Linear(relu(Linear([base_remap, view embedding])))).  `base_remap` (Linear 128->256) has no activation behind it:
+ * the caller folds it into the first rgb layer (rgbh_W_base = W_rgb0[:, :256] @ W_remap, rgbh_b = W_rgb0[:, :256] @ b_remap + b_rgb0). */
+typedef struct tvr_mlpnet_desc {
+    int32_t D;                  /* base layers (bg_D; 2..4) */
+    int32_t W;                  /* 128 (nerfplusplus.py:159) */
+    int32_t skip;               /* `skips=[int(bg_D/2)]`: after base layer `skip` the point embedding is concatenated in front */
+    int32_t pos_freqs;          /* bg_freq: the 4-vector point gets 4 + 8*pos_freqs inputs */
+    int32_t view_freqs;         /* bg_view_freq (2): 3 + 6*view_freqs inputs */
+    int32_t samples_per_ray;    /* sample s uses viewdirs[s / samples_per_ray] */
+} tvr_mlpnet_desc;
+
+typedef struct tvr_mlpnet_params {   /* fp32 device pointers, row-major [out,in] as torch / Jittor Linear */
+    const void *base_W[4], *base_b[4];
+    const void *sigma_W, *sigma_b;   /* [1,128], [1] */
+    const void *rgbh_W_base;         /* [64,128]  (folded, see above) */
+    const void *rgbh_W_view;         /* [64,15] = W_rgb0[:, 256:] */
+    const void *rgbh_b;              /* [64] */
+    const void *rgbo_W, *rgbo_b;     /* [3,64], [3] */
+} tvr_mlpnet_params;
+
+size_t tvr_mlpnet_packed_bytes(const tvr_mlpnet_desc *desc);
+/* builds the MFMA fragment image (synchronises the stream once: packing is an explicit, rare call) */
+int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *params, void *packed, size_t packed_bytes, void *stream);
+/* pts [n,4] (inverted-sphere points, depth2pts_outside), viewdirs [ceil(n / samples_per_ray), 3] -> rgb [n,3] (sigmoid applied), sigma [n] (abs applied) */
+int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
+                       void *sigma, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,15 @@ class DenseOut(C.Structure):
                                           "weight", "rgb", "bg_weight", "acc", "t_min")]
 
 
+class MlpnetDesc(C.Structure):           # tvr_mlpnet_desc
+    _fields_ = [(n, C.c_int32) for n in ("D", "W", "skip", "pos_freqs", "view_freqs", "samples_per_ray")]
+
+
+class MlpnetParams(C.Structure):         # tvr_mlpnet_params
+    _fields_ = [("base_W", C.c_void_p * 4), ("base_b", C.c_void_p * 4), ("sigma_W", C.c_void_p), ("sigma_b", C.c_void_p), ("rgbh_W_base", C.c_void_p),
+                ("rgbh_W_view", C.c_void_p), ("rgbh_b", C.c_void_p), ("rgbo_W", C.c_void_p), ("rgbo_b", C.c_void_p)]
+
+
 class NgpMarchCfg(C.Structure):          # tvr_ngp_march_cfg (include/tvr_ngp.h)
     _fields_ = [("aabb_lo", C.c_float * 3), ("aabb_hi", C.c_float * 3), ("near_distance", C.c_float), ("cone_angle", C.c_float),
                 ("const_dt", C.c_int32), ("rng_state", C.c_uint64), ("rng_inc", C.c_uint64), ("slab_rays", C.c_uint32)]
@@ -99,6 +108,9 @@ SYMBOLS = {
     "tvr_profile_reset": (C.c_int, [C.c_void_p]),
     "tvr_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3)]),
     "tvr_profile_destroy": (C.c_int, [C.c_void_p]),
+    "tvr_mlpnet_packed_bytes": (C.c_size_t, [C.POINTER(MlpnetDesc)]),
+    "tvr_mlpnet_pack": (C.c_int, [C.POINTER(MlpnetDesc), C.POINTER(MlpnetParams), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_mlpnet_forward": (C.c_int, [C.POINTER(MlpnetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     # include/tvr_ngp.h
     "tvr_ngp_update_bitfield": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_ngp_sample_scratch_bytes": (C.c_size_t, [C.c_int64]),

@@ -1,0 +1,365 @@
+// tvr_bg.hip — NerfPlusPlus's background network as ONE kernel (second half): `Embedder` (nerfplusplus.py:7-56) of the
+// inverted-sphere points and of the view directions + `MLPNet.forward` (:66-140) — what `NerfPlusPlus.execute` evaluates on 512
+// background samples per ray (:280-302), i.e. 328 M samples per 800x800 frame.
+//
+// Network (W = 128): base layers Linear+ReLU x D (layer 0 from the point embedding, the layer after the skip from
+// cat(embedding, base)), sigma = |Linear(128,1)|, base_remap Linear(128,256), rgb = sigmoid(Linear(64,3)(relu(Linear(256+view,64)))).
+// base_remap has no activation behind it, so the host folds it into the first rgb layer (W_eff = W_rgb0[:, :256] W_remap, fp64 on
+// the host): 128 -> 64 instead of 128 -> 256 -> 64, a third of the network's multiply-adds gone, same function.
+//
+// Kernel: a workgroup of 8 waves, one per SIMD pair, each wave carrying 32 samples through all layers with activations
+// register-resident (tvr_mfma.h: fp16 hi/lo split, 3 products, accumulator layout == next layer's B layout).  The weight image
+// (up to 300 KB as hi/lo fragments) does not fit the 160 KB LDS, so the layers are cut into two stages; the workgroup switches the
+// LDS image between them (two barriers per stage), every wave keeping its 128 activations in registers across the switch.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <vector>
+#include "tvr_kernels.h"
+#include "tvr_mfma.h"
+
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return tvr_set_error(TVR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define BG_MAX_BLOCKS 77                      // fragment blocks (2 KiB each) per stage image
+#define BG_BIAS_FLOATS 640                    // 4 x 128 base biases, 64 rgb-hidden, sigma, 3 rgb (padded)
+#define BG_LDS_BYTES (BG_MAX_BLOCKS * 2048 + BG_BIAS_FLOATS * 4)
+#define BG_WAVES 8
+
+struct BgProgram {
+    int D, n_pe_steps, input_ch, split;       // base layers [0, split) run from stage A, the rest and the heads from stage B
+    int blocksA, blocksB;                     // blocks per stage (<= BG_MAX_BLOCKS); stage B's image follows stage A's in global memory
+    int base_block0[4];                       // first block of each base layer inside its stage
+    int base_prev[4], base_pe[4];             // does the layer read the previous activations / the point embedding
+    int sig_block0, rgbh_block0, rgbo_block0; // inside stage B
+    int samples_per_ray;
+};
+
+// ------------------------------------------------------------------------------------------------ packing
+struct PackBlock {
+    const float *W;      // [n_out, ld] row-major
+    int ld, n_out, row0; // rows row0 .. row0+31 of W
+    int kind, t, koff;   // how lane (h, j) maps to a column of W (see bg_pack_kernel)
+    int n_valid;         // columns >= koff + n_valid are padding (kind PE / VIEW)
+};
+enum { K_PREV = 0, K_PE = 1, K_VIEW = 2 };
+
+__global__ void __launch_bounds__(64) bg_pack_kernel(const PackBlock *__restrict__ blocks, uint4 *__restrict__ image)
+{
+    const PackBlock b = blocks[blockIdx.x];
+    const int l = threadIdx.x, h = l >> 5, row = b.row0 + (l & 31);
+    float v[8];
+    for (int j = 0; j < 8; ++j) {
+        int k, ok = 1;
+        if (b.kind == K_PREV) k = (b.t / 2) * 32 + (2 * (b.t & 1) + j / 4) * 8 + 4 * h + (j & 3);     // accumulator order of a 32-neuron block pair
+        else if (b.kind == K_PE) { k = 16 * b.t + 8 * h + j; ok = k < b.n_valid; }
+        else { k = 8 * h + j; ok = k < b.n_valid; }
+        v[j] = (ok && row < b.n_out) ? b.W[(size_t)row * b.ld + b.koff + k] : 0.f;
+    }
+    const Frag f = split8(v);
+    image[((size_t)blockIdx.x * 2 + 0) * 64 + l] = f.hi;
+    image[((size_t)blockIdx.x * 2 + 1) * 64 + l] = f.lo;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel
+// Embedder feature f of a 4-vector x (nerfplusplus.py:36-56: [x, sin(x f0), cos(x f0), sin(x f1), ...], f_q = 2^q)
+__device__ __forceinline__ float pe_feature(int f, const float x[4])
+{
+    if (f < 4) return x[f];
+    const int g = f - 4, q = g >> 3, r = g & 7;
+    const float a = x[r & 3] * (float)(1 << q);
+    return r < 4 ? __sinf(a) : __cosf(a);
+}
+__device__ __forceinline__ Frag pe_frag(int t, int hh, const float x[4])
+{
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float lo = pe_feature(16 * t + j, x), hi = pe_feature(16 * t + 8 + j, x);
+        v[j] = hh ? hi : lo;
+    }
+    return split8(v);
+}
+// B fragment of k-step t (0..7) of a 128-wide activation held in four accumulators, relu applied
+__device__ __forceinline__ Frag relu_frag4(const f32x16 a[4], int t)
+{
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = relu_f(a[t >> 1][8 * (t & 1) + j]);
+    return split8(v);
+}
+__device__ __forceinline__ f32x16 bias_acc(const float *__restrict__ bias32, int hh)
+{
+    // accumulator register i <-> neuron (i/4)*8 + 4h + i%4 of the block
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4 *>(bias32 + q * 8 + 4 * hh);
+        a[4 * q] = b.x; a[4 * q + 1] = b.y; a[4 * q + 2] = b.z; a[4 * q + 3] = b.w;
+    }
+    return a;
+}
+// one k-step into NB accumulators (independent blocks: their MFMAs interleave)
+template <int NB>
+__device__ __forceinline__ void kstep(const uint4 *__restrict__ w4, const int (&blk)[NB], const Frag &b, f32x16 (&acc)[NB])
+{
+    uint4 ah[NB], al[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+        ah[m] = w4[(blk[m] * 2 + 0) * 64];
+        al[m] = w4[(blk[m] * 2 + 1) * 64];
+    }
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(al[m], b.hi, acc[m]);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(ah[m], b.lo, acc[m]);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(ah[m], b.hi, acc[m]);
+}
+
+__device__ __forceinline__ void load_stage(uint4 *__restrict__ lds4, const uint4 *__restrict__ image, int n_blocks)
+{
+    const int n = n_blocks * 128;
+    for (int e = threadIdx.x; e < n; e += BG_WAVES * 64) lds4[e] = image[e];
+}
+
+__global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, const uint4 *__restrict__ image, const float *__restrict__ bias,
+                                                                 const float *__restrict__ pts, const float *__restrict__ viewdirs, long long M,
+                                                                 float *__restrict__ rgb, float *__restrict__ sigma)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *lds4 = reinterpret_cast<uint4 *>(smem);
+    float *lbias = reinterpret_cast<float *>(smem + BG_MAX_BLOCKS * 2048);
+    for (int e = threadIdx.x; e < BG_BIAS_FLOATS; e += BG_WAVES * 64) lbias[e] = bias[e];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+    const long long n_super = (M + 32 * BG_WAVES - 1) / (32 * BG_WAVES);
+    const uint4 *imgA = image, *imgB = image + (size_t)P.blocksA * 128;
+
+    for (long long super = blockIdx.x; super < n_super; super += gridDim.x) {
+        int hh = h, lane_off = lane;
+        asm volatile("" : "+v"(hh), "+v"(lane_off));                // opaque per tile: keeps per-lane selects / LDS reads from being hoisted
+        const long long s = (super * BG_WAVES + wave) * 32 + col, sr = min(s, M - 1);
+        float x[4], d[3];
+        {
+            const float4 p = *reinterpret_cast<const float4 *>(pts + 4 * sr);
+            x[0] = p.x; x[1] = p.y; x[2] = p.z; x[3] = p.w;
+            const float *v = viewdirs + 3 * (sr / P.samples_per_ray);
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2];
+        }
+        const uint4 *w4 = lds4 + lane_off;
+        f32x16 act[4];
+
+        // ---------------- base layers; the LDS image switches from stage A to stage B at layer P.split
+        __syncthreads();                                             // everyone is done with the previous tile's stage B
+        load_stage(lds4, imgA, P.blocksA);
+        __syncthreads();
+        for (int l = 0; l < P.D; ++l) {
+            if (l == P.split) {
+                __syncthreads();
+                load_stage(lds4, imgB, P.blocksB);
+                __syncthreads();
+            }
+            f32x16 out[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) out[mb] = bias_acc(lbias + l * 128 + mb * 32, hh);
+            const int prev = P.base_prev[l], pe = P.base_pe[l], spm = (prev ? 8 : 0) + (pe ? P.n_pe_steps : 0), b0 = P.base_block0[l];
+            if (prev) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const Frag b = relu_frag4(act, t);
+                    const int blk[4] = {b0 + t, b0 + spm + t, b0 + 2 * spm + t, b0 + 3 * spm + t};
+                    kstep<4>(w4, blk, b, out);
+                }
+            }
+            if (pe) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    if (t < P.n_pe_steps) {
+                        const Frag b = pe_frag(t, hh, x);
+                        const int o = b0 + (prev ? 8 : 0) + t;
+                        const int blk[4] = {o, o + spm, o + 2 * spm, o + 3 * spm};
+                        kstep<4>(w4, blk, b, out);
+                    }
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) act[mb] = out[mb];
+        }
+        if (P.split >= P.D) {                                        // (all base layers fitted stage A)
+            __syncthreads();
+            load_stage(lds4, imgB, P.blocksB);
+            __syncthreads();
+        }
+        // ---------------- heads: sigma and the 64-wide rgb hidden layer share the fragments of `base`
+        f32x16 hd[3] = {{0}, bias_acc(lbias + 512, hh), bias_acc(lbias + 512 + 32, hh)};      // sigma, rgb hidden block 0 / 1
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const Frag b = relu_frag4(act, t);
+            const int blk[3] = {P.sig_block0 + t, P.rgbh_block0 + t, P.rgbh_block0 + 9 + t};
+            kstep<3>(w4, blk, b, hd);
+        }
+        f32x16 rh[2] = {hd[1], hd[2]};
+        {
+            // view-direction embedding: [d, sin d, cos d, sin 2d, cos 2d] (15 values, one k-step)
+            float v[8];
+            const float v0[8] = {d[0], d[1], d[2], __sinf(d[0]), __sinf(d[1]), __sinf(d[2]), __cosf(d[0]), __cosf(d[1])};
+            const float v1[8] = {__cosf(d[2]), __sinf(2.f * d[0]), __sinf(2.f * d[1]), __sinf(2.f * d[2]), __cosf(2.f * d[0]), __cosf(2.f * d[1]), __cosf(2.f * d[2]), 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = hh ? v1[j] : v0[j];
+            const int blk[2] = {P.rgbh_block0 + 8, P.rgbh_block0 + 9 + 8};
+            kstep<2>(w4, blk, split8(v), rh);
+        }
+        f32x16 eo[1] = {{0}};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = relu_f(t < 2 ? rh[0][8 * (t & 1) + j] : rh[1][8 * (t & 1) + j]);
+            const int blk[1] = {P.rgbo_block0 + t};
+            kstep<1>(w4, blk, split8(v), eo);
+        }
+        const f32x16 sg = hd[0], e = eo[0];
+        if (h == 0 && s < M) {
+            sigma[s] = fabsf(sg[0] + lbias[576]);
+            rgb[3 * s] = 1.0f / (1.0f + __expf(-(e[0] + lbias[580])));
+            rgb[3 * s + 1] = 1.0f / (1.0f + __expf(-(e[1] + lbias[581])));
+            rgb[3 * s + 2] = 1.0f / (1.0f + __expf(-(e[2] + lbias[582])));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+static inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+struct BgLayout {
+    BgProgram P;
+    int total_blocks;
+};
+
+static int plan(const tvr_mlpnet_desc *d, BgLayout &L)
+{
+    if (!d) return tvr_set_error(TVR_ERR_INVALID, "mlpnet desc is NULL");
+    if (d->W != 128) return tvr_set_error(TVR_ERR_UNSUPPORTED, "MLPNet width %d (the kernel is built for W = 128, nerfplusplus.py:159)", d->W);
+    if (d->D < 2 || d->D > 4) return tvr_set_error(TVR_ERR_UNSUPPORTED, "MLPNet depth %d outside [2,4]", d->D);
+    if (d->pos_freqs < 1 || d->pos_freqs > 4) return tvr_set_error(TVR_ERR_UNSUPPORTED, "position embedding with %d frequencies outside [1,4]", d->pos_freqs);
+    if (d->view_freqs != 2) return tvr_set_error(TVR_ERR_UNSUPPORTED, "view embedding with %d frequencies (built for 2)", d->view_freqs);
+    if (d->skip < 0 || d->skip >= d->D) return tvr_set_error(TVR_ERR_INVALID, "skip layer %d outside [0,%d)", d->skip, d->D);
+    if (d->samples_per_ray < 1) return tvr_set_error(TVR_ERR_INVALID, "samples_per_ray < 1");
+    BgProgram &P = L.P;
+    P.D = d->D;
+    P.input_ch = 4 + 8 * d->pos_freqs;
+    P.n_pe_steps = (P.input_ch + 15) / 16;
+    P.samples_per_ray = d->samples_per_ray;
+    int blocks[4];
+    for (int l = 0; l < P.D; ++l) {
+        P.base_prev[l] = l > 0;
+        P.base_pe[l] = l == 0 || (l - 1 == d->skip && l - 1 != P.D - 1);     // MLPNet.__init__: `if i in skips and i != D-1: dim += input_ch`
+        blocks[l] = 4 * ((P.base_prev[l] ? 8 : 0) + (P.base_pe[l] ? P.n_pe_steps : 0));
+    }
+    const int heads = 8 + 18 + 4;
+    int total = heads;
+    for (int l = 0; l < P.D; ++l) total += blocks[l];
+    // the split that balances the two stages and fits both
+    P.split = -1;
+    for (int s = 1; s <= P.D; ++s) {
+        int a = 0, b = heads;
+        for (int l = 0; l < P.D; ++l) (l < s ? a : b) += blocks[l];
+        if (a <= BG_MAX_BLOCKS && b <= BG_MAX_BLOCKS) P.split = s;
+    }
+    if (P.split < 0) return tvr_set_error(TVR_ERR_UNSUPPORTED, "MLPNet does not fit two LDS stages");
+    int a = 0, b = 0;
+    for (int l = 0; l < P.D; ++l) {
+        if (l < P.split) { P.base_block0[l] = a; a += blocks[l]; }
+        else { P.base_block0[l] = b; b += blocks[l]; }
+    }
+    P.sig_block0 = b; b += 8;
+    P.rgbh_block0 = b; b += 18;
+    P.rgbo_block0 = b; b += 4;
+    P.blocksA = a;
+    P.blocksB = b;
+    L.total_blocks = a + b;
+    return TVR_OK;
+}
+
+extern "C" {
+
+size_t tvr_mlpnet_packed_bytes(const tvr_mlpnet_desc *desc)
+{
+    BgLayout L;
+    if (plan(desc, L) != TVR_OK) return 0;
+    // fragment image, biases, and the block table the pack kernel reads
+    return (size_t)L.total_blocks * 2048 + BG_BIAS_FLOATS * 4 + (size_t)L.total_blocks * sizeof(PackBlock);
+}
+
+int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *p, void *packed, size_t packed_bytes, void *stream)
+{
+    BgLayout L;
+    if (int rc = plan(desc, L)) return rc;
+    if (!p || !p->sigma_W || !p->sigma_b || !p->rgbh_W_base || !p->rgbh_W_view || !p->rgbh_b || !p->rgbo_W || !p->rgbo_b)
+        return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_pack: NULL weights");
+    for (int l = 0; l < desc->D; ++l)
+        if (!p->base_W[l] || !p->base_b[l]) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_pack: NULL base layer %d", l);
+    if (!packed || misaligned(packed) || packed_bytes < tvr_mlpnet_packed_bytes(desc)) return tvr_set_error(TVR_ERR_SCRATCH, "tvr_mlpnet_pack: packed buffer too small or misaligned");
+    const BgProgram &P = L.P;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::vector<PackBlock> tab((size_t)L.total_blocks);
+    auto put = [&](int stage, int blk, const void *W, int ld, int n_out, int row0, int kind, int t, int koff, int n_valid) {
+        tab[(size_t)(stage ? P.blocksA : 0) + blk] = PackBlock{static_cast<const float *>(W), ld, n_out, row0, kind, t, koff, n_valid};
+    };
+    for (int l = 0; l < P.D; ++l) {
+        const int stage = l >= P.split, prev = P.base_prev[l], pe = P.base_pe[l], spm = (prev ? 8 : 0) + (pe ? P.n_pe_steps : 0);
+        const int ld = (prev ? 128 : 0) + (pe ? P.input_ch : 0);
+        for (int mb = 0; mb < 4; ++mb) {
+            const int b0 = P.base_block0[l] + mb * spm;
+            // cat(input_pts, base): the embedding occupies the first input_ch columns, the previous activations follow (MLPNet.forward)
+            if (prev) for (int t = 0; t < 8; ++t) put(stage, b0 + t, p->base_W[l], ld, 128, mb * 32, K_PREV, t, pe ? P.input_ch : 0, 128);
+            if (pe) for (int t = 0; t < P.n_pe_steps; ++t) put(stage, b0 + (prev ? 8 : 0) + t, p->base_W[l], ld, 128, mb * 32, K_PE, t, 0, P.input_ch);
+        }
+    }
+    for (int t = 0; t < 8; ++t) put(1, P.sig_block0 + t, p->sigma_W, 128, 1, 0, K_PREV, t, 0, 128);
+    for (int mb = 0; mb < 2; ++mb) {
+        for (int t = 0; t < 8; ++t) put(1, P.rgbh_block0 + mb * 9 + t, p->rgbh_W_base, 128, 64, mb * 32, K_PREV, t, 0, 128);
+        put(1, P.rgbh_block0 + mb * 9 + 8, p->rgbh_W_view, 15, 64, mb * 32, K_VIEW, 0, 0, 15);
+    }
+    for (int t = 0; t < 4; ++t) put(1, P.rgbo_block0 + t, p->rgbo_W, 64, 3, 0, K_PREV, t, 0, 64);
+    char *base = static_cast<char *>(packed);
+    float *bias = reinterpret_cast<float *>(base + (size_t)L.total_blocks * 2048);
+    PackBlock *dtab = reinterpret_cast<PackBlock *>(base + (size_t)L.total_blocks * 2048 + BG_BIAS_FLOATS * 4);
+    HIP_TRY(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(PackBlock), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));                               // `tab` is a host temporary (packing is a rare, explicit call)
+    HIP_TRY(hipMemsetAsync(bias, 0, BG_BIAS_FLOATS * 4, st));
+    for (int l = 0; l < P.D; ++l) HIP_TRY(hipMemcpyAsync(bias + l * 128, p->base_b[l], 128 * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bias + 512, p->rgbh_b, 64 * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bias + 576, p->sigma_b, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bias + 580, p->rgbo_b, 12, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(bg_pack_kernel, dim3((unsigned)L.total_blocks), dim3(64), 0, st, dtab, reinterpret_cast<uint4 *>(base));
+    HIP_TRY(hipGetLastError());
+    return TVR_OK;
+}
+
+int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
+                       void *stream)
+{
+    BgLayout L;
+    if (int rc = plan(desc, L)) return rc;
+    if (n_samples < 0) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_forward: n_samples < 0");
+    if (n_samples == 0) return TVR_OK;
+    if (!packed || !pts || !viewdirs || !rgb || !sigma || misaligned(packed) || misaligned(pts)) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_forward: NULL or misaligned argument");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)bg_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS_BYTES));
+        attr_set = true;
+    }
+    const long long n_super = (n_samples + 32 * BG_WAVES - 1) / (32 * BG_WAVES);
+    const unsigned blocks = (unsigned)(n_super < 256 ? n_super : 256);                     // one workgroup per CU (the LDS image)
+    const char *base = static_cast<const char *>(packed);
+    hipLaunchKernelGGL(bg_mlp_kernel, dim3(blocks), dim3(BG_WAVES * 64), BG_LDS_BYTES, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
+                       reinterpret_cast<const float *>(base + (size_t)L.total_blocks * 2048), static_cast<const float *>(pts), static_cast<const float *>(viewdirs),
+                       (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma));
+    HIP_TRY(hipGetLastError());
+    return TVR_OK;
+}
+
+}  // extern "C"

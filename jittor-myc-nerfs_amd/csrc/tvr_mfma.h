@@ -1,0 +1,40 @@
+// tvr_mfma.h — fp16 hi/lo split MFMA idioms shared by the fused-MLP kernels (tvr_ngp.hip, tvr_bg.hip).
+// Arithmetic: v_mfma_f32_32x32x16_f16 with every fp32 operand split into fp16 hi + lo and three products per k-step (hi*lo, lo*hi,
+// hi*hi): error ~2^-22 relative, i.e. fp32-grade.  Operand layout (lane l, col = l%32, h = l/32): A fragment = 8 halves of row col,
+// k = 8h..8h+7 of the step; B fragment = 8 halves of column col, same k; accumulator register i = row (i/4)*8 + 4h + i%4, column col.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+#define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
+
+// relu as ONE VALU op: integer max on the bit pattern (negative floats, -0.0 included, are negative integers)
+__device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
+// fp32 pair -> packed fp16 hi and lo words (x = hi + lo up to ~2^-22 |x|; round-toward-zero never overflows to inf).  x - hi is one
+// v_fma_mix_f32 reading the packed half in place; its result goes through the compiler-visible v_cvt_pkrtz, never into an MFMA
+// directly (VALU-write -> MFMA-read wait states are software-managed on gfx950 and the compiler cannot pad inline asm; see tvr_shade.hip).
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hb), "v"(b));
+    hi = hb;
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+struct Frag {   // one 8-element fp16 operand fragment, hi and lo parts
+    uint4 hi, lo;
+};
+__device__ __forceinline__ Frag split8(const float v[8])
+{
+    Frag f;
+    split2(v[0], v[1], f.hi.x, f.lo.x);
+    split2(v[2], v[3], f.hi.y, f.lo.y);
+    split2(v[4], v[5], f.hi.z, f.lo.z);
+    split2(v[6], v[7], f.hi.w, f.lo.w);
+    return f;
+}
+

@@ -15,6 +15,7 @@
 #include <cfloat>
 #include <cstdint>
 #include "tvr_kernels.h"
+#include "tvr_mfma.h"
 #include "../../include/tvr_ngp.h"
 
 #define NGP_G TVR_NGP_GRIDSIZE
@@ -26,7 +27,6 @@
         if (e_ != hipSuccess) return tvr_set_error(TVR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------ PCG32 (pcg32.h)
 struct Pcg {
@@ -448,7 +448,6 @@ enum { NGP_L_D0 = 0, NGP_L_D1 = 2 * 16 * 64, NGP_L_C0 = NGP_L_D1 + 32 * 64, NGP_
 enum { NGP_H_D0 = 0, NGP_H_D1 = 4, NGP_H_C0 = 8, NGP_H_C1 = 12, NGP_H_C2 = 20, NGP_H_BLOCKS = 24, NGP_HIMAGE_FLOATS = NGP_H_BLOCKS * 2 * 64 * 4 };
 static_assert(NGP_HIMAGE_FLOATS == NGP_IMAGE_FLOATS, "both images are 48 KiB");
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int acc_row(int i) { return (i / 4) * 8 + i % 4; }
 
@@ -472,31 +471,6 @@ __global__ void __launch_bounds__(256) ngp_pack_f32_kernel(const float *__restri
     else { ka = 16 + 2 * (s - 8); kb = ka + 1; }
     const int row = mb * 32 + (l & 31), k = l < 32 ? ka : kb;
     image[e] = row < n_out ? W[row * n_in + k] : 0.f;
-}
-
-// fp32 pair -> packed fp16 hi and lo words (x = hi + lo up to ~2^-22 |x|; round-toward-zero never overflows to inf).  x - hi is one
-// v_fma_mix_f32 reading the packed half in place; its result goes through the compiler-visible v_cvt_pkrtz, never into an MFMA
-// directly (VALU-write -> MFMA-read wait states are software-managed on gfx950 and the compiler cannot pad inline asm; see tvr_shade.hip).
-__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
-{
-    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-    float ra, rb;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hb), "v"(b));
-    hi = hb;
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
-}
-struct Frag {   // one 8-element fp16 operand fragment, hi and lo parts
-    uint4 hi, lo;
-};
-__device__ __forceinline__ Frag split8(const float v[8])
-{
-    Frag f;
-    split2(v[0], v[1], f.hi.x, f.lo.x);
-    split2(v[2], v[3], f.hi.y, f.lo.y);
-    split2(v[4], v[5], f.hi.z, f.lo.z);
-    split2(v[6], v[7], f.hi.w, f.lo.w);
-    return f;
 }
 
 // one thread per (block, lane): the 8 weights of that lane's A fragment, split into hi / lo
@@ -527,10 +501,8 @@ __global__ void __launch_bounds__(256) ngp_pack_f16_kernel(const float *__restri
     image[(blk * 2 + 1) * 64 + l] = f.lo;
 }
 
-__device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-#define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
 
 // one k-step (16 inputs) into the two 32-neuron blocks of a 64-wide layer; the two blocks alternate so that no MFMA directly follows
 // the one it depends on

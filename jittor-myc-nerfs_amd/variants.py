@@ -5,6 +5,8 @@
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from . import _lib as L
@@ -294,6 +296,62 @@ class NerfPlusPlus(TensorVMSplit):
         rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)
         return rgb_map.clamp(0, 1), depth, lam                                                # white_bg=False (:276), tensorBase.py:527
 
+    # -- the background network on the HIP kernel (tvr_mlpnet_*): inference only; training keeps the torch modules under autograd
+    def _bg_kernel_desc(self):
+        net = self.bg_net
+        ok = (net is not None and isinstance(net, MLPNet) and net.use_viewdirs and len(net.skips) == 1 and 2 <= len(net.base_layers) <= 4
+              and net.base_layers[0][0].out_features == 128 and self.bg_view_freq == 2 and 1 <= self.bg_freq <= 4)
+        if not ok:
+            return None
+        return L.MlpnetDesc(len(net.base_layers), 128, int(net.skips[0]), int(self.bg_freq), int(self.bg_view_freq), self.BG_SAMPLES)
+
+    def _bg_packed(self, desc):
+        """Fragment image of the background network.  `base_remap_layers` (Linear 128->256, no activation) is folded into the first rgb
+        layer here, in fp64: W_eff = W_rgb0[:, :256] @ W_remap, b_eff = W_rgb0[:, :256] @ b_remap + b_rgb0."""
+        net = self.bg_net
+        ps = list(net.parameters())
+        sig = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_bg_sig", None) == sig and self._bg_image is not None:
+            return self._bg_image
+        f = lambda t: t.detach().to(self.device, torch.float32).contiguous()
+        W0, b0 = net.rgb_layers[0].weight.detach().double(), net.rgb_layers[0].bias.detach().double()
+        Wr, br = net.base_remap_layers[0].weight.detach().double(), net.base_remap_layers[0].bias.detach().double()
+        keep = {"rgbh_W_base": f(W0[:, :256] @ Wr), "rgbh_W_view": f(W0[:, 256:]), "rgbh_b": f(W0[:, :256] @ br + b0),
+                "sigma_W": f(net.sigma_layers[0].weight), "sigma_b": f(net.sigma_layers[0].bias), "rgbo_W": f(net.rgb_layers[2].weight),
+                "rgbo_b": f(net.rgb_layers[2].bias)}
+        p = L.MlpnetParams()
+        for i, layer in enumerate(net.base_layers):
+            keep[f"W{i}"], keep[f"b{i}"] = f(layer[0].weight), f(layer[0].bias)
+            p.base_W[i], p.base_b[i] = keep[f"W{i}"].data_ptr(), keep[f"b{i}"].data_ptr()
+        for k in ("sigma_W", "sigma_b", "rgbh_W_base", "rgbh_W_view", "rgbh_b", "rgbo_W", "rgbo_b"):
+            setattr(p, k, keep[k].data_ptr())
+        nbytes = L.lib().tvr_mlpnet_packed_bytes(C.byref(desc))
+        if nbytes == 0:
+            raise L.TvrError("tvr_mlpnet_packed_bytes: " + L.lib().tvr_last_error().decode(errors="replace"))
+        img = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        L.check(L.lib().tvr_mlpnet_pack(C.byref(desc), C.byref(p), img.data_ptr(), nbytes, _stream_ptr(self.device)), "tvr_mlpnet_pack")
+        self._bg_image, self._bg_sig = img, sig
+        return img
+
+    def _mlpnet(self, bg_pts, viewdirs):
+        """`self.bg_net(cat(embed(pts), embed(viewdirs)))` for pts [n, N, 4] and per-ray viewdirs [n, 3]: dict(rgb [n,N,3], sigma [n,N])."""
+        n, N = bg_pts.shape[:2]
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.bg_net.parameters())
+        # torch modules: under autograd, for shapes the kernel is not built for, and for host-logic checks of this class on a CPU device
+        # (the foreground has no such path: it raises without the GPU)
+        desc = None if training or bg_pts.device.type != "cuda" else self._bg_kernel_desc()
+        if desc is None or N != self.BG_SAMPLES:
+            inp = torch.cat((self.bg_embedder_position(bg_pts), self.bg_embedder_viewdir(viewdirs.unsqueeze(-2).expand(n, N, 3))), dim=-1)
+            return self.bg_net(inp)
+        img = self._bg_packed(desc)
+        pts = bg_pts.detach().to(torch.float32).contiguous()
+        vd = viewdirs.detach().to(torch.float32).contiguous()
+        rgb = torch.empty(n, N, 3, device=self.device)
+        sigma = torch.empty(n, N, device=self.device)
+        L.check(L.lib().tvr_mlpnet_forward(C.byref(desc), img.data_ptr(), pts.data_ptr(), vd.data_ptr(), n * N, rgb.data_ptr(), sigma.data_ptr(),
+                                           _stream_ptr(self.device)), "tvr_mlpnet_forward")
+        return {'rgb': rgb, 'sigma': sigma}
+
     def _background(self, ray_o, ray_d, rand_bg=None):                                        # :280-308
         n, N = ray_d.shape[0], self.BG_SAMPLES
         viewdirs = ray_d / torch.norm(ray_d, dim=-1, keepdim=True)
@@ -301,14 +359,13 @@ class NerfPlusPlus(TensorVMSplit):
         bg_z_vals = self.perturb_samples(bg_z_vals, rand_bg)
         bg_ray_o = ray_o.unsqueeze(-2).expand(n, N, 3)
         bg_ray_d = ray_d.unsqueeze(-2).expand(n, N, 3)
-        bg_viewdirs = viewdirs.unsqueeze(-2).expand(n, N, 3)
         bg_pts, _ = self.depth2pts_outside(bg_ray_o, bg_ray_d, bg_z_vals, radii=self.radii)
-        input = torch.cat((self.bg_embedder_position(bg_pts), self.bg_embedder_viewdir(bg_viewdirs)), dim=-1)
-        input = torch.flip(input, dims=[-2])
+        # the reference flips the network INPUT along the sample axis (:296); flipping the points first is the same thing
+        bg_pts = torch.flip(bg_pts, dims=[-2])
         bg_z_vals = torch.flip(bg_z_vals, dims=[-1])
         bg_dists = bg_z_vals[..., :-1] - bg_z_vals[..., 1:]
         bg_dists = torch.cat((bg_dists, self.HUGE_NUMBER * torch.ones_like(bg_dists[..., 0:1])), dim=-1)
-        bg_raw = self.bg_net(input)
+        bg_raw = self._mlpnet(bg_pts, viewdirs)
         bg_alpha = 1. - torch.exp(-bg_raw['sigma'] * bg_dists)
         T = torch.cumprod(1. - bg_alpha + self.TINY_NUMBER, dim=-1)[..., :-1]
         T = torch.cat((torch.ones_like(T[..., 0:1]), T), dim=-1)
@@ -330,9 +387,17 @@ class NerfPlusPlus(TensorVMSplit):
             rgb_map, depth_map, bg_lambda = self._render_z_autograd(rays, z_vals, S, eps_T)
         else:
             rgb_map, depth_map, bg_lambda = self._render_z(rays, z_vals, S, eps_T)
-        bg_rgb_map = self._background(rays[:, :3], rays[:, 3:6], rand_bg)
         bg_lambda = torch.where(bg_lambda > 0.1, bg_lambda, torch.zeros_like(bg_lambda))     # :311
-        rgb_map = rgb_map + bg_lambda.unsqueeze(-1) * bg_rgb_map                              # :312-314
+        if torch.is_grad_enabled() and is_train:
+            bg_rgb_map = self._background(rays[:, :3], rays[:, 3:6], rand_bg)
+            rgb_map = rgb_map + bg_lambda.unsqueeze(-1) * bg_rgb_map                          # :312-314
+        else:
+            # inference: rays whose foreground transmittance is <= 0.1 get 0 * background in the reference — their 512 background samples
+            # are not evaluated here (same picture)
+            idx = torch.nonzero(bg_lambda > 0).squeeze(-1)
+            if idx.numel():
+                bg = self._background(rays[idx, :3], rays[idx, 3:6], None if rand_bg is None else torch.as_tensor(rand_bg, device=self.device)[idx])
+                rgb_map = rgb_map.index_add(0, idx, bg_lambda[idx].unsqueeze(-1) * bg)
         return rgb_map, depth_map
 
     execute = forward

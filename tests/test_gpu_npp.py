@@ -137,3 +137,38 @@ def test_npp_training_loop_and_checkpoint(tmp_path, tiny_npp, tiny_npp_arrays, h
         a, _ = m(rays, N_samples=TINY["N_samples"], rand_fg=rf, rand_bg=rb)
         b, _ = m2(rays, N_samples=TINY["N_samples"], rand_fg=rf, rand_bg=rb)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("bg_freq,bg_D", [(4, 4), (2, 3), (1, 2), (3, 4)])
+def test_background_network_kernel_matches_torch(tiny_npp_arrays, hyper_tiny, bg_freq, bg_D):
+    """tvr_mlpnet_forward (Embedder + MLPNet with base_remap folded into the rgb layer) against the torch modules it replaces:
+    opt.py's defaults (4, 4), configs/Scarf.txt (2, 3), and two more shapes of the stage split."""
+    from jittor_myc_nerfs_amd import _lib as L
+    m = make_model(tiny_npp_arrays, hyper_tiny)
+    m.set_nerfplusplus(bg_freq=bg_freq, bg_view_freq=2, bg_D=bg_D, radii=6.0)
+    g = torch.Generator(device="cpu").manual_seed(bg_freq * 10 + bg_D)
+    with torch.no_grad():
+        for p in m.bg_net.parameters():                                # wider than the default init: exercises relu on both sides
+            p.copy_((torch.rand(p.shape, generator=g) - 0.5).to(p.device) * (4.0 / max(p.shape[-1], 8) ** 0.5))
+    n, N = 37, m.BG_SAMPLES                                            # 18 944 samples: not a multiple of the 256-sample workgroup tile
+    u = torch.randn(n, N, 3, generator=g)
+    pts = torch.cat([u / u.norm(dim=-1, keepdim=True), torch.rand(n, N, 1, generator=g)], -1).cuda()
+    v = torch.randn(n, 3, generator=g)
+    v = (v / v.norm(dim=-1, keepdim=True)).cuda()
+    with torch.no_grad():
+        got = m._mlpnet(pts, v)
+        inp = torch.cat((m.bg_embedder_position(pts), m.bg_embedder_viewdir(v.unsqueeze(-2).expand(n, N, 3))), dim=-1)
+        want = m.bg_net(inp)
+    assert m._bg_image is not None, "the HIP path did not run"
+    es, er = (got["sigma"] - want["sigma"]).abs().max().item(), (got["rgb"] - want["rgb"]).abs().max().item()
+    print(f"bg net D={bg_D} freq={bg_freq}: sigma err {es:.2e} (max {want['sigma'].abs().max().item():.2f}), rgb err {er:.2e}")
+    assert es < 2e-5 * max(1.0, want["sigma"].abs().max().item()) and er < 2e-5
+    assert want["rgb"].std().item() > 0.05 and want["sigma"].std().item() > 0.05
+    # a weight update re-packs the image
+    with torch.no_grad():
+        m.bg_net.sigma_layers[0].bias.add_(1.0)
+        again = m._mlpnet(pts, v)["sigma"]
+    assert (again - (want["sigma"] - 0)).abs().max().item() > 0.5
+    # unsupported shapes keep the torch path
+    m.set_nerfplusplus(bg_freq=5, bg_view_freq=2, bg_D=4, radii=6.0)
+    assert m._bg_kernel_desc() is None
