@@ -267,7 +267,9 @@ class NerfPlusPlus(TensorVMSplit):
         fg_far_depth = self.intersect_sphere(rays_o, rays_d, radii=self.radii * self.radii)
         near, far = self.near_far
         step = (fg_far_depth - near) / (N_samples - 1)
-        fg_depth = torch.stack([near + i * step for i in range(N_samples)], dim=-1)
+        # `jt.stack([near + i * step for i in range(N_samples)], -1)` (:247): the same fp32 multiply and add per element, in one pass
+        i = torch.arange(N_samples, dtype=torch.float32, device=step.device)
+        fg_depth = near + i * step.unsqueeze(-1)
         return self.perturb_samples(fg_depth, t_rand).contiguous()
 
     def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1, t_rand=None):           # :239-269 (host form)
