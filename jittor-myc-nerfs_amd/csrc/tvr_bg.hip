@@ -125,6 +125,79 @@ __device__ __forceinline__ void load_stage(uint4 *__restrict__ lds4, const uint4
     for (int e = threadIdx.x; e < n; e += BG_WAVES * 64) lds4[e] = image[e];
 }
 
+// base layers [l0, l1) on one 32-sample tile: act in (unused when l0 == 0) -> act out
+__device__ __forceinline__ void base_layers(const BgProgram &P, int l0, int l1, const uint4 *__restrict__ w4, const float *__restrict__ lbias, int hh,
+                                            const float x[4], f32x16 (&act)[4])
+{
+    for (int l = l0; l < l1; ++l) {
+        f32x16 out[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) out[mb] = bias_acc(lbias + l * 128 + mb * 32, hh);
+        const int prev = P.base_prev[l], pe = P.base_pe[l], spm = (prev ? 8 : 0) + (pe ? P.n_pe_steps : 0), b0 = P.base_block0[l];
+        if (prev) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const Frag b = relu_frag4(act, t);
+                const int blk[4] = {b0 + t, b0 + spm + t, b0 + 2 * spm + t, b0 + 3 * spm + t};
+                kstep<4>(w4, blk, b, out);
+            }
+        }
+        if (pe) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (t < P.n_pe_steps) {
+                    const Frag b = pe_frag(t, hh, x);
+                    const int o = b0 + (prev ? 8 : 0) + t;
+                    const int blk[4] = {o, o + spm, o + 2 * spm, o + 3 * spm};
+                    kstep<4>(w4, blk, b, out);
+                }
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) act[mb] = out[mb];
+    }
+}
+
+// heads on one tile: sigma and the 64-wide rgb hidden layer share the fragments of `base`; returns (rgb, sigma) of sample col in the
+// lanes with hh == 0
+__device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restrict__ w4, const float *__restrict__ lbias, int hh, const float d[3],
+                                        const f32x16 (&act)[4])
+{
+    f32x16 hd[3] = {{0}, bias_acc(lbias + 512, hh), bias_acc(lbias + 512 + 32, hh)};      // sigma, rgb hidden block 0 / 1
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const Frag b = relu_frag4(act, t);
+        const int blk[3] = {P.sig_block0 + t, P.rgbh_block0 + t, P.rgbh_block0 + 9 + t};
+        kstep<3>(w4, blk, b, hd);
+    }
+    f32x16 rh[2] = {hd[1], hd[2]};
+    {
+        // view-direction embedding: [d, sin d, cos d, sin 2d, cos 2d] (15 values, one k-step)
+        float v[8];
+        const float v0[8] = {d[0], d[1], d[2], __sinf(d[0]), __sinf(d[1]), __sinf(d[2]), __cosf(d[0]), __cosf(d[1])};
+        const float v1[8] = {__cosf(d[2]), __sinf(2.f * d[0]), __sinf(2.f * d[1]), __sinf(2.f * d[2]), __cosf(2.f * d[0]), __cosf(2.f * d[1]), __cosf(2.f * d[2]), 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = hh ? v1[j] : v0[j];
+        const int blk[2] = {P.rgbh_block0 + 8, P.rgbh_block0 + 9 + 8};
+        kstep<2>(w4, blk, split8(v), rh);
+    }
+    f32x16 eo[1] = {{0}};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = relu_f(t < 2 ? rh[0][8 * (t & 1) + j] : rh[1][8 * (t & 1) + j]);
+        const int blk[1] = {P.rgbo_block0 + t};
+        kstep<1>(w4, blk, split8(v), eo);
+    }
+    return make_float4(1.0f / (1.0f + __expf(-(eo[0][0] + lbias[580]))), 1.0f / (1.0f + __expf(-(eo[0][1] + lbias[581]))),
+                       1.0f / (1.0f + __expf(-(eo[0][2] + lbias[582]))), fabsf(hd[0][0] + lbias[576]));
+}
+
+#ifndef TVR_BG_NT
+#define TVR_BG_NT 1               // 32-sample tiles a wave carries through each LDS stage (their stage-A activations wait in registers)
+#endif
+
 __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, const uint4 *__restrict__ image, const float *__restrict__ bias,
                                                                  const float *__restrict__ pts, const float *__restrict__ viewdirs, long long M,
                                                                  float *__restrict__ rgb, float *__restrict__ sigma)
@@ -134,98 +207,46 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
     float *lbias = reinterpret_cast<float *>(smem + BG_MAX_BLOCKS * 2048);
     for (int e = threadIdx.x; e < BG_BIAS_FLOATS; e += BG_WAVES * 64) lbias[e] = bias[e];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
-    const long long n_super = (M + 32 * BG_WAVES - 1) / (32 * BG_WAVES);
+    constexpr int NT = TVR_BG_NT, PER_SUPER = 32 * BG_WAVES * NT;
+    const long long n_super = (M + PER_SUPER - 1) / PER_SUPER;
     const uint4 *imgA = image, *imgB = image + (size_t)P.blocksA * 128;
+    const int la = min(P.split, P.D);
 
     for (long long super = blockIdx.x; super < n_super; super += gridDim.x) {
         int hh = h, lane_off = lane;
         asm volatile("" : "+v"(hh), "+v"(lane_off));                // opaque per tile: keeps per-lane selects / LDS reads from being hoisted
-        const long long s = (super * BG_WAVES + wave) * 32 + col, sr = min(s, M - 1);
-        float x[4], d[3];
-        {
-            const float4 p = *reinterpret_cast<const float4 *>(pts + 4 * sr);
-            x[0] = p.x; x[1] = p.y; x[2] = p.z; x[3] = p.w;
-            const float *v = viewdirs + 3 * (sr / P.samples_per_ray);
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2];
-        }
         const uint4 *w4 = lds4 + lane_off;
-        f32x16 act[4];
-
-        // ---------------- base layers; the LDS image switches from stage A to stage B at layer P.split
+        f32x16 act[NT][4];
+        // ---------------- stage A: base layers [0, split)
         __syncthreads();                                             // everyone is done with the previous tile's stage B
         load_stage(lds4, imgA, P.blocksA);
         __syncthreads();
-        for (int l = 0; l < P.D; ++l) {
-            if (l == P.split) {
-                __syncthreads();
-                load_stage(lds4, imgB, P.blocksB);
-                __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const long long sr = min(((super * NT + nt) * BG_WAVES + wave) * 32 + col, M - 1);
+            const float4 p = *reinterpret_cast<const float4 *>(pts + 4 * sr);
+            const float x[4] = {p.x, p.y, p.z, p.w};
+            base_layers(P, 0, la, w4, lbias, hh, x, act[nt]);
+        }
+        // ---------------- stage B: the remaining base layers and the heads
+        __syncthreads();
+        load_stage(lds4, imgB, P.blocksB);
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const long long s = ((super * NT + nt) * BG_WAVES + wave) * 32 + col, sr = min(s, M - 1);
+            const float4 p = *reinterpret_cast<const float4 *>(pts + 4 * sr);
+            const float x[4] = {p.x, p.y, p.z, p.w};
+            const float *v = viewdirs + 3 * (sr / P.samples_per_ray);
+            const float d[3] = {v[0], v[1], v[2]};
+            base_layers(P, la, P.D, w4, lbias, hh, x, act[nt]);
+            const float4 r = heads(P, w4, lbias, hh, d, act[nt]);
+            if (h == 0 && s < M) {
+                sigma[s] = r.w;
+                rgb[3 * s] = r.x;
+                rgb[3 * s + 1] = r.y;
+                rgb[3 * s + 2] = r.z;
             }
-            f32x16 out[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) out[mb] = bias_acc(lbias + l * 128 + mb * 32, hh);
-            const int prev = P.base_prev[l], pe = P.base_pe[l], spm = (prev ? 8 : 0) + (pe ? P.n_pe_steps : 0), b0 = P.base_block0[l];
-            if (prev) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const Frag b = relu_frag4(act, t);
-                    const int blk[4] = {b0 + t, b0 + spm + t, b0 + 2 * spm + t, b0 + 3 * spm + t};
-                    kstep<4>(w4, blk, b, out);
-                }
-            }
-            if (pe) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    if (t < P.n_pe_steps) {
-                        const Frag b = pe_frag(t, hh, x);
-                        const int o = b0 + (prev ? 8 : 0) + t;
-                        const int blk[4] = {o, o + spm, o + 2 * spm, o + 3 * spm};
-                        kstep<4>(w4, blk, b, out);
-                    }
-                }
-            }
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) act[mb] = out[mb];
-        }
-        if (P.split >= P.D) {                                        // (all base layers fitted stage A)
-            __syncthreads();
-            load_stage(lds4, imgB, P.blocksB);
-            __syncthreads();
-        }
-        // ---------------- heads: sigma and the 64-wide rgb hidden layer share the fragments of `base`
-        f32x16 hd[3] = {{0}, bias_acc(lbias + 512, hh), bias_acc(lbias + 512 + 32, hh)};      // sigma, rgb hidden block 0 / 1
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const Frag b = relu_frag4(act, t);
-            const int blk[3] = {P.sig_block0 + t, P.rgbh_block0 + t, P.rgbh_block0 + 9 + t};
-            kstep<3>(w4, blk, b, hd);
-        }
-        f32x16 rh[2] = {hd[1], hd[2]};
-        {
-            // view-direction embedding: [d, sin d, cos d, sin 2d, cos 2d] (15 values, one k-step)
-            float v[8];
-            const float v0[8] = {d[0], d[1], d[2], __sinf(d[0]), __sinf(d[1]), __sinf(d[2]), __cosf(d[0]), __cosf(d[1])};
-            const float v1[8] = {__cosf(d[2]), __sinf(2.f * d[0]), __sinf(2.f * d[1]), __sinf(2.f * d[2]), __cosf(2.f * d[0]), __cosf(2.f * d[1]), __cosf(2.f * d[2]), 0.f};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = hh ? v1[j] : v0[j];
-            const int blk[2] = {P.rgbh_block0 + 8, P.rgbh_block0 + 9 + 8};
-            kstep<2>(w4, blk, split8(v), rh);
-        }
-        f32x16 eo[1] = {{0}};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = relu_f(t < 2 ? rh[0][8 * (t & 1) + j] : rh[1][8 * (t & 1) + j]);
-            const int blk[1] = {P.rgbo_block0 + t};
-            kstep<1>(w4, blk, split8(v), eo);
-        }
-        const f32x16 sg = hd[0], e = eo[0];
-        if (h == 0 && s < M) {
-            sigma[s] = fabsf(sg[0] + lbias[576]);
-            rgb[3 * s] = 1.0f / (1.0f + __expf(-(e[0] + lbias[580])));
-            rgb[3 * s + 1] = 1.0f / (1.0f + __expf(-(e[1] + lbias[581])));
-            rgb[3 * s + 2] = 1.0f / (1.0f + __expf(-(e[2] + lbias[582])));
         }
     }
 }
@@ -352,7 +373,7 @@ int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const vo
         HIP_TRY(hipFuncSetAttribute((const void *)bg_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS_BYTES));
         attr_set = true;
     }
-    const long long n_super = (n_samples + 32 * BG_WAVES - 1) / (32 * BG_WAVES);
+    const long long per_super = 32 * BG_WAVES * TVR_BG_NT, n_super = (n_samples + per_super - 1) / per_super;
     const unsigned blocks = (unsigned)(n_super < 256 ? n_super : 256);                     // one workgroup per CU (the LDS image)
     const char *base = static_cast<const char *>(packed);
     hipLaunchKernelGGL(bg_mlp_kernel, dim3(blocks), dim3(BG_WAVES * 64), BG_LDS_BYTES, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),

@@ -29,7 +29,7 @@ def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray
     if not (is_train and torch.is_grad_enabled()) and N_rays_all > chunk:
         S = N_samples if N_samples > 0 else getattr(tensorf, "nSamples", 1024)
         cap = min(_INFER_SCRATCH_BUDGET // (40 * S), ((1 << 32) - 1) // S)
-        cap = min(cap, getattr(tensorf, "max_render_chunk", cap))      # e.g. NerfPlusPlus: its torch background holds [chunk,512,*] tensors
+        cap = min(cap, getattr(tensorf, "max_render_chunk", cap))      # e.g. NerfPlusPlus: its background geometry holds [chunk,512,*] tensors
         chunk = max(chunk, min(N_rays_all, (cap // 4096) * 4096 if cap >= 4096 else cap))
     rgbs, depth_maps = [], []
     for chunk_idx in range(N_rays_all // chunk + int(N_rays_all % chunk > 0)):

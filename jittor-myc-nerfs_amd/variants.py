@@ -202,7 +202,7 @@ class NerfPlusPlus(TensorVMSplit):
     background (Embedder + MLPNet over 512 samples per ray) is plain torch.  `rand_fg` / `rand_bg` inject the two jt.rand_like draws."""
 
     HUGE_NUMBER, TINY_NUMBER, BG_SAMPLES = 1e10, 1e-6, 512                                    # :4-5, :284
-    max_render_chunk = 8192       # rays per merged inference call (renderer): the background holds [rays, 512, <=420] fp32 activations
+    max_render_chunk = 65536      # rays per merged inference call (renderer): the background holds [rays, 512, ~20] fp32 temporaries (2.7 GB)
 
     def __init__(self, aabb, gridSize, device, **kargs):
         super().__init__(aabb, gridSize, device, **kargs)

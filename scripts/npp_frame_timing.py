@@ -26,3 +26,15 @@ with torch.no_grad():
     torch.cuda.synchronize(); t_fg = (time.perf_counter() - t0) / 5
 print(f"NerfPlusPlus 800x800 x {S} fg samples + 512 bg samples: {t_all * 1e3:.0f} ms / frame ({rays.shape[0] * S / t_all:.3e} fg ray-samples/s); "
       f"foreground kernels alone (tvr_render_z, one call) {t_fg * 1e3:.1f} ms; rgb range {float(rgb.min()):.3f}..{float(rgb.max()):.3f}")
+# the background network kernel alone: 65 536 rays x 512 samples per call (tvr_mlpnet_forward)
+with torch.no_grad():
+    n = 65536
+    u = torch.randn(n, 512, 3, device="cuda")
+    pts = torch.cat([u / u.norm(dim=-1, keepdim=True), torch.rand(n, 512, 1, device="cuda")], -1)
+    v = rays[:n, 3:6] / rays[:n, 3:6].norm(dim=-1, keepdim=True)
+    m._mlpnet(pts, v); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3): m._mlpnet(pts, v)
+    torch.cuda.synchronize(); t_bg = (time.perf_counter() - t0) / 3
+    lam = m._render_z(rays, z, S, 1e-4)[2]
+print(f"background network kernel: {n * 512 / t_bg / 1e9:.2f} G samples/s ({t_bg * 1e3:.1f} ms per {n * 512 / 1e6:.1f} M samples; a full frame has 327.7 M); "
+      f"rays with bg_lambda > 0.1 on this scene: {float((lam > 0.1).float().mean()) * 100:.0f} %")
