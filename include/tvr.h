@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 107
+#define TVR_VERSION 108
 
 typedef enum {
     TVR_OK = 0,
@@ -241,6 +241,15 @@ int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *params
 /* pts [n,4] (inverted-sphere points, depth2pts_outside), viewdirs [ceil(n / samples_per_ray), 3] -> rgb [n,3] (sigmoid applied), sigma [n] (abs applied) */
 int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
                        void *sigma, void *stream);
+/* The background of NerfPlusPlus.execute around that network (nerfplusplus.py:280-308).
+ * tvr_npp_bg_points: z_lin [n_samples] (the `linspace(0, radii, N)` depths), t_rand [n_rays,n_samples] (the `rand_like` draw of
+ *   `perturb_samples`, :196-205) -> pts [n_rays,n_samples,4] = `depth2pts_outside` (:207-237) of the perturbed depths and z
+ *   [n_rays,n_samples] = those depths, both already FLIPPED along the sample axis (:296-297).
+ * tvr_npp_bg_composite: rgb [n_rays,n_samples,3], sigma, z (flipped order) -> rgb_out [n_rays,3] = sum_k alpha_k T_k rgb_k with
+ *   alpha = 1 - exp(-sigma * (z_k - z_{k+1})), last distance 1e10, T = cumprod(1 - alpha + 1e-6) shifted by one (:298-308). */
+int tvr_npp_bg_points(const void *rays_o, const void *rays_d, int64_t n_rays, const void *z_lin, int32_t n_samples, const void *t_rand, float radii,
+                      void *pts, void *z, void *stream);
+int tvr_npp_bg_composite(const void *rgb, const void *sigma, const void *z, int64_t n_rays, int32_t n_samples, void *rgb_out, void *stream);
 
 #ifdef __cplusplus
 }

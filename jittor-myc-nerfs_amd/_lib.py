@@ -111,6 +111,8 @@ SYMBOLS = {
     "tvr_mlpnet_packed_bytes": (C.c_size_t, [C.POINTER(MlpnetDesc)]),
     "tvr_mlpnet_pack": (C.c_int, [C.POINTER(MlpnetDesc), C.POINTER(MlpnetParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_mlpnet_forward": (C.c_int, [C.POINTER(MlpnetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvr_npp_bg_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvr_npp_bg_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     # include/tvr_ngp.h
     "tvr_ngp_update_bitfield": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_ngp_sample_scratch_bytes": (C.c_size_t, [C.c_int64]),

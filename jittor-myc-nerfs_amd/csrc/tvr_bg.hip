@@ -251,6 +251,82 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ background geometry and compositing
+// NerfPlusPlus.execute around the network (nerfplusplus.py:280-308): perturbed depths (`perturb_samples` :196-205), inverted-sphere
+// points (`depth2pts_outside` :207-237), the flip along the sample axis (:296-297) — one thread per (ray, flipped sample) — and the
+// front-to-back weights  alpha = 1 - exp(-sigma * dist), T = cumprod(1 - alpha + 1e-6), rgb = sum alpha T rgb  (:298-308) — one wave per ray.
+__global__ void __launch_bounds__(256) bg_points_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, long long n_rays,
+                                                        const float *__restrict__ z_lin, int N, const float *__restrict__ t_rand, float radii,
+                                                        float4 *__restrict__ pts, float *__restrict__ z_out)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rays * N) return;
+    const long long ray = idx / N;
+    const int kf = (int)(idx - ray * N), k = N - 1 - kf;             // kf: position after the flip, k: position before it
+    const float z = z_lin[k], zl = k > 0 ? 0.5f * (z + z_lin[k - 1]) : z, zu = k < N - 1 ? 0.5f * (z_lin[k + 1] + z) : z;
+    const float depth = zl + (zu - zl) * t_rand[ray * N + k];
+    const float o0 = rays_o[3 * ray], o1 = rays_o[3 * ray + 1], o2 = rays_o[3 * ray + 2], d0 = rays_d[3 * ray], d1v = rays_d[3 * ray + 1], d2v = rays_d[3 * ray + 2];
+    const float dd = d0 * d0 + d1v * d1v + d2v * d2v;
+    const float d1 = -(d0 * o0 + d1v * o1 + d2v * o2) / dd;
+    const float m0 = o0 + d1 * d0, m1 = o1 + d1 * d1v, m2 = o2 + d1 * d2v;
+    const float mn = sqrtf(m0 * m0 + m1 * m1 + m2 * m2);
+    const float dcos = 1.0f / sqrtf(dd);
+    const float d2 = sqrtf(radii * radii - mn * mn) * dcos;
+    const float s0 = o0 + (d1 + d2) * d0, s1 = o1 + (d1 + d2) * d1v, s2 = o2 + (d1 + d2) * d2v;
+    float a0 = o1 * s2 - o2 * s1, a1 = o2 * s0 - o0 * s2, a2 = o0 * s1 - o1 * s0;                // cross(ray_o, p_sphere)
+    const float an = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    a0 /= an; a1 /= an; a2 /= an;
+    const float ang = asinf(mn / radii) - asinf(mn * depth / (radii * radii));
+    const float ca = cosf(ang), sa = sinf(ang);
+    const float c0 = a1 * s2 - a2 * s1, c1 = a2 * s0 - a0 * s2, c2 = a0 * s1 - a1 * s0;          // cross(rot_axis, p_sphere)
+    const float dot = a0 * s0 + a1 * s1 + a2 * s2;
+    pts[idx] = make_float4(s0 * ca + c0 * sa + a0 * dot * (1.f - ca), s1 * ca + c1 * sa + a1 * dot * (1.f - ca), s2 * ca + c2 * sa + a2 * dot * (1.f - ca), depth);
+    z_out[idx] = depth;
+}
+
+__global__ void __launch_bounds__(256) bg_composite_kernel(const float *__restrict__ rgb, const float *__restrict__ sigma, const float *__restrict__ z, long long n_rays, int N,
+                                                           float *__restrict__ out)
+{
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (ray >= n_rays) return;
+    const float *sg = sigma + ray * N, *zz = z + ray * N, *cc = rgb + 3 * ray * N;
+    float carry = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        const int k = k0 + lane;
+        const bool in = k < N;
+        const float dist = in ? (k < N - 1 ? zz[k] - zz[k + 1] : 1e10f) : 0.f;
+        const float alpha = in ? 1.f - expf(-sg[k] * dist) : 0.f;
+        float f = in ? 1.f - alpha + 1e-6f : 1.f;                  // inclusive prefix product over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float u = __shfl_up(f, d, 64);
+            if (lane >= d) f *= u;
+        }
+        const float excl = __shfl_up(f, 1, 64);
+        const float T = carry * (lane == 0 ? 1.f : excl);
+        if (in) {
+            const float w = alpha * T;
+            c0 += w * cc[3 * k];
+            c1 += w * cc[3 * k + 1];
+            c2 += w * cc[3 * k + 2];
+        }
+        carry *= __shfl(f, 63, 64);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        c0 += __shfl_xor(c0, m, 64);
+        c1 += __shfl_xor(c1, m, 64);
+        c2 += __shfl_xor(c2, m, 64);
+    }
+    if (lane == 0) {
+        out[3 * ray] = c0;
+        out[3 * ray + 1] = c1;
+        out[3 * ray + 2] = c2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 static inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
@@ -379,6 +455,31 @@ int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const vo
     hipLaunchKernelGGL(bg_mlp_kernel, dim3(blocks), dim3(BG_WAVES * 64), BG_LDS_BYTES, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
                        reinterpret_cast<const float *>(base + (size_t)L.total_blocks * 2048), static_cast<const float *>(pts), static_cast<const float *>(viewdirs),
                        (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma));
+    HIP_TRY(hipGetLastError());
+    return TVR_OK;
+}
+
+int tvr_npp_bg_points(const void *rays_o, const void *rays_d, int64_t n_rays, const void *z_lin, int32_t n_samples, const void *t_rand, float radii,
+                      void *pts, void *z, void *stream)
+{
+    if (n_rays < 0 || n_samples < 1 || !(radii > 0.f)) return tvr_set_error(TVR_ERR_INVALID, "tvr_npp_bg_points: n_rays < 0, n_samples < 1 or radii <= 0");
+    if (n_rays == 0) return TVR_OK;
+    if (!rays_o || !rays_d || !z_lin || !t_rand || !pts || !z || misaligned(pts)) return tvr_set_error(TVR_ERR_INVALID, "tvr_npp_bg_points: NULL or misaligned argument");
+    const long long total = (long long)n_rays * n_samples;
+    hipLaunchKernelGGL(bg_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float *>(rays_o),
+                       static_cast<const float *>(rays_d), (long long)n_rays, static_cast<const float *>(z_lin), (int)n_samples, static_cast<const float *>(t_rand),
+                       radii, static_cast<float4 *>(pts), static_cast<float *>(z));
+    HIP_TRY(hipGetLastError());
+    return TVR_OK;
+}
+
+int tvr_npp_bg_composite(const void *rgb, const void *sigma, const void *z, int64_t n_rays, int32_t n_samples, void *rgb_out, void *stream)
+{
+    if (n_rays < 0 || n_samples < 1) return tvr_set_error(TVR_ERR_INVALID, "tvr_npp_bg_composite: n_rays < 0 or n_samples < 1");
+    if (n_rays == 0) return TVR_OK;
+    if (!rgb || !sigma || !z || !rgb_out) return tvr_set_error(TVR_ERR_INVALID, "tvr_npp_bg_composite: NULL argument");
+    hipLaunchKernelGGL(bg_composite_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float *>(rgb),
+                       static_cast<const float *>(sigma), static_cast<const float *>(z), (long long)n_rays, (int)n_samples, static_cast<float *>(rgb_out));
     HIP_TRY(hipGetLastError());
     return TVR_OK;
 }

@@ -354,8 +354,29 @@ class NerfPlusPlus(TensorVMSplit):
                                            _stream_ptr(self.device)), "tvr_mlpnet_forward")
         return {'rgb': rgb, 'sigma': sigma}
 
+    def _background_fused(self, ray_o, ray_d, rand_bg, desc):
+        """`_background` in three launches: points (perturbed depths, inverted-sphere geometry, flip), network, compositing."""
+        n, N, lib = ray_d.shape[0], self.BG_SAMPLES, L.lib()
+        o, d = _f32c(ray_o, self.device), _f32c(ray_d, self.device)
+        z_lin = torch.linspace(0., self.radii, N, device=self.device)
+        t_rand = torch.rand(n, N, device=self.device) if rand_bg is None else _f32c(torch.as_tensor(rand_bg), self.device)
+        pts = torch.empty(n, N, 4, device=self.device)
+        z = torch.empty(n, N, device=self.device)
+        st = _stream_ptr(self.device)
+        L.check(lib.tvr_npp_bg_points(o.data_ptr(), d.data_ptr(), n, z_lin.data_ptr(), N, t_rand.data_ptr(), float(self.radii), pts.data_ptr(), z.data_ptr(), st),
+                "tvr_npp_bg_points")
+        raw = self._mlpnet(pts, d / torch.norm(d, dim=-1, keepdim=True))
+        out = torch.empty(n, 3, device=self.device)
+        L.check(lib.tvr_npp_bg_composite(raw['rgb'].data_ptr(), raw['sigma'].data_ptr(), z.data_ptr(), n, N, out.data_ptr(), st), "tvr_npp_bg_composite")
+        return out
+
     def _background(self, ray_o, ray_d, rand_bg=None):                                        # :280-308
         n, N = ray_d.shape[0], self.BG_SAMPLES
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.bg_net.parameters())
+        if not training and ray_d.device.type == "cuda":
+            desc = self._bg_kernel_desc()
+            if desc is not None:
+                return self._background_fused(ray_o, ray_d, rand_bg, desc)
         viewdirs = ray_d / torch.norm(ray_d, dim=-1, keepdim=True)
         bg_z_vals = torch.linspace(0., self.radii, N, device=self.device).view(1, N).expand(n, N)
         bg_z_vals = self.perturb_samples(bg_z_vals, rand_bg)

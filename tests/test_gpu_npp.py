@@ -172,3 +172,44 @@ def test_background_network_kernel_matches_torch(tiny_npp_arrays, hyper_tiny, bg
     # unsupported shapes keep the torch path
     m.set_nerfplusplus(bg_freq=5, bg_view_freq=2, bg_D=4, radii=6.0)
     assert m._bg_kernel_desc() is None
+
+
+def test_background_fused_matches_torch_path(tiny_npp_arrays, hyper_tiny):
+    """tvr_npp_bg_points + tvr_mlpnet_forward + tvr_npp_bg_composite against the op-for-op torch restatement of nerfplusplus.py:280-308
+    (the path training uses), same injected draws."""
+    m = make_model(tiny_npp_arrays, hyper_tiny)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = 301
+    o = (torch.randn(n, 3, generator=g) * 1.2).cuda()
+    d = torch.randn(n, 3, generator=g).cuda()
+    d[: n // 2] = d[: n // 2] / d[: n // 2].norm(dim=-1, keepdim=True)          # unit and non-unit directions
+    rb = torch.rand(n, m.BG_SAMPLES, generator=g).cuda()
+    with torch.no_grad():
+        got = m._background(o, d, rb)
+        assert m._bg_image is not None
+        for p in m.bg_net.parameters():
+            p.requires_grad_(True)
+    with torch.enable_grad():
+        want = m._background(o, d, rb).detach()                                   # parameters require grad -> torch modules
+    err = (got - want).abs().max().item()
+    print(f"background fused vs torch: {err:.2e}, range {want.min().item():.3f}..{want.max().item():.3f}")
+    assert err < 2e-5 and want.std().item() > 0.01
+    # pieces: points / depths and compositing on their own
+    from jittor_myc_nerfs_amd import _lib as L
+    from jittor_myc_nerfs_amd.autograd_ops import _stream_ptr
+    N = m.BG_SAMPLES
+    z_lin = torch.linspace(0., m.radii, N, device="cuda")
+    pts, z = torch.empty(n, N, 4, device="cuda"), torch.empty(n, N, device="cuda")
+    L.check(L.lib().tvr_npp_bg_points(o.data_ptr(), d.data_ptr(), n, z_lin.data_ptr(), N, rb.data_ptr(), float(m.radii), pts.data_ptr(), z.data_ptr(),
+                                      _stream_ptr(o.device)), "points")
+    zp = m.perturb_samples(z_lin.view(1, N).expand(n, N), rb)
+    ref_pts, _ = m.depth2pts_outside(o.unsqueeze(-2).expand(n, N, 3), d.unsqueeze(-2).expand(n, N, 3), zp, radii=m.radii)
+    assert torch.equal(z, torch.flip(zp, dims=[-1])) and (pts - torch.flip(ref_pts, dims=[-2])).abs().max().item() < 5e-6
+    rgb, sig = torch.rand(n, N, 3, generator=g).cuda(), (torch.rand(n, N, generator=g) * 3).cuda()
+    out = torch.empty(n, 3, device="cuda")
+    L.check(L.lib().tvr_npp_bg_composite(rgb.data_ptr(), sig.data_ptr(), z.data_ptr(), n, N, out.data_ptr(), _stream_ptr(o.device)), "composite")
+    dists = torch.cat((z[..., :-1] - z[..., 1:], 1e10 * torch.ones_like(z[..., :1])), -1)
+    alpha = 1. - torch.exp(-sig * dists)
+    T = torch.cumprod(1. - alpha + 1e-6, dim=-1)[..., :-1]
+    T = torch.cat((torch.ones_like(T[..., :1]), T), -1)
+    assert (out - ((alpha * T).unsqueeze(-1) * rgb).sum(-2)).abs().max().item() < 2e-6
