@@ -339,6 +339,8 @@ class NerfPlusPlus(TensorVMSplit):
         """`self.bg_net(cat(embed(pts), embed(viewdirs)))` for pts [n, N, 4] and per-ray viewdirs [n, 3]: dict(rgb [n,N,3], sigma [n,N])."""
         n, N = bg_pts.shape[:2]
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.bg_net.parameters())
+        if training:
+            self._bg_sig = None       # an optimizer step follows; fused optimizers do not bump the version counters `_bg_packed` watches
         # torch modules: under autograd, for shapes the kernel is not built for, and for host-logic checks of this class on a CPU device
         # (the foreground has no such path: it raises without the GPU)
         desc = None if training or bg_pts.device.type != "cuda" else self._bg_kernel_desc()
@@ -373,6 +375,8 @@ class NerfPlusPlus(TensorVMSplit):
     def _background(self, ray_o, ray_d, rand_bg=None):                                        # :280-308
         n, N = ray_d.shape[0], self.BG_SAMPLES
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.bg_net.parameters())
+        if training:
+            self._bg_sig = None
         if not training and ray_d.device.type == "cuda":
             desc = self._bg_kernel_desc()
             if desc is not None:

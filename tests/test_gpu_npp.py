@@ -213,3 +213,24 @@ def test_background_fused_matches_torch_path(tiny_npp_arrays, hyper_tiny):
     T = torch.cumprod(1. - alpha + 1e-6, dim=-1)[..., :-1]
     T = torch.cat((torch.ones_like(T[..., :1]), T), -1)
     assert (out - ((alpha * T).unsqueeze(-1) * rgb).sum(-2)).abs().max().item() < 2e-6
+
+
+def test_background_image_follows_fused_optimizer_steps(tiny_npp_arrays, hyper_tiny):
+    """Fused optimizers write parameters without bumping their version counters; the packed background image must still be refreshed
+    (a stale image is how a trained model evaluated 16 dB below its checkpoint)."""
+    m = make_model(tiny_npp_arrays, hyper_tiny)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    o, d = (torch.randn(64, 3, generator=g) * 1.2).cuda(), torch.randn(64, 3, generator=g).cuda()
+    rb = torch.rand(64, m.BG_SAMPLES, generator=g).cuda()
+    with torch.no_grad():
+        before = m._background(o, d, rb)                               # packs the image
+    opt = torch.optim.Adam(m.bg_net.parameters(), lr=5e-2, fused=True)
+    loss = m._background(o, d, rb).square().mean()                     # training path (torch modules under autograd)
+    loss.backward()
+    opt.step()
+    with torch.no_grad():
+        after = m._background(o, d, rb)
+        inp_free = [p.requires_grad_(True) for p in m.bg_net.parameters()]
+    with torch.enable_grad():
+        want = m._background(o, d, rb).detach()
+    assert (after - before).abs().max().item() > 1e-3 and (after - want).abs().max().item() < 2e-5
