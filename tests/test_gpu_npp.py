@@ -234,3 +234,31 @@ def test_background_image_follows_fused_optimizer_steps(tiny_npp_arrays, hyper_t
     with torch.enable_grad():
         want = m._background(o, d, rb).detach()
     assert (after - before).abs().max().item() > 1e-3 and (after - want).abs().max().item() < 2e-5
+
+
+def test_mlpnet_abi_tail_and_errors(tiny_npp_arrays, hyper_tiny):
+    """tvr_mlpnet_forward on a sample count that is not a multiple of the 256-sample workgroup tile, and its argument checks."""
+    import ctypes as C
+    from jittor_myc_nerfs_amd import _lib as L
+    from jittor_myc_nerfs_amd.autograd_ops import _stream_ptr
+    m = make_model(tiny_npp_arrays, hyper_tiny)
+    desc = m._bg_kernel_desc()
+    img = m._bg_packed(desc)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n = 3 * 512 + 77
+    u = torch.randn(n, 3, generator=g)
+    pts = torch.cat([u / u.norm(dim=-1, keepdim=True), torch.rand(n, 1, generator=g)], -1).cuda()
+    v = torch.randn(4, 3, generator=g)
+    v = (v / v.norm(dim=-1, keepdim=True)).cuda()
+    rgb, sig = torch.full((n + 64, 3), -7.0, device="cuda"), torch.full((n + 64,), -7.0, device="cuda")
+    L.check(L.lib().tvr_mlpnet_forward(C.byref(desc), img.data_ptr(), pts.data_ptr(), v.data_ptr(), n, rgb.data_ptr(), sig.data_ptr(), _stream_ptr(pts.device)), "fwd")
+    assert bool((rgb[n:] == -7).all()) and bool((sig[n:] == -7).all())          # nothing written past the end
+    with torch.no_grad():
+        vv = v[torch.arange(n, device="cuda") // 512]
+        want = m.bg_net(torch.cat((m.bg_embedder_position(pts), m.bg_embedder_viewdir(vv)), -1))
+    assert (rgb[:n] - want["rgb"]).abs().max().item() < 2e-5 and (sig[:n] - want["sigma"]).abs().max().item() < 2e-5 * max(1.0, want["sigma"].max().item())
+    bad = L.MlpnetDesc(4, 256, 2, 4, 2, 512)
+    assert L.lib().tvr_mlpnet_packed_bytes(C.byref(bad)) == 0 and b"W = 128" in L.lib().tvr_last_error()
+    assert L.lib().tvr_mlpnet_forward(C.byref(desc), None, None, None, 5, None, None, None) == -1
+    assert L.lib().tvr_npp_bg_points(None, None, 3, None, 512, None, 6.0, None, None, None) == -1
+    assert L.lib().tvr_npp_bg_composite(None, None, None, 0, 512, None, None) == 0
