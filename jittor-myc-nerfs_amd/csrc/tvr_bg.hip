@@ -27,6 +27,9 @@
 #define BG_BIAS_FLOATS 640                    // 4 x 128 base biases, 64 rgb-hidden, sigma, 3 rgb (padded)
 #define BG_LDS_BYTES (BG_MAX_BLOCKS * 2048 + BG_BIAS_FLOATS * 4)
 #define BG_WAVES 8
+#ifndef TVR_BG_APF
+#define TVR_BG_APF 0
+#endif
 
 struct BgProgram {
     int D, n_pe_steps, input_ch, split;       // base layers [0, split) run from stage A, the rest and the heads from stage B
@@ -101,22 +104,36 @@ __device__ __forceinline__ f32x16 bias_acc(const float *__restrict__ bias32, int
     }
     return a;
 }
-// one k-step into NB accumulators (independent blocks: their MFMAs interleave)
+// one k-step into NB accumulators (independent blocks: their MFMAs interleave): A fragments from LDS, then 3 products per block
+template <int NB>
+struct AFrags {
+    uint4 h[NB], l[NB];
+};
+template <int NB>
+__device__ __forceinline__ AFrags<NB> load_a(const uint4 *__restrict__ w4, const int (&blk)[NB])
+{
+    AFrags<NB> a;
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+        a.h[m] = w4[(blk[m] * 2 + 0) * 64];
+        a.l[m] = w4[(blk[m] * 2 + 1) * 64];
+    }
+    return a;
+}
+template <int NB>
+__device__ __forceinline__ void mma(const AFrags<NB> &a, const Frag &b, f32x16 (&acc)[NB])
+{
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(a.l[m], b.hi, acc[m]);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(a.h[m], b.lo, acc[m]);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(a.h[m], b.hi, acc[m]);
+}
 template <int NB>
 __device__ __forceinline__ void kstep(const uint4 *__restrict__ w4, const int (&blk)[NB], const Frag &b, f32x16 (&acc)[NB])
 {
-    uint4 ah[NB], al[NB];
-#pragma unroll
-    for (int m = 0; m < NB; ++m) {
-        ah[m] = w4[(blk[m] * 2 + 0) * 64];
-        al[m] = w4[(blk[m] * 2 + 1) * 64];
-    }
-#pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(al[m], b.hi, acc[m]);
-#pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(ah[m], b.lo, acc[m]);
-#pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(ah[m], b.hi, acc[m]);
+    mma<NB>(load_a<NB>(w4, blk), b, acc);
 }
 
 __device__ __forceinline__ void load_stage(uint4 *__restrict__ lds4, const uint4 *__restrict__ image, int n_blocks)
@@ -135,12 +152,27 @@ __device__ __forceinline__ void base_layers(const BgProgram &P, int l0, int l1, 
         for (int mb = 0; mb < 4; ++mb) out[mb] = bias_acc(lbias + l * 128 + mb * 32, hh);
         const int prev = P.base_prev[l], pe = P.base_pe[l], spm = (prev ? 8 : 0) + (pe ? P.n_pe_steps : 0), b0 = P.base_block0[l];
         if (prev) {
+#if TVR_BG_APF
+            // the A fragments of k-step t+1 are fetched from LDS before the MFMAs of k-step t are issued (LDS latency off the MFMA path)
+            const int blk0[4] = {b0, b0 + spm, b0 + 2 * spm, b0 + 3 * spm};
+            AFrags<4> a = load_a<4>(w4, blk0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int tn = t < 7 ? t + 1 : 7;
+                const int blk[4] = {b0 + tn, b0 + spm + tn, b0 + 2 * spm + tn, b0 + 3 * spm + tn};
+                const AFrags<4> an = load_a<4>(w4, blk);
+                const Frag b = relu_frag4(act, t);
+                mma<4>(a, b, out);
+                a = an;
+            }
+#else
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const Frag b = relu_frag4(act, t);
                 const int blk[4] = {b0 + t, b0 + spm + t, b0 + 2 * spm + t, b0 + 3 * spm + t};
                 kstep<4>(w4, blk, b, out);
             }
+#endif
         }
         if (pe) {
 #pragma unroll
