@@ -388,8 +388,6 @@ static int plan(const tvr_mlpnet_desc *d, BgLayout &L)
         blocks[l] = 4 * ((P.base_prev[l] ? 8 : 0) + (P.base_pe[l] ? P.n_pe_steps : 0));
     }
     const int heads = 8 + 18 + 4;
-    int total = heads;
-    for (int l = 0; l < P.D; ++l) total += blocks[l];
     // the split that balances the two stages and fits both
     P.split = -1;
     for (int s = 1; s <= P.D; ++s) {
