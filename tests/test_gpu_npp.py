@@ -160,6 +160,9 @@ def test_background_network_kernel_matches_torch(tiny_npp_arrays, hyper_tiny, bg
         inp = torch.cat((m.bg_embedder_position(pts), m.bg_embedder_viewdir(v.unsqueeze(-2).expand(n, N, 3))), dim=-1)
         want = m.bg_net(inp)
     assert m._bg_image is not None, "the HIP path did not run"
+    with torch.no_grad():
+        again = m._mlpnet(pts, v)
+    assert torch.equal(again["rgb"], got["rgb"]) and torch.equal(again["sigma"], got["sigma"])          # bit-reproducible
     es, er = (got["sigma"] - want["sigma"]).abs().max().item(), (got["rgb"] - want["rgb"]).abs().max().item()
     print(f"bg net D={bg_D} freq={bg_freq}: sigma err {es:.2e} (max {want['sigma'].abs().max().item():.2f}), rgb err {er:.2e}")
     assert es < 2e-5 * max(1.0, want["sigma"].abs().max().item()) and er < 2e-5
