@@ -39,17 +39,55 @@ class _LinearFn(torch.autograd.Function):
         gx = gy @ weight if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
-            Ka, Kb, M = weight.shape[0], weight.shape[1], x.shape[0]
-            if x.is_cuda and M >= 4096 and ((Ka + 31) // 32) * ((Kb + 31) // 32) <= 20 and x.dtype == torch.float32:
-                xc = x.contiguous()
-                gw = torch.empty((Ka, Kb), dtype=torch.float32, device=x.device)
-                scratch = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb, M), dtype=torch.uint8, device=x.device)
-                L.check(L.lib().tvr_gemm_tn(gy.data_ptr(), Ka, Ka, xc.data_ptr(), Kb, Kb, M, gw.data_ptr(), scratch.data_ptr(), scratch.numel(),
-                                            _stream_ptr(x.device)), "tvr_gemm_tn")
-            else:
-                gw = gy.t() @ x
-        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            gw = _gemm_tn(gy, x.contiguous()) if (x.is_cuda and x.shape[0] >= 4096 and x.dtype == torch.float32) else gy.t() @ x
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            # torch's column reduction is fine at the foreground's M ~ 3.5e5 (0.1 ms) and collapses at the background's 2.1e6 (2.3 ms)
+            gb = _colsum(gy) if (gy.is_cuda and gy.shape[0] >= 1000000 and gy.dtype == torch.float32) else gy.sum(0)
         return gx, gw, gb
+
+
+_ONES = {}
+
+
+def _gemm_tn_call(a, lda, Ka, b, ldb, Kb, M, a_off=0, b_off=0):
+    out = torch.empty((Ka, Kb), dtype=torch.float32, device=a.device)
+    scratch = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb, M), dtype=torch.uint8, device=a.device)
+    L.check(L.lib().tvr_gemm_tn(a.data_ptr() + 4 * a_off, lda, Ka, b.data_ptr() + 4 * b_off, ldb, Kb, M, out.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                _stream_ptr(a.device)), "tvr_gemm_tn")
+    return out
+
+
+def _gemm_tn(gy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW [Ka,Kb] = gy^T x for contiguous fp32 gy [M,Ka], x [M,Kb] through tvr_gemm_tn (deterministic).  The kernel takes at most 20
+    32x32 output tiles per call: wider products are cut into column blocks of gy and x (pointer offsets, same row strides)."""
+    M, Ka, Kb = gy.shape[0], gy.shape[1], x.shape[1]
+    ta, tb = (Ka + 31) // 32, (Kb + 31) // 32
+    if ta * tb <= 20:
+        return _gemm_tn_call(gy, Ka, Ka, x, Kb, Kb, M)
+    ca = min(ta, 4) * 32                                   # rows of dW per call
+    cb = max(1, 20 // min(ta, 4)) * 32                     # columns of dW per call
+    out = torch.empty((Ka, Kb), dtype=torch.float32, device=gy.device)
+    for a0 in range(0, Ka, ca):
+        for b0 in range(0, Kb, cb):
+            out[a0:a0 + ca, b0:b0 + cb] = _gemm_tn_call(gy, Ka, min(ca, Ka - a0), x, Kb, min(cb, Kb - b0), M, a_off=a0, b_off=b0)
+    return out
+
+
+def _colsum(gy: torch.Tensor) -> torch.Tensor:
+    """Bias gradient gy.sum(0) for tall gy [M,K] as gy^T 1 through tvr_gemm_tn: torch's column reduction takes ~2.3 ms for
+    M = 2.1e6, K = 128; this reads gy once at memory speed and has a fixed summation order."""
+    M, K = gy.shape
+    key = (gy.device, M)
+    ones = _ONES.get(key)
+    if ones is None:
+        _ONES.clear()
+        ones = _ONES[key] = torch.ones(M, dtype=torch.float32, device=gy.device)
+    out = torch.empty(K, dtype=torch.float32, device=gy.device)
+    for k0 in range(0, K, 640):                            # 20 tiles of 32 rows
+        kk = min(640, K - k0)
+        out[k0:k0 + kk] = _gemm_tn_call(gy, K, kk, ones, 1, 1, M, a_off=k0).view(-1)
+    return out
 
 
 def _linear(lin: torch.nn.Linear, x):

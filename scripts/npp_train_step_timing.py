@@ -1,0 +1,34 @@
+"""NerfPlusPlus training step (what configs/Scarf.txt trains) at the reference's batch size: 4096 rays, nSamples from the grid,
+foreground through the HIP kernels under autograd, background network (512 samples per ray) as torch modules under autograd."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench
+from jittor_myc_nerfs_amd import NerfPlusPlus, OctreeRender_trilinear_fast, synthetic
+A, H = synthetic.SCENE_A, synthetic.HYPER
+arrs = synthetic.make_scene_arrays(A["gridSize"], A["aabb"], npp=6.0)
+m = NerfPlusPlus(arrs["aabb"], A["gridSize"], "cuda", density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, app_dim=27, near_far=A["near_far"],
+                 shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=H["density_shift"], distance_scale=H["distance_scale"],
+                 rayMarch_weight_thres=H["rayMarch_weight_thres"], pos_pe=6, view_pe=2, fea_pe=2, featureC=128, step_ratio=A["step_ratio"],
+                 fea2denseAct=H["fea2denseAct"])
+m.load_arrays(arrs)
+rays = bench.frames(A)[0].cuda()
+target = torch.rand(rays.shape[0], 3, device="cuda")
+nS = int(np.linalg.norm(A["gridSize"]) / 0.5)
+opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99), fused=True)
+g = torch.Generator(device="cuda").manual_seed(0)
+def step(profile=None):
+    idx = torch.randint(0, rays.shape[0], (4096,), device="cuda", generator=g)
+    opt.zero_grad()
+    rgb_map = OctreeRender_trilinear_fast(rays[idx], m, chunk=4096, N_samples=nS, white_bg=False, is_train=True)[0]
+    loss = torch.mean((rgb_map - target[idx]) ** 2)
+    loss.backward()
+    opt.step()
+    return loss
+for _ in range(3): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+N = 10
+for _ in range(N): l = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
+print(f"NerfPlusPlus train step: {dt * 1e3:.1f} ms ({1 / dt:.1f} it/s), 4096 rays x {nS} fg samples + 512 bg samples, loss {float(l.detach()):.3e}")
