@@ -182,3 +182,28 @@ def test_fixed_order_reductions_are_bit_reproducible():
         (gx,) = torch.autograd.grad(v, x)
         vals.append(v.detach().clone()); grads.append(gx.clone())
     assert torch.equal(vals[0], vals[1]) and torch.equal(vals[0], vals[2]) and torch.equal(grads[0], grads[2])
+
+
+def test_wide_weight_and_bias_gradients_through_gemm_tn():
+    """_gemm_tn cuts products wider than 20 output tiles into column blocks; _colsum is gy^T 1 (the background network's M = 2.1e6 rows)."""
+    from jittor_myc_nerfs_amd.autograd_ops import _LinearFn, _colsum, _gemm_tn
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M = 1_050_001
+    gy = torch.randn(M, 256, device="cuda", generator=g)
+    x = torch.randn(M, 164, device="cuda", generator=g)
+    want = (gy.double().t() @ x.double())
+    got = _gemm_tn(gy, x)
+    assert (got.double() - want).abs().max().item() < 2e-6 * M ** 0.5 * 4
+    assert torch.equal(got, _gemm_tn(gy, x))                           # fixed summation order
+    cs = _colsum(gy)
+    assert (cs.double() - gy.double().sum(0)).abs().max().item() < 2e-6 * M ** 0.5 * 4
+    # through the autograd function at this size (bias path switches to _colsum at M >= 1e6)
+    w = torch.randn(64, 164, device="cuda", generator=g, requires_grad=True)
+    b = torch.zeros(64, device="cuda", requires_grad=True)
+    xin = x.clone().requires_grad_(True)
+    y = _LinearFn.apply(xin, w, b)
+    gyy = torch.randn(M, 64, device="cuda", generator=g)
+    y.backward(gyy)
+    assert (w.grad.double() - gyy.double().t() @ x.double()).abs().max().item() < 1e-2
+    assert (b.grad.double() - gyy.double().sum(0)).abs().max().item() < 1e-2
+    assert (xin.grad - gyy @ w.detach()).abs().max().item() < 1e-3
