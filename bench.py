@@ -99,6 +99,105 @@ def cpu_baseline(arrs, A, rays_cpu, budget_s=15.0, with_c=True):
     return out
 
 
+def bench_ngp(args, world, rank, device):
+    """BASELINE configs[4]: JNeRF Instant-NGP inference, one 800x800 frame per step through the fused frame path (tvr_ngp_render).  The
+    path has no exchange step: for N > 1 every rank renders its own frames (replicas only)."""
+    import math
+    import torch.distributed as dist
+    from jittor_myc_nerfs_amd import ngp, rays as R, synthetic
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("TVR_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, device_id=device) if backend == "nccl" else dist.init_process_group(backend)
+    aabb_scale, W = 4, 800
+    model = ngp.NGPNetworks(aabb_scale).to(device)
+    sampler = ngp.DensityGridSampler(model, aabb_scale, rng=ngp.Pcg32(1337)).to(device)
+    arrs = synthetic.make_ngp_scene_arrays(model.pos_encoder.offsets)
+    ngp.load_scene_arrays(model, sampler, arrs)
+    focal = 0.5 * W / math.tan(0.5 * 0.6911)
+    poses = R.sphere_poses(8, 4.0)
+    frames = [ngp.generate_rays(ngp.matrix_nerf2ngp(p), W, W, (focal, focal), device=device) for p in poses]
+    for i in range(args.warmup):
+        sampler.render_frame(*frames[i % len(frames)])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    marched = evaluated = 0
+    k_ms = [0.0, 0.0]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        st, pr = {}, {}
+        sampler.render_frame(*frames[(args.warmup + i) % len(frames)], stats=st, profile=pr)
+        marched += st["samples"]
+        evaluated += st["evaluated"]
+        k_ms[0] += pr["march_ms"]
+        k_ms[1] += pr["render_ms"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    k_ms = [k / args.steps for k in k_ms]
+    ev_per = evaluated / args.steps
+    BYTES = 16 * 8 * 8 + 4 + 12                  # per evaluated sample: 16 levels x 8 corners x 8 B of table, its recorded t, 12 B of output share
+    ach = BYTES * ev_per / (k_ms[1] * 1e-3) / 1e9
+    result = {
+        "metric": "ray_samples_per_sec", "value": marched * world / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "JNeRF Instant-NGP inference (BASELINE configs[4]): 16-level hash grid 2^19 x 2, SH-16, MLPs 32-64-16 / 32-64-64-3, 5 x 128^3 "
+                               "occupancy bitfield, 800x800 rays per GPU, up to 1024 steps per ray, dt = sqrt(3)/2048; fused frame path tvr_ngp_render; "
+                               "N > 1: independent replicas (no exchange step on this path)",
+                   "scene": "synthetic.make_ngp_scene_arrays, aabb_scale 4 (hollow-ball occupancy + 2 % speckle)", "rays_per_step": W * W * world,
+                   "samples": "value counts the occupied steps the march produces (what the reference feeds its networks); the frame kernel "
+                              "evaluates only those in front of the compositor's T < 1e-4 break"},
+        "rays_per_sec": W * W * world * args.steps / dt,
+        "effective": {"marched_samples_per_frame": marched / args.steps, "evaluated_samples_per_frame": ev_per},
+        "kernel_ms": {"march": k_ms[0], "render": k_ms[1]},
+        "roofline": {"kernel": "ngp_render_kernel<true>", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                     "traffic": _ngp_traffic(), "algorithmic_bytes_per_launch": BYTES * ev_per, "ms": k_ms[1],
+                     "note": f"{BYTES} B per evaluated sample; the 52 MB of tables sit in L2 / MALL, so the measured traffic is fabric traffic of random 128-B lines"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ngp_oracle as N
+        o, d = frames[0]
+        sel = torch.arange(0, W * W, 311, device=device)[:2048]                                 # a strided sample of pose 0
+        on, dn = o[sel].cpu().numpy(), d[sel].cpu().numpy()
+        levels = N.grid_levels(aabb_scale)
+        a2 = dict(arrs)
+        a2["density_grid_bitfield"], _ = N.update_bitfield(arrs["density_grid"])
+        t1 = time.perf_counter()
+        coords, _, numsteps, _, _ = N.sample(on, dn, a2["density_grid_bitfield"], aabb_scale, N.Pcg32(1337).state)
+        out = N.network_c(levels, a2, coords)
+        N.composite_c(out, coords, numsteps)
+        tc = time.perf_counter() - t1
+        result["cpu_baseline"] = {"value": coords.shape[0] / tc, "unit": "ray-samples/s", "cores": 1, "kind": "port",
+                                  "sample": f"every 311th ray of pose 0: {len(on)} rays, {coords.shape[0]} samples in {tc:.1f} s; oracle/ngp_oracle.c "
+                                            "(scalar C restatement: march + hash grid + SH + MLPs + compositing, every sample evaluated); the reference's CUDA/Jittor path cannot run here"}
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _ngp_traffic():
+    """FETCH_SIZE (x2, gfx950) of ngp_render_kernel from the committed PMC pass, bytes per launch."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_ngp_pmc.json")))
+        for k, v in d.items():
+            if "ngp_render_kernel" in k and "FETCH_SIZE" in v:
+                return v["FETCH_SIZE"] * 1024.0 * 2.0
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,8 +209,9 @@ def main():
                                                           "configs[3] / train.py batch size)")
     ap.add_argument("--alpha-mask", type=int, default=0, help="build an AlphaGridMask of this resolution with updateAlphaMask first "
                                                                "(the reference does so at iteration 2000/4000); 0 = none")
-    ap.add_argument("--model", choices=["TensorVMSplit", "REFTensoRF"], default="TensorVMSplit",
-                    help="model_name (opt.py:44): TensorVMSplit is the BASELINE workload; REFTensoRF is the variant configs/Scar.txt trains")
+    ap.add_argument("--model", choices=["TensorVMSplit", "REFTensoRF", "NGPNetworks"], default="TensorVMSplit",
+                    help="model_name (opt.py:44): TensorVMSplit is the BASELINE workload; REFTensoRF is the variant configs/Scar.txt trains; "
+                         "NGPNetworks is the JNeRF Instant-NGP alt path (BASELINE configs[4]; replicas only for N > 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,6 +227,8 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     import torch.distributed as dist
+    if args.model == "NGPNetworks":
+        return bench_ngp(args, world, rank, device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("TVR_BENCH_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm; "gloo" only for 1-GPU rehearsals

@@ -104,6 +104,12 @@ int tvr_ngp_render(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cf
                    const void *rays_d, int64_t n_rays, const void *bitfield, const float background[3], void *rgb, void *stats,
                    void *scratch, size_t scratch_bytes, void *stream);
 
+/* tvr_ngp_render with HIP events around its two kernels, recorded on `stream`; WAITS for completion (a measurement entry point, unlike
+ * everything else here) and returns ms_out = (march ms, render-kernel ms). */
+int tvr_ngp_render_profiled(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const void *net_packed, const void *rays_o,
+                            const void *rays_d, int64_t n_rays, const void *bitfield, const float background[3], void *rgb, void *stats,
+                            void *scratch, size_t scratch_bytes, void *stream, float ms_out[2]);
+
 #ifdef __cplusplus
 }
 #endif

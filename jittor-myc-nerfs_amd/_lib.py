@@ -127,6 +127,8 @@ SYMBOLS = {
     "tvr_ngp_render_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tvr_ngp_render": (C.c_int, [C.POINTER(NgpMarchCfg), C.POINTER(NgpGridCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.POINTER(C.c_float * 3), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_ngp_render_profiled": (C.c_int, [C.POINTER(NgpMarchCfg), C.POINTER(NgpGridCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.POINTER(C.c_float * 3), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_float * 2)]),
     "tvr_ngp_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float * 3), C.c_void_p, C.c_void_p]),
 }
 

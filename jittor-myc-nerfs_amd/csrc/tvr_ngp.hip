@@ -1037,9 +1037,11 @@ size_t tvr_ngp_render_scratch_bytes(int64_t n_rays)
     return align_up((size_t)n_rays * 4, 256) + 256 + (size_t)n_rays * TVR_NGP_STEPS * sizeof(float);
 }
 
-int tvr_ngp_render(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const void *net_packed, const void *rays_o,
-                   const void *rays_d, int64_t n_rays, const void *bitfield, const float background[3], void *rgb, void *stats,
-                   void *scratch, size_t scratch_bytes, void *stream)
+}  // extern "C" (interrupted: the shared body below has C++ linkage)
+
+static int ngp_render_impl(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const void *net_packed, const void *rays_o,
+                           const void *rays_d, int64_t n_rays, const void *bitfield, const float background[3], void *rgb, void *stats,
+                           void *scratch, size_t scratch_bytes, void *stream, hipEvent_t *ev)
 {
     MarchCfg c;
     GridCfg g;
@@ -1059,14 +1061,46 @@ int tvr_ngp_render(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cf
     float *tslab = reinterpret_cast<float *>(p + n + 256);
     HIP_TRY(hipMemsetAsync(queue, 0, 8, st));
     const float *o = static_cast<const float *>(rays_o), *d = static_cast<const float *>(rays_d);
+    if (ev) HIP_TRY(hipEventRecord(ev[0], st));
     hipLaunchKernelGGL(ngp_march_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, c, o, d, (long long)n_rays, static_cast<const uint8_t *>(bitfield), counts, tslab);
+    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     const bool f16 = !TVR_NGP_MLP_F32;
     const unsigned blocks = (unsigned)(n_rays < 4 * 512 ? (n_rays + 3) / 4 : 512);         // 256 CUs x 2 blocks (LDS image + 2 waves / SIMD)
     hipLaunchKernelGGL(f16 ? ngp_render_kernel<true> : ngp_render_kernel<false>, dim3(blocks), dim3(256), 0, st, c, g, static_cast<const float *>(grid),
                        static_cast<const float *>(net_packed) + (f16 ? NGP_IMAGE_FLOATS : 0), o, d, (long long)n_rays, counts, tslab, queue, background[0],
                        background[1], background[2], static_cast<float *>(rgb), static_cast<unsigned long long *>(stats));
+    if (ev) HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipGetLastError());
     return TVR_OK;
+}
+
+
+extern "C" {
+
+int tvr_ngp_render(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const void *net_packed, const void *rays_o,
+                   const void *rays_d, int64_t n_rays, const void *bitfield, const float background[3], void *rgb, void *stats,
+                   void *scratch, size_t scratch_bytes, void *stream)
+{
+    return ngp_render_impl(cfg, grid_cfg, grid, net_packed, rays_o, rays_d, n_rays, bitfield, background, rgb, stats, scratch, scratch_bytes, stream, nullptr);
+}
+
+int tvr_ngp_render_profiled(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const void *net_packed, const void *rays_o,
+                            const void *rays_d, int64_t n_rays, const void *bitfield, const float background[3], void *rgb, void *stats,
+                            void *scratch, size_t scratch_bytes, void *stream, float ms_out[2])
+{
+    if (!ms_out) return tvr_set_error(TVR_ERR_INVALID, "tvr_ngp_render_profiled: ms_out is NULL");
+    hipEvent_t ev[3];
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreate(&ev[k]));
+    int rc = ngp_render_impl(cfg, grid_cfg, grid, net_packed, rays_o, rays_d, n_rays, bitfield, background, rgb, stats, scratch, scratch_bytes, stream, ev);
+    ms_out[0] = ms_out[1] = 0.f;
+    if (rc == TVR_OK && n_rays > 0) {
+        hipError_t e = hipEventSynchronize(ev[2]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms_out[0], ev[0], ev[1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms_out[1], ev[1], ev[2]);
+        if (e != hipSuccess) rc = tvr_set_error(TVR_ERR_HIP, "tvr_ngp_render_profiled: %s", hipGetErrorString(e));
+    }
+    for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);
+    return rc;
 }
 
 }  // extern "C"

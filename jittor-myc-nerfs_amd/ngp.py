@@ -313,10 +313,11 @@ class DensityGridSampler(torch.nn.Module):
         return rgb
 
     # -- one frame without the slab loop
-    def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, stats: Optional[dict] = None) -> torch.Tensor:
+    def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, stats: Optional[dict] = None, profile: Optional[dict] = None) -> torch.Tensor:
         """The image `render_img` produces, in two launches and no host read (`tvr_ngp_render`): the march over all rays (each ray draws
         the jitter it would get in its 4096-ray slab), then one kernel that walks every ray's steps through the encoders and networks
-        and composites them in order, stopping where `compute_rgbs_inference` breaks (T < 1e-4).  Nothing in between is materialised."""
+        and composites them in order, stopping where `compute_rgbs_inference` breaks (T < 1e-4).  Nothing in between is materialised.
+        `profile` (a dict) switches to the measuring entry point: per-kernel milliseconds, at the price of waiting for the frame."""
         dev = self.density_grid_bitfield.device
         _need_gpu(self.density_grid_bitfield, "DensityGridSampler")
         o = rays_o.detach().to(dev, torch.float32).contiguous()
@@ -330,9 +331,15 @@ class DensityGridSampler(torch.nn.Module):
         cfg = self._cfg(self.n_rays_per_batch)
         bgc = (C.c_float * 3)(*self.background_color)
         m = self.model
-        L.check(L.lib().tvr_ngp_render(C.byref(cfg), C.byref(m.pos_encoder.cfg), m.pos_encoder.m_grid.data_ptr(), m.packed().data_ptr(), o.data_ptr(), d.data_ptr(),
-                                       R, self.density_grid_bitfield.data_ptr(), C.byref(bgc), rgb.data_ptr(), None if st is None else st.data_ptr(),
-                                       self._scratch.data_ptr(), self._scratch.numel(), _stream(dev)), "tvr_ngp_render")
+        args = (C.byref(cfg), C.byref(m.pos_encoder.cfg), m.pos_encoder.m_grid.data_ptr(), m.packed().data_ptr(), o.data_ptr(), d.data_ptr(),
+                R, self.density_grid_bitfield.data_ptr(), C.byref(bgc), rgb.data_ptr(), None if st is None else st.data_ptr(),
+                self._scratch.data_ptr(), self._scratch.numel(), _stream(dev))
+        if profile is None:
+            L.check(L.lib().tvr_ngp_render(*args), "tvr_ngp_render")
+        else:                                                           # HIP events around the two kernels; waits for completion
+            ms = (C.c_float * 2)()
+            L.check(L.lib().tvr_ngp_render_profiled(*args, C.byref(ms)), "tvr_ngp_render_profiled")
+            profile.update(march_ms=float(ms[0]), render_ms=float(ms[1]))
         for _ in range((R + self.n_rays_per_batch - 1) // self.n_rays_per_batch):
             self.rng.advance()                                          # as many advances as the slab loop would make
         if stats is not None:
