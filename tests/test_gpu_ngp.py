@@ -161,7 +161,9 @@ def test_render_img_and_render_frame(setup):
     assert fs["samples"] == stats["samples"] and 0.2 * fs["samples"] < fs["evaluated"] < 0.9 * fs["samples"]
     assert (a - c).abs().max().item() < 2e-6, "fused frame differs from the slab loop beyond summation order"
     sampler.rng = ngp.Pcg32(1337)
-    assert torch.equal(sampler.render_frame(to, td), c)                # deterministic despite the dynamic ray queue
+    prof = {}
+    assert torch.equal(sampler.render_frame(to, td, profile=prof), c)  # deterministic despite the dynamic ray queue; measuring entry point
+    assert prof["march_ms"] > 0 and prof["render_ms"] > 0
     want = N.render_img(arrs, levels, o, d, NGP_AABB_SCALE, N.Pcg32(1337))
     err = np.abs(a.cpu().numpy() - want).max()
     assert err < RGB_TOL, f"RGB L-inf vs oracle {err:.3e}"
