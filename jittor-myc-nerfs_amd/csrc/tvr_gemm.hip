@@ -95,6 +95,7 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
 // Measured and rejected as the default: 0.227 vs 0.26 ms at M = 3.6e5 and 0.8 vs 1.1 ms at M = 2.1e6 (the kernel is on memory and launch
 // latency, not on the fp32 matrix pipe), and fp16's exponent range is wrong for gradients — dY entries below 6e-8 vanish in the split and a
 // NerfPlusPlus background gradient came out 6e-3 off (tests/test_gpu_npp.py).  Forward activations are O(1); gradients are not.
+// (An fp32 kernel with this wave-owns-a-block fragment sharing was also tried: 0.63 vs 0.26 ms at 356 000 x 128 x 128 — slower, removed.)
 #ifndef TVR_GEMM_F32
 #define TVR_GEMM_F32 1
 #endif
