@@ -8,6 +8,8 @@
 //                             of one layer IS the B-operand layout of the next once the k index is paired (r, r+4), and that
 //                             pairing is folded into the packed weight image (LDS, one ds_read_b32 per MFMA).
 //   ngp_composite_kernel      compute_rgbs_inference: one lane per ray over its contiguous rows.
+//   ngp_render_kernel         the whole frame in one kernel after the march (tvr_ngp_render): a wave walks a ray's recorded steps 32 at a
+//                             time through the same field_tile code and composites in order, stopping at the compositor's T < 1e-4 break.
 //   + stand-alone hash / SH encoders (the reference's separate ops) and update_bitfield.
 //
 // Compiled with -ffp-contract=off; FMAs are explicit where the reference's compiler contracts (see oracle/ngp_oracle.c header).
@@ -1037,7 +1039,7 @@ size_t tvr_ngp_render_scratch_bytes(int64_t n_rays)
     return align_up((size_t)n_rays * 4, 256) + 256 + (size_t)n_rays * TVR_NGP_STEPS * sizeof(float);
 }
 
-}  // extern "C" (interrupted: the shared body below has C++ linkage)
+}  // extern "C" — closed here: the body shared by tvr_ngp_render / tvr_ngp_render_profiled has internal linkage
 
 static int ngp_render_impl(const tvr_ngp_march_cfg *cfg, const tvr_ngp_grid_cfg *grid_cfg, const void *grid, const void *net_packed, const void *rays_o,
                            const void *rays_d, int64_t n_rays, const void *bitfield, const float background[3], void *rgb, void *stats,
