@@ -209,6 +209,28 @@ def test_other_aabb_scales(aabb_scale):
     assert np.array_equal(sampler._coords.cpu().numpy().view(np.uint32), want[0].view(np.uint32))
 
 
+def test_reference_initialisation_magnitudes():
+    """The reference initialises the hash grid U(+-1e-4) (hash_encoder.py:23-24): features of that size sit near fp16's subnormal range,
+    where the hi/lo split of the fused network loses relative accuracy — the outputs must still match fp32 arithmetic absolutely."""
+    from jittor_myc_nerfs_amd import ngp
+    from oracle import ngp_oracle as N
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = ngp.NGPNetworks(1).to(dev)                                 # default init: grid U(+-1e-4), torch Linear init
+    levels = N.grid_levels(1)
+    arrs = {"grid": model.pos_encoder.m_grid.detach().cpu().numpy()}
+    for name, mod in (("density_mlp.0", model.density_mlp[0]), ("density_mlp.2", model.density_mlp[2]), ("rgb_mlp.0", model.rgb_mlp[0]),
+                      ("rgb_mlp.2", model.rgb_mlp[2]), ("rgb_mlp.4", model.rgb_mlp[4])):
+        arrs[name + ".weight"] = mod.weight.detach().cpu().numpy()
+    rng = np.random.default_rng(0)
+    coords = np.concatenate([rng.random((5000, 3), dtype=np.float32), np.zeros((5000, 1), np.float32), rng.random((5000, 3), dtype=np.float32)], 1)
+    want = N.network_c(levels, arrs, coords)
+    c = torch.from_numpy(coords).to(dev)
+    got = model(c[:, :3], c[:, 4:]).cpu().numpy()
+    assert np.abs(want[:, 3]).max() < 1e-3                             # density head driven by 1e-4 features
+    assert np.abs(got - want).max() < 1e-6, np.abs(got - want).max()
+
+
 def test_against_committed_golden(setup):
     """tests/golden/ngp.npz (make_golden_ngp.py): sampler rows bit for bit (digest), network / picture to tolerance."""
     import hashlib
