@@ -443,11 +443,26 @@ def load_jnerf_checkpoint(path: str, model: NGPNetworks, sampler: Optional[Densi
     with open(path, "rb") as f:
         ckpt = pickle.load(f)
     m = {k: np.asarray(v) for k, v in ckpt["model"].items()}
+    # `fp16 = True` configs (ngp_comp.py:100) build the networks as FMLP (ngp_network.py:9-39): each keeps ONE flat `con_weights` =
+    # concat_i(dweights[i].T.reshape(-1)) with dweights[i] of shape (in, out) and the last layer zero-padded to 16 outputs.  dweights[i].T is
+    # the [out, in] matrix of the equivalent bias-free Linear; they are evaluated here in fp32 (the FMLP kernels themselves ship without
+    # source, so their fp16 rounding is not reproduced).
+    for prefix, shapes, names in (("density_mlp", [(64, 32), (16, 64)], ["0", "2"]), ("rgb_mlp", [(64, 32), (64, 64), (16, 64)], ["0", "2", "4"])):
+        key = prefix + ".con_weights"
+        if key in m and prefix + ".0.weight" not in m:
+            flat, off = m[key].astype(np.float32).reshape(-1), 0
+            if flat.size != sum(a * b for a, b in shapes):
+                raise ValueError(f"{path}: {key} has {flat.size} entries, expected {sum(a * b for a, b in shapes)}")
+            for (o, i), nm in zip(shapes, names):
+                m[f"{prefix}.{nm}.weight"] = flat[off:off + o * i].reshape(o, i)
+                off += o * i
+            if prefix == "rgb_mlp":
+                m["rgb_mlp.4.weight"] = m["rgb_mlp.4.weight"][:3]          # drop the zero padding rows
     want = {"pos_encoder.m_grid": (model.pos_encoder.m_n_params,), "density_mlp.0.weight": (64, 32), "density_mlp.2.weight": (16, 64),
             "rgb_mlp.0.weight": (64, 32), "rgb_mlp.2.weight": (64, 64), "rgb_mlp.4.weight": (3, 64)}
     for k, shape in want.items():
         if k not in m:
-            raise KeyError(f"{path}: 'model' has no '{k}' (FullyFusedMlp checkpoints keep their weights in `con_weights`; not supported)")
+            raise KeyError(f"{path}: 'model' has no '{k}'")
         if tuple(m[k].shape) != shape:
             raise ValueError(f"{path}: {k} has shape {tuple(m[k].shape)}, this model (aabb_scale {model.pos_encoder.aabb_scale}) needs {shape}")
     load_scene_arrays(model, None, {k: m[k].astype(np.float32) for k in want})
