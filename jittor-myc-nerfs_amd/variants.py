@@ -420,16 +420,13 @@ class NerfPlusPlus(TensorVMSplit):
         else:
             rgb_map, depth_map, bg_lambda = self._render_z(rays, z_vals, S, eps_T)
         bg_lambda = torch.where(bg_lambda > 0.1, bg_lambda, torch.zeros_like(bg_lambda))     # :311
-        if torch.is_grad_enabled() and is_train:
-            bg_rgb_map = self._background(rays[:, :3], rays[:, 3:6], rand_bg)
-            rgb_map = rgb_map + bg_lambda.unsqueeze(-1) * bg_rgb_map                          # :312-314
-        else:
-            # inference: rays whose foreground transmittance is <= 0.1 get 0 * background in the reference — their 512 background samples
-            # are not evaluated here (same picture)
-            idx = torch.nonzero(bg_lambda > 0).squeeze(-1)
-            if idx.numel():
-                bg = self._background(rays[idx, :3], rays[idx, 3:6], None if rand_bg is None else torch.as_tensor(rand_bg, device=self.device)[idx])
-                rgb_map = rgb_map.index_add(0, idx, bg_lambda[idx].unsqueeze(-1) * bg)
+        # rgb_map + bg_lambda * bg_rgb_map (:312-314).  Rays whose foreground transmittance is <= 0.1 get 0 * background in the reference: their
+        # 512 background samples contribute neither to the picture nor to any gradient (the `where` passes a constant zero), so they are
+        # not evaluated — at inference and in training alike.
+        idx = torch.nonzero(bg_lambda > 0).squeeze(-1)
+        if idx.numel():
+            bg = self._background(rays[idx, :3], rays[idx, 3:6], None if rand_bg is None else torch.as_tensor(rand_bg, device=self.device)[idx])
+            rgb_map = rgb_map.index_add(0, idx, bg_lambda[idx].unsqueeze(-1) * bg)
         return rgb_map, depth_map
 
     execute = forward
