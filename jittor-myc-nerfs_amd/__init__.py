@@ -6,7 +6,7 @@ hand-written HIP kernels for gfx950 behind the C-ABI in include/tvr.h (csrc/, bu
 from .field import AlphaGridMask, MLPRender_Fea, TensorBase, TensorVMSplit, load_checkpoint  # noqa: F401
 from .variants import Embedder, MLPNet, MLPRender_Fea_Ref, NerfPlusPlus, REFTensoRF  # noqa: F401
 from .render import OctreeRender_trilinear_fast, N_to_reso, cal_n_samples, render_sharded, shard_indices, shard_capacity  # noqa: F401
-from .evaluation import BlenderRays, evaluation, evaluation_path, rgb_ssim  # noqa: F401
+from .evaluation import BlenderRays, evaluation, evaluation_path, rgb_ssim, rgb_ssim_torch  # noqa: F401
 from .losses import TVLoss  # noqa: F401
 from .training import GradBucket, shard_batch  # noqa: F401
 from . import ngp, rays, synthetic  # noqa: F401

@@ -76,6 +76,42 @@ def rgb_ssim(img0, img1, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=
     return float(np.mean(((2 * mu01 + c1) * (2 * s01 + c2)) / ((mu00 + mu11 + c1) * (s00 + s11 + c2))))
 
 
+def rgb_ssim_torch(img0: torch.Tensor, img1: torch.Tensor, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03) -> float:
+    """`rgb_ssim` on the tensors' device: the same separable 11-tap Gaussian, 'valid' window, float64 — two depthwise conv2d calls per
+    blur instead of 30 scipy convolutions per frame (0.4 s per 800x800 frame on the host, the render itself takes 23 ms)."""
+    x0 = img0.to(torch.float64).permute(2, 0, 1).unsqueeze(1)          # [3,1,H,W]: channels as a batch
+    x1 = img1.to(device=x0.device, dtype=torch.float64).permute(2, 0, 1).unsqueeze(1)
+    hw = filter_size // 2
+    shift = (2 * hw - filter_size + 1) / 2
+    f = torch.exp(-0.5 * ((torch.arange(filter_size, dtype=torch.float64, device=x0.device) - hw + shift) / filter_sigma) ** 2)
+    f = f / f.sum()
+    blur = lambda z: torch.nn.functional.conv2d(torch.nn.functional.conv2d(z, f.view(1, 1, -1, 1)), f.view(1, 1, 1, -1))
+    mu0, mu1 = blur(x0), blur(x1)
+    mu00, mu11, mu01 = mu0 * mu0, mu1 * mu1, mu0 * mu1
+    s00 = torch.clamp(blur(x0 * x0) - mu00, min=0.0)
+    s11 = torch.clamp(blur(x1 * x1) - mu11, min=0.0)
+    s01 = blur(x0 * x1) - mu01
+    s01 = torch.sign(s01) * torch.minimum(torch.sqrt(s00 * s11), torch.abs(s01))
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    return float(torch.mean(((2 * mu01 + c1) * (2 * s01 + c2)) / ((mu00 + mu11 + c1) * (s00 + s11 + c2))))
+
+
+class _ImageWriter:
+    """PNG encoding off the render loop: a few worker threads (zlib releases the GIL); `close()` waits for the files."""
+
+    def __init__(self, workers: int = 4):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool, self.jobs = ThreadPoolExecutor(max_workers=workers), []
+
+    def write(self, path, arr):
+        self.jobs.append(self.pool.submit(_imwrite, path, arr))
+
+    def close(self):
+        for j in self.jobs:
+            j.result()
+        self.pool.shutdown()
+
+
 def visualize_depth_numpy(depth, minmax=None):
     """utils.py:11-26 with a numpy jet ramp instead of cv2.applyColorMap (returns BGR-ordered uint8 like cv2 does)."""
     x = np.nan_to_num(depth)
@@ -105,21 +141,24 @@ def evaluation(test_dataset, tensorf, args, renderer, savePath=None, N_vis=5, pr
     idxs = list(range(0, n, interval))
     W, H = test_dataset.img_wh
     expname = getattr(args, "expname", "render") if args is not None else "render"
+    writer = _ImageWriter() if savePath is not None else None
     for idx, samples in enumerate(test_dataset.all_rays[0::interval]):
         rays = samples.view(-1, samples.shape[-1]).to(device)
         rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=1024, N_samples=N_samples, ndc_ray=ndc_ray, white_bg=white_bg, device=device)
-        rgb_map = rgb_map.clamp(0.0, 1.0).reshape(H, W, 3).cpu()
-        depth_vis, _ = visualize_depth_numpy(depth_map.reshape(H, W).cpu().numpy(), near_far)
+        rgb_dev = rgb_map.clamp(0.0, 1.0).reshape(H, W, 3)
         if len(test_dataset.all_rgbs):
-            gt = test_dataset.all_rgbs[idxs[idx]].view(H, W, 3)
-            loss = torch.mean((rgb_map - gt) ** 2)
+            gt = test_dataset.all_rgbs[idxs[idx]].view(H, W, 3).to(rgb_dev.device)
+            loss = torch.mean((rgb_dev - gt) ** 2)
             PSNRs.append(-10.0 * np.log(loss.item()) / np.log(10.0))
             if compute_extra_metrics:
-                ssims.append(rgb_ssim(rgb_map.numpy(), gt.numpy(), 1))
-        img = (rgb_map.numpy() * 255).astype('uint8')
+                ssims.append(rgb_ssim_torch(rgb_dev, gt, 1))                # utils.py:73-119 on the device
+        img = (rgb_dev.cpu().numpy() * 255).astype('uint8')
         if savePath is not None:
-            _imwrite(f'{savePath}/{expname}_r_{idx}.png', img)
-            _imwrite(f'{savePath}/rgbd/{prtx}{idx:03d}.png', np.concatenate((img, depth_vis), axis=1))
+            depth_vis, _ = visualize_depth_numpy(depth_map.reshape(H, W).cpu().numpy(), near_far)
+            writer.write(f'{savePath}/{expname}_r_{idx}.png', img)
+            writer.write(f'{savePath}/rgbd/{prtx}{idx:03d}.png', np.concatenate((img, depth_vis), axis=1))
+    if writer is not None:
+        writer.close()
     if PSNRs and savePath is not None:
         vals = [np.mean(PSNRs)] + ([np.mean(ssims), 0.0, 0.0] if compute_extra_metrics else [])
         np.savetxt(f'{savePath}/{prtx}mean.txt', np.asarray(vals))
@@ -136,14 +175,17 @@ def evaluation_path(test_dataset, tensorf, c2ws, renderer, savePath=None, N_vis=
     dirs = R.get_ray_directions(H, W, [focal, focal])
     dirs = dirs / np.sqrt((dirs * dirs).sum(-1, keepdims=True))
     frames = []
+    writer = _ImageWriter() if savePath is not None else None
     for idx, c2w in enumerate(c2ws):
         o, d = R.get_rays(dirs, np.asarray(c2w, dtype=np.float32))
         rays = torch.from_numpy(np.ascontiguousarray(np.concatenate([o, d], 1), dtype=np.float32)).to(device)
         rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=8192, N_samples=N_samples, ndc_ray=ndc_ray, white_bg=white_bg, device=device)
         img = (rgb_map.clamp(0.0, 1.0).reshape(H, W, 3).cpu().numpy() * 255).astype('uint8')
-        depth_vis, _ = visualize_depth_numpy(depth_map.reshape(H, W).cpu().numpy(), test_dataset.near_far)
         frames.append(img)
         if savePath is not None:
-            _imwrite(f'{savePath}/{prtx}{idx:03d}.png', img)
-            _imwrite(f'{savePath}/rgbd/{prtx}{idx:03d}.png', np.concatenate((img, depth_vis), axis=1))
+            depth_vis, _ = visualize_depth_numpy(depth_map.reshape(H, W).cpu().numpy(), test_dataset.near_far)
+            writer.write(f'{savePath}/{prtx}{idx:03d}.png', img)
+            writer.write(f'{savePath}/rgbd/{prtx}{idx:03d}.png', np.concatenate((img, depth_vis), axis=1))
+    if writer is not None:
+        writer.close()
     return frames

@@ -50,6 +50,12 @@ def test_blender_rays_and_evaluation_loop(tmp_path):
     assert len(frames) == 3 and np.array_equal(frames[0], img)                     # same poses -> same images as evaluation()
     a = np.random.default_rng(1).random((24, 24, 3))
     assert abs(rgb_ssim(a, a, 1) - 1.0) < 1e-12 and rgb_ssim(a, 1 - a, 1) < 0.5
+    # the device version (what `evaluation` calls) is the same computation
+    from jittor_myc_nerfs_amd import rgb_ssim_torch
+    rng2 = np.random.default_rng(4)
+    x, y = rng2.random((37, 41, 3)).astype(np.float32), rng2.random((37, 41, 3)).astype(np.float32)
+    y = 0.7 * x + 0.3 * y
+    assert abs(rgb_ssim_torch(torch.from_numpy(x), torch.from_numpy(y), 1) - rgb_ssim(x, y, 1)) < 1e-12
 
 
 def test_reads_the_reference_repos_refined_poses_if_present():
