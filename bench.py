@@ -8,11 +8,20 @@
 A "step" = one pass of the hot path over one batch of synthetic rays resident in HBM:
   N = 1 : one 800x800 frame = 640 000 rays x 512 samples of scene A (TensorVMSplit 300^3) — BASELINE configs[1];
           ONE tvr_render call (march + shade + composite kernels).
-  N > 1 : a batch of N such frames (N camera poses); the N*640 000 rays are cut into 4096-ray tiles dealt
-          round-robin to the ranks (every rank renders 640 000 rays: weak scaling), then ONE all_gather of
-          [rays,4] fp32 pixels (rgb+depth) over RCCL/xGMI returns all N frames to every rank (configs[2]).
+  N > 1, --scaling weak (default): a batch of N such frames (N camera poses); the N*640 000 rays are cut into 4096-ray
+          tiles dealt round-robin to the ranks (every rank renders 640 000 rays), then ONE all_gather of [rays,4] fp32
+          pixels (rgb+depth) over RCCL/xGMI returns all N frames to every rank and ONE index gather undoes the interleave.
+  N > 1, --scaling strong: BASELINE configs[2] as written — ONE 640 000-ray frame, rank r renders tiles r, r+N, ...
+          (80 000 rays each at N = 8), one all_gather, one index gather; efficiency = t_1 / (N t_N).
+  --emulate-world N (single GPU): time rank 0's share of an N-way strong split without the exchange (what a rank's
+          kernels cost at that size: persistent-kernel fill, LDS image reload).
 value = nominal ray-samples/s = (rays x 512) / time, whole job (every ray counted with all 512 samples, masked or
 terminated or not — SURVEY.md §8d).  Timed region: barrier + synchronize, K steps, synchronize + barrier; MAX over ranks.
+
+roofline.traffic is measured by THIS run: before the parent touches the GPU, rank 0 (N = 1) re-runs a 2-step bench under
+`rocprofv3 --pmc` in child processes, one pass per counter set (FETCH_SIZE; WRITE_SIZE; SQ/GRBM set), as
+MI355X_MICROARCH.md's HBM section prescribes (FETCH_SIZE doubled on gfx950).  If the profiler is unavailable the field is
+null and `traffic_source` says why — never a constant read from a committed file.
 """
 import argparse
 import json
@@ -148,7 +157,7 @@ def bench_ngp(args, world, rank, device):
     ach = BYTES * ev_per / (k_ms[1] * 1e-3) / 1e9
     result = {
         "metric": "ray_samples_per_sec", "value": marched * world / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (emulated: 3 x f16-split MFMA products, fp32 accumulate; fp32 VALU elsewhere)", "data": "synthetic",
         "config": {"workload": "JNeRF Instant-NGP inference (BASELINE configs[4]): 16-level hash grid 2^19 x 2, SH-16, MLPs 32-64-16 / 32-64-64-3, 5 x 128^3 "
                                "occupancy bitfield, 800x800 rays per GPU, up to 1024 steps per ray, dt = sqrt(3)/2048; fused frame path tvr_ngp_render; "
                                "N > 1: independent replicas (no exchange step on this path)",
@@ -159,7 +168,7 @@ def bench_ngp(args, world, rank, device):
         "effective": {"marched_samples_per_frame": marched / args.steps, "evaluated_samples_per_frame": ev_per},
         "kernel_ms": {"march": k_ms[0], "render": k_ms[1]},
         "roofline": {"kernel": "ngp_render_kernel<true>", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                     "traffic": _ngp_traffic(), "algorithmic_bytes_per_launch": BYTES * ev_per, "ms": k_ms[1],
+                     "traffic": None, "traffic_source": "not measured in this run (a committed pass, profiles/r01_ngp_pmc.json: 70.6 GB per launch)", "algorithmic_bytes_per_launch": BYTES * ev_per, "ms": k_ms[1],
                      "note": f"{BYTES} B per evaluated sample; the 52 MB of tables sit in L2 / MALL, so the measured traffic is fabric traffic of random 128-B lines"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -186,16 +195,60 @@ def bench_ngp(args, world, rank, device):
         dist.destroy_process_group()
 
 
-def _ngp_traffic():
-    """FETCH_SIZE (x2, gfx950) of ngp_render_kernel from the committed PMC pass, bytes per launch."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_ngp_pmc.json")))
-        for k, v in d.items():
-            if "ngp_render_kernel" in k and "FETCH_SIZE" in v:
-                return v["FETCH_SIZE"] * 1024.0 * 2.0
-    except Exception:
-        pass
-    return None
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("GRBM_GUI_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES",
+               "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"),
+              ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"))
+
+
+def collect_pmc(extra_args, budget_s=420.0):
+    """One rocprofv3 --pmc pass per counter set over `bench.py --steps 2 --warmup 1` in a child process (program directly behind `--`).
+    Returns ({kernel short name: {counter: mean per dispatch}}, source string).  Must run before this process initialises the GPU."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found: traffic not measured"
+    out, t_start, done = {}, time.time(), []
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counters in PMC_PASSES:
+        if time.time() - t_start > budget_s:
+            break
+        d = tempfile.mkdtemp(prefix="tvr_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pmc", "off", *extra_args]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                shutil.rmtree(d, ignore_errors=True)
+                continue
+            acc = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                    acc.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for k, cs in acc.items():
+                for c, v in cs.items():
+                    out.setdefault(k, {})[c] = sum(v) / len(v)
+            done.append("+".join(counters))
+        except Exception:
+            pass
+        shutil.rmtree(d, ignore_errors=True)
+    if not done:
+        return {}, "rocprofv3 --pmc child passes failed on this box: traffic not measured"
+    return out, ("live: rocprofv3 --pmc child passes of this bench run (2 steps each; mean per dispatch): " + "; ".join(done) +
+                 "; traffic = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B; gfx950 tallies 128-B reads at 64 B, MI355X_MICROARCH.md HBM section)")
+
+
+def _pmc_kernel(pmc, prefix):
+    for k, v in pmc.items():
+        if k.startswith(prefix):
+            return v
+    return {}
 
 
 def main():
@@ -212,6 +265,13 @@ def main():
     ap.add_argument("--model", choices=["TensorVMSplit", "REFTensoRF", "NGPNetworks"], default="TensorVMSplit",
                     help="model_name (opt.py:44): TensorVMSplit is the BASELINE workload; REFTensoRF is the variant configs/Scar.txt trains; "
                          "NGPNetworks is the JNeRF Instant-NGP alt path (BASELINE configs[4]; replicas only for N > 1)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = N frames per step (per-GPU work fixed); strong = ONE frame split over the ranks (BASELINE configs[2])")
+    ap.add_argument("--emulate-world", type=int, default=0, help="single GPU: render only rank 0's share of an N-way strong split (no exchange)")
+    ap.add_argument("--check", action="store_true", help="N > 1: every rank also renders the whole batch alone and compares the gathered pixels bit for bit")
+    ap.add_argument("--pmc", choices=["auto", "off"], default="auto", help="auto: rank 0 at N = 1 measures roofline.traffic with rocprofv3 --pmc child passes")
+    ap.add_argument("--img", type=int, default=int(os.environ.get("TVR_BENCH_IMG", "800")), help="frame edge in pixels (800 = the BASELINE workload; "
+                                                                                              "smaller only for rehearsals / tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,6 +281,13 @@ def main():
         if args.gpus != 1 and world == 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() == 0:                              # (counting devices does not initialise the GPU)
+        raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
+    pmc, pmc_source = {}, "not collected (--pmc off, N > 1, or a non-default workload)"
+    default_workload = args.model == "TensorVMSplit" and args.chunk == 0 and args.emulate_world == 0 and args.img == 800
+    if args.pmc == "auto" and world == 1 and rank == 0 and default_workload:
+        extra = (["--alpha-mask", str(args.alpha_mask)] if args.alpha_mask else []) + (["--eps-T", str(args.eps_T)] if args.eps_T is not None else [])
+        pmc, pmc_source = collect_pmc(extra)                        # child processes; this process has not touched the GPU yet
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()              # (rehearsals may put several ranks on one card)
@@ -237,29 +304,36 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from jittor_myc_nerfs_amd import _lib as L, shard_capacity, shard_indices
+    from jittor_myc_nerfs_amd import _lib as L, shard_capacity, shard_gather_index, shard_indices
     import ctypes as C
     model, arrs, A = build_model(device, args.model)
     S = A["N_samples"]
     if args.alpha_mask > 0:
         model.updateAlphaMask((args.alpha_mask,) * 3)
-    fr = frames(A)                                                  # 8 poses x [640000,6] on the host
+    if args.img != 800:
+        A = dict(A, img_wh=(args.img, args.img))
+    fr = frames(A)                                                  # 8 poses x [img*img,6] on the host
     R1 = fr[0].shape[0]
+    strong = args.scaling == "strong" and world > 1
+    split = world if world > 1 else max(args.emulate_world, 1)      # ways the step's batch is cut (emulation: only rank 0's share is rendered)
+    frames_per_step = 1 if (strong or world == 1) else world
+    R_step = frames_per_step * R1                                   # rays per step, whole job
 
-    # per-step inputs, resident in HBM before the timed region.  Step s renders poses (s*N + r) % 8, r < N.
-    n_patterns = N_POSES if world < N_POSES else 1
-    cap = shard_capacity(world * R1, world, TILE)
-    step_rays, step_idx = [], []
+    # per-step inputs, resident in HBM before the timed region.  Weak: step s renders poses (s*N + r) % 8, r < N.  Strong: pose s % 8.
+    n_patterns = N_POSES if frames_per_step < N_POSES else 1
+    cap = shard_capacity(R_step, split, TILE)
+    step_rays, full_rays = [], []
     for pat in range(n_patterns):
-        batch = torch.cat([fr[(pat * world + r) % N_POSES] for r in range(world)]) if world > 1 else fr[pat]
-        idx = shard_indices(batch.shape[0], rank, world, TILE)
+        batch = torch.cat([fr[(pat * frames_per_step + r) % N_POSES] for r in range(frames_per_step)]) if frames_per_step > 1 else fr[pat % N_POSES]
+        idx = shard_indices(R_step, rank, split, TILE)
         step_rays.append(batch[idx].contiguous().to(device))
-        step_idx.append(idx)
+        if args.check and world > 1:
+            full_rays.append(batch.to(device))
     n_mine = step_rays[0].shape[0]
-    all_idx = [shard_indices(world * R1, r, world, TILE).to(device) for r in range(world)] if world > 1 else None
+    inv = shard_gather_index(R_step, world, TILE, device) if world > 1 else None
     mine = torch.zeros((cap, 4), device=device)
     gathered = torch.empty((world * cap, 4), device=device) if world > 1 else None
-    out_img = torch.empty((world * R1, 4), device=device) if world > 1 else None
+    gloo = world > 1 and dist.get_backend() == "gloo"
 
     prof = C.c_void_p()
     L.check(L.lib().tvr_profile_create(max(args.steps, 1), C.byref(prof)), "tvr_profile_create")
@@ -275,15 +349,12 @@ def main():
         if world > 1:
             mine[:n_mine, :3] = rgb
             mine[:n_mine, 3] = depth
-            if dist.get_backend() == "gloo":                        # rehearsal path only
+            if gloo:                                                # rehearsal path only
                 parts = [torch.empty_like(mine) for _ in range(world)]
                 dist.all_gather(parts, mine)
-                gathered.copy_(torch.cat(parts))
-            else:
-                dist.all_gather_into_tensor(gathered, mine)
-            for r in range(world):                                  # undo the tile interleave: index permutation only
-                out_img.index_copy_(0, all_idx[r], gathered[r * cap:r * cap + all_idx[r].numel()])
-            return out_img
+                return torch.cat(parts).index_select(0, inv)
+            dist.all_gather_into_tensor(gathered, mine)
+            return gathered.index_select(0, inv)                    # undo the tile interleave: ONE precomputed index gather
         return rgb
 
     for s in range(args.warmup):
@@ -312,6 +383,21 @@ def main():
     if n_calls == 0:                                               # chunked mode records no per-kernel events
         k_ms = [0.0, 0.0, 0.0]
 
+    check = None
+    if args.check and world > 1:                                   # outside the timed region
+        ok = True
+        for pat in range(n_patterns):
+            img = step(pat)
+            rgb1, depth1 = model.render_rays(full_rays[pat], white_bg=True, N_samples=S, eps_T=args.eps_T)
+            ok = ok and torch.equal(img[:, :3], rgb1) and torch.equal(img[:, 3], depth1)
+        flag = torch.tensor([1 if ok else 0], device=device)
+        if gloo:
+            flag = flag.cpu()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            raise SystemExit("bench.py --check: the gathered frame differs from the single-rank render")
+        check = "gathered == single-rank render, bit for bit"
+
     # occupancy statistics of exactly the timed steps (untimed pass with counters on)
     stats = torch.zeros(8, dtype=torch.int64, device=device)
     for s in range(args.steps):
@@ -320,53 +406,72 @@ def main():
     st = stats.cpu().numpy().astype(np.float64) / max(args.steps, 1)      # per launch (this rank)
     m_eval, m_bbox, m_app = float(st[0]), float(st[1]), float(st[2])
 
-    total_rays = world * R1
-    value = total_rays * S * args.steps / dt
+    rays_job = R_step if args.emulate_world <= 1 else n_mine       # emulation reports the share that was rendered
+    value = rays_job * S * args.steps / dt
     has_mask = model.alphaMask is not None
-    march_bytes = 40.0 * n_mine + 1152.0 * m_eval + (32.0 * m_bbox if has_mask else 0.0)
-    shade_bytes = 3456.0 * m_app
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
-    # correction + WRITE_SIZE, KB -> B); only valid for the workload it was collected on (this one)
-    pmc = {}
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc_path) and args.model == "TensorVMSplit" and args.alpha_mask == 0:
-        try:
-            pmc = json.load(open(pmc_path))
-        except Exception:
-            pmc = {}
     t_march, t_shade = k_ms[0] * 1e-3, k_ms[1] * 1e-3
     FLOP_APP = 8.0e4            # algorithmic FLOP per appearance sample (basis 7 776 + MLP 71 936 + PE)
-    FLOP_APP_EXEC = 3 * 2 * (32 * 144 + 128 * 160 + 128 * 128 + 32 * 128)   # executed on the matrix cores: 3 fp16 products, padded
+    FLOP_APP_EXEC = 3 * 2 * (32 * 144 + 128 * 160 + 128 * 128 + 32 * 128)   # executed on the matrix cores: 3 fp16 products, padded tiles
     if args.model == "REFTensoRF":                                         # + four 144 -> {3,3,1,1} heads, 151-input layer 1
         FLOP_APP += 2 * 8 * 144 + 2 * 128
         FLOP_APP_EXEC += 3 * 2 * 32 * 144
-    roof_march = {"kernel": "march_kernel<false>", "bound": "hbm", "achieved": march_bytes / t_march / 1e9 if t_march > 0 else None,
-                  "peak": 8000.0, "unit": "GB/s", "frac": march_bytes / t_march / 1e9 / 8000.0 if t_march > 0 else None,
-                  "traffic": pmc.get("march_hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": march_bytes, "ms": k_ms[0],
-                  "note": "40 B/ray + 1152 B per density sample actually evaluated (+32 B per alpha-mask lookup); the 17 MB of density "
-                          "factors are L2/Infinity-Cache resident (frac > 1 against HBM): the kernel runs at the L1 (TA) rate"}
-    roof_shade = {"kernel": "shade_kernel<0,0,%s>" % ("true" if args.model == "REFTensoRF" else "false"), "bound": "mfma", "achieved": FLOP_APP * m_app / t_shade / 1e12 if t_shade > 0 else None,
-                  "peak": 2500.0, "unit": "TFLOP/s", "frac": FLOP_APP * m_app / t_shade / 1e12 / 2500.0 if t_shade > 0 else None,
-                  "traffic": pmc.get("shade_hbm_bytes_per_launch"), "algorithmic_flops_per_launch": FLOP_APP * m_app, "ms": k_ms[1],
+    pm, ps = _pmc_kernel(pmc, "march_kernel<false"), _pmc_kernel(pmc, "shade_kernel<0, 0")
+
+    def hbm(c):
+        return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if ("FETCH_SIZE" in c and "WRITE_SIZE" in c) else None
+
+    def clock_ghz(c, t):                                           # GRBM_GUI_ACTIVE sums the 8 XCDs (MI355X_MICROARCH.md 'DVFS give-back')
+        return c["GRBM_GUI_ACTIVE"] / 8.0 / t / 1e9 if ("GRBM_GUI_ACTIVE" in c and t > 0) else None
+
+    # march: a cache-bandwidth gather.  Per evaluated density sample 768 B of plane texels come through the vector L1 (TA path) and 384 B of
+    # line texels from LDS; per ray 24 B in + 16 B out.  The roof that binds is the L1 -> register path, 64 B/clk/CU (CDNA3/4 vector L1 data
+    # return width; the guide gives no L1 figure, its L2 aggregate is 34.5 TB/s) x 256 CUs x the clock measured under this load.
+    l1_bytes = 40.0 * n_mine + 768.0 * m_eval + (32.0 * m_bbox if has_mask else 0.0)
+    lds_bytes = 384.0 * m_eval
+    ck_m = clock_ghz(pm, t_march) or 2.1
+    l1_peak = 256 * 64 * ck_m                                       # GB/s
+    roof_march = {"kernel": "march_kernel<false>", "bound": "l1", "achieved": l1_bytes / t_march / 1e9 if t_march > 0 else None,
+                  "peak": l1_peak, "unit": "GB/s", "frac": l1_bytes / t_march / 1e9 / l1_peak if t_march > 0 else None,
+                  "traffic": hbm(pm), "algorithmic_bytes_per_launch": l1_bytes + lds_bytes, "l1_bytes_per_launch": l1_bytes,
+                  "lds_bytes_per_launch": lds_bytes, "lds_GBps": lds_bytes / t_march / 1e9 if t_march > 0 else None,
+                  "clock_GHz": ck_m, "clock_source": "GRBM_GUI_ACTIVE / 8 / t (PMC child pass)" if clock_ghz(pm, t_march) else "nominal 2.1 (no PMC pass)",
+                  "vs_hbm_8TBps": (l1_bytes + lds_bytes) / t_march / 1e9 / 8000.0 if t_march > 0 else None, "ms": k_ms[0],
+                  "lds_bank_conflict_frac": (pm["SQ_LDS_BANK_CONFLICT"] / pm["SQ_LDS_IDX_ACTIVE"]) if pm.get("SQ_LDS_IDX_ACTIVE") else None,
+                  "note": "40 B/ray + 768 B through L1 + 384 B through LDS per density sample actually evaluated (+32 B per alpha-mask lookup); peak = 256 CUs x "
+                          "64 B/clk x measured clock.  The 17 MB of density factors are L2 / Infinity-Cache resident, so HBM is not the roof "
+                          "(vs_hbm_8TBps > 1 by construction, kept for SURVEY 8d's formula)"}
+    ach_shade = FLOP_APP * m_app / t_shade / 1e12 if t_shade > 0 else None
+    roof_shade = {"kernel": "shade_kernel<0,0,%s>" % ("true" if args.model == "REFTensoRF" else "false"), "bound": "mfma", "achieved": ach_shade,
+                  "peak": 2500.0, "unit": "TFLOP/s", "frac": ach_shade / 2500.0 if ach_shade else None,
+                  "frac_vs_fp32class_ceiling": ach_shade / (2500.0 / 3.0) if ach_shade else None,
+                  "traffic": hbm(ps), "algorithmic_flops_per_launch": FLOP_APP * m_app, "ms": k_ms[1],
                   "executed_mfma_TFLOPs": FLOP_APP_EXEC * m_app / t_shade / 1e12 if t_shade > 0 else None,
-                  "gather_algorithmic_GBps": shade_bytes / t_shade / 1e9 if t_shade > 0 else None,
-                  "note": f"{FLOP_APP / 1e3:.1f} kFLOP per appearance sample (algorithmic, fp32 semantics) against the dense f16 MFMA peak; the kernel "
-                          "executes 3 fp16 products per fp32 product (hi/lo split, fp32-class accuracy) on padded tiles = "
-                          f"{FLOP_APP_EXEC} FLOP per sample, and gathers 3456 B per sample through L1"}
+                  "gather_algorithmic_GBps": 3456.0 * m_app / t_shade / 1e9 if t_shade > 0 else None,
+                  "mfma_busy_frac": (ps["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (ps["GRBM_GUI_ACTIVE"] / 8.0)) if ps.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in ps else None,
+                  "mfma_valu_coexec_frac_of_busy": (ps["SQ_VALU_MFMA_COEXEC_CYCLES"] / ps["SQ_VALU_MFMA_BUSY_CYCLES"]) if ps.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
+                  "valu_insts_per_32_entry_tile": (ps["SQ_INSTS_VALU"] / (m_app / 32.0)) if ps.get("SQ_INSTS_VALU") and m_app > 0 else None,
+                  "clock_GHz": clock_ghz(ps, t_shade),
+                  "note": f"{FLOP_APP / 1e3:.1f} kFLOP per appearance sample (algorithmic, fp32 semantics) against the dense f16 MFMA peak (2.5 PFLOP/s); "
+                          "fp32-class arithmetic on this chip needs 3 fp16 products per fp32 product (hi/lo split; the fp32-input MFMA runs at 1/16 rate), "
+                          f"so the ceiling for this arithmetic is peak / 3 = 833 TFLOP/s (frac_vs_fp32class_ceiling); executed on padded tiles: {FLOP_APP_EXEC} FLOP "
+                          "per sample; the gather moves 3456 B per sample through L1"}
+    for r_ in (roof_march, roof_shade):
+        r_["traffic_source"] = pmc_source
     dominant = roof_shade if k_ms[1] >= k_ms[0] else roof_march
+    mode = ("N>1 weak: N frames per step" if not strong else "N>1 strong: ONE frame split over the ranks (BASELINE configs[2])")
     result = {
         "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "f32 (emulated: 3 x f16-split MFMA products, fp32 accumulate; fp32 VALU elsewhere)", "data": "synthetic",
         "config": {"workload": ("TensorVMSplit 300^3 (16/48 comps, MLP_Fea 150-128-128-3)" if args.model == "TensorVMSplit" else
                                 "REFTensoRF 300^3 (16/48 comps, 4 heads on h, MLP_Fea_Ref 151-128-128-3)") +
-                               ", 800x800 rays x 512 samples/ray per GPU "
-                               "(BASELINE configs[1]; N>1: configs[2] as N frames, 4096-ray tiles round-robin, one RCCL all_gather "
-                               "of [rays,4] fp32)", "scene": "synthetic scene A (SURVEY 8d), no alpha mask, white_bg",
-                   "rays_per_step": total_rays, "samples_per_ray": S,
+                               f", {args.img}x{args.img} rays x 512 samples/ray (BASELINE configs[1]); {mode}, 4096-ray tiles round-robin, one RCCL "
+                               "all_gather of [rays,4] fp32 + one index gather",
+                   "scene": "synthetic scene A (SURVEY 8d), no alpha mask, white_bg",
+                   "rays_per_step": rays_job, "samples_per_ray": S, "rays_per_rank": n_mine,
                    "eps_T": float(model.rayMarch_weight_thres) if args.eps_T is None else args.eps_T, "tile": TILE,
-                   "chunk": args.chunk if args.chunk > 0 else n_mine, "alpha_mask": args.alpha_mask},
-        "rays_per_sec": total_rays * args.steps / dt,
+                   "chunk": args.chunk if args.chunk > 0 else n_mine, "alpha_mask": args.alpha_mask, "emulate_world": args.emulate_world},
+        "rays_per_sec": rays_job * args.steps / dt,
         "effective": {"density_samples_evaluated_per_sec": m_eval * world * args.steps / dt,
                       "appearance_samples_per_sec": m_app * world * args.steps / dt,
                       "frac_samples_evaluated": m_eval / (n_mine * S), "frac_samples_in_box": m_bbox / (n_mine * S),
@@ -375,6 +480,8 @@ def main():
         "roofline": dominant,
         "roofline_all": {"march": roof_march, "shade": roof_shade},
     }
+    if check is not None:
+        result["check"] = check
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(arrs, A, fr[0], with_c=(args.model == "TensorVMSplit"))
     elif rank == 0:

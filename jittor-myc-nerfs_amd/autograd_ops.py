@@ -191,7 +191,9 @@ class _MarchFn(torch.autograd.Function):
             out.density_plane[i], out.density_line[i] = grads[i].data_ptr(), grads[3 + i].data_ptr()
         gs = model._get_grad_scratch()
         n = ctx.rays.shape[0]
-        gw = torch.zeros(max(ctx.M, 1), device=model.device) if gw is None else gw.contiguous().float()
+        # an empty queue (M == 0: every weight <= rayMarch_weight_thres, the state of a freshly initialised 128^3 scene — density only
+        # learns through acc_map then, tensorBase.py:515 `if app_mask.any()`) hands autograd a [0] gradient whose data_ptr() is NULL
+        gw = torch.zeros(max(ctx.M, 1), device=model.device) if (gw is None or ctx.M == 0) else gw.contiguous().float()
         gacc = torch.zeros(n, device=model.device) if gacc is None else gacc.contiguous().float()
         if ctx.z_vals is None:
             L.check(lib.tvr_march_backward(sc, ctx.rays.data_ptr(), n, ctx.S, None if ctx.jitter is None else ctx.jitter.data_ptr(),

@@ -59,17 +59,41 @@ class AlphaGridMask:
         return (xyz_sampled - self.aabb[0].to(xyz_sampled.device)) * self.invgridSize.to(xyz_sampled.device) - 1
 
 
+class _ArrayUnpickler:
+    """pickle.Unpickler restricted to what a `jt.save` file holds: builtin containers and scalars, numpy arrays / dtypes / scalars and
+    OrderedDict.  Anything else (a checkpoint downloaded from somewhere is untrusted input) raises instead of being imported."""
+    _ALLOWED = {("collections", "OrderedDict"), ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"),
+                ("numpy._core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"), ("builtins", "slice"), ("builtins", "set"),
+                ("builtins", "frozenset"), ("builtins", "complex"), ("builtins", "bytearray")}
+
+    @classmethod
+    def load(cls, f):
+        import pickle
+
+        class _U(pickle.Unpickler):
+            def find_class(self, module, name):
+                if (module, name) in cls._ALLOWED or (module == "numpy" and name in ("float32", "float64", "int32", "int64", "uint8", "bool_", "float16")):
+                    return super().find_class(module, name)
+                raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}: only numpy arrays and builtin containers are accepted")
+        return _U(f).load()
+
+
 def load_checkpoint(path):
     """jt.load for the reference's `.th` checkpoints (train.py:43,75,148; written by tensorBase.py:253-264 through jt.save).  Jittor
-    (third-party, absent here) pickles the dict with every jt.Var turned into a numpy array, so plain `pickle` reads the file;
-    files written by this package's `save` (torch.save, a zip archive) are read with torch.load.  Returns the dict as stored."""
-    import pickle
+    (third-party, absent here) pickles the dict with every jt.Var turned into a numpy array, so a pickle reader restricted to numpy
+    arrays and builtin containers reads the file; files written by this package's `save` (torch.save, a zip archive) are read with
+    torch.load(weights_only=True).  Returns the dict as stored."""
     with open(path, "rb") as f:
         magic = f.read(2)
     if magic == b"PK":
-        return torch.load(path, map_location="cpu", weights_only=False)
+        import numpy
+        ma = getattr(getattr(numpy, "_core", None) or numpy.core, "multiarray")
+        with torch.serialization.safe_globals([ma._reconstruct, ma.scalar, numpy.ndarray, numpy.dtype, type(numpy.dtype(numpy.uint8)), type(numpy.dtype(numpy.float32)),
+                                               type(numpy.dtype(numpy.int64)), type(numpy.dtype(numpy.bool_))]):
+            return torch.load(path, map_location="cpu", weights_only=True)
     with open(path, "rb") as f:
-        return pickle.load(f)
+        return _ArrayUnpickler.load(f)
 
 
 class MLPRender_Fea(torch.nn.Module):

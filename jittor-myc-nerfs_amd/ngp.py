@@ -439,9 +439,9 @@ def load_jnerf_checkpoint(path: str, model: NGPNetworks, sampler: Optional[Densi
     (Jittor's published behaviour, restated; Jittor itself is absent here).  Fills `model` from `ckpt['model']` (`pos_encoder.m_grid`,
     `density_mlp.{0,2}.weight`, `rgb_mlp.{0,2,4}.weight`) and `sampler` from `ckpt['sampler']` (`density_grid`, `density_grid_bitfield`,
     `density_grid_mean`); fp16 checkpoints (`fp16 = True` configs) are widened to fp32.  Returns `global_step`."""
-    import pickle
+    from .field import _ArrayUnpickler                       # numpy arrays + builtin containers only: a downloaded checkpoint is untrusted input
     with open(path, "rb") as f:
-        ckpt = pickle.load(f)
+        ckpt = _ArrayUnpickler.load(f)
     m = {k: np.asarray(v) for k, v in ckpt["model"].items()}
     # `fp16 = True` configs (ngp_comp.py:100) build the networks as FMLP (ngp_network.py:9-39): each keeps ONE flat `con_weights` =
     # concat_i(dweights[i].T.reshape(-1)) with dweights[i] of shape (in, out) and the last layer zero-padded to 16 outputs.  dweights[i].T is

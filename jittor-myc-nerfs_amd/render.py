@@ -70,12 +70,35 @@ def shard_capacity(n_rays: int, world: int, tile: int = 4096) -> int:
     return ((n_tiles + world - 1) // world) * tile
 
 
+_GATHER_INDEX_CACHE = {}
+
+
+def shard_gather_index(n_rays: int, world: int, tile: int = 4096, device=None) -> torch.Tensor:
+    """inv [n_rays] with  image[i] = gathered[inv[i]]  for the all_gather layout (rank r's rows at r*cap .. r*cap + its ray count):
+    ray i lies in tile t = i // tile, which rank t % world renders as its (t // world)-th tile.  The un-permute after the
+    all_gather is then ONE index_select, whatever the world size (cached per shape and device)."""
+    key = (n_rays, world, tile, str(device))
+    inv = _GATHER_INDEX_CACHE.get(key)
+    if inv is None:
+        cap = shard_capacity(n_rays, world, tile)
+        i = torch.arange(n_rays)
+        t = i // tile
+        inv = (t % world) * cap + (t // world) * tile + (i % tile)
+        if device is not None:
+            inv = inv.to(device)
+        if len(_GATHER_INDEX_CACHE) > 16:
+            _GATHER_INDEX_CACHE.clear()
+        _GATHER_INDEX_CACHE[key] = inv
+    return inv
+
+
 def render_sharded(rays: torch.Tensor, render_fn: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
                    rank: int, world: int, tile: int = 4096, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Render `rays` [R,6] (the full batch, present on every rank) across `world` ranks.
 
     render_fn(rays_subset) -> (rgb [n,3], depth [n]) renders on this rank's device.  Returns the full
-    (rgb [R,3], depth [R]) on every rank after one all_gather of [cap,4] fp32 (rgb + depth packed together)."""
+    (rgb [R,3], depth [R]) on every rank after one all_gather of [cap,4] fp32 (rgb + depth packed together) and one
+    index_select that undoes the tile interleave."""
     import torch.distributed as dist
     R = rays.shape[0]
     if world == 1:
@@ -87,9 +110,11 @@ def render_sharded(rays: torch.Tensor, render_fn: Callable[[torch.Tensor], Tuple
     mine[:idx.numel(), :3] = rgb
     mine[:idx.numel(), 3] = depth
     gathered = rays.new_empty((world * cap, 4))
-    dist.all_gather_into_tensor(gathered, mine, group=group)
-    out = rays.new_empty((R, 4))
-    for r in range(world):                                     # undo the interleave (index permutation only)
-        ridx = shard_indices(R, r, world, tile).to(rays.device)
-        out.index_copy_(0, ridx, gathered[r * cap:r * cap + ridx.numel()])
+    if dist.get_backend(group) == "gloo" and gathered.is_cuda:          # 1-GPU rehearsals: gloo has no all_gather_into_tensor for device tensors
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        gathered = torch.cat(parts)
+    else:
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+    out = gathered.index_select(0, shard_gather_index(R, world, tile, rays.device))
     return out[:, :3].contiguous(), out[:, 3].contiguous()

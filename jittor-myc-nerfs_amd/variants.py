@@ -416,6 +416,9 @@ class NerfPlusPlus(TensorVMSplit):
         with torch.no_grad():
             z_vals = self._fg_depths(rays[:, :3], rays[:, 3:6], S, rand_fg)
         if is_train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # an optimizer step follows.  Invalidate the packed background image here, not only where the background is evaluated: a batch
+            # whose rays all have bg_lambda <= 0.1 skips it, and a fused Adam still moves bg_net by momentum without bumping `_version`
+            self._bg_sig = None
             rgb_map, depth_map, bg_lambda = self._render_z_autograd(rays, z_vals, S, eps_T)
         else:
             rgb_map, depth_map, bg_lambda = self._render_z(rays, z_vals, S, eps_T)

@@ -7,7 +7,7 @@ name=$1; shift
 out=$R/jittor-myc-nerfs_amd/lib/variants
 mkdir -p $out/obj_$name
 cd $R/jittor-myc-nerfs_amd/csrc
-for f in tvr_api tvr_march tvr_shade tvr_train tvr_gemm tvr_ngp; do
+for f in $(sed -n 's/^SRCS *:= *//p' Makefile | sed 's/\.hip//g'); do        # the Makefile's list: a variant library exports every symbol
   /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -std=c++17 -Wno-unused-function "$@" -c $f.hip -o $out/obj_$name/$f.o &
 done
 wait

@@ -188,10 +188,15 @@ def test_full_size_properties_config2():
     st = stats.cpu().numpy()
     assert 0 < st[2] < st[0] <= st[1] <= 640000 * 512
     assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0 and bool(torch.isfinite(depth).all())
-    # chunk invariance at full size: 4096-ray chunks (train.py / config 4) == one 640000-ray call, bit for bit
+    # chunk invariance at full size: 65536-ray chunks == one 640000-ray call, bit for bit
     parts = [m.render_rays(rays[c0:c0 + 65536], white_bg=True, N_samples=A["N_samples"]) for c0 in range(0, rays.shape[0], 65536)]
     rgb_c, depth_c = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     assert torch.equal(rgb_c, rgb) and torch.equal(depth_c, depth)
+    # BASELINE configs[3]: the frame as 157 DIRECT tvr_render calls of 4096 rays (train.py:225-226 batch size; renderer.py:16-25 without
+    # the chunk merging OctreeRender_trilinear_fast applies at inference), no host sync in between: bit-identical again
+    calls = [m.render_rays(rays[c0:c0 + 4096], white_bg=True, N_samples=A["N_samples"]) for c0 in range(0, rays.shape[0], 4096)]
+    assert len(calls) == 157 and calls[-1][0].shape[0] == 640000 - 156 * 4096
+    assert torch.equal(torch.cat([c[0] for c in calls]), rgb) and torch.equal(torch.cat([c[1] for c in calls]), depth)
     # oracle on a random subset
     sel = torch.randperm(640000, generator=torch.Generator().manual_seed(1))[:192]
     sc = TO.scene_from_arrays(arrs, **hyper)

@@ -1,6 +1,8 @@
-"""CPU, world_size 2 over gloo: the N>1 path of render_sharded (tile interleave + one all_gather + un-permute)
-returns exactly the single-process image.  The per-rank renderer here is the C oracle (tests may use it as a
-stand-in renderer; the product path passes the HIP field's render_rays)."""
+"""world_size 2 over gloo: the N>1 path of render_sharded (tile interleave + one all_gather + one index gather) returns exactly the
+single-process image.
+  * CPU (not gpu): the per-rank renderer is the C oracle (a stand-in renderer: the host logic is what is under test);
+  * -m gpu: the per-rank renderer is the HIP field (`render_rays` through the C-ABI), two spawned ranks sharing the box's one card —
+    BASELINE configs[2] in miniature, and bench.py's own multi-rank step function (weak and strong mode) under TVR_BENCH_BACKEND=gloo."""
 import os
 import sys
 
@@ -51,3 +53,72 @@ def test_render_sharded_world2_equals_single(tiny_arrays, hyper_tiny, tiny_edge)
     for rank, rgb, depth in res:
         assert np.array_equal(rgb, single["rgb_map"]), f"rank {rank}: gathered image != single-process image"
         assert np.array_equal(depth, single["depth_map"])
+
+
+# ---- the HIP renderer behind render_sharded (BASELINE configs[2]) ------------------------------------------------------------
+def _hip_worker(rank, world, port, arrs, hyper, rays_np, tiles, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # gloo stages device tensors through the host: both ranks share cuda:0
+    from conftest import make_model as mk
+    from jittor_myc_nerfs_amd import render_sharded
+    m = mk(arrs, hyper)
+    m.eps_T = 0.0
+    rays = torch.tensor(rays_np, device="cuda")
+    out = {}
+    for tile in tiles:
+        rgb, depth = render_sharded(rays, lambda r: m.render_rays(r, white_bg=True, N_samples=TINY["N_samples"]), rank, world, tile=tile)
+        out[tile] = (rgb.cpu().numpy(), depth.cpu().numpy())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_render_sharded_world2_hip_renderer_equals_single(tiny_arrays, hyper_tiny, tiny_dump, tiny_edge):
+    from conftest import make_model
+    rng = np.random.default_rng(5)
+    base = np.concatenate([tiny_dump["rays"], tiny_edge["rays"]])
+    rays = np.concatenate([base] * 140)[:9001].copy()                  # ragged: 9001 rays -> 563 tiles of 16 (last one short), 3 tiles of 4096
+    rays[:, :3] += 0.02 * rng.standard_normal((rays.shape[0], 3)).astype(np.float32)
+    m = make_model(tiny_arrays, hyper_tiny)
+    m.eps_T = 0.0
+    rgb1, depth1 = m.render_rays(torch.tensor(rays, device="cuda"), white_bg=True, N_samples=TINY["N_samples"])
+    rgb1, depth1 = rgb1.cpu().numpy(), depth1.cpu().numpy()
+    assert rgb1.std() > 0.01                                            # a picture, not a constant
+    ctx = mp.get_context("spawn")                                       # fresh child processes: no re-exec of a GPU-initialised one
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_hip_worker, args=(r, 2, port, tiny_arrays, hyper_tiny, rays, (16, 4096), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, out in res:
+        for tile, (rgb, depth) in out.items():
+            assert np.array_equal(rgb, rgb1), f"rank {rank}, tile {tile}: gathered HIP image != single-process HIP image"
+            assert np.array_equal(depth, depth1)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_step_world2_on_one_card(scaling, tmp_path):
+    """bench.py's multi-rank path exactly as the driver launches it (torch.distributed.run, 2 ranks) except for the rehearsal backend and a
+    small frame: `--check` makes every rank compare the gathered frame(s) with its own single-rank render of the same rays, bit for bit."""
+    import json
+    import subprocess
+    env = dict(os.environ, TVR_BENCH_BACKEND="gloo", TVR_BENCH_IMG="96", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 35500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scaling", scaling, "--check", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["check"] == "gathered == single-rank render, bit for bit"
+    assert d["config"]["rays_per_step"] == (96 * 96 * (2 if scaling == "weak" else 1))
