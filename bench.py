@@ -411,7 +411,7 @@ def main():
     has_mask = model.alphaMask is not None
     t_march, t_shade = k_ms[0] * 1e-3, k_ms[1] * 1e-3
     FLOP_APP = 8.0e4            # algorithmic FLOP per appearance sample (basis 7 776 + MLP 71 936 + PE)
-    FLOP_APP_EXEC = 3 * 2 * (32 * 144 + 128 * 160 + 128 * 128 + 32 * 128)   # executed on the matrix cores: 3 fp16 products, padded tiles
+    FLOP_APP_EXEC = 3 * 2 * (32 * 144 + 128 * 160 + 128 * 128)             # executed on the matrix cores: 3 fp16 products, padded tiles (layer 3 runs as fp32 VALU FMAs)
     if args.model == "REFTensoRF":                                         # + four 144 -> {3,3,1,1} heads, 151-input layer 1
         FLOP_APP += 2 * 8 * 144 + 2 * 128
         FLOP_APP_EXEC += 3 * 2 * 32 * 144

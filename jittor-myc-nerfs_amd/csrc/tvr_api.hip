@@ -160,10 +160,12 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
     char *img = s->packed + s->lay.mlp_image;
     HIP_TRY(launch_pack_mlp(p->W1, p->b1, img + TVR_IMG_W1H, img + TVR_IMG_W1L, d.variant == 1 ? 4 : 0, stream));
     HIP_TRY(launch_pack_mlp(p->W2, nullptr, img + TVR_IMG_W2H, img + TVR_IMG_W2L, 1, stream));
-    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B1, p->b1, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemsetAsync(img + TVR_IMG_B1, 0, TVR_FEATC * sizeof(float), stream));
+    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B2, p->b2, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(launch_pack_mlp(p->basis_mat, nullptr, s->packed + s->lay.basis_frag, nullptr, 2, stream));
-    HIP_TRY(launch_pack_mlp(p->W3, nullptr, img + TVR_IMG_W3, nullptr, 3, stream));
+    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_W3, p->W3, 3 * TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemsetAsync(img + TVR_IMG_W3 + 3 * TVR_IMG_W3_ROW, 0, TVR_IMG_W3_ROW, stream));
     HIP_TRY(hipMemcpyAsync(s->packed + s->lay.b3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemsetAsync(img + TVR_MLP_IMAGE_BYTES, 0, TVR_MLP_IMAGE_BYTES_REF - TVR_MLP_IMAGE_BYTES, stream));
     if (d.variant == 1) {

@@ -31,7 +31,8 @@
 #define TVR_IMG_W2L (TVR_IMG_W2H + 128 * TVR_IMG_W2_ROW)
 #define TVR_IMG_B1 (TVR_IMG_W2H + 2 * 128 * TVR_IMG_W2_ROW)
 #define TVR_IMG_B2 (TVR_IMG_B1 + 512)
-#define TVR_IMG_W3 (TVR_IMG_B2 + 512)              // [4 rows: W3 rows 0..2 + one zero row][8 k-steps][2 halves][hi 8 | lo 8] fp16
+#define TVR_IMG_B3 TVR_IMG_B1                      // b3 (3 floats + pad): b1 itself rides in W1's image as the column of a constant-1 input
+#define TVR_IMG_W3 (TVR_IMG_B2 + 512)              // W3 [3][128] fp32 (layer 3 runs as fp32 FMAs), then 512 zero bytes (REFTensoRF's zero row)
 #define TVR_IMG_W3_ROW 512
 #define TVR_MLP_IMAGE_BYTES (TVR_IMG_W3 + 4 * TVR_IMG_W3_ROW)     // 158 720 B of the 163 840 B LDS
 // REFTensoRF (variant 1) appends the four 144 -> {3,3,1,1} linears of REFTensoRF.compute_appfeature (models/REFTensoRF.py:126-132):

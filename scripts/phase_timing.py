@@ -3,6 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, numpy as np
 import bench
+if os.environ.get('TVR_LIB_PATH') is None: print('note: set TVR_LIB_PATH to a -DTVR_TIMING=1 build')
 m, arrs, A = bench.build_model(torch.device("cuda"))
 rays = bench.frames(A)[0].cuda()
 stats = torch.zeros(16, dtype=torch.int64, device="cuda")
@@ -13,7 +14,7 @@ torch.cuda.synchronize()
 st = stats.cpu().numpy().astype(float)
 tot = st[8:15].sum()
 print("entries", st[2], "tiles", st[2] / 32)
-names = ("basis", "gather begin + PE", "L1 (+gather 0..4)", "L2 (+gather 5..8)", "L3", "epilogue", "-") if os.environ.get("TVR_PIPE_NAMES") else ("gather", "basis", "PE", "token wait", "L1+L2", "L3", "epilogue")
+names = ("finish(prev): L3 + store", "gather", "basis", "L1 (+PE)", "L2", "-", "-")      # stamps of a -DTVR_TIMING=1 build (scripts/build_variant.sh timing -DTVR_TIMING=1)
 for n, v in zip(names, st[8:15]):
-    print(f"{n:12s} {v / (st[2] / 32):9.0f} cycles/tile  {100 * v / tot:5.1f} %")
+    print(f"{n:26s} {v / (st[2] / 32):9.0f} cycles/tile  {100 * v / tot:5.1f} %")
 print("sum cycles/tile", tot / (st[2] / 32))

@@ -1,0 +1,54 @@
+"""CPU: the gfx950 instructions that SHIP in libtvr.so obey the rules DESIGN.md §4.2 derives for the shade kernel (scripts/isa_check.py):
+an independent recount of every `s_waitcnt vmcnt` (no register is read while a load into it is outstanding — along the fall-through
+path and with every exec-masked block skipped), no global load inside a tile's matrix phase, no load into a register that an MFMA issued
+just before reads, and no register spills (a spill reload is a VMEM load the phase rule does not allow either)."""
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+LIB = os.path.join(ROOT, "jittor-myc-nerfs_amd", "lib", "libtvr.so")
+
+
+@pytest.fixture(scope="module")
+def report():
+    import __graft_entry__ as g
+    import isa_check
+    if not os.path.exists(LIB):
+        g.build()
+    return isa_check.audit(LIB, "shade_kernel")
+
+
+def test_every_shade_kernel_variant_is_audited(report):
+    assert len(report) == 6                     # {queue, xyz->features, features->rgb} x {TensorVMSplit, REFTensoRF}
+    assert all(v["mfma"] >= 27 for v in report.values())
+
+
+def test_vmcnt_accounting_of_shade_kernels(report):
+    for name, v in report.items():
+        assert v["raw_violations_fallthrough"] == 0 and v["raw_violations_execz_taken"] == 0, (name, v["examples"]["raw"])
+
+
+def test_phase_rule_of_shade_kernels(report):
+    for name, v in report.items():
+        assert v["vmem_loads_between_first_and_last_mfma"] == 0, f"{name}: a global (or spill) load sits between the MFMAs of a tile"
+        assert v["war_adjacent"] == 0, (name, v["examples"]["war"])
+
+
+def test_checker_flags_the_round1_pattern():
+    """The checker must see what the round-1 build looked like: a load into an MFMA's A operand directly behind it, and a missing wait."""
+    import isa_check
+    bad = ["s_waitcnt vmcnt(0)", "v_mfma_f32_32x32x16_f16 v[6:21], v[110:113], v[22:25], 0", "global_load_dwordx4 v[110:113], v[104:105], off offset:272",
+           "v_mfma_f32_32x32x16_f16 v[6:21], v[110:113], v[22:25], v[6:21]", "s_endpgm"]
+    r = isa_check.check_kernel("k", bad, False)
+    assert len(r["war_adjacent"]) == 1 and len(r["raw_violations"]) == 1      # the second MFMA reads v[110:113] with the load still outstanding
+    good = bad[:3] + ["s_waitcnt vmcnt(0)"] + bad[3:]
+    assert len(isa_check.check_kernel("k", good, False)["raw_violations"]) == 0
+    # a wait that only covers the load if an exec-masked block in between ISSUED its own load
+    masked = ["global_load_dwordx4 v[0:3], v[8:9], off", "s_cbranch_execz .LBB0_2", "global_load_dword v4, v[8:9], off", ".LBB0_2:",
+              "s_waitcnt vmcnt(1)", "v_add_f32_e32 v5, v0, v0", "s_endpgm"]
+    assert len(isa_check.check_kernel("k", masked, False)["raw_violations"]) == 0
+    assert len(isa_check.check_kernel("k", masked, True)["raw_violations"]) == 1
