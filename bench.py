@@ -198,7 +198,8 @@ def bench_ngp(args, world, rank, device):
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
               ("GRBM_GUI_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES",
                "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"),
-              ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"))
+              ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"),
+              ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"))
 
 
 def collect_pmc(extra_args, budget_s=420.0):
@@ -455,8 +456,11 @@ def main():
                           "fp32-class arithmetic on this chip needs 3 fp16 products per fp32 product (hi/lo split; the fp32-input MFMA runs at 1/16 rate), "
                           f"so the ceiling for this arithmetic is peak / 3 = 833 TFLOP/s (frac_vs_fp32class_ceiling); executed on padded tiles: {FLOP_APP_EXEC} FLOP "
                           "per sample; the gather moves 3456 B per sample through L1"}
-    for r_ in (roof_march, roof_shade):
+    for r_, c_ in ((roof_march, pm), (roof_shade, ps)):
         r_["traffic_source"] = pmc_source
+        if c_.get("SQ_WAVE_CYCLES"):                                  # where a wave's cycles go (quad-cycle units; the three are disjoint)
+            r_["wave_cycles_frac"] = {k: c_[n] / c_["SQ_WAVE_CYCLES"] for k, n in (("waiting_on_waitcnt_or_barrier", "SQ_WAIT_ANY"), ("issue_stalled", "SQ_WAIT_INST_ANY"),
+                                                                            ("issuing", "SQ_ACTIVE_INST_ANY")) if n in c_}
     dominant = roof_shade if k_ms[1] >= k_ms[0] else roof_march
     mode = ("N>1 weak: N frames per step" if not strong else "N>1 strong: ONE frame split over the ranks (BASELINE configs[2])")
     result = {

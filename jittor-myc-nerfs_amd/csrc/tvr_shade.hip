@@ -49,6 +49,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #else
 #define TVR_STAMP(x)
 #endif
+#ifndef TVR_BASIS_LATE
+#define TVR_BASIS_LATE 0
+#endif
+#ifndef TVR_DEFER
+#define TVR_DEFER 1     // 1: layer 3 + epilogue of a tile run in the next tile's gather phase; 0: at the end of its own matrix phase
+#endif
 #ifndef TVR_STAGGER
 #define TVR_STAGGER 1     // the two waves of a SIMD (w and w + 4) run the same program: the second starts half a tile late so that one
 #endif                    // gathers while the other multiplies (MI355X_MICROARCH 'Two waves per SIMD', item 9)
@@ -63,7 +69,31 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // relu as ONE VALU op: integer max on the bit pattern (negative floats, -0.0 included, are negative integers).  fmaxf(x, 0) costs
 // two v_max_f32 (hipcc canonicalises the operand first)
 __device__ __forceinline__ float relu_f(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+#ifndef TVR_NOPK
+#define TVR_NOPK 1        // 1: plain v_fma_f32 / v_mul_f32 instead of the packed-fp32 forms.  Twice the instructions and faster (14.5 vs 14.8 ms):
+#endif                    //    a packed op costs more than two plain ones beside the partner wave's MFMAs (cdna guide, cycle constants)
+#ifndef TVR_PRIO_G
+#define TVR_PRIO_G 2      // s_setprio while a wave is in its gather phase / its matrix phase.  The gather phase is a dependent chain of loads and
+#define TVR_PRIO_M 0      // short VALU bursts: when its instructions win arbitration against the partner's MFMA stream the tile takes 6 % less
+#endif                    // time (15.55 -> 14.75 ms); the opposite polarity costs 2 % (15.9).  Measured on one box, interleaved rounds.
+#if TVR_NOPK
+// two plain v_fma_f32 / v_mul_f32 (opaque to the SLP vectoriser, which would re-pack them)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c)
+{
+    float x = __builtin_fmaf(a.x, b.x, c.x), y = __builtin_fmaf(a.y, b.y, c.y);
+    asm volatile("" : "+v"(x)); asm volatile("" : "+v"(y));
+    return f32x2{x, y};
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b)
+{
+    float x = a.x * b.x, y = a.y * b.y;
+    asm volatile("" : "+v"(x)); asm volatile("" : "+v"(y));
+    return f32x2{x, y};
+}
+#else
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
+#endif
 
 // fp32 pair -> packed fp16 hi and lo words (x = hi + lo up to ~2^-22 |x|; round-toward-zero never overflows to inf)
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
@@ -139,7 +169,8 @@ __device__ __forceinline__ void load_taps(Taps &T, const float4 *__restrict__ P,
     const int x0 = (int)x0f, y0 = (int)y0f, l0 = (int)l0f;
     const int Wp = W + 1;
     if (!CHECK) {
-        // 32-bit texel offsets against the (wave-uniform) plane base: SGPR-base addressing, no 64-bit per-lane address registers
+        // 32-bit texel offsets against the (wave-uniform) plane base: SGPR-base addressing, no 64-bit per-lane address registers (measured:
+        // 15.4 vs 15.8 ms with 64-bit per-lane addresses)
         const unsigned o0 = ((unsigned)y0 * (unsigned)Wp + (unsigned)x0) * 12u + (unsigned)q0, o1 = o0 + (unsigned)Wp * 12u;
         const float4 *p = P + o0, *p2 = P + o1;
         T.t[0][0] = p[0]; T.t[0][1] = p[1];
@@ -202,13 +233,13 @@ __device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, fl
             const f32x2 t3 = hh ? f32x2{T.t[3][g].z, T.t[3][g].w} : f32x2{T.t[3][g].x, T.t[3][g].y};
             const f32x2 l0 = hh ? f32x2{T.lv[0][g].z, T.lv[0][g].w} : f32x2{T.lv[0][g].x, T.lv[0][g].y};
             const f32x2 l1 = hh ? f32x2{T.lv[1][g].z, T.lv[1][g].w} : f32x2{T.lv[1][g].x, T.lv[1][g].y};
-            f32x2 p = w00 * t0;
+            f32x2 p = pk_mul(w00, t0);
             p = pk_fma(w01, t1, p);
             p = pk_fma(w10, t2, p);
             p = pk_fma(w11, t3, p);
-            f32x2 q = ul * l0;
+            f32x2 q = pk_mul(ul, l0);
             q = pk_fma(wl, l1, q);
-            const f32x2 r = p * q;
+            const f32x2 r = pk_mul(p, q);
             out[g * 4 + hh * 2] = r.x;
             out[g * 4 + hh * 2 + 1] = r.y;
         }
@@ -218,40 +249,18 @@ __device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, fl
 // accumulator register r of lane half h  <->  row of the 32x32 tile
 __device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// sin/cos with a 3-term Cody-Waite reduction and short minimax polynomials (|err| < ~2e-7 for |x| < ~1e4)
-__device__ __forceinline__ void sincos_fast(float x, float &s, float &c)
-{
-    const float k = rintf(x * 0.636619772367581343f);          // x / (pi/2)
-    float r = __builtin_fmaf(k, -1.5707962512969971f, x);
-    r = __builtin_fmaf(k, -7.5497894158615964e-8f, r);
-    r = __builtin_fmaf(k, -5.3903029534742384e-15f, r);
-    const float r2 = r * r;
-    float sp = __builtin_fmaf(r2, 2.7183114939898219e-6f, -1.9839334836096632e-4f);
-    sp = __builtin_fmaf(sp, r2, 8.3333095484102479e-3f);
-    sp = __builtin_fmaf(sp, r2, -1.6666665461976921e-1f);
-    sp = __builtin_fmaf(sp * r2, r, r);
-    float cp = __builtin_fmaf(r2, 2.4433157656e-5f, -1.3887316255e-3f);
-    cp = __builtin_fmaf(cp, r2, 4.1666645683e-2f);
-    cp = __builtin_fmaf(cp, r2, -0.5f);
-    cp = __builtin_fmaf(cp, r2, 1.0f);
-    const int q = (int)k;
-    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
-    s = (q & 2) ? -ss : ss;
-    c = ((q + 1) & 2) ? -cc : cc;
-}
-
-// hardware sine / cosine (v_sin_f32 / v_cos_f32 take revolutions): 4 instructions per pair instead of ~25 (shade 15.2 -> 14.2 ms in
-// round 1, RGB error against the oracle unchanged: scripts/accuracy_report.py).  Their error is the fp32 reduction to revolutions,
-// |v| * 6e-8 rad, so a wave in which any lane holds |v| > 256 takes the Cody-Waite polynomial for that base value.
+// sine / cosine for the positional encoding: v_sin_f32 / v_cos_f32 (they take revolutions) behind a two-term Cody-Waite reduction
+// x - k*2pi, 7 instructions per pair and no branch (a branch per value kept hipcc from interleaving layer 1's VALU work with its MFMAs).
+// The reduction is exact to an ulp of the remainder for |x| < ~1e4 (k has <= 11 bits), so the error is the hardware's (~1e-6 abs),
+// the same as round 1's fract() form had for small |x| (scripts/accuracy_report.py), and smaller than that form's for |x| > 100.
 __device__ __forceinline__ void sincos_pe(float x, float &s, float &c)
 {
-    if (__ballot(fabsf(x) > 256.0f) == 0ull) {
-        const float r = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
-        s = __builtin_amdgcn_sinf(r);
-        c = __builtin_amdgcn_cosf(r);
-    } else {
-        sincos_fast(x, s, c);
-    }
+    const float k = rintf(x * 0.15915494309189535f);
+    float r = __builtin_fmaf(k, -6.2831854820251465f, x);
+    r = __builtin_fmaf(k, 1.7484555e-7f, r);                   // 2pi = 6.2831854820251465 - 1.7484555e-7
+    const float t = r * 0.15915494309189535f;
+    s = __builtin_amdgcn_sinf(t);
+    c = __builtin_amdgcn_cosf(t);
 }
 
 // what a tile carries from its matrix phase into the next tile's gather phase, where layer 3 and the epilogue run
@@ -274,18 +283,29 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
     unsigned w3a = (unsigned)(size_t)(smem + TVR_IMG_W3) + 16u * (unsigned)h;
     asm volatile("" : "+v"(w3a));
     const float *W3 = (const float *)(const void __attribute__((address_space(3))) *)(size_t)w3a;
+    // the 12 weight quads of a row block are fetched while the previous block's FMAs run (one LDS round trip per block, not per quad)
+    float4 w[2][12];
+    auto fetch = [&](int rb, float4 (&d)[12]) {
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) d[q * 3 + c3] = *(const float4 *)(W3 + c3 * 128 + 32 * rb + 8 * q);    // hidden units u + 4h .. + 3
+    };
+    fetch(0, w[0]);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        if (rb + 1 < 4) fetch(rb + 1, w[(rb + 1) & 1]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int u = 32 * rb + 8 * q;                         // hidden units u + 4h .. + 3 are registers 4q .. 4q+3 of acc2[rb]
-            const float4 w0 = *(const float4 *)(W3 + u), w1 = *(const float4 *)(W3 + 128 + u), w2 = *(const float4 *)(W3 + 256 + u);
+            const float4 w0 = w[rb & 1][q * 3], w1 = w[rb & 1][q * 3 + 1], w2 = w[rb & 1][q * 3 + 2];
             const f32x2 xa = {relu_f(c.acc2[rb][4 * q]), relu_f(c.acc2[rb][4 * q + 1])};
             const f32x2 xb = {relu_f(c.acc2[rb][4 * q + 2]), relu_f(c.acc2[rb][4 * q + 3])};
             s0 = pk_fma(xa, f32x2{w0.x, w0.y}, s0); s0 = pk_fma(xb, f32x2{w0.z, w0.w}, s0);
             s1 = pk_fma(xa, f32x2{w1.x, w1.y}, s1); s1 = pk_fma(xb, f32x2{w1.z, w1.w}, s1);
             s2 = pk_fma(xa, f32x2{w2.x, w2.y}, s2); s2 = pk_fma(xb, f32x2{w2.z, w2.w}, s2);
         }
+        TVR_SB;
+    }
     float r0 = s0.x + s0.y, r1 = s1.x + s1.y, r2 = s2.x + s2.y;
     r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
     const float4 b3 = *(const float4 *)(smem + TVR_IMG_B3);
@@ -333,7 +353,21 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     Carry prev;
     bool have_prev = false;
     const long long tile_stride = (long long)gridDim.x * SH_WAVES;
-    for (long long tile = (long long)blockIdx.x * SH_WAVES + wave; tile < n_tiles; tile += tile_stride) {
+#ifndef TVR_SHADE_XCD
+#define TVR_SHADE_XCD 1
+#endif
+    // workgroups b, b + 8, ... share an XCD (and its 4 MB L2): give each XCD a contiguous eighth of every window of tiles, so that its L2
+    // holds one stretch of the image row instead of all of it (speed only; correctness does not depend on the placement)
+    const unsigned lblk = TVR_SHADE_XCD ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;       // (measured neutral: 15.4 both ways)
+    float4 qe_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned qray_next = 0;
+    if (SRC == SH_SRC_QUEUE && n_total > 0) {
+        const long long e0 = ((long long)lblk * SH_WAVES + wave) * SH_TILE + e;
+        const long long le = e0 < n_total ? e0 : n_total - 1;
+        qe_next = a.q_pos[le];
+        qray_next = a.q_ray[le];
+    }
+    for (long long tile = (long long)lblk * SH_WAVES + wave; tile < n_tiles; tile += tile_stride) {
         const long long ent = tile * SH_TILE + e;
         const bool live = ent < n_total;
         float F[16];                               // base values: row c = acc_row(r, h) of the feature tile, column = entry
@@ -342,7 +376,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
         for (int r = 0; r < 8; ++r) G[r] = 0.f;
 #if TVR_TIMING
-        unsigned long long tg0 = 0, tgF = 0, tg1 = 0, tg2 = 0, tg3 = 0, tg4 = 0;
+        unsigned long long tg0 = 0, tgD = 0, tgF = 0, tg1 = 0, tg2 = 0, tg3 = 0, tg4 = 0;
 #endif
         TVR_STAMP(tg0);
         // ---------------------------------------------------------------- GATHER phase: global loads + VALU + LDS, no MFMA ----
@@ -352,24 +386,30 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             for (int r = 0; r < 16; ++r) prev.acc2[3][r] = relu_f(prev.acc2[3][r]);
             TVR_SB;
         }
-        float4 qe = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned qray = 0;
-        if (SRC == SH_SRC_QUEUE && live) { qe = a.q_pos[ent]; qray = a.q_ray[ent]; }
+        TVR_STAMP(tgD);
+        // queue entry: fetched one tile ahead (the loads are issued in the previous tile's gather phase and have landed by its phase
+        // boundary), unconditionally (a dead lane of the last tile re-reads the last entry; nothing of it is stored)
+        float4 qe = qe_next;
+        unsigned qray = qray_next;
+        if (SRC == SH_SRC_QUEUE) {
+            const long long en = ent + tile_stride * SH_TILE;
+            const long long le = en < n_total ? en : n_total - 1;
+            qe_next = a.q_pos[le];
+            qray_next = a.q_ray[le];
+        }
         if (DST != SH_DST_FEAT && have_prev) {
-            finish_tile<DST, REF, HAVE_G>(prev, smem, a, h);       // hides the latency of the entry loads above
+            finish_tile<DST, REF, HAVE_G>(prev, smem, a, h);
             TVR_SB;
         }
         TVR_STAMP(tgF);
         if (SRC != SH_SRC_FEAT) {
             float pn[3] = {0.f, 0.f, 0.f};
-            if (live) {
-                if (SRC == SH_SRC_QUEUE) {
-                    pn[0] = qe.x; pn[1] = qe.y; pn[2] = qe.z; wq = qe.w;
-                    const float *rp = a.rays + (size_t)qray * 6 + 3;
-                    dir[0] = rp[0]; dir[1] = rp[1]; dir[2] = rp[2];
-                } else {
-                    pn[0] = a.xyz[ent * 3]; pn[1] = a.xyz[ent * 3 + 1]; pn[2] = a.xyz[ent * 3 + 2];
-                }
+            if (SRC == SH_SRC_QUEUE) {
+                pn[0] = qe.x; pn[1] = qe.y; pn[2] = qe.z; wq = qe.w;
+                const float *rp = a.rays + (size_t)qray * 6 + 3;
+                dir[0] = rp[0]; dir[1] = rp[1]; dir[2] = rp[2];
+            } else if (live) {
+                pn[0] = a.xyz[ent * 3]; pn[1] = a.xyz[ent * 3 + 1]; pn[2] = a.xyz[ent * 3 + 2];
             }
             float fc[3];
 #pragma unroll
@@ -393,7 +433,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
                         load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx],
                                            4 * (s2 % 3) + 2 * h);
-                    } else if (s + TVR_PF == 9 + (REF ? 1 : 0)) {      // (REFTensoRF: after the last evaluation — its extra live values leave no room earlier)
+                    } else if (s + TVR_PF == 9 + ((REF || TVR_BASIS_LATE) ? 1 : 0)) {      // (REFTensoRF: after the last evaluation — its extra live values leave no room earlier)
                         // the basis A fragments (the tile's last global loads) ride behind the last taps
                         // (byte offsets against the uniform base, opaque per tile: the k-step stride of 2 KB does not fit a load's immediate,
                         // and hoisted per-step 64-bit addresses would spill)
@@ -414,7 +454,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     TVR_SB;
                 }
             }
-            if (REF) {
+            if (REF || TVR_BASIS_LATE) {
                 unsigned boff = (unsigned)((h * 32 + e) * 32);
                 asm volatile("" : "+v"(boff));
 #pragma unroll
@@ -428,6 +468,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TVR_SB;
             TVR_STAMP(tg1);
+            __builtin_amdgcn_s_setprio(TVR_PRIO_M);
             // ------------------------------------------------------------ MATRIX phase: MFMA + LDS + VALU, no global load ----
             // three independent accumulation chains (hi*lo products) summed at the end: no MFMA directly follows its producer
             f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};
@@ -578,17 +619,22 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         }
         cur.ent = ent; cur.live = live; cur.wq = wq;
         cur.g[0] = G[3]; cur.g[1] = G[4]; cur.g[2] = G[5]; cur.g[3] = G[6];
+        __builtin_amdgcn_s_setprio(TVR_PRIO_G);
+#if TVR_DEFER
         prev = cur;
         have_prev = true;
+#else
+        finish_tile<DST, REF, HAVE_G>(cur, smem, a, h);
+#endif
         TVR_STAMP(tg4);
 #if TVR_TIMING
-        tsum[0] += tgF - tg0; tsum[1] += tg1 - tgF; tsum[2] += tg2 - tg1; tsum[3] += tg3 - tg2; tsum[4] += tg4 - tg3;
+        tsum[0] += tgF - tgD; tsum[5] += tgD - tg0; tsum[1] += tg1 - tgF; tsum[2] += tg2 - tg1; tsum[3] += tg3 - tg2; tsum[4] += tg4 - tg3;
 #endif
     }
     if (DST != SH_DST_FEAT && have_prev) finish_tile<DST, REF, HAVE_G>(prev, smem, a, h);
 #if TVR_TIMING
     if (a.stats && lane == 0)
-        for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // finish, gather, basis, L1 (+PE), L2
+        for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // finish, gather, basis, L1 (+PE), L2, MFMA drain
 #endif
     if (a.stats && SRC == SH_SRC_QUEUE && blockIdx.x == 0 && tid == 0)
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);

@@ -56,8 +56,8 @@ def disassemble(path):
         for f in sorted(os.listdir(tmp)):
             if "gfx950" not in f:
                 continue
-            txt = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", os.path.join(tmp, f)], capture_output=True, text=True, check=True).stdout
-            kernels.update(split_kernels(txt.split("\n"), asm=False))
+            txt = subprocess.run([f"{LLVM}/llvm-objdump", "-d", os.path.join(tmp, f)], capture_output=True, text=True, check=True).stdout
+            kernels.update(resolve_branches(split_kernels(txt.split("\n"), asm=False)))
         return kernels
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -91,10 +91,41 @@ def split_kernels(lines, asm):
                 continue
             if cur is None or not s:
                 continue
+            m = re.search(r"//\s*([0-9A-Fa-f]+):", s)
             s = s.split("//")[0].strip()
             if s:
-                cur.append(s)
+                cur.append(s + (" @" + m.group(1) if m else ""))
     return {k: v for k, v in kernels.items() if v}
+
+
+def resolve_branches(kernels):
+    """objdump prints branch targets as signed dword offsets: turn them into `.LA<addr>` labels placed in front of the target instruction."""
+    out = {}
+    for name, ins in kernels.items():
+        addr = []
+        for x in ins:
+            m = re.search(r" @([0-9A-Fa-f]+)$", x)
+            addr.append(int(m.group(1), 16) if m else None)
+        targets = {}
+        clean = []
+        for x, a in zip(ins, addr):
+            y = re.sub(r" @[0-9A-Fa-f]+$", "", x)
+            parts = y.split()
+            if parts and (parts[0] == "s_branch" or parts[0].startswith("s_cbranch")) and a is not None and re.fullmatch(r"-?\d+", parts[-1]):
+                off = int(parts[-1])
+                if off >= 32768:
+                    off -= 65536
+                t = a + 4 + 4 * off
+                targets[t] = f".LA{t:x}"
+                y = f"{parts[0]} .LA{t:x}"
+            clean.append((a, y))
+        res = []
+        for a, y in clean:
+            if a in targets:
+                res.append(targets[a] + ":")
+            res.append(y)
+        out[name] = res
+    return out
 
 
 def parse(ins):
@@ -151,7 +182,7 @@ def check_kernel(name, ins_list, skip_execz):
     recent_valu = []                     # (index, dst regs)
     labels = {}
     for i, ins in enumerate(ins_list):
-        if ins.startswith("LABEL ") or re.match(r"^\.LBB\w+:", ins):
+        if ins.startswith("LABEL ") or re.match(r"^\.L\w+:", ins):
             labels[ins.replace("LABEL ", "").rstrip(":")] = i
     i, n = 0, len(ins_list)
     while i < n:
@@ -169,6 +200,11 @@ def check_kernel(name, ins_list, skip_execz):
                     outstanding = []
             i += 1
             continue
+        if mn == "s_branch":                       # unconditional: continue at the target when it lies ahead (an if/else join)
+            j = labels.get(ins.split()[-1])
+            if j is not None and j > i:
+                i = j
+                continue
         if mn in ("s_cbranch_execz",) and skip_execz:
             tgt = ins.split()[-1]
             j = labels.get(tgt)
@@ -211,7 +247,7 @@ def phase_report(ins_list):
     its first and last MFMA."""
     labels, out = {}, []
     for i, ins in enumerate(ins_list):
-        if ins.startswith("LABEL ") or re.match(r"^\.LBB\w+:", ins):
+        if ins.startswith("LABEL ") or re.match(r"^\.L\w+:", ins):
             labels[ins.replace("LABEL ", "").rstrip(":")] = i
     for i, ins in enumerate(ins_list):
         if ins.split()[0] in ("s_branch", "s_cbranch_vccnz", "s_cbranch_vccz", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_execnz"):
