@@ -18,8 +18,8 @@ A "step" = one pass of the hot path over one batch of synthetic rays resident in
 value = nominal ray-samples/s = (rays x 512) / time, whole job (every ray counted with all 512 samples, masked or
 terminated or not — SURVEY.md §8d).  Timed region: barrier + synchronize, K steps, synchronize + barrier; MAX over ranks.
 
-roofline.traffic is measured by THIS run: before the parent touches the GPU, rank 0 (N = 1) re-runs a 2-step bench under
-`rocprofv3 --pmc` in child processes, one pass per counter set (FETCH_SIZE; WRITE_SIZE; SQ/GRBM set), as
+roofline.traffic is measured by THIS run: after the timed region, rank 0 (N = 1) re-runs a 2-step bench under
+`rocprofv3 --pmc` in child processes, one pass per counter set (FETCH_SIZE; WRITE_SIZE; SQ/GRBM sets), as
 MI355X_MICROARCH.md's HBM section prescribes (FETCH_SIZE doubled on gfx950).  If the profiler is unavailable the field is
 null and `traffic_source` says why — never a constant read from a committed file.
 """
@@ -204,7 +204,7 @@ PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
 
 def collect_pmc(extra_args, budget_s=420.0):
     """One rocprofv3 --pmc pass per counter set over `bench.py --steps 2 --warmup 1` in a child process (program directly behind `--`).
-    Returns ({kernel short name: {counter: mean per dispatch}}, source string).  Must run before this process initialises the GPU."""
+    Returns ({kernel short name: {counter: mean per dispatch}}, source string)."""
     import csv
     import glob
     import shutil
@@ -286,9 +286,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
     pmc, pmc_source = {}, "not collected (--pmc off, N > 1, or a non-default workload)"
     default_workload = args.model == "TensorVMSplit" and args.chunk == 0 and args.emulate_world == 0 and args.img == 800
-    if args.pmc == "auto" and world == 1 and rank == 0 and default_workload:
-        extra = (["--alpha-mask", str(args.alpha_mask)] if args.alpha_mask else []) + (["--eps-T", str(args.eps_T)] if args.eps_T is not None else [])
-        pmc, pmc_source = collect_pmc(extra)                        # child processes; this process has not touched the GPU yet
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()              # (rehearsals may put several ranks on one card)
@@ -407,6 +404,13 @@ def main():
     st = stats.cpu().numpy().astype(np.float64) / max(args.steps, 1)      # per launch (this rank)
     m_eval, m_bbox, m_app = float(st[0]), float(st[1]), float(st[2])
 
+    # roofline.traffic: rocprofv3 --pmc passes over a 2-step run of this same bench, in CHILD processes (spawned, never exec'd from this
+    # process), after the timed region — run before it, the profiler sessions left every later launch of this process ~0.5 ms slower
+    # (24.0 vs 22.5 ms per step at identical kernel times), which would have distorted `value`.
+    if args.pmc == "auto" and world == 1 and rank == 0 and default_workload:
+        extra = (["--alpha-mask", str(args.alpha_mask)] if args.alpha_mask else []) + (["--eps-T", str(args.eps_T)] if args.eps_T is not None else [])
+        pmc, pmc_source = collect_pmc(extra)
+
     rays_job = R_step if args.emulate_world <= 1 else n_mine       # emulation reports the share that was rendered
     value = rays_job * S * args.steps / dt
     has_mask = model.alphaMask is not None
@@ -430,16 +434,19 @@ def main():
     l1_bytes = 40.0 * n_mine + 768.0 * m_eval + (32.0 * m_bbox if has_mask else 0.0)
     lds_bytes = 384.0 * m_eval
     ck_m = clock_ghz(pm, t_march) or 2.1
-    l1_peak = 256 * 64 * ck_m                                       # GB/s
+    L1_BCLK = 48.9               # B/clk/CU: the L1 -> register rate measured on MI355X for wave-level dwordx4 loads that all hit L1, 16 waves per CU
+                                 # (scripts/hwprobe/ta_rate.hip, profiles/r02_l1_rate_probe.txt: 21.0 cycles per 1-KB load); the nominal width is 64
+    l1_peak = 256 * L1_BCLK * ck_m                                  # GB/s
     roof_march = {"kernel": "march_kernel<false>", "bound": "l1", "achieved": l1_bytes / t_march / 1e9 if t_march > 0 else None,
                   "peak": l1_peak, "unit": "GB/s", "frac": l1_bytes / t_march / 1e9 / l1_peak if t_march > 0 else None,
                   "traffic": hbm(pm), "algorithmic_bytes_per_launch": l1_bytes + lds_bytes, "l1_bytes_per_launch": l1_bytes,
                   "lds_bytes_per_launch": lds_bytes, "lds_GBps": lds_bytes / t_march / 1e9 if t_march > 0 else None,
+                  "frac_vs_nominal_64B_per_clk": l1_bytes / t_march / 1e9 / (256 * 64 * ck_m) if t_march > 0 else None,
                   "clock_GHz": ck_m, "clock_source": "GRBM_GUI_ACTIVE / 8 / t (PMC child pass)" if clock_ghz(pm, t_march) else "nominal 2.1 (no PMC pass)",
                   "vs_hbm_8TBps": (l1_bytes + lds_bytes) / t_march / 1e9 / 8000.0 if t_march > 0 else None, "ms": k_ms[0],
                   "lds_bank_conflict_frac": (pm["SQ_LDS_BANK_CONFLICT"] / pm["SQ_LDS_IDX_ACTIVE"]) if pm.get("SQ_LDS_IDX_ACTIVE") else None,
                   "note": "40 B/ray + 768 B through L1 + 384 B through LDS per density sample actually evaluated (+32 B per alpha-mask lookup); peak = 256 CUs x "
-                          "64 B/clk x measured clock.  The 17 MB of density factors are L2 / Infinity-Cache resident, so HBM is not the roof "
+                          "48.9 B/clk (measured L1-hit rate of wave-level 16-B-per-lane loads, profiles/r02_l1_rate_probe.txt) x measured clock.  The 17 MB of density factors are L2 / Infinity-Cache resident, so HBM is not the roof "
                           "(vs_hbm_8TBps > 1 by construction, kept for SURVEY 8d's formula)"}
     ach_shade = FLOP_APP * m_app / t_shade / 1e12 if t_shade > 0 else None
     roof_shade = {"kernel": "shade_kernel<0,0,%s>" % ("true" if args.model == "REFTensoRF" else "false"), "bound": "mfma", "achieved": ach_shade,
@@ -452,6 +459,11 @@ def main():
                   "mfma_valu_coexec_frac_of_busy": (ps["SQ_VALU_MFMA_COEXEC_CYCLES"] / ps["SQ_VALU_MFMA_BUSY_CYCLES"]) if ps.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
                   "valu_insts_per_32_entry_tile": (ps["SQ_INSTS_VALU"] / (m_app / 32.0)) if ps.get("SQ_INSTS_VALU") and m_app > 0 else None,
                   "clock_GHz": clock_ghz(ps, t_shade),
+                  # the second roof of this kernel: every appearance sample pulls 3456 B of taps + 576 B of basis fragments (18 KB per 32-entry tile)
+                  # + 36 B of queue entry / view direction through the vector L1
+                  "l1": {"bytes_per_launch": 4068.0 * m_app, "achieved_GBps": 4068.0 * m_app / t_shade / 1e9 if t_shade > 0 else None,
+                         "peak_GBps": 256 * L1_BCLK * (clock_ghz(ps, t_shade) or 1.9),
+                         "frac": 4068.0 * m_app / t_shade / 1e9 / (256 * L1_BCLK * (clock_ghz(ps, t_shade) or 1.9)) if t_shade > 0 else None},
                   "note": f"{FLOP_APP / 1e3:.1f} kFLOP per appearance sample (algorithmic, fp32 semantics) against the dense f16 MFMA peak (2.5 PFLOP/s); "
                           "fp32-class arithmetic on this chip needs 3 fp16 products per fp32 product (hi/lo split; the fp32-input MFMA runs at 1/16 rate), "
                           f"so the ceiling for this arithmetic is peak / 3 = 833 TFLOP/s (frac_vs_fp32class_ceiling); executed on padded tiles: {FLOP_APP_EXEC} FLOP "

@@ -20,6 +20,7 @@
 // (eps_T <= weight threshold, so no appearance sample is ever skipped).  Appearance samples (w > thres) are compacted
 // with a ballot into a per-wave LDS list and flushed once per ray into a contiguous, sample-ordered segment of the
 // global queue (one atomicAdd per ray) -> the compositing order per ray is fixed, results are deterministic.
+#include <cstdlib>
 #include "tvr_device.h"
 #include "tvr_kernels.h"
 
@@ -469,6 +470,7 @@ hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S
     const int n_tiles = (n_rays + MARCH_TILE - 1) / MARCH_TILE;
     // one group per CU when it holds 16 waves; proportionally more groups when the lists force smaller ones
     long long grid = (long long)device_cu_count() * (16 / waves > 0 ? 16 / waves : 1);
+    if (const char *g = getenv("TVR_EXP_GRID_MARCH")) { const long long v = atoll(g); if (v > 0 && v < grid) grid = v; }   // scripts/overlap_experiment.py only
     if (grid > n_tiles) grid = n_tiles;
     if (grid < 1) grid = 1;
     tvr_dense_out none = {};

@@ -29,6 +29,7 @@
 // today), so the kernel keeps global LOADS and MFMAs in separate phases and scripts/isa_check.py verifies that on the shipped ISA
 // (tests/test_isa_rules.py): no VMEM load between the first and the last MFMA of the tile body, no load into a register an MFMA issued
 // within the previous 16 instructions reads, and an independent recount of every s_waitcnt vmcnt.
+#include <cstdlib>
 #include "tvr_device.h"
 #include "tvr_kernels.h"
 
@@ -647,6 +648,7 @@ static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStre
     hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
     unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
+    if (const char *g = getenv("TVR_EXP_GRID_SHADE")) { const long long v = atoll(g); if (v > 0 && v < 256) grid = (unsigned)v; }   // scripts/overlap_experiment.py only
     if (SRC != SH_SRC_QUEUE) {
         const long long groups = (a.n + SH_TILE * SH_WAVES - 1) / (SH_TILE * SH_WAVES);
         if (groups < grid) grid = (unsigned)(groups > 0 ? groups : 1);

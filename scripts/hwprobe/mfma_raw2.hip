@@ -52,8 +52,9 @@ __global__ void probe(float *__restrict__ out, int *__restrict__ bad)
         if (G == 10) BODY(GAPS);
         if (G == 11) BODY(GAPSS);
     }
-    // each MFMA: 14 halves of 1.0*1.0 + 2 halves of 2.0*1.0 = 18 per element; two per iteration
-    const float want = (float)ITER * 36.0f;
+    // the last dword of a fragment holds 2 of a lane's 8 k-values, in both lane halves: 4 of an element's 16 k-terms are 2.0 * 1.0 when the
+    // MFMA reads the FRESH value (12 + 8 = 20 per MFMA, 40 per iteration); a STALE read gives 16 per MFMA
+    const float want = (float)ITER * 40.0f;
     int wrong = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) wrong += (acc[r] != want);
@@ -69,8 +70,8 @@ static void run(const char *tag, float *out, int *bad)
         hipLaunchKernelGGL(probe<G>, dim3(256), dim3(64 * w), 0, 0, out, bad);
         int h = 0; float o = 0;
         (void)hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&o, out, 4, hipMemcpyDeviceToHost);
-        printf("VALU write -> [%-28s] -> MFMA read, waves/SIMD %d: lanes with a wrong accumulator %7d of %d (acc[0] = %.0f, want %.0f)\n", tag, w / 4, h,
-               256 * 64 * w, o, (float)ITER * 36.0f);
+        printf("VALU write -> [%-28s] -> MFMA read, waves/SIMD %d: lanes that read a stale operand %7d of %d (acc[0] = %.0f; fresh %.0f, stale %.0f)\n", tag, w / 4, h,
+               256 * 64 * w, o, (float)ITER * 40.0f, (float)ITER * 32.0f);
     }
 }
 
