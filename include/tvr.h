@@ -113,7 +113,13 @@ int tvr_scene_destroy(tvr_scene *scene);
  * OctreeRender_trilinear_fast (tensorf-myc/renderer.py:12-27).
  *   rays [n,6] (o,d); jitter [n] or NULL (is_train: one u per ray, tensorBase.py:351-353);
  *   eps_T: stop a ray once transmittance < eps_T (0 = exact, never stop); must be <= weight_thres;
- *   rgb_out [n,3], depth_out [n]; scratch of tvr_render_scratch_bytes(); dense/stats/prof may be NULL. */
+ *   rgb_out [n,3], depth_out [n]; scratch of tvr_render_scratch_bytes(); dense/stats/prof may be NULL.
+ * Arithmetic and its range: everything is fp32 except the matrix products of the appearance network (basis 144->27, layers 1 and 2), which
+ * run on the matrix cores as THREE fp16 products per fp32 product (each operand = fp16 hi + fp16 lo, hi*hi + hi*lo + lo*hi, fp32
+ * accumulation): ~2^-22 relative error per product, i.e. fp32-class results, but operands pass through fp16's exponent range —
+ * |weight|, |appearance feature|, |activation| must stay below 65 504 (conversion saturates there, silently) and parts below 6e-8 are
+ * flushed.  Layer 3, the positional encoding, interpolation, density and compositing are plain fp32.  The shipped scenes and the reference's
+ * 0.1 * randn initialisation are far inside this range (tests: |feature| up to ~1100, weights at 1e-4 scale). */
 size_t tvr_render_scratch_bytes(const tvr_scene *scene, int64_t n_rays, int32_t n_samples);
 int tvr_render(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, int32_t white_bg,
                const float *jitter, float eps_T, float *rgb_out, float *depth_out,
@@ -185,6 +191,28 @@ int tvr_march_backward_z(tvr_scene *scene, const float *rays, int64_t n_rays, in
 int tvr_app_h_forward(tvr_scene *scene, const float *xyz_norm, int64_t m, float *h_out, void *stream);
 int tvr_app_h_backward(tvr_scene *scene, const float *xyz_norm, int64_t m, const float *dh, void *grad_scratch,
                        size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream);
+
+/* The appearance network of a TRAINING step (TensorVMSplit; train.py:225-261 through tensoRF.py:244 `basis_mat` and tensorBase.py:76-86
+ * `MLPRender_Fea.execute`) on the m appearance samples of a batch, forward and backward, as register-resident MFMA chains.
+ *   forward : h [m,144] (tvr_app_h_forward), viewdirs [m,3] -> rgb [m,3]; the inference kernel's own instructions, so a training forward and
+ *             an evaluation render agree bit for bit.  Saved for the backward: feats32 [m,32] (27 features + 5 zeros), h1 / h2 [m,128] = the
+ *             outputs of layers 1 / 2 after their ReLU.  Uses the scene's packed weights (tvr_scene_update first).
+ *   backward: grad_rgb [m,3] (w.r.t. the sigmoid output) -> dh [m,144] (feed tvr_app_h_backward), plus the matrices whose products with
+ *             the saved activations are the weight gradients (tvr_gemm_tn): d_out4 [m,4] = {grad of layer 3's output, 0}, dh2 / dh1 [m,128] =
+ *             gradients of the pre-ReLU outputs of layers 2 / 1, dfeats32 [m,32] = gradient of the 27 features (+ 5 zeros):
+ *               dW3 = d_out^T h2, db3 = colsum(d_out); dW2 = dh2^T h1, db2 = colsum(dh2); dW1 = dh1^T X with X = tvr_pe_concat(feats, viewdirs),
+ *               db1 = colsum(dh1); d basis_mat = dfeats^T h.
+ *             W1 [128,150], W2 [128,128], W3 [3,128], basis [27,144]: the CURRENT parameters in the reference layout; they are packed into
+ *             `image` (tvr_mlp_train_image_bytes() of 256-byte aligned device memory, caller-owned) by the call itself.
+ *             gscale_dev: device scalar, a power of two.  The MFMA operands pass through fp16 (see tvr_render), and MSE gradients of a
+ *             4096-ray batch are O(1e-5): gradients are multiplied by gscale on entry and by 1 / gscale on exit; choose it so that
+ *             max |grad_rgb| * gscale is O(100) (results do not depend on it beyond rounding).
+ * All matrices row-major, contiguous, 16-byte aligned; m * 576 < 2^32 per call. */
+size_t tvr_mlp_train_image_bytes(void);
+int tvr_mlp_train_forward(tvr_scene *scene, const float *h, const float *viewdirs, int64_t m, float *rgb, float *feats32, float *h1, float *h2, void *stream);
+int tvr_mlp_train_backward(const float *W1, const float *W2, const float *W3, const float *basis, const float *grad_rgb, const float *rgb, const float *feats32,
+                           const float *h1, const float *h2, int64_t m, const float *gscale_dev, float *d_out4, float *dh2, float *dh1, float *dfeats32, float *dh,
+                           void *image, size_t image_bytes, void *stream);
 
 /* C [Ka,Kb] = A^T B for tall-skinny fp32 operands A [M,Ka] (row stride lda), B [M,Kb] (row stride ldb): the weight gradients dW = dY^T X of
  * the training step's Linears (MLPRender_Fea's three layers tensorBase.py:69-71, basis_mat tensoRF.py:150) over the M appearance samples of

@@ -98,6 +98,9 @@ SYMBOLS = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.c_void_p]),
     "tvr_app_h_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tvr_app_h_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.c_void_p]),
+    "tvr_mlp_train_image_bytes": (C.c_size_t, []),
+    "tvr_mlp_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvr_mlp_train_backward": (C.c_int, [C.c_void_p] * 9 + [C.c_int64] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),
     "tvr_gemm_tn_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     "tvr_gemm_tn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.c_void_p]),

@@ -3,7 +3,9 @@
   * _MarchFn      tvr_march_forward(_z) / tvr_march_backward(_z)   sample_ray .. raw2alpha (tensorBase.py:487-513) w.r.t. the density factors
   * _AppHFn       tvr_app_h_forward / tvr_app_h_backward           the plane*line products of compute_appfeature (tensoRF.py:235-241)
   * _PEConcatFn   tvr_pe_concat (+ backward)                        the MLP input of MLPRender_Fea(_Ref).execute (tensorBase.py:76-82)
-  * _LinearFn     library GEMMs forward / dX, tvr_gemm_tn for dW    the Linears of the MLP and basis_mat
+  * _LinearFn     library GEMMs forward / dX, tvr_gemm_tn for dW    the Linears of REFTensoRF / NerfPlusPlus (and of shapes the fused kernels are not built for)
+  * _MlpTrainFn   tvr_mlp_train_forward / tvr_mlp_train_backward    basis_mat + MLPRender_Fea of TensorVMSplit (tensoRF.py:244, tensorBase.py:76-86): the
+                                                                    inference kernel's forward, register-resident MFMA backward, weight gradients by tvr_gemm_tn
 """
 from __future__ import annotations
 
@@ -233,3 +235,73 @@ class _AppHFn(torch.autograd.Function):
         L.check(L.lib().tvr_app_h_backward(sc, ctx.xyz.data_ptr(), ctx.xyz.shape[0], dh.data_ptr(), gs.data_ptr(), gs.numel(), C.byref(out),
                                            _stream_ptr(model.device)), "tvr_app_h_backward")
         return (None, None, *grads)
+
+
+class _MlpTrainFn(torch.autograd.Function):
+    """rgb [M,3] = sigmoid(MLP([f, d, PE(f), PE(d)])) with f = basis_mat(h), for TensorVMSplit's MLPRender_Fea (27 features, 2/2 frequencies, width 128).
+    Forward = the inference shade kernel fed with h (bit-identical to an evaluation render); backward = tvr_mlp_train_backward (dX chain on
+    the matrix cores) + seven tall-skinny reductions (tvr_gemm_tn) for the weight and bias gradients.  No library GEMM."""
+
+    @staticmethod
+    def forward(ctx, model, h, viewdirs, basis_w, W1, b1, W2, b2, W3, b3):
+        lib = L.lib()
+        sc = model._ensure_scene()                     # packed by _MarchFn.forward of this step
+        dev = h.device
+        m = h.shape[0]
+        h = h.contiguous()
+        vd = viewdirs.detach().contiguous().float()
+        rgb = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        feats = torch.empty((m, 32), dtype=torch.float32, device=dev)
+        h1 = torch.empty((m, 128), dtype=torch.float32, device=dev)
+        h2 = torch.empty((m, 128), dtype=torch.float32, device=dev)
+        L.check(lib.tvr_mlp_train_forward(sc, h.data_ptr(), vd.data_ptr(), m, rgb.data_ptr(), feats.data_ptr(), h1.data_ptr(), h2.data_ptr(),
+                                          _stream_ptr(dev)), "tvr_mlp_train_forward")
+        ctx.save_for_backward(h, vd, rgb, feats, h1, h2, basis_w, W1, W2, W3)
+        ctx.model = model
+        return rgb
+
+    @staticmethod
+    def backward(ctx, grgb):
+        lib = L.lib()
+        h, vd, rgb, feats, h1, h2, basis_w, W1, W2, W3 = ctx.saved_tensors
+        dev = h.device
+        m = h.shape[0]
+        if m == 0:
+            z = lambda t: torch.zeros_like(t)
+            return (None, torch.zeros_like(h), None, z(basis_w), z(W1), torch.zeros(128, device=dev), z(W2), torch.zeros(128, device=dev), z(W3),
+                    torch.zeros(3, device=dev))
+        grgb = grgb.contiguous().float()
+        # power-of-two scale that brings the largest output gradient to ~2^6 (device side: no host sync)
+        gmax = (grgb.abs().max() * 0.25).clamp_min(1e-30)
+        gscale = torch.exp2(torch.floor(torch.log2(64.0 / gmax))).clamp(1.0, 2.0 ** 60).reshape(1).float()
+        d_out = torch.empty((m, 4), dtype=torch.float32, device=dev)
+        dh2 = torch.empty((m, 128), dtype=torch.float32, device=dev)
+        dh1 = torch.empty((m, 128), dtype=torch.float32, device=dev)
+        dfe = torch.empty((m, 32), dtype=torch.float32, device=dev)
+        dh = torch.empty((m, 144), dtype=torch.float32, device=dev)
+        image = ctx.model._get_train_image()
+        W1c, W2c, W3c, Bc = (t.detach().contiguous().float() for t in (W1, W2, W3, basis_w))
+        L.check(lib.tvr_mlp_train_backward(W1c.data_ptr(), W2c.data_ptr(), W3c.data_ptr(), Bc.data_ptr(), grgb.data_ptr(), rgb.data_ptr(), feats.data_ptr(),
+                                           h1.data_ptr(), h2.data_ptr(), m, gscale.data_ptr(), d_out.data_ptr(), dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(),
+                                           dh.data_ptr(), image.data_ptr(), image.numel(), _stream_ptr(dev)), "tvr_mlp_train_backward")
+        X = torch.empty((m, 150), dtype=torch.float32, device=dev)                      # the MLP input, re-derived from the saved features (tensorBase.py:77-82)
+        f27 = feats[:, :27].contiguous()
+        L.check(lib.tvr_pe_concat(f27.data_ptr(), vd.data_ptr(), None, m, X.data_ptr(), _stream_ptr(dev)), "tvr_pe_concat")
+        big = m >= 4096
+        tn = (lambda a_, lda, ka, b_, ldb, kb: _gemm_tn_call(a_, lda, ka, b_, ldb, kb, m)) if big else None
+        if big:
+            gW3 = tn(d_out, 4, 3, h2, 128, 128)
+            gW2 = tn(dh2, 128, 128, h1, 128, 128)
+            gW1 = tn(dh1, 128, 128, X, 150, 150)
+            gB = tn(dfe, 32, 27, h, 144, 144)
+            ones = _ONES.get((dev, m))
+            if ones is None:
+                _ONES.clear()
+                ones = _ONES[(dev, m)] = torch.ones(m, dtype=torch.float32, device=dev)
+            gb3 = tn(d_out, 4, 3, ones, 1, 1).view(-1)
+            gb2 = tn(dh2, 128, 128, ones, 1, 1).view(-1)
+            gb1 = tn(dh1, 128, 128, ones, 1, 1).view(-1)
+        else:                                          # tiny batches (tests): the reductions as plain torch products
+            gW3, gW2, gW1, gB = d_out[:, :3].t() @ h2, dh2.t() @ h1, dh1.t() @ X, dfe[:, :27].t() @ h
+            gb3, gb2, gb1 = d_out[:, :3].sum(0), dh2.sum(0), dh1.sum(0)
+        return None, dh, None, gB, gW1, gb1, gW2, gb2, gW3, gb3

@@ -473,6 +473,39 @@ int tvr_app_h_forward(tvr_scene *s, const float *xyz, int64_t m, float *h_out, v
     return TVR_OK;
 }
 
+size_t tvr_mlp_train_image_bytes(void) { return mlp_train_image_bytes(); }
+
+int tvr_mlp_train_forward(tvr_scene *s, const float *h, const float *viewdirs, int64_t m, float *rgb, float *feats32, float *h1, float *h2, void *stream)
+{
+    int rc = scene_ready(s);
+    if (rc != TVR_OK) return rc;
+    if (s->desc.variant != 0) return fail(TVR_ERR_UNSUPPORTED, "tvr_mlp_train_forward: TensorVMSplit scenes only (REFTensoRF trains through the library-GEMM path)");
+    if (m == 0) return TVR_OK;
+    if (!h || !viewdirs || !rgb || !feats32 || !h1 || !h2 || m < 0) return fail(TVR_ERR_INVALID, "NULL argument or m < 0");
+    if (((uintptr_t)h | (uintptr_t)feats32 | (uintptr_t)h1 | (uintptr_t)h2) % 16) return fail(TVR_ERR_INVALID, "h / feats32 / h1 / h2 must be 16-byte aligned");
+    ShadeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.n = m; sa.h_in = h; sa.viewdirs = viewdirs; sa.out = rgb; sa.t_feats = feats32; sa.t_h1 = h1; sa.t_h2 = h2;
+    HIP_TRY(launch_shade(s->dev, SH_SRC_H, SH_DST_TRAIN, sa, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_mlp_train_backward(const float *W1, const float *W2, const float *W3, const float *basis, const float *grad_rgb, const float *rgb, const float *feats32,
+                           const float *h1, const float *h2, int64_t m, const float *gscale_dev, float *d_out4, float *dh2, float *dh1, float *dfeats32, float *dh,
+                           void *image, size_t image_bytes, void *stream)
+{
+    if (m == 0) return TVR_OK;
+    if (!W1 || !W2 || !W3 || !basis || !grad_rgb || !rgb || !feats32 || !h1 || !h2 || !gscale_dev || !d_out4 || !dh2 || !dh1 || !dfeats32 || !dh || !image || m < 0)
+        return fail(TVR_ERR_INVALID, "NULL argument or m < 0");
+    if (image_bytes < mlp_train_image_bytes() || (uintptr_t)image % 256) return fail(TVR_ERR_SCRATCH, "training image buffer too small or misaligned");
+    if ((uint64_t)m * 576u >= (1ull << 32)) return fail(TVR_ERR_INVALID, "m = %lld: 32-bit row offsets inside the kernels allow 7.4 M entries per call", (long long)m);
+    if (((uintptr_t)feats32 | (uintptr_t)h1 | (uintptr_t)h2 | (uintptr_t)d_out4 | (uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)dfeats32 | (uintptr_t)dh) % 16)
+        return fail(TVR_ERR_INVALID, "activation / gradient matrices must be 16-byte aligned");
+    HIP_TRY(launch_pack_train_image(W1, W2, W3, basis, image, (hipStream_t)stream));
+    HIP_TRY(launch_mlp_train_backward(grad_rgb, rgb, feats32, h1, h2, m, gscale_dev, d_out4, dh2, dh1, dfeats32, dh, image, (hipStream_t)stream));
+    return TVR_OK;
+}
+
 int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *dh, void *grad_scratch, size_t grad_scratch_bytes,
                        const tvr_vm_grads *out, void *stream_)
 {

@@ -202,3 +202,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
     const unsigned q = nblk >> 3, r = nblk & 7u, x = b & 7u, i = b >> 3;
     return x * q + (x < r ? x : r) + i;
 }
+
+// accumulator register r of lane half h  <->  row of the 32x32 tile
+__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// reference input index (tensorBase.py:77-82 concat order) of derived value t of base value c; -1 = zero weight
+__device__ __forceinline__ int ref_in_index(int c, int t)
+{
+    if (c < TVR_APPDIM) return t == 0 ? c : (t == 1 ? 30 + 2 * c : (t == 2 ? 31 + 2 * c : (t == 3 ? 84 + 2 * c : 85 + 2 * c)));
+    if (c < TVR_APPDIM + 3) {
+        const int d = c - TVR_APPDIM;
+        return t == 0 ? 27 + d : (t == 1 ? 138 + 2 * d : (t == 2 ? 139 + 2 * d : (t == 3 ? 144 + 2 * d : 145 + 2 * d)));
+    }
+    return -1;
+}
+

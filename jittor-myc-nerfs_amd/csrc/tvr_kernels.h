@@ -35,8 +35,8 @@ struct TrainGrads {
     float *dplane[3], *dline[3], *aplane[3], *aline[3];
 };
 
-enum { SH_SRC_QUEUE = 0, SH_SRC_XYZ = 1, SH_SRC_FEAT = 2 };
-enum { SH_DST_QUEUE = 0, SH_DST_FEAT = 1, SH_DST_RGB = 2 };
+enum { SH_SRC_QUEUE = 0, SH_SRC_XYZ = 1, SH_SRC_FEAT = 2, SH_SRC_H = 3 };       // SRC_H: h [n,144] given (training forward)
+enum { SH_DST_QUEUE = 0, SH_DST_FEAT = 1, SH_DST_RGB = 2, SH_DST_TRAIN = 3 };    // DST_TRAIN: rgb + the activations the backward needs
 
 struct ShadeArgs {
     const unsigned *counter;   // SRC_QUEUE: entry count lives on the device
@@ -51,6 +51,8 @@ struct ShadeArgs {
     float *out;                // DST_FEAT [n,27] / DST_RGB [n,3]
     const float *dots;         // REFTensoRF, SRC_FEAT: the dot_product input of MLPRender_Fea_Ref [n]
     float *out2;               // REFTensoRF, DST_FEAT: [n,8] {normal 3, rgb_d 3, specular_tint, rho}
+    const float *h_in;         // SRC_H: h [n,144] (tvr_app_h_forward)
+    float *t_feats, *t_h1, *t_h2;   // DST_TRAIN: features [n,32] (27 + zero pad), relu(layer 1) [n,128], relu(layer 2) [n,128]
     unsigned long long *stats;
 };
 
@@ -75,5 +77,9 @@ size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M);
 hipError_t launch_pe_concat(const float *feat, const float *dir, const float *dot, long long m, float *X, hipStream_t stream);
 hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const float *gX, long long m, int with_dot, float *gfeat, float *gdir,
                                      float *gdot, hipStream_t stream);
+size_t mlp_train_image_bytes();
+hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, void *image, hipStream_t stream);
+hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
+                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, const void *image, hipStream_t stream);
 hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, float *value, float *grad, float *part, hipStream_t stream);
 hipError_t launch_alpha_bits(const float *vol, long long n, unsigned *bits, hipStream_t stream);

@@ -1,0 +1,377 @@
+// tvr_mlp_train.hip — backward of the appearance network of the training step (tensorf-myc/train.py:225-261 through
+// models/tensoRF.py:244 `basis_mat` and models/tensorBase.py:76-86 `MLPRender_Fea.execute`) as register-resident MFMA chains.
+//
+// The forward of a training step is the inference shade kernel itself (tvr_shade.hip, SRC_H / DST_TRAIN: same instructions, so a training
+// forward and an evaluation render agree bit for bit); it leaves  features [m,32], relu(layer 1) [m,128], relu(layer 2) [m,128], rgb [m,3].
+// Here, per 32-entry tile and wave (entry = MFMA column, lane (e, h) as in the shade kernel):
+//   d_out  = grad_rgb * rgb * (1 - rgb)                                        sigmoid', VALU
+//   dH2^T  = mask(relu 2) . W3^T d_out^T                       [128 x 32e]     K = 3: plain fp32 FMAs, W3 as fp32 in LDS
+//   dH1^T  = mask(relu 1) . W2^T dH2^T                         [128 x 32e]     MFMA: A = W2^T image in LDS, B = the dH2 registers in place
+//   dX^T   = W1^T dH1^T                                        [160 x 32e]     MFMA: row 32 t + c of W1^T's image is derived value t of base value c,
+//                                                                              so lane (e, h) ends up with the five slot gradients of its own 16 base values
+//   dF     = dX0 + cos v dX1 + 2 cos 2v dX2 - sin v dX3 - 2 sin 2v dX4                 derivative of [v, sin v, sin 2v, cos v, cos 2v]
+// and a second, small kernel:  dh^T = Bas^T dF^T [144 x 32e]  (the gradient that tvr_app_h_backward scatters into planes and lines).
+// Stored for the weight gradients (tall-skinny reductions, tvr_gemm_tn): d_out [m,4], dH2 [m,128], dH1 [m,128], dF [m,32].
+// Arithmetic: fp16 hi/lo split MFMA, 3 products, fp32 accumulate, as in the forward (tvr_mfma.h).  GRADIENT RANGE: operands pass through fp16,
+// so |dH| must stay below 65 504 and parts below 6e-8 of the largest... are flushed: the gradients are therefore scaled per call by `gscale`
+// (a power of two chosen by the host from max |grad_rgb|) on entry and unscaled on exit — the MSE gradients of a 4096-ray batch are O(1e-4).
+// Phase discipline as in tvr_shade.hip: all loads of a tile are issued and waited for before its first MFMA (stores are not loads).
+#include "tvr_device.h"
+#include "tvr_kernels.h"
+#include "tvr_mfma.h"
+
+#define TI_ROW 272                                   // 128 k positions * 2 B + 16 B pad (conflict-free ds_read_b128, as the forward image)
+#define TI_W2T_H 0
+#define TI_W2T_L (128 * TI_ROW)
+#define TI_W1T_H (2 * 128 * TI_ROW)
+#define TI_W1T_L (TI_W1T_H + 160 * TI_ROW)
+#define TI_W3 (TI_W1T_H + 2 * 160 * TI_ROW)          // W3 [3][128] fp32
+#define TI_LDS_BYTES (TI_W3 + 3 * 128 * 4)           // 158 208 B
+#define TI_BAST (TI_LDS_BYTES)                       // Bas^T fragments [5 row blocks][2 k-steps][2 halves][32 rows][hi 8 | lo 8] fp16 (not copied to LDS)
+#define TI_BYTES (TI_BAST + 5 * 2 * 2 * 32 * 32)     // 178 688 B
+
+#define MT_WAVES 8
+#define MT_THREADS (64 * MT_WAVES)
+
+// hidden unit of k position kpos of a hidden-layer k-step (the accumulator-as-operand order, tvr_shade.hip pack mode 1)
+__device__ __forceinline__ int unit_of_kpos(int kpos)
+{
+    const int s = kpos >> 4, hh = (kpos >> 3) & 1, j = kpos & 7;
+    return 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+}
+
+// one thread per element of the three transposed images
+__global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
+                                                               const float *__restrict__ Bas, unsigned char *__restrict__ img)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_w2 = 128 * 128, n_w1 = 160 * 128, n_w3 = 3 * 128, n_b = 160 * 32;
+    if (i < n_w2) {
+        const int row = i >> 7, kpos = i & 127;                                   // row = layer-1 unit, k = layer-2 unit
+        unsigned hi, lo;
+        split2(W2[(size_t)unit_of_kpos(kpos) * TVR_FEATC + row], 0.0f, hi, lo);
+        ((unsigned short *)(img + TI_W2T_H + row * TI_ROW))[kpos] = (unsigned short)hi;
+        ((unsigned short *)(img + TI_W2T_L + row * TI_ROW))[kpos] = (unsigned short)lo;
+    } else if (i < n_w2 + n_w1) {
+        const int k = i - n_w2, row = k >> 7, kpos = k & 127;                     // row = 32 t + c: derived value t of base value c; k = layer-1 unit
+        const int idx = ref_in_index(row & 31, row >> 5);
+        const int c = row & 31, t = row >> 5;
+        float w = idx >= 0 ? W1[(size_t)unit_of_kpos(kpos) * TVR_NIN + idx] : 0.0f;
+        (void)c; (void)t;
+        unsigned hi, lo;
+        split2(w, 0.0f, hi, lo);
+        ((unsigned short *)(img + TI_W1T_H + row * TI_ROW))[kpos] = (unsigned short)hi;
+        ((unsigned short *)(img + TI_W1T_L + row * TI_ROW))[kpos] = (unsigned short)lo;
+    } else if (i < n_w2 + n_w1 + n_w3) {
+        const int k = i - n_w2 - n_w1;
+        ((float *)(img + TI_W3))[k] = W3[k];
+    } else if (i < n_w2 + n_w1 + n_w3 + n_b) {
+        const int k = i - n_w2 - n_w1 - n_w3, row = k >> 5, kpos = k & 31;        // row = channel (144, padded to 160), k = feature (27, padded to 32)
+        const int f = unit_of_kpos(kpos);
+        const float w = (row < TVR_KAPP && f < TVR_APPDIM) ? Bas[(size_t)f * TVR_KAPP + row] : 0.0f;
+        unsigned hi, lo;
+        split2(w, 0.0f, hi, lo);
+        const int s = kpos >> 4, hh = (kpos >> 3) & 1, j = kpos & 7, rb = row >> 5, r = row & 31;
+        unsigned short *o = (unsigned short *)(img + TI_BAST) + ((size_t)(((rb * 2 + s) * 2 + hh) * 32 + r)) * 16;
+        o[j] = (unsigned short)hi;
+        o[8 + j] = (unsigned short)lo;
+    }
+}
+
+struct AFragN { uint4 h[5], l[5]; };
+
+template <int NB>
+__device__ __forceinline__ void load_afragn(AFragN &A, const unsigned char *WH, const unsigned char *WL, int off0)
+{
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+        A.h[rb] = *(const uint4 *)(WH + off0 + rb * 32 * TI_ROW);
+        A.l[rb] = *(const uint4 *)(WL + off0 + rb * 32 * TI_ROW);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void mfma3xn(const AFragN &A, const Frag &b, f32x16 acc[NB])
+{
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) acc[rb] = MFMAH(A.l[rb], b.hi, acc[rb]);
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) acc[rb] = MFMAH(A.h[rb], b.lo, acc[rb]);
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) acc[rb] = MFMAH(A.h[rb], b.hi, acc[rb]);
+}
+
+struct MlpBwdArgs {
+    const float *grad_rgb, *rgb, *feats, *h1, *h2;   // [m,3], [m,3], [m,32], [m,128], [m,128]
+    long long m;
+    const float *gscale;                             // device scalar: gradients are multiplied by this power of two on entry, by its inverse on exit
+    float *d_out, *dh2, *dh1, *dfeats;               // [m,4], [m,128], [m,128], [m,32]
+    const unsigned char *image;                      // TI_BYTES
+};
+
+__global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_kernel(const MlpBwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e = lane & 31, h = lane >> 5;
+    {
+        const uint4 *src = (const uint4 *)a.image;
+        for (int i = tid; i < TI_LDS_BYTES / 16; i += MT_THREADS) ((uint4 *)smem)[i] = src[i];
+        __syncthreads();
+    }
+    const long long n_tiles = (a.m + 31) / 32;
+    const float gscale = *a.gscale, inv_scale = 1.0f / gscale;
+    for (long long tile = (long long)blockIdx.x * MT_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * MT_WAVES) {
+        const long long ent = tile * 32 + e;
+        const bool live = ent < a.m;
+        const long long le = live ? ent : a.m - 1;
+        // ---------------------------------------------------------------- loads (all of this tile's) ----
+        float g[3], o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { g[c] = a.grad_rgb[le * 3 + c]; o[c] = a.rgb[le * 3 + c]; }
+        unsigned long long m1 = 0ull, m2 = 0ull;     // bit 16 rb + r: relu(layer 1 / 2) of hidden unit 32 rb + acc_row(r, h) is positive
+        const unsigned lrow128 = (unsigned)le * (TVR_FEATC * 4u) + 16u * (unsigned)h;
+        {
+            float4 t2[16], t1[16];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    t2[rb * 4 + q] = *(const float4 *)((const unsigned char *)a.h2 + (lrow128 + (unsigned)(128 * rb + 32 * q)));
+                    t1[rb * 4 + q] = *(const float4 *)((const unsigned char *)a.h1 + (lrow128 + (unsigned)(128 * rb + 32 * q)));
+                }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                m2 |= (unsigned long long)((t2[i].x > 0.f) | ((t2[i].y > 0.f) << 1) | ((t2[i].z > 0.f) << 2) | ((t2[i].w > 0.f) << 3)) << (4 * i);
+                m1 |= (unsigned long long)((t1[i].x > 0.f) | ((t1[i].y > 0.f) << 1) | ((t1[i].z > 0.f) << 2) | ((t1[i].w > 0.f) << 3)) << (4 * i);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------------------------------------------------------- d_out, dH2 (VALU) ----
+        float d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[c] = live ? (g[c] * gscale) * (o[c] * (1.0f - o[c])) : 0.0f;
+        if (live && h == 0) *(float4 *)(a.d_out + ent * 4) = make_float4(d[0] * inv_scale, d[1] * inv_scale, d[2] * inv_scale, 0.0f);
+        f32x16 dh2[4];
+        {
+            unsigned w3a = (unsigned)(size_t)(smem + TI_W3) + 16u * (unsigned)h;
+            asm volatile("" : "+v"(w3a));
+            const float *W3 = (const float *)(const void __attribute__((address_space(3))) *)(size_t)w3a;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w0 = *(const float4 *)(W3 + 32 * rb + 8 * q), w1 = *(const float4 *)(W3 + 128 + 32 * rb + 8 * q),
+                                 w2 = *(const float4 *)(W3 + 256 + 32 * rb + 8 * q);
+                    const float x[4] = {__builtin_fmaf(w2.x, d[2], __builtin_fmaf(w1.x, d[1], w0.x * d[0])), __builtin_fmaf(w2.y, d[2], __builtin_fmaf(w1.y, d[1], w0.y * d[0])),
+                                        __builtin_fmaf(w2.z, d[2], __builtin_fmaf(w1.z, d[1], w0.z * d[0])), __builtin_fmaf(w2.w, d[2], __builtin_fmaf(w1.w, d[1], w0.w * d[0]))};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dh2[rb][4 * q + i] = ((m2 >> (16 * rb + 4 * q + i)) & 1ull) ? x[i] : 0.0f;
+                }
+        }
+        const unsigned row128 = (unsigned)ent * (TVR_FEATC * 4u) + 16u * (unsigned)h;       // byte offset of this lane's first quad in a [m,128] matrix
+        if (live) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4 *)((unsigned char *)a.dh2 + (row128 + (unsigned)(128 * rb + 32 * q))) =
+                        make_float4(dh2[rb][4 * q] * inv_scale, dh2[rb][4 * q + 1] * inv_scale, dh2[rb][4 * q + 2] * inv_scale, dh2[rb][4 * q + 3] * inv_scale);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------------------------------------------------------- dH1 = mask . W2^T dH2 ----
+        f32x16 dh1[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) dh1[rb] = f32x16{0};
+        {
+            const int rowoff = e * TI_ROW + h * 16;
+            auto frag = [&](int s, Frag &b) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = dh2[s >> 1][8 * (s & 1) + j];
+                b = split8(x);
+            };
+            Frag bcur, bnxt;
+            AFragN acur, anxt;
+            frag(0, bcur);
+            load_afragn<4>(acur, smem + TI_W2T_H, smem + TI_W2T_L, rowoff);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8) {
+                    load_afragn<4>(anxt, smem + TI_W2T_H, smem + TI_W2T_L, rowoff + (s + 1) * 32);
+                    frag(s + 1, bnxt);
+                }
+                mfma3xn<4>(acur, bcur, dh1);
+                acur = anxt;
+                bcur = bnxt;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh1[rb][r] = ((m1 >> (16 * rb + r)) & 1ull) ? dh1[rb][r] : 0.0f;
+        if (live) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4 *)((unsigned char *)a.dh1 + (row128 + (unsigned)(128 * rb + 32 * q))) =
+                        make_float4(dh1[rb][4 * q] * inv_scale, dh1[rb][4 * q + 1] * inv_scale, dh1[rb][4 * q + 2] * inv_scale, dh1[rb][4 * q + 3] * inv_scale);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------------------------------------------------------- dX = W1^T dH1  (5 row blocks: block t = derived value t) ----
+        f32x16 dx[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) dx[t] = f32x16{0};
+        {
+            const int rowoff = e * TI_ROW + h * 16;
+            auto frag = [&](int s, Frag &b) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = dh1[s >> 1][8 * (s & 1) + j];
+                b = split8(x);
+            };
+            // (the ten weight fragments of a step are fetched in the step itself: 144 accumulator registers leave no room for a second set;
+            //  the partner wave covers the LDS latency)
+            Frag bcur;
+            AFragN acur;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                load_afragn<5>(acur, smem + TI_W1T_H, smem + TI_W1T_L, rowoff + s * 32);
+                frag(s, bcur);
+                mfma3xn<5>(acur, bcur, dx);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---------------------------------------------------------------- dF: through the positional encoding ----
+        // The features are fetched HERE, behind the matrix phase (144 accumulator registers leave no room to hold them across it): first every
+        // lane reads block 4 of dX, whose last MFMA is the last one issued — that completes this tile's MFMAs (the pipe is in order) —, then
+        // the loads are issued and waited for.
+        float df[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            df[r] = dx[4][r] * inv_scale;                                      // block 4's last MFMA is the last one issued
+            asm volatile("" : "+v"(df[r]) :: "memory");                        // computed HERE: nothing below (the loads) may move above it
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 f4 = *(const float4 *)(a.feats + le * 32 + 8 * q + 4 * h);
+            v[4 * q] = f4.x; v[4 * q + 1] = f4.y; v[4 * q + 2] = f4.z; v[4 * q + 3] = f4.w;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float k = rintf(v[r] * 0.15915494309189535f);                    // the forward's reduction (tvr_shade.hip sincos_pe)
+            float rr = __builtin_fmaf(k, -6.2831854820251465f, v[r]);
+            rr = __builtin_fmaf(k, 1.7484555e-7f, rr);
+            const float tt = rr * 0.15915494309189535f;
+            const float sn = __builtin_amdgcn_sinf(tt), cs = __builtin_amdgcn_cosf(tt);
+            const float s2 = 2.0f * sn * cs, c2 = __builtin_fmaf(-2.0f * sn, sn, 1.0f);
+            float acc = dx[0][r];
+            acc = __builtin_fmaf(cs, dx[1][r], acc);
+            acc = __builtin_fmaf(2.0f * c2, dx[2][r], acc);
+            acc = __builtin_fmaf(-sn, dx[3][r], acc);
+            df[r] = (acc_row(r, h) < TVR_APPDIM) ? __builtin_fmaf(-2.0f * s2, df[r], acc * inv_scale) : 0.0f;
+        }
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4 *)(a.dfeats + ent * 32 + 8 * q + 4 * h) = make_float4(df[4 * q], df[4 * q + 1], df[4 * q + 2], df[4 * q + 3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// dh^T [144 x 32e] = Bas^T [144 x 32] dF^T [32 x 32e]  (gscale as above; dF is stored unscaled)
+__global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__restrict__ dfeats, long long m, const float *__restrict__ gscale_p, const unsigned char *__restrict__ image,
+                                                                float *__restrict__ dh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = lane & 31, h = lane >> 5;
+    const long long n_tiles = (m + 31) / 32;
+    const float gscale = *gscale_p, inv_scale = 1.0f / gscale;
+    // the 20 A fragments of this lane (same for every tile)
+    uint4 ah[5][2], al[5][2];
+#pragma unroll
+    for (int rb = 0; rb < 5; ++rb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint4 *ap = (const uint4 *)(image + TI_BAST) + (size_t)((((rb * 2 + s) * 2 + h) * 32 + e) * 2);
+            ah[rb][s] = ap[0];
+            al[rb][s] = ap[1];
+        }
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+        const long long ent = tile * 32 + e;
+        const bool live = ent < m;
+        const long long le = live ? ent : m - 1;
+        float x[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 f4 = *(const float4 *)(dfeats + le * 32 + 8 * q + 4 * h);
+            x[4 * q] = f4.x * gscale; x[4 * q + 1] = f4.y * gscale; x[4 * q + 2] = f4.z * gscale; x[4 * q + 3] = f4.w * gscale;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const Frag b0 = split8(x), b1 = split8(x + 8);
+        f32x16 acc[5];
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) acc[rb] = f32x16{0};
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(al[rb][0], b0.hi, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][0], b0.lo, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][0], b0.hi, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(al[rb][1], b1.hi, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][1], b1.lo, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][1], b1.hi, acc[rb]);
+        if (live) {
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 32 * rb + 8 * q + 4 * h;
+                    if (row < TVR_KAPP)
+                        *(float4 *)(dh + ent * TVR_KAPP + row) =
+                            make_float4(acc[rb][4 * q] * inv_scale, acc[rb][4 * q + 1] * inv_scale, acc[rb][4 * q + 2] * inv_scale, acc[rb][4 * q + 3] * inv_scale);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+size_t mlp_train_image_bytes() { return TI_BYTES; }
+
+hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, void *image, hipStream_t stream)
+{
+    const int n = 128 * 128 + 160 * 128 + 3 * 128 + 160 * 32;
+    hipLaunchKernelGGL(pack_train_image_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W1, W2, W3, Bas, (unsigned char *)image);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
+                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, const void *image, hipStream_t stream)
+{
+    hipError_t rc = hipFuncSetAttribute((const void *)mlp_train_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TI_LDS_BYTES);
+    if (rc != hipSuccess) return rc;
+    MlpBwdArgs a;
+    a.grad_rgb = grad_rgb; a.rgb = rgb; a.feats = feats; a.h1 = h1; a.h2 = h2; a.m = m; a.gscale = gscale;
+    a.d_out = d_out; a.dh2 = dh2; a.dh1 = dh1; a.dfeats = dfeats; a.image = (const unsigned char *)image;
+    const long long groups = (m + 32 * MT_WAVES - 1) / (32 * MT_WAVES);
+    unsigned grid = groups < 256 ? (unsigned)(groups > 0 ? groups : 1) : 256u;
+    hipLaunchKernelGGL(mlp_train_backward_kernel, dim3(grid), dim3(MT_THREADS), TI_LDS_BYTES, stream, a);
+    rc = hipGetLastError();
+    if (rc != hipSuccess) return rc;
+    const long long g2 = (m + 127) / 128;
+    hipLaunchKernelGGL(basis_backward_kernel, dim3((unsigned)(g2 < 1024 ? (g2 > 0 ? g2 : 1) : 1024)), dim3(256), 0, stream, dfeats, m, gscale, (const unsigned char *)image, dh);
+    return hipGetLastError();
+}

@@ -32,9 +32,8 @@
 #include <cstdlib>
 #include "tvr_device.h"
 #include "tvr_kernels.h"
+#include "tvr_mfma.h"       // split2 / split8 / Frag / relu_f: the fp16 hi/lo split idioms shared with tvr_bg.hip, tvr_ngp.hip, tvr_mlp_train.hip
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define TVR_SB __builtin_amdgcn_sched_barrier(0)
@@ -67,9 +66,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SH_TILE 32
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
-// relu as ONE VALU op: integer max on the bit pattern (negative floats, -0.0 included, are negative integers).  fmaxf(x, 0) costs
-// two v_max_f32 (hipcc canonicalises the operand first)
-__device__ __forceinline__ float relu_f(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 #ifndef TVR_NOPK
 #define TVR_NOPK 1        // 1: plain v_fma_f32 / v_mul_f32 instead of the packed-fp32 forms.  Twice the instructions and faster (14.5 vs 14.8 ms):
 #endif                    //    a packed op costs more than two plain ones beside the partner wave's MFMAs (cdna guide, cycle constants)
@@ -95,37 +91,6 @@ __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
 #endif
-
-// fp32 pair -> packed fp16 hi and lo words (x = hi + lo up to ~2^-22 |x|; round-toward-zero never overflows to inf)
-__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
-{
-    const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    // x - hi as fma(hi, -1, x): one v_fma_mix_f32 reading the packed half in place (exact: the product by -1 is exact); hipcc
-    // does not select the mixed-precision form by itself (it emits v_cvt_f32_f16 + v_sub), hence the asm.  Its results feed the
-    // compiler-visible v_cvt_pkrtz below, never an MFMA directly: a VALU write needs one wait state before an MFMA reads it
-    // (scripts/hwprobe/mfma_raw2.hip; hipcc pads its own code with two, but not inline asm).
-    const unsigned hb = __builtin_bit_cast(unsigned, h);
-    float ra, rb;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hb), "v"(b));
-    const auto l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
-    hi = hb;
-    lo = __builtin_bit_cast(unsigned, l);
-}
-
-struct Frag {   // one 8-element fp16 operand fragment, hi and lo parts
-    uint4 hi, lo;
-};
-
-__device__ __forceinline__ Frag split8(const float v[8])
-{
-    Frag f;
-    split2(v[0], v[1], f.hi.x, f.lo.x);
-    split2(v[2], v[3], f.hi.y, f.lo.y);
-    split2(v[4], v[5], f.hi.z, f.lo.z);
-    split2(v[6], v[7], f.hi.w, f.lo.w);
-    return f;
-}
 
 // A fragments (hi, lo) of the four 32-row blocks of one k-step, from the LDS weight image
 struct AFrag4 { uint4 h[4], l[4]; };
@@ -247,8 +212,6 @@ __device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, fl
     }
 }
 
-// accumulator register r of lane half h  <->  row of the 32x32 tile
-__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // sine / cosine for the positional encoding: v_sin_f32 / v_cos_f32 (they take revolutions) behind a two-term Cody-Waite reduction
 // x - k*2pi, 7 instructions per pair and no branch (a branch per value kept hipcc from interleaving layer 1's VALU work with its MFMAs).
@@ -301,6 +264,8 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
             const float4 w0 = w[rb & 1][q * 3], w1 = w[rb & 1][q * 3 + 1], w2 = w[rb & 1][q * 3 + 2];
             const f32x2 xa = {relu_f(c.acc2[rb][4 * q]), relu_f(c.acc2[rb][4 * q + 1])};
             const f32x2 xb = {relu_f(c.acc2[rb][4 * q + 2]), relu_f(c.acc2[rb][4 * q + 3])};
+            if (DST == SH_DST_TRAIN && c.live)           // relu(layer 2), hidden units 32 rb + 8 q + 4 h .. + 3: the backward's mask and dW3's operand
+                *(float4 *)(a.t_h2 + c.ent * TVR_FEATC + 32 * rb + 8 * q + 4 * h) = make_float4(xa.x, xa.y, xb.x, xb.y);
             s0 = pk_fma(xa, f32x2{w0.x, w0.y}, s0); s0 = pk_fma(xb, f32x2{w0.z, w0.w}, s0);
             s1 = pk_fma(xa, f32x2{w1.x, w1.y}, s1); s1 = pk_fma(xb, f32x2{w1.z, w1.w}, s1);
             s2 = pk_fma(xa, f32x2{w2.x, w2.y}, s2); s2 = pk_fma(xb, f32x2{w2.z, w2.w}, s2);
@@ -403,7 +368,46 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             TVR_SB;
         }
         TVR_STAMP(tgF);
-        if (SRC != SH_SRC_FEAT) {
+        if (SRC == SH_SRC_H) {
+            // training forward: h [n,144] comes from tvr_app_h_forward; this lane's 8 channels of each k-step are 32 contiguous bytes
+            Frag hf[9];
+            uint4 bah[9], bal[9];
+            if (live) { dir[0] = a.viewdirs[ent * 3]; dir[1] = a.viewdirs[ent * 3 + 1]; dir[2] = a.viewdirs[ent * 3 + 2]; }
+            {
+                const long long le = live ? ent : n_total - 1;
+                const float4 *hp = (const float4 *)(a.h_in + le * TVR_KAPP) + 2 * h;
+                float4 hv4[9][2];
+#pragma unroll
+                for (int s = 0; s < 9; ++s) { hv4[s][0] = hp[4 * s]; hv4[s][1] = hp[4 * s + 1]; }
+                unsigned boff = (unsigned)((h * 32 + e) * 32);
+                asm volatile("" : "+v"(boff));
+#pragma unroll
+                for (int s3 = 0; s3 < 9; ++s3) {
+                    const uint4 *ap = (const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 2048)));
+                    bah[s3] = ap[0];
+                    bal[s3] = ap[1];
+                }
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    const float hv[8] = {hv4[s][0].x, hv4[s][0].y, hv4[s][0].z, hv4[s][0].w, hv4[s][1].x, hv4[s][1].y, hv4[s][1].z, hv4[s][1].w};
+                    hf[s] = split8(hv);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TVR_SB;
+            TVR_STAMP(tg1);
+            __builtin_amdgcn_s_setprio(TVR_PRIO_M);
+            f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const h8 Ah = __builtin_bit_cast(h8, bah[s]), Al = __builtin_bit_cast(h8, bal[s]);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);
+                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) F[r] = (accA[r] + accB[r]) + accC[r];
+        } else if (SRC != SH_SRC_FEAT) {
             float pn[3] = {0.f, 0.f, 0.f};
             if (SRC == SH_SRC_QUEUE) {
                 pn[0] = qe.x; pn[1] = qe.y; pn[2] = qe.z; wq = qe.w;
@@ -534,6 +538,11 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         }
 
         TVR_STAMP(tg2);
+        if (DST == SH_DST_TRAIN && live) {           // features [n,32]: rows 27..31 are zero (zero basis rows)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4 *)(a.t_feats + ent * 32 + 8 * q + 4 * h) = make_float4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3]);
+        }
         // view direction occupies base rows 27 (h=0, r=15), 28, 29 (h=1, r=12, 13); row 30 = REF's -dot, row 31 = the constant 1 (b1's column)
         if (REF && SRC != SH_SRC_FEAT) {
             // REFTensoRF.execute :215-227: normalise the normal, d = -view, dot = d.n, reflection = 2 dot n - d; the MLP
@@ -600,6 +609,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = relu_f(acc[s >> 1][8 * (s & 1) + j]);
+                if (DST == SH_DST_TRAIN && live) {   // relu(layer 1): element j is hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3)
+                    *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 8 + 4 * h) = make_float4(v[4], v[5], v[6], v[7]);
+                }
                 b = split8(v);
             };
             Frag bcur, bnxt;
@@ -668,6 +681,7 @@ hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a
     if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false>(sc, a, stream);
     if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, false>(sc, a, stream);
     if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false>(sc, a, stream);
+    if (src == SH_SRC_H && dst == SH_DST_TRAIN) return launch_shade_t<SH_SRC_H, SH_DST_TRAIN, false>(sc, a, stream);
     return hipErrorInvalidValue;
 }
 
@@ -692,17 +706,6 @@ hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, h
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(pack_plane_kernel, dim3(grid), dim3(256), 0, stream, in, out, C, H, W, Wp);
     return hipGetLastError();
-}
-
-// reference input index (tensorBase.py:77-82 concat order) of derived value t of base value c; -1 = zero weight
-__device__ __forceinline__ int ref_in_index(int c, int t)
-{
-    if (c < TVR_APPDIM) return t == 0 ? c : (t == 1 ? 30 + 2 * c : (t == 2 ? 31 + 2 * c : (t == 3 ? 84 + 2 * c : 85 + 2 * c)));
-    if (c < TVR_APPDIM + 3) {
-        const int d = c - TVR_APPDIM;
-        return t == 0 ? 27 + d : (t == 1 ? 138 + 2 * d : (t == 2 ? 139 + 2 * d : (t == 3 ? 144 + 2 * d : 145 + 2 * d)));
-    }
-    return -1;
 }
 
 // MLP weights -> fp16 hi/lo operand images.  One thread per (row, k position).

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .autograd_ops import _AppHFn, _MarchFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
+from .autograd_ops import _MlpTrainFn, _AppHFn, _MarchFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
 
 
 class AlphaGridMask:
@@ -344,12 +344,29 @@ class TensorBase(torch.nn.Module):
         eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
         w, acc, xyz, ray_id, depth, _ = _MarchFn.apply(self, rays, jitter, S, eps_T, None, *self.density_plane, *self.density_line)
         h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
-        feats = _linear(self.basis_mat, h)                                                    # tensoRF.py:244
-        rgb = self.renderModule.forward_autograd(rays[ray_id, 3:6], feats)                    # tensorBase.py:517
+        rgb = self._shade_autograd(h, rays[ray_id, 3:6])                                      # tensoRF.py:244 + tensorBase.py:517
         rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)   # :521
         if white_bg:
             rgb_map = rgb_map + (1.0 - acc[:, None])                                          # :524
         return rgb_map.clamp(0, 1), depth                                                     # :527 (depth under no_grad, :529-531)
+
+    fused_mlp_training = True     # False: basis_mat + MLP as library GEMMs under autograd (the round-1 path; kept for A/B and as a second opinion in tests)
+
+    def _shade_autograd(self, h, viewdirs):
+        """basis_mat (tensoRF.py:244) + MLPRender_Fea.execute (tensorBase.py:76-86) on the appearance samples, under autograd.  TensorVMSplit
+        scenes in the shape the shade kernel is built for go through the fused kernels (_MlpTrainFn); anything else through _LinearFn."""
+        rm = self.renderModule
+        if (self.fused_mlp_training and type(rm) is MLPRender_Fea and h.is_cuda and h.shape[0] > 0 and getattr(self, "_variant", 0) == 0
+                and self.app_dim == 27 and rm.feape == 2 and rm.viewpe == 2 and rm.mlp[0].out_features == 128 and h.shape[0] * 576 < (1 << 32)):
+            m = rm.mlp
+            return _MlpTrainFn.apply(self, h, viewdirs, self.basis_mat.weight, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
+        return rm.forward_autograd(viewdirs, _linear(self.basis_mat, h))
+
+    def _get_train_image(self) -> torch.Tensor:
+        nbytes = L.lib().tvr_mlp_train_image_bytes()
+        if getattr(self, "_train_image", None) is None or self._train_image.numel() < nbytes:
+            self._train_image = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._train_image
 
     def _get_scratch(self, nbytes: int) -> torch.Tensor:
         if self._scratch is None or self._scratch.numel() < nbytes:

@@ -19,20 +19,24 @@ def report():
     import isa_check
     if not os.path.exists(LIB):
         g.build()
-    return isa_check.audit(LIB, "shade_kernel")
+    rep = isa_check.audit(LIB, "shade_kernel")
+    rep.update(isa_check.audit(LIB, "mlp_train_backward_kernel"))
+    rep.update(isa_check.audit(LIB, "basis_backward_kernel"))
+    return rep
 
 
 def test_every_shade_kernel_variant_is_audited(report):
-    assert len(report) == 6                     # {queue, xyz->features, features->rgb} x {TensorVMSplit, REFTensoRF}
+    # {queue, xyz->features, features->rgb} x {TensorVMSplit, REFTensoRF} + the training forward (h -> rgb + activations) + the two backward kernels
+    assert len(report) == 9
     assert all(v["mfma"] >= 27 for v in report.values())
 
 
-def test_vmcnt_accounting_of_shade_kernels(report):
+def test_vmcnt_accounting_of_mfma_kernels(report):
     for name, v in report.items():
         assert v["raw_violations_fallthrough"] == 0 and v["raw_violations_execz_taken"] == 0, (name, v["examples"]["raw"])
 
 
-def test_phase_rule_of_shade_kernels(report):
+def test_phase_rule_of_mfma_kernels(report):
     for name, v in report.items():
         assert v["vmem_loads_between_first_and_last_mfma"] == 0, f"{name}: a global (or spill) load sits between the MFMAs of a tile"
         assert v["war_adjacent"] == 0, (name, v["examples"]["war"])
