@@ -294,13 +294,8 @@ class _MlpTrainFn(torch.autograd.Function):
             gW2 = tn(dh2, 128, 128, h1, 128, 128)
             gW1 = tn(dh1, 128, 128, X, 150, 150)
             gB = tn(dfe, 32, 27, h, 144, 144)
-            ones = _ONES.get((dev, m))
-            if ones is None:
-                _ONES.clear()
-                ones = _ONES[(dev, m)] = torch.ones(m, dtype=torch.float32, device=dev)
-            gb3 = tn(d_out, 4, 3, ones, 1, 1).view(-1)
-            gb2 = tn(dh2, 128, 128, ones, 1, 1).view(-1)
-            gb1 = tn(dh1, 128, 128, ones, 1, 1).view(-1)
+            # bias gradients = column sums: torch's column reduction takes 0.1 ms at M ~ 3.5e5 (a gemm_tn pass over the same matrix 0.25 ms)
+            gb3, gb2, gb1 = d_out[:, :3].sum(0), dh2.sum(0), dh1.sum(0)
         else:                                          # tiny batches (tests): the reductions as plain torch products
             gW3, gW2, gW1, gB = d_out[:, :3].t() @ h2, dh2.t() @ h1, dh1.t() @ X, dfe[:, :27].t() @ h
             gb3, gb2, gb1 = d_out[:, :3].sum(0), dh2.sum(0), dh1.sum(0)

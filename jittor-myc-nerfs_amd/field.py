@@ -10,8 +10,9 @@ place of jt.Var.  Parameters stay in the reference layout ((1,C,H,W) planes, (1,
 the Python-visible truth; a packed channels-last device copy is refreshed automatically when they change.
 
 There is NO CPU fallback: every compute call goes through the C-ABI and raises if the HIP library is missing.
-Scope this round: shadingMode 'MLP_Fea', ndc_ray=False.  Inference runs entirely in the fused HIP kernels; under autograd
-(training, train.py:225-261) the march and the VM gathers run as HIP kernels forward and backward and the small MLP as library GEMMs.
+Scope: shadingMode 'MLP_Fea', ndc_ray=False.  Inference runs entirely in the fused HIP kernels; under autograd (training,
+train.py:225-261) the march, the VM gathers and — for TensorVMSplit — basis_mat + the MLP run as HIP kernels forward and backward
+(tvr_mlp_train_forward = the inference shade kernel, tvr_mlp_train_backward; weight gradients by tvr_gemm_tn): no library GEMM in the step.
 """
 from __future__ import annotations
 
@@ -338,7 +339,7 @@ class TensorBase(torch.nn.Module):
 
     def render_rays_autograd(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None):
         """TensorBase.execute with gradients (train.py:225-261): HIP march / VM-gather kernels forward and backward, the 144->27
-        basis + PE + MLP as library GEMMs under torch autograd, compositing as an index_add over the appearance-sample queue."""
+        basis + PE + MLP through `_shade_autograd` (fused kernels), compositing as an index_add over the appearance-sample queue."""
         rays = _f32c(rays_chunk, self.device)
         S = int(N_samples) if N_samples > 0 else self.nSamples
         eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
@@ -629,7 +630,9 @@ class TensorVMSplit(TensorBase):
         for idx in range(len(vector_comps)):
             n_comp, n_size = vector_comps[idx].shape[1:-1]
             v = vector_comps[idx].view(n_comp, n_size)
-            dotp = torch.matmul(v, v.transpose(-1, -2))
+            # the n_comp x n_comp Gram matrix of the line factors (tensoRF.py:183 `jt.matmul`), as a broadcast product + row sums: at 16 / 48 x ~300
+            # a library GEMM launch (plus two in the backward) costs more than the arithmetic, and the step then runs no library GEMM at all
+            dotp = (v.unsqueeze(1) * v.unsqueeze(0)).sum(-1)
             non_diagonal = dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]
             total = total + torch.mean(torch.abs(non_diagonal))
         return total

@@ -13,6 +13,7 @@ if world > 1:
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist.init_process_group(os.environ.get("TVR_BENCH_BACKEND", "nccl"))
 m, arrs, A = bench.build_model(torch.device("cuda"))
+m.fused_mlp_training = bool(int(os.environ.get("TVR_FUSED_MLP", "1")))      # 0: round-1 path (library GEMMs for the MLP forward / dX)
 with torch.no_grad():                                  # start from a perturbed copy so that gradients are non-trivial
     for p in m.parameters():
         p.mul_(0.9)
