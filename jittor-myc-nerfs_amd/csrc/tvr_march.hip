@@ -29,6 +29,11 @@
 #endif
 #define MARCH_MAX_WAVES 16
 #define MARCH_TILE 16                     // rays per tile
+#ifndef MARCH_LSTRIDE
+#define MARCH_LSTRIDE 4                   // float4 per line texel in LDS.  4 = packed; 5 (80 B: the texels of 16 consecutive cells in distinct banks) removes
+#endif                                    // the line taps' bank conflicts (34 % of the LDS-active cycles) and measures SLOWER: 8.2 vs 8.0 ms — the kernel sits on the L1 path
+#if 0
+#endif
 
 // quad-level data movement as DPP VALU ops (quad_perm) instead of ds_bpermute: no LDS hop in front of the gather addresses
 template <int CTRL>
@@ -64,8 +69,8 @@ __device__ __forceinline__ float4 vm_term_lds(const float4 *__restrict__ P, cons
     const int Wp = W + 1;
     const float4 *p = P + ((size_t)y0 * Wp + x0) * 4 + sub;
     const float4 t00 = p[0], t01 = p[4], t10 = p[(size_t)Wp * 4], t11 = p[(size_t)Wp * 4 + 4];
-    const float4 *q = Ls + l0 * 4 + sub;
-    const float4 l0v = q[0], l1v = q[4];
+    const float4 *q = Ls + l0 * MARCH_LSTRIDE + sub;
+    const float4 l0v = q[0], l1v = q[MARCH_LSTRIDE];
     float4 p4 = f4_mul(ux * uy, t00);
     p4 = f4_fma(wx * uy, t01, p4);
     p4 = f4_fma(ux * wy, t10, p4);
@@ -88,16 +93,16 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
     const int n_waves = blockDim.x >> 6;
     unsigned *cursor = (unsigned *)lds_raw;
     const float4 *ls0 = (const float4 *)(lds_raw + 16);
-    const int ln0 = LDSL ? (sc.grid[2] + 1) * 4 : 0, ln1 = LDSL ? (sc.grid[1] + 1) * 4 : 0, ln2 = LDSL ? (sc.grid[0] + 1) * 4 : 0;
+    const int ln0 = LDSL ? (sc.grid[2] + 1) * MARCH_LSTRIDE : 0, ln1 = LDSL ? (sc.grid[1] + 1) * MARCH_LSTRIDE : 0, ln2 = LDSL ? (sc.grid[0] + 1) * MARCH_LSTRIDE : 0;
     const float4 *ls1 = ls0 + ln0, *ls2 = ls1 + ln1;                     // line i runs along axis vecMode[i] = 2 - i
     float *bufw = (float *)(ls2 + ln2) + (size_t)wave * s_cap;
     unsigned short *bufj = (unsigned short *)((float *)(ls2 + ln2) + (size_t)n_waves * s_cap) + (size_t)wave * s_cap;
     if (threadIdx.x == 0) *cursor = 0u;
     if (LDSL) {
         float4 *dst = (float4 *)(lds_raw + 16);
-        for (int i = threadIdx.x; i < ln0; i += blockDim.x) dst[i] = sc.dline[0][i];
-        for (int i = threadIdx.x; i < ln1; i += blockDim.x) dst[ln0 + i] = sc.dline[1][i];
-        for (int i = threadIdx.x; i < ln2; i += blockDim.x) dst[ln0 + ln1 + i] = sc.dline[2][i];
+        for (int i = threadIdx.x; i < (sc.grid[2] + 1) * 4; i += blockDim.x) dst[(i >> 2) * MARCH_LSTRIDE + (i & 3)] = sc.dline[0][i];
+        for (int i = threadIdx.x; i < (sc.grid[1] + 1) * 4; i += blockDim.x) dst[ln0 + (i >> 2) * MARCH_LSTRIDE + (i & 3)] = sc.dline[1][i];
+        for (int i = threadIdx.x; i < (sc.grid[0] + 1) * 4; i += blockDim.x) dst[ln0 + ln1 + (i >> 2) * MARCH_LSTRIDE + (i & 3)] = sc.dline[2][i];
     }
     __syncthreads();
     const int sub = lane & 3;
@@ -461,7 +466,7 @@ hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S
                         const MarchOut &mo, const tvr_dense_out *dense, hipStream_t stream)
 {
     // LDS budget: the density lines (if they fit next to at least 4 waves' lists) + 6 B per sample and wave for the appearance lists
-    const size_t kLds = 160 * 1024, line_bytes = ((size_t)sc.grid[0] + sc.grid[1] + sc.grid[2] + 3) * 64, per_wave = (size_t)S * 6;
+    const size_t kLds = 160 * 1024, line_bytes = ((size_t)sc.grid[0] + sc.grid[1] + sc.grid[2] + 3) * 16 * MARCH_LSTRIDE, per_wave = (size_t)S * 6;
     bool ldsl = 16 + line_bytes + 4 * per_wave + 64 <= kLds;
     const size_t fixed = 16 + (ldsl ? line_bytes : 0) + 64;
     int waves = (int)((kLds - fixed) / per_wave);
