@@ -32,8 +32,6 @@
 #ifndef MARCH_LSTRIDE
 #define MARCH_LSTRIDE 4                   // float4 per line texel in LDS.  4 = packed; 5 (80 B: the texels of 16 consecutive cells in distinct banks) removes
 #endif                                    // the line taps' bank conflicts (34 % of the LDS-active cycles) and measures SLOWER: 8.2 vs 8.0 ms — the kernel sits on the L1 path
-#if 0
-#endif
 
 // quad-level data movement as DPP VALU ops (quad_perm) instead of ds_bpermute: no LDS hop in front of the gather addresses
 template <int CTRL>
