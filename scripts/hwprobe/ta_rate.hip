@@ -6,6 +6,9 @@
 //   quad     lanes 4g..4g+3 read one 64-B segment of a random texel            (16 segments per load: the march kernel's shape)
 //   pair     lanes l and l+32 read two 16-B pieces of a random 64-B segment    (32 segments per load: the shade kernel's shape)
 //   lane     every lane its own random 16 B                                    (64 segments per load)
+//   padj     as pair, but the two lanes read ADJACENT 16-B pieces (one 32-B sector)
+//   s32      16 B per lane at a stride of 32 B (2 x 1 KB regions per load: the shape of the round-1 basis-fragment layout)
+//   cont     one contiguous, aligned 1 KB per load
 // Table sizes: 16 KB (L1-resident), 16 MB (L2-resident across the chip), 64 MB (Infinity Cache).
 // Build: hipcc --offload-arch=gfx950 -O2 ta_rate.hip -o ta_rate_probe
 #include <hip/hip_runtime.h>
@@ -31,7 +34,10 @@ __global__ __launch_bounds__(1024) void probe(const float4 *__restrict__ tab, un
             if (PAT == 0) { seg = hash32(key) % n_seg; piece = 0; }
             else if (PAT == 1) { seg = hash32(key * 16u + (lane >> 2)) % n_seg; piece = lane & 3u; }
             else if (PAT == 2) { seg = hash32(key * 32u + (lane & 31u)) % n_seg; piece = (lane >> 5) * 2u; }
-            else { seg = hash32(key * 64u + lane) % n_seg; piece = lane & 3u; }
+            else if (PAT == 3) { seg = hash32(key * 64u + lane) % n_seg; piece = lane & 3u; }
+            else if (PAT == 4) { seg = hash32(key * 32u + (lane & 31u)) % n_seg; piece = lane >> 5; }                       // pair, ADJACENT pieces 0 and 1
+            else if (PAT == 5) { seg = (hash32(key) % (n_seg / 64u)) * 64u + (lane >> 5) * 16u + ((lane & 31u) >> 1); piece = (lane & 1u) * 2u; }   // 16 B at stride 32 B
+            else { seg = (hash32(key) % (n_seg / 16u)) * 16u + (lane >> 2); piece = lane & 3u; }                             // one contiguous 1 KB
             v[i] = tab[seg * 4u + piece];
         }
 #pragma unroll
@@ -64,11 +70,14 @@ int main()
     hipMalloc(&out, 64); hipMalloc(&cyc, 256 * 8); hipMalloc(&tab, maxb);
     hipMemset(tab, 0, maxb);
     for (size_t bytes : {(size_t)16384, (size_t)16 << 20, (size_t)64 << 20})
-        for (int waves : {4, 8, 16}) {
+        for (int waves : {8, 16}) {
             run<0>("same", tab, bytes, waves, out, cyc);
             run<1>("quad", tab, bytes, waves, out, cyc);
             run<2>("pair", tab, bytes, waves, out, cyc);
             run<3>("lane", tab, bytes, waves, out, cyc);
+            run<4>("padj", tab, bytes, waves, out, cyc);
+            run<5>("s32", tab, bytes, waves, out, cyc);
+            run<6>("cont", tab, bytes, waves, out, cyc);
         }
     return 0;
 }
