@@ -272,7 +272,7 @@ static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     mo.lam6 = lam6_out;
 
     hipEvent_t *ev = prof ? &prof->ev[(size_t)prof->n_calls * 4] : nullptr;
-    HIP_TRY(hipMemsetAsync(mo.counter, 0, 4, stream));
+    HIP_TRY(hipMemsetAsync(mo.counter, 0, 8, stream));                 // [0] queue length, [1] the march's tile counter
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, dense, stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
@@ -369,7 +369,7 @@ static int march_forward_impl(tvr_scene *s, const float *rays, int64_t n_rays, i
     hipStream_t stream = (hipStream_t)stream_;
     MarchOut mo = carve_scratch((char *)scratch, L, depth_out);
     mo.lam6 = lam6_out;
-    HIP_TRY(hipMemsetAsync(mo.counter, 0, 4, stream));
+    HIP_TRY(hipMemsetAsync(mo.counter, 0, 8, stream));                 // [0] queue length, [1] the march's tile counter
     HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, nullptr, stream));
     return TVR_OK;
 }

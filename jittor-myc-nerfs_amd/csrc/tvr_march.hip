@@ -29,6 +29,10 @@
 #endif
 #define MARCH_MAX_WAVES 16
 #define MARCH_TILE 16                     // rays per tile
+#define MARCH_HDR 272                     // LDS header: ray cursor (16 B) + 32 slots of {local tile number + 1, global tile} (dynamic tile queue)
+#ifndef TVR_MARCH_DYN
+#define TVR_MARCH_DYN 1                   // 1: workgroups take 16-ray tiles from ONE global counter (in order), not a fixed stride: no tail when a launch has few tiles per group
+#endif
 #ifndef MARCH_LSTRIDE
 #define MARCH_LSTRIDE 4                   // float4 per line texel in LDS.  4 = packed; 5 (80 B: the texels of 16 consecutive cells in distinct banks) removes
 #endif                                    // the line taps' bank conflicts (34 % of the LDS-active cycles) and measures SLOWER: 8.2 vs 8.0 ms — the kernel sits on the L1 path
@@ -90,14 +94,16 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_waves = blockDim.x >> 6;
     unsigned *cursor = (unsigned *)lds_raw;
-    const float4 *ls0 = (const float4 *)(lds_raw + 16);
+    const float4 *ls0 = (const float4 *)(lds_raw + MARCH_HDR);
     const int ln0 = LDSL ? (sc.grid[2] + 1) * MARCH_LSTRIDE : 0, ln1 = LDSL ? (sc.grid[1] + 1) * MARCH_LSTRIDE : 0, ln2 = LDSL ? (sc.grid[0] + 1) * MARCH_LSTRIDE : 0;
     const float4 *ls1 = ls0 + ln0, *ls2 = ls1 + ln1;                     // line i runs along axis vecMode[i] = 2 - i
     float *bufw = (float *)(ls2 + ln2) + (size_t)wave * s_cap;
     unsigned short *bufj = (unsigned short *)((float *)(ls2 + ln2) + (size_t)n_waves * s_cap) + (size_t)wave * s_cap;
     if (threadIdx.x == 0) *cursor = 0u;
+    unsigned long long *slots = (unsigned long long *)(lds_raw + 16);
+    if (threadIdx.x < 32) slots[threadIdx.x] = 0ull;
     if (LDSL) {
-        float4 *dst = (float4 *)(lds_raw + 16);
+        float4 *dst = (float4 *)(lds_raw + MARCH_HDR);
         for (int i = threadIdx.x; i < (sc.grid[2] + 1) * 4; i += blockDim.x) dst[(i >> 2) * MARCH_LSTRIDE + (i & 3)] = sc.dline[0][i];
         for (int i = threadIdx.x; i < (sc.grid[1] + 1) * 4; i += blockDim.x) dst[ln0 + (i >> 2) * MARCH_LSTRIDE + (i & 3)] = sc.dline[1][i];
         for (int i = threadIdx.x; i < (sc.grid[0] + 1) * 4; i += blockDim.x) dst[ln0 + ln1 + (i >> 2) * MARCH_LSTRIDE + (i & 3)] = sc.dline[2][i];
@@ -119,7 +125,30 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
         unsigned ci = 0;
         if (lane == 0) ci = atomicAdd(cursor, 1u);
         ci = __builtin_amdgcn_readfirstlane(ci);
-#if TVR_MARCH_RASTER
+#if TVR_MARCH_DYN
+        // the wave that draws the first ray of local tile k takes the next global tile and publishes it; the others wait for the slot
+        // (32 slots: a waiter would have to fall 512 rays behind the cursor to see its slot reused)
+        int tile;
+        {
+            const unsigned k = ci / MARCH_TILE, slot = k & 31u;
+            if ((ci % MARCH_TILE) == 0u) {
+                unsigned t = 0;
+                if (lane == 0) {
+                    t = atomicAdd(mo.counter + 1, 1u);
+                    __hip_atomic_store(&slots[slot], ((unsigned long long)(k + 1u) << 32) | t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                tile = (int)__builtin_amdgcn_readfirstlane(t);
+            } else {
+                unsigned long long v;
+                do {
+                    v = __hip_atomic_load(&slots[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((unsigned)(v >> 32) != k + 1u) __builtin_amdgcn_s_sleep(1);
+                } while ((unsigned)(v >> 32) != k + 1u);
+                tile = (int)(unsigned)v;
+            }
+        }
+        if (tile >= n_tiles) break;
+#elif TVR_MARCH_RASTER
         const int tile = (int)(ci / MARCH_TILE) * (int)gridDim.x + (int)blockIdx.x;     // all groups sweep the image together
         if (tile >= n_tiles) break;
 #else
@@ -465,8 +494,8 @@ hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S
 {
     // LDS budget: the density lines (if they fit next to at least 4 waves' lists) + 6 B per sample and wave for the appearance lists
     const size_t kLds = 160 * 1024, line_bytes = ((size_t)sc.grid[0] + sc.grid[1] + sc.grid[2] + 3) * 16 * MARCH_LSTRIDE, per_wave = (size_t)S * 6;
-    bool ldsl = 16 + line_bytes + 4 * per_wave + 64 <= kLds;
-    const size_t fixed = 16 + (ldsl ? line_bytes : 0) + 64;
+    bool ldsl = MARCH_HDR + line_bytes + 4 * per_wave + 64 <= kLds;
+    const size_t fixed = MARCH_HDR + (ldsl ? line_bytes : 0) + 64;
     int waves = (int)((kLds - fixed) / per_wave);
     waves = waves >= 16 ? 16 : (waves >= 12 ? 12 : (waves >= 8 ? 8 : (waves >= 4 ? 4 : (waves >= 2 ? 2 : 1))));
     const size_t lds = fixed + (size_t)waves * per_wave;

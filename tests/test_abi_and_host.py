@@ -294,3 +294,24 @@ def test_renderer_merges_inference_chunks_but_not_training_batches():
     with torch.no_grad():
         OctreeRender_trilinear_fast(torch.zeros(3_000_000, 6), Fake(), chunk=1024, N_samples=1036, device="cpu")
     assert len(calls) > 1 and max(calls) * 1036 * 40 <= 16 << 30 and sum(calls) == 3_000_000
+
+
+def test_checkpoint_reader_refuses_code_and_reads_arrays(tmp_path):
+    """load_checkpoint: a `.th` file is a pickle of numpy arrays and builtin containers (jt.save); anything that would import code is refused."""
+    import pickle
+    import numpy as np
+    from jittor_myc_nerfs_amd.field import load_checkpoint
+    good = {"kwargs": {"aabb": np.zeros((2, 3), np.float32), "gridSize": [3, 4, 5]}, "state_dict": {"w": np.arange(6, dtype=np.float32).reshape(2, 3)},
+            "global_step": 7, "lr": np.float32(0.02), "alphaMask.mask": np.packbits(np.ones(8, bool))}
+    p = tmp_path / "good.th"
+    pickle.dump(good, open(p, "wb"))
+    d = load_checkpoint(str(p))
+    assert d["global_step"] == 7 and np.array_equal(d["state_dict"]["w"], good["state_dict"]["w"]) and d["alphaMask.mask"].dtype == np.uint8
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    q = tmp_path / "evil.th"
+    pickle.dump({"state_dict": Evil()}, open(q, "wb"))
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint(str(q))

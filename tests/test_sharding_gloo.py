@@ -122,3 +122,16 @@ def test_bench_step_world2_on_one_card(scaling, tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["check"] == "gathered == single-rank render, bit for bit"
     assert d["config"]["rays_per_step"] == (96 * 96 * (2 if scaling == "weak" else 1))
+
+
+def test_shard_gather_index_is_the_inverse_of_the_tile_interleave():
+    """CPU: image[i] = gathered[inv[i]] for every (rays, world, tile) — ragged last tiles, more ranks than tiles, one rank."""
+    from jittor_myc_nerfs_amd import shard_capacity, shard_gather_index, shard_indices
+    for R, w, t in [(77, 2, 16), (640000, 8, 4096), (640000, 3, 4096), (5, 4, 16), (4096 * 8, 8, 4096), (100, 1, 16), (1, 2, 4096)]:
+        cap = shard_capacity(R, w, t)
+        g = torch.full((w * cap,), -1, dtype=torch.long)
+        for r in range(w):
+            idx = shard_indices(R, r, w, t)
+            assert idx.numel() <= cap
+            g[r * cap:r * cap + idx.numel()] = idx
+        assert torch.equal(g[shard_gather_index(R, w, t)], torch.arange(R)), (R, w, t)
