@@ -55,6 +55,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef TVR_DEFER
 #define TVR_DEFER 1     // 1: layer 3 + epilogue of a tile run in the next tile's gather phase; 0: at the end of its own matrix phase
 #endif
+#ifndef TVR_APF
+#define TVR_APF 1         // 1: the weight fragments of hidden-layer k-step s + 1 are fetched from LDS during step s (32 more live registers);
+                          //    0 measured 15.2 vs 14.8 ms (and still no room for a tap ring of depth 2: one spill, 15.7)
+#endif
 #ifndef TVR_STAGGER
 #define TVR_STAGGER 1     // the two waves of a SIMD (w and w + 4) run the same program: the second starts half a tile late so that one
 #endif                    // gathers while the other multiplies (MI355X_MICROARCH 'Two waves per SIMD', item 9)
@@ -580,15 +584,21 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             Frag bcur, bnxt;
             AFrag4 acur, anxt;
             l1_frag(0, bcur);
+#if TVR_APF
             load_afrag4(acur, W1H, W1L, rowoff, 32 * TVR_IMG_W1_ROW);
+#endif
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
-                if (s + 1 < 10) {
-                    load_afrag4(anxt, W1H, W1L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W1_ROW);
-                    l1_frag(s + 1, bnxt);
-                }
+#if TVR_APF
+                if (s + 1 < 10) load_afrag4(anxt, W1H, W1L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W1_ROW);
+#else
+                load_afrag4(acur, W1H, W1L, rowoff + s * 32, 32 * TVR_IMG_W1_ROW);
+#endif
+                if (s + 1 < 10) l1_frag(s + 1, bnxt);
                 mfma3x4(acur, bcur, acc);
+#if TVR_APF
                 acur = anxt;
+#endif
                 bcur = bnxt;
                 TVR_SB;
             }
@@ -618,15 +628,21 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             Frag bcur, bnxt;
             AFrag4 acur, anxt;
             relu_frag(0, bcur);
+#if TVR_APF
             load_afrag4(acur, W2H, W2L, rowoff, 32 * TVR_IMG_W2_ROW);
+#endif
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                if (s + 1 < 8) {
-                    load_afrag4(anxt, W2H, W2L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W2_ROW);
-                    relu_frag(s + 1, bnxt);
-                }
+#if TVR_APF
+                if (s + 1 < 8) load_afrag4(anxt, W2H, W2L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W2_ROW);
+#else
+                load_afrag4(acur, W2H, W2L, rowoff + s * 32, 32 * TVR_IMG_W2_ROW);
+#endif
+                if (s + 1 < 8) relu_frag(s + 1, bnxt);
                 mfma3x4(acur, bcur, cur.acc2);
+#if TVR_APF
                 acur = anxt;
+#endif
                 bcur = bnxt;
                 TVR_SB;
             }
