@@ -163,7 +163,7 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
     HIP_TRY(hipMemsetAsync(img + TVR_IMG_B1, 0, TVR_FEATC * sizeof(float), stream));
     HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B2, p->b2, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(launch_pack_mlp(p->basis_mat, nullptr, s->packed + s->lay.basis_frag, nullptr, 2, stream));
+    HIP_TRY(launch_pack_mlp(p->basis_mat, nullptr, img + TVR_IMG_BASH, s->packed + s->lay.basis_frag, 2, stream));
     HIP_TRY(hipMemcpyAsync(img + TVR_IMG_W3, p->W3, 3 * TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemsetAsync(img + TVR_IMG_W3 + 3 * TVR_IMG_W3_ROW, 0, TVR_IMG_W3_ROW, stream));
     HIP_TRY(hipMemcpyAsync(s->packed + s->lay.b3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));

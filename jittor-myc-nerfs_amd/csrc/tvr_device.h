@@ -6,9 +6,9 @@
 //   density line  i : [L_i+1][16]
 //   app plane     i : [H_i+1][W_i+1][48]       (192 B texel = 12 x float4)
 //   app line      i : [L_i+1][48]
-//   MLP LDS image (TVR_MLP_IMAGE_BYTES): W1 / W2 as fp16 hi and lo parts, row-major [128 hidden][k position] with padded
-//                      rows (conflict-free ds_read_b128 A-operand reads) and permuted k columns (see tvr_shade.hip), b1, b2
-//   basis fragments: [k-step][lane half][row 32][hi 8 | lo 8] fp16 — one 32-B A-operand pair per lane, coalesced
+//   MLP LDS image (TVR_MLP_IMAGE_BYTES): W1 / W2 as fp16 hi and lo parts, k-step major [k-step][lane half][128 hidden][8 halfs]
+//                      (conflict-free ds_read_b128 A-operand reads, no padding) with permuted k columns (see tvr_shade.hip), b2, b3, W3 fp32,
+//                      and the hi parts of the basis fragments; the lo parts [k-step][lane half][row 32][8 halfs] stay in global memory
 // Compiled with -ffp-contract=off: every a*b+c below is two rounded ops unless written as fmaf, so the
 // position / mask / cell-index arithmetic reproduces SURVEY.md Appendix A steps 1-7 bit for bit.
 #pragma once
@@ -22,19 +22,24 @@
 #define TVR_NIN 150    // 27 + 3 + 2*2*27 + 2*2*3
 #define TVR_KAPP 144
 
-// byte offsets inside the MLP LDS image
-#define TVR_IMG_W1_ROW 336                 // 160 k positions * 2 B + 16 B pad: row r lands on 16-B slot 5r mod 16
-#define TVR_IMG_W2_ROW 272                 // 128 * 2 B + 16 B pad
+// byte offsets inside the MLP LDS image.  Round 2: the weight images are K-STEP MAJOR — [k-step][lane half][128 rows][8 halfs = 16 B] — so the 32
+// lanes of a ds_read_b128 A-fragment read (row = lane & 31) touch 512 contiguous bytes: conflict-free without the 16 B of padding per row
+// that the row-major layout of round 1 needed.  The 8 KB this frees hold the hi parts of the basis fragments (27 rows): 9 of the 18 basis
+// loads per tile no longer go through the vector L1, which is what binds the shade kernel.
+#define TVR_IMG_STEP 4096                  // bytes per k-step of one image: 2 halves x 128 rows x 16 B
+#define TVR_IMG_RB 512                     // bytes between 32-row blocks inside a (k-step, half)
 #define TVR_IMG_W1H 0
-#define TVR_IMG_W1L (128 * TVR_IMG_W1_ROW)
-#define TVR_IMG_W2H (2 * 128 * TVR_IMG_W1_ROW)
-#define TVR_IMG_W2L (TVR_IMG_W2H + 128 * TVR_IMG_W2_ROW)
-#define TVR_IMG_B1 (TVR_IMG_W2H + 2 * 128 * TVR_IMG_W2_ROW)
+#define TVR_IMG_W1L (10 * TVR_IMG_STEP)
+#define TVR_IMG_W2H (20 * TVR_IMG_STEP)
+#define TVR_IMG_W2L (28 * TVR_IMG_STEP)
+#define TVR_IMG_B1 (36 * TVR_IMG_STEP)             // 147 456
 #define TVR_IMG_B2 (TVR_IMG_B1 + 512)
 #define TVR_IMG_B3 TVR_IMG_B1                      // b3 (3 floats + pad): b1 itself rides in W1's image as the column of a constant-1 input
 #define TVR_IMG_W3 (TVR_IMG_B2 + 512)              // W3 [3][128] fp32 (layer 3 runs as fp32 FMAs), then 512 zero bytes (REFTensoRF's zero row)
 #define TVR_IMG_W3_ROW 512
-#define TVR_MLP_IMAGE_BYTES (TVR_IMG_W3 + 4 * TVR_IMG_W3_ROW)     // 158 720 B of the 163 840 B LDS
+#define TVR_IMG_BASH (TVR_IMG_W3 + 4 * TVR_IMG_W3_ROW)   // basis fragments, hi parts: [9 k-steps][2 halves][27 rows][16 B]
+#define TVR_IMG_BASH_ROWS 27
+#define TVR_MLP_IMAGE_BYTES (TVR_IMG_BASH + 9 * 2 * TVR_IMG_BASH_ROWS * 16)     // 158 304 B of the 163 840 B LDS
 // REFTensoRF (variant 1) appends the four 144 -> {3,3,1,1} linears of REFTensoRF.compute_appfeature (models/REFTensoRF.py:126-132):
 //   64 zero bytes (they extend W3's zero row to the 576 B of a 9-k-step row), 8 rows [9 k-steps][2 halves][hi 8 | lo 8] fp16
 //   (normal 0..2, specular 3, diffuse 4..6, rho 7) and 16 fp32 biases in accumulator-row order.
@@ -42,9 +47,9 @@
 #define TVR_IMG_REFW (TVR_MLP_IMAGE_BYTES + 64)
 #define TVR_IMG_REF_ROW 576
 #define TVR_IMG_REFB (TVR_IMG_REFW + 8 * TVR_IMG_REF_ROW)
-#define TVR_MLP_IMAGE_BYTES_REF (TVR_IMG_REFB + 64)               // 163 456 B
+#define TVR_MLP_IMAGE_BYTES_REF (TVR_IMG_REFB + 64)               // 163 040 B
 #define TVR_NIN_REF 151  // 1 + 27 + 3 + 2*2*27 + 2*2*3 (MLPRender_Fea_Ref, models/REFTensoRF.py:9)
-#define TVR_BASIS_FRAG_BYTES (9 * 2 * 32 * 16 * 2)
+#define TVR_BASIS_FRAG_BYTES (9 * 2 * 32 * 16)   // global: the LO parts of the basis fragments [9 k-steps][2 halves][32 rows][16 B] (hi parts: LDS image)
 
 struct SceneDev {
     float lo[3], hi[3], inv[3];
@@ -55,7 +60,7 @@ struct SceneDev {
     const float4 *aplane[3];
     const float4 *aline[3];
     const void *mlp_image;        // TVR_MLP_IMAGE_BYTES(_REF), copied to LDS by the shade kernel
-    const void *basis_frag;       // [9][2][32][16] fp16
+    const void *basis_frag;       // lo parts of the basis fragments [9][2][32][8] fp16 (hi parts: mlp_image + TVR_IMG_BASH)
     const float *b3;              // [3]
     float near_, far_, step, shift, scale, thres;
     int act;

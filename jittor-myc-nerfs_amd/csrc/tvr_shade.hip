@@ -53,16 +53,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define TVR_BASIS_LATE 0   // 1: fetch the basis fragments after the last tap evaluation instead of behind the last taps (measured equal: 15.5 vs 15.5 ms)
 #endif
 #ifndef TVR_DEFER
-#define TVR_DEFER 1        // 1: layer 3 + epilogue of a tile run in the next tile's gather phase; 0: at the end of its own matrix phase (with the
-                          //    gather-phase priority: 14.8 vs 15.3 ms)
+#define TVR_DEFER 0        // 1: layer 3 + epilogue of a tile run in the next tile's gather phase; 0: behind its own matrix phase, after the matrix token
+                          //    is handed over (with the token: 12.55 vs 12.83 ms; without it 1 was better, 14.8 vs 15.3)
 #endif
 #ifndef TVR_APF
 #define TVR_APF 1         // 1: the weight fragments of hidden-layer k-step s + 1 are fetched from LDS during step s (32 more live registers);
                           //    0 measured 15.2 vs 14.8 ms (and still no room for a tap ring of depth 2: one spill, 15.7)
 #endif
 #ifndef TVR_STAGGER
-#define TVR_STAGGER 1     // the two waves of a SIMD (w and w + 4) run the same program: the second starts half a tile late so that one
-#endif                    // gathers while the other multiplies (MI355X_MICROARCH 'Two waves per SIMD', item 9)
+#define TVR_STAGGER 0     // 1: the second wave of a SIMD starts half a tile late (round 1's way of getting one wave to gather while the other
+#endif                    //    multiplies; it does not last — see TVR_MTOKEN — and measures 12.85 vs 12.84 ms beside the token)
 #ifndef SH_WAVES
 #define SH_WAVES 8        // two waves per SIMD
 #endif
@@ -297,6 +297,39 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 // REF = REFTensoRF (models/REFTensoRF.py:107-133, 174-256): a second basis row block gives normal / diffuse / specular / rho from the
 // same h, the view direction is replaced by the reflection about the normalised normal, layer 1 takes one more input (-dot) and the
 // colour is  specular_tint * rgb_s + rgb_d.
+// The two waves of a SIMD (w and w + 4) run the same program.  Left alone they CONVOY: while both are in their matrix phase they share the MFMA
+// pipe, finish together, gather together (matrix pipe idle) and meet again at the next matrix phase — a stable state, whatever the start offset.
+// TVR_MTOKEN 1: a per-SIMD token in LDS makes the matrix phase mutually exclusive, which locks the pair in anti-phase (one gathers while the other
+// multiplies): 13.9 -> 12.55 ms on one box, interleaved rounds.  Unequal matrix-phase priorities for the two waves instead: 14.0, no effect;
+// two tokens (basis + layer 1 | layer 2 as a two-stage pipeline): 12.98; spin back-off s_sleep 1 vs 8: equal; the token taken only at layer 1
+// (basis product outside it): 12.88; that plus all sin / cos in front of the token: 13.5 (12.97 same box); matrix-phase priority above
+// the gather's: 12.95; without the LDS prefetch of the weight fragments (TVR_APF 0): 13.2.
+// Every path takes the token after its last global load has landed and gives it back before the next tile's first load, at most once per tile:
+// a wave never waits for the token while holding it, so the spin always ends.
+#ifndef TVR_MTOKEN
+#define TVR_MTOKEN 1
+#endif
+#ifndef TVR_MSLEEP
+#define TVR_MSLEEP 2
+#endif
+#if TVR_MTOKEN
+#define TVR_TOKEN_TAKE(t)                                                                   \
+    do {                                                                                    \
+        int got_;                                                                           \
+        do {                                                                                \
+            int r_ = 1;                                                                     \
+            if (lane == 0) r_ = atomicCAS((t), 0, 1);                                       \
+            got_ = __builtin_amdgcn_readfirstlane(r_);                                      \
+            if (got_) __builtin_amdgcn_s_sleep(TVR_MSLEEP);                                 \
+        } while (got_);                                                                     \
+    } while (0)
+#define TVR_TOKEN_GIVE(t) do { if (lane == 0) atomicExch((t), 0); } while (0)
+#define TVR_ENTER_MATRIX() do { TVR_TOKEN_TAKE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_M); } while (0)
+#define TVR_LEAVE_MATRIX() do { TVR_TOKEN_GIVE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_G); } while (0)
+#else
+#define TVR_ENTER_MATRIX() __builtin_amdgcn_s_setprio(TVR_PRIO_M)
+#define TVR_LEAVE_MATRIX() __builtin_amdgcn_s_setprio(TVR_PRIO_G)
+#endif
 template <int SRC, int DST, bool REF>
 __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
@@ -304,11 +337,23 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e = lane & 31, h = lane >> 5;
-    if (DST != SH_DST_FEAT || REF) {              // MLP weights -> LDS once per workgroup
-        const uint4 *src = (const uint4 *)sc.mlp_image;
-        for (int i = tid; i < (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES) / 16; i += SH_THREADS) ((uint4 *)smem)[i] = src[i];
+    // MLP weights -> LDS once per workgroup (the xyz -> features kernel of TensorVMSplit needs only the basis fragments' hi parts)
+    constexpr bool BAS_ONLY = DST == SH_DST_FEAT && !REF;
+    constexpr int BASH = BAS_ONLY ? 0 : TVR_IMG_BASH;
+    {
+        const uint4 *src = (const uint4 *)((const unsigned char *)sc.mlp_image + (BAS_ONLY ? TVR_IMG_BASH : 0));
+        constexpr int nb = BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES);
+        for (int i = tid; i < nb / 16; i += SH_THREADS) ((uint4 *)smem)[i] = src[i];
+#if TVR_MTOKEN
+        if (tid < 4) ((int *)(smem + nb))[tid] = 0;
+#endif
         __syncthreads();
     }
+#if TVR_MTOKEN
+    int *mtok = (int *)(smem + (BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES))) + (wave & 3);
+#endif
+    // basis hi fragment of lane (e, h) at k-step s: rows 27..31 of the 32-row tile do not exist (their outputs are never used): clamp
+    const unsigned char *bashp = smem + BASH + (h * TVR_IMG_BASH_ROWS + (e < TVR_IMG_BASH_ROWS ? e : TVR_IMG_BASH_ROWS - 1)) * 16;
     const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
     const long long n_tiles = (n_total + SH_TILE - 1) / SH_TILE;
 #if TVR_TIMING
@@ -347,7 +392,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
         for (int r = 0; r < 8; ++r) G[r] = 0.f;
 #if TVR_TIMING
-        unsigned long long tg0 = 0, tgD = 0, tgF = 0, tg1 = 0, tg2 = 0, tg3 = 0, tg4 = 0;
+        unsigned long long tg0 = 0, tgD = 0, tgF = 0, tg1 = 0, tgW = 0, tg2 = 0, tg3 = 0, tg4 = 0;
 #endif
         TVR_STAMP(tg0);
         // ---------------------------------------------------------------- GATHER phase: global loads + VALU + LDS, no MFMA ----
@@ -376,7 +421,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         if (SRC == SH_SRC_H) {
             // training forward: h [n,144] comes from tvr_app_h_forward; this lane's 8 channels of each k-step are 32 contiguous bytes
             Frag hf[9];
-            uint4 bah[9], bal[9];
+            uint4 bal[9];
             if (live) { dir[0] = a.viewdirs[ent * 3]; dir[1] = a.viewdirs[ent * 3 + 1]; dir[2] = a.viewdirs[ent * 3 + 2]; }
             {
                 const long long le = live ? ent : n_total - 1;
@@ -384,14 +429,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 float4 hv4[9][2];
 #pragma unroll
                 for (int s = 0; s < 9; ++s) { hv4[s][0] = hp[4 * s]; hv4[s][1] = hp[4 * s + 1]; }
-                unsigned boff = (unsigned)((h * 32 + e) * 32);
+                unsigned boff = (unsigned)((h * 32 + e) * 16);
                 asm volatile("" : "+v"(boff));
 #pragma unroll
-                for (int s3 = 0; s3 < 9; ++s3) {
-                    const uint4 *ap = (const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 2048)));
-                    bah[s3] = ap[0];
-                    bal[s3] = ap[1];
-                }
+                for (int s3 = 0; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
                     const float hv[8] = {hv4[s][0].x, hv4[s][0].y, hv4[s][0].z, hv4[s][0].w, hv4[s][1].x, hv4[s][1].y, hv4[s][1].z, hv4[s][1].w};
@@ -401,11 +442,12 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TVR_SB;
             TVR_STAMP(tg1);
-            __builtin_amdgcn_s_setprio(TVR_PRIO_M);
+            TVR_ENTER_MATRIX();
+            TVR_STAMP(tgW);
             f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
-                const h8 Ah = __builtin_bit_cast(h8, bah[s]), Al = __builtin_bit_cast(h8, bal[s]);
+                const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s * (2 * TVR_IMG_BASH_ROWS * 16))), Al = __builtin_bit_cast(h8, bal[s]);
                 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);
                 accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);
                 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);
@@ -427,7 +469,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             // 9 k-steps of 16 channels (plane p = s/3, channels 16(s%3) + 8h .. +7 of this lane); the B fragments (plane*line products,
             // fp16 hi/lo) stay in registers
             Frag hf[9];
-            uint4 bah[9], bal[9];
+            uint4 bal[9];
             {
                 Taps T[TVR_PF + 1];                                // ring: taps of k-steps s .. s+TVR_PF in flight
 #pragma unroll
@@ -445,16 +487,12 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                                            4 * (s2 % 3) + 2 * h);
                     } else if (s + TVR_PF == 9 + ((REF || TVR_BASIS_LATE) ? 1 : 0)) {      // (REFTensoRF: after the last evaluation — its extra live values leave no room earlier)
                         // the basis A fragments (the tile's last global loads) ride behind the last taps
-                        // (byte offsets against the uniform base, opaque per tile: the k-step stride of 2 KB does not fit a load's immediate,
-                        // and hoisted per-step 64-bit addresses would spill)
-                        unsigned boff = (unsigned)((h * 32 + e) * 32);
+                        // (lo parts; the hi parts are in LDS.  Byte offsets against the uniform base, opaque per tile: hoisted per-step 64-bit
+                        // addresses would spill)
+                        unsigned boff = (unsigned)((h * 32 + e) * 16);
                         asm volatile("" : "+v"(boff));
 #pragma unroll
-                        for (int s3 = 0; s3 < 9; ++s3) {
-                            const uint4 *ap = (const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 2048)));
-                            bah[s3] = ap[0];
-                            bal[s3] = ap[1];
-                        }
+                        for (int s3 = 0; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
                     }
                     const int p = s / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
@@ -465,26 +503,23 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 }
             }
             if (REF || TVR_BASIS_LATE) {
-                unsigned boff = (unsigned)((h * 32 + e) * 32);
+                unsigned boff = (unsigned)((h * 32 + e) * 16);
                 asm volatile("" : "+v"(boff));
 #pragma unroll
-                for (int s3 = 0; s3 < 9; ++s3) {
-                    const uint4 *ap = (const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 2048)));
-                    bah[s3] = ap[0];
-                    bal[s3] = ap[1];
-                }
+                for (int s3 = 0; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
             }
             // phase boundary: every load of this tile has landed before the first MFMA issues, and the compiler may not move loads below it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TVR_SB;
             TVR_STAMP(tg1);
-            __builtin_amdgcn_s_setprio(TVR_PRIO_M);
+            TVR_ENTER_MATRIX();
+            TVR_STAMP(tgW);
             // ------------------------------------------------------------ MATRIX phase: MFMA + LDS + VALU, no global load ----
             // three independent accumulation chains (hi*lo products) summed at the end: no MFMA directly follows its producer
             f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
-                const h8 Ah = __builtin_bit_cast(h8, bah[s]), Al = __builtin_bit_cast(h8, bal[s]);
+                const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s * (2 * TVR_IMG_BASH_ROWS * 16))), Al = __builtin_bit_cast(h8, bal[s]);
                 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);
                 accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);
                 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);
@@ -523,9 +558,12 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // phase boundary: nothing of this tile's loads outlives the gather phase
             TVR_STAMP(tg1);
+            TVR_ENTER_MATRIX();
+            TVR_STAMP(tgW);
         }
 
         if (DST == SH_DST_FEAT) {
+            TVR_LEAVE_MATRIX();
             if (live) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -543,10 +581,11 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         }
 
         TVR_STAMP(tg2);
-        if (DST == SH_DST_TRAIN && live) {           // features [n,32]: rows 27..31 are zero (zero basis rows)
+        if (DST == SH_DST_TRAIN && live) {           // features [n,32]: rows 27..31 (h=0: r=15; h=1: r=12..15) are written as zero
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                *(float4 *)(a.t_feats + ent * 32 + 8 * q + 4 * h) = make_float4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3]);
+                *(float4 *)(a.t_feats + ent * 32 + 8 * q + 4 * h) = q < 3 ? make_float4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3])
+                                                                    : (h == 0 ? make_float4(F[12], F[13], F[14], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
         }
         // view direction occupies base rows 27 (h=0, r=15), 28, 29 (h=1, r=12, 13); row 30 = REF's -dot, row 31 = the constant 1 (b1's column)
         if (REF && SRC != SH_SRC_FEAT) {
@@ -569,7 +608,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x16{0};
         {
             float S1[16], C1[16];
-            const int rowoff = e * TVR_IMG_W1_ROW + h * 16;
+            const int rowoff = (h * 128 + e) * 16;
             auto l1_frag = [&](int s, Frag &b) {
                 float v[8];
 #pragma unroll
@@ -586,14 +625,14 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             AFrag4 acur, anxt;
             l1_frag(0, bcur);
 #if TVR_APF
-            load_afrag4(acur, W1H, W1L, rowoff, 32 * TVR_IMG_W1_ROW);
+            load_afrag4(acur, W1H, W1L, rowoff, TVR_IMG_RB);
 #endif
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
 #if TVR_APF
-                if (s + 1 < 10) load_afrag4(anxt, W1H, W1L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W1_ROW);
+                if (s + 1 < 10) load_afrag4(anxt, W1H, W1L, rowoff + (s + 1) * TVR_IMG_STEP, TVR_IMG_RB);
 #else
-                load_afrag4(acur, W1H, W1L, rowoff + s * 32, 32 * TVR_IMG_W1_ROW);
+                load_afrag4(acur, W1H, W1L, rowoff + s * TVR_IMG_STEP, TVR_IMG_RB);
 #endif
                 if (s + 1 < 10) l1_frag(s + 1, bnxt);
                 mfma3x4(acur, bcur, acc);
@@ -615,7 +654,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 cur.acc2[rb][4 * q] = bv.x; cur.acc2[rb][4 * q + 1] = bv.y; cur.acc2[rb][4 * q + 2] = bv.z; cur.acc2[rb][4 * q + 3] = bv.w;
             }
         {
-            const int rowoff = e * TVR_IMG_W2_ROW + h * 16;
+            const int rowoff = (h * 128 + e) * 16;
             auto relu_frag = [&](int s, Frag &b) {
                 float v[8];
 #pragma unroll
@@ -630,14 +669,14 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             AFrag4 acur, anxt;
             relu_frag(0, bcur);
 #if TVR_APF
-            load_afrag4(acur, W2H, W2L, rowoff, 32 * TVR_IMG_W2_ROW);
+            load_afrag4(acur, W2H, W2L, rowoff, TVR_IMG_RB);
 #endif
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
 #if TVR_APF
-                if (s + 1 < 8) load_afrag4(anxt, W2H, W2L, rowoff + (s + 1) * 32, 32 * TVR_IMG_W2_ROW);
+                if (s + 1 < 8) load_afrag4(anxt, W2H, W2L, rowoff + (s + 1) * TVR_IMG_STEP, TVR_IMG_RB);
 #else
-                load_afrag4(acur, W2H, W2L, rowoff + s * 32, 32 * TVR_IMG_W2_ROW);
+                load_afrag4(acur, W2H, W2L, rowoff + s * TVR_IMG_STEP, TVR_IMG_RB);
 #endif
                 if (s + 1 < 8) relu_frag(s + 1, bnxt);
                 mfma3x4(acur, bcur, cur.acc2);
@@ -650,7 +689,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         }
         cur.ent = ent; cur.live = live; cur.wq = wq;
         cur.g[0] = G[3]; cur.g[1] = G[4]; cur.g[2] = G[5]; cur.g[3] = G[6];
-        __builtin_amdgcn_s_setprio(TVR_PRIO_G);
+        TVR_LEAVE_MATRIX();
 #if TVR_DEFER
         prev = cur;
         have_prev = true;
@@ -659,13 +698,13 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #endif
         TVR_STAMP(tg4);
 #if TVR_TIMING
-        tsum[0] += tgF - tgD; tsum[5] += tgD - tg0; tsum[1] += tg1 - tgF; tsum[2] += tg2 - tg1; tsum[3] += tg3 - tg2; tsum[4] += tg4 - tg3;
+        tsum[0] += tgF - tgD; tsum[5] += tgD - tg0; tsum[1] += tg1 - tgF; tsum[6] += tgW - tg1; tsum[2] += tg2 - tgW; tsum[3] += tg3 - tg2; tsum[4] += tg4 - tg3;
 #endif
     }
     if (DST != SH_DST_FEAT && have_prev) finish_tile<DST, REF, HAVE_G>(prev, smem, a, h);
 #if TVR_TIMING
     if (a.stats && lane == 0)
-        for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // finish, gather, basis, L1 (+PE), L2, MFMA drain
+        for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // finish, gather, basis, L1 (+PE), L2, MFMA drain, wait for the matrix token
 #endif
     if (a.stats && SRC == SH_SRC_QUEUE && blockIdx.x == 0 && tid == 0)
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
@@ -674,7 +713,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 template <int SRC, int DST, bool REF>
 static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
-    const int lds = REF ? TVR_MLP_IMAGE_BYTES_REF : ((DST == SH_DST_FEAT) ? 0 : TVR_MLP_IMAGE_BYTES);
+    const int lds = (REF ? TVR_MLP_IMAGE_BYTES_REF : ((DST == SH_DST_FEAT) ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : TVR_MLP_IMAGE_BYTES)) + (TVR_MTOKEN ? 16 : 0);
     hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
     unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
@@ -726,10 +765,10 @@ hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, h
 }
 
 // MLP weights -> fp16 hi/lo operand images.  One thread per (row, k position).
-//  mode 0: W1 LDS image  [128][W1_ROW/2 halfs]: kpos = 16s + 8h + j  <->  derived (i%5) of base acc_row(i/5, h), i = 8s + j;
+//  mode 0: W1 LDS image  [s][h][128][8 halfs]: kpos = 16s + 8h + j  <->  derived (i%5) of base acc_row(i/5, h), i = 8s + j;
 //          base row 31's plain slot (the constant-1 input) carries b1
-//  mode 1: W2 LDS image  [128][W2_ROW/2 halfs]: kpos = 16s + 8h + j  <->  hidden unit 16s + 8(j>>2) + 4h + (j&3)
-//  mode 2: basis fragments [9][2][32][hi 8 | lo 8]: row r < 27, k = 16s + 8h + j (natural)
+//  mode 1: W2 LDS image  [s][h][128][8 halfs]: kpos = 16s + 8h + j  <->  hidden unit 16s + 8(j>>2) + 4h + (j&3)
+//  mode 2: basis fragments, hi [9][2][27][8] (LDS image) and lo [9][2][32][8] (global): row r < 27, k = 16s + 8h + j (natural)
 //  (layer 3 runs as fp32 FMAs: W3 [3][128] fp32 and b3 are copied into the LDS image as they are, tvr_api.hip)
 //  mode 4: mode 0 for MLPRender_Fea_Ref (REFTensoRF.py:19-24: [dot, features, viewdirs, PE(features), PE(viewdirs)], 151 inputs):
 //          every index moves up by one and base row 30's plain slot carries input 0 (dot)
@@ -762,16 +801,12 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
     }
     unsigned hi, lo;
     split2(w, 0.0f, hi, lo);
-    if (mode == 0 || mode == 4) {
-        out_hi[row * (TVR_IMG_W1_ROW / 2) + kpos] = (unsigned short)hi;
-        out_lo[row * (TVR_IMG_W1_ROW / 2) + kpos] = (unsigned short)lo;
-    } else if (mode == 1) {
-        out_hi[row * (TVR_IMG_W2_ROW / 2) + kpos] = (unsigned short)hi;
-        out_lo[row * (TVR_IMG_W2_ROW / 2) + kpos] = (unsigned short)lo;
-    } else if (mode == 2) {
-        unsigned short *o = out_hi + ((size_t)((s * 2 + hh) * 32 + row)) * 16;   // [hi 8 | lo 8] per (s, h, row)
-        o[j] = (unsigned short)hi;
-        o[8 + j] = (unsigned short)lo;
+    if (mode == 0 || mode == 1 || mode == 4) {                                   // k-step major weight image: [s][h][row 128][8]
+        out_hi[((s * 2 + hh) * 128 + row) * 8 + j] = (unsigned short)hi;
+        out_lo[((s * 2 + hh) * 128 + row) * 8 + j] = (unsigned short)lo;
+    } else if (mode == 2) {                                                      // basis: hi parts -> the LDS image [s][h][27 rows][8], lo parts -> global [s][h][32 rows][8]
+        if (row < TVR_IMG_BASH_ROWS) out_hi[((s * 2 + hh) * TVR_IMG_BASH_ROWS + row) * 8 + j] = (unsigned short)hi;
+        out_lo[((s * 2 + hh) * 32 + row) * 8 + j] = (unsigned short)lo;
     } else {
         unsigned short *o = out_hi + ((size_t)((row * 8 + s) * 2 + hh)) * 16;    // [hi 8 | lo 8] per (row, s, h)
         o[j] = (unsigned short)hi;
