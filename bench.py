@@ -434,6 +434,7 @@ def main():
     l1_bytes = 40.0 * n_mine + 768.0 * m_eval + (32.0 * m_bbox if has_mask else 0.0)
     lds_bytes = 384.0 * m_eval
     ck_m = clock_ghz(pm, t_march) or 2.1
+    SHADE_L1_B = 123 * 1024 / 32.0
     L1_BCLK = 48.9               # B/clk/CU: the L1 -> register rate measured on MI355X for wave-level dwordx4 loads that all hit L1, 16 waves per CU
                                  # (scripts/hwprobe/ta_rate.hip, profiles/r02_l1_rate_probe.txt: 21.0 cycles per 1-KB load); the nominal width is 64
     l1_peak = 256 * L1_BCLK * ck_m                                  # GB/s
@@ -461,9 +462,10 @@ def main():
                   "clock_GHz": clock_ghz(ps, t_shade),
                   # the second roof of this kernel: every appearance sample pulls 3456 B of taps + 576 B of basis fragments (18 KB per 32-entry tile)
                   # + 36 B of queue entry / view direction through the vector L1
-                  "l1": {"bytes_per_launch": 4068.0 * m_app, "achieved_GBps": 4068.0 * m_app / t_shade / 1e9 if t_shade > 0 else None,
+                  # 123 wave-level dwordx4 loads (1 KB each) per 32-entry tile: 108 taps, 9 basis fragments (lo parts), 6 entry / direction
+                  "l1": {"bytes_per_launch": SHADE_L1_B * m_app, "achieved_GBps": SHADE_L1_B * m_app / t_shade / 1e9 if t_shade > 0 else None,
                          "peak_GBps": 256 * L1_BCLK * (clock_ghz(ps, t_shade) or 1.9),
-                         "frac": 4068.0 * m_app / t_shade / 1e9 / (256 * L1_BCLK * (clock_ghz(ps, t_shade) or 1.9)) if t_shade > 0 else None},
+                         "frac": SHADE_L1_B * m_app / t_shade / 1e9 / (256 * L1_BCLK * (clock_ghz(ps, t_shade) or 1.9)) if t_shade > 0 else None},
                   "note": f"{FLOP_APP / 1e3:.1f} kFLOP per appearance sample (algorithmic, fp32 semantics) against the dense f16 MFMA peak (2.5 PFLOP/s); "
                           "fp32-class arithmetic on this chip needs 3 fp16 products per fp32 product (hi/lo split; the fp32-input MFMA runs at 1/16 rate), "
                           f"so the ceiling for this arithmetic is peak / 3 = 833 TFLOP/s (frac_vs_fp32class_ceiling); executed on padded tiles: {FLOP_APP_EXEC} FLOP "

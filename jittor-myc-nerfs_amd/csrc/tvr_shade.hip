@@ -303,7 +303,8 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 // multiplies): 13.9 -> 12.55 ms on one box, interleaved rounds.  Unequal matrix-phase priorities for the two waves instead: 14.0, no effect;
 // two tokens (basis + layer 1 | layer 2 as a two-stage pipeline): 12.98; spin back-off s_sleep 1 vs 8: equal; the token taken only at layer 1
 // (basis product outside it): 12.88; that plus all sin / cos in front of the token: 13.5 (12.97 same box); matrix-phase priority above
-// the gather's: 12.95; without the LDS prefetch of the weight fragments (TVR_APF 0): 13.2.
+// the gather's: 12.95; without the LDS prefetch of the weight fragments (TVR_APF 0): 13.2; the hidden layers' VALU / LDS work forced
+// between their MFMAs one group per MFMA (sched_group_barrier: M vvv d M vvv d ... instead of hipcc's MMMM vvvvvvvvvvvvvv): 13.01 vs 12.95.
 // Every path takes the token after its last global load has landed and gives it back before the next tile's first load, at most once per tile:
 // a wave never waits for the token while holding it, so the spin always ends.
 #ifndef TVR_MTOKEN
