@@ -460,6 +460,10 @@ def main():
                   "mfma_valu_coexec_frac_of_busy": (ps["SQ_VALU_MFMA_COEXEC_CYCLES"] / ps["SQ_VALU_MFMA_BUSY_CYCLES"]) if ps.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
                   "valu_insts_per_32_entry_tile": (ps["SQ_INSTS_VALU"] / (m_app / 32.0)) if ps.get("SQ_INSTS_VALU") and m_app > 0 else None,
                   "clock_GHz": clock_ghz(ps, t_shade),
+                  "valu_busy_frac": (ps["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (ps["GRBM_GUI_ACTIVE"] / 8.0)) if ps.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in ps else None,
+                  "lds_busy_frac": (ps["SQ_LDS_IDX_ACTIVE"] / 256.0 / (ps["GRBM_GUI_ACTIVE"] / 8.0)) if ps.get("GRBM_GUI_ACTIVE") and "SQ_LDS_IDX_ACTIVE" in ps else None,
+                  "lds_bank_conflict_frac": (ps["SQ_LDS_BANK_CONFLICT"] / ps["SQ_LDS_IDX_ACTIVE"]) if ps.get("SQ_LDS_IDX_ACTIVE") else None,
+                  "pmc_counters": {k: ps[k] for k in sorted(ps)},
                   # the second roof of this kernel: every appearance sample pulls 3456 B of taps + 576 B of basis fragments (18 KB per 32-entry tile)
                   # + 36 B of queue entry / view direction through the vector L1
                   # 123 wave-level dwordx4 loads (1 KB each) per 32-entry tile: 108 taps, 9 basis fragments (lo parts), 6 entry / direction
