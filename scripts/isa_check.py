@@ -13,9 +13,10 @@ are held to rules that can be CHECKED on the instructions that ship, instead of 
       kernel is listed as a single-MFMA-wave-per-SIMD kernel.  Reported per kernel as `vmem_in_matrix_phase`.
   R3  WAR adjacency: a VMEM load whose destination overlaps an A/B/C operand of an MFMA issued fewer than WAR_WINDOW instructions earlier.
       (What the round-1 ISA showed: `global_load_dwordx4 v[110:113]` directly behind `v_mfma ... v[110:113]`.)  Reported as `war_adjacent`.
-  R4  inline-asm VALU results never feed an MFMA directly (VALU write -> MFMA read needs software wait states on gfx950 which hipcc pads
-      for its own code only, scripts/hwprobe/mfma_raw.hip): every MFMA source written by a VALU within the previous 2 instructions is
-      reported as `valu_to_mfma_lt2`.
+  R4  a VALU result never feeds the DIRECTLY following MFMA: gfx950 needs one instruction (any: an `s_nop 0`, a satisfied `s_waitcnt`) between
+      a VALU write and an MFMA read of the register (scripts/hwprobe/mfma_raw2.hip), hipcc pads for that, and the fp16 residuals come out of
+      inline asm (`v_fma_mix_f32`, csrc/tvr_mfma.h) — reported as `valu_to_mfma_adjacent` (must be 0).  `valu_to_mfma_lt2` also counts
+      the padded cases (one instruction in between; informational).
 
 usage: isa_check.py <libtvr.so | file.s> [--kernel SUBSTR] [--json]
 """
@@ -176,7 +177,7 @@ def is_valu(mn):
 
 def check_kernel(name, ins_list, skip_execz):
     """One linear pass.  skip_execz: treat every forward `s_cbranch_execz L` as taken (drop the instructions up to L)."""
-    res = {"raw_violations": [], "war_adjacent": [], "valu_to_mfma_lt2": [], "n_mfma": 0, "n_vmem_load": 0}
+    res = {"raw_violations": [], "war_adjacent": [], "valu_to_mfma_lt2": [], "valu_to_mfma_adjacent": [], "n_mfma": 0, "n_vmem_load": 0}
     outstanding = []                     # FIFO of (index, dst regs) of VMEM ops in issue order (stores have empty dst but still count)
     recent_mfma = []                     # (index, operand regs)
     recent_valu = []                     # (index, dst regs)
@@ -225,6 +226,8 @@ def check_kernel(name, ins_list, skip_execz):
             for (k, d) in recent_valu:
                 if i - k <= 2 and (d & src):
                     res["valu_to_mfma_lt2"].append((i, ins_list[k], ins))
+                if i - k == 1 and (d & src):
+                    res["valu_to_mfma_adjacent"].append((i, ins_list[k], ins))
             recent_mfma.append((i, src | dst))
             recent_mfma = [(k, r) for k, r in recent_mfma if i - k < WAR_WINDOW]
         if is_vmem(mn):
@@ -273,7 +276,7 @@ def audit(path, kernel_filter=None):
         report[name] = {
             "instructions": len(ins), "mfma": a["n_mfma"], "vmem_loads": a["n_vmem_load"], "vmem_loads_between_first_and_last_mfma": between,
             "raw_violations_fallthrough": len(a["raw_violations"]), "raw_violations_execz_taken": len(b["raw_violations"]),
-            "war_adjacent": len(a["war_adjacent"]), "valu_to_mfma_lt2": len(a["valu_to_mfma_lt2"]),
+            "war_adjacent": len(a["war_adjacent"]), "valu_to_mfma_lt2": len(a["valu_to_mfma_lt2"]), "valu_to_mfma_adjacent": len(a["valu_to_mfma_adjacent"]),
             "loops": phase_report(ins),
             "examples": {"raw": [x[1] for x in (a["raw_violations"] + b["raw_violations"])[:3]], "war": [f"{x[1]}  ->  {x[2]}" for x in a["war_adjacent"][:3]],
                          "valu_to_mfma": [f"{x[1]}  ->  {x[2]}" for x in a["valu_to_mfma_lt2"][:3]]},
@@ -295,7 +298,7 @@ if __name__ == "__main__":
             if v["mfma"] == 0 and not v["raw_violations_fallthrough"] and not v["raw_violations_execz_taken"]:
                 continue
             print(f"{k[:70]:70s} ins {v['instructions']:6d} mfma {v['mfma']:4d} vmem_ld {v['vmem_loads']:4d}  RAW {v['raw_violations_fallthrough']}/{v['raw_violations_execz_taken']}"
-                  f"  loads-in-matrix-phase {v['vmem_loads_between_first_and_last_mfma']:3d}  WAR-adjacent {v['war_adjacent']:3d}  valu->mfma<2 {v['valu_to_mfma_lt2']:3d}  loops {[(l['mfma'], l['vmem_loads_between_first_and_last_mfma']) for l in v['loops']]}")
+                  f"  loads-in-matrix-phase {v['vmem_loads_between_first_and_last_mfma']:3d}  WAR-adjacent {v['war_adjacent']:3d}  valu->mfma<2 {v['valu_to_mfma_lt2']:3d} (adjacent {v['valu_to_mfma_adjacent']})  loops {[(l['mfma'], l['vmem_loads_between_first_and_last_mfma']) for l in v['loops']]}")
             for kind, ex in v["examples"].items():
                 for e in ex[:2]:
                     print(f"      {kind}: {e}")

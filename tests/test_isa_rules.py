@@ -42,6 +42,22 @@ def test_phase_rule_of_mfma_kernels(report):
         assert v["war_adjacent"] == 0, (name, v["examples"]["war"])
 
 
+def test_no_valu_result_feeds_the_next_instruction_if_that_is_an_mfma():
+    """gfx950 needs one instruction between a VALU write and an MFMA read of the register (scripts/hwprobe/mfma_raw2.hip); the fp16 residuals
+    of every hi/lo split pass through inline asm (csrc/tvr_mfma.h).  Every MFMA kernel of the library, not only the shade kernels."""
+    import isa_check
+    rep = isa_check.audit(LIB, "")
+    with_mfma = {k: v for k, v in rep.items() if v["mfma"] > 0}
+    assert len(with_mfma) >= 14
+    for name, v in with_mfma.items():
+        assert v["valu_to_mfma_adjacent"] == 0, (name, v["examples"]["valu_to_mfma"])
+    # and the checker sees the pattern when it is there
+    bad = ["v_fma_mixhi_f16 v23, v27, -1.0, v28 op_sel:[1,0,0] op_sel_hi:[1,0,0]", "v_mfma_f32_32x32x16_f16 v[124:139], v[40:43], v[20:23], v[124:139]", "s_endpgm"]
+    assert len(isa_check.check_kernel("k", bad, False)["valu_to_mfma_adjacent"]) == 1
+    ok = [bad[0], "s_nop 0", bad[1], bad[2]]
+    assert len(isa_check.check_kernel("k", ok, False)["valu_to_mfma_adjacent"]) == 0
+
+
 def test_checker_flags_the_round1_pattern():
     """The checker must see what the round-1 build looked like: a load into an MFMA's A operand directly behind it, and a missing wait."""
     import isa_check
