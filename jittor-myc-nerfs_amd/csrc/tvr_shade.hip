@@ -79,7 +79,7 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 #define TVR_PRIO_M 0      // short VALU bursts: when its instructions win arbitration against the partner's MFMA stream the tile takes 6 % less
 #endif                    // time (15.55 -> 14.75 ms); the opposite polarity costs 2 % (15.9).  Measured on one box, interleaved rounds.
 #if TVR_NOPK
-// two plain v_fma_f32 / v_mul_f32 (opaque to the SLP vectoriser, which would re-pack them)
+// two plain v_fma_f32 / v_mul_f32, each pinned by an empty asm (without the pins, and with the SLP vectoriser off: 12.92 vs 12.75 ms)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c)
 {
     float x = __builtin_fmaf(a.x, b.x, c.x), y = __builtin_fmaf(a.y, b.y, c.y);
