@@ -290,10 +290,12 @@ class _MlpTrainFn(torch.autograd.Function):
         big = m >= 4096
         tn = (lambda a_, lda, ka, b_, ldb, kb: _gemm_tn_call(a_, lda, ka, b_, ldb, kb, m)) if big else None
         if big:
-            gW3 = tn(d_out, 4, 3, h2, 128, 128)
+            # (d_out and dfe are handed over at their full row length — 4 and 32 columns, the surplus rows of the product are dropped: rows that
+            #  are contiguous and 16-B aligned take tvr_gemm_tn's 16-B staging loads)
+            gW3 = tn(d_out, 4, 4, h2, 128, 128)[:3]
             gW2 = tn(dh2, 128, 128, h1, 128, 128)
             gW1 = tn(dh1, 128, 128, X, 150, 150)
-            gB = tn(dfe, 32, 27, h, 144, 144)
+            gB = tn(dfe, 32, 32, h, 144, 144)[:27]
             # bias gradients = column sums: torch's column reduction takes 0.1 ms at M ~ 3.5e5 (a gemm_tn pass over the same matrix 0.25 ms)
             gb3, gb2, gb1 = d_out[:, :3].sum(0), dh2.sum(0), dh1.sum(0)
         else:                                          # tiny batches (tests): the reductions as plain torch products

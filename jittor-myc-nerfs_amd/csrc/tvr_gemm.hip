@@ -86,6 +86,168 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-staged fp32 kernel (the default since round 2)
+// The kernel above fetches every MFMA operand with its own dword load — a wave-level load costs the CU's L1 path ~18 cycles whatever its
+// width (scripts/hwprobe/l1_width.hip) and a block of A is fetched once per column block of B: 40 wave-level loads per 2 rows and workgroup.
+// Here a workgroup copies TL_ROWS rows of A and of B into LDS once per chunk (16-B loads when the rows are contiguous and aligned, dword
+// loads otherwise), double-buffered; the waves take their fragments from there with ds_read_b32, one 2-row step ahead of the MFMAs; tiles
+// a wave does not have cost no MFMA.  Global loads of the next chunk are issued before the chunk's MFMAs and written to LDS after the
+// MFMAs have drained: no load is issued while an MFMA is in flight.
+// Measured (scripts/gemm_bench.py, one box, M = 356 123): 128 x 150: 0.283 -> 0.241 ms; 128 x 128: 0.263 -> 0.193; 3 x 128: 0.224 -> 0.095;
+// 27 x 144: 0.229 -> 0.111; 2.1e6 x 128 x 128: 1.36 -> 0.92.  What is left at the full shapes is the fp32 matrix pipe (0.107 ms for 20 tiles)
+// PLUS ~0.09 ms of memory wait that two waves per SIMD (139 VGPRs + 80 accumulators) do not overlap; chunk sizes 8 / 32 rows and a second
+// register set (prefetch distance 2) measured equal / slower.
+#ifndef TL_ROWS
+#define TL_ROWS 16
+#endif
+#define TL_PF ((TL_ROWS * 320 + 255) / 256)          // floats (or float4s / 4) per thread and chunk, at most: 20 tiles = 320 columns
+
+template <bool VEC4>
+__global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float *__restrict__ A, const int lda, const int Ka,
+                                                                     const float *__restrict__ B, const int ldb, const int Kb,
+                                                                     const long long M, float *__restrict__ P, const long long rows_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, k = lane >> 5;
+    const int nrb = (Ka + 31) >> 5, ncb = (Kb + 31) >> 5, ntiles = nrb * ncb;
+    const int na = TL_ROWS * Ka, nab = TL_ROWS * (Ka + Kb);             // floats of A / of A and B in one chunk (both multiples of 4)
+    int offA[TG_MAXT], offB[TG_MAXT];
+    f32x16 acc[TG_MAXT];
+#pragma unroll
+    for (int q = 0; q < TG_MAXT; ++q) {
+        const int t = wave + q * TG_WAVES;
+        const int rb = t / ncb, cb = t - rb * ncb;
+        offA[q] = (t < ntiles && rb * 32 + i < Ka) ? rb * 32 + i : -1;
+        offB[q] = (t < ntiles && cb * 32 + i < Kb) ? cb * 32 + i : -1;
+        acc[q] = f32x16{0};
+    }
+    const long long m0 = (long long)blockIdx.x * rows_per_block;
+    const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    // chunk [m, m + TL_ROWS) -> registers: element e of the chunk's A floats (row-major, Ka per row) followed by its B floats; rows >= m1 read as zero
+    constexpr int NPRE = VEC4 ? 4 * ((TL_PF + 3) / 4) : TL_PF;
+    float preA[NPRE];                                                  // (prefetch distance 2 with a second register set measured slower: 0.32 vs 0.23 ms)
+    // dword staging: element e = tid + 256 j of a chunk is (row erow[j], column c) of A or B whatever the chunk — the division is done once
+    int eoff[VEC4 ? 1 : TL_PF], erow[VEC4 ? 1 : TL_PF];
+    if (!VEC4) {
+#pragma unroll
+        for (int j = 0; j < TL_PF; ++j) {
+            const int e = tid + 256 * j;
+            const bool isa = e < na;
+            const int el = isa ? e : e - na, K = isa ? Ka : Kb;
+            const int r = el / K, c = el - r * K;
+            erow[j] = e < nab ? r : TL_ROWS;                           // TL_ROWS: never inside a chunk
+            eoff[j] = r * (isa ? lda : ldb) + c;
+        }
+    }
+    auto fetch = [&](long long m, float (&pre)[NPRE]) {
+        const long long rows = m1 - m < TL_ROWS ? m1 - m : TL_ROWS;    // may be <= 0 past the end
+        if (VEC4) {
+#pragma unroll
+            for (int j = 0; j < (TL_PF + 3) / 4; ++j) {
+                const int e = 4 * (tid + 256 * j);                      // a float4 never straddles A | B: na is a multiple of 4
+                const bool isa = e < na;
+                const int el = isa ? e : e - na, K = isa ? Ka : Kb;
+                const long long valid = rows > 0 ? rows * K : 0;       // floats of this operand's part of the chunk that exist
+                const float *src = (isa ? A + m * (long long)Ka : B + m * (long long)Kb) + el;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < nab) {
+                    if (el + 3 < valid) v = *(const float4 *)src;
+                    else {                                              // the ragged end of the last chunk
+                        if (el < valid) v.x = src[0];
+                        if (el + 1 < valid) v.y = src[1];
+                        if (el + 2 < valid) v.z = src[2];
+                    }
+                }
+                pre[4 * j] = v.x; pre[4 * j + 1] = v.y; pre[4 * j + 2] = v.z; pre[4 * j + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TL_PF; ++j) {
+                const bool in = erow[j] < rows;
+                const float *base = (tid + 256 * j < na) ? A : B;
+                const float v = base[in ? m * (long long)(base == A ? lda : ldb) + eoff[j] : 0];     // unconditional load, clamped address
+                pre[j] = in ? v : 0.0f;
+            }
+        }
+    };
+    auto stash = [&](float *buf, const float (&pre)[NPRE]) {
+        if (VEC4) {
+#pragma unroll
+            for (int j = 0; j < (TL_PF + 3) / 4; ++j) {
+                const int e = 4 * (tid + 256 * j);
+                if (e < nab) *(float4 *)(buf + e) = make_float4(pre[4 * j], pre[4 * j + 1], pre[4 * j + 2], pre[4 * j + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TL_PF; ++j) {
+                const int e = tid + 256 * j;
+                if (e < nab) buf[e] = pre[j];
+            }
+        }
+    };
+    const int bufsz = (nab + 3) & ~3;
+    fetch(m0, preA);
+    stash(sm, preA);
+    __syncthreads();
+    float drain = 0.0f;
+    int cur = 0;
+    // LDS word offsets of this lane's operands (row k of a 2-row step; 0 and a zero mask for tiles / columns that do not exist)
+    const int nq = __builtin_amdgcn_readfirstlane(wave < ntiles ? (ntiles - wave + TG_WAVES - 1) / TG_WAVES : 0);       // tiles of this wave
+    int la[TG_MAXT], lb[TG_MAXT];
+#pragma unroll
+    for (int q = 0; q < TG_MAXT; ++q) {
+        la[q] = k * Ka + (offA[q] >= 0 ? offA[q] : 0);
+        lb[q] = na + k * Kb + (offB[q] >= 0 ? offB[q] : 0);
+    }
+    for (long long m = m0; m < m1; m += TL_ROWS) {
+        const bool more = m + TL_ROWS < m1;
+        if (more) fetch(m + TL_ROWS, preA);                             // global loads of the next chunk: in flight during this chunk's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const float *c_s = sm + cur * bufsz;
+        // the operands of step u + 1 are read from LDS while the MFMAs of step u run (an MFMA that waits for its own ds_read costs the LDS
+        // latency every time: 12 k cycles per chunk instead of 2.6 k)
+        float va[2][TG_MAXT], vb[2][TG_MAXT];
+#pragma unroll
+        for (int q = 0; q < TG_MAXT; ++q) { va[0][q] = c_s[la[q]]; vb[0][q] = c_s[lb[q]]; }
+#pragma unroll
+        for (int u = 0; u < TL_ROWS / 2; ++u) {
+            if (u + 1 < TL_ROWS / 2) {
+#pragma unroll
+                for (int q = 0; q < TG_MAXT; ++q) {
+                    va[(u + 1) & 1][q] = c_s[la[q] + 2 * (u + 1) * Ka];
+                    vb[(u + 1) & 1][q] = c_s[lb[q] + 2 * (u + 1) * Kb];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                          // (hipcc would sink the reads behind this step's MFMAs and wait for them at once)
+#pragma unroll
+            for (int q = 0; q < TG_MAXT; ++q)
+                if (q < nq)                                             // wave-uniform: tiles this wave does not have cost no matrix-pipe time
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(offA[q] >= 0 ? va[u & 1][q] : 0.0f, offB[q] >= 0 ? vb[u & 1][q] : 0.0f, acc[q], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < TG_MAXT; ++q) drain += acc[q][15];          // every MFMA of the chunk has completed
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stash(sm + (cur ^ 1) * bufsz, preA);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (drain == 1.2345e-30f && P == nullptr) P[0] = drain;             // keeps `drain` alive; never true
+#pragma unroll
+    for (int q = 0; q < TG_MAXT; ++q) {
+        const int t = wave + q * TG_WAVES;
+        if (t >= ntiles) continue;
+        const int rb = t / ncb, cb = t - rb * ncb;
+        const int col = cb * 32 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * k;
+            if (row < Ka && col < Kb) P[((size_t)blockIdx.x * Ka + row) * Kb + col] = acc[q][r];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ fp16-split variant (-DTVR_GEMM_F32=0; NOT the default)
 // Same reduction on v_mfma_f32_32x32x16_f16 with both operands split into fp16 hi + lo and three products per 16-row step (tvr_mfma.h;
 // error ~2^-22 relative, fp32-grade): 96 MFMA cycles per 16 rows and tile instead of 512, which moves the kernel from the fp32 matrix
@@ -98,6 +260,9 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
 // (An fp32 kernel with this wave-owns-a-block fragment sharing was also tried: 0.63 vs 0.26 ms at 356 000 x 128 x 128 — slower, removed.)
 #ifndef TVR_GEMM_F32
 #define TVR_GEMM_F32 1
+#endif
+#ifndef TVR_GEMM_LDS
+#define TVR_GEMM_LDS 1
 #endif
 
 struct Rows8 {
@@ -236,7 +401,13 @@ hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int l
     const int lds = 64 * 1024;                                     // unused; caps the CU at two workgroups (see header)
     hipError_t rc = hipFuncSetAttribute((const void *)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
-    if (TVR_GEMM_F32) {
+    if (TVR_GEMM_F32 && TVR_GEMM_LDS && TL_ROWS * (Ka + Kb) <= 256 * TL_PF) {          // (a 20 x 1 tile product, e.g. a column sum, has up to 672 columns: old kernel)
+        const int lds2 = 2 * ((TL_ROWS * (Ka + Kb) + 3) & ~3) * (int)sizeof(float);       // <= 40 KB
+        // 16-B loads need contiguous rows (a chunk is then one flat run of floats) and 16-B aligned chunk starts (TL_ROWS * K * 4 B is)
+        const bool vec4 = lda == Ka && ldb == Kb && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
+        if (vec4) hipLaunchKernelGGL((gemm_tn_lds_kernel<true>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb);
+        else hipLaunchKernelGGL((gemm_tn_lds_kernel<false>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb);
+    } else if (TVR_GEMM_F32) {
         hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb);
     } else {
         rc = hipFuncSetAttribute((const void *)gemm_tn_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -109,6 +109,26 @@ def test_gemm_tn_matches_fp64(M, Ka, Kb):
         assert L.lib().tvr_gemm_tn(A.data_ptr(), Ka, Ka, B.data_ptr(), Kb, Kb, M, out.data_ptr(), sc.data_ptr(), 16, None) == -3          # scratch too small
 
 
+@pytest.mark.parametrize("M,Ka,Kb,lda,ldb,offa,offb", [(60_001, 128, 123, 128, 283, 0, 160), (33_333, 96, 160, 200, 283, 7, 0), (20_011, 640, 1, 640, 1, 0, 0),
+                                                        (5_003, 150, 128, 150, 128, 0, 0), (16, 150, 128, 150, 128, 0, 0), (31, 30, 2, 30, 2, 0, 0)])
+def test_gemm_tn_strided_blocks_and_column_sums(M, Ka, Kb, lda, ldb, offa, offb):
+    """The shapes autograd_ops._gemm_tn / _colsum hand over: column blocks of wider matrices (row stride > row length, unaligned starts: the dword
+    staging path), a 20 x 1 tile column sum (the direct-load kernel), and short / odd row counts through the 16-B staging path's ragged end."""
+    from jittor_myc_nerfs_amd import _lib as L
+    g = torch.Generator(device="cuda").manual_seed(M + Ka + lda)
+    A = torch.randn((M, lda), device="cuda", generator=g)
+    B = torch.randn((M, ldb), device="cuda", generator=g)
+    out = torch.full((Ka, Kb), float("nan"), device="cuda")
+    sc = torch.empty(max(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb, M), 1), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().tvr_gemm_tn(A.data_ptr() + 4 * offa, lda, Ka, B.data_ptr() + 4 * offb, ldb, Kb, M, out.data_ptr(), sc.data_ptr(), sc.numel(), None), "tvr_gemm_tn")
+    ref = A[:, offa:offa + Ka].double().t() @ B[:, offb:offb + Kb].double()
+    err = float((out.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    assert err < 2e-6, err
+    out2 = torch.empty_like(out)
+    L.check(L.lib().tvr_gemm_tn(A.data_ptr() + 4 * offa, lda, Ka, B.data_ptr() + 4 * offb, ldb, Kb, M, out2.data_ptr(), sc.data_ptr(), sc.numel(), None), "tvr_gemm_tn")
+    assert torch.equal(out, out2)
+
+
 def test_fused_adam_updates_reach_the_packed_scene(tiny_arrays, hyper_tiny, tiny_dump):
     """torch.optim.Adam(fused=True) writes the parameters without bumping their version counters; the packed device scene must follow
     anyway (the training forward re-packs, and a backward invalidates the pack for whatever renders next)."""
