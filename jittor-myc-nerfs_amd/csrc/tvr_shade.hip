@@ -7,18 +7,17 @@
 // Design (CDNA4): every wave is an independent pipeline over 32 queue entries, entry = MFMA column (lane & 31), and the
 // whole chain stays in registers — no LDS round trip, no barrier in the tile loop.  Per tile a wave runs two phases:
 //   GATHER phase (global loads + VALU + LDS, no MFMA)
-//     finish   the PREVIOUS tile's layer 3 + sigmoid + store: plain fp32 FMAs on the carried layer-2 accumulators (W3 as fp32 in LDS).
-//              It sits behind the issue of this tile's queue-entry loads, so it hides their latency, and it runs beside the
-//              partner wave's MFMAs instead of in this wave's matrix phase.
-//     gather   lane (e, h) fetches 8 channels (2 x float4) of each tap of entry e per k-step; the interpolated plane*line
-//              products ARE the B fragments of the basis product (9 k-steps, kept as fp16 hi/lo in 72 registers)
+//     gather   the queue entry arrives one tile ahead; lane (e, h) fetches 8 channels (2 x float4) of each tap of entry e per k-step; the
+//              interpolated plane*line products ARE the B fragments of the basis product (9 k-steps, kept as fp16 hi/lo in 72 registers);
+//              the phase ends with s_waitcnt vmcnt(0), then the wave takes its SIMD's matrix token (see TVR_MTOKEN)
 //   MATRIX phase (MFMA + LDS + VALU, no global load)
-//     basis    F^T[32 x 32e]   = Bas[32 x 144] · h^T          A (basis) fragments fetched at the end of the gather phase
+//     basis    F^T[32 x 32e]   = Bas[32 x 144] · h^T          A (basis) fragments: hi parts in LDS, lo parts fetched at the end of the gather phase
 //     L1       H^T[128 x 32e]  = W1[128 x 160] · X^T          A (weights) from LDS (resident for the workgroup's lifetime); the B
 //              fragments [v, sin v, sin 2v, cos v, cos 2v] of the 16 base values a lane owns are derived step by step between the
 //              MFMAs (W1's columns are permuted to this order at pack time; b1 is the column of a constant-1 input)
 //     L2       H2^T = W2 · relu(H^T): B = the layer-1 accumulators converted in place ("accumulator tile as the next MFMA's
-//              operand": the k order inside a step is a fixed permutation, folded into the packed weight columns)
+//              operand": the k order inside a step is a fixed permutation, folded into the packed weight columns); token handed over
+//   finish     layer 3 + sigmoid + store: plain fp32 FMAs on the layer-2 accumulators (W3 as fp32 in LDS), beside the partner's matrix phase
 // Arithmetic: v_mfma_f32_32x32x16_f16 with every fp32 operand split into fp16 hi + lo and three products per step
 // (hi·hi + hi·lo + lo·hi, fp32 accumulate): ~2^-22 relative error per product — fp32-class accuracy at 16/3 the rate of
 // the fp32-input MFMA.  Range: operands pass through fp16, so |x| <= 65504 (cvt_pkrtz saturates) and parts below 6e-8 flush;
@@ -49,20 +48,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #else
 #define TVR_STAMP(x)
 #endif
-#ifndef TVR_BASIS_LATE
-#define TVR_BASIS_LATE 0   // 1: fetch the basis fragments after the last tap evaluation instead of behind the last taps (measured equal: 15.5 vs 15.5 ms)
-#endif
-#ifndef TVR_DEFER
-#define TVR_DEFER 0        // 1: layer 3 + epilogue of a tile run in the next tile's gather phase; 0: behind its own matrix phase, after the matrix token
-                          //    is handed over (with the token: 12.55 vs 12.83 ms; without it 1 was better, 14.8 vs 15.3)
-#endif
-#ifndef TVR_APF
-#define TVR_APF 1         // 1: the weight fragments of hidden-layer k-step s + 1 are fetched from LDS during step s (32 more live registers);
-                          //    0 measured 15.2 vs 14.8 ms (and still no room for a tap ring of depth 2: one spill, 15.7)
-#endif
-#ifndef TVR_STAGGER
-#define TVR_STAGGER 0     // 1: the second wave of a SIMD starts half a tile late (round 1's way of getting one wave to gather while the other
-#endif                    //    multiplies; it does not last — see TVR_MTOKEN — and measures 12.85 vs 12.84 ms beside the token)
 #ifndef SH_WAVES
 #define SH_WAVES 8        // two waves per SIMD
 #endif
@@ -71,14 +56,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SH_TILE 32
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
-#ifndef TVR_NOPK
-#define TVR_NOPK 1        // 1: plain v_fma_f32 / v_mul_f32 instead of the packed-fp32 forms.  Twice the instructions and faster (14.5 vs 14.8 ms):
-#endif                    //    a packed op costs more than two plain ones beside the partner wave's MFMAs (cdna guide, cycle constants)
 #ifndef TVR_PRIO_G
 #define TVR_PRIO_G 2      // s_setprio while a wave is in its gather phase / its matrix phase.  The gather phase is a dependent chain of loads and
 #define TVR_PRIO_M 0      // short VALU bursts: when its instructions win arbitration against the partner's MFMA stream the tile takes 6 % less
 #endif                    // time (15.55 -> 14.75 ms); the opposite polarity costs 2 % (15.9).  Measured on one box, interleaved rounds.
-#if TVR_NOPK
+// (the packed forms v_pk_fma_f32 / v_pk_mul_f32: half the instructions and 2 % SLOWER — beside the partner wave's MFMA stream a packed fp32 op takes
+// 52.7 cycles instead of 4.6, scripts/hwprobe/valu_rate.hip)
 // two plain v_fma_f32 / v_mul_f32, each pinned by an empty asm (without the pins, and with the SLP vectoriser off: 12.92 vs 12.75 ms)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c)
 {
@@ -92,10 +75,6 @@ __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b)
     asm volatile("" : "+v"(x)); asm volatile("" : "+v"(y));
     return f32x2{x, y};
 }
-#else
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
-__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
-#endif
 
 // A fragments (hi, lo) of the four 32-row blocks of one k-step, from the LDS weight image
 struct AFrag4 { uint4 h[4], l[4]; };
@@ -232,7 +211,7 @@ __device__ __forceinline__ void sincos_pe(float x, float &s, float &c)
     c = __builtin_amdgcn_cosf(t);
 }
 
-// what a tile carries from its matrix phase into the next tile's gather phase, where layer 3 and the epilogue run
+// what a tile hands from its matrix phase to finish_tile (layer 3 + epilogue)
 struct Carry {
     f32x16 acc2[4];              // layer-2 accumulators (b2 included), hidden unit 32 rb + acc_row(r, h) in acc2[rb][r]
     long long ent;
@@ -303,7 +282,7 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 // multiplies): 13.9 -> 12.55 ms on one box, interleaved rounds.  Unequal matrix-phase priorities for the two waves instead: 14.0, no effect;
 // two tokens (basis + layer 1 | layer 2 as a two-stage pipeline): 12.98; spin back-off s_sleep 1 vs 8: equal; the token taken only at layer 1
 // (basis product outside it): 12.88; that plus all sin / cos in front of the token: 13.5 (12.97 same box); matrix-phase priority above
-// the gather's: 12.95; without the LDS prefetch of the weight fragments (TVR_APF 0): 13.2; the hidden layers' VALU / LDS work forced
+// the gather's: 12.95; without the one-step-ahead LDS prefetch of the weight fragments: 13.2; the hidden layers' VALU / LDS work forced
 // between their MFMAs one group per MFMA (sched_group_barrier: M vvv d M vvv d ... instead of hipcc's MMMM vvvvvvvvvvvvvv): 13.01 vs 12.95.
 // Every path takes the token after its last global load has landed and gives it back before the next tile's first load, at most once per tile:
 // a wave never waits for the token while holding it, so the spin always ends.
@@ -360,22 +339,13 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #if TVR_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-#if TVR_STAGGER
-    if (wave >= 4)
-        for (int i = 0; i < TVR_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     const unsigned char *W1H = smem + TVR_IMG_W1H, *W1L = smem + TVR_IMG_W1L;
     const unsigned char *W2H = smem + TVR_IMG_W2H, *W2L = smem + TVR_IMG_W2L;
     constexpr bool HAVE_G = REF && SRC != SH_SRC_FEAT;
-    Carry prev;
-    bool have_prev = false;
     const long long tile_stride = (long long)gridDim.x * SH_WAVES;
-#ifndef TVR_SHADE_XCD
-#define TVR_SHADE_XCD 1
-#endif
     // workgroups b, b + 8, ... share an XCD (and its 4 MB L2): give each XCD a contiguous eighth of every window of tiles, so that its L2
     // holds one stretch of the image row instead of all of it (speed only; correctness does not depend on the placement)
-    const unsigned lblk = TVR_SHADE_XCD ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;       // (measured neutral: 15.4 both ways)
+    const unsigned lblk = xcd_remap(blockIdx.x, gridDim.x);       // (measured neutral against the identity: 15.4 ms both ways)
     float4 qe_next = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned qray_next = 0;
     if (SRC == SH_SRC_QUEUE && n_total > 0) {
@@ -397,12 +367,6 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #endif
         TVR_STAMP(tg0);
         // ---------------------------------------------------------------- GATHER phase: global loads + VALU + LDS, no MFMA ----
-        if (DST != SH_DST_FEAT && have_prev) {
-            // the previous tile's last MFMAs wrote acc2[3]: reading it completes them before this tile's first global load
-#pragma unroll
-            for (int r = 0; r < 16; ++r) prev.acc2[3][r] = relu_f(prev.acc2[3][r]);
-            TVR_SB;
-        }
         TVR_STAMP(tgD);
         // queue entry: fetched one tile ahead (the loads are issued in the previous tile's gather phase and have landed by its phase
         // boundary), unconditionally (a dead lane of the last tile re-reads the last entry; nothing of it is stored)
@@ -413,10 +377,6 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             const long long le = en < n_total ? en : n_total - 1;
             qe_next = a.q_pos[le];
             qray_next = a.q_ray[le];
-        }
-        if (DST != SH_DST_FEAT && have_prev) {
-            finish_tile<DST, REF, HAVE_G>(prev, smem, a, h);
-            TVR_SB;
         }
         TVR_STAMP(tgF);
         if (SRC == SH_SRC_H) {
@@ -486,7 +446,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
                         load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx],
                                            4 * (s2 % 3) + 2 * h);
-                    } else if (s + TVR_PF == 9 + ((REF || TVR_BASIS_LATE) ? 1 : 0)) {      // (REFTensoRF: after the last evaluation — its extra live values leave no room earlier)
+                    } else if (s + TVR_PF == 9 + (REF ? 1 : 0)) {      // (REFTensoRF: after the last evaluation — its extra live values leave no room earlier)
                         // the basis A fragments (the tile's last global loads) ride behind the last taps
                         // (lo parts; the hi parts are in LDS.  Byte offsets against the uniform base, opaque per tile: hoisted per-step 64-bit
                         // addresses would spill)
@@ -503,7 +463,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     TVR_SB;
                 }
             }
-            if (REF || TVR_BASIS_LATE) {
+            if (REF) {
                 unsigned boff = (unsigned)((h * 32 + e) * 16);
                 asm volatile("" : "+v"(boff));
 #pragma unroll
@@ -625,21 +585,13 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             Frag bcur, bnxt;
             AFrag4 acur, anxt;
             l1_frag(0, bcur);
-#if TVR_APF
             load_afrag4(acur, W1H, W1L, rowoff, TVR_IMG_RB);
-#endif
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
-#if TVR_APF
                 if (s + 1 < 10) load_afrag4(anxt, W1H, W1L, rowoff + (s + 1) * TVR_IMG_STEP, TVR_IMG_RB);
-#else
-                load_afrag4(acur, W1H, W1L, rowoff + s * TVR_IMG_STEP, TVR_IMG_RB);
-#endif
                 if (s + 1 < 10) l1_frag(s + 1, bnxt);
                 mfma3x4(acur, bcur, acc);
-#if TVR_APF
                 acur = anxt;
-#endif
                 bcur = bnxt;
                 TVR_SB;
             }
@@ -669,21 +621,13 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             Frag bcur, bnxt;
             AFrag4 acur, anxt;
             relu_frag(0, bcur);
-#if TVR_APF
             load_afrag4(acur, W2H, W2L, rowoff, TVR_IMG_RB);
-#endif
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-#if TVR_APF
                 if (s + 1 < 8) load_afrag4(anxt, W2H, W2L, rowoff + (s + 1) * TVR_IMG_STEP, TVR_IMG_RB);
-#else
-                load_afrag4(acur, W2H, W2L, rowoff + s * TVR_IMG_STEP, TVR_IMG_RB);
-#endif
                 if (s + 1 < 8) relu_frag(s + 1, bnxt);
                 mfma3x4(acur, bcur, cur.acc2);
-#if TVR_APF
                 acur = anxt;
-#endif
                 bcur = bnxt;
                 TVR_SB;
             }
@@ -691,18 +635,12 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         cur.ent = ent; cur.live = live; cur.wq = wq;
         cur.g[0] = G[3]; cur.g[1] = G[4]; cur.g[2] = G[5]; cur.g[3] = G[6];
         TVR_LEAVE_MATRIX();
-#if TVR_DEFER
-        prev = cur;
-        have_prev = true;
-#else
         finish_tile<DST, REF, HAVE_G>(cur, smem, a, h);
-#endif
         TVR_STAMP(tg4);
 #if TVR_TIMING
         tsum[0] += tgF - tgD; tsum[5] += tgD - tg0; tsum[1] += tg1 - tgF; tsum[6] += tgW - tg1; tsum[2] += tg2 - tgW; tsum[3] += tg3 - tg2; tsum[4] += tg4 - tg3;
 #endif
     }
-    if (DST != SH_DST_FEAT && have_prev) finish_tile<DST, REF, HAVE_G>(prev, smem, a, h);
 #if TVR_TIMING
     if (a.stats && lane == 0)
         for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // finish, gather, basis, L1 (+PE), L2, MFMA drain, wait for the matrix token
