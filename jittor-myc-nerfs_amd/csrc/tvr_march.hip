@@ -502,7 +502,9 @@ hipError_t launch_march(const SceneDev &sc, const float *rays, int n_rays, int S
     const int n_tiles = (n_rays + MARCH_TILE - 1) / MARCH_TILE;
     // one group per CU when it holds 16 waves; proportionally more groups when the lists force smaller ones
     long long grid = (long long)device_cu_count() * (16 / waves > 0 ? 16 / waves : 1);
-    if (const char *g = getenv("TVR_EXP_GRID_MARCH")) { const long long v = atoll(g); if (v > 0 && v < grid) grid = v; }   // scripts/overlap_experiment.py only
+#ifdef TVR_EXP_GRID                                             // scripts/overlap_experiment.py only: a build_variant.sh -DTVR_EXP_GRID library
+    if (const char *g = getenv("TVR_EXP_GRID_MARCH")) { const long long v = atoll(g); if (v > 0 && v < grid) grid = v; }
+#endif
     if (grid > n_tiles) grid = n_tiles;
     if (grid < 1) grid = 1;
     tvr_dense_out none = {};

@@ -656,7 +656,9 @@ static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStre
     hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
     unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
-    if (const char *g = getenv("TVR_EXP_GRID_SHADE")) { const long long v = atoll(g); if (v > 0 && v < 256) grid = (unsigned)v; }   // scripts/overlap_experiment.py only
+#ifdef TVR_EXP_GRID                                             // scripts/overlap_experiment.py only: a build_variant.sh -DTVR_EXP_GRID library
+    if (const char *g = getenv("TVR_EXP_GRID_SHADE")) { const long long v = atoll(g); if (v > 0 && v < 256) grid = (unsigned)v; }
+#endif
     if (SRC != SH_SRC_QUEUE) {
         const long long groups = (a.n + SH_TILE * SH_WAVES - 1) / (SH_TILE * SH_WAVES);
         if (groups < grid) grid = (unsigned)(groups > 0 ? groups : 1);

@@ -6,7 +6,8 @@ workgroup cannot share a CU; the only way to run them side by side is on disjoin
 This script renders one 800x800 frame as K ray batches
   serial   : one stream, full grids (what tvr_render does per batch)
   overlap  : two streams (batch i on stream i % 2, own scratch each), grids limited to G_march + G_shade <= 256 through the
-             TVR_EXP_GRID_* experiment hooks, so that march(i+1) and shade(i) can be resident together
+             TVR_EXP_GRID_* experiment hooks, so that march(i+1) and shade(i) can be resident together.  The hooks exist only in a library built
+             with them:  scripts/build_variant.sh expgrid -DTVR_EXP_GRID ; TVR_LIB_PATH=.../lib/variants/libtvr_expgrid.so python scripts/overlap_experiment.py
 and prints wall times (median of 7 repetitions)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
