@@ -104,6 +104,10 @@ struct Taps {
     float4 t[4][2], lv[2][2];
 };
 
+// first float4 of the two this lane fetches from a texel (12 float4 = 48 channels) in k-step t of a plane.  (Measured alternative: lane half 0
+// takes float4s 0..5 and half 1 float4s 6..11 of the texel, so that a load instruction touches every 64-B segment once instead of from both
+// halves of the wave — 12.77 vs 12.70 ms, no gain: the ray-sorted queue already coalesces.)
+#define TVR_Q0(t, h) (4 * (t) + 2 * (h))
 template <bool CHECK>
 __device__ __forceinline__ void load_taps(Taps &T, const float4 *__restrict__ P, const float4 *__restrict__ Ln, int W, int H, int L,
                                           float fx, float fy, float fl, int q0)
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 for (int s0 = 0; s0 < TVR_PF; ++s0) {
                     const int p = s0 / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
-                    load_taps<TVR_CHK>(T[s0], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], 4 * (s0 % 3) + 2 * h);
+                    load_taps<TVR_CHK>(T[s0], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], TVR_Q0(s0 % 3, h));
                 }
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         const int s2 = s + TVR_PF, p = s2 / 3;
                         const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
                         load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx],
-                                           4 * (s2 % 3) + 2 * h);
+                                           TVR_Q0(s2 % 3, h));
                     } else if (s + TVR_PF == 9 + (REF ? 1 : 0)) {      // (REFTensoRF: after the last evaluation — its extra live values leave no room earlier)
                         // the basis A fragments (the tile's last global loads) ride behind the last taps
                         // (lo parts; the hi parts are in LDS.  Byte offsets against the uniform base, opaque per tile: hoisted per-step 64-bit
