@@ -474,6 +474,9 @@ def main():
     roof_shade = {"kernel": "shade_kernel<0,0,%s>" % ("true" if args.model == "REFTensoRF" else "false"), "bound": "mfma", "achieved": ach_shade,
                   "peak": 2500.0, "unit": "TFLOP/s", "frac": ach_shade / 2500.0 if ach_shade else None,
                   "frac_vs_fp32class_ceiling": ach_shade / (2500.0 / 3.0) if ach_shade else None,
+                  # what the matrix pipe sustains on toggling operands (power envelope): scripts/hwprobe/mfma_clock.hip, profiles/r02_mfma_clock_probe.txt
+                  "sustained_mfma_TFLOPs": 1704.0, "frac_vs_sustained_mfma": ach_shade / 1704.0 if ach_shade else None,
+                  "executed_frac_vs_sustained_mfma": FLOP_APP_EXEC * m_app / t_shade / 1e12 / 1704.0 if t_shade > 0 else None,
                   "traffic": hbm(ps), "algorithmic_flops_per_launch": FLOP_APP * m_app, "ms": k_ms[1],
                   "executed_mfma_TFLOPs": FLOP_APP_EXEC * m_app / t_shade / 1e12 if t_shade > 0 else None,
                   "gather_algorithmic_GBps": 3456.0 * m_app / t_shade / 1e9 if t_shade > 0 else None,
