@@ -197,6 +197,18 @@ def test_full_size_properties_config2():
     calls = [m.render_rays(rays[c0:c0 + 4096], white_bg=True, N_samples=A["N_samples"]) for c0 in range(0, rays.shape[0], 4096)]
     assert len(calls) == 157 and calls[-1][0].shape[0] == 640000 - 156 * 4096
     assert torch.equal(torch.cat([c[0] for c in calls]), rgb) and torch.equal(torch.cat([c[1] for c in calls]), depth)
+    # batch-order invariance at full size: a random permutation of the rays gives the permuted image, bit for bit (which 32-entry tile, lane,
+    # wave or workgroup a sample lands in does not matter; neither does which wave holds a SIMD's matrix token when)
+    perm = torch.randperm(640000, generator=torch.Generator().manual_seed(7)).cuda()
+    rgb_p, depth_p = m.render_rays(rays[perm].contiguous(), white_bg=True, N_samples=A["N_samples"])
+    assert torch.equal(rgb_p, rgb[perm]) and torch.equal(depth_p, depth[perm])
+    # black background: the same weights, so rgb_white - rgb_black = 1 - acc on every channel wherever neither image is clamped
+    rgb_k, depth_k = m.render_rays(rays, white_bg=False, N_samples=A["N_samples"])
+    assert torch.equal(depth_k, depth)
+    d = rgb - rgb_k
+    free = ((rgb < 1.0) & (rgb_k > 0.0)).all(dim=1)
+    assert int(free.sum()) > 100000
+    assert float((d[free] - d[free][:, :1]).abs().max()) < 1e-6 and float(d[free].min()) > -1e-6
     # oracle on a random subset
     sel = torch.randperm(640000, generator=torch.Generator().manual_seed(1))[:192]
     sc = TO.scene_from_arrays(arrs, **hyper)
