@@ -41,11 +41,12 @@ typedef struct tvr_profile tvr_profile;
 typedef struct {
     float aabb[6];                 /* lo[3], hi[3] */
     int32_t grid[3];               /* gridSize (x, y, z) */
-    int32_t density_n_comp[3];     /* must be 16 each in this build */
-    int32_t app_n_comp[3];         /* must be 48 each in this build */
+    int32_t density_n_comp[3];     /* 1..16 per plane (the kernels are built for 16; fewer are packed with zero channels, exact) */
+    int32_t app_n_comp[3];         /* 1..48 per plane (built for 48; zero-padded likewise) */
     int32_t app_dim;               /* 27 */
-    int32_t featureC;              /* 128 */
-    int32_t view_pe, fea_pe;       /* 2, 2  (shadingMode MLP_Fea) */
+    int32_t featureC;              /* 1..128 (built for 128; hidden units that do not exist are zero weights) */
+    int32_t view_pe, fea_pe;       /* 0..2 each (shadingMode MLP_Fea; built for 2, 2).  variant 1 (REFTensoRF): the built-for shape only.
+                                    * Anything larger: TVR_ERR_UNSUPPORTED from tvr_scene_packed_bytes / tvr_scene_create */
     float near_, far_;             /* near_far */
     float step_size;               /* stepSize = mean(units)*step_ratio, computed by the host in fp32 */
     float inv_aabb_size[3];        /* invaabbSize = 2/(hi-lo), computed by the host in fp32 (:201) */
@@ -61,8 +62,9 @@ typedef struct {
 typedef struct {
     const float *density_plane[3], *density_line[3];
     const float *app_plane[3], *app_line[3];
-    const float *basis_mat;              /* [app_dim, 144] */
-    const float *W1, *b1, *W2, *b2, *W3, *b3;   /* W1 [128,150]; variant 1: [128,151] (MLPRender_Fea_Ref, REFTensoRF.py:9-16) */
+    const float *basis_mat;              /* [app_dim, sum(app_n_comp)]  (144 columns at the built-for shape) */
+    const float *W1, *b1, *W2, *b2, *W3, *b3;   /* W1 [featureC, 30 + 54 fea_pe + 6 view_pe] = [128,150]; variant 1: [128,151] (MLPRender_Fea_Ref, REFTensoRF.py:9-16);
+                                                 * W2 [featureC,featureC], W3 [3,featureC] */
     /* variant 1 only (REFTensoRF.init_svd_volume, REFTensoRF.py:86-96): normal_linear [3,144], diffuse_linear [3,144],
      * specular_linear [1,144], rho_linear [1,144] and their biases, in that order */
     const float *ref_W[4], *ref_b[4];

@@ -216,7 +216,7 @@ class _AppHFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, xyz, *app_params):
         sc = model._ensure_scene()
-        h = torch.empty((xyz.shape[0], sum(model.app_n_comp)), dtype=torch.float32, device=model.device)
+        h = torch.empty((xyz.shape[0], 144), dtype=torch.float32, device=model.device)       # the kernels' layout: 3 planes x 48 channels (zero behind a plane's own components)
         L.check(L.lib().tvr_app_h_forward(sc, xyz.data_ptr(), xyz.shape[0], h.data_ptr(), _stream_ptr(model.device)), "tvr_app_h_forward")
         ctx.model, ctx.xyz = model, xyz
         ctx.shapes = [p.shape for p in app_params]

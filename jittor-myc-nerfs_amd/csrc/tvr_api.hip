@@ -74,13 +74,21 @@ static int check_desc(const tvr_scene_desc *d)
     if (!d) return fail(TVR_ERR_INVALID, "desc is NULL");
     for (int i = 0; i < 3; ++i) {
         if (d->grid[i] < 2 || d->grid[i] > 4096) return fail(TVR_ERR_INVALID, "grid[%d]=%d out of [2,4096]", i, d->grid[i]);
-        if (d->density_n_comp[i] != TVR_CD) return fail(TVR_ERR_UNSUPPORTED, "density_n_comp[%d]=%d; this build supports %d", i, d->density_n_comp[i], TVR_CD);
-        if (d->app_n_comp[i] != TVR_CA) return fail(TVR_ERR_UNSUPPORTED, "appearance_n_comp[%d]=%d; this build supports %d", i, d->app_n_comp[i], TVR_CA);
+        // fewer components / narrower layers than the kernels are built for are packed with zero padding (exact); more are not supported
+        if (d->density_n_comp[i] < 1 || d->density_n_comp[i] > TVR_CD)
+            return fail(TVR_ERR_UNSUPPORTED, "density_n_comp[%d]=%d; this build supports 1..%d", i, d->density_n_comp[i], TVR_CD);
+        if (d->app_n_comp[i] < 1 || d->app_n_comp[i] > TVR_CA)
+            return fail(TVR_ERR_UNSUPPORTED, "appearance_n_comp[%d]=%d; this build supports 1..%d", i, d->app_n_comp[i], TVR_CA);
         if (!(d->aabb[3 + i] > d->aabb[i])) return fail(TVR_ERR_INVALID, "aabb hi <= lo on axis %d", i);
     }
-    if (d->app_dim != TVR_APPDIM || d->featureC != TVR_FEATC || d->view_pe != 2 || d->fea_pe != 2)
-        return fail(TVR_ERR_UNSUPPORTED, "MLP_Fea shape app_dim=%d featureC=%d view_pe=%d fea_pe=%d; this build supports 27/128/2/2",
+    if (d->app_dim != TVR_APPDIM || d->featureC < 1 || d->featureC > TVR_FEATC || d->view_pe < 0 || d->view_pe > 2 || d->fea_pe < 0 || d->fea_pe > 2)
+        return fail(TVR_ERR_UNSUPPORTED, "MLP_Fea shape app_dim=%d featureC=%d view_pe=%d fea_pe=%d; this build supports app_dim 27, featureC 1..128, view_pe / fea_pe 0..2",
                     d->app_dim, d->featureC, d->view_pe, d->fea_pe);
+    if (d->variant == 1) {
+        bool std_shape = d->featureC == TVR_FEATC && d->view_pe == 2 && d->fea_pe == 2;
+        for (int i = 0; i < 3; ++i) std_shape = std_shape && d->density_n_comp[i] == TVR_CD && d->app_n_comp[i] == TVR_CA;
+        if (!std_shape) return fail(TVR_ERR_UNSUPPORTED, "REFTensoRF scenes are supported at 16 / 48 components, featureC 128, view_pe = fea_pe = 2 only");
+    }
     if (d->fea2dense_act != 0 && d->fea2dense_act != 1) return fail(TVR_ERR_INVALID, "fea2dense_act must be 0 or 1");
     if (d->variant != 0 && d->variant != 1) return fail(TVR_ERR_INVALID, "variant must be 0 (TensorVMSplit) or 1 (REFTensoRF)");
     if (!(d->step_size > 0.0f)) return fail(TVR_ERR_INVALID, "step_size must be > 0");
@@ -151,21 +159,25 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
         if (!p->density_plane[i] || !p->density_line[i] || !p->app_plane[i] || !p->app_line[i])
             return fail(TVR_ERR_INVALID, "plane/line pointer %d is NULL", i);
         const int W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
-        HIP_TRY(launch_pack_plane(p->density_plane[i], (float *)(s->packed + s->lay.dplane[i]), TVR_CD, H, W, stream));
-        HIP_TRY(launch_pack_plane(p->density_line[i], (float *)(s->packed + s->lay.dline[i]), TVR_CD, Ln, 1, stream));
-        HIP_TRY(launch_pack_plane(p->app_plane[i], (float *)(s->packed + s->lay.aplane[i]), TVR_CA, H, W, stream));
-        HIP_TRY(launch_pack_plane(p->app_line[i], (float *)(s->packed + s->lay.aline[i]), TVR_CA, Ln, 1, stream));
+        HIP_TRY(launch_pack_plane(p->density_plane[i], (float *)(s->packed + s->lay.dplane[i]), d.density_n_comp[i], TVR_CD, H, W, stream));
+        HIP_TRY(launch_pack_plane(p->density_line[i], (float *)(s->packed + s->lay.dline[i]), d.density_n_comp[i], TVR_CD, Ln, 1, stream));
+        HIP_TRY(launch_pack_plane(p->app_plane[i], (float *)(s->packed + s->lay.aplane[i]), d.app_n_comp[i], TVR_CA, H, W, stream));
+        HIP_TRY(launch_pack_plane(p->app_line[i], (float *)(s->packed + s->lay.aline[i]), d.app_n_comp[i], TVR_CA, Ln, 1, stream));
     }
     if (!p->basis_mat || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3) return fail(TVR_ERR_INVALID, "MLP pointer is NULL");
     char *img = s->packed + s->lay.mlp_image;
-    HIP_TRY(launch_pack_mlp(p->W1, p->b1, img + TVR_IMG_W1H, img + TVR_IMG_W1L, d.variant == 1 ? 4 : 0, stream));
-    HIP_TRY(launch_pack_mlp(p->W2, nullptr, img + TVR_IMG_W2H, img + TVR_IMG_W2L, 1, stream));
-    HIP_TRY(hipMemsetAsync(img + TVR_IMG_B1, 0, TVR_FEATC * sizeof(float), stream));
+    MlpShape sh;
+    sh.featureC = d.featureC; sh.fea_pe = d.fea_pe; sh.view_pe = d.view_pe;
+    sh.n_in = TVR_APPDIM + 3 + 2 * TVR_APPDIM * d.fea_pe + 6 * d.view_pe + (d.variant == 1 ? 1 : 0);
+    sh.k_app = 0;
+    for (int i = 0; i < 3; ++i) { sh.app_n_comp[i] = d.app_n_comp[i]; sh.app_off[i] = sh.k_app; sh.k_app += d.app_n_comp[i]; }
+    HIP_TRY(launch_pack_mlp(p->W1, p->b1, img + TVR_IMG_W1H, img + TVR_IMG_W1L, d.variant == 1 ? 4 : 0, sh, stream));
+    HIP_TRY(launch_pack_mlp(p->W2, nullptr, img + TVR_IMG_W2H, img + TVR_IMG_W2L, 1, sh, stream));
+    HIP_TRY(hipMemsetAsync(img + TVR_IMG_B1, 0, 2 * 512 + 4 * TVR_IMG_W3_ROW, stream));       // b3 slot, b2, W3 + zero row: hidden units >= featureC stay zero
     HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B2, p->b2, TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(launch_pack_mlp(p->basis_mat, nullptr, img + TVR_IMG_BASH, s->packed + s->lay.basis_frag, 2, stream));
-    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_W3, p->W3, 3 * TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemsetAsync(img + TVR_IMG_W3 + 3 * TVR_IMG_W3_ROW, 0, TVR_IMG_W3_ROW, stream));
+    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B2, p->b2, d.featureC * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(launch_pack_mlp(p->basis_mat, nullptr, img + TVR_IMG_BASH, s->packed + s->lay.basis_frag, 2, sh, stream));
+    HIP_TRY(hipMemcpy2DAsync(img + TVR_IMG_W3, TVR_IMG_W3_ROW, p->W3, d.featureC * sizeof(float), d.featureC * sizeof(float), 3, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(s->packed + s->lay.b3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemsetAsync(img + TVR_MLP_IMAGE_BYTES, 0, TVR_MLP_IMAGE_BYTES_REF - TVR_MLP_IMAGE_BYTES, stream));
     if (d.variant == 1) {
@@ -435,8 +447,8 @@ static int march_backward_impl(tvr_scene *s, const float *rays, int64_t n_rays, 
     for (int i = 0; i < 3; ++i) {
         if (!out->density_plane[i] || !out->density_line[i]) return fail(TVR_ERR_INVALID, "density gradient pointer %d is NULL", i);
         const int W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
-        HIP_TRY(launch_unpack_grad(tg.dplane[i], out->density_plane[i], TVR_CD, H, W, stream));
-        HIP_TRY(launch_unpack_grad(tg.dline[i], out->density_line[i], TVR_CD, Ln, 1, stream));
+        HIP_TRY(launch_unpack_grad(tg.dplane[i], out->density_plane[i], s->desc.density_n_comp[i], TVR_CD, H, W, stream));
+        HIP_TRY(launch_unpack_grad(tg.dline[i], out->density_line[i], s->desc.density_n_comp[i], TVR_CD, Ln, 1, stream));
     }
     return TVR_OK;
 }
@@ -480,6 +492,13 @@ int tvr_mlp_train_forward(tvr_scene *s, const float *h, const float *viewdirs, i
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
     if (s->desc.variant != 0) return fail(TVR_ERR_UNSUPPORTED, "tvr_mlp_train_forward: TensorVMSplit scenes only (REFTensoRF trains through the library-GEMM path)");
+    {
+        const tvr_scene_desc &d = s->desc;
+        bool std_shape = d.featureC == TVR_FEATC && d.view_pe == 2 && d.fea_pe == 2;
+        for (int i = 0; i < 3; ++i) std_shape = std_shape && d.app_n_comp[i] == TVR_CA;
+        if (!std_shape) return fail(TVR_ERR_UNSUPPORTED, "tvr_mlp_train_forward: the fused training kernels take 48 appearance components, featureC 128, view_pe = fea_pe = 2 "
+                                                         "(zero-padded shapes train through the library-GEMM path)");
+    }
     if (m == 0) return TVR_OK;
     if (!h || !viewdirs || !rgb || !feats32 || !h1 || !h2 || m < 0) return fail(TVR_ERR_INVALID, "NULL argument or m < 0");
     if (((uintptr_t)h | (uintptr_t)feats32 | (uintptr_t)h1 | (uintptr_t)h2) % 16) return fail(TVR_ERR_INVALID, "h / feats32 / h1 / h2 must be 16-byte aligned");
@@ -525,8 +544,8 @@ int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *d
     for (int i = 0; i < 3; ++i) {
         if (!out->app_plane[i] || !out->app_line[i]) return fail(TVR_ERR_INVALID, "appearance gradient pointer %d is NULL", i);
         const int W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
-        HIP_TRY(launch_unpack_grad(tg.aplane[i], out->app_plane[i], TVR_CA, H, W, stream));
-        HIP_TRY(launch_unpack_grad(tg.aline[i], out->app_line[i], TVR_CA, Ln, 1, stream));
+        HIP_TRY(launch_unpack_grad(tg.aplane[i], out->app_plane[i], s->desc.app_n_comp[i], TVR_CA, H, W, stream));
+        HIP_TRY(launch_unpack_grad(tg.aline[i], out->app_line[i], s->desc.app_n_comp[i], TVR_CA, Ln, 1, stream));
     }
     return TVR_OK;
 }

@@ -211,14 +211,23 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
 // accumulator register r of lane half h  <->  row of the 32x32 tile
 __device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// reference input index (tensorBase.py:77-82 concat order) of derived value t of base value c; -1 = zero weight
-__device__ __forceinline__ int ref_in_index(int c, int t)
+// reference input index (tensorBase.py:77-82 concat order [features, viewdirs, PE(features, fea_pe), PE(viewdirs, view_pe)], PE = [sin | cos] with
+// entry Ff*c + f inside each, tensorBase.py:9-15) of derived value t (0: v, 1: sin v, 2: sin 2v, 3: cos v, 4: cos 2v) of base value c
+// (0..26 features, 27..29 view direction); -1 = the reference network has no such input (fea_pe / view_pe < 2): zero weight
+__host__ __device__ __forceinline__ int ref_in_index(int c, int t, int fea_pe, int view_pe)
 {
-    if (c < TVR_APPDIM) return t == 0 ? c : (t == 1 ? 30 + 2 * c : (t == 2 ? 31 + 2 * c : (t == 3 ? 84 + 2 * c : 85 + 2 * c)));
+    const int f = (t == 2 || t == 4) ? 1 : 0, is_cos = t >= 3;
+    const int off1 = TVR_APPDIM + 3, off2 = off1 + 2 * TVR_APPDIM * fea_pe;
+    if (c < TVR_APPDIM) {
+        if (t == 0) return c;
+        return f < fea_pe ? off1 + (is_cos ? TVR_APPDIM * fea_pe : 0) + fea_pe * c + f : -1;
+    }
     if (c < TVR_APPDIM + 3) {
         const int d = c - TVR_APPDIM;
-        return t == 0 ? 27 + d : (t == 1 ? 138 + 2 * d : (t == 2 ? 139 + 2 * d : (t == 3 ? 144 + 2 * d : 145 + 2 * d)));
+        if (t == 0) return TVR_APPDIM + d;
+        return f < view_pe ? off2 + (is_cos ? 3 * view_pe : 0) + view_pe * d + f : -1;
     }
     return -1;
 }
+__host__ __device__ __forceinline__ int ref_in_index(int c, int t) { return ref_in_index(c, t, 2, 2); }
 

@@ -63,15 +63,20 @@ hipError_t launch_scatter_rgb(const MarchOut &mo, int S, float *rgb_dense, hipSt
 hipError_t launch_density_feature(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream);
 hipError_t launch_alpha_sample(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream);
 hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream);
-hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, hipStream_t stream);
-hipError_t launch_pack_mlp(const float *W, const float *bias, void *out_hi, void *out_lo, int mode, hipStream_t stream);
+hipError_t launch_pack_plane(const float *in, float *out, int Cin, int C, int H, int W, hipStream_t stream);
+// the scene's MLP_Fea / basis shape as the reference holds it (<= the shape the kernels are built for; packed with zero padding)
+struct MlpShape {
+    int featureC, fea_pe, view_pe, n_in;          // n_in = 30 + 54 fea_pe + 6 view_pe (+ 1 for REFTensoRF)
+    int app_n_comp[3], app_off[3], k_app;         // basis_mat is [27][k_app], k_app = sum app_n_comp
+};
+hipError_t launch_pack_mlp(const float *W, const float *bias, void *out_hi, void *out_lo, int mode, const MlpShape &sh, hipStream_t stream);
 hipError_t launch_pack_ref(const float *const W[4], const float *const b[4], void *rows, float *bias, hipStream_t stream);
 hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T, const MarchOut &mo,
                                  const float *grad_w, const float *grad_acc, const float *lam6, const float *grad_lam6, const TrainGrads &tg,
                                  hipStream_t stream);
 hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream);
 hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream);
-hipError_t launch_unpack_grad(const float *in, float *out, int C, int H, int W, hipStream_t stream);
+hipError_t launch_unpack_grad(const float *in, float *out, int Cout, int C, int H, int W, hipStream_t stream);
 hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream);
 size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M);
 hipError_t launch_pe_concat(const float *feat, const float *dir, const float *dot, long long m, float *X, hipStream_t stream);

@@ -687,25 +687,26 @@ hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a
 }
 
 // ---- scene packing (reference layout -> channels-last, zero-padded) ----
-// in (C,H,W) -> out [H+1][W+1][C]; a line (W == 1) packs to [H+1][C]
-__global__ __launch_bounds__(256) void pack_plane_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int H, int W, int Wp)
+// in (Cin,H,W) -> out [H+1][W+1][C]; a line (W == 1) packs to [H+1][C].  Cin <= C: a scene with fewer components than the kernels are built
+// for (TensorBase's defaults are 8 / 24) is packed with zero channels, which contribute exact zeros to every sum
+__global__ __launch_bounds__(256) void pack_plane_kernel(const float *__restrict__ in, float *__restrict__ out, int Cin, int C, int H, int W, int Wp)
 {
     const long long total = (long long)(H + 1) * Wp * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const long long t = i / C;
         const int x = (int)(t % Wp), y = (int)(t / Wp);
-        out[i] = (x < W && y < H) ? in[((size_t)c * H + y) * W + x] : 0.0f;
+        out[i] = (x < W && y < H && c < Cin) ? in[((size_t)c * H + y) * W + x] : 0.0f;
     }
 }
 
-hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, hipStream_t stream)
+hipError_t launch_pack_plane(const float *in, float *out, int Cin, int C, int H, int W, hipStream_t stream)
 {
     const int Wp = (W == 1) ? 1 : W + 1;
     const long long total = (long long)(H + 1) * Wp * C;
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_plane_kernel, dim3(grid), dim3(256), 0, stream, in, out, C, H, W, Wp);
+    hipLaunchKernelGGL(pack_plane_kernel, dim3(grid), dim3(256), 0, stream, in, out, Cin, C, H, W, Wp);
     return hipGetLastError();
 }
 
@@ -717,8 +718,10 @@ hipError_t launch_pack_plane(const float *in, float *out, int C, int H, int W, h
 //  (layer 3 runs as fp32 FMAs: W3 [3][128] fp32 and b3 are copied into the LDS image as they are, tvr_api.hip)
 //  mode 4: mode 0 for MLPRender_Fea_Ref (REFTensoRF.py:19-24: [dot, features, viewdirs, PE(features), PE(viewdirs)], 151 inputs):
 //          every index moves up by one and base row 30's plain slot carries input 0 (dot)
+// Shapes smaller than the kernels' (hidden width < 128, fea_pe / view_pe < 2, fewer appearance components) are packed with zero weights:
+// a hidden unit that does not exist outputs relu(0) = 0 and feeds zero columns, an input that does not exist has a zero column.
 __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__ W, const float *__restrict__ bias,
-                                                       unsigned short *__restrict__ out_hi, unsigned short *__restrict__ out_lo, int mode)
+                                                       unsigned short *__restrict__ out_hi, unsigned short *__restrict__ out_lo, int mode, const MlpShape sh)
 {
     const int nrows = (mode <= 1 || mode == 4) ? 128 : (mode == 2 ? 32 : 4);
     const int K = (mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : 128);
@@ -729,18 +732,20 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
     float w = 0.0f;
     if (mode == 0) {
         const int ii = 8 * s + j;
-        const int c = acc_row(ii / 5, hh), idx = ref_in_index(c, ii % 5);
-        if (idx >= 0) w = W[(size_t)row * TVR_NIN + idx];
-        if (c == 31 && ii % 5 == 0) w = bias[row];                 // the constant-1 input (base row 31): b1 rides in the weight image
+        const int c = acc_row(ii / 5, hh), idx = ref_in_index(c, ii % 5, sh.fea_pe, sh.view_pe);
+        if (idx >= 0 && row < sh.featureC) w = W[(size_t)row * sh.n_in + idx];
+        if (c == 31 && ii % 5 == 0 && row < sh.featureC) w = bias[row];      // the constant-1 input (base row 31): b1 rides in the weight image
     } else if (mode == 4) {
         const int ii = 8 * s + j, c = acc_row(ii / 5, hh), t = ii % 5;
         const int idx = (c == TVR_APPDIM + 3) ? (t == 0 ? 0 : -1) : (ref_in_index(c, t) >= 0 ? ref_in_index(c, t) + 1 : -1);
         if (idx >= 0) w = W[(size_t)row * TVR_NIN_REF + idx];
         if (c == 31 && t == 0) w = bias[row];
     } else if (mode == 1) {
-        w = W[(size_t)row * TVR_FEATC + (16 * s + 8 * (j >> 2) + 4 * hh + (j & 3))];
+        const int u = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+        if (row < sh.featureC && u < sh.featureC) w = W[(size_t)row * sh.featureC + u];
     } else if (mode == 2) {
-        if (row < TVR_APPDIM) w = W[(size_t)row * TVR_KAPP + kpos];
+        const int pl = kpos / TVR_CA, c = kpos - pl * TVR_CA;              // the kernels' k = 48 * plane + channel; basis_mat's column = its plane's offset + channel
+        if (row < TVR_APPDIM && c < sh.app_n_comp[pl]) w = W[(size_t)row * sh.k_app + sh.app_off[pl] + c];
     } else {
         if (row < 3) w = W[(size_t)row * TVR_FEATC + (16 * s + 8 * (j >> 2) + 4 * hh + (j & 3))];
     }
@@ -759,10 +764,10 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
     }
 }
 
-hipError_t launch_pack_mlp(const float *W, const float *bias, void *out_hi, void *out_lo, int mode, hipStream_t stream)
+hipError_t launch_pack_mlp(const float *W, const float *bias, void *out_hi, void *out_lo, int mode, const MlpShape &sh, hipStream_t stream)
 {
     const int n = ((mode <= 1 || mode == 4) ? 128 : (mode == 2 ? 32 : 4)) * ((mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : 128));
-    hipLaunchKernelGGL(pack_mlp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, bias, (unsigned short *)out_hi, (unsigned short *)out_lo, mode);
+    hipLaunchKernelGGL(pack_mlp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, bias, (unsigned short *)out_hi, (unsigned short *)out_lo, mode, sh);
     return hipGetLastError();
 }
 

@@ -452,10 +452,10 @@ __global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const Scene
     }
 }
 
-// packed [H+1][Wp][C] gradient image -> reference (C,H,W) (a line: W == 1, Wp == 1)
-__global__ __launch_bounds__(256) void unpack_grad_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int H, int W, int Wp)
+// packed [H+1][Wp][C] gradient image -> reference (Cout,H,W) (a line: W == 1, Wp == 1); Cout <= C: the scene's own component count
+__global__ __launch_bounds__(256) void unpack_grad_kernel(const float *__restrict__ in, float *__restrict__ out, int Cout, int C, int H, int W, int Wp)
 {
-    const long long total = (long long)C * H * W;
+    const long long total = (long long)Cout * H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % W);
         const long long t = i / W;
@@ -505,13 +505,13 @@ hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long
     return hipGetLastError();
 }
 
-hipError_t launch_unpack_grad(const float *in, float *out, int C, int H, int W, hipStream_t stream)
+hipError_t launch_unpack_grad(const float *in, float *out, int Cout, int C, int H, int W, hipStream_t stream)
 {
     const int Wp = (W == 1) ? 1 : W + 1;
-    const long long total = (long long)C * H * W;
+    const long long total = (long long)Cout * H * W;
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(unpack_grad_kernel, dim3(grid), dim3(256), 0, stream, in, out, C, H, W, Wp);
+    hipLaunchKernelGGL(unpack_grad_kernel, dim3(grid), dim3(256), 0, stream, in, out, Cout, C, H, W, Wp);
     return hipGetLastError();
 }
 

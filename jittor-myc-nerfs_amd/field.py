@@ -344,12 +344,26 @@ class TensorBase(torch.nn.Module):
         S = int(N_samples) if N_samples > 0 else self.nSamples
         eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
         w, acc, xyz, ray_id, depth, _ = _MarchFn.apply(self, rays, jitter, S, eps_T, None, *self.density_plane, *self.density_line)
-        h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
+        h = self._app_h_autograd(xyz)
         rgb = self._shade_autograd(h, rays[ray_id, 3:6])                                      # tensoRF.py:244 + tensorBase.py:517
         rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)   # :521
         if white_bg:
             rgb_map = rgb_map + (1.0 - acc[:, None])                                          # :524
         return rgb_map.clamp(0, 1), depth                                                     # :527 (depth under no_grad, :529-531)
+
+    def _app_h_autograd(self, xyz):
+        """h [M, sum(app_n_comp)] = bilinear(app_plane) * linear(app_line) at xyz under autograd (tensoRF.py:235-241).  The kernels' own h is
+        [M, 3 x 48]; a scene with fewer components per plane has zero columns behind them, which are dropped here."""
+        h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
+        return h if list(self.app_n_comp) == [48, 48, 48] else h[:, self._app_columns()]
+
+    def _app_columns(self) -> torch.Tensor:
+        """Columns of the kernels' 144-wide appearance vector that hold this scene's components (basis_mat's column order, tensoRF.py:228-244)."""
+        key = tuple(int(c) for c in self.app_n_comp)
+        if getattr(self, "_app_cols", None) is None or self._app_cols[0] != key:
+            idx = torch.cat([torch.arange(48 * p, 48 * p + c) for p, c in enumerate(key)]).to(self.device)
+            self._app_cols = (key, idx)
+        return self._app_cols[1]
 
     fused_mlp_training = True     # False: basis_mat + MLP as library GEMMs under autograd (the round-1 path; kept for A/B and as a second opinion in tests)
 
@@ -358,7 +372,8 @@ class TensorBase(torch.nn.Module):
         scenes in the shape the shade kernel is built for go through the fused kernels (_MlpTrainFn); anything else through _LinearFn."""
         rm = self.renderModule
         if (self.fused_mlp_training and type(rm) is MLPRender_Fea and h.is_cuda and h.shape[0] > 0 and getattr(self, "_variant", 0) == 0
-                and self.app_dim == 27 and rm.feape == 2 and rm.viewpe == 2 and rm.mlp[0].out_features == 128 and h.shape[0] * 576 < (1 << 32)):
+                and self.app_dim == 27 and rm.feape == 2 and rm.viewpe == 2 and rm.mlp[0].out_features == 128 and h.shape[1] == 144
+                and h.shape[0] * 576 < (1 << 32)):
             m = rm.mlp
             return _MlpTrainFn.apply(self, h, viewdirs, self.basis_mat.weight, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
         return rm.forward_autograd(viewdirs, _linear(self.basis_mat, h))

@@ -298,7 +298,7 @@ class NerfPlusPlus(TensorVMSplit):
 
     def _render_z_autograd(self, rays, z_vals, S, eps_T):
         w, acc, xyz, ray_id, depth, lam = _MarchFn.apply(self, rays, None, S, eps_T, z_vals, *self.density_plane, *self.density_line)
-        h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
+        h = self._app_h_autograd(xyz)
         rgb = self._shade_autograd(h, rays[ray_id, 3:6])
         rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)
         return rgb_map.clamp(0, 1), depth, lam                                                # white_bg=False (:276), tensorBase.py:527

@@ -36,12 +36,17 @@ def test_abi_argument_errors_without_gpu():
     assert b"grid" in lib.tvr_last_error()
     d.grid[:] = [300, 300, 300]
     d.aabb[:] = [-1.5] * 3 + [1.5] * 3
-    d.density_n_comp[:] = [8, 8, 8]
+    d.density_n_comp[:] = [17, 8, 8]                                   # more components than the kernels are built for: refused
     d.app_n_comp[:] = [48] * 3
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"density_n_comp" in lib.tvr_last_error()
     d.density_n_comp[:] = [16] * 3
-    d.app_dim, d.featureC, d.view_pe, d.fea_pe, d.step_size = 27, 128, 2, 2, 0.005
+    d.app_dim, d.featureC, d.view_pe, d.fea_pe, d.step_size = 27, 128, 6, 6, 0.005     # opt.py's default frequencies do not fit either
+    assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"view_pe" in lib.tvr_last_error()
+    d.view_pe, d.fea_pe = 2, 2
     nbytes = lib.tvr_scene_packed_bytes(C.byref(d))
+    d.density_n_comp[:], d.app_n_comp[:], d.featureC, d.view_pe = [8, 8, 8], [24, 24, 24], 64, 0      # fewer / narrower: zero-padded into the same layout
+    assert lib.tvr_scene_packed_bytes(C.byref(d)) == nbytes
+    d.density_n_comp[:], d.app_n_comp[:], d.featureC, d.view_pe = [16] * 3, [48] * 3, 128, 2
     # 3 planes x 301x301 x (16+48) ch + lines + MLP, fp32, 256-B aligned blocks (DESIGN.md "data layout")
     assert 69.5e6 < nbytes < 70.5e6
     h = C.c_void_p()
@@ -52,6 +57,9 @@ def test_abi_argument_errors_without_gpu():
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"variant" in lib.tvr_last_error()
     d.variant = 1                                                       # REFTensoRF: same packed size (the LDS image has room for both)
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == nbytes
+    d.featureC = 64                                                     # ... at the standard shape only
+    assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"REFTensoRF" in lib.tvr_last_error()
+    d.featureC = 128
     assert lib.tvr_app_feature_ref(None, None, 0, None, None, None) == -1
     assert lib.tvr_mlp_render_ref(None, None, None, None, 0, None, None) == -1
 
