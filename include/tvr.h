@@ -11,6 +11,11 @@
  *   - ALL device memory is caller-owned (torch allocations): fp32, contiguous, 16-byte aligned.
  *     The library never allocates device memory; sizes come from the *_bytes() queries.
  *   - all work is enqueued on the caller-supplied stream (a hipStream_t passed as void*).
+ *   - every OUTPUT matrix whose row width is the kernels' own (not a shape the reference shows) is passed with its size in bytes
+ *     (`*_bytes`) and checked on the host before anything is launched: a buffer that is too small is refused with TVR_ERR_SCRATCH
+ *     instead of being overrun on the device.  (Round 2: a caller that allocated tvr_app_h_forward's h as [m, sum(app_n_comp)]
+ *     instead of the kernels' [m,144] had 144 - sum columns written past its end — a device fault at the next sync.)
+ *     tvr_render's rgb_out [n,3] / depth_out [n] and the tvr_vm_grads tensors have the reference's own shapes and carry no count.
  *   - a tvr_scene may be used from one stream at a time; distinct scenes are independent.
  */
 #ifndef TVR_H
@@ -23,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 108
+#define TVR_VERSION 109
 
 typedef enum {
     TVR_OK = 0,
@@ -137,29 +142,32 @@ int tvr_render_z(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_
                  void *scratch, size_t scratch_bytes, const tvr_dense_out *dense, uint64_t *stats, void *stream);
 
 /* TensorVMSplit.compute_densityfeature (tensoRF.py:209-225): xyz_norm [m,3] -> out [m]. */
-int tvr_density_feature(tvr_scene *scene, const float *xyz_norm, int64_t m, float *out, void *stream);
+int tvr_density_feature(tvr_scene *scene, const float *xyz_norm, int64_t m, float *out, size_t out_bytes, void *stream);
 /* TensorVMSplit.compute_appfeature (tensoRF.py:228-244): xyz_norm [m,3] -> out [m,app_dim]. */
-int tvr_app_feature(tvr_scene *scene, const float *xyz_norm, int64_t m, float *out, void *stream);
+int tvr_app_feature(tvr_scene *scene, const float *xyz_norm, int64_t m, float *out, size_t out_bytes, void *stream);
 /* MLPRender_Fea.execute (tensorBase.py:76-86): viewdirs [m,3], features [m,app_dim] -> rgb [m,3]. */
-int tvr_mlp_render(tvr_scene *scene, const float *viewdirs, const float *features, int64_t m, float *rgb, void *stream);
+int tvr_mlp_render(tvr_scene *scene, const float *viewdirs, const float *features, int64_t m, float *rgb, size_t rgb_bytes, void *stream);
 /* REFTensoRF.compute_appfeature (models/REFTensoRF.py:107-133), variant-1 scenes: xyz_norm [m,3] -> features [m,app_dim] and
  * extra [m,8] = {normal_vector 3 (not normalised), rgb_d 3, relu(specular_tint), relu(rho)}. */
-int tvr_app_feature_ref(tvr_scene *scene, const float *xyz_norm, int64_t m, float *features, float *extra, void *stream);
+int tvr_app_feature_ref(tvr_scene *scene, const float *xyz_norm, int64_t m, float *features, size_t features_bytes, float *extra, size_t extra_bytes,
+                        void *stream);
 /* MLPRender_Fea_Ref.execute (models/REFTensoRF.py:18-28), variant-1 scenes: viewdirs [m,3] (the reflection directions),
  * features [m,app_dim], dot_product [m] -> sigmoid rgb [m,3]. */
 int tvr_mlp_render_ref(tvr_scene *scene, const float *viewdirs, const float *features, const float *dot_product, int64_t m,
-                       float *rgb, void *stream);
+                       float *rgb, size_t rgb_bytes, void *stream);
 /* AlphaGridMask.sample_alpha (tensorBase.py:50-56): xyz [m,3] (world) -> out [m].  Stand-alone (the reference's
  * AlphaGridMask is its own module): volume (gz,gy,gx) fp32, grid (gx,gy,gz), aabb, invgridSize = 1/size*2 (:46). */
 int tvr_alpha_sample(const float *alpha_volume_dev, const int32_t agrid_xyz[3], const float alpha_aabb[6],
-                     const float alpha_inv_size[3], const float *xyz, int64_t m, float *out, void *stream);
+                     const float alpha_inv_size[3], const float *xyz, int64_t m, float *out, size_t out_bytes, void *stream);
 
 /* ---- training step (caller: tensorf-myc/train.py:225-261) ------------------------------------------------
  * The TensoRF-specific halves of forward and backward are HIP kernels; the 144->27 basis, the positional encoding and the
  * three Linears run as library GEMMs under the host's autograd between them. */
 
 /* Byte offsets of the regions of a tvr_render / tvr_march_forward scratch buffer, for hosts that consume the queue:
- * counter u32; ray_off/ray_cnt u32[n]; acc f32[n]; q_pos float4[cap] {xyz_norm, weight}; q_out float4[cap] {rgb, weight};
+ * counter u32[4] = {queue length, the march's tile counter, FAULT flag, -}: the flag is non-zero if a wave of the march kernel gave up waiting for its
+ * tile number (1: overtaken in the 32-slot ring, 2: spin limit; tvr_march.hip) — tvr_render then writes NaN to every pixel and depth of the call,
+ * hosts that consume the queue read it with the queue length; ray_off/ray_cnt u32[n]; acc f32[n]; q_pos float4[cap] {xyz_norm, weight}; q_out float4[cap] {rgb, weight};
  * q_ray u32[cap]; q_j u32[cap]; cap = n_rays * n_samples.  Each ray's entries are contiguous and in sample order. */
 typedef struct { size_t counter, ray_off, ray_cnt, acc, q_pos, q_out, q_ray, q_j, total; } tvr_scratch_layout;
 int tvr_scratch_describe(int64_t n_rays, int32_t n_samples, tvr_scratch_layout *out);
@@ -189,9 +197,12 @@ int tvr_march_backward_z(tvr_scene *scene, const float *rays, int64_t n_rays, in
                          const float *t_last_tiny, const float *grad_t_last_tiny, void *grad_scratch, size_t grad_scratch_bytes,
                          const tvr_vm_grads *out, void *stream);
 
-/* h [m,144] = bilinear(app_plane) * linear(app_line), plane-major (tensoRF.py:235-241, before basis_mat), and its backward. */
-int tvr_app_h_forward(tvr_scene *scene, const float *xyz_norm, int64_t m, float *h_out, void *stream);
-int tvr_app_h_backward(tvr_scene *scene, const float *xyz_norm, int64_t m, const float *dh, void *grad_scratch,
+/* h [m,144] = bilinear(app_plane) * linear(app_line), plane-major (tensoRF.py:235-241, before basis_mat), and its backward.
+ * h is ALWAYS 144 columns wide — the kernels' layout, 3 planes x 48 channels: column 48 p + c is component c of plane p, and the columns
+ * behind a plane's own app_n_comp[p] components are written as zeros — whatever the scene's component counts (a zero-padded scene's
+ * basis_mat is [27, sum(app_n_comp)]; the host gathers the columns it owns).  h_bytes / dh_bytes >= m * 144 * 4. */
+int tvr_app_h_forward(tvr_scene *scene, const float *xyz_norm, int64_t m, float *h_out, size_t h_bytes, void *stream);
+int tvr_app_h_backward(tvr_scene *scene, const float *xyz_norm, int64_t m, const float *dh, size_t dh_bytes, void *grad_scratch,
                        size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream);
 
 /* The appearance network of a TRAINING step (TensorVMSplit; train.py:225-261 through tensoRF.py:244 `basis_mat` and tensorBase.py:76-86
@@ -209,12 +220,18 @@ int tvr_app_h_backward(tvr_scene *scene, const float *xyz_norm, int64_t m, const
  *             gscale_dev: device scalar, a power of two.  The MFMA operands pass through fp16 (see tvr_render), and MSE gradients of a
  *             4096-ray batch are O(1e-5): gradients are multiplied by gscale on entry and by 1 / gscale on exit; choose it so that
  *             max |grad_rgb| * gscale is O(100) (results do not depend on it beyond rounding).
- * All matrices row-major, contiguous, 16-byte aligned; m * 576 < 2^32 per call. */
+ *             sat_flag_dev (optional device uint32, caller zeroes): set to 1 by the backward kernel if a scaled gradient reached fp16's largest
+ *             finite value on its way into a matrix product (the split saturates there silently) — the step's gradients are then clipped and
+ *             the caller should lower gscale.
+ * All matrices row-major, contiguous, 16-byte aligned; m * 576 < 2^32 per call (both directions).  Every output is passed with its size in
+ * bytes: rgb m*3*4, feats32 / dfeats32 m*32*4, h1 / h2 / dh1 / dh2 m*128*4, d_out4 m*4*4, dh m*144*4. */
 size_t tvr_mlp_train_image_bytes(void);
-int tvr_mlp_train_forward(tvr_scene *scene, const float *h, const float *viewdirs, int64_t m, float *rgb, float *feats32, float *h1, float *h2, void *stream);
+int tvr_mlp_train_forward(tvr_scene *scene, const float *h, const float *viewdirs, int64_t m, float *rgb, size_t rgb_bytes, float *feats32,
+                          size_t feats32_bytes, float *h1, size_t h1_bytes, float *h2, size_t h2_bytes, void *stream);
 int tvr_mlp_train_backward(const float *W1, const float *W2, const float *W3, const float *basis, const float *grad_rgb, const float *rgb, const float *feats32,
-                           const float *h1, const float *h2, int64_t m, const float *gscale_dev, float *d_out4, float *dh2, float *dh1, float *dfeats32, float *dh,
-                           void *image, size_t image_bytes, void *stream);
+                           const float *h1, const float *h2, int64_t m, const float *gscale_dev, float *d_out4, size_t d_out4_bytes, float *dh2,
+                           size_t dh2_bytes, float *dh1, size_t dh1_bytes, float *dfeats32, size_t dfeats32_bytes, float *dh, size_t dh_bytes,
+                           uint32_t *sat_flag_dev, void *image, size_t image_bytes, void *stream);
 
 /* C [Ka,Kb] = A^T B for tall-skinny fp32 operands A [M,Ka] (row stride lda), B [M,Kb] (row stride ldb): the weight gradients dW = dY^T X of
  * the training step's Linears (MLPRender_Fea's three layers tensorBase.py:69-71, basis_mat tensoRF.py:150) over the M appearance samples of
@@ -227,9 +244,9 @@ int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t
 /* The MLP input of the training step in one pass: X [m,150] = [features 27, viewdirs 3, PE(features), PE(viewdirs)] (MLPRender_Fea.execute,
  * tensorBase.py:76-82; positional_encoding :9-15), or X [m,151] with dot_product [m] in front (MLPRender_Fea_Ref, REFTensoRF.py:19-24) when
  * dot_product is non-NULL; and its backward (grad_viewdirs / grad_dot may be NULL). */
-int tvr_pe_concat(const float *features, const float *viewdirs, const float *dot_product, int64_t m, float *X, void *stream);
+int tvr_pe_concat(const float *features, const float *viewdirs, const float *dot_product, int64_t m, float *X, size_t X_bytes, void *stream);
 int tvr_pe_concat_backward(const float *features, const float *viewdirs, const float *grad_X, int64_t m, int32_t with_dot,
-                           float *grad_features, float *grad_viewdirs, float *grad_dot, void *stream);
+                           float *grad_features, size_t grad_features_bytes, float *grad_viewdirs, float *grad_dot, void *stream);
 
 /* TVLoss.forward (tensorf-myc/utils.py:123-142) of one plane x (C,H,W), batch 1: value [1] = weight * 2 (h_tv/count_h + w_tv/count_w) and
  * grad (C,H,W) = d value / d x in the same pass; fixed summation order.  scratch: 2048 bytes. */

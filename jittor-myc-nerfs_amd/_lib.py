@@ -83,29 +83,29 @@ SYMBOLS = {
                                       C.c_size_t, C.c_void_p]),
     "tvr_march_backward_z": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.c_void_p]),
-    "tvr_density_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "tvr_app_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "tvr_mlp_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "tvr_app_feature_ref": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tvr_mlp_render_ref": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tvr_density_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_app_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_mlp_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_app_feature_ref": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_mlp_render_ref": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_alpha_sample": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_float * 6), C.POINTER(C.c_float * 3),
-                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_scratch_describe": (C.c_int, [C.c_int64, C.c_int32, C.POINTER(ScratchLayout)]),
     "tvr_march_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
     "tvr_grad_scratch_bytes": (C.c_size_t, [C.c_void_p]),
     "tvr_march_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.c_void_p]),
-    "tvr_app_h_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "tvr_app_h_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.c_void_p]),
+    "tvr_app_h_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_app_h_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.c_void_p]),
     "tvr_mlp_train_image_bytes": (C.c_size_t, []),
-    "tvr_mlp_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tvr_mlp_train_backward": (C.c_int, [C.c_void_p] * 9 + [C.c_int64] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),
+    "tvr_mlp_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p, C.c_size_t] * 4 + [C.c_void_p]),
+    "tvr_mlp_train_backward": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_void_p] + [C.c_void_p, C.c_size_t] * 5 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_gemm_tn_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     "tvr_gemm_tn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.c_void_p]),
-    "tvr_pe_concat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "tvr_pe_concat_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvr_pe_concat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_pe_concat_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tvr_tv_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_profile_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
     "tvr_profile_reset": (C.c_int, [C.c_void_p]),
@@ -158,6 +158,11 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+def nbytes(t) -> int:
+    """Size in bytes of a tensor's storage from its first element on: what the `*_bytes` arguments of include/tvr.h take."""
+    return t.numel() * t.element_size()
 
 
 def check(rc: int, what: str = "") -> None:

@@ -111,7 +111,7 @@ class _PEConcatFn(torch.autograd.Function):
         d = None if dot is None else dot.contiguous().view(-1)
         m = f.shape[0]
         X = torch.empty((m, 150 + (0 if d is None else 1)), dtype=torch.float32, device=f.device)
-        L.check(L.lib().tvr_pe_concat(f.data_ptr(), v.data_ptr(), None if d is None else d.data_ptr(), m, X.data_ptr(), _stream_ptr(f.device)),
+        L.check(L.lib().tvr_pe_concat(f.data_ptr(), v.data_ptr(), None if d is None else d.data_ptr(), m, X.data_ptr(), L.nbytes(X), _stream_ptr(f.device)),
                 "tvr_pe_concat")
         ctx.save_for_backward(f, v)
         ctx.with_dot = d is not None
@@ -126,7 +126,7 @@ class _PEConcatFn(torch.autograd.Function):
         gf = torch.empty_like(f)
         gv = torch.empty_like(v) if ctx.needs_input_grad[1] else None
         gd = torch.empty(m, dtype=torch.float32, device=f.device) if (ctx.with_dot and ctx.needs_input_grad[2]) else None
-        L.check(L.lib().tvr_pe_concat_backward(f.data_ptr(), v.data_ptr(), gX.data_ptr(), m, int(ctx.with_dot), gf.data_ptr(),
+        L.check(L.lib().tvr_pe_concat_backward(f.data_ptr(), v.data_ptr(), gX.data_ptr(), m, int(ctx.with_dot), gf.data_ptr(), L.nbytes(gf),
                                                None if gv is None else gv.data_ptr(), None if gd is None else gd.data_ptr(), _stream_ptr(f.device)),
                 "tvr_pe_concat_backward")
         return gf, gv, (None if gd is None else gd.view(ctx.dot_shape))
@@ -217,7 +217,7 @@ class _AppHFn(torch.autograd.Function):
     def forward(ctx, model, xyz, *app_params):
         sc = model._ensure_scene()
         h = torch.empty((xyz.shape[0], 144), dtype=torch.float32, device=model.device)       # the kernels' layout: 3 planes x 48 channels (zero behind a plane's own components)
-        L.check(L.lib().tvr_app_h_forward(sc, xyz.data_ptr(), xyz.shape[0], h.data_ptr(), _stream_ptr(model.device)), "tvr_app_h_forward")
+        L.check(L.lib().tvr_app_h_forward(sc, xyz.data_ptr(), xyz.shape[0], h.data_ptr(), L.nbytes(h), _stream_ptr(model.device)), "tvr_app_h_forward")
         ctx.model, ctx.xyz = model, xyz
         ctx.shapes = [p.shape for p in app_params]
         return h
@@ -232,7 +232,7 @@ class _AppHFn(torch.autograd.Function):
             out.app_plane[i], out.app_line[i] = grads[i].data_ptr(), grads[3 + i].data_ptr()
         gs = model._get_grad_scratch()
         dh = dh.contiguous().float()
-        L.check(L.lib().tvr_app_h_backward(sc, ctx.xyz.data_ptr(), ctx.xyz.shape[0], dh.data_ptr(), gs.data_ptr(), gs.numel(), C.byref(out),
+        L.check(L.lib().tvr_app_h_backward(sc, ctx.xyz.data_ptr(), ctx.xyz.shape[0], dh.data_ptr(), L.nbytes(dh), gs.data_ptr(), gs.numel(), C.byref(out),
                                            _stream_ptr(model.device)), "tvr_app_h_backward")
         return (None, None, *grads)
 
@@ -254,8 +254,8 @@ class _MlpTrainFn(torch.autograd.Function):
         feats = torch.empty((m, 32), dtype=torch.float32, device=dev)
         h1 = torch.empty((m, 128), dtype=torch.float32, device=dev)
         h2 = torch.empty((m, 128), dtype=torch.float32, device=dev)
-        L.check(lib.tvr_mlp_train_forward(sc, h.data_ptr(), vd.data_ptr(), m, rgb.data_ptr(), feats.data_ptr(), h1.data_ptr(), h2.data_ptr(),
-                                          _stream_ptr(dev)), "tvr_mlp_train_forward")
+        L.check(lib.tvr_mlp_train_forward(sc, h.data_ptr(), vd.data_ptr(), m, rgb.data_ptr(), L.nbytes(rgb), feats.data_ptr(), L.nbytes(feats),
+                                          h1.data_ptr(), L.nbytes(h1), h2.data_ptr(), L.nbytes(h2), _stream_ptr(dev)), "tvr_mlp_train_forward")
         ctx.save_for_backward(h, vd, rgb, feats, h1, h2, basis_w, W1, W2, W3)
         ctx.model = model
         return rgb
@@ -271,9 +271,11 @@ class _MlpTrainFn(torch.autograd.Function):
             return (None, torch.zeros_like(h), None, z(basis_w), z(W1), torch.zeros(128, device=dev), z(W2), torch.zeros(128, device=dev), z(W3),
                     torch.zeros(3, device=dev))
         grgb = grgb.contiguous().float()
-        # power-of-two scale that brings the largest output gradient to ~2^6 (device side: no host sync)
+        # power-of-two scale that brings the largest output gradient to ~model.grad_scale_target (2^6; device side: no host sync).  If the chain
+        # still reaches fp16's range (large weights) the kernels set model._sat_flag: model.check_gradient_saturation() reads it and lowers the target
         gmax = (grgb.abs().max() * 0.25).clamp_min(1e-30)
-        gscale = torch.exp2(torch.floor(torch.log2(64.0 / gmax))).clamp(1.0, 2.0 ** 60).reshape(1).float()
+        gscale = torch.exp2(torch.floor(torch.log2(float(ctx.model.grad_scale_target) / gmax))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1).float()
+        sat = ctx.model._get_sat_flag()
         d_out = torch.empty((m, 4), dtype=torch.float32, device=dev)
         dh2 = torch.empty((m, 128), dtype=torch.float32, device=dev)
         dh1 = torch.empty((m, 128), dtype=torch.float32, device=dev)
@@ -282,11 +284,12 @@ class _MlpTrainFn(torch.autograd.Function):
         image = ctx.model._get_train_image()
         W1c, W2c, W3c, Bc = (t.detach().contiguous().float() for t in (W1, W2, W3, basis_w))
         L.check(lib.tvr_mlp_train_backward(W1c.data_ptr(), W2c.data_ptr(), W3c.data_ptr(), Bc.data_ptr(), grgb.data_ptr(), rgb.data_ptr(), feats.data_ptr(),
-                                           h1.data_ptr(), h2.data_ptr(), m, gscale.data_ptr(), d_out.data_ptr(), dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(),
-                                           dh.data_ptr(), image.data_ptr(), image.numel(), _stream_ptr(dev)), "tvr_mlp_train_backward")
+                                           h1.data_ptr(), h2.data_ptr(), m, gscale.data_ptr(), d_out.data_ptr(), L.nbytes(d_out), dh2.data_ptr(), L.nbytes(dh2),
+                                           dh1.data_ptr(), L.nbytes(dh1), dfe.data_ptr(), L.nbytes(dfe), dh.data_ptr(), L.nbytes(dh), sat.data_ptr(),
+                                           image.data_ptr(), image.numel(), _stream_ptr(dev)), "tvr_mlp_train_backward")
         X = torch.empty((m, 150), dtype=torch.float32, device=dev)                      # the MLP input, re-derived from the saved features (tensorBase.py:77-82)
         f27 = feats[:, :27].contiguous()
-        L.check(lib.tvr_pe_concat(f27.data_ptr(), vd.data_ptr(), None, m, X.data_ptr(), _stream_ptr(dev)), "tvr_pe_concat")
+        L.check(lib.tvr_pe_concat(f27.data_ptr(), vd.data_ptr(), None, m, X.data_ptr(), L.nbytes(X), _stream_ptr(dev)), "tvr_pe_concat")
         big = m >= 4096
         tn = (lambda a_, lda, ka, b_, ldb, kb: _gemm_tn_call(a_, lda, ka, b_, ldb, kb, m)) if big else None
         if big:

@@ -29,6 +29,21 @@ int tvr_set_error(int code, const char *fmt, ...)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// an output (or gradient input) matrix of `rows` x `cols` fp32 must have been allocated with at least that many bytes: checked on the host,
+// before anything is launched (round 2's device fault was a caller buffer 144 - sum(app_n_comp) columns short of the kernel's row width)
+static int need_bytes(const char *fn, const char *what, size_t have, int64_t rows, int cols)
+{
+    const size_t want = (size_t)rows * (size_t)cols * sizeof(float);
+    if (have < want)
+        return fail(TVR_ERR_SCRATCH, "%s: %s holds %zu B, the kernel writes %lld rows x %d fp32 = %zu B", fn, what, have, (long long)rows, cols, want);
+    return TVR_OK;
+}
+#define NEED(what, have, rows, cols)                                     \
+    do {                                                                 \
+        int rc_ = need_bytes(__func__, what, (have), (rows), (cols));    \
+        if (rc_ != TVR_OK) return rc_;                                   \
+    } while (0)
+
 static const int kMatH[3][2] = {{0, 1}, {0, 2}, {1, 2}};
 static const int kVecH[3] = {2, 1, 0};
 
@@ -284,7 +299,7 @@ static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     mo.lam6 = lam6_out;
 
     hipEvent_t *ev = prof ? &prof->ev[(size_t)prof->n_calls * 4] : nullptr;
-    HIP_TRY(hipMemsetAsync(mo.counter, 0, 8, stream));                 // [0] queue length, [1] the march's tile counter
+    HIP_TRY(hipMemsetAsync(mo.counter, 0, 16, stream));                // [0] queue length, [1] the march's tile counter, [2] its fault flag
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, dense, stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
@@ -381,7 +396,7 @@ static int march_forward_impl(tvr_scene *s, const float *rays, int64_t n_rays, i
     hipStream_t stream = (hipStream_t)stream_;
     MarchOut mo = carve_scratch((char *)scratch, L, depth_out);
     mo.lam6 = lam6_out;
-    HIP_TRY(hipMemsetAsync(mo.counter, 0, 8, stream));                 // [0] queue length, [1] the march's tile counter
+    HIP_TRY(hipMemsetAsync(mo.counter, 0, 16, stream));                // [0] queue length, [1] the march's tile counter, [2] its fault flag
     HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, nullptr, stream));
     return TVR_OK;
 }
@@ -475,8 +490,9 @@ int tvr_march_backward_z(tvr_scene *s, const float *rays, int64_t n_rays, int32_
                                grad_scratch, grad_scratch_bytes, out, stream);
 }
 
-int tvr_app_h_forward(tvr_scene *s, const float *xyz, int64_t m, float *h_out, void *stream)
+int tvr_app_h_forward(tvr_scene *s, const float *xyz, int64_t m, float *h_out, size_t h_bytes, void *stream)
 {
+    if (m > 0) NEED("h_out [m,144]", h_bytes, m, TVR_KAPP);
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
     if (m == 0) return TVR_OK;
@@ -487,8 +503,16 @@ int tvr_app_h_forward(tvr_scene *s, const float *xyz, int64_t m, float *h_out, v
 
 size_t tvr_mlp_train_image_bytes(void) { return mlp_train_image_bytes(); }
 
-int tvr_mlp_train_forward(tvr_scene *s, const float *h, const float *viewdirs, int64_t m, float *rgb, float *feats32, float *h1, float *h2, void *stream)
+int tvr_mlp_train_forward(tvr_scene *s, const float *h, const float *viewdirs, int64_t m, float *rgb, size_t rgb_bytes, float *feats32, size_t feats32_bytes,
+                          float *h1, size_t h1_bytes, float *h2, size_t h2_bytes, void *stream)
 {
+    if (m > 0) {
+        NEED("rgb [m,3]", rgb_bytes, m, 3);
+        NEED("feats32 [m,32]", feats32_bytes, m, 32);
+        NEED("h1 [m,128]", h1_bytes, m, TVR_FEATC);
+        NEED("h2 [m,128]", h2_bytes, m, TVR_FEATC);
+        if ((uint64_t)m * 576u >= (1ull << 32)) return fail(TVR_ERR_INVALID, "m = %lld: 32-bit row offsets inside the kernels allow 7.4 M entries per call", (long long)m);
+    }
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
     if (s->desc.variant != 0) return fail(TVR_ERR_UNSUPPORTED, "tvr_mlp_train_forward: TensorVMSplit scenes only (REFTensoRF trains through the library-GEMM path)");
@@ -510,10 +534,18 @@ int tvr_mlp_train_forward(tvr_scene *s, const float *h, const float *viewdirs, i
 }
 
 int tvr_mlp_train_backward(const float *W1, const float *W2, const float *W3, const float *basis, const float *grad_rgb, const float *rgb, const float *feats32,
-                           const float *h1, const float *h2, int64_t m, const float *gscale_dev, float *d_out4, float *dh2, float *dh1, float *dfeats32, float *dh,
+                           const float *h1, const float *h2, int64_t m, const float *gscale_dev, float *d_out4, size_t d_out4_bytes, float *dh2, size_t dh2_bytes,
+                           float *dh1, size_t dh1_bytes, float *dfeats32, size_t dfeats32_bytes, float *dh, size_t dh_bytes, uint32_t *sat_flag_dev,
                            void *image, size_t image_bytes, void *stream)
 {
     if (m == 0) return TVR_OK;
+    if (m > 0) {
+        NEED("d_out4 [m,4]", d_out4_bytes, m, 4);
+        NEED("dh2 [m,128]", dh2_bytes, m, TVR_FEATC);
+        NEED("dh1 [m,128]", dh1_bytes, m, TVR_FEATC);
+        NEED("dfeats32 [m,32]", dfeats32_bytes, m, 32);
+        NEED("dh [m,144]", dh_bytes, m, TVR_KAPP);
+    }
     if (!W1 || !W2 || !W3 || !basis || !grad_rgb || !rgb || !feats32 || !h1 || !h2 || !gscale_dev || !d_out4 || !dh2 || !dh1 || !dfeats32 || !dh || !image || m < 0)
         return fail(TVR_ERR_INVALID, "NULL argument or m < 0");
     if (image_bytes < mlp_train_image_bytes() || (uintptr_t)image % 256) return fail(TVR_ERR_SCRATCH, "training image buffer too small or misaligned");
@@ -521,13 +553,14 @@ int tvr_mlp_train_backward(const float *W1, const float *W2, const float *W3, co
     if (((uintptr_t)feats32 | (uintptr_t)h1 | (uintptr_t)h2 | (uintptr_t)d_out4 | (uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)dfeats32 | (uintptr_t)dh) % 16)
         return fail(TVR_ERR_INVALID, "activation / gradient matrices must be 16-byte aligned");
     HIP_TRY(launch_pack_train_image(W1, W2, W3, basis, image, (hipStream_t)stream));
-    HIP_TRY(launch_mlp_train_backward(grad_rgb, rgb, feats32, h1, h2, m, gscale_dev, d_out4, dh2, dh1, dfeats32, dh, image, (hipStream_t)stream));
+    HIP_TRY(launch_mlp_train_backward(grad_rgb, rgb, feats32, h1, h2, m, gscale_dev, d_out4, dh2, dh1, dfeats32, dh, sat_flag_dev, image, (hipStream_t)stream));
     return TVR_OK;
 }
 
-int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *dh, void *grad_scratch, size_t grad_scratch_bytes,
+int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *dh, size_t dh_bytes, void *grad_scratch, size_t grad_scratch_bytes,
                        const tvr_vm_grads *out, void *stream_)
 {
+    if (m > 0) NEED("dh [m,144]", dh_bytes, m, TVR_KAPP);
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
     if (!grad_scratch || !out || m < 0 || (m > 0 && (!xyz || !dh))) return fail(TVR_ERR_INVALID, "NULL argument");
@@ -550,18 +583,20 @@ int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *d
     return TVR_OK;
 }
 
-int tvr_pe_concat(const float *features, const float *viewdirs, const float *dot_product, int64_t m, float *X, void *stream)
+int tvr_pe_concat(const float *features, const float *viewdirs, const float *dot_product, int64_t m, float *X, size_t X_bytes, void *stream)
 {
     if (m == 0) return TVR_OK;
+    if (m > 0) NEED(dot_product ? "X [m,151]" : "X [m,150]", X_bytes, m, dot_product ? TVR_NIN_REF : TVR_NIN);
     if (!features || !viewdirs || !X || m < 0) return fail(TVR_ERR_INVALID, "features/viewdirs/X NULL or m < 0");
     HIP_TRY(launch_pe_concat(features, viewdirs, dot_product, m, X, (hipStream_t)stream));
     return TVR_OK;
 }
 
 int tvr_pe_concat_backward(const float *features, const float *viewdirs, const float *grad_X, int64_t m, int32_t with_dot, float *grad_features,
-                           float *grad_viewdirs, float *grad_dot, void *stream)
+                           size_t grad_features_bytes, float *grad_viewdirs, float *grad_dot, void *stream)
 {
     if (m == 0) return TVR_OK;
+    if (m > 0) NEED("grad_features [m,27]", grad_features_bytes, m, TVR_APPDIM);
     if (!features || !viewdirs || !grad_X || !grad_features || m < 0) return fail(TVR_ERR_INVALID, "NULL argument or m < 0");
     HIP_TRY(launch_pe_concat_backward(features, viewdirs, grad_X, m, with_dot ? 1 : 0, grad_features, grad_viewdirs, grad_dot, (hipStream_t)stream));
     return TVR_OK;
@@ -601,8 +636,9 @@ int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t
     return TVR_OK;
 }
 
-int tvr_density_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, void *stream)
+int tvr_density_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, size_t out_bytes, void *stream)
 {
+    if (m > 0) NEED("out [m]", out_bytes, m, 1);
     if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
     if (m == 0) return TVR_OK;
     if (!xyz || !out || m < 0) return fail(TVR_ERR_INVALID, "xyz/out NULL or m < 0");
@@ -610,8 +646,9 @@ int tvr_density_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, v
     return TVR_OK;
 }
 
-int tvr_app_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, void *stream)
+int tvr_app_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, size_t out_bytes, void *stream)
 {
+    if (m > 0) NEED("out [m,27]", out_bytes, m, TVR_APPDIM);
     if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
     if (m == 0) return TVR_OK;
     if (!xyz || !out || m < 0) return fail(TVR_ERR_INVALID, "xyz/out NULL or m < 0");
@@ -624,8 +661,12 @@ int tvr_app_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, void 
     return TVR_OK;
 }
 
-int tvr_app_feature_ref(tvr_scene *s, const float *xyz, int64_t m, float *features, float *extra, void *stream)
+int tvr_app_feature_ref(tvr_scene *s, const float *xyz, int64_t m, float *features, size_t features_bytes, float *extra, size_t extra_bytes, void *stream)
 {
+    if (m > 0) {
+        NEED("features [m,27]", features_bytes, m, TVR_APPDIM);
+        NEED("extra [m,8]", extra_bytes, m, 8);
+    }
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
     if (s->desc.variant != 1) return fail(TVR_ERR_INVALID, "tvr_app_feature_ref needs a REFTensoRF (variant 1) scene");
@@ -642,8 +683,9 @@ int tvr_app_feature_ref(tvr_scene *s, const float *xyz, int64_t m, float *featur
 }
 
 int tvr_mlp_render_ref(tvr_scene *s, const float *viewdirs, const float *features, const float *dot_product, int64_t m, float *rgb,
-                       void *stream)
+                       size_t rgb_bytes, void *stream)
 {
+    if (m > 0) NEED("rgb [m,3]", rgb_bytes, m, 3);
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
     if (s->desc.variant != 1) return fail(TVR_ERR_INVALID, "tvr_mlp_render_ref needs a REFTensoRF (variant 1) scene");
@@ -660,8 +702,9 @@ int tvr_mlp_render_ref(tvr_scene *s, const float *viewdirs, const float *feature
     return TVR_OK;
 }
 
-int tvr_mlp_render(tvr_scene *s, const float *viewdirs, const float *features, int64_t m, float *rgb, void *stream)
+int tvr_mlp_render(tvr_scene *s, const float *viewdirs, const float *features, int64_t m, float *rgb, size_t rgb_bytes, void *stream)
 {
+    if (m > 0) NEED("rgb [m,3]", rgb_bytes, m, 3);
     if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
     if (s->desc.variant != 0) return fail(TVR_ERR_INVALID, "tvr_mlp_render is MLPRender_Fea; a REFTensoRF scene takes tvr_mlp_render_ref");
     if (m == 0) return TVR_OK;
@@ -677,8 +720,9 @@ int tvr_mlp_render(tvr_scene *s, const float *viewdirs, const float *features, i
 }
 
 int tvr_alpha_sample(const float *vol, const int32_t ag[3], const float aabb[6], const float inv[3], const float *xyz,
-                     int64_t m, float *out, void *stream)
+                     int64_t m, float *out, size_t out_bytes, void *stream)
 {
+    if (m > 0) NEED("out [m]", out_bytes, m, 1);
     if (!vol || !ag || !aabb || !inv) return fail(TVR_ERR_INVALID, "alpha volume/grid/aabb/inv is NULL");
     if (m == 0) return TVR_OK;
     if (!xyz || !out || m < 0) return fail(TVR_ERR_INVALID, "xyz/out NULL or m < 0");

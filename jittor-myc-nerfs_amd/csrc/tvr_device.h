@@ -35,19 +35,21 @@
 #define TVR_IMG_B1 (36 * TVR_IMG_STEP)             // 147 456
 #define TVR_IMG_B2 (TVR_IMG_B1 + 512)
 #define TVR_IMG_B3 TVR_IMG_B1                      // b3 (3 floats + pad): b1 itself rides in W1's image as the column of a constant-1 input
-#define TVR_IMG_W3 (TVR_IMG_B2 + 512)              // W3 [3][128] fp32 (layer 3 runs as fp32 FMAs), then 512 zero bytes (REFTensoRF's zero row)
+#define TVR_IMG_W3 (TVR_IMG_B2 + 512)              // W3 [3][128] fp32 (layer 3 runs as fp32 FMAs), then 512 unused zero bytes
 #define TVR_IMG_W3_ROW 512
 #define TVR_IMG_BASH (TVR_IMG_W3 + 4 * TVR_IMG_W3_ROW)   // basis fragments, hi parts: [9 k-steps][2 halves][27 rows][16 B]
 #define TVR_IMG_BASH_ROWS 27
 #define TVR_MLP_IMAGE_BYTES (TVR_IMG_BASH + 9 * 2 * TVR_IMG_BASH_ROWS * 16)     // 158 304 B of the 163 840 B LDS
 // REFTensoRF (variant 1) appends the four 144 -> {3,3,1,1} linears of REFTensoRF.compute_appfeature (models/REFTensoRF.py:126-132):
-//   64 zero bytes (they extend W3's zero row to the 576 B of a 9-k-step row), 8 rows [9 k-steps][2 halves][hi 8 | lo 8] fp16
+//   576 zero bytes (the A-operand row of the lanes that own no head: 9 k-steps x 2 halves x 32 B, all of it zero — round 2 pointed this at
+//   W3's 512-B zero row, whose k-step 8 ran into the basis fragments), 8 rows [9 k-steps][2 halves][hi 8 | lo 8] fp16
 //   (normal 0..2, specular 3, diffuse 4..6, rho 7) and 16 fp32 biases in accumulator-row order.
-#define TVR_IMG_REF_ZROW (TVR_IMG_W3 + 3 * TVR_IMG_W3_ROW)
-#define TVR_IMG_REFW (TVR_MLP_IMAGE_BYTES + 64)
 #define TVR_IMG_REF_ROW 576
+#define TVR_IMG_REF_ZROW TVR_MLP_IMAGE_BYTES
+#define TVR_IMG_REFW (TVR_MLP_IMAGE_BYTES + TVR_IMG_REF_ROW)
 #define TVR_IMG_REFB (TVR_IMG_REFW + 8 * TVR_IMG_REF_ROW)
-#define TVR_MLP_IMAGE_BYTES_REF (TVR_IMG_REFB + 64)               // 163 040 B
+#define TVR_MLP_IMAGE_BYTES_REF (TVR_IMG_REFB + 64)               // 163 552 B (+ 16 B of matrix tokens <= 163 840)
+static_assert(TVR_MLP_IMAGE_BYTES_REF + 16 <= 160 * 1024, "REFTensoRF's LDS image must fit the CU's 160 KB");
 #define TVR_NIN_REF 151  // 1 + 27 + 3 + 2*2*27 + 2*2*3 (MLPRender_Fea_Ref, models/REFTensoRF.py:9)
 #define TVR_BASIS_FRAG_BYTES (9 * 2 * 32 * 16)   // global: the LO parts of the basis fragments [9 k-steps][2 halves][32 rows][16 B] (hi parts: LDS image)
 

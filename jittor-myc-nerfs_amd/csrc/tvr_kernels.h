@@ -85,6 +85,6 @@ hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const 
 size_t mlp_train_image_bytes();
 hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, void *image, hipStream_t stream);
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
-                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, const void *image, hipStream_t stream);
+                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, hipStream_t stream);
 hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, float *value, float *grad, float *part, hipStream_t stream);
 hipError_t launch_alpha_bits(const float *vol, long long n, unsigned *bits, hipStream_t stream);

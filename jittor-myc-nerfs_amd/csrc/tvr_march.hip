@@ -29,6 +29,7 @@
 #endif
 #define MARCH_MAX_WAVES 16
 #define MARCH_TILE 16                     // rays per tile
+#define MARCH_SPIN_LIMIT (1u << 22)       // s_sleep(1) each: ~0.15 s, against a legitimate wait of microseconds
 #define MARCH_HDR 272                     // LDS header: ray cursor (16 B) + 32 slots of {local tile number + 1, global tile} (dynamic tile queue)
 #ifndef TVR_MARCH_DYN
 #define TVR_MARCH_DYN 1                   // 1: workgroups take 16-ray tiles from ONE global counter (in order), not a fixed stride: no tail when a launch has few tiles per group
@@ -126,8 +127,12 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
         if (lane == 0) ci = atomicAdd(cursor, 1u);
         ci = __builtin_amdgcn_readfirstlane(ci);
 #if TVR_MARCH_DYN
-        // the wave that draws the first ray of local tile k takes the next global tile and publishes it; the others wait for the slot
-        // (32 slots: a waiter would have to fall 512 rays behind the cursor to see its slot reused)
+        // the wave that draws the first ray of local tile k takes the next global tile and publishes it {k + 1, tile} in slot k & 31; the others
+        // wait for the slot's generation to become k + 1.  Why the wait ends: the publisher stores right behind its draw (one global atomic,
+        // ~2 us), and the slot is only overwritten by the publisher of local tile k + 32, which needs the group's cursor to advance by 512 rays
+        // first — 34 rays per partner wave, >= 1 us each even when they miss the box.  The wait is nevertheless BOUNDED and a miss is LOUD:
+        // a waiter that finds a later generation in its slot (it was overtaken) or spins MARCH_SPIN_LIMIT times raises mo.counter[2], stops
+        // drawing rays, and the composite kernel then writes NaN to every pixel of the call (tvr.h: tvr_scratch_layout.counter).
         int tile;
         {
             const unsigned k = ci / MARCH_TILE, slot = k & 31u;
@@ -135,15 +140,28 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
                 unsigned t = 0;
                 if (lane == 0) {
                     t = atomicAdd(mo.counter + 1, 1u);
+#ifdef TVR_FAULT_INJECT_MARCH                          // test build only (tests/test_gpu_faults.py): the publisher of local tile 3 of group 0 skips a generation
+                    if (blockIdx.x == 0 && k == 3u) __hip_atomic_store(&slots[slot], ((unsigned long long)(k + 33u) << 32) | t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else
+#endif
                     __hip_atomic_store(&slots[slot], ((unsigned long long)(k + 1u) << 32) | t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 tile = (int)__builtin_amdgcn_readfirstlane(t);
             } else {
                 unsigned long long v;
-                do {
+                unsigned spins = 0u, fault = 0u;
+                for (;;) {
                     v = __hip_atomic_load(&slots[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if ((unsigned)(v >> 32) != k + 1u) __builtin_amdgcn_s_sleep(1);
-                } while ((unsigned)(v >> 32) != k + 1u);
+                    const unsigned gen = (unsigned)(v >> 32);
+                    if (gen == k + 1u) break;
+                    if (gen > k + 1u) { fault = 1u; break; }                       // overtaken: this tile's number is gone
+                    if (++spins > MARCH_SPIN_LIMIT) { fault = 2u; break; }         // the publisher never stored
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (fault) {
+                    if (lane == 0) atomicOr(mo.counter + 2, fault);
+                    break;
+                }
                 tile = (int)(unsigned)v;
             }
         }
@@ -389,6 +407,12 @@ __global__ __launch_bounds__(256) void composite_kernel(const MarchOut mo, const
         c2 = c2 + __shfl_xor(c2, off);
     }
     if (!live || l != 0) return;
+    if (mo.counter[2] != 0u) {                        // the march raised its fault flag (tile-queue wait): no pixel of this call is trustworthy
+        const float qnan = __int_as_float(0x7fc00000);
+        rgb_out[(size_t)r * 3 + 0] = qnan; rgb_out[(size_t)r * 3 + 1] = qnan; rgb_out[(size_t)r * 3 + 2] = qnan;
+        mo.depth[r] = qnan;
+        return;
+    }
     const float acc = mo.acc[r];
     if (white_bg) {
         const float bg = 1.0f - acc;

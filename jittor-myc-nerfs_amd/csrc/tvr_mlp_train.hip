@@ -107,6 +107,7 @@ struct MlpBwdArgs {
     const float *gscale;                             // device scalar: gradients are multiplied by this power of two on entry, by its inverse on exit
     float *d_out, *dh2, *dh1, *dfeats;               // [m,4], [m,128], [m,128], [m,32]
     const unsigned char *image;                      // TI_BYTES
+    unsigned *sat;                                   // optional: set to 1 when a scaled gradient reaches fp16's largest finite value on its way into a product
 };
 
 __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_kernel(const MlpBwdArgs a)
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
     }
     const long long n_tiles = (a.m + 31) / 32;
     const float gscale = *a.gscale, inv_scale = 1.0f / gscale;
+    float amax = 0.0f;                               // largest |operand| this lane split to fp16 (v_cvt_pkrtz saturates at 65 504 silently)
     for (long long tile = (long long)blockIdx.x * MT_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * MT_WAVES) {
         const long long ent = tile * 32 + e;
         const bool live = ent < a.m;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
             auto frag = [&](int s, Frag &b) {
                 float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = dh2[s >> 1][8 * (s & 1) + j];
+                for (int j = 0; j < 8; ++j) { x[j] = dh2[s >> 1][8 * (s & 1) + j]; amax = fmaxf(amax, fabsf(x[j])); }
                 b = split8(x);
             };
             Frag bcur, bnxt;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
             auto frag = [&](int s, Frag &b) {
                 float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = dh1[s >> 1][8 * (s & 1) + j];
+                for (int j = 0; j < 8; ++j) { x[j] = dh1[s >> 1][8 * (s & 1) + j]; amax = fmaxf(amax, fabsf(x[j])); }
                 b = split8(x);
             };
             // (the ten weight fragments of a step are fetched in the step itself: 144 accumulator registers leave no room for a second set;
@@ -286,16 +288,18 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (a.sat && amax >= 65504.0f) atomicOr(a.sat, 1u);
 }
 
 // dh^T [144 x 32e] = Bas^T [144 x 32] dF^T [32 x 32e]  (gscale as above; dF is stored unscaled)
 __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__restrict__ dfeats, long long m, const float *__restrict__ gscale_p, const unsigned char *__restrict__ image,
-                                                                float *__restrict__ dh)
+                                                                float *__restrict__ dh, unsigned *sat)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = lane & 31, h = lane >> 5;
     const long long n_tiles = (m + 31) / 32;
     const float gscale = *gscale_p, inv_scale = 1.0f / gscale;
+    float amax = 0.0f;
     // the 20 A fragments of this lane (same for every tile)
     uint4 ah[5][2], al[5][2];
 #pragma unroll
@@ -318,6 +322,8 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(x[r]));
         const Frag b0 = split8(x), b1 = split8(x + 8);
         f32x16 acc[5];
 #pragma unroll
@@ -347,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (sat && amax >= 65504.0f) atomicOr(sat, 1u);
 }
 
 size_t mlp_train_image_bytes() { return TI_BYTES; }
@@ -359,19 +366,19 @@ hipError_t launch_pack_train_image(const float *W1, const float *W2, const float
 }
 
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
-                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, const void *image, hipStream_t stream)
+                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, hipStream_t stream)
 {
     hipError_t rc = hipFuncSetAttribute((const void *)mlp_train_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TI_LDS_BYTES);
     if (rc != hipSuccess) return rc;
     MlpBwdArgs a;
     a.grad_rgb = grad_rgb; a.rgb = rgb; a.feats = feats; a.h1 = h1; a.h2 = h2; a.m = m; a.gscale = gscale;
-    a.d_out = d_out; a.dh2 = dh2; a.dh1 = dh1; a.dfeats = dfeats; a.image = (const unsigned char *)image;
+    a.d_out = d_out; a.dh2 = dh2; a.dh1 = dh1; a.dfeats = dfeats; a.image = (const unsigned char *)image; a.sat = sat_flag;
     const long long groups = (m + 32 * MT_WAVES - 1) / (32 * MT_WAVES);
     unsigned grid = groups < 256 ? (unsigned)(groups > 0 ? groups : 1) : 256u;
     hipLaunchKernelGGL(mlp_train_backward_kernel, dim3(grid), dim3(MT_THREADS), TI_LDS_BYTES, stream, a);
     rc = hipGetLastError();
     if (rc != hipSuccess) return rc;
     const long long g2 = (m + 127) / 128;
-    hipLaunchKernelGGL(basis_backward_kernel, dim3((unsigned)(g2 < 1024 ? (g2 > 0 ? g2 : 1) : 1024)), dim3(256), 0, stream, dfeats, m, gscale, (const unsigned char *)image, dh);
+    hipLaunchKernelGGL(basis_backward_kernel, dim3((unsigned)(g2 < 1024 ? (g2 > 0 ? g2 : 1) : 1024)), dim3(256), 0, stream, dfeats, m, gscale, (const unsigned char *)image, dh, sat_flag);
     return hipGetLastError();
 }

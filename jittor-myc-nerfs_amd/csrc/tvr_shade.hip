@@ -297,17 +297,24 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 #define TVR_MSLEEP 2
 #endif
 #if TVR_MTOKEN
+// The token only shapes the schedule: results do not depend on it.  The wait is therefore BOUNDED — after TVR_MTOKEN_SPINS polls (a legitimate wait
+// is the partner's matrix phase, ~6 us = ~50 polls) the wave goes ahead WITHOUT the token and gives nothing back (`have_tok`), so a lost or
+// stuck token can cost speed but never hang the grid or change a pixel.
+#ifndef TVR_MTOKEN_SPINS
+#define TVR_MTOKEN_SPINS 4096
+#endif
 #define TVR_TOKEN_TAKE(t)                                                                   \
     do {                                                                                    \
-        int got_;                                                                           \
+        int got_, n_ = 0;                                                                   \
         do {                                                                                \
             int r_ = 1;                                                                     \
             if (lane == 0) r_ = atomicCAS((t), 0, 1);                                       \
             got_ = __builtin_amdgcn_readfirstlane(r_);                                      \
             if (got_) __builtin_amdgcn_s_sleep(TVR_MSLEEP);                                 \
-        } while (got_);                                                                     \
+        } while (got_ && ++n_ < TVR_MTOKEN_SPINS);                                          \
+        have_tok = !got_;                                                                   \
     } while (0)
-#define TVR_TOKEN_GIVE(t) do { if (lane == 0) atomicExch((t), 0); } while (0)
+#define TVR_TOKEN_GIVE(t) do { if (have_tok && lane == 0) atomicExch((t), 0); } while (0)
 #define TVR_ENTER_MATRIX() do { TVR_TOKEN_TAKE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_M); } while (0)
 #define TVR_LEAVE_MATRIX() do { TVR_TOKEN_GIVE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_G); } while (0)
 #else
@@ -333,7 +340,22 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #endif
         __syncthreads();
     }
+#ifdef TVR_DEBUG_SIMD
+    // debug build (tests/test_gpu_faults.py): the token pairs waves w and w + 4, assuming they sit on one SIMD.  HW_REG_HW_ID bits [5:4] = SIMD id.
+    // Every wave publishes its id through the (not yet used) q_out tail slot of stats: stats[16 + wave] of workgroup 0, and every workgroup
+    // counts its mismatching pairs into stats[15].
+    {
+        __shared__ int simd_of[SH_WAVES];
+        const int hw = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) /* HW_REG_HW_ID (4), offset 4, size 2: simm16 = id | offset << 6 | (size - 1) << 11 */;
+        if (lane == 0) simd_of[wave] = hw;
+        __syncthreads();
+        if (a.stats && tid < SH_WAVES / 2 && simd_of[tid] != simd_of[tid + SH_WAVES / 2]) atomicAdd((unsigned long long *)&a.stats[15], 1ull);
+        if (a.stats && blockIdx.x == 0 && tid < SH_WAVES) a.stats[16 + tid] = (unsigned long long)simd_of[tid];
+        __syncthreads();
+    }
+#endif
 #if TVR_MTOKEN
+    bool have_tok = false;
     int *mtok = (int *)(smem + (BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES))) + (wave & 3);
 #endif
     // basis hi fragment of lane (e, h) at k-step s: rows 27..31 of the 32-row tile do not exist (their outputs are never used): clamp

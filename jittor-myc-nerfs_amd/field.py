@@ -52,7 +52,7 @@ class AlphaGridMask:
             return out
         ag, ab, inv = self._c_args()
         L.check(L.lib().tvr_alpha_sample(self.alpha_volume.data_ptr(), C.byref(ag), C.byref(ab), C.byref(inv),
-                                         x.data_ptr(), x.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+                                         x.data_ptr(), x.shape[0], out.data_ptr(), L.nbytes(out), _stream_ptr(self.device)),
                 "tvr_alpha_sample")
         return out
 
@@ -384,6 +384,27 @@ class TensorBase(torch.nn.Module):
             self._train_image = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._train_image
 
+    # The fused backward multiplies the output gradients by a power of two that brings max |grad_rgb| to ~grad_scale_target (its matrix products
+    # take fp16 hi/lo operands: 65 504 is the largest finite one and the conversion saturates silently).  |dH1| <= 128 |W2|max * 3 |W3|max * target,
+    # so unusually large MLP weights can run the chain into that limit; the kernels then raise this device flag.
+    grad_scale_target = 64.0
+
+    def _get_sat_flag(self) -> torch.Tensor:
+        if getattr(self, "_sat_flag", None) is None:
+            self._sat_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._sat_flag
+
+    def check_gradient_saturation(self) -> bool:
+        """True if a training backward since the last call clipped a gradient at fp16's range (one host read: call it where the loop reads the
+        loss anyway).  The scale target is lowered by 2^4 and the flag cleared, so the following steps are clean; the clipped step is the caller's
+        to skip or accept."""
+        f = getattr(self, "_sat_flag", None)
+        if f is None or int(f.item()) == 0:
+            return False
+        f.zero_()
+        self.grad_scale_target = max(self.grad_scale_target / 16.0, 2.0 ** -20)
+        return True
+
     def _get_scratch(self, nbytes: int) -> torch.Tensor:
         if self._scratch is None or self._scratch.numel() < nbytes:
             self._scratch = None
@@ -395,7 +416,7 @@ class TensorBase(torch.nn.Module):
         sc = self._ensure_scene()
         x = _f32c(xyz_sampled, self.device).view(-1, 3)
         out = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
-        L.check(L.lib().tvr_density_feature(sc, x.data_ptr(), x.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+        L.check(L.lib().tvr_density_feature(sc, x.data_ptr(), x.shape[0], out.data_ptr(), L.nbytes(out), _stream_ptr(self.device)),
                 "tvr_density_feature")
         return out
 
@@ -403,7 +424,7 @@ class TensorBase(torch.nn.Module):
         sc = self._ensure_scene()
         x = _f32c(xyz_sampled, self.device).view(-1, 3)
         out = torch.empty((x.shape[0], self.app_dim), dtype=torch.float32, device=self.device)
-        L.check(L.lib().tvr_app_feature(sc, x.data_ptr(), x.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+        L.check(L.lib().tvr_app_feature(sc, x.data_ptr(), x.shape[0], out.data_ptr(), L.nbytes(out), _stream_ptr(self.device)),
                 "tvr_app_feature")
         return out
 
@@ -412,7 +433,7 @@ class TensorBase(torch.nn.Module):
         v = _f32c(viewdirs, self.device).view(-1, 3)
         f = _f32c(features, self.device).view(-1, self.app_dim)
         out = torch.empty((v.shape[0], 3), dtype=torch.float32, device=self.device)
-        L.check(L.lib().tvr_mlp_render(sc, v.data_ptr(), f.data_ptr(), v.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+        L.check(L.lib().tvr_mlp_render(sc, v.data_ptr(), f.data_ptr(), v.shape[0], out.data_ptr(), L.nbytes(out), _stream_ptr(self.device)),
                 "tvr_mlp_render")
         return out
 

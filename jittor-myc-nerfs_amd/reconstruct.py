@@ -235,7 +235,11 @@ def reconstruction(args, device="cuda", log=print):
             total_loss = total_loss + pen_w * tensorf.penalty
             tensorf.penalty = torch.zeros((), device=device)
         total_loss.backward()
-        optimizer.step()
+        if tensorf.check_gradient_saturation():       # the fused backward clipped a gradient at fp16's range (field.py): drop this update; the scale is already lowered
+            log(f"Iteration {iteration:05d}: gradient scale lowered to {tensorf.grad_scale_target:g} (fp16 operand range reached); update skipped")
+            optimizer.zero_grad(set_to_none=True)
+        else:
+            optimizer.step()
         PSNRs.append(-10.0 * np.log(float(loss.detach())) / np.log(10.0))
         for pg in optimizer.param_groups:
             pg["lr"] = pg["lr"] * lr_factor

@@ -93,7 +93,8 @@ class REFTensoRF(TensorVMSplit):
             return self._heads(_AppHFn.apply(self, x, *self.app_plane, *self.app_line))
         feats = torch.empty((x.shape[0], self.app_dim), dtype=torch.float32, device=self.device)
         extra = torch.empty((x.shape[0], 8), dtype=torch.float32, device=self.device)
-        L.check(L.lib().tvr_app_feature_ref(sc, x.data_ptr(), x.shape[0], feats.data_ptr(), extra.data_ptr(), _stream_ptr(self.device)),
+        L.check(L.lib().tvr_app_feature_ref(sc, x.data_ptr(), x.shape[0], feats.data_ptr(), L.nbytes(feats), extra.data_ptr(), L.nbytes(extra),
+                                             _stream_ptr(self.device)),
                 "tvr_app_feature_ref")
         return feats, extra[:, 3:6], extra[:, 6:7], extra[:, 0:3], extra[:, 7:8]
 
@@ -108,7 +109,7 @@ class REFTensoRF(TensorVMSplit):
         if d.shape[0] != v.shape[0] or f.shape[0] != v.shape[0]:
             raise ValueError("viewdirs, features and dot_product must describe the same samples")
         out = torch.empty((v.shape[0], 3), dtype=torch.float32, device=self.device)
-        L.check(L.lib().tvr_mlp_render_ref(sc, v.data_ptr(), f.data_ptr(), d.data_ptr(), v.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+        L.check(L.lib().tvr_mlp_render_ref(sc, v.data_ptr(), f.data_ptr(), d.data_ptr(), v.shape[0], out.data_ptr(), L.nbytes(out), _stream_ptr(self.device)),
                 "tvr_mlp_render_ref")
         return out
 

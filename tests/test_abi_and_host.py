@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(l, n), f"libtvr.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and include/*.h disagree"
-    assert _lib.lib().tvr_version() == 108
+    assert _lib.lib().tvr_version() == 109
 
 
 def test_abi_argument_errors_without_gpu():
@@ -60,8 +60,55 @@ def test_abi_argument_errors_without_gpu():
     d.featureC = 64                                                     # ... at the standard shape only
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"REFTensoRF" in lib.tvr_last_error()
     d.featureC = 128
-    assert lib.tvr_app_feature_ref(None, None, 0, None, None, None) == -1
-    assert lib.tvr_mlp_render_ref(None, None, None, None, 0, None, None) == -1
+    assert lib.tvr_app_feature_ref(None, None, 0, None, 0, None, 0, None) == -1
+    assert lib.tvr_mlp_render_ref(None, None, None, None, 0, None, 0, None) == -1
+
+
+def test_abi_refuses_undersized_output_buffers_without_gpu():
+    """Every output matrix whose row width is the kernels' own carries a byte count that is checked on the host BEFORE any launch (round 2:
+    tvr_app_h_forward's h allocated as [m, sum(app_n_comp)] instead of the kernels' [m,144] was overrun on the device and aborted the process).
+    The check precedes every other argument check, so it can be exercised here without a GPU: a buffer one float short is TVR_ERR_SCRATCH (-3)."""
+    from jittor_myc_nerfs_amd import _lib as L
+    lib, m, SCRATCH = L.lib(), 1000, -3
+    dummy = C.c_void_p(4096)                                           # never dereferenced: the size check comes first
+    big = 1 << 40
+
+    def refused(rc, what):
+        assert rc == SCRATCH, (what, rc, lib.tvr_last_error())
+        assert what.encode() in lib.tvr_last_error(), lib.tvr_last_error()
+
+    refused(lib.tvr_app_h_forward(None, dummy, m, dummy, m * 144 * 4 - 4, None), "h_out [m,144]")
+    refused(lib.tvr_app_h_forward(None, dummy, m, dummy, m * 96 * 4, None), "h_out [m,144]")          # the round-2 caller: 96 = 3 x 32 components
+    refused(lib.tvr_app_h_backward(None, dummy, m, dummy, m * 144 * 4 - 4, dummy, big, None, None), "dh [m,144]")
+    refused(lib.tvr_density_feature(None, dummy, m, dummy, m * 4 - 4, None), "out [m]")
+    refused(lib.tvr_app_feature(None, dummy, m, dummy, m * 27 * 4 - 4, None), "out [m,27]")
+    refused(lib.tvr_mlp_render(None, dummy, dummy, m, dummy, m * 3 * 4 - 4, None), "rgb [m,3]")
+    refused(lib.tvr_app_feature_ref(None, dummy, m, dummy, m * 27 * 4 - 4, dummy, big, None), "features [m,27]")
+    refused(lib.tvr_app_feature_ref(None, dummy, m, dummy, big, dummy, m * 8 * 4 - 4, None), "extra [m,8]")
+    refused(lib.tvr_mlp_render_ref(None, dummy, dummy, dummy, m, dummy, m * 3 * 4 - 4, None), "rgb [m,3]")
+    ag, ab, inv = (C.c_int32 * 3)(4, 4, 4), (C.c_float * 6)(), (C.c_float * 3)()
+    refused(lib.tvr_alpha_sample(dummy, C.byref(ag), C.byref(ab), C.byref(inv), dummy, m, dummy, m * 4 - 4, None), "out [m]")
+    refused(lib.tvr_pe_concat(dummy, dummy, None, m, dummy, m * 150 * 4 - 4, None), "X [m,150]")
+    refused(lib.tvr_pe_concat(dummy, dummy, dummy, m, dummy, m * 150 * 4, None), "X [m,151]")          # with dot_product the row is 151 wide
+    refused(lib.tvr_pe_concat_backward(dummy, dummy, dummy, m, 0, dummy, m * 27 * 4 - 4, None, None, None), "grad_features [m,27]")
+    ok = [m * 3 * 4, m * 32 * 4, m * 128 * 4, m * 128 * 4]
+    names = ["rgb [m,3]", "feats32 [m,32]", "h1 [m,128]", "h2 [m,128]"]
+    for i, n in enumerate(names):
+        sizes = list(ok)
+        sizes[i] -= 4
+        args = [x for sz in sizes for x in (dummy, sz)]
+        refused(lib.tvr_mlp_train_forward(None, dummy, dummy, m, *args, None), n)
+    assert lib.tvr_mlp_train_forward(None, dummy, dummy, 8_000_000, *[x for sz in ok for x in (dummy, big)], None) == -1      # m * 576 >= 2^32
+    assert b"32-bit row offsets" in lib.tvr_last_error()
+    okb = [m * 4 * 4, m * 128 * 4, m * 128 * 4, m * 32 * 4, m * 144 * 4]
+    namesb = ["d_out4 [m,4]", "dh2 [m,128]", "dh1 [m,128]", "dfeats32 [m,32]", "dh [m,144]"]
+    for i, n in enumerate(namesb):
+        sizes = list(okb)
+        sizes[i] -= 4
+        args = [x for sz in sizes for x in (dummy, sz)]
+        refused(lib.tvr_mlp_train_backward(*([dummy] * 9), m, dummy, *args, None, dummy, big, None), n)
+    # with every size right, the next check (no scene / NULL arguments) answers: nothing was launched
+    assert lib.tvr_app_h_forward(None, dummy, m, dummy, m * 144 * 4, None) == -1
 
 
 def test_ref_field_host_logic():
