@@ -8,11 +8,12 @@
 A "step" = one pass of the hot path over one batch of synthetic rays resident in HBM:
   N = 1 : one 800x800 frame = 640 000 rays x 512 samples of scene A (TensorVMSplit 300^3) — BASELINE configs[1];
           ONE tvr_render call (march + shade + composite kernels).
-  N > 1, --scaling weak (default): a batch of N such frames (N camera poses); the N*640 000 rays are cut into 4096-ray
-          tiles dealt round-robin to the ranks (every rank renders 640 000 rays), then ONE all_gather of [rays,4] fp32
-          pixels (rgb+depth) over RCCL/xGMI returns all N frames to every rank and ONE index gather undoes the interleave.
-  N > 1, --scaling strong: BASELINE configs[2] as written — ONE 640 000-ray frame, rank r renders tiles r, r+N, ...
-          (80 000 rays each at N = 8), one all_gather, one index gather; efficiency = t_1 / (N t_N).
+  N > 1 (default, --scaling strong): BASELINE configs[2] as written — the SAME ONE 640 000-ray frame, cut into 4096-ray tiles dealt
+          round-robin to the ranks (rank r renders tiles r, r+N, ...: 80 000 rays each at N = 8), then ONE all_gather of [rays,4] fp32
+          pixels (rgb+depth) over RCCL/xGMI returns the frame to every rank and ONE index gather undoes the interleave.  Total work is
+          fixed, so the line says "scaling": "strong" at every N (N = 1 included) and SURVEY 8e's t_1 / (N t_N) is value(N) / (N value(1)).
+          Rank 0 also times the whole frame alone (outside the timed region) and reports it as `strong_split.t1_ms`.
+  N > 1, --scaling weak (on request): a batch of N such frames (N camera poses), every rank renders 640 000 rays.
   --emulate-world N (single GPU): time rank 0's share of an N-way strong split without the exchange (what a rank's
           kernels cost at that size: persistent-kernel fill, LDS image reload).
 value = nominal ray-samples/s = (rays x 512) / time, whole job (every ray counted with all 512 samples, masked or
@@ -38,6 +39,7 @@ import torch  # noqa: E402
 
 N_POSES = 8
 TILE = 4096
+SHADE_LOADS_PER_TILE = 123      # tvr_shade.hip, wave-level global loads per 32-entry tile: 108 taps + 9 basis fragments (lo parts) + 6 entry / direction
 
 
 def build_model(device, name="TensorVMSplit"):
@@ -156,6 +158,12 @@ def bench_ngp(args, world, rank, device):
     ev_per = evaluated / args.steps
     BYTES = 16 * 8 * 8 + 4 + 12                  # per evaluated sample: 16 levels x 8 corners x 8 B of table, its recorded t, 12 B of output share
     ach = BYTES * ev_per / (k_ms[1] * 1e-3) / 1e9
+    # roofline.traffic, live, as on the main path: rocprofv3 --pmc child passes of this same command after the timed region (rank 0, N = 1)
+    pmc, pmc_source = {}, "not collected (--pmc off or N > 1)"
+    if args.pmc == "auto" and world == 1 and rank == 0:
+        pmc, pmc_source = collect_pmc(["--model", "NGPNetworks"], passes=PMC_PASSES[:3])
+    pr_ = _pmc_kernel(pmc, "ngp_render_kernel")
+    traffic = (2.0 * pr_["FETCH_SIZE"] + pr_["WRITE_SIZE"]) * 1024.0 if ("FETCH_SIZE" in pr_ and "WRITE_SIZE" in pr_) else None
     result = {
         "metric": "ray_samples_per_sec", "value": marched * world / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (emulated: 3 x f16-split MFMA products, fp32 accumulate; fp32 VALU elsewhere)", "data": "synthetic",
@@ -169,7 +177,9 @@ def bench_ngp(args, world, rank, device):
         "effective": {"marched_samples_per_frame": marched / args.steps, "evaluated_samples_per_frame": ev_per},
         "kernel_ms": {"march": k_ms[0], "render": k_ms[1]},
         "roofline": {"kernel": "ngp_render_kernel<true>", "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                     "traffic": None, "traffic_source": "not measured in this run (a committed pass, profiles/r01_ngp_pmc.json: 70.6 GB per launch)", "algorithmic_bytes_per_launch": BYTES * ev_per, "ms": k_ms[1],
+                     "traffic": traffic, "traffic_source": pmc_source, "algorithmic_bytes_per_launch": BYTES * ev_per, "ms": k_ms[1],
+                     "clock_GHz_pmc_pass": (pr_["GRBM_GUI_ACTIVE"] / 8.0 / pr_["_dur_s"] / 1e9) if (pr_.get("GRBM_GUI_ACTIVE") and pr_.get("_dur_s")) else None,
+                     "mfma_busy_frac": (pr_["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (pr_["GRBM_GUI_ACTIVE"] / 8.0)) if pr_.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in pr_ else None,
                      "note": f"{BYTES} B per evaluated sample; the 52 MB of tables sit in L2 / MALL, so the measured traffic is fabric traffic of random 128-B lines"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -203,7 +213,7 @@ PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
               ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"))
 
 
-def collect_pmc(extra_args, budget_s=420.0):
+def collect_pmc(extra_args, budget_s=420.0, passes=None):
     """One rocprofv3 --pmc pass per counter set over `bench.py --steps 2 --warmup 1` in a child process (program directly behind `--`).
     Returns ({kernel short name: {counter: mean per dispatch}}, source string)."""
     import csv
@@ -216,7 +226,7 @@ def collect_pmc(extra_args, budget_s=420.0):
         return {}, "rocprofv3 not found: traffic not measured"
     out, t_start, done = {}, time.time(), []
     env = dict(os.environ, TMPDIR="/tmp")
-    for counters in PMC_PASSES:
+    for counters in (passes or PMC_PASSES):
         if time.time() - t_start > budget_s:
             break
         d = tempfile.mkdtemp(prefix="tvr_pmc_", dir="/tmp")
@@ -233,6 +243,8 @@ def collect_pmc(extra_args, budget_s=420.0):
                 for row in csv.DictReader(open(f)):
                     k = row["Kernel_Name"].split("(")[0].replace("void ", "")
                     acc.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                    if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("End_Timestamp"):       # this pass's own kernel duration, for its own clock
+                        acc[k].setdefault("_dur_s", []).append((float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-9)
             for k, cs in acc.items():
                 for c, v in cs.items():
                     out.setdefault(k, {})[c] = sum(v) / len(v)
@@ -267,8 +279,9 @@ def main():
     ap.add_argument("--model", choices=["TensorVMSplit", "REFTensoRF", "NGPNetworks"], default="TensorVMSplit",
                     help="model_name (opt.py:44): TensorVMSplit is the BASELINE workload; REFTensoRF is the variant configs/Scar.txt trains; "
                          "NGPNetworks is the JNeRF Instant-NGP alt path (BASELINE configs[4]; replicas only for N > 1)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = N frames per step (per-GPU work fixed); strong = ONE frame split over the ranks (BASELINE configs[2])")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: strong (default) = ONE frame split over the ranks (BASELINE configs[2]; SURVEY 8e's metric); weak = N frames per step "
+                         "(per-GPU work fixed)")
     ap.add_argument("--emulate-world", type=int, default=0, help="single GPU: render only rank 0's share of an N-way strong split (no exchange)")
     ap.add_argument("--check", action="store_true", help="N > 1: every rank also renders the whole batch alone and compares the gathered pixels bit for bit")
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto", help="auto: rank 0 at N = 1 measures roofline.traffic with rocprofv3 --pmc child passes")
@@ -326,7 +339,7 @@ def main():
         batch = torch.cat([fr[(pat * frames_per_step + r) % N_POSES] for r in range(frames_per_step)]) if frames_per_step > 1 else fr[pat % N_POSES]
         idx = shard_indices(R_step, rank, split, TILE)
         step_rays.append(batch[idx].contiguous().to(device))
-        if args.check and world > 1:
+        if world > 1 and (args.check or strong):
             full_rays.append(batch.to(device))
     n_mine = step_rays[0].shape[0]
     inv = shard_gather_index(R_step, world, TILE, device) if world > 1 else None
@@ -370,12 +383,14 @@ def main():
     torch.cuda.synchronize()
     # the interpreter's cyclic collector is parked for the timed region: a full collection of this process's heap takes ~40 ms of host time
     # (TVR_BENCH_TRACE=1 shows it as one step call that long), invisible beside 20 ms steps, 1 ms per step beside a 2.7 ms share of a frame
+    # occupancy counters and the in-kernel clock probes (TVR_STAT_*) of exactly the timed launches: a handful of atomics at the END of each kernel
+    stats = torch.zeros(8, dtype=torch.int64, device=device)
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
     trace = [] if os.environ.get("TVR_BENCH_TRACE") else None
     for s in range(args.steps):
-        step(args.warmup + s, profile=prof if prof_in_region else None)
+        step(args.warmup + s, profile=prof if prof_in_region else None, stats=stats)
         if trace is not None:
             trace.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
@@ -417,13 +432,31 @@ def main():
             raise SystemExit("bench.py --check: the gathered frame differs from the single-rank render")
         check = "gathered == single-rank render, bit for bit"
 
-    # occupancy statistics of exactly the timed steps (untimed pass with counters on)
-    stats = torch.zeros(8, dtype=torch.int64, device=device)
-    for s in range(args.steps):
-        step(args.warmup + s, stats=stats)
-    torch.cuda.synchronize()
-    st = stats.cpu().numpy().astype(np.float64) / max(args.steps, 1)      # per launch (this rank)
+    # BASELINE configs[2]'s own yardstick: the SAME frame rendered by one rank alone (outside the timed region; every rank does it on its own
+    # GPU so that nobody idles at the next barrier, rank 0's time is reported).  SURVEY 8e: efficiency = t_1 / (N t_N).
+    strong_split = None
+    if strong:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1s = []
+        for s in range(max(3, min(args.steps, 10)) + 1):
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            model.render_rays(full_rays[s % n_patterns], white_bg=True, N_samples=S, eps_T=args.eps_T)
+            torch.cuda.synchronize()
+            t1s.append(time.perf_counter() - ta)
+        t1 = float(np.median(t1s[1:]))
+        strong_split = {"t1_ms": t1 * 1e3, "tN_ms": dt / args.steps * 1e3, "N": world, "t1_over_N_tN": t1 / (world * dt / args.steps),
+                        "note": "t1 = the whole frame on rank 0's GPU alone, median of %d synchronised calls behind the timed region; tN = ms_per_step "
+                                "(max over ranks, exchange and un-permute included)" % (len(t1s) - 1)}
+        dist.barrier()
+
+    st = stats.cpu().numpy().astype(np.float64) / max(args.steps, 1)      # per step (this rank): counters of the timed launches themselves
     m_eval, m_bbox, m_app = float(st[0]), float(st[1]), float(st[2])
+
+    def probe_clock(i_clk, i_ref):                                  # s_memtime (shader clock) over s_memrealtime (100 MHz), summed over workgroups
+        return 0.1 * st[i_clk] / st[i_ref] if st[i_ref] > 0 else None
+    ck_march_probe, ck_shade_probe = probe_clock(4, 5), probe_clock(6, 7)
 
     # roofline.traffic: rocprofv3 --pmc passes over a 2-step run of this same bench, in CHILD processes (spawned, never exec'd from this
     # process), after the timed region — run before it, the profiler sessions left every later launch of this process ~0.5 ms slower
@@ -454,22 +487,32 @@ def main():
     # return width; the guide gives no L1 figure, its L2 aggregate is 34.5 TB/s) x 256 CUs x the clock measured under this load.
     l1_bytes = 40.0 * n_mine + 768.0 * m_eval + (32.0 * m_bbox if has_mask else 0.0)
     lds_bytes = 384.0 * m_eval
-    ck_m = clock_ghz(pm, t_march) or 2.1
-    SHADE_L1_B = 123 * 1024 / 32.0
-    L1_BCLK = 48.9               # B/clk/CU: the L1 -> register rate measured on MI355X for wave-level dwordx4 loads that all hit L1, 16 waves per CU
-                                 # (scripts/hwprobe/ta_rate.hip, profiles/r02_l1_rate_probe.txt: 21.0 cycles per 1-KB load); the nominal width is 64
-    l1_peak = 256 * L1_BCLK * ck_m                                  # GB/s
+    # The clock of the roof is the one the kernel ran at IN THE TIMED LAUNCHES (in-kernel s_memtime / s_memrealtime probe); the PMC child pass's
+    # GRBM_GUI_ACTIVE / 8 / (that pass's own kernel duration) is kept beside it as a cross-check.  peak = 256 CUs x 64 B/clk (the vector L1's
+    # data-return width) x that clock: bytes <= 64 B x CU-cycles, so frac <= 1 by construction.
+    ck_m = ck_march_probe or clock_ghz(pm, pm.get("_dur_s", 0.0)) or 2.1
+    L1_NOMINAL = 64.0
+    L1_PROBE = 48.9              # B/clk/CU a micro-probe of wave-level dwordx4 loads that all hit L1 sustains with 16 waves per CU (scripts/hwprobe/ta_rate.hip,
+                                 # profiles/r02_l1_rate_probe.txt: 21.0 cycles per 1-KB load).  A measurement of ONE access shape, not a roof: the march kernel's
+                                 # own shape (16 contiguous 64-B segments per load, 16 waves) runs slightly above it
+    l1_peak = 256 * L1_NOMINAL * ck_m                               # GB/s
     roof_march = {"kernel": "march_kernel<false>", "bound": "l1", "achieved": l1_bytes / t_march / 1e9 if t_march > 0 else None,
                   "peak": l1_peak, "unit": "GB/s", "frac": l1_bytes / t_march / 1e9 / l1_peak if t_march > 0 else None,
                   "traffic": hbm(pm), "algorithmic_bytes_per_launch": l1_bytes + lds_bytes, "l1_bytes_per_launch": l1_bytes,
                   "lds_bytes_per_launch": lds_bytes, "lds_GBps": lds_bytes / t_march / 1e9 if t_march > 0 else None,
-                  "frac_vs_nominal_64B_per_clk": l1_bytes / t_march / 1e9 / (256 * 64 * ck_m) if t_march > 0 else None,
-                  "clock_GHz": ck_m, "clock_source": "GRBM_GUI_ACTIVE / 8 / t (PMC child pass)" if clock_ghz(pm, t_march) else "nominal 2.1 (no PMC pass)",
+                  "ratio_to_l1_microprobe_48.9B_per_clk": l1_bytes / t_march / 1e9 / (256 * L1_PROBE * ck_m) if t_march > 0 else None,
+                  "clock_GHz": ck_m, "clock_source": ("in-kernel probe over the timed launches: 0.1 GHz x sum(s_memtime) / sum(s_memrealtime)" if ck_march_probe else
+                                                      ("GRBM_GUI_ACTIVE / 8 / kernel duration, both of the PMC child pass" if clock_ghz(pm, pm.get("_dur_s", 0.0)) else "nominal 2.1 (no probe, no PMC pass)")),
+                  "clock_GHz_pmc_pass": clock_ghz(pm, pm.get("_dur_s", 0.0)),
                   "vs_hbm_8TBps": (l1_bytes + lds_bytes) / t_march / 1e9 / 8000.0 if t_march > 0 else None, "ms": k_ms[0],
                   "lds_bank_conflict_frac": (pm["SQ_LDS_BANK_CONFLICT"] / pm["SQ_LDS_IDX_ACTIVE"]) if pm.get("SQ_LDS_IDX_ACTIVE") else None,
                   "note": "40 B/ray + 768 B through L1 + 384 B through LDS per density sample actually evaluated (+32 B per alpha-mask lookup); peak = 256 CUs x "
-                          "48.9 B/clk (measured L1-hit rate of wave-level 16-B-per-lane loads, profiles/r02_l1_rate_probe.txt) x measured clock.  The 17 MB of density factors are L2 / Infinity-Cache resident, so HBM is not the roof "
-                          "(vs_hbm_8TBps > 1 by construction, kept for SURVEY 8d's formula)"}
+                          "64 B/clk (vector-L1 data-return width) x the clock measured inside the timed launches.  The 17 MB of density factors are L2 / Infinity-Cache "
+                          "resident, so HBM is not the roof (vs_hbm_8TBps > 1 by construction, kept for SURVEY 8d's formula)"}
+    # wave-level dwordx4 loads (1 KB each) per 32-entry tile of the shade kernel: counted by the PMC pass when there is one, else the source's own count
+    loads_per_tile = (ps["SQ_INSTS_VMEM_RD"] / (m_app / 32.0)) if (ps.get("SQ_INSTS_VMEM_RD") and m_app > 0) else float(SHADE_LOADS_PER_TILE)
+    SHADE_L1_B = loads_per_tile * 1024 / 32.0
+    ck_s = ck_shade_probe or clock_ghz(ps, ps.get("_dur_s", 0.0)) or 1.7
     ach_shade = FLOP_APP * m_app / t_shade / 1e12 if t_shade > 0 else None
     roof_shade = {"kernel": "shade_kernel<0,0,%s>" % ("true" if args.model == "REFTensoRF" else "false"), "bound": "mfma", "achieved": ach_shade,
                   "peak": 2500.0, "unit": "TFLOP/s", "frac": ach_shade / 2500.0 if ach_shade else None,
@@ -483,7 +526,8 @@ def main():
                   "mfma_busy_frac": (ps["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (ps["GRBM_GUI_ACTIVE"] / 8.0)) if ps.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in ps else None,
                   "mfma_valu_coexec_frac_of_busy": (ps["SQ_VALU_MFMA_COEXEC_CYCLES"] / ps["SQ_VALU_MFMA_BUSY_CYCLES"]) if ps.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
                   "valu_insts_per_32_entry_tile": (ps["SQ_INSTS_VALU"] / (m_app / 32.0)) if ps.get("SQ_INSTS_VALU") and m_app > 0 else None,
-                  "clock_GHz": clock_ghz(ps, t_shade),
+                  "clock_GHz": ck_s, "clock_source": "in-kernel probe over the timed launches" if ck_shade_probe else "PMC child pass or nominal",
+                  "clock_GHz_pmc_pass": clock_ghz(ps, ps.get("_dur_s", 0.0)), "vmem_loads_per_32_entry_tile": loads_per_tile,
                   "valu_busy_frac": (ps["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (ps["GRBM_GUI_ACTIVE"] / 8.0)) if ps.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in ps else None,
                   "lds_busy_frac": (ps["SQ_LDS_IDX_ACTIVE"] / 256.0 / (ps["GRBM_GUI_ACTIVE"] / 8.0)) if ps.get("GRBM_GUI_ACTIVE") and "SQ_LDS_IDX_ACTIVE" in ps else None,
                   "lds_bank_conflict_frac": (ps["SQ_LDS_BANK_CONFLICT"] / ps["SQ_LDS_IDX_ACTIVE"]) if ps.get("SQ_LDS_IDX_ACTIVE") else None,
@@ -492,8 +536,9 @@ def main():
                   # + 36 B of queue entry / view direction through the vector L1
                   # 123 wave-level dwordx4 loads (1 KB each) per 32-entry tile: 108 taps, 9 basis fragments (lo parts), 6 entry / direction
                   "l1": {"bytes_per_launch": SHADE_L1_B * m_app, "achieved_GBps": SHADE_L1_B * m_app / t_shade / 1e9 if t_shade > 0 else None,
-                         "peak_GBps": 256 * L1_BCLK * (clock_ghz(ps, t_shade) or 1.9),
-                         "frac": SHADE_L1_B * m_app / t_shade / 1e9 / (256 * L1_BCLK * (clock_ghz(ps, t_shade) or 1.9)) if t_shade > 0 else None},
+                         "peak_GBps": 256 * L1_NOMINAL * ck_s,
+                         "frac": SHADE_L1_B * m_app / t_shade / 1e9 / (256 * L1_NOMINAL * ck_s) if t_shade > 0 else None,
+                         "ratio_to_l1_microprobe_48.9B_per_clk": SHADE_L1_B * m_app / t_shade / 1e9 / (256 * L1_PROBE * ck_s) if t_shade > 0 else None},
                   "note": f"{FLOP_APP / 1e3:.1f} kFLOP per appearance sample (algorithmic, fp32 semantics) against the dense f16 MFMA peak (2.5 PFLOP/s); "
                           "fp32-class arithmetic on this chip needs 3 fp16 products per fp32 product (hi/lo split; the fp32-input MFMA runs at 1/16 rate), "
                           f"so the ceiling for this arithmetic is peak / 3 = 833 TFLOP/s (frac_vs_fp32class_ceiling); executed on padded tiles: {FLOP_APP_EXEC} FLOP "
@@ -504,10 +549,11 @@ def main():
             r_["wave_cycles_frac"] = {k: c_[n] / c_["SQ_WAVE_CYCLES"] for k, n in (("waiting_on_waitcnt_or_barrier", "SQ_WAIT_ANY"), ("issue_stalled", "SQ_WAIT_INST_ANY"),
                                                                             ("issuing", "SQ_ACTIVE_INST_ANY")) if n in c_}
     dominant = roof_shade if k_ms[1] >= k_ms[0] else roof_march
-    mode = ("N>1 weak: N frames per step" if not strong else "N>1 strong: ONE frame split over the ranks (BASELINE configs[2])")
+    mode = ("N>1 weak: N frames per step" if (world > 1 and not strong) else "ONE frame per step at every N (N>1: split over the ranks, BASELINE configs[2])")
     result = {
         "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak" if (world > 1 and not strong) else "strong",          # default: ONE frame per step at every N (total work fixed)
         "vs_baseline": None, "dtype": "f32 (emulated: 3 x f16-split MFMA products, fp32 accumulate; fp32 VALU elsewhere)", "data": "synthetic",
         "config": {"workload": ("TensorVMSplit 300^3 (16/48 comps, MLP_Fea 150-128-128-3)" if args.model == "TensorVMSplit" else
                                 "REFTensoRF 300^3 (16/48 comps, 4 heads on h, MLP_Fea_Ref 151-128-128-3)") +
@@ -528,6 +574,8 @@ def main():
     }
     if check is not None:
         result["check"] = check
+    if strong_split is not None:
+        result["strong_split"] = strong_split
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(arrs, A, fr[0], with_c=(args.model == "TensorVMSplit"))
     elif rank == 0:

@@ -97,6 +97,9 @@ enum { TVR_STAT_SAMPLES_EVAL = 0,   /* density samples actually gathered (valid,
        TVR_STAT_SAMPLES_BBOX = 1,   /* in-box samples visited (alpha-mask lookups when a mask is set) */
        TVR_STAT_APP = 2,            /* appearance samples (weight > thres) */
        TVR_STAT_RAYS_TERMINATED = 3,/* rays stopped early by eps_T */
+       /* clock probes, summed over the workgroups of a launch: shader-clock ticks (s_memtime) and 100 MHz reference ticks (s_memrealtime) between
+        * a workgroup's first and last instruction -> the clock the kernel really ran at = 0.1 GHz * CLK / REF (bench.py's roofline peaks) */
+       TVR_STAT_MARCH_CLK = 4, TVR_STAT_MARCH_REF = 5, TVR_STAT_SHADE_CLK = 6, TVR_STAT_SHADE_REF = 7,
        TVR_STAT_COUNT = 8 };
 
 int tvr_version(void);

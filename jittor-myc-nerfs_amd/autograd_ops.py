@@ -171,7 +171,11 @@ class _MarchFn(torch.autograd.Function):
         else:
             L.check(lib.tvr_march_forward_z(sc, rays.data_ptr(), n, S, z_vals.data_ptr(), float(eps_T), depth.data_ptr(), lam.data_ptr(),
                                             scratch.data_ptr(), scratch.numel(), _stream_ptr(model.device)), "tvr_march_forward_z")
-        M = int(scratch[lay.counter:lay.counter + 4].view(torch.int32).item())           # host sync: the queue length sizes what follows
+        hdr = scratch[lay.counter:lay.counter + 16].view(torch.int32).tolist()           # host sync: the queue length sizes what follows
+        if hdr[2] != 0:
+            raise L.TvrError(f"tvr_march_forward: the march kernel raised its fault flag ({hdr[2]}): a wave gave up waiting for its tile number "
+                             f"(include/tvr.h, tvr_scratch_layout); the queue of this call is incomplete")
+        M = int(hdr[0])
         q_pos = scratch[lay.q_pos:lay.q_pos + M * 16].view(torch.float32).view(M, 4)
         w = q_pos[:, 3].clone()
         xyz = q_pos[:, :3].contiguous()

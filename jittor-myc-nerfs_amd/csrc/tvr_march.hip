@@ -111,6 +111,9 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
     }
     __syncthreads();
     const int sub = lane & 3;
+    // clock probe (stats only): shader-clock and 100 MHz reference ticks over this workgroup's lifetime
+    unsigned long long clk0 = 0ull, ref0 = 0ull;
+    if (mo.stats && threadIdx.x == 0) { clk0 = __builtin_amdgcn_s_memtime(); ref0 = __builtin_amdgcn_s_memrealtime(); }
 
     // this group's tiles: XCD x (groups x, x+8, ...: observed round-robin dispatch) owns a contiguous tile range; speed only
     const int n_tiles = (n_rays + MARCH_TILE - 1) / MARCH_TILE;
@@ -374,6 +377,10 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (mo.stats) {
+        if (threadIdx.x == 0) {
+            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_MARCH_CLK], __builtin_amdgcn_s_memtime() - clk0);
+            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_MARCH_REF], __builtin_amdgcn_s_memrealtime() - ref0);
+        }
         if (lane == 0) {
             atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_SAMPLES_EVAL], st_eval);
             atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_SAMPLES_BBOX], st_bbox);

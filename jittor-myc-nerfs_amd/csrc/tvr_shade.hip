@@ -362,6 +362,8 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     const unsigned char *bashp = smem + BASH + (h * TVR_IMG_BASH_ROWS + (e < TVR_IMG_BASH_ROWS ? e : TVR_IMG_BASH_ROWS - 1)) * 16;
     const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
     const long long n_tiles = (n_total + SH_TILE - 1) / SH_TILE;
+    unsigned long long clk0 = 0ull, ref0 = 0ull;              // clock probe (stats only), as in the march kernel
+    if (a.stats && SRC == SH_SRC_QUEUE && tid == 0) { clk0 = __builtin_amdgcn_s_memtime(); ref0 = __builtin_amdgcn_s_memrealtime(); }
 #if TVR_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -671,6 +673,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     if (a.stats && lane == 0)
         for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // finish, gather, basis, L1 (+PE), L2, MFMA drain, wait for the matrix token
 #endif
+    if (a.stats && SRC == SH_SRC_QUEUE && tid == 0) {
+        atomicAdd((unsigned long long *)&a.stats[TVR_STAT_SHADE_CLK], __builtin_amdgcn_s_memtime() - clk0);
+        atomicAdd((unsigned long long *)&a.stats[TVR_STAT_SHADE_REF], __builtin_amdgcn_s_memrealtime() - ref0);
+    }
     if (a.stats && SRC == SH_SRC_QUEUE && blockIdx.x == 0 && tid == 0)
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
 }

@@ -105,23 +105,32 @@ def test_render_sharded_world2_hip_renderer_equals_single(tiny_arrays, hyper_tin
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_step_world2_on_one_card(scaling, tmp_path):
-    """bench.py's multi-rank path exactly as the driver launches it (torch.distributed.run, 2 ranks) except for the rehearsal backend and a
-    small frame: `--check` makes every rank compare the gathered frame(s) with its own single-rank render of the same rays, bit for bit."""
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("scaling,img", [("weak", 96), ("strong", 96), ("strong", 800), ("default", 96)])
+def test_bench_step_world2_on_one_card(scaling, img, tmp_path):
+    """bench.py's multi-rank path exactly as the driver launches it (torch.distributed.run, 2 ranks) except for the rehearsal backend (and, for
+    three of the cases, a small frame): `--check` makes every rank compare the gathered frame(s) with its own single-rank render of the same
+    rays, bit for bit.  ("strong", 800) is BASELINE configs[2]'s own frame: the 640 000 rays of scene A split in two.  "default" passes no
+    --scaling: N > 1 must then be the strong split of ONE frame (SURVEY 8e's metric), not N frames."""
     import json
     import subprocess
-    env = dict(os.environ, TVR_BENCH_BACKEND="gloo", TVR_BENCH_IMG="96", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, TVR_BENCH_BACKEND="gloo", TVR_BENCH_IMG=str(img), HSA_ENABLE_IPC_MODE_LEGACY="0")
     port = 35500 + os.getpid() % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scaling", scaling, "--check", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--check", "--no-cpu-baseline"]
+    if scaling != "default":
+        cmd += ["--scaling", scaling]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1100)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["check"] == "gathered == single-rank render, bit for bit"
-    assert d["config"]["rays_per_step"] == (96 * 96 * (2 if scaling == "weak" else 1))
+    want = "strong" if scaling == "default" else scaling
+    assert d["n_gpus"] == 2 and d["scaling"] == want and d["check"] == "gathered == single-rank render, bit for bit"
+    assert d["config"]["rays_per_step"] == (img * img * (2 if want == "weak" else 1))
+    if want == "strong":
+        ss = d["strong_split"]
+        assert ss["N"] == 2 and ss["t1_ms"] > 0 and ss["tN_ms"] > 0 and 0.05 < ss["t1_over_N_tN"] < 1.5
+        assert d["config"]["rays_per_rank"] <= (img * img + 4095) // 4096 // 2 * 4096 + 4096
 
 
 def test_shard_gather_index_is_the_inverse_of_the_tile_interleave():
