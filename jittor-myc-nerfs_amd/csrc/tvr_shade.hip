@@ -293,6 +293,9 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 #ifndef TVR_MTOKEN
 #define TVR_MTOKEN 1
 #endif
+#ifndef TVR_NLO_LDS
+#define TVR_NLO_LDS 6     // k-steps whose basis LO fragments live in LDS (TensorVMSplit kernels; 6 x 864 B fit behind the image, 9 would not)
+#endif
 #ifndef TVR_MSLEEP
 #define TVR_MSLEEP 2
 #endif
@@ -331,6 +334,12 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     // MLP weights -> LDS once per workgroup (the xyz -> features kernel of TensorVMSplit needs only the basis fragments' hi parts)
     constexpr bool BAS_ONLY = DST == SH_DST_FEAT && !REF;
     constexpr int BASH = BAS_ONLY ? 0 : TVR_IMG_BASH;
+    // round 3: the LO parts of the basis fragments of the first NLO k-steps also live in LDS (27-row packing like the hi parts), in the 5.5 KB the
+    // TensorVMSplit image leaves free: 6 of the 9 per-tile loads of those fragments (L1 hits, but the L1 instruction rate is what binds the gather)
+    // and 24 of the 36 registers they held across the phase boundary are gone.  REFTensoRF's image fills the LDS: NLO = 0 there.
+    constexpr int NLO = REF ? 0 : (BAS_ONLY ? 9 : TVR_NLO_LDS);
+    constexpr int IMG_END = (BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES));
+    constexpr int BASL = IMG_END + 16;                 // behind the four matrix-token words
     {
         const uint4 *src = (const uint4 *)((const unsigned char *)sc.mlp_image + (BAS_ONLY ? TVR_IMG_BASH : 0));
         constexpr int nb = BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES);
@@ -338,6 +347,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #if TVR_MTOKEN
         if (tid < 4) ((int *)(smem + nb))[tid] = 0;
 #endif
+        for (int i = tid; i < NLO * 2 * TVR_IMG_BASH_ROWS; i += SH_THREADS) {            // global [s][half][32 rows] -> LDS [s][half][27 rows]
+            const int sh = i / TVR_IMG_BASH_ROWS, row = i - sh * TVR_IMG_BASH_ROWS;
+            ((uint4 *)(smem + BASL))[i] = ((const uint4 *)sc.basis_frag)[sh * 32 + row];
+        }
         __syncthreads();
     }
 #ifdef TVR_DEBUG_SIMD
@@ -356,10 +369,11 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #endif
 #if TVR_MTOKEN
     bool have_tok = false;
-    int *mtok = (int *)(smem + (BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : (REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES))) + (wave & 3);
+    int *mtok = (int *)(smem + IMG_END) + (wave & 3);
 #endif
     // basis hi fragment of lane (e, h) at k-step s: rows 27..31 of the 32-row tile do not exist (their outputs are never used): clamp
     const unsigned char *bashp = smem + BASH + (h * TVR_IMG_BASH_ROWS + (e < TVR_IMG_BASH_ROWS ? e : TVR_IMG_BASH_ROWS - 1)) * 16;
+    const unsigned char *baslp = bashp + (BASL - BASH);  // lo parts, same addressing, k-steps 0 .. NLO-1
     const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
     const long long n_tiles = (n_total + SH_TILE - 1) / SH_TILE;
     unsigned long long clk0 = 0ull, ref0 = 0ull;              // clock probe (stats only), as in the march kernel
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 unsigned boff = (unsigned)((h * 32 + e) * 16);
                 asm volatile("" : "+v"(boff));
 #pragma unroll
-                for (int s3 = 0; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
+                for (int s3 = NLO; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
                     const float hv[8] = {hv4[s][0].x, hv4[s][0].y, hv4[s][0].z, hv4[s][0].w, hv4[s][1].x, hv4[s][1].y, hv4[s][1].z, hv4[s][1].w};
@@ -436,7 +450,8 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
-                const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s * (2 * TVR_IMG_BASH_ROWS * 16))), Al = __builtin_bit_cast(h8, bal[s]);
+                const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s * (2 * TVR_IMG_BASH_ROWS * 16)));
+                const h8 Al = s < NLO ? __builtin_bit_cast(h8, *(const uint4 *)(baslp + s * (2 * TVR_IMG_BASH_ROWS * 16))) : __builtin_bit_cast(h8, bal[s]);
                 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);
                 accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);
                 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         unsigned boff = (unsigned)((h * 32 + e) * 16);
                         asm volatile("" : "+v"(boff));
 #pragma unroll
-                        for (int s3 = 0; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
+                        for (int s3 = NLO; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
                     }
                     const int p = s / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 unsigned boff = (unsigned)((h * 32 + e) * 16);
                 asm volatile("" : "+v"(boff));
 #pragma unroll
-                for (int s3 = 0; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
+                for (int s3 = NLO; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
             }
             // phase boundary: every load of this tile has landed before the first MFMA issues, and the compiler may not move loads below it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -508,7 +523,8 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
-                const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s * (2 * TVR_IMG_BASH_ROWS * 16))), Al = __builtin_bit_cast(h8, bal[s]);
+                const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s * (2 * TVR_IMG_BASH_ROWS * 16)));
+                const h8 Al = s < NLO ? __builtin_bit_cast(h8, *(const uint4 *)(baslp + s * (2 * TVR_IMG_BASH_ROWS * 16))) : __builtin_bit_cast(h8, bal[s]);
                 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);
                 accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);
                 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);
@@ -684,7 +700,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 template <int SRC, int DST, bool REF>
 static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
-    const int lds = (REF ? TVR_MLP_IMAGE_BYTES_REF : ((DST == SH_DST_FEAT) ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : TVR_MLP_IMAGE_BYTES)) + (TVR_MTOKEN ? 16 : 0);
+    constexpr bool BAS_ONLY = DST == SH_DST_FEAT && !REF;
+    constexpr int NLO = REF ? 0 : (BAS_ONLY ? 9 : TVR_NLO_LDS);
+    const int lds = (REF ? TVR_MLP_IMAGE_BYTES_REF : (BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : TVR_MLP_IMAGE_BYTES)) + 16 + NLO * 2 * TVR_IMG_BASH_ROWS * 16;
+    static_assert((REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES) + 16 + (REF ? 0 : TVR_NLO_LDS) * 2 * TVR_IMG_BASH_ROWS * 16 <= 160 * 1024, "LDS image + tokens + basis lo parts must fit 160 KB");
     hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
     unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
