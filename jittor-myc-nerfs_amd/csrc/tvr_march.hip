@@ -27,10 +27,16 @@
 #ifndef TVR_MARCH_RASTER
 #define TVR_MARCH_RASTER 1      // 1: every group sweeps the image together (tile k*grid + group) -> the queue is in ~raster order; measured march 7.9 vs 8.8 ms and shade 15.25 vs 15.65 ms against per-XCD contiguous bands (0)
 #endif
+// Small launches (a 4096-ray training batch or render chunk, a rank's share of a split frame: 16 rays per CU, one per wave) — measured in round 3
+// (scripts/march_timeline.py, profiles/r03_march_timeline.txt): a wave's chain takes 10.4 us per 64-sample chunk at 4096 rays, 8.3 at 16 384,
+// 7.2 in the full frame; the kernel ends 80 us after it starts where its share of a full frame is 49 us.  Tried and dropped: staggering the
+// waves' starts over a chunk period (no change: it is not a lock-step effect) and touching the next chunk's 12 plane texels per sample one
+// chunk ahead (12.1 us per chunk, 32.8 vs 30.2 ms per 157-call frame: the extra loads cost more than the misses they hide).  What DID cost a
+// small launch 100 us was this kernel's own statistics: three same-address global atomics per wave (4096 waves) — now one per group.
 #define MARCH_MAX_WAVES 16
 #define MARCH_TILE 16                     // rays per tile
 #define MARCH_SPIN_LIMIT (1u << 22)       // s_sleep(1) each: ~0.15 s, against a legitimate wait of microseconds
-#define MARCH_HDR 272                     // LDS header: ray cursor (16 B) + 32 slots of {local tile number + 1, global tile} (dynamic tile queue)
+#define MARCH_HDR 304                     // LDS header: ray cursor (16 B) + 32 slots of {local tile number + 1, global tile} (dynamic tile queue) + 3 u64 statistics sums + pad
 #ifndef TVR_MARCH_DYN
 #define TVR_MARCH_DYN 1                   // 1: workgroups take 16-ray tiles from ONE global counter (in order), not a fixed stride: no tail when a launch has few tiles per group
 #endif
@@ -100,9 +106,15 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
     const float4 *ls1 = ls0 + ln0, *ls2 = ls1 + ln1;                     // line i runs along axis vecMode[i] = 2 - i
     float *bufw = (float *)(ls2 + ln2) + (size_t)wave * s_cap;
     unsigned short *bufj = (unsigned short *)((float *)(ls2 + ln2) + (size_t)n_waves * s_cap) + (size_t)wave * s_cap;
+#ifdef TVR_MARCH_TIMELINE                               // diagnostic build (scripts/march_timeline.py): stats[32 + 8 b ..] = {start, filled, first wave end, last wave end, chunks, rays} of group b, 100 MHz ticks
+    unsigned long long tl_chunks = 0ull, tl_rays = 0ull;
+    if (mo.stats && threadIdx.x == 0) mo.stats[32 + 8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) *cursor = 0u;
     unsigned long long *slots = (unsigned long long *)(lds_raw + 16);
     if (threadIdx.x < 32) slots[threadIdx.x] = 0ull;
+    unsigned long long *gstat = (unsigned long long *)(lds_raw + 272);       // per-group sums of the three counters: ONE global atomic each per group
+    if (threadIdx.x < 3) gstat[threadIdx.x] = 0ull;                           // (4096 same-address atomics per launch cost a 4096-ray call ~100 us)
     if (LDSL) {
         float4 *dst = (float4 *)(lds_raw + MARCH_HDR);
         for (int i = threadIdx.x; i < (sc.grid[2] + 1) * 4; i += blockDim.x) dst[(i >> 2) * MARCH_LSTRIDE + (i & 3)] = sc.dline[0][i];
@@ -110,6 +122,9 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
         for (int i = threadIdx.x; i < (sc.grid[0] + 1) * 4; i += blockDim.x) dst[ln0 + ln1 + (i >> 2) * MARCH_LSTRIDE + (i & 3)] = sc.dline[2][i];
     }
     __syncthreads();
+#ifdef TVR_MARCH_TIMELINE
+    if (mo.stats && threadIdx.x == 0) mo.stats[32 + 8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int sub = lane & 3;
     // clock probe (stats only): shader-clock and 100 MHz reference ticks over this workgroup's lifetime
     unsigned long long clk0 = 0ull, ref0 = 0ull;
@@ -252,6 +267,9 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
             }
             seen = true;
             st_eval += __popcll(mv);
+#ifdef TVR_MARCH_TIMELINE
+            tl_chunks++;
+#endif
 
             // ---- density feature: 4 sub-steps, quad-per-sample gather ----
             float sf = 0.0f;
@@ -340,6 +358,9 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
             }
         }
         st_term += terminated ? 1 : 0;
+#ifdef TVR_MARCH_TIMELINE
+        tl_rays++;
+#endif
 
         const float acc = wave_sum(acc_l);
         const float dep = wave_sum(dep_l);
@@ -376,15 +397,28 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (mo.stats) {
+#ifdef TVR_MARCH_TIMELINE
+    if (mo.stats && lane == 0) {
+        const unsigned long long te = __builtin_amdgcn_s_memrealtime();
+        atomicMin((unsigned long long *)&mo.stats[32 + 8 * blockIdx.x + 2], te);
+        atomicMax((unsigned long long *)&mo.stats[32 + 8 * blockIdx.x + 3], te);
+        atomicAdd((unsigned long long *)&mo.stats[32 + 8 * blockIdx.x + 4], tl_chunks);
+        atomicAdd((unsigned long long *)&mo.stats[32 + 8 * blockIdx.x + 5], tl_rays);
+    }
+#endif
+    if (mo.stats) {                                      // (wave-uniform: every wave of the group reaches this barrier exactly once)
+        if (lane == 0) {
+            atomicAdd(&gstat[0], st_eval);
+            atomicAdd(&gstat[1], st_bbox);
+            atomicAdd(&gstat[2], st_term);
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
+            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_SAMPLES_EVAL], gstat[0]);
+            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_SAMPLES_BBOX], gstat[1]);
+            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_RAYS_TERMINATED], gstat[2]);
             atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_MARCH_CLK], __builtin_amdgcn_s_memtime() - clk0);
             atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_MARCH_REF], __builtin_amdgcn_s_memrealtime() - ref0);
-        }
-        if (lane == 0) {
-            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_SAMPLES_EVAL], st_eval);
-            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_SAMPLES_BBOX], st_bbox);
-            atomicAdd((unsigned long long *)&mo.stats[TVR_STAT_RAYS_TERMINATED], st_term);
         }
     }
 }
@@ -401,8 +435,19 @@ __global__ __launch_bounds__(256) void composite_kernel(const MarchOut mo, const
     const bool live = r < n_rays;
     const unsigned base = live ? mo.ray_off[r] : 0u, cnt = live ? mo.ray_cnt[r] : 0u;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    for (unsigned i = l; i < cnt; i += COMP_LANES) {
-        const float4 e = mo.q_out[base + i];     // {r,g,b,w} written by the shade kernel
+    // four entries in flight per lane (a 4096-ray call is one wave per 8 rays and ~11 dependent round trips per lane otherwise: 10.9 us per
+    // call, rocprofv3, where the data would take 3); the additions keep their order
+    unsigned i = l;
+    for (; i + 3 * COMP_LANES < cnt; i += 4 * COMP_LANES) {
+        const float4 e0 = mo.q_out[base + i], e1 = mo.q_out[base + i + COMP_LANES], e2 = mo.q_out[base + i + 2 * COMP_LANES],
+                     e3 = mo.q_out[base + i + 3 * COMP_LANES];     // {r,g,b,w} written by the shade kernel
+        c0 = c0 + e0.w * e0.x; c1 = c1 + e0.w * e0.y; c2 = c2 + e0.w * e0.z;
+        c0 = c0 + e1.w * e1.x; c1 = c1 + e1.w * e1.y; c2 = c2 + e1.w * e1.z;
+        c0 = c0 + e2.w * e2.x; c1 = c1 + e2.w * e2.y; c2 = c2 + e2.w * e2.z;
+        c0 = c0 + e3.w * e3.x; c1 = c1 + e3.w * e3.y; c2 = c2 + e3.w * e3.z;
+    }
+    for (; i < cnt; i += COMP_LANES) {
+        const float4 e = mo.q_out[base + i];
         c0 = c0 + e.w * e.x;
         c1 = c1 + e.w * e.y;
         c2 = c2 + e.w * e.z;
