@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 109
+#define TVR_VERSION 110
 
 typedef enum {
     TVR_OK = 0,
@@ -235,6 +235,26 @@ int tvr_mlp_train_backward(const float *W1, const float *W2, const float *W3, co
                            const float *h1, const float *h2, int64_t m, const float *gscale_dev, float *d_out4, size_t d_out4_bytes, float *dh2,
                            size_t dh2_bytes, float *dh1, size_t dh1_bytes, float *dfeats32, size_t dfeats32_bytes, float *dh, size_t dh_bytes,
                            uint32_t *sat_flag_dev, void *image, size_t image_bytes, void *stream);
+
+/* The same for a REFTensoRF scene (what configs/Scar.txt:28 trains; models/REFTensoRF.py:107-133, 174-256): h -> basis_mat and the four heads
+ * {normal, specular tint, diffuse, rho} -> normalised normal, d = -view, dot = d.n, reflection = 2 dot n - d -> MLPRender_Fea_Ref([-dot, features, reflection,
+ * PE(features), PE(reflection)]) = rgb_s -> rgb = relu(tint) * rgb_s + rgb_d, in one kernel (the inference kernel's instructions).
+ *   forward : additionally saves g8 [m,8] = the raw head outputs {normal 3 (not normalised), tint, rgb_d 3, rho} and rgb_s [m,3] (the network's sigmoid output);
+ *             feats32 [m,32] = {27 features, reflection 3, -dot, 0}: the 31 base values of layer 1.  -dot (column 30) is a differentiable output of the host's
+ *             autograd function: REFTensoRF's normal penalty sum_i w_i relu(-dot_i)^2 (REFTensoRF.py:236-239) is formed from it.
+ *   backward: grad_rgb [m,3] w.r.t. the final colour, grad_in0 [m] or NULL = d loss / d(-dot) arriving through that output -> dh [m,144] (through basis_mat AND the
+ *             heads), d_out4 / dh2 / dh1 as above, dfeats32 [m,32] = gradients of {features 27, reflection 3, -dot, 0}, dg8 [m,8] = gradients of the raw head
+ *             outputs.  Weight gradients: as above with X = tvr_pe_concat(features, reflection, -dot) [m,151] for dW1, d basis_mat = dfeats32[:, :27]^T h, and
+ *             d heads = dg8^T h (rows {normal 3, specular, diffuse 3, rho}), bias gradients = column sums.
+ *             W1 [128,151]; heads_W = {normal_linear [3,144], diffuse_linear [3,144], specular_linear [1,144], rho_linear [1,144]} weights (the order of
+ *             tvr_scene_params.ref_W). */
+int tvr_mlp_train_forward_ref(tvr_scene *scene, const float *h, const float *viewdirs, int64_t m, float *rgb, size_t rgb_bytes, float *feats32, size_t feats32_bytes,
+                              float *h1, size_t h1_bytes, float *h2, size_t h2_bytes, float *g8, size_t g8_bytes, float *rgb_s, size_t rgb_s_bytes, void *stream);
+int tvr_mlp_train_backward_ref(const float *W1, const float *W2, const float *W3, const float *basis, const float *const heads_W[4], const float *grad_rgb,
+                               const float *grad_in0, const float *rgb_s, const float *feats32, const float *h1, const float *h2, const float *g8, const float *viewdirs,
+                               int64_t m, const float *gscale_dev, float *d_out4, size_t d_out4_bytes, float *dh2, size_t dh2_bytes, float *dh1, size_t dh1_bytes,
+                               float *dfeats32, size_t dfeats32_bytes, float *dg8, size_t dg8_bytes, float *dh, size_t dh_bytes, uint32_t *sat_flag_dev, void *image,
+                               size_t image_bytes, void *stream);
 
 /* C [Ka,Kb] = A^T B for tall-skinny fp32 operands A [M,Ka] (row stride lda), B [M,Kb] (row stride ldb): the weight gradients dW = dY^T X of
  * the training step's Linears (MLPRender_Fea's three layers tensorBase.py:69-71, basis_mat tensoRF.py:150) over the M appearance samples of

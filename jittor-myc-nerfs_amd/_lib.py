@@ -101,6 +101,9 @@ SYMBOLS = {
     "tvr_mlp_train_image_bytes": (C.c_size_t, []),
     "tvr_mlp_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p, C.c_size_t] * 4 + [C.c_void_p]),
     "tvr_mlp_train_backward": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_void_p] + [C.c_void_p, C.c_size_t] * 5 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_mlp_train_forward_ref": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p, C.c_size_t] * 6 + [C.c_void_p]),
+    "tvr_mlp_train_backward_ref": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(C.c_void_p * 4)] + [C.c_void_p] * 8 + [C.c_int64, C.c_void_p] + [C.c_void_p, C.c_size_t] * 6 +
+                                   [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_gemm_tn_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     "tvr_gemm_tn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.c_void_p]),

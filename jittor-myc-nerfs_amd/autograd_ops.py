@@ -309,3 +309,76 @@ class _MlpTrainFn(torch.autograd.Function):
             gW3, gW2, gW1, gB = d_out[:, :3].t() @ h2, dh2.t() @ h1, dh1.t() @ X, dfe[:, :27].t() @ h
             gb3, gb2, gb1 = d_out[:, :3].sum(0), dh2.sum(0), dh1.sum(0)
         return None, dh, None, gB, gW1, gb1, gW2, gb2, gW3, gb3
+
+
+class _RefMlpTrainFn(torch.autograd.Function):
+    """REFTensoRF's appearance network under autograd (models/REFTensoRF.py:125-133, 217-232): h [M,144] -> basis_mat and the four heads -> normalised
+    normal, reflection, -dot -> MLPRender_Fea_Ref -> relu(tint) * rgb_s + rgb_d, as ONE forward kernel (tvr_mlp_train_forward_ref = the inference shade
+    kernel fed with h) and the register-resident backward chain (tvr_mlp_train_backward_ref); weight and bias gradients by tvr_gemm_tn / column sums.
+    No library GEMM.  Outputs (rgb [M,3], in0 [M] = -dot_product): the caller forms the normal penalty sum w relu(in0)^2 (:236-239) from the second."""
+
+    @staticmethod
+    def forward(ctx, model, h, viewdirs, basis_w, nW, nb, dW, db, sW, sb, rW, rb_, W1, b1, W2, b2, W3, b3):
+        lib = L.lib()
+        sc = model._ensure_scene()
+        dev, m = h.device, h.shape[0]
+        h = h.contiguous()
+        vd = viewdirs.detach().contiguous().float()
+        rgb = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        rgb_s = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        feats = torch.empty((m, 32), dtype=torch.float32, device=dev)
+        g8 = torch.empty((m, 8), dtype=torch.float32, device=dev)
+        h1 = torch.empty((m, 128), dtype=torch.float32, device=dev)
+        h2 = torch.empty((m, 128), dtype=torch.float32, device=dev)
+        L.check(lib.tvr_mlp_train_forward_ref(sc, h.data_ptr(), vd.data_ptr(), m, rgb.data_ptr(), L.nbytes(rgb), feats.data_ptr(), L.nbytes(feats), h1.data_ptr(),
+                                              L.nbytes(h1), h2.data_ptr(), L.nbytes(h2), g8.data_ptr(), L.nbytes(g8), rgb_s.data_ptr(), L.nbytes(rgb_s),
+                                              _stream_ptr(dev)), "tvr_mlp_train_forward_ref")
+        ctx.save_for_backward(h, vd, rgb_s, feats, h1, h2, g8, basis_w, nW, dW, sW, rW, W1, W2, W3)
+        ctx.model = model
+        return rgb, feats[:, 30].clone()
+
+    @staticmethod
+    def backward(ctx, grgb, gin0):
+        lib = L.lib()
+        h, vd, rgb_s, feats, h1, h2, g8, basis_w, nW, dW, sW, rW, W1, W2, W3 = ctx.saved_tensors
+        dev, m = h.device, h.shape[0]
+        z = torch.zeros_like
+        if m == 0:
+            return (None, z(h), None, z(basis_w), z(nW), torch.zeros(3, device=dev), z(dW), torch.zeros(3, device=dev), z(sW), torch.zeros(1, device=dev), z(rW),
+                    torch.zeros(1, device=dev), z(W1), torch.zeros(128, device=dev), z(W2), torch.zeros(128, device=dev), z(W3), torch.zeros(3, device=dev))
+        grgb = torch.zeros((m, 3), device=dev) if grgb is None else grgb.contiguous().float()
+        gin0 = None if gin0 is None else gin0.contiguous().float()
+        tint = g8[:, 3].clamp_min(0)
+        gmax = ((grgb * tint[:, None]).abs().max() * 0.25).clamp_min(1e-30)                   # the gradient that enters the network is tint * grad
+        gscale = torch.exp2(torch.floor(torch.log2(float(ctx.model.grad_scale_target) / gmax))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1).float()
+        sat = ctx.model._get_sat_flag()
+        d_out = torch.empty((m, 4), dtype=torch.float32, device=dev)
+        dh2 = torch.empty((m, 128), dtype=torch.float32, device=dev)
+        dh1 = torch.empty((m, 128), dtype=torch.float32, device=dev)
+        dfe = torch.empty((m, 32), dtype=torch.float32, device=dev)
+        dg8 = torch.empty((m, 8), dtype=torch.float32, device=dev)
+        dh = torch.empty((m, 144), dtype=torch.float32, device=dev)
+        image = ctx.model._get_train_image()
+        W1c, W2c, W3c, Bc, nWc, dWc, sWc, rWc = (t.detach().contiguous().float() for t in (W1, W2, W3, basis_w, nW, dW, sW, rW))
+        heads = (C.c_void_p * 4)(nWc.data_ptr(), dWc.data_ptr(), sWc.data_ptr(), rWc.data_ptr())
+        L.check(lib.tvr_mlp_train_backward_ref(W1c.data_ptr(), W2c.data_ptr(), W3c.data_ptr(), Bc.data_ptr(), C.byref(heads), grgb.data_ptr(),
+                                               None if gin0 is None else gin0.data_ptr(), rgb_s.data_ptr(), feats.data_ptr(), h1.data_ptr(), h2.data_ptr(), g8.data_ptr(),
+                                               vd.data_ptr(), m, gscale.data_ptr(), d_out.data_ptr(), L.nbytes(d_out), dh2.data_ptr(), L.nbytes(dh2), dh1.data_ptr(),
+                                               L.nbytes(dh1), dfe.data_ptr(), L.nbytes(dfe), dg8.data_ptr(), L.nbytes(dg8), dh.data_ptr(), L.nbytes(dh), sat.data_ptr(),
+                                               image.data_ptr(), image.numel(), _stream_ptr(dev)), "tvr_mlp_train_backward_ref")
+        # X [m,151] = [-dot, features, reflection, PE(features), PE(reflection)] re-derived from the saved base values (REFTensoRF.py:19-24)
+        X = torch.empty((m, 151), dtype=torch.float32, device=dev)
+        f27, refl, in0 = feats[:, :27].contiguous(), feats[:, 27:30].contiguous(), feats[:, 30].contiguous()
+        L.check(lib.tvr_pe_concat(f27.data_ptr(), refl.data_ptr(), in0.data_ptr(), m, X.data_ptr(), L.nbytes(X), _stream_ptr(dev)), "tvr_pe_concat")
+        if m >= 4096:
+            tn = lambda a_, lda, ka, b_, ldb, kb: _gemm_tn_call(a_, lda, ka, b_, ldb, kb, m)
+            gW3 = tn(d_out, 4, 4, h2, 128, 128)[:3]
+            gW2 = tn(dh2, 128, 128, h1, 128, 128)
+            gW1 = tn(dh1, 128, 128, X, 151, 151)
+            gB = tn(dfe, 32, 32, h, 144, 144)[:27]
+            gH = tn(dg8, 8, 8, h, 144, 144)
+        else:
+            gW3, gW2, gW1, gB, gH = d_out[:, :3].t() @ h2, dh2.t() @ h1, dh1.t() @ X, dfe[:, :27].t() @ h, dg8.t() @ h
+        gb3, gb2, gb1, gbh = d_out[:, :3].sum(0), dh2.sum(0), dh1.sum(0), dg8.sum(0)
+        # head rows: normal 0..2, specular 3, diffuse 4..6, rho 7 (rho's gradient is zero: `k = 1 / rho` is unused by MLPRender_Fea_Ref, REFTensoRF.py:18)
+        return (None, dh, None, gB, gH[0:3], gbh[0:3], gH[4:7], gbh[4:7], gH[3:4], gbh[3:4], gH[7:8], gbh[7:8], gW1, gb1, gW2, gb2, gW3, gb3)

@@ -503,34 +503,54 @@ int tvr_app_h_forward(tvr_scene *s, const float *xyz, int64_t m, float *h_out, s
 
 size_t tvr_mlp_train_image_bytes(void) { return mlp_train_image_bytes(); }
 
-int tvr_mlp_train_forward(tvr_scene *s, const float *h, const float *viewdirs, int64_t m, float *rgb, size_t rgb_bytes, float *feats32, size_t feats32_bytes,
-                          float *h1, size_t h1_bytes, float *h2, size_t h2_bytes, void *stream)
+static int mlp_train_forward_impl(tvr_scene *s, int variant, const float *h, const float *viewdirs, int64_t m, float *rgb, size_t rgb_bytes, float *feats32,
+                                  size_t feats32_bytes, float *h1, size_t h1_bytes, float *h2, size_t h2_bytes, float *g8, size_t g8_bytes, float *rgb_s, size_t rgb_s_bytes,
+                                  void *stream)
 {
+    const char *fn = variant ? "tvr_mlp_train_forward_ref" : "tvr_mlp_train_forward";
     if (m > 0) {
-        NEED("rgb [m,3]", rgb_bytes, m, 3);
-        NEED("feats32 [m,32]", feats32_bytes, m, 32);
-        NEED("h1 [m,128]", h1_bytes, m, TVR_FEATC);
-        NEED("h2 [m,128]", h2_bytes, m, TVR_FEATC);
+        int rc_;
+        if ((rc_ = need_bytes(fn, "rgb [m,3]", rgb_bytes, m, 3)) != TVR_OK) return rc_;
+        if ((rc_ = need_bytes(fn, "feats32 [m,32]", feats32_bytes, m, 32)) != TVR_OK) return rc_;
+        if ((rc_ = need_bytes(fn, "h1 [m,128]", h1_bytes, m, TVR_FEATC)) != TVR_OK) return rc_;
+        if ((rc_ = need_bytes(fn, "h2 [m,128]", h2_bytes, m, TVR_FEATC)) != TVR_OK) return rc_;
+        if (variant) {
+            if ((rc_ = need_bytes(fn, "g8 [m,8]", g8_bytes, m, 8)) != TVR_OK) return rc_;
+            if ((rc_ = need_bytes(fn, "rgb_s [m,3]", rgb_s_bytes, m, 3)) != TVR_OK) return rc_;
+        }
         if ((uint64_t)m * 576u >= (1ull << 32)) return fail(TVR_ERR_INVALID, "m = %lld: 32-bit row offsets inside the kernels allow 7.4 M entries per call", (long long)m);
     }
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
-    if (s->desc.variant != 0) return fail(TVR_ERR_UNSUPPORTED, "tvr_mlp_train_forward: TensorVMSplit scenes only (REFTensoRF trains through the library-GEMM path)");
+    if (s->desc.variant != variant)
+        return fail(TVR_ERR_UNSUPPORTED, "%s: the scene is %s", fn, s->desc.variant ? "a REFTensoRF scene (tvr_mlp_train_forward_ref)" : "a TensorVMSplit scene (tvr_mlp_train_forward)");
     {
         const tvr_scene_desc &d = s->desc;
         bool std_shape = d.featureC == TVR_FEATC && d.view_pe == 2 && d.fea_pe == 2;
         for (int i = 0; i < 3; ++i) std_shape = std_shape && d.app_n_comp[i] == TVR_CA;
-        if (!std_shape) return fail(TVR_ERR_UNSUPPORTED, "tvr_mlp_train_forward: the fused training kernels take 48 appearance components, featureC 128, view_pe = fea_pe = 2 "
-                                                         "(zero-padded shapes train through the library-GEMM path)");
+        if (!std_shape) return fail(TVR_ERR_UNSUPPORTED, "%s: the fused training kernels take 48 appearance components, featureC 128, view_pe = fea_pe = 2 "
+                                                         "(zero-padded shapes train through the library-GEMM path)", fn);
     }
     if (m == 0) return TVR_OK;
-    if (!h || !viewdirs || !rgb || !feats32 || !h1 || !h2 || m < 0) return fail(TVR_ERR_INVALID, "NULL argument or m < 0");
-    if (((uintptr_t)h | (uintptr_t)feats32 | (uintptr_t)h1 | (uintptr_t)h2) % 16) return fail(TVR_ERR_INVALID, "h / feats32 / h1 / h2 must be 16-byte aligned");
+    if (!h || !viewdirs || !rgb || !feats32 || !h1 || !h2 || m < 0 || (variant && (!g8 || !rgb_s))) return fail(TVR_ERR_INVALID, "NULL argument or m < 0");
+    if (((uintptr_t)h | (uintptr_t)feats32 | (uintptr_t)h1 | (uintptr_t)h2 | (uintptr_t)g8) % 16) return fail(TVR_ERR_INVALID, "h / feats32 / h1 / h2 / g8 must be 16-byte aligned");
     ShadeArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.n = m; sa.h_in = h; sa.viewdirs = viewdirs; sa.out = rgb; sa.t_feats = feats32; sa.t_h1 = h1; sa.t_h2 = h2;
+    sa.n = m; sa.h_in = h; sa.viewdirs = viewdirs; sa.out = rgb; sa.t_feats = feats32; sa.t_h1 = h1; sa.t_h2 = h2; sa.t_g8 = g8; sa.t_rgbs = rgb_s;
     HIP_TRY(launch_shade(s->dev, SH_SRC_H, SH_DST_TRAIN, sa, (hipStream_t)stream));
     return TVR_OK;
+}
+
+int tvr_mlp_train_forward(tvr_scene *s, const float *h, const float *viewdirs, int64_t m, float *rgb, size_t rgb_bytes, float *feats32, size_t feats32_bytes,
+                          float *h1, size_t h1_bytes, float *h2, size_t h2_bytes, void *stream)
+{
+    return mlp_train_forward_impl(s, 0, h, viewdirs, m, rgb, rgb_bytes, feats32, feats32_bytes, h1, h1_bytes, h2, h2_bytes, nullptr, 0, nullptr, 0, stream);
+}
+
+int tvr_mlp_train_forward_ref(tvr_scene *s, const float *h, const float *viewdirs, int64_t m, float *rgb, size_t rgb_bytes, float *feats32, size_t feats32_bytes,
+                              float *h1, size_t h1_bytes, float *h2, size_t h2_bytes, float *g8, size_t g8_bytes, float *rgb_s, size_t rgb_s_bytes, void *stream)
+{
+    return mlp_train_forward_impl(s, 1, h, viewdirs, m, rgb, rgb_bytes, feats32, feats32_bytes, h1, h1_bytes, h2, h2_bytes, g8, g8_bytes, rgb_s, rgb_s_bytes, stream);
 }
 
 int tvr_mlp_train_backward(const float *W1, const float *W2, const float *W3, const float *basis, const float *grad_rgb, const float *rgb, const float *feats32,
@@ -552,8 +572,37 @@ int tvr_mlp_train_backward(const float *W1, const float *W2, const float *W3, co
     if ((uint64_t)m * 576u >= (1ull << 32)) return fail(TVR_ERR_INVALID, "m = %lld: 32-bit row offsets inside the kernels allow 7.4 M entries per call", (long long)m);
     if (((uintptr_t)feats32 | (uintptr_t)h1 | (uintptr_t)h2 | (uintptr_t)d_out4 | (uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)dfeats32 | (uintptr_t)dh) % 16)
         return fail(TVR_ERR_INVALID, "activation / gradient matrices must be 16-byte aligned");
-    HIP_TRY(launch_pack_train_image(W1, W2, W3, basis, image, (hipStream_t)stream));
-    HIP_TRY(launch_mlp_train_backward(grad_rgb, rgb, feats32, h1, h2, m, gscale_dev, d_out4, dh2, dh1, dfeats32, dh, sat_flag_dev, image, (hipStream_t)stream));
+    HIP_TRY(launch_pack_train_image(W1, W2, W3, basis, nullptr, image, (hipStream_t)stream));
+    HIP_TRY(launch_mlp_train_backward(grad_rgb, rgb, feats32, h1, h2, m, gscale_dev, d_out4, dh2, dh1, dfeats32, dh, sat_flag_dev, image, nullptr, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_mlp_train_backward_ref(const float *W1, const float *W2, const float *W3, const float *basis, const float *const heads_W[4], const float *grad_rgb,
+                               const float *grad_in0, const float *rgb_s, const float *feats32, const float *h1, const float *h2, const float *g8, const float *viewdirs,
+                               int64_t m, const float *gscale_dev, float *d_out4, size_t d_out4_bytes, float *dh2, size_t dh2_bytes, float *dh1, size_t dh1_bytes,
+                               float *dfeats32, size_t dfeats32_bytes, float *dg8, size_t dg8_bytes, float *dh, size_t dh_bytes, uint32_t *sat_flag_dev, void *image,
+                               size_t image_bytes, void *stream)
+{
+    if (m == 0) return TVR_OK;
+    if (m > 0) {
+        NEED("d_out4 [m,4]", d_out4_bytes, m, 4);
+        NEED("dh2 [m,128]", dh2_bytes, m, TVR_FEATC);
+        NEED("dh1 [m,128]", dh1_bytes, m, TVR_FEATC);
+        NEED("dfeats32 [m,32]", dfeats32_bytes, m, 32);
+        NEED("dg8 [m,8]", dg8_bytes, m, 8);
+        NEED("dh [m,144]", dh_bytes, m, TVR_KAPP);
+    }
+    if (!W1 || !W2 || !W3 || !basis || !heads_W || !heads_W[0] || !heads_W[1] || !heads_W[2] || !heads_W[3] || !grad_rgb || !rgb_s || !feats32 || !h1 || !h2 || !g8 ||
+        !viewdirs || !gscale_dev || !d_out4 || !dh2 || !dh1 || !dfeats32 || !dg8 || !dh || !image || m < 0)
+        return fail(TVR_ERR_INVALID, "NULL argument or m < 0");
+    if (image_bytes < mlp_train_image_bytes() || (uintptr_t)image % 256) return fail(TVR_ERR_SCRATCH, "training image buffer too small or misaligned");
+    if ((uint64_t)m * 576u >= (1ull << 32)) return fail(TVR_ERR_INVALID, "m = %lld: 32-bit row offsets inside the kernels allow 7.4 M entries per call", (long long)m);
+    if (((uintptr_t)feats32 | (uintptr_t)h1 | (uintptr_t)h2 | (uintptr_t)g8 | (uintptr_t)d_out4 | (uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)dfeats32 | (uintptr_t)dg8 | (uintptr_t)dh) % 16)
+        return fail(TVR_ERR_INVALID, "activation / gradient matrices must be 16-byte aligned");
+    HIP_TRY(launch_pack_train_image(W1, W2, W3, basis, heads_W, image, (hipStream_t)stream));
+    MlpRefBwd rb;
+    rb.g8 = g8; rb.viewdirs = viewdirs; rb.grad_in0 = grad_in0; rb.dg8 = dg8;
+    HIP_TRY(launch_mlp_train_backward(grad_rgb, rgb_s, feats32, h1, h2, m, gscale_dev, d_out4, dh2, dh1, dfeats32, dh, sat_flag_dev, image, &rb, (hipStream_t)stream));
     return TVR_OK;
 }
 

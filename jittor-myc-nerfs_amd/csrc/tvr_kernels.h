@@ -53,6 +53,7 @@ struct ShadeArgs {
     float *out2;               // REFTensoRF, DST_FEAT: [n,8] {normal 3, rgb_d 3, specular_tint, rho}
     const float *h_in;         // SRC_H: h [n,144] (tvr_app_h_forward)
     float *t_feats, *t_h1, *t_h2;   // DST_TRAIN: features [n,32] (27 + zero pad), relu(layer 1) [n,128], relu(layer 2) [n,128]
+    float *t_g8, *t_rgbs;           // DST_TRAIN, REFTensoRF: raw head outputs [n,8] {normal 3, tint, rgb_d 3, rho}, the MLP's sigmoid output [n,3]
     unsigned long long *stats;
 };
 
@@ -83,8 +84,12 @@ hipError_t launch_pe_concat(const float *feat, const float *dir, const float *do
 hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const float *gX, long long m, int with_dot, float *gfeat, float *gdir,
                                      float *gdot, hipStream_t stream);
 size_t mlp_train_image_bytes();
-hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, void *image, hipStream_t stream);
+// heads: REFTensoRF's {normal [3,144], diffuse [3,144], specular [1,144], rho [1,144]} weights, or nullptr (TensorVMSplit)
+hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream);
+// REFTensoRF's additions to the backward: raw head outputs, view directions, optional gradient of the -dot output; dg8 [m,8] is written
+struct MlpRefBwd { const float *g8, *viewdirs, *grad_in0; float *dg8; };
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
-                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, hipStream_t stream);
+                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, const MlpRefBwd *ref,
+                                     hipStream_t stream);
 hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, float *value, float *grad, float *part, hipStream_t stream);
 hipError_t launch_alpha_bits(const float *vol, long long n, unsigned *bits, hipStream_t stream);

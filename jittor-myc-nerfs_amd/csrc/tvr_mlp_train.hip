@@ -27,8 +27,9 @@
 #define TI_W1T_L (TI_W1T_H + 160 * TI_ROW)
 #define TI_W3 (TI_W1T_H + 2 * 160 * TI_ROW)          // W3 [3][128] fp32
 #define TI_LDS_BYTES (TI_W3 + 3 * 128 * 4)           // 158 208 B
-#define TI_BAST (TI_LDS_BYTES)                       // Bas^T fragments [5 row blocks][2 k-steps][2 halves][32 rows][hi 8 | lo 8] fp16 (not copied to LDS)
-#define TI_BYTES (TI_BAST + 5 * 2 * 2 * 32 * 32)     // 178 688 B
+#define TI_BAST (TI_LDS_BYTES)                       // Bas^T fragments [5 row blocks][KS k-steps][2 halves][32 rows][hi 8 | lo 8] fp16 (not copied to LDS);
+                                                     // KS = 2 (27 features, padded to 32); REFTensoRF: KS = 3, k 32..39 = the eight head outputs
+#define TI_BYTES (TI_BAST + 5 * 3 * 2 * 32 * 32)     // 188 928 B (sized for KS = 3)
 
 #define MT_WAVES 8
 #define MT_THREADS (64 * MT_WAVES)
@@ -40,12 +41,21 @@ __device__ __forceinline__ int unit_of_kpos(int kpos)
     return 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
 }
 
-// one thread per element of the three transposed images
+// REFTensoRF's four heads on h (REFTensoRF.py:86-96), in the order of the shade kernel's second row block: normal 0..2, specular 3, diffuse 4..6, rho 7
+struct HeadPtrs { const float *W[4]; };              // normal [3,144], diffuse [3,144], specular [1,144], rho [1,144]; all NULL: TensorVMSplit
+__device__ __forceinline__ float head_weight(const HeadPtrs &hp, int i, int ch)
+{
+    return i < 3 ? hp.W[0][i * TVR_KAPP + ch] : (i == 3 ? hp.W[2][ch] : (i < 7 ? hp.W[1][(i - 4) * TVR_KAPP + ch] : hp.W[3][ch]));
+}
+
+// one thread per element of the three transposed images.  ref: W1 is MLPRender_Fea_Ref's [128,151] (REFTensoRF.py:9-16: every input index moves up
+// by one, base row 30's plain slot is input 0 = -dot) and Bas^T gets a third k-step holding the heads' weights.
 __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
-                                                               const float *__restrict__ Bas, unsigned char *__restrict__ img)
+                                                               const float *__restrict__ Bas, const HeadPtrs hp, const int ref, unsigned char *__restrict__ img)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_w2 = 128 * 128, n_w1 = 160 * 128, n_w3 = 3 * 128, n_b = 160 * 32;
+    const int KB = ref ? 48 : 32;
+    const int n_w2 = 128 * 128, n_w1 = 160 * 128, n_w3 = 3 * 128, n_b = 160 * KB;
     if (i < n_w2) {
         const int row = i >> 7, kpos = i & 127;                                   // row = layer-1 unit, k = layer-2 unit
         unsigned hi, lo;
@@ -54,10 +64,10 @@ __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__re
         ((unsigned short *)(img + TI_W2T_L + row * TI_ROW))[kpos] = (unsigned short)lo;
     } else if (i < n_w2 + n_w1) {
         const int k = i - n_w2, row = k >> 7, kpos = k & 127;                     // row = 32 t + c: derived value t of base value c; k = layer-1 unit
-        const int idx = ref_in_index(row & 31, row >> 5);
         const int c = row & 31, t = row >> 5;
-        float w = idx >= 0 ? W1[(size_t)unit_of_kpos(kpos) * TVR_NIN + idx] : 0.0f;
-        (void)c; (void)t;
+        int idx = ref_in_index(c, t);
+        if (ref) idx = (c == TVR_APPDIM + 3) ? (t == 0 ? 0 : -1) : (idx >= 0 ? idx + 1 : -1);
+        const float w = idx >= 0 ? W1[(size_t)unit_of_kpos(kpos) * (ref ? TVR_NIN_REF : TVR_NIN) + idx] : 0.0f;
         unsigned hi, lo;
         split2(w, 0.0f, hi, lo);
         ((unsigned short *)(img + TI_W1T_H + row * TI_ROW))[kpos] = (unsigned short)hi;
@@ -66,13 +76,17 @@ __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__re
         const int k = i - n_w2 - n_w1;
         ((float *)(img + TI_W3))[k] = W3[k];
     } else if (i < n_w2 + n_w1 + n_w3 + n_b) {
-        const int k = i - n_w2 - n_w1 - n_w3, row = k >> 5, kpos = k & 31;        // row = channel (144, padded to 160), k = feature (27, padded to 32)
+        const int k = i - n_w2 - n_w1 - n_w3, row = k / KB, kpos = k - row * KB;  // row = channel (144, padded to 160), k = feature (27, padded to 32) [+ 8 heads, padded to 16]
         const int f = unit_of_kpos(kpos);
-        const float w = (row < TVR_KAPP && f < TVR_APPDIM) ? Bas[(size_t)f * TVR_KAPP + row] : 0.0f;
+        float w = 0.0f;
+        if (row < TVR_KAPP) {
+            if (f < TVR_APPDIM) w = Bas[(size_t)f * TVR_KAPP + row];
+            else if (ref && f >= 32 && f < 40) w = head_weight(hp, f - 32, row);
+        }
         unsigned hi, lo;
         split2(w, 0.0f, hi, lo);
         const int s = kpos >> 4, hh = (kpos >> 3) & 1, j = kpos & 7, rb = row >> 5, r = row & 31;
-        unsigned short *o = (unsigned short *)(img + TI_BAST) + ((size_t)(((rb * 2 + s) * 2 + hh) * 32 + r)) * 16;
+        unsigned short *o = (unsigned short *)(img + TI_BAST) + ((size_t)(((rb * (ref ? 3 : 2) + s) * 2 + hh) * 32 + r)) * 16;
         o[j] = (unsigned short)hi;
         o[8 + j] = (unsigned short)lo;
     }
@@ -107,9 +121,14 @@ struct MlpBwdArgs {
     const float *gscale;                             // device scalar: gradients are multiplied by this power of two on entry, by its inverse on exit
     float *d_out, *dh2, *dh1, *dfeats;               // [m,4], [m,128], [m,128], [m,32]
     const unsigned char *image;                      // TI_BYTES
+    const float *g8;                                 // REFTensoRF: raw head outputs [m,8] (the tint scales the gradient entering the network)
     unsigned *sat;                                   // optional: set to 1 when a scaled gradient reaches fp16's largest finite value on its way into a product
 };
 
+// REF: MLPRender_Fea_Ref inside REFTensoRF.execute (REFTensoRF.py:229-232): the colour is relu(tint) * rgb_s + rgb_d, so the gradient entering the
+// network is relu(tint) * grad_rgb and `rgb` is rgb_s; the direction rows 27..29 (the reflection) and row 30 (-dot) of layer 1's input are
+// functions of h as well: their gradients come out in dfeats columns 27..30 (ref_heads_backward_kernel takes them to the heads).
+template <bool REF>
 __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_kernel(const MlpBwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,6 +151,11 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
         float g[3], o[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { g[c] = a.grad_rgb[le * 3 + c]; o[c] = a.rgb[le * 3 + c]; }
+        if (REF) {
+            const float tint = fmaxf(a.g8[le * 8 + 3], 0.0f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = g[c] * tint;
+        }
         unsigned long long m1 = 0ull, m2 = 0ull;     // bit 16 rb + r: relu(layer 1 / 2) of hidden unit 32 rb + acc_row(r, h) is positive
         const unsigned lrow128 = (unsigned)le * (TVR_FEATC * 4u) + 16u * (unsigned)h;
         {
@@ -279,7 +303,9 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
             acc = __builtin_fmaf(cs, dx[1][r], acc);
             acc = __builtin_fmaf(2.0f * c2, dx[2][r], acc);
             acc = __builtin_fmaf(-sn, dx[3][r], acc);
-            df[r] = (acc_row(r, h) < TVR_APPDIM) ? __builtin_fmaf(-2.0f * s2, df[r], acc * inv_scale) : 0.0f;
+            const int row = acc_row(r, h);
+            df[r] = (row < (REF ? TVR_APPDIM + 3 : TVR_APPDIM)) ? __builtin_fmaf(-2.0f * s2, df[r], acc * inv_scale)
+                    : ((REF && row == TVR_APPDIM + 3) ? dx[0][r] * inv_scale : 0.0f);            // row 30 (-dot) enters layer 1 plainly only
         }
         if (live) {
 #pragma unroll
@@ -291,22 +317,64 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
     if (a.sat && amax >= 65504.0f) atomicOr(a.sat, 1u);
 }
 
-// dh^T [144 x 32e] = Bas^T [144 x 32] dF^T [32 x 32e]  (gscale as above; dF is stored unscaled)
-__global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__restrict__ dfeats, long long m, const float *__restrict__ gscale_p, const unsigned char *__restrict__ image,
-                                                                float *__restrict__ dh, unsigned *sat)
+// REFTensoRF: the heads' backward between the two kernels.  Per entry, from the gradients of the reflection / -dot inputs (dfeats columns 27..30),
+// of the colour and (optional) of the -dot OUTPUT (the normal penalty of REFTensoRF.py:236-239 is taken by the host's autograd on that output):
+//   n = G[0..2], nh = n / sqrt(max(n.n, 1e-30)), d = -view, dot = d.nh, refl = 2 dot nh - d, in0 = -dot            (REFTensoRF.py:217-229)
+//   d dot = 2 nh.d_refl - d_in0 ;  d nh = 2 dot d_refl + d_dot d ;  d n = (d nh - nh (nh.d nh)) / |n|
+//   d tint_raw = [tint_raw > 0] sum_c grad_rgb_c rgb_s_c ;  d rgb_d = grad_rgb ;  d rho = 0                          (REFTensoRF.py:232)
+__global__ __launch_bounds__(256) void ref_heads_backward_kernel(const float *__restrict__ grad_rgb, const float *__restrict__ rgb_s, const float *__restrict__ g8,
+                                                                 const float *__restrict__ viewdirs, const float *__restrict__ dfeats, const float *__restrict__ grad_in0,
+                                                                 const long long m, float *__restrict__ dg8)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float4 ga = *(const float4 *)(g8 + i * 8), gb = *(const float4 *)(g8 + i * 8 + 4);
+    const float n[3] = {ga.x, ga.y, ga.z};
+    const float nn = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
+    const float nrm = sqrtf(fmaxf(nn, 1e-30f));
+    const float nh[3] = {n[0] / nrm, n[1] / nrm, n[2] / nrm};
+    const float d[3] = {-viewdirs[i * 3], -viewdirs[i * 3 + 1], -viewdirs[i * 3 + 2]};
+    const float dot = (d[0] * nh[0] + d[1] * nh[1]) + d[2] * nh[2];
+    const float dr[3] = {dfeats[i * 32 + 27], dfeats[i * 32 + 28], dfeats[i * 32 + 29]};
+    const float din0 = dfeats[i * 32 + 30] + (grad_in0 ? grad_in0[i] : 0.0f);
+    const float ddot = 2.0f * ((nh[0] * dr[0] + nh[1] * dr[1]) + nh[2] * dr[2]) - din0;
+    float dnh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dnh[k] = 2.0f * dot * dr[k] + ddot * d[k];
+    float dn[3];
+    if (nn > 1e-30f) {
+        const float pr = (nh[0] * dnh[0] + nh[1] * dnh[1]) + nh[2] * dnh[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dn[k] = (dnh[k] - nh[k] * pr) / nrm;
+    } else {                                            // the clamp holds the norm: no gradient through it
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dn[k] = dnh[k] / nrm;
+    }
+    const float g0 = grad_rgb[i * 3], g1 = grad_rgb[i * 3 + 1], g2 = grad_rgb[i * 3 + 2];
+    const float dt = ga.w > 0.0f ? (g0 * rgb_s[i * 3] + g1 * rgb_s[i * 3 + 1]) + g2 * rgb_s[i * 3 + 2] : 0.0f;
+    *(float4 *)(dg8 + i * 8) = make_float4(dn[0], dn[1], dn[2], dt);
+    *(float4 *)(dg8 + i * 8 + 4) = make_float4(g0, g1, g2, 0.0f);
+    (void)gb;
+}
+
+// dh^T [144 x 32e] = Bas^T [144 x 32] dF^T [32 x 32e]  (gscale as above; dF is stored unscaled).  KS = 3 (REFTensoRF): a third k-step adds
+// Heads^T [144 x 8] dG^T, the gradient through normal / tint / rgb_d (k 32..35 = dg8[0..3] in lane half 0, k 36..39 = dg8[4..7] in lane half 1).
+template <int KS>
+__global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__restrict__ dfeats, const float *__restrict__ dg8, long long m, const float *__restrict__ gscale_p,
+                                                                const unsigned char *__restrict__ image, float *__restrict__ dh, unsigned *sat)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = lane & 31, h = lane >> 5;
     const long long n_tiles = (m + 31) / 32;
     const float gscale = *gscale_p, inv_scale = 1.0f / gscale;
     float amax = 0.0f;
-    // the 20 A fragments of this lane (same for every tile)
-    uint4 ah[5][2], al[5][2];
+    // the 10 (15) A fragments of this lane, hi and lo (same for every tile)
+    uint4 ah[5][KS], al[5][KS];
 #pragma unroll
     for (int rb = 0; rb < 5; ++rb)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const uint4 *ap = (const uint4 *)(image + TI_BAST) + (size_t)((((rb * 2 + s) * 2 + h) * 32 + e) * 2);
+        for (int s = 0; s < KS; ++s) {
+            const uint4 *ap = (const uint4 *)(image + TI_BAST) + (size_t)((((rb * KS + s) * 2 + h) * 32 + e) * 2);
             ah[rb][s] = ap[0];
             al[rb][s] = ap[1];
         }
@@ -314,32 +382,36 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
         const long long ent = tile * 32 + e;
         const bool live = ent < m;
         const long long le = live ? ent : m - 1;
-        float x[16];
+        float x[8 * KS];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 f4 = *(const float4 *)(dfeats + le * 32 + 8 * q + 4 * h);
             x[4 * q] = f4.x * gscale; x[4 * q + 1] = f4.y * gscale; x[4 * q + 2] = f4.z * gscale; x[4 * q + 3] = f4.w * gscale;
         }
+        if (KS == 3) {
+            const float4 g4 = *(const float4 *)(dg8 + le * 8 + 4 * h);
+            x[16] = g4.x * gscale; x[17] = g4.y * gscale; x[18] = g4.z * gscale; x[19] = g4.w * gscale;
+            x[20] = 0.f; x[21] = 0.f; x[22] = 0.f; x[23] = 0.f;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(x[r]));
-        const Frag b0 = split8(x), b1 = split8(x + 8);
+        for (int r = 0; r < 8 * KS; ++r) amax = fmaxf(amax, fabsf(x[r]));
+        Frag b[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[s] = split8(x + 8 * s);
         f32x16 acc[5];
 #pragma unroll
         for (int rb = 0; rb < 5; ++rb) acc[rb] = f32x16{0};
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(al[rb][0], b0.hi, acc[rb]);
+        for (int s = 0; s < KS; ++s) {
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][0], b0.lo, acc[rb]);
+            for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(al[rb][s], b[s].hi, acc[rb]);
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][0], b0.hi, acc[rb]);
+            for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][s], b[s].lo, acc[rb]);
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(al[rb][1], b1.hi, acc[rb]);
-#pragma unroll
-        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][1], b1.lo, acc[rb]);
-#pragma unroll
-        for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][1], b1.hi, acc[rb]);
+            for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][s], b[s].hi, acc[rb]);
+        }
         if (live) {
 #pragma unroll
             for (int rb = 0; rb < 5; ++rb)
@@ -358,27 +430,43 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
 
 size_t mlp_train_image_bytes() { return TI_BYTES; }
 
-hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, void *image, hipStream_t stream)
+hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream)
 {
-    const int n = 128 * 128 + 160 * 128 + 3 * 128 + 160 * 32;
-    hipLaunchKernelGGL(pack_train_image_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W1, W2, W3, Bas, (unsigned char *)image);
+    HeadPtrs hp;
+    for (int i = 0; i < 4; ++i) hp.W[i] = heads ? heads[i] : nullptr;
+    const int ref = heads ? 1 : 0;
+    const int n = 128 * 128 + 160 * 128 + 3 * 128 + 160 * (ref ? 48 : 32);
+    hipLaunchKernelGGL(pack_train_image_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W1, W2, W3, Bas, hp, ref, (unsigned char *)image);
     return hipGetLastError();
 }
 
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
-                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, hipStream_t stream)
+                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, const MlpRefBwd *ref,
+                                     hipStream_t stream)
 {
-    hipError_t rc = hipFuncSetAttribute((const void *)mlp_train_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TI_LDS_BYTES);
+    hipError_t rc = hipFuncSetAttribute(ref ? (const void *)mlp_train_backward_kernel<true> : (const void *)mlp_train_backward_kernel<false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, TI_LDS_BYTES);
     if (rc != hipSuccess) return rc;
     MlpBwdArgs a;
     a.grad_rgb = grad_rgb; a.rgb = rgb; a.feats = feats; a.h1 = h1; a.h2 = h2; a.m = m; a.gscale = gscale;
     a.d_out = d_out; a.dh2 = dh2; a.dh1 = dh1; a.dfeats = dfeats; a.image = (const unsigned char *)image; a.sat = sat_flag;
+    a.g8 = ref ? ref->g8 : nullptr;
     const long long groups = (m + 32 * MT_WAVES - 1) / (32 * MT_WAVES);
     unsigned grid = groups < 256 ? (unsigned)(groups > 0 ? groups : 1) : 256u;
-    hipLaunchKernelGGL(mlp_train_backward_kernel, dim3(grid), dim3(MT_THREADS), TI_LDS_BYTES, stream, a);
+    if (ref) hipLaunchKernelGGL(mlp_train_backward_kernel<true>, dim3(grid), dim3(MT_THREADS), TI_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(mlp_train_backward_kernel<false>, dim3(grid), dim3(MT_THREADS), TI_LDS_BYTES, stream, a);
     rc = hipGetLastError();
     if (rc != hipSuccess) return rc;
     const long long g2 = (m + 127) / 128;
-    hipLaunchKernelGGL(basis_backward_kernel, dim3((unsigned)(g2 < 1024 ? (g2 > 0 ? g2 : 1) : 1024)), dim3(256), 0, stream, dfeats, m, gscale, (const unsigned char *)image, dh, sat_flag);
+    const unsigned grid2 = (unsigned)(g2 < 1024 ? (g2 > 0 ? g2 : 1) : 1024);
+    if (ref) {
+        hipLaunchKernelGGL(ref_heads_backward_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, grad_rgb, rgb, ref->g8, ref->viewdirs, dfeats, ref->grad_in0, m,
+                           ref->dg8);
+        rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+        hipLaunchKernelGGL(basis_backward_kernel<3>, dim3(grid2), dim3(256), 0, stream, dfeats, ref->dg8, m, gscale, (const unsigned char *)image, dh, sat_flag);
+    } else {
+        hipLaunchKernelGGL(basis_backward_kernel<2>, dim3(grid2), dim3(256), 0, stream, dfeats, (const float *)nullptr, m, gscale, (const unsigned char *)image, dh, sat_flag);
+    }
     return hipGetLastError();
 }

@@ -264,6 +264,9 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
     r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
     const float4 b3 = *(const float4 *)(smem + TVR_IMG_B3);
     r0 = sigmoid_f(r0 + b3.x); r1 = sigmoid_f(r1 + b3.y); r2 = sigmoid_f(r2 + b3.z);
+    if (REF && DST == SH_DST_TRAIN && c.live && h == 0) {        // the MLP's own output: the backward needs sigmoid' and d rgb / d tint
+        a.t_rgbs[c.ent * 3] = r0; a.t_rgbs[c.ent * 3 + 1] = r1; a.t_rgbs[c.ent * 3 + 2] = r2;
+    }
     if (REF && HAVE_G) {                                         // REFTensoRF.py:232  specular_tint * clamp(rgb_s, 0) + rgb_d
         const float tint = fmaxf(c.g[0], 0.0f);
         r0 = tint * fmaxf(r0, 0.0f) + c.g[1]; r1 = tint * fmaxf(r1, 0.0f) + c.g[2]; r2 = tint * fmaxf(r2, 0.0f) + c.g[3];
@@ -324,6 +327,27 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 #define TVR_ENTER_MATRIX() __builtin_amdgcn_s_setprio(TVR_PRIO_M)
 #define TVR_LEAVE_MATRIX() __builtin_amdgcn_s_setprio(TVR_PRIO_G)
 #endif
+// REFTensoRF's second row block on the same h fragments (REFTensoRF.py:126-132): A from the LDS image (8 weight rows; lanes 4..6 re-read the
+// normal rows so that both lane halves hold the normal, every other lane reads the zero row), biases as the initial accumulator.
+// Uses hf[], accA/B/C, G[], e, h, smem of the enclosing scope.
+#define TVR_REF_HEADS()                                                                                                              \
+    do {                                                                                                                            \
+        const int rr = e < 4 ? e : (e < 7 ? e - 4 : ((e >= 8 && e < 12) ? e - 4 : -1));                                             \
+        const unsigned char *rowp = rr >= 0 ? smem + TVR_IMG_REFW + rr * TVR_IMG_REF_ROW : smem + TVR_IMG_REF_ZROW;                 \
+        const float4 g0 = *(const float4 *)(smem + TVR_IMG_REFB + 16 * h), g1 = *(const float4 *)(smem + TVR_IMG_REFB + 32 + 16 * h); \
+        accA = f32x16{0}; accB = f32x16{0}; accC = f32x16{0};                                                                       \
+        accA[0] = g0.x; accA[1] = g0.y; accA[2] = g0.z; accA[3] = g0.w;                                                             \
+        accA[4] = g1.x; accA[5] = g1.y; accA[6] = g1.z; accA[7] = g1.w;                                                             \
+        _Pragma("unroll") for (int s = 0; s < 9; ++s) {                                                                             \
+            const uint4 *ap = (const uint4 *)(rowp + (s * 2 + h) * 32);                                                             \
+            const h8 Ah = __builtin_bit_cast(h8, ap[0]), Al = __builtin_bit_cast(h8, ap[1]);                                        \
+            accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);                     \
+            accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);                     \
+            accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);                     \
+        }                                                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) G[r] = (accA[r] + accB[r]) + accC[r];                                         \
+    } while (0)
+
 template <int SRC, int DST, bool REF>
 __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
@@ -458,6 +482,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) F[r] = (accA[r] + accB[r]) + accC[r];
+            if (REF) { TVR_REF_HEADS(); }
         } else if (SRC != SH_SRC_FEAT) {
             float pn[3] = {0.f, 0.f, 0.f};
             if (SRC == SH_SRC_QUEUE) {
@@ -531,26 +556,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) F[r] = (accA[r] + accB[r]) + accC[r];
-            if (REF) {
-                // second row block: A from the LDS image (8 weight rows; lanes 4..6 re-read the normal rows so that both lane halves
-                // hold the normal, every other lane reads the zero row), biases as the initial accumulator
-                const int rr = e < 4 ? e : (e < 7 ? e - 4 : ((e >= 8 && e < 12) ? e - 4 : -1));
-                const unsigned char *rowp = rr >= 0 ? smem + TVR_IMG_REFW + rr * TVR_IMG_REF_ROW : smem + TVR_IMG_REF_ZROW;
-                const float4 g0 = *(const float4 *)(smem + TVR_IMG_REFB + 16 * h), g1 = *(const float4 *)(smem + TVR_IMG_REFB + 32 + 16 * h);
-                accA = f32x16{0}; accB = f32x16{0}; accC = f32x16{0};
-                accA[0] = g0.x; accA[1] = g0.y; accA[2] = g0.z; accA[3] = g0.w;
-                accA[4] = g1.x; accA[5] = g1.y; accA[6] = g1.z; accA[7] = g1.w;
-#pragma unroll
-                for (int s = 0; s < 9; ++s) {
-                    const uint4 *ap = (const uint4 *)(rowp + (s * 2 + h) * 32);
-                    const h8 Ah = __builtin_bit_cast(h8, ap[0]), Al = __builtin_bit_cast(h8, ap[1]);
-                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);
-                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) G[r] = (accA[r] + accB[r]) + accC[r];
-            }
+            if (REF) { TVR_REF_HEADS(); }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         }
 
         TVR_STAMP(tg2);
-        if (DST == SH_DST_TRAIN && live) {           // features [n,32]: rows 27..31 (h=0: r=15; h=1: r=12..15) are written as zero
+        if (DST == SH_DST_TRAIN && !REF && live) {   // features [n,32]: rows 27..31 (h=0: r=15; h=1: r=12..15) are written as zero
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *(float4 *)(a.t_feats + ent * 32 + 8 * q + 4 * h) = q < 3 ? make_float4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3])
@@ -605,6 +611,19 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         }
         if (h == 0) F[15] = dir[0];
         else { F[12] = dir[1]; F[13] = dir[2]; F[14] = dotin; F[15] = 1.0f; }
+        if (DST == SH_DST_TRAIN && REF && live) {
+            // REFTensoRF training forward: the 31 base values of layer 1 — 27 features, the reflection direction (rows 27..29) and -dot (row 30),
+            // both functions of h through the normal head — are what the backward differentiates through; row 31 (the constant) is stored as 0.
+            // And the raw outputs of the four heads {normal 3, tint, rgb_d 3, rho} (h = 0 lanes hold all eight).
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4 *)(a.t_feats + ent * 32 + 8 * q + 4 * h) = (q < 3 || h == 0) ? make_float4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3])
+                                                                                      : make_float4(F[12], F[13], F[14], 0.f);
+            if (h == 0) {
+                *(float4 *)(a.t_g8 + ent * 8) = make_float4(G[0], G[1], G[2], G[3]);
+                *(float4 *)(a.t_g8 + ent * 8 + 4) = make_float4(G[4], G[5], G[6], G[7]);
+            }
+        }
 
         // ---- layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5.  sin / cos of a base
         //      value are taken in the step that first needs them (2-3 per step), between the MFMAs of the step before ----
@@ -724,6 +743,7 @@ hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a
         if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, true>(sc, a, stream);
         if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, true>(sc, a, stream);
         if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, true>(sc, a, stream);
+        if (src == SH_SRC_H && dst == SH_DST_TRAIN) return launch_shade_t<SH_SRC_H, SH_DST_TRAIN, true>(sc, a, stream);
         return hipErrorInvalidValue;
     }
     if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false>(sc, a, stream);

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .autograd_ops import _AppHFn, _MarchFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
+from .autograd_ops import _AppHFn, _MarchFn, _RefMlpTrainFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
 from .field import TensorVMSplit
 
 
@@ -125,14 +125,25 @@ class REFTensoRF(TensorVMSplit):
         eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
         w, acc, xyz, ray_id, depth, _ = _MarchFn.apply(self, rays, jitter, S, eps_T, None, *self.density_plane, *self.density_line)
         h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
-        app_features, rgb_d, specular_tint, normal_vector, rho = self._heads(h)
-        normal_vector = self._normalize(normal_vector)                                        # :217
-        d = -rays[ray_id, 3:6]                                                                # :219
-        dot_product = (d * normal_vector).sum(dim=1, keepdim=True)                            # :221-223
-        reflection = 2 * dot_product * normal_vector - d                                      # :225
-        rgb_s = self.renderModule.forward_autograd(reflection, app_features, -dot_product)    # :229
-        rgb = specular_tint * rgb_s.clamp(min=0) + rgb_d                                      # :232
-        penalty = torch.relu(-dot_product).square().squeeze(-1)                               # :237-238
+        rm = self.renderModule
+        if (self.fused_mlp_training and h.shape[0] > 0 and list(self.app_n_comp) == [48, 48, 48] and rm.feape == 2 and rm.viewpe == 2
+                and rm.mlp[0].out_features == 128 and h.shape[0] * 576 < (1 << 32)):
+            # heads + normalisation + reflection + MLPRender_Fea_Ref + the colour mix as one fused forward / backward pair (no library GEMM)
+            mlp = rm.mlp
+            rgb, in0 = _RefMlpTrainFn.apply(self, h, rays[ray_id, 3:6], self.basis_mat.weight, self.normal_linear.weight, self.normal_linear.bias,
+                                            self.diffuse_linear.weight, self.diffuse_linear.bias, self.specular_linear.weight, self.specular_linear.bias,
+                                            self.rho_linear.weight, self.rho_linear.bias, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias,
+                                            mlp[4].weight, mlp[4].bias)
+            penalty = torch.relu(in0).square()                                                # :237-238 (in0 = -dot_product)
+        else:
+            app_features, rgb_d, specular_tint, normal_vector, rho = self._heads(h)
+            normal_vector = self._normalize(normal_vector)                                    # :217
+            d = -rays[ray_id, 3:6]                                                            # :219
+            dot_product = (d * normal_vector).sum(dim=1, keepdim=True)                        # :221-223
+            reflection = 2 * dot_product * normal_vector - d                                  # :225
+            rgb_s = self.renderModule.forward_autograd(reflection, app_features, -dot_product)    # :229
+            rgb = specular_tint * rgb_s.clamp(min=0) + rgb_d                                  # :232
+            penalty = torch.relu(-dot_product).square().squeeze(-1)                           # :237-238
         self.penalty = torch.sum(w * penalty, -1)                                             # :239
         rgb_map = torch.zeros((rays.shape[0], 3), device=self.device).index_add_(0, ray_id, w[:, None] * rgb)
         if white_bg:

@@ -80,8 +80,11 @@ def _oracle_with_grads(arrs, hyper):
     return sc, leaves
 
 
-def test_ref_gradients_match_oracle_autograd(tiny_ref, tiny_ref_arrays, hyper_tiny):
-    """train.py:225-257 with model_name = REFTensoRF: loss = sum(rgb_map * c) + 0.5 * penalty (normal_vector_penalty_weight, Scar.txt:7)."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_ref_gradients_match_oracle_autograd(fused, tiny_ref, tiny_ref_arrays, hyper_tiny):
+    """train.py:225-257 with model_name = REFTensoRF: loss = sum(rgb_map * c) + 0.5 * penalty (normal_vector_penalty_weight, Scar.txt:7).
+    fused = True: heads, normalisation, reflection, MLPRender_Fea_Ref and the colour mix run as tvr_mlp_train_forward_ref / _backward_ref (no library GEMM);
+    fused = False: the same algebra as torch ops over library GEMMs (the round-2 path, kept as a second opinion)."""
     from oracle import tensorf_oracle as TO
     rays_np = tiny_ref["rays"]
     S = TINY["N_samples"]
@@ -91,8 +94,13 @@ def test_ref_gradients_match_oracle_autograd(tiny_ref, tiny_ref_arrays, hyper_ti
     ((rgb_o * cw).sum() + 0.5 * sc.penalty).backward()
     m = make_model(tiny_ref_arrays, hyper_tiny)
     m.eps_T = 0.0
+    m.fused_mlp_training = fused
     rgb, depth = m.render_rays_autograd(torch.tensor(rays_np, device="cuda"), white_bg=True, N_samples=S)
     assert np.abs(_np(rgb) - rgb_o.detach().numpy()).max() < 2e-4
+    if fused:                                            # the training forward IS the evaluation kernel (per-sample colours bit for bit); the pixels differ
+        with torch.no_grad():                            # only by the order in which the compositing sums run (index_add vs the composite kernel)
+            rgb_eval, _ = m.render_rays(torch.tensor(rays_np, device="cuda"), white_bg=True, N_samples=S)
+        assert float((rgb_eval - rgb.detach()).abs().max()) < 2e-6
     assert abs(float(m.penalty.detach()) - float(sc.penalty.detach())) < 1e-3 * max(1.0, abs(float(sc.penalty.detach())))
     ((rgb * cw.cuda()).sum() + 0.5 * m.penalty).backward()
     mlp = m.renderModule.mlp
