@@ -12,7 +12,8 @@ world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK",
 if world > 1:
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist.init_process_group(os.environ.get("TVR_BENCH_BACKEND", "nccl"))
-m, arrs, A = bench.build_model(torch.device("cuda"))
+MODEL = os.environ.get("TVR_MODEL", "TensorVMSplit")        # REFTensoRF: what configs/Scar.txt:28 trains (+ the normal penalty, train.py:253-257)
+m, arrs, A = bench.build_model(torch.device("cuda"), MODEL)
 m.fused_mlp_training = bool(int(os.environ.get("TVR_FUSED_MLP", "1")))      # 0: round-1 path (library GEMMs for the MLP forward / dX)
 with torch.no_grad():                                  # start from a perturbed copy so that gradients are non-trivial
     for p in m.parameters():
@@ -20,7 +21,7 @@ with torch.no_grad():                                  # start from a perturbed 
 fr = bench.frames(A)
 allrays = torch.cat(fr[:4]).cuda()
 with torch.no_grad():
-    teacher, _, _ = bench.build_model(torch.device("cuda"))
+    teacher, _, _ = bench.build_model(torch.device("cuda"), MODEL)
     allrgbs = torch.cat([teacher.render_rays(allrays[i:i + 640000], N_samples=512)[0] for i in range(0, allrays.shape[0], 640000)])
     del teacher
 nS = int(np.linalg.norm(A["gridSize"]) / 0.5)
@@ -34,6 +35,9 @@ def step():
     rgb_map, _, _, _, _ = OctreeRender_trilinear_fast(allrays[idx], m, chunk=4096, N_samples=nS, white_bg=True, is_train=True)
     loss = torch.mean((rgb_map - allrgbs[idx]) ** 2)
     total = loss + 1e-4 * m.vector_comp_diffs() + 8e-5 * m.density_L1() + 0.1 * m.TV_loss_density(tv) + 0.01 * m.TV_loss_app(tv)
+    if MODEL == "REFTensoRF":
+        total = total + 0.5 * m.penalty
+        m.penalty = torch.zeros((), device="cuda")
     total.backward()
     if bucket: bucket.all_reduce_mean()
     opt.step()
@@ -43,4 +47,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 N = 20
 for _ in range(N): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
-if rank == 0: print(f"train step ({world} rank(s), {4096 // world} rays each): {dt * 1e3:.2f} ms  ({1 / dt:.1f} it/s), batch 4096 rays x {nS} samples, loss {float(l.detach()):.3e}")
+if rank == 0: print(f"{MODEL} (fused MLP kernels {int(m.fused_mlp_training)}) train step ({world} rank(s), {4096 // world} rays each): {dt * 1e3:.2f} ms  ({1 / dt:.1f} it/s), batch 4096 rays x {nS} samples, loss {float(l.detach()):.3e}")
