@@ -9,8 +9,8 @@ A "step" = one pass of the hot path over one batch of synthetic rays resident in
   N = 1 : one 800x800 frame = 640 000 rays x 512 samples of scene A (TensorVMSplit 300^3) — BASELINE configs[1];
           ONE tvr_render call (march + shade + composite kernels).
   N > 1 (default, --scaling strong): BASELINE configs[2] as written — the SAME ONE 640 000-ray frame, cut into 4096-ray tiles dealt
-          round-robin to the ranks (rank r renders tiles r, r+N, ...: 80 000 rays each at N = 8), then ONE all_gather of [rays,4] fp32
-          pixels (rgb+depth) over RCCL/xGMI returns the frame to every rank and ONE index gather undoes the interleave.  Total work is
+          round-robin to the ranks (rank r renders tiles r, r+N, ...: 80 000 rays each at N = 8) straight into its send buffer, then ONE
+          all_gather of [4 cap] fp32 (rgb block + depth block) over RCCL/xGMI returns the frame to every rank and two strided copies undo the interleave.  Total work is
           fixed, so the line says "scaling": "strong" at every N (N = 1 included) and SURVEY 8e's t_1 / (N t_N) is value(N) / (N value(1)).
           Rank 0 also times the whole frame alone (outside the timed region) and reports it as `strong_split.t1_ms`.
   N > 1, --scaling weak (on request): a batch of N such frames (N camera poses), every rank renders 640 000 rays.
@@ -316,7 +316,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from jittor_myc_nerfs_amd import _lib as L, shard_capacity, shard_gather_index, shard_indices
+    from jittor_myc_nerfs_amd import _lib as L, shard_capacity, shard_indices, shard_send_views, shard_unpermute
     import ctypes as C
     model, arrs, A = build_model(device, args.model)
     S = A["N_samples"]
@@ -342,9 +342,10 @@ def main():
         if world > 1 and (args.check or strong):
             full_rays.append(batch.to(device))
     n_mine = step_rays[0].shape[0]
-    inv = shard_gather_index(R_step, world, TILE, device) if world > 1 else None
-    mine = torch.zeros((cap, 4), device=device)
-    gathered = torch.empty((world * cap, 4), device=device) if world > 1 else None
+    # the send buffer of the exchange: [rgb block 3 cap | depth block cap] fp32; the render kernels write straight into views of it
+    mine = torch.zeros((4 * cap,), device=device)
+    send_views = shard_send_views(mine, cap, n_mine) if world > 1 else None
+    gathered = torch.empty((world * 4 * cap,), device=device) if world > 1 else None
     gloo = world > 1 and dist.get_backend() == "gloo"
 
     prof = C.c_void_p()
@@ -357,17 +358,18 @@ def main():
                     for c0 in range(0, rays.shape[0], args.chunk)]
             rgb, depth = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
         else:
-            rgb, depth = model.render_rays(rays, white_bg=True, N_samples=S, eps_T=args.eps_T, stats=stats, profile=profile)
+            rgb, depth = model.render_rays(rays, white_bg=True, N_samples=S, eps_T=args.eps_T, stats=stats, profile=profile, out=send_views)
         if world > 1:
-            mine[:n_mine, :3] = rgb
-            mine[:n_mine, 3] = depth
+            if args.chunk > 0:
+                send_views[0].copy_(rgb)
+                send_views[1].copy_(depth)
             if gloo:                                                # rehearsal path only
                 parts = [torch.empty_like(mine) for _ in range(world)]
                 dist.all_gather(parts, mine)
-                return torch.cat(parts).index_select(0, inv)
+                return shard_unpermute(torch.cat(parts), R_step, world, cap, TILE)
             dist.all_gather_into_tensor(gathered, mine)
-            return gathered.index_select(0, inv)                    # undo the tile interleave: ONE precomputed index gather
-        return rgb
+            return shard_unpermute(gathered, R_step, world, cap, TILE)      # undo the tile interleave: two strided copies (rgb, depth)
+        return rgb, depth
 
     # kernel durations come from HIP events recorded around each kernel inside tvr_render, in the timed region itself for the full-size frame
     # (20.64 ms per step against 20.62 ms of kernels).  When a rank's share is a fraction of a frame (strong split / --emulate-world: 2.7 ms
@@ -421,9 +423,9 @@ def main():
     if args.check and world > 1:                                   # outside the timed region
         ok = True
         for pat in range(n_patterns):
-            img = step(pat)
+            rgb_g, depth_g = step(pat)
             rgb1, depth1 = model.render_rays(full_rays[pat], white_bg=True, N_samples=S, eps_T=args.eps_T)
-            ok = ok and torch.equal(img[:, :3], rgb1) and torch.equal(img[:, 3], depth1)
+            ok = ok and torch.equal(rgb_g, rgb1) and torch.equal(depth_g, depth1)
         flag = torch.tensor([1 if ok else 0], device=device)
         if gloo:
             flag = flag.cpu()
@@ -558,7 +560,7 @@ def main():
         "config": {"workload": ("TensorVMSplit 300^3 (16/48 comps, MLP_Fea 150-128-128-3)" if args.model == "TensorVMSplit" else
                                 "REFTensoRF 300^3 (16/48 comps, 4 heads on h, MLP_Fea_Ref 151-128-128-3)") +
                                f", {args.img}x{args.img} rays x 512 samples/ray (BASELINE configs[1]); {mode}, 4096-ray tiles round-robin, one RCCL "
-                               "all_gather of [rays,4] fp32 + one index gather",
+                               "all_gather of [4 cap] fp32 (rgb block + depth block, written in place by the render) + two strided un-permute copies",
                    "scene": "synthetic scene A (SURVEY 8d), no alpha mask, white_bg",
                    "rays_per_step": rays_job, "samples_per_ray": S, "rays_per_rank": n_mine,
                    "eps_T": float(model.rayMarch_weight_thres) if args.eps_T is None else args.eps_T, "tile": TILE,

@@ -526,9 +526,11 @@ class TensorBase(torch.nn.Module):
         return all_rays[mask_filtered], all_rgbs[mask_filtered]
 
     def render_rays(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None, eps_T=None, dense=False,
-                    stats: Optional[torch.Tensor] = None, profile=None):
+                    stats: Optional[torch.Tensor] = None, profile=None, out=None):
         """One tvr_render call.  Returns (rgb_map [N,3], depth_map [N]) or, with dense=True, additionally a dict
-        of per-sample tensors.  `stats`: uint64/int64[8] device tensor the kernels add counters to."""
+        of per-sample tensors.  `stats`: uint64/int64[8] device tensor the kernels add counters to.
+        `out` = (rgb [N,3], depth [N]): contiguous fp32 device tensors the kernels write instead of fresh ones (render_sharded hands in
+        views of its all_gather send buffer, so the pixels are produced where the exchange reads them)."""
         sc = self._ensure_scene()
         lib = L.lib()
         rays = _f32c(rays_chunk, self.device)
@@ -536,8 +538,14 @@ class TensorBase(torch.nn.Module):
             raise ValueError(f"rays must be [N,6] (origin, direction); got {tuple(rays.shape)}")
         n = rays.shape[0]
         S = int(N_samples) if N_samples > 0 else self.nSamples                                # :341
-        rgb = torch.empty((n, 3), dtype=torch.float32, device=self.device)
-        depth = torch.empty((n,), dtype=torch.float32, device=self.device)
+        if out is not None:
+            rgb, depth = out
+            if (rgb.shape != (n, 3) or depth.shape != (n,) or rgb.dtype != torch.float32 or depth.dtype != torch.float32 or not rgb.is_contiguous()
+                    or not depth.is_contiguous() or rgb.device != rays.device or depth.device != rays.device):
+                raise ValueError("out must be (contiguous fp32 [N,3], contiguous fp32 [N]) on the rays' device")
+        else:
+            rgb = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+            depth = torch.empty((n,), dtype=torch.float32, device=self.device)
         if n == 0:
             return (rgb, depth, {}) if dense else (rgb, depth)
         if eps_T is None:

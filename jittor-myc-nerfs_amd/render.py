@@ -5,7 +5,8 @@
     stream, with no host synchronisation between chunks (the reference syncs and garbage-collects per chunk, :23-25).
   * render_sharded — new functionality (the reference is single-GPU): rays are cut into fixed-size
     tiles dealt round-robin to the ranks (interleaving evens out empty-vs-dense image regions), each rank renders
-    its tiles, and ONE all_gather (RCCL over xGMI when the backend is "nccl") returns every pixel to every rank.
+    its tiles straight into its all_gather send buffer, and ONE all_gather (RCCL over xGMI when the backend is "nccl") returns every
+    pixel to every rank; two strided copies undo the interleave.
     Per-ray results do not depend on the partition, so the gathered image equals the single-GPU image bit for bit.
 """
 from __future__ import annotations
@@ -92,29 +93,53 @@ def shard_gather_index(n_rays: int, world: int, tile: int = 4096, device=None) -
     return inv
 
 
-def render_sharded(rays: torch.Tensor, render_fn: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
+def shard_send_views(buf: torch.Tensor, cap: int, n_mine: int):
+    """Views of a flat [4 cap] fp32 send buffer: (rgb [n_mine,3] inside its first 3 cap floats, depth [n_mine] inside its last cap).  The render
+    kernels write the pixels straight into them (render_rays(out=...)): no pad copy in front of the all_gather."""
+    return buf[:3 * cap].view(cap, 3)[:n_mine], buf[3 * cap:][:n_mine]
+
+
+def shard_unpermute(gathered: torch.Tensor, n_rays: int, world: int, cap: int, tile: int = 4096):
+    """gathered [world, 4 cap] (every rank's send buffer, rank-major) -> (rgb [n_rays,3], depth [n_rays]) in ray order.  Rank r's t-th tile is
+    tile t * world + r of the frame, so the frame is the [tiles-per-rank, world] transpose of the gathered [world, tiles-per-rank] tile grid:
+    two strided copies (rgb, depth), whatever the world size; the padding tiles land behind the last ray and are cut off."""
+    L = cap // tile
+    g = gathered.view(world, 4 * cap)
+    rgb = g[:, :3 * cap].reshape(world, L, tile, 3).transpose(0, 1).reshape(-1, 3)[:n_rays]
+    depth = g[:, 3 * cap:].reshape(world, L, tile).transpose(0, 1).reshape(-1)[:n_rays]
+    return rgb, depth
+
+
+def render_sharded(rays: torch.Tensor, render_fn: Callable[..., Tuple[torch.Tensor, torch.Tensor]],
                    rank: int, world: int, tile: int = 4096, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Render `rays` [R,6] (the full batch, present on every rank) across `world` ranks.
 
-    render_fn(rays_subset) -> (rgb [n,3], depth [n]) renders on this rank's device.  Returns the full
-    (rgb [R,3], depth [R]) on every rank after one all_gather of [cap,4] fp32 (rgb + depth packed together) and one
-    index_select that undoes the tile interleave."""
+    render_fn(rays_subset, out=(rgb [n,3], depth [n])) renders on this rank's device INTO `out` (field.render_rays does; a render_fn without
+    an `out` parameter is called plainly and its result copied).  Returns the full (rgb [R,3], depth [R]) on every rank after ONE all_gather of
+    the [4 cap] fp32 send buffers (rgb block, then depth block) and two strided copies that undo the tile interleave (shard_unpermute)."""
+    import inspect
     import torch.distributed as dist
     R = rays.shape[0]
     if world == 1:
         return render_fn(rays)
     idx = shard_indices(R, rank, world, tile).to(rays.device)
     cap = shard_capacity(R, world, tile)
-    rgb, depth = render_fn(rays.index_select(0, idx)) if idx.numel() else (rays.new_zeros((0, 3)), rays.new_zeros((0,)))
-    mine = rays.new_zeros((cap, 4))
-    mine[:idx.numel(), :3] = rgb
-    mine[:idx.numel(), 3] = depth
-    gathered = rays.new_empty((world * cap, 4))
+    mine = rays.new_zeros((4 * cap,))
+    if idx.numel():
+        views = shard_send_views(mine, cap, idx.numel())
+        sub = rays.index_select(0, idx)
+        if "out" in inspect.signature(render_fn).parameters:
+            render_fn(sub, out=views)
+        else:
+            rgb, depth = render_fn(sub)
+            views[0].copy_(rgb)
+            views[1].copy_(depth)
+    gathered = rays.new_empty((world * 4 * cap,))
     if dist.get_backend(group) == "gloo" and gathered.is_cuda:          # 1-GPU rehearsals: gloo has no all_gather_into_tensor for device tensors
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
         gathered = torch.cat(parts)
     else:
         dist.all_gather_into_tensor(gathered, mine, group=group)
-    out = gathered.index_select(0, shard_gather_index(R, world, tile, rays.device))
-    return out[:, :3].contiguous(), out[:, 3].contiguous()
+    rgb, depth = shard_unpermute(gathered, R, world, cap, tile)
+    return rgb.contiguous(), depth.contiguous()

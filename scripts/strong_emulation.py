@@ -5,8 +5,8 @@
 
   * kernels: `bench.py --emulate-world N` renders rank 0's share of the N-way split (tiles 0, N, 2N, ... of 4096 rays) — N = 1, 2, 4, 8, each in a
     fresh child process; efficiency_kernels = t_1 / (N t_N) over the whole step (march + shade + composite + launch gaps).
-  * exchange, device side: the pad copy into the [cap,4] send buffer and the ONE index gather that undoes the tile interleave of the [N cap,4]
-    gathered buffer, timed with HIP events at each N's own sizes.
+  * exchange, device side: the two strided copies that undo the tile interleave of the gathered [N, 4 cap] buffer (the render writes its pixels
+    straight into the send buffer: no pad copy), timed with HIP events at each N's own sizes, beside round 2's single index gather.
   * exchange, transport: a 2-rank `gloo` run of the real step (`bench.py --gpus 2 --scaling strong --check`, both ranks on this card).  gloo stages
     device tensors through the host, so its all_gather is an UPPER bound for RCCL over xGMI (10.2 MB per frame); the number is recorded, not used.
 No multi-GPU node has been available to the build; the hardware curve stays unmeasured until the driver's SCALE run."""
@@ -31,32 +31,30 @@ def run_json(cmd, env=None, timeout=900):
 def device_side_exchange(worlds, R=640000, tile=4096, reps=50):
     import torch
     sys.path.insert(0, ROOT)
-    from jittor_myc_nerfs_amd import shard_capacity, shard_gather_index, shard_indices
+    from jittor_myc_nerfs_amd import shard_capacity, shard_gather_index, shard_indices, shard_unpermute
     dev = torch.device("cuda", 0)
     out = {}
     for w in worlds:
         cap = shard_capacity(R, w, tile)
         n_mine = shard_indices(R, 0, w, tile).numel()
-        rgb, depth = torch.rand((n_mine, 3), device=dev), torch.rand((n_mine,), device=dev)
-        mine = torch.zeros((cap, 4), device=dev)
-        gathered = torch.rand((w * cap, 4), device=dev)
+        gathered = torch.rand((w * 4 * cap,), device=dev)
         inv = shard_gather_index(R, w, tile, dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        t_pad = t_gather = 0.0
+        t_new = t_old = 0.0
         for i in range(reps + 5):
             ev[0].record()
-            mine[:n_mine, :3] = rgb
-            mine[:n_mine, 3] = depth
+            rgb, depth = shard_unpermute(gathered, R, w, cap, tile)
             ev[1].record()
-            img = gathered.index_select(0, inv)
+            img = gathered.view(-1, 4)[:w * cap].index_select(0, inv)        # round 2's form: one index gather of [N cap,4] (same bytes)
             ev[2].record()
             torch.cuda.synchronize()
             if i >= 5:
-                t_pad += ev[0].elapsed_time(ev[1])
-                t_gather += ev[1].elapsed_time(ev[2])
+                t_new += ev[0].elapsed_time(ev[1])
+                t_old += ev[1].elapsed_time(ev[2])
         out[str(w)] = {"cap_rays": cap, "rays_rank0": n_mine, "send_bytes": cap * 16, "gathered_bytes": w * cap * 16,
-                       "pad_copy_ms": t_pad / reps, "index_gather_ms": t_gather / reps}
-        del img
+                       "pad_copy_ms": 0.0, "unpermute_ms": t_new / reps, "round2_index_gather_ms": t_old / reps,
+                       "note": "no pad copy: the render kernels write rgb / depth straight into the send buffer; the un-permute is two strided copies"}
+        del img, rgb, depth
     return out
 
 
@@ -82,7 +80,7 @@ def main():
     ex = device_side_exchange(worlds[1:])
     for w in worlds[1:]:
         r, e = rows[str(w)], ex[str(w)]
-        r["efficiency_step_with_device_side_exchange"] = t1 / (w * (r["ms_per_step"] + e["pad_copy_ms"] + e["index_gather_ms"]))
+        r["efficiency_step_with_device_side_exchange"] = t1 / (w * (r["ms_per_step"] + e["pad_copy_ms"] + e["unpermute_ms"]))
     out = {"what": "BASELINE configs[2] on ONE MI355X: rank 0's share of the N-way strong split of the 800x800 frame (kernels, --emulate-world), the device-side "
                    "half of the exchange, and a 2-rank gloo rehearsal; t_1 / (N t_N) per SURVEY 8e.  The RCCL all_gather itself is not measurable on one card.",
            "command": "python3 scripts/strong_emulation.py --steps %d" % args.steps, "emulation": rows, "exchange_device_side": ex}

@@ -68,7 +68,7 @@ def _hip_worker(rank, world, port, arrs, hyper, rays_np, tiles, q):
     rays = torch.tensor(rays_np, device="cuda")
     out = {}
     for tile in tiles:
-        rgb, depth = render_sharded(rays, lambda r: m.render_rays(r, white_bg=True, N_samples=TINY["N_samples"]), rank, world, tile=tile)
+        rgb, depth = render_sharded(rays, lambda r, out=None: m.render_rays(r, white_bg=True, N_samples=TINY["N_samples"], out=out), rank, world, tile=tile)
         out[tile] = (rgb.cpu().numpy(), depth.cpu().numpy())
     q.put((rank, out))
     dist.barrier()
@@ -135,8 +135,22 @@ def test_bench_step_world2_on_one_card(scaling, img, tmp_path):
 
 
 def test_shard_gather_index_is_the_inverse_of_the_tile_interleave():
-    """CPU: image[i] = gathered[inv[i]] for every (rays, world, tile) — ragged last tiles, more ranks than tiles, one rank."""
-    from jittor_myc_nerfs_amd import shard_capacity, shard_gather_index, shard_indices
+    """CPU: image[i] = gathered[inv[i]] for every (rays, world, tile) — ragged last tiles, more ranks than tiles, one rank; and the strided
+    un-permute of the [rgb block | depth block] send buffers (shard_send_views / shard_unpermute) returns the same frame."""
+    from jittor_myc_nerfs_amd import shard_capacity, shard_gather_index, shard_indices, shard_send_views, shard_unpermute
+    for R, w, t in [(77, 2, 16), (9001, 2, 4096), (640000, 8, 4096), (640000, 3, 4096), (5, 4, 16), (100, 1, 16), (1, 2, 4096)]:
+        cap = shard_capacity(R, w, t)
+        frame_rgb, frame_depth = torch.arange(R * 3, dtype=torch.float32).view(R, 3), -torch.arange(R, dtype=torch.float32)
+        bufs = []
+        for r in range(w):
+            idx = shard_indices(R, r, w, t)
+            buf = torch.full((4 * cap,), float("nan"))
+            v_rgb, v_depth = shard_send_views(buf, cap, idx.numel())
+            v_rgb.copy_(frame_rgb[idx])
+            v_depth.copy_(frame_depth[idx])
+            bufs.append(buf)
+        rgb, depth = shard_unpermute(torch.cat(bufs), R, w, cap, t)
+        assert torch.equal(rgb, frame_rgb) and torch.equal(depth, frame_depth), (R, w, t)
     for R, w, t in [(77, 2, 16), (640000, 8, 4096), (640000, 3, 4096), (5, 4, 16), (4096 * 8, 8, 4096), (100, 1, 16), (1, 2, 4096)]:
         cap = shard_capacity(R, w, t)
         g = torch.full((w * cap,), -1, dtype=torch.long)
