@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 110
+#define TVR_VERSION 111
 
 typedef enum {
     TVR_OK = 0,
@@ -168,7 +168,7 @@ int tvr_alpha_sample(const float *alpha_volume_dev, const int32_t agrid_xyz[3], 
  * three Linears run as library GEMMs under the host's autograd between them. */
 
 /* Byte offsets of the regions of a tvr_render / tvr_march_forward scratch buffer, for hosts that consume the queue:
- * counter u32[4] = {queue length, the march's tile counter, FAULT flag, -}: the flag is non-zero if a wave of the march kernel gave up waiting for its
+ * counter u32[4] = {queue length, the march's tile counter, FAULT flag, training-workspace OVERFLOW flag (tvr_train_forward)}: the flag is non-zero if a wave of the march kernel gave up waiting for its
  * tile number (1: overtaken in the 32-slot ring, 2: spin limit; tvr_march.hip) — tvr_render then writes NaN to every pixel and depth of the call,
  * hosts that consume the queue read it with the queue length; ray_off/ray_cnt u32[n]; acc f32[n]; q_pos float4[cap] {xyz_norm, weight}; q_out float4[cap] {rgb, weight};
  * q_ray u32[cap]; q_j u32[cap]; cap = n_rays * n_samples.  Each ray's entries are contiguous and in sample order. */
@@ -255,6 +255,31 @@ int tvr_mlp_train_backward_ref(const float *W1, const float *W2, const float *W3
                                int64_t m, const float *gscale_dev, float *d_out4, size_t d_out4_bytes, float *dh2, size_t dh2_bytes, float *dh1, size_t dh1_bytes,
                                float *dfeats32, size_t dfeats32_bytes, float *dg8, size_t dg8_bytes, float *dh, size_t dh_bytes, uint32_t *sat_flag_dev, void *image,
                                size_t image_bytes, void *stream);
+
+/* ---- the training step as two calls with NO host read in between (round 3) -------------------------------------------------------------------
+ * tvr_train_forward  = tvr_march_forward -> tvr_app_h_forward -> tvr_mlp_train_forward(_ref) -> the compositing tail (tensorBase.py:520-527);
+ * tvr_train_backward = its gradient -> tvr_mlp_train_backward(_ref) -> the weight / bias gradients (tvr_gemm_tn, column sums) -> tvr_app_h_backward ->
+ *                      tvr_march_backward.
+ * Every kernel behind the march takes the number of appearance samples from the device (the queue counter in the forward scratch) and works in `work`,
+ * a caller-owned buffer of tvr_train_work_bytes(app_cap) sized for app_cap appearance samples — so the sequence of launches is fixed and the step can be
+ * captured in a hipGraph.  If a step's queue is longer than app_cap, word 3 of the scratch header (tvr_scratch_layout.counter) is set and the step's
+ * results are void: the caller reads that word where it reads the loss and repeats with a larger capacity.  The compositing sums run in a fixed order:
+ * the step is bit-reproducible (torch's index_add is not).
+ *   forward : rgb_map [n,3], depth [n]; pen_ray [n] (variant 1 only, else NULL) = per-ray sum_e w_e relu(-dot_e)^2, whose sum over rays is REFTensoRF's
+ *             normal penalty (REFTensoRF.py:236-239).
+ *   backward: grad_rgb_map [n,3], grad_pen_ray [n] or NULL -> gradients of every parameter: the VM factors through `vm_out` (all twelve), the network
+ *             through `mlp_out` (reference layouts; heads: variant 1 only).  `weights`: the CURRENT parameters (reference layout), packed by the call.
+ *             grad_scale_target: see tvr_mlp_train_backward's gscale (64 is the tested default); sat_flag_dev as there. */
+typedef struct { const float *W1, *W2, *W3, *basis; const float *heads_W[4]; } tvr_train_weights;   /* heads_W: normal, diffuse, specular, rho (variant 1) */
+typedef struct { float *W1, *b1, *W2, *b2, *W3, *b3, *basis; float *heads_W[4], *heads_b[4]; } tvr_train_mlp_grads;
+size_t tvr_train_work_bytes(const tvr_scene *scene, int64_t n_rays, int32_t n_samples, int64_t app_cap);
+int tvr_train_forward(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *jitter, float eps_T, int32_t white_bg,
+                      void *fwd_scratch, size_t fwd_scratch_bytes, void *work, size_t work_bytes, int64_t app_cap,
+                      float *rgb_map, float *depth, float *pen_ray, void *stream);
+int tvr_train_backward(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *jitter, float eps_T, int32_t white_bg,
+                       const void *fwd_scratch, size_t fwd_scratch_bytes, void *work, size_t work_bytes, int64_t app_cap, const tvr_train_weights *weights,
+                       const float *grad_rgb_map, const float *grad_pen_ray, float grad_scale_target, void *grad_scratch, size_t grad_scratch_bytes,
+                       const tvr_vm_grads *vm_out, const tvr_train_mlp_grads *mlp_out, uint32_t *sat_flag_dev, void *stream);
 
 /* C [Ka,Kb] = A^T B for tall-skinny fp32 operands A [M,Ka] (row stride lda), B [M,Kb] (row stride ldb): the weight gradients dW = dY^T X of
  * the training step's Linears (MLPRender_Fea's three layers tensorBase.py:69-71, basis_mat tensoRF.py:150) over the M appearance samples of

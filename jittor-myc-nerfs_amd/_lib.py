@@ -35,6 +35,15 @@ class VmGrads(C.Structure):
     _fields_ = [("density_plane", C.c_void_p * 3), ("density_line", C.c_void_p * 3), ("app_plane", C.c_void_p * 3), ("app_line", C.c_void_p * 3)]
 
 
+class TrainWeights(C.Structure):         # tvr_train_weights
+    _fields_ = [("W1", C.c_void_p), ("W2", C.c_void_p), ("W3", C.c_void_p), ("basis", C.c_void_p), ("heads_W", C.c_void_p * 4)]
+
+
+class TrainMlpGrads(C.Structure):        # tvr_train_mlp_grads
+    _fields_ = [("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("W3", C.c_void_p), ("b3", C.c_void_p), ("basis", C.c_void_p),
+                ("heads_W", C.c_void_p * 4), ("heads_b", C.c_void_p * 4)]
+
+
 class DenseOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("z", "valid", "bbox_valid", "cell", "sigma_feature", "sigma", "alpha",
                                           "weight", "rgb", "bg_weight", "acc", "t_min")]
@@ -104,6 +113,12 @@ SYMBOLS = {
     "tvr_mlp_train_forward_ref": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p, C.c_size_t] * 6 + [C.c_void_p]),
     "tvr_mlp_train_backward_ref": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(C.c_void_p * 4)] + [C.c_void_p] * 8 + [C.c_int64, C.c_void_p] + [C.c_void_p, C.c_size_t] * 6 +
                                    [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_train_work_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64]),
+    "tvr_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvr_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int64,
+                                     C.POINTER(TrainWeights), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.POINTER(VmGrads), C.POINTER(TrainMlpGrads),
+                                     C.c_void_p, C.c_void_p]),
     "tvr_gemm_tn_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     "tvr_gemm_tn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.c_void_p]),

@@ -382,3 +382,61 @@ class _RefMlpTrainFn(torch.autograd.Function):
         gb3, gb2, gb1, gbh = d_out[:, :3].sum(0), dh2.sum(0), dh1.sum(0), dg8.sum(0)
         # head rows: normal 0..2, specular 3, diffuse 4..6, rho 7 (rho's gradient is zero: `k = 1 / rho` is unused by MLPRender_Fea_Ref, REFTensoRF.py:18)
         return (None, dh, None, gB, gH[0:3], gbh[0:3], gH[4:7], gbh[4:7], gH[3:4], gbh[3:4], gH[7:8], gbh[7:8], gW1, gb1, gW2, gb2, gW3, gb3)
+
+
+class _FusedStepFn(torch.autograd.Function):
+    """TensorBase.execute / REFTensoRF.execute under autograd (train.py:225-261) as TWO C-ABI calls with no host read in between: tvr_train_forward
+    (march -> appearance gather -> basis / heads / MLP -> compositing) and tvr_train_backward (its gradient, weight gradients, scatter into the VM
+    factors, march backward).  Every kernel behind the march takes the number of appearance samples from the device; the buffers live in the model
+    (model._train_buffers: sized once for `app_cap` samples, reused every step), so the step is a fixed sequence of launches — hipGraph-capturable —
+    and, with fixed-order compositing sums, bit-reproducible.  Outputs: rgb_map [n,3], depth [n] (no gradient), pen_ray [n] (REFTensoRF: per-ray normal
+    penalty terms; zeros otherwise).  Parameter order: density planes 0..2, density lines 0..2, app planes, app lines, basis, W1, b1, W2, b2, W3, b3
+    (+ normal W b, diffuse W b, specular W b, rho W b)."""
+
+    @staticmethod
+    def forward(ctx, model, rays, jitter, S, eps_T, white_bg, *params):
+        lib = L.lib()
+        sc = model._ensure_scene(force=True)
+        n = rays.shape[0]
+        B = model._train_buffers(n, S)
+        ref = getattr(model, "_variant", 0) == 1
+        rgb_map = torch.empty((n, 3), dtype=torch.float32, device=model.device)
+        depth = torch.empty((n,), dtype=torch.float32, device=model.device)
+        pen = torch.zeros((n,), dtype=torch.float32, device=model.device)
+        L.check(lib.tvr_train_forward(sc, rays.data_ptr(), n, S, None if jitter is None else jitter.data_ptr(), float(eps_T), int(bool(white_bg)),
+                                      B["scratch"].data_ptr(), B["scratch"].numel(), B["work"].data_ptr(), B["work"].numel(), B["cap"], rgb_map.data_ptr(),
+                                      depth.data_ptr(), pen.data_ptr() if ref else None, _stream_ptr(model.device)), "tvr_train_forward")
+        ctx.model, ctx.rays, ctx.jitter, ctx.S, ctx.eps_T, ctx.white_bg, ctx.buf, ctx.ref = model, rays, jitter, S, eps_T, white_bg, B, ref
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(*params[12:])                 # the network parameters: their CURRENT values are packed by the backward call
+        ctx.mark_non_differentiable(depth)
+        return rgb_map, depth, pen
+
+    @staticmethod
+    def backward(ctx, g_map, _gd, g_pen):
+        model, lib, B = ctx.model, L.lib(), ctx.buf
+        sc = model._ensure_scene()
+        net = [t.detach().contiguous().float() for t in ctx.saved_tensors]
+        dev, n = model.device, ctx.rays.shape[0]
+        grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes]
+        vm = L.VmGrads()
+        for i in range(3):
+            vm.density_plane[i], vm.density_line[i] = grads[i].data_ptr(), grads[3 + i].data_ptr()
+            vm.app_plane[i], vm.app_line[i] = grads[6 + i].data_ptr(), grads[9 + i].data_ptr()
+        wt, mg = L.TrainWeights(), L.TrainMlpGrads()
+        wt.basis, wt.W1, wt.W2, wt.W3 = net[0].data_ptr(), net[1].data_ptr(), net[3].data_ptr(), net[5].data_ptr()
+        g = grads[12:]
+        mg.basis, mg.W1, mg.b1, mg.W2, mg.b2, mg.W3, mg.b3 = (t.data_ptr() for t in g[:7])
+        if ctx.ref:                                         # params 19..26: normal W b, diffuse W b, specular W b, rho W b
+            for i in range(4):
+                wt.heads_W[i] = net[7 + 2 * i].data_ptr()
+                mg.heads_W[i], mg.heads_b[i] = g[7 + 2 * i].data_ptr(), g[8 + 2 * i].data_ptr()
+        g_map = torch.zeros((n, 3), device=dev) if g_map is None else g_map.contiguous().float()
+        g_pen = None if (g_pen is None or not ctx.ref) else g_pen.contiguous().float()
+        gs = model._get_grad_scratch()
+        L.check(lib.tvr_train_backward(sc, ctx.rays.data_ptr(), n, ctx.S, None if ctx.jitter is None else ctx.jitter.data_ptr(), float(ctx.eps_T), int(bool(ctx.white_bg)),
+                                       B["scratch"].data_ptr(), B["scratch"].numel(), B["work"].data_ptr(), B["work"].numel(), B["cap"], C.byref(wt), g_map.data_ptr(),
+                                       None if g_pen is None else g_pen.data_ptr(), float(model.grad_scale_target), gs.data_ptr(), gs.numel(), C.byref(vm), C.byref(mg),
+                                       model._get_sat_flag().data_ptr(), _stream_ptr(dev)), "tvr_train_backward")
+        model._sig = None
+        return (None, None, None, None, None, None, *grads)

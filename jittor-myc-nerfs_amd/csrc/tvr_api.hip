@@ -601,15 +601,16 @@ int tvr_mlp_train_backward_ref(const float *W1, const float *W2, const float *W3
         return fail(TVR_ERR_INVALID, "activation / gradient matrices must be 16-byte aligned");
     HIP_TRY(launch_pack_train_image(W1, W2, W3, basis, heads_W, image, (hipStream_t)stream));
     MlpRefBwd rb;
-    rb.g8 = g8; rb.viewdirs = viewdirs; rb.grad_in0 = grad_in0; rb.dg8 = dg8;
+    rb.g8 = g8; rb.viewdirs = viewdirs; rb.grad_in0 = grad_in0; rb.dg8 = dg8; rb.rays = nullptr; rb.q_ray = nullptr;
     HIP_TRY(launch_mlp_train_backward(grad_rgb, rgb_s, feats32, h1, h2, m, gscale_dev, d_out4, dh2, dh1, dfeats32, dh, sat_flag_dev, image, &rb, (hipStream_t)stream));
     return TVR_OK;
 }
 
-int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *dh, size_t dh_bytes, void *grad_scratch, size_t grad_scratch_bytes,
-                       const tvr_vm_grads *out, void *stream_)
+}  // extern "C"
+
+static int app_h_backward_impl(tvr_scene *s, const float *xyz, int xyz_stride, int64_t m, const unsigned *m_dev, const float *dh, void *grad_scratch,
+                               size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream_)
 {
-    if (m > 0) NEED("dh [m,144]", dh_bytes, m, TVR_KAPP);
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
     if (!grad_scratch || !out || m < 0 || (m > 0 && (!xyz || !dh))) return fail(TVR_ERR_INVALID, "NULL argument");
@@ -622,7 +623,7 @@ int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *d
         HIP_TRY(hipMemsetAsync(tg.aplane[i], 0, (H + 1) * (W + 1) * TVR_CA * sizeof(float), stream));
         HIP_TRY(hipMemsetAsync(tg.aline[i], 0, (Ln + 1) * TVR_CA * sizeof(float), stream));
     }
-    if (m > 0) HIP_TRY(launch_app_h_backward(s->dev, xyz, m, dh, tg, stream));
+    if (m > 0) HIP_TRY(launch_app_h_backward(s->dev, xyz, m, dh, tg, stream, xyz_stride, m_dev));
     for (int i = 0; i < 3; ++i) {
         if (!out->app_plane[i] || !out->app_line[i]) return fail(TVR_ERR_INVALID, "appearance gradient pointer %d is NULL", i);
         const int W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
@@ -630,6 +631,160 @@ int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *d
         HIP_TRY(launch_unpack_grad(tg.aline[i], out->app_line[i], s->desc.app_n_comp[i], TVR_CA, Ln, 1, stream));
     }
     return TVR_OK;
+}
+
+// ---- the training step without a host read (include/tvr.h: tvr_train_forward / tvr_train_backward) ----
+struct WorkLayout {
+    size_t h, feats32, h1, h2, rgb, g8, rgb_s, pre, grgb, gin0, grad_w, grad_acc, d_out4, dh2, dh1, dfeats32, dg8, dh, X, tmp, gemm, colsum, image, scalars, total;
+};
+static WorkLayout work_layout(int64_t n_rays, int32_t S, int64_t cap)
+{
+    WorkLayout L;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
+    const size_t c = (size_t)cap, n = (size_t)n_rays;
+    L.h = take(c * TVR_KAPP); L.feats32 = take(c * 32); L.h1 = take(c * TVR_FEATC); L.h2 = take(c * TVR_FEATC); L.rgb = take(c * 3);
+    L.g8 = take(c * 8); L.rgb_s = take(c * 3); L.pre = take(n * 3);
+    L.grgb = take(c * 3); L.gin0 = take(c); L.grad_w = take(n * (size_t)S); L.grad_acc = take(n);
+    L.d_out4 = take(c * 4); L.dh2 = take(c * TVR_FEATC); L.dh1 = take(c * TVR_FEATC); L.dfeats32 = take(c * 32); L.dg8 = take(c * 8); L.dh = take(c * TVR_KAPP);
+    L.X = take(c * TVR_NIN_REF);
+    L.tmp = take(32 * TVR_KAPP + 128);                        // gemm_tn results that are wider than the gradient they feed ([4,128], [32,144], [8,144]) and bias sums
+    size_t g = gemm_tn_scratch_bytes(TVR_FEATC, TVR_NIN_REF, cap);
+    L.gemm = take(g / sizeof(float) + 64);
+    L.colsum = take(colsum_scratch_bytes() / sizeof(float));
+    L.image = take(mlp_train_image_bytes() / sizeof(float) + 64);
+    L.scalars = take(64);                                     // [0] max |gradient| bits, [1] gscale
+    L.total = off;
+    return L;
+}
+
+static int train_args_ok(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const void *fwd_scratch, size_t fwd_bytes, const void *work, size_t work_bytes,
+                         int64_t app_cap)
+{
+    int rc = scene_ready(s);
+    if (rc != TVR_OK) return rc;
+    const tvr_scene_desc &d = s->desc;
+    bool std_shape = d.featureC == TVR_FEATC && d.view_pe == 2 && d.fea_pe == 2;
+    for (int i = 0; i < 3; ++i) std_shape = std_shape && d.app_n_comp[i] == TVR_CA;
+    if (!std_shape) return fail(TVR_ERR_UNSUPPORTED, "the fused training step takes 48 appearance components, featureC 128, view_pe = fea_pe = 2");
+    if (!rays || n_rays <= 0 || S <= 0 || S > 4096 || app_cap <= 0) return fail(TVR_ERR_INVALID, "rays NULL, or n_rays / n_samples / app_cap out of range");
+    if ((size_t)n_rays * (size_t)S >= (1ull << 32) || (uint64_t)app_cap * 576u >= (1ull << 32)) return fail(TVR_ERR_INVALID, "n_rays * n_samples and app_cap * 576 must be < 2^32");
+    if (!fwd_scratch || fwd_bytes < scratch_layout(n_rays, S).total || (uintptr_t)fwd_scratch % 256) return fail(TVR_ERR_SCRATCH, "forward scratch too small or misaligned");
+    if (!work || work_bytes < work_layout(n_rays, S, app_cap).total || (uintptr_t)work % 256) return fail(TVR_ERR_SCRATCH, "training workspace too small (tvr_train_work_bytes) or misaligned");
+    return TVR_OK;
+}
+
+extern "C" {
+
+size_t tvr_train_work_bytes(const tvr_scene *s, int64_t n_rays, int32_t n_samples, int64_t app_cap)
+{
+    (void)s;
+    if (n_rays <= 0 || n_samples <= 0 || app_cap <= 0) return 0;
+    return work_layout(n_rays, n_samples, app_cap).total;
+}
+
+int tvr_train_forward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *jitter, float eps_T, int32_t white_bg, void *fwd_scratch,
+                      size_t fwd_bytes, void *work, size_t work_bytes, int64_t app_cap, float *rgb_map, float *depth, float *pen_ray, void *stream_)
+{
+    int rc = train_args_ok(s, rays, n_rays, S, fwd_scratch, fwd_bytes, work, work_bytes, app_cap);
+    if (rc != TVR_OK) return rc;
+    const bool ref = s->desc.variant == 1;
+    if (!rgb_map || !depth || (ref && !pen_ray)) return fail(TVR_ERR_INVALID, "rgb_map / depth (/ pen_ray for a REFTensoRF scene) is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    const MarchSampling sm = {jitter, nullptr};
+    rc = march_forward_impl(s, rays, n_rays, S, sm, eps_T, depth, nullptr, fwd_scratch, fwd_bytes, stream_);
+    if (rc != TVR_OK) return rc;
+    const ScratchLayout SL = scratch_layout(n_rays, S);
+    const MarchOut mo = carve_scratch((char *)fwd_scratch, SL, depth);
+    const WorkLayout W = work_layout(n_rays, S, app_cap);
+    char *w = (char *)work;
+    HIP_TRY(launch_app_h_forward(s->dev, (const float *)mo.q_pos, app_cap, (float *)(w + W.h), stream, 4, mo.counter));
+    ShadeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.n = app_cap; sa.counter = mo.counter; sa.h_in = (const float *)(w + W.h); sa.q_ray = mo.q_ray; sa.rays = rays;
+    sa.out = (float *)(w + W.rgb); sa.t_feats = (float *)(w + W.feats32); sa.t_h1 = (float *)(w + W.h1); sa.t_h2 = (float *)(w + W.h2);
+    sa.t_g8 = (float *)(w + W.g8); sa.t_rgbs = (float *)(w + W.rgb_s);
+    HIP_TRY(launch_shade(s->dev, SH_SRC_H, SH_DST_TRAIN, sa, stream));
+    HIP_TRY(launch_composite_train_forward(mo, (int)n_rays, app_cap, white_bg, (const float *)(w + W.rgb), (const float *)(w + W.feats32), ref ? 1 : 0, rgb_map,
+                                           (float *)(w + W.pre), pen_ray, stream));
+    return TVR_OK;
+}
+
+int tvr_train_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *jitter, float eps_T, int32_t white_bg, const void *fwd_scratch,
+                       size_t fwd_bytes, void *work, size_t work_bytes, int64_t app_cap, const tvr_train_weights *wt, const float *grad_rgb_map,
+                       const float *grad_pen_ray, float grad_scale_target, void *grad_scratch, size_t grad_scratch_bytes, const tvr_vm_grads *vm_out,
+                       const tvr_train_mlp_grads *mo_, uint32_t *sat_flag_dev, void *stream_)
+{
+    int rc = train_args_ok(s, rays, n_rays, S, fwd_scratch, fwd_bytes, work, work_bytes, app_cap);
+    if (rc != TVR_OK) return rc;
+    const bool ref = s->desc.variant == 1;
+    if (!wt || !wt->W1 || !wt->W2 || !wt->W3 || !wt->basis || !grad_rgb_map || !vm_out || !mo_ || !(grad_scale_target > 0.0f)) return fail(TVR_ERR_INVALID, "NULL argument or grad_scale_target <= 0");
+    if (!mo_->W1 || !mo_->b1 || !mo_->W2 || !mo_->b2 || !mo_->W3 || !mo_->b3 || !mo_->basis) return fail(TVR_ERR_INVALID, "a network gradient pointer is NULL");
+    if (ref)
+        for (int i = 0; i < 4; ++i)
+            if (!wt->heads_W[i] || !mo_->heads_W[i] || !mo_->heads_b[i]) return fail(TVR_ERR_INVALID, "REFTensoRF head %d (normal, diffuse, specular, rho): weight or gradient pointer is NULL", i);
+    hipStream_t stream = (hipStream_t)stream_;
+    const ScratchLayout SL = scratch_layout(n_rays, S);
+    const MarchOut mo = carve_scratch((char *)fwd_scratch, SL, nullptr);
+    const WorkLayout W = work_layout(n_rays, S, app_cap);
+    char *w = (char *)work;
+    auto F = [&](size_t off) { return (float *)(w + off); };
+    unsigned *amax = (unsigned *)(w + W.scalars);
+    float *gscale = (float *)(w + W.scalars) + 1;
+    const unsigned *mdev = mo.counter;
+    const int nin = ref ? TVR_NIN_REF : TVR_NIN;
+    // 1. compositing backward: gradients of the per-sample colours, of the weights and of acc; the scale of the fused backward
+    HIP_TRY(launch_composite_train_backward(mo, (int)n_rays, app_cap, white_bg, F(W.rgb), F(W.feats32), ref ? F(W.g8) : nullptr, F(W.pre), grad_rgb_map, ref ? grad_pen_ray : nullptr,
+                                            F(W.grgb), F(W.gin0), F(W.grad_w), F(W.grad_acc), amax, grad_scale_target, gscale, stream));
+    // 2. the network backward (register-resident MFMA chains), dh through basis_mat (and the heads)
+    HIP_TRY(launch_pack_train_image(wt->W1, wt->W2, wt->W3, wt->basis, ref ? wt->heads_W : nullptr, w + W.image, stream));
+    MlpRefBwd rb;
+    rb.g8 = F(W.g8); rb.viewdirs = nullptr; rb.grad_in0 = F(W.gin0); rb.dg8 = F(W.dg8); rb.rays = rays; rb.q_ray = mo.q_ray;
+    HIP_TRY(launch_mlp_train_backward(F(W.grgb), ref ? F(W.rgb_s) : F(W.rgb), F(W.feats32), F(W.h1), F(W.h2), app_cap, gscale, F(W.d_out4), F(W.dh2), F(W.dh1), F(W.dfeats32),
+                                      F(W.dh), sat_flag_dev, w + W.image, ref ? &rb : nullptr, stream, mdev));
+    // 3. weight gradients: dW = dY^T X over the step's appearance samples (tall-skinny reductions, fixed order), bias gradients = column sums
+    if (ref) HIP_TRY(launch_pe_concat_strided(F(W.feats32), 32, F(W.feats32) + 27, 32, nullptr, nullptr, F(W.feats32) + 30, 32, app_cap, mdev, F(W.X), stream));
+    else HIP_TRY(launch_pe_concat_strided(F(W.feats32), 32, nullptr, 0, rays, mo.q_ray, nullptr, 0, app_cap, mdev, F(W.X), stream));
+    float *tmp = F(W.tmp), *gsc = F(W.gemm), *csc = F(W.colsum);
+    HIP_TRY(launch_gemm_tn(F(W.d_out4), 4, 4, F(W.h2), TVR_FEATC, TVR_FEATC, app_cap, tmp, gsc, stream, mdev));
+    HIP_TRY(hipMemcpyAsync(mo_->W3, tmp, 3 * TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(launch_gemm_tn(F(W.dh2), TVR_FEATC, TVR_FEATC, F(W.h1), TVR_FEATC, TVR_FEATC, app_cap, mo_->W2, gsc, stream, mdev));
+    HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X), nin, nin, app_cap, mo_->W1, gsc, stream, mdev));
+    HIP_TRY(launch_gemm_tn(F(W.dfeats32), 32, 32, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev));
+    HIP_TRY(hipMemcpyAsync(mo_->basis, tmp, TVR_APPDIM * TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (ref) {
+        HIP_TRY(launch_gemm_tn(F(W.dg8), 8, 8, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev));      // rows: normal 0..2, specular 3, diffuse 4..6, rho 7
+        HIP_TRY(hipMemcpyAsync(mo_->heads_W[0], tmp, 3 * TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(mo_->heads_W[2], tmp + 3 * TVR_KAPP, TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(mo_->heads_W[1], tmp + 4 * TVR_KAPP, 3 * TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(mo_->heads_W[3], tmp + 7 * TVR_KAPP, TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        float *bs = tmp + 32 * TVR_KAPP;
+        HIP_TRY(launch_colsum(F(W.dg8), 8, 8, app_cap, mdev, bs, csc, stream));
+        HIP_TRY(hipMemcpyAsync(mo_->heads_b[0], bs, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(mo_->heads_b[2], bs + 3, sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(mo_->heads_b[1], bs + 4, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(mo_->heads_b[3], bs + 7, sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    {
+        float *bs = tmp + 32 * TVR_KAPP + 16;
+        HIP_TRY(launch_colsum(F(W.d_out4), 4, 4, app_cap, mdev, bs, csc, stream));
+        HIP_TRY(hipMemcpyAsync(mo_->b3, bs, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(launch_colsum(F(W.dh2), TVR_FEATC, TVR_FEATC, app_cap, mdev, mo_->b2, csc, stream));
+        HIP_TRY(launch_colsum(F(W.dh1), TVR_FEATC, TVR_FEATC, app_cap, mdev, mo_->b1, csc, stream));
+    }
+    // 4. scatter dh into the appearance planes / lines, then the march backward for the density factors
+    rc = app_h_backward_impl(s, (const float *)mo.q_pos, 4, app_cap, mdev, F(W.dh), grad_scratch, grad_scratch_bytes, vm_out, stream_);
+    if (rc != TVR_OK) return rc;
+    const MarchSampling sm = {jitter, nullptr};
+    return march_backward_impl(s, rays, n_rays, S, sm, eps_T, fwd_scratch, fwd_bytes, F(W.grad_w), F(W.grad_acc), nullptr, nullptr, grad_scratch, grad_scratch_bytes, vm_out,
+                               stream_);
+}
+
+int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *dh, size_t dh_bytes, void *grad_scratch, size_t grad_scratch_bytes,
+                       const tvr_vm_grads *out, void *stream_)
+{
+    if (m > 0) NEED("dh [m,144]", dh_bytes, m, TVR_KAPP);
+    return app_h_backward_impl(s, xyz, 3, m, nullptr, dh, grad_scratch, grad_scratch_bytes, out, stream_);
 }
 
 int tvr_pe_concat(const float *features, const float *viewdirs, const float *dot_product, int64_t m, float *X, size_t X_bytes, void *stream)

@@ -19,8 +19,15 @@
 
 __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__restrict__ A, const int lda, const int Ka,
                                                                  const float *__restrict__ B, const int ldb, const int Kb,
-                                                                 const long long M, float *__restrict__ P, const long long rows_per_block)
+                                                                 const long long M_cap, float *__restrict__ P, const long long rpb_host, const unsigned *__restrict__ m_dev)
 {
+    // m_dev: the row count lives on the device (M_cap = capacity, the grid is sized for it); the slabs are then cut from the true count here
+    const long long M = m_dev ? ((long long)*m_dev < M_cap ? (long long)*m_dev : M_cap) : M_cap;
+    long long rows_per_block = rpb_host;
+    if (m_dev) {
+        rows_per_block = ((M + (long long)gridDim.x - 1) / (long long)gridDim.x + 15) / 16 * 16;
+        if (rows_per_block < 64) rows_per_block = 64;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, k = lane >> 5;
     const int nrb = (Ka + 31) >> 5, ncb = (Kb + 31) >> 5, ntiles = nrb * ncb;
@@ -36,7 +43,7 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
         acc[q] = f32x16{0};
     }
     const long long m0 = (long long)blockIdx.x * rows_per_block;
-    const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    const long long m1 = m0 >= M ? m0 : (m0 + rows_per_block < M ? m0 + rows_per_block : M);
     // software pipeline: the operands of the next 8 rows are in flight while the MFMAs of the current 8 run
     float a[TG_UNROLL][TG_MAXT], b[TG_UNROLL][TG_MAXT];
     auto fetch = [&](long long m, float (&fa)[TG_UNROLL][TG_MAXT], float (&fb)[TG_UNROLL][TG_MAXT]) {
@@ -105,8 +112,15 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
 template <bool VEC4>
 __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float *__restrict__ A, const int lda, const int Ka,
                                                                      const float *__restrict__ B, const int ldb, const int Kb,
-                                                                     const long long M, float *__restrict__ P, const long long rows_per_block)
+                                                                     const long long M_cap, float *__restrict__ P, const long long rpb_host, const unsigned *__restrict__ m_dev)
 {
+    // m_dev: the row count lives on the device (M_cap = capacity, the grid is sized for it); the slabs are then cut from the true count here
+    const long long M = m_dev ? ((long long)*m_dev < M_cap ? (long long)*m_dev : M_cap) : M_cap;
+    long long rows_per_block = rpb_host;
+    if (m_dev) {
+        rows_per_block = ((M + (long long)gridDim.x - 1) / (long long)gridDim.x + 15) / 16 * 16;
+        if (rows_per_block < 64) rows_per_block = 64;
+    }
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, k = lane >> 5;
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
         acc[q] = f32x16{0};
     }
     const long long m0 = (long long)blockIdx.x * rows_per_block;
-    const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    const long long m1 = m0 >= M ? m0 : (m0 + rows_per_block < M ? m0 + rows_per_block : M);
     // chunk [m, m + TL_ROWS) -> registers: element e of the chunk's A floats (row-major, Ka per row) followed by its B floats; rows >= m1 read as zero
     constexpr int NPRE = VEC4 ? 4 * ((TL_PF + 3) / 4) : TL_PF;
     float preA[NPRE];                                                  // (prefetch distance 2 with a second register set measured slower: 0.32 vs 0.23 ms)
@@ -283,8 +297,15 @@ __device__ __forceinline__ Rows8 fetch8(const float *__restrict__ X, int ld, int
 
 __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_f16_kernel(const float *__restrict__ A, const int lda, const int Ka,
                                                                      const float *__restrict__ B, const int ldb, const int Kb,
-                                                                     const long long M, float *__restrict__ P, const long long rows_per_block)
+                                                                     const long long M_cap, float *__restrict__ P, const long long rpb_host, const unsigned *__restrict__ m_dev)
 {
+    // m_dev: the row count lives on the device (M_cap = capacity, the grid is sized for it); the slabs are then cut from the true count here
+    const long long M = m_dev ? ((long long)*m_dev < M_cap ? (long long)*m_dev : M_cap) : M_cap;
+    long long rows_per_block = rpb_host;
+    if (m_dev) {
+        rows_per_block = ((M + (long long)gridDim.x - 1) / (long long)gridDim.x + 15) / 16 * 16;
+        if (rows_per_block < 64) rows_per_block = 64;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int nrb = (Ka + 31) >> 5, ncb = (Kb + 31) >> 5;
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_f16_kernel(const float 
         acc[q] = f32x16{0};
     }
     const long long m0 = (long long)blockIdx.x * rows_per_block;
-    const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    const long long m1 = m0 >= M ? m0 : (m0 + rows_per_block < M ? m0 + rows_per_block : M);
     if (active) {
         Rows8 ro = fetch8(Xo, ldo, col_o, m0, m1, h), rw[TG_MAXT];
 #pragma unroll
@@ -393,7 +414,8 @@ size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M)
     return (size_t)(grid > 0 ? grid : 1) * Ka * Kb * sizeof(float);
 }
 
-hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream)
+hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream,
+                          const unsigned *m_dev)
 {
     long long grid, rpb;
     gemm_tn_shape(M, grid, rpb);
@@ -405,14 +427,14 @@ hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int l
         const int lds2 = 2 * ((TL_ROWS * (Ka + Kb) + 3) & ~3) * (int)sizeof(float);       // <= 40 KB
         // 16-B loads need contiguous rows (a chunk is then one flat run of floats) and 16-B aligned chunk starts (TL_ROWS * K * 4 B is)
         const bool vec4 = lda == Ka && ldb == Kb && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
-        if (vec4) hipLaunchKernelGGL((gemm_tn_lds_kernel<true>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb);
-        else hipLaunchKernelGGL((gemm_tn_lds_kernel<false>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb);
+        if (vec4) hipLaunchKernelGGL((gemm_tn_lds_kernel<true>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
+        else hipLaunchKernelGGL((gemm_tn_lds_kernel<false>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
     } else if (TVR_GEMM_F32) {
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
     } else {
         rc = hipFuncSetAttribute((const void *)gemm_tn_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (rc != hipSuccess) return rc;
-        hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb);
+        hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
     }
     const int n = Ka * Kb;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, scratch, (int)grid, n, C);

@@ -75,21 +75,36 @@ hipError_t launch_pack_ref(const float *const W[4], const float *const b[4], voi
 hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T, const MarchOut &mo,
                                  const float *grad_w, const float *grad_acc, const float *lam6, const float *grad_lam6, const TrainGrads &tg,
                                  hipStream_t stream);
-hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream);
-hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream);
+// xyz_stride: 3 (xyz [m,3]) or 4 (the march queue's {xyz, w}); m_dev: optional device-side entry count, m is then the capacity (min of the two is processed)
+hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream, int xyz_stride = 3, const unsigned *m_dev = nullptr);
+hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream, int xyz_stride = 3,
+                                 const unsigned *m_dev = nullptr);
 hipError_t launch_unpack_grad(const float *in, float *out, int Cout, int C, int H, int W, hipStream_t stream);
-hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream);
+// m_dev: optional device-side row count; M is then the capacity (the grid is sized for it, the slabs are cut from min(*m_dev, M) on the device)
+hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream,
+                          const unsigned *m_dev = nullptr);
 size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M);
 hipError_t launch_pe_concat(const float *feat, const float *dir, const float *dot, long long m, float *X, hipStream_t stream);
+hipError_t launch_pe_concat_strided(const float *feat, int fs, const float *dir, int ds, const float *rays, const unsigned *q_ray, const float *dot, int dts,
+                                    long long m_cap, const unsigned *m_dev, float *X, hipStream_t stream);
 hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const float *gX, long long m, int with_dot, float *gfeat, float *gdir,
                                      float *gdot, hipStream_t stream);
 size_t mlp_train_image_bytes();
 // heads: REFTensoRF's {normal [3,144], diffuse [3,144], specular [1,144], rho [1,144]} weights, or nullptr (TensorVMSplit)
 hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream);
 // REFTensoRF's additions to the backward: raw head outputs, view directions, optional gradient of the -dot output; dg8 [m,8] is written
-struct MlpRefBwd { const float *g8, *viewdirs, *grad_in0; float *dg8; };
+struct MlpRefBwd { const float *g8, *viewdirs, *grad_in0; float *dg8; const float *rays; const unsigned *q_ray; };   // q_ray set: the direction of entry e is rays[q_ray[e]][3..5]
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
                                      float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, const MlpRefBwd *ref,
-                                     hipStream_t stream);
+                                     hipStream_t stream, const unsigned *m_dev = nullptr);
 hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, float *value, float *grad, float *part, hipStream_t stream);
 hipError_t launch_alpha_bits(const float *vol, long long n, unsigned *bits, hipStream_t stream);
+
+// tvr_step.hip: the training step's compositing tail (forward / backward over the queue, device-side counts), gradient scale, column sums
+hipError_t launch_composite_train_forward(const MarchOut &mo, int n_rays, long long cap, int white_bg, const float *rgb, const float *feats32, int with_pen, float *rgb_map,
+                                          float *pre, float *pen_ray, hipStream_t stream);
+hipError_t launch_composite_train_backward(const MarchOut &mo, int n_rays, long long cap, int white_bg, const float *rgb, const float *feats32, const float *g8, const float *pre,
+                                           const float *g_map, const float *g_pen, float *grgb, float *gin0, float *grad_w, float *grad_acc, unsigned *amax_bits,
+                                           float target, float *gscale, hipStream_t stream);
+size_t colsum_scratch_bytes();
+hipError_t launch_colsum(const float *A, int lda, int K, long long m_cap, const unsigned *m_dev, float *out, float *scratch, hipStream_t stream);

@@ -117,7 +117,8 @@ __device__ __forceinline__ void mfma3xn(const AFragN &A, const Frag &b, f32x16 a
 
 struct MlpBwdArgs {
     const float *grad_rgb, *rgb, *feats, *h1, *h2;   // [m,3], [m,3], [m,32], [m,128], [m,128]
-    long long m;
+    long long m;                                     // entries, or the buffers' capacity when m_dev is set
+    const unsigned *m_dev;                           // optional device-side entry count
     const float *gscale;                             // device scalar: gradients are multiplied by this power of two on entry, by its inverse on exit
     float *d_out, *dh2, *dh1, *dfeats;               // [m,4], [m,128], [m,128], [m,32]
     const unsigned char *image;                      // TI_BYTES
@@ -140,13 +141,14 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
         for (int i = tid; i < TI_LDS_BYTES / 16; i += MT_THREADS) ((uint4 *)smem)[i] = src[i];
         __syncthreads();
     }
-    const long long n_tiles = (a.m + 31) / 32;
+    const long long a_m = a.m_dev ? ((long long)*a.m_dev < a.m ? (long long)*a.m_dev : a.m) : a.m;
+    const long long n_tiles = (a_m + 31) / 32;
     const float gscale = *a.gscale, inv_scale = 1.0f / gscale;
     float amax = 0.0f;                               // largest |operand| this lane split to fp16 (v_cvt_pkrtz saturates at 65 504 silently)
     for (long long tile = (long long)blockIdx.x * MT_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * MT_WAVES) {
         const long long ent = tile * 32 + e;
-        const bool live = ent < a.m;
-        const long long le = live ? ent : a.m - 1;
+        const bool live = ent < a_m;
+        const long long le = live ? ent : a_m - 1;
         // ---------------------------------------------------------------- loads (all of this tile's) ----
         float g[3], o[3];
 #pragma unroll
@@ -323,9 +325,11 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
 //   d dot = 2 nh.d_refl - d_in0 ;  d nh = 2 dot d_refl + d_dot d ;  d n = (d nh - nh (nh.d nh)) / |n|
 //   d tint_raw = [tint_raw > 0] sum_c grad_rgb_c rgb_s_c ;  d rgb_d = grad_rgb ;  d rho = 0                          (REFTensoRF.py:232)
 __global__ __launch_bounds__(256) void ref_heads_backward_kernel(const float *__restrict__ grad_rgb, const float *__restrict__ rgb_s, const float *__restrict__ g8,
-                                                                 const float *__restrict__ viewdirs, const float *__restrict__ dfeats, const float *__restrict__ grad_in0,
-                                                                 const long long m, float *__restrict__ dg8)
+                                                                 const float *__restrict__ viewdirs, const float *__restrict__ rays, const unsigned *__restrict__ q_ray,
+                                                                 const float *__restrict__ dfeats, const float *__restrict__ grad_in0, const long long m_cap,
+                                                                 const unsigned *__restrict__ m_dev, float *__restrict__ dg8)
 {
+    const long long m = m_dev ? ((long long)*m_dev < m_cap ? (long long)*m_dev : m_cap) : m_cap;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const float4 ga = *(const float4 *)(g8 + i * 8), gb = *(const float4 *)(g8 + i * 8 + 4);
@@ -333,7 +337,8 @@ __global__ __launch_bounds__(256) void ref_heads_backward_kernel(const float *__
     const float nn = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
     const float nrm = sqrtf(fmaxf(nn, 1e-30f));
     const float nh[3] = {n[0] / nrm, n[1] / nrm, n[2] / nrm};
-    const float d[3] = {-viewdirs[i * 3], -viewdirs[i * 3 + 1], -viewdirs[i * 3 + 2]};
+    const float *vp = q_ray ? rays + (size_t)q_ray[i] * 6 + 3 : viewdirs + i * 3;
+    const float d[3] = {-vp[0], -vp[1], -vp[2]};
     const float dot = (d[0] * nh[0] + d[1] * nh[1]) + d[2] * nh[2];
     const float dr[3] = {dfeats[i * 32 + 27], dfeats[i * 32 + 28], dfeats[i * 32 + 29]};
     const float din0 = dfeats[i * 32 + 30] + (grad_in0 ? grad_in0[i] : 0.0f);
@@ -360,9 +365,10 @@ __global__ __launch_bounds__(256) void ref_heads_backward_kernel(const float *__
 // dh^T [144 x 32e] = Bas^T [144 x 32] dF^T [32 x 32e]  (gscale as above; dF is stored unscaled).  KS = 3 (REFTensoRF): a third k-step adds
 // Heads^T [144 x 8] dG^T, the gradient through normal / tint / rgb_d (k 32..35 = dg8[0..3] in lane half 0, k 36..39 = dg8[4..7] in lane half 1).
 template <int KS>
-__global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__restrict__ dfeats, const float *__restrict__ dg8, long long m, const float *__restrict__ gscale_p,
-                                                                const unsigned char *__restrict__ image, float *__restrict__ dh, unsigned *sat)
+__global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__restrict__ dfeats, const float *__restrict__ dg8, long long m_cap, const unsigned *__restrict__ m_dev,
+                                                                const float *__restrict__ gscale_p, const unsigned char *__restrict__ image, float *__restrict__ dh, unsigned *sat)
 {
+    const long long m = m_dev ? ((long long)*m_dev < m_cap ? (long long)*m_dev : m_cap) : m_cap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = lane & 31, h = lane >> 5;
     const long long n_tiles = (m + 31) / 32;
@@ -442,13 +448,13 @@ hipError_t launch_pack_train_image(const float *W1, const float *W2, const float
 
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
                                      float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, const MlpRefBwd *ref,
-                                     hipStream_t stream)
+                                     hipStream_t stream, const unsigned *m_dev)
 {
     hipError_t rc = hipFuncSetAttribute(ref ? (const void *)mlp_train_backward_kernel<true> : (const void *)mlp_train_backward_kernel<false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, TI_LDS_BYTES);
     if (rc != hipSuccess) return rc;
     MlpBwdArgs a;
-    a.grad_rgb = grad_rgb; a.rgb = rgb; a.feats = feats; a.h1 = h1; a.h2 = h2; a.m = m; a.gscale = gscale;
+    a.grad_rgb = grad_rgb; a.rgb = rgb; a.feats = feats; a.h1 = h1; a.h2 = h2; a.m = m; a.m_dev = m_dev; a.gscale = gscale;
     a.d_out = d_out; a.dh2 = dh2; a.dh1 = dh1; a.dfeats = dfeats; a.image = (const unsigned char *)image; a.sat = sat_flag;
     a.g8 = ref ? ref->g8 : nullptr;
     const long long groups = (m + 32 * MT_WAVES - 1) / (32 * MT_WAVES);
@@ -460,13 +466,13 @@ hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, co
     const long long g2 = (m + 127) / 128;
     const unsigned grid2 = (unsigned)(g2 < 1024 ? (g2 > 0 ? g2 : 1) : 1024);
     if (ref) {
-        hipLaunchKernelGGL(ref_heads_backward_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, grad_rgb, rgb, ref->g8, ref->viewdirs, dfeats, ref->grad_in0, m,
-                           ref->dg8);
+        hipLaunchKernelGGL(ref_heads_backward_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, grad_rgb, rgb, ref->g8, ref->viewdirs, ref->rays, ref->q_ray,
+                           dfeats, ref->grad_in0, m, m_dev, ref->dg8);
         rc = hipGetLastError();
         if (rc != hipSuccess) return rc;
-        hipLaunchKernelGGL(basis_backward_kernel<3>, dim3(grid2), dim3(256), 0, stream, dfeats, ref->dg8, m, gscale, (const unsigned char *)image, dh, sat_flag);
+        hipLaunchKernelGGL(basis_backward_kernel<3>, dim3(grid2), dim3(256), 0, stream, dfeats, ref->dg8, m, m_dev, gscale, (const unsigned char *)image, dh, sat_flag);
     } else {
-        hipLaunchKernelGGL(basis_backward_kernel<2>, dim3(grid2), dim3(256), 0, stream, dfeats, (const float *)nullptr, m, gscale, (const unsigned char *)image, dh, sat_flag);
+        hipLaunchKernelGGL(basis_backward_kernel<2>, dim3(grid2), dim3(256), 0, stream, dfeats, (const float *)nullptr, m, m_dev, gscale, (const unsigned char *)image, dh, sat_flag);
     }
     return hipGetLastError();
 }

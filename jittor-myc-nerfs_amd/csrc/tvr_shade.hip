@@ -398,7 +398,9 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     // basis hi fragment of lane (e, h) at k-step s: rows 27..31 of the 32-row tile do not exist (their outputs are never used): clamp
     const unsigned char *bashp = smem + BASH + (h * TVR_IMG_BASH_ROWS + (e < TVR_IMG_BASH_ROWS ? e : TVR_IMG_BASH_ROWS - 1)) * 16;
     const unsigned char *baslp = bashp + (BASL - BASH);  // lo parts, same addressing, k-steps 0 .. NLO-1
-    const long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
+    // SRC_QUEUE: the count lives on the device.  SRC_H (training forward): optionally too — a.n is then the capacity of the buffers
+    long long n_total = (SRC == SH_SRC_QUEUE) ? (long long)(*a.counter) : a.n;
+    if (SRC == SH_SRC_H && a.counter) n_total = (long long)(*a.counter) < a.n ? (long long)(*a.counter) : a.n;
     const long long n_tiles = (n_total + SH_TILE - 1) / SH_TILE;
     unsigned long long clk0 = 0ull, ref0 = 0ull;              // clock probe (stats only), as in the march kernel
     if (a.stats && SRC == SH_SRC_QUEUE && tid == 0) { clk0 = __builtin_amdgcn_s_memtime(); ref0 = __builtin_amdgcn_s_memrealtime(); }
@@ -449,7 +451,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             // training forward: h [n,144] comes from tvr_app_h_forward; this lane's 8 channels of each k-step are 32 contiguous bytes
             Frag hf[9];
             uint4 bal[9];
-            if (live) { dir[0] = a.viewdirs[ent * 3]; dir[1] = a.viewdirs[ent * 3 + 1]; dir[2] = a.viewdirs[ent * 3 + 2]; }
+            if (live) {                                  // view direction: [n,3] given, or that of the entry's ray (the fused training step)
+                const float *dp = a.q_ray ? a.rays + (size_t)a.q_ray[ent] * 6 + 3 : a.viewdirs + ent * 3;
+                dir[0] = dp[0]; dir[1] = dp[1]; dir[2] = dp[2];
+            }
             {
                 const long long le = live ? ent : n_total - 1;
                 const float4 *hp = (const float4 *)(a.h_in + le * TVR_KAPP) + 2 * h;

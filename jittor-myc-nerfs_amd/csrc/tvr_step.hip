@@ -1,0 +1,183 @@
+// tvr_step.hip — the small kernels that make a TRAINING step (tensorf-myc/train.py:225-261) run without a host read of the queue length:
+// every kernel behind the march takes the number of appearance samples from the device (the queue counter the march kernel leaves) and its
+// buffers at a host-chosen capacity, so the step is a fixed sequence of launches (hipGraph-capturable; tvr_train_forward / tvr_train_backward,
+// tvr_api.hip).  Here: the compositing tail of TensorBase.execute (models/tensorBase.py:520-527) forward and backward over the queue, the
+// power-of-two gradient scale of the fused MLP backward chosen on the device, and deterministic column sums (bias gradients).
+//
+//   forward  rgb_map[r] = clamp(sum_e w_e rgb_e + [white_bg] (1 - acc_r), 0, 1)          e over the ray's contiguous queue segment, fixed order
+//            pen_ray[r] = sum_e w_e relu(in0_e)^2                                          REFTensoRF's normal penalty (REFTensoRF.py:236-239), per ray
+//   backward grgb_e = w_e gm_r,  grad_w_e = rgb_e . gm_r (+ g_pen_r relu(in0_e)^2),  gin0_e = 2 g_pen_r w_e relu(in0_e),  grad_acc_r = -[white_bg] sum_c gm_r,c
+//            with gm_r = grad_rgb_map_r where the pre-clamp value lies in [0,1], else 0 (torch.clamp's gradient)
+#include "tvr_device.h"
+#include "tvr_kernels.h"
+
+#define CT_LANES 8
+
+__global__ __launch_bounds__(256) void composite_train_forward_kernel(const MarchOut mo, const int n_rays, const long long cap, const int white_bg,
+                                                                      const float *__restrict__ rgb, const float *__restrict__ feats32, const int with_pen,
+                                                                      float *__restrict__ rgb_map, float *__restrict__ pre, float *__restrict__ pen_ray)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = t / CT_LANES, l = t % CT_LANES;
+    const bool live = r < n_rays;
+    const unsigned base = live ? mo.ray_off[r] : 0u, cnt = live ? mo.ray_cnt[r] : 0u;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, pn = 0.f;
+    bool over = false;
+    for (unsigned i = l; i < cnt; i += CT_LANES) {
+        const long long e = (long long)base + i;
+        if (e >= cap) { over = true; break; }              // the appearance workspace is smaller than this step's queue: flagged, the step is void
+        const float w = mo.q_pos[e].w;
+        c0 = c0 + w * rgb[e * 3];
+        c1 = c1 + w * rgb[e * 3 + 1];
+        c2 = c2 + w * rgb[e * 3 + 2];
+        if (with_pen) {
+            const float q = fmaxf(feats32[e * 32 + 30], 0.0f);
+            pn = pn + w * (q * q);
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < CT_LANES; off <<= 1) {
+        c0 = c0 + __shfl_xor(c0, off);
+        c1 = c1 + __shfl_xor(c1, off);
+        c2 = c2 + __shfl_xor(c2, off);
+        pn = pn + __shfl_xor(pn, off);
+    }
+    if (over) atomicOr(mo.counter + 3, 1u);
+    if (!live || l != 0) return;
+    if (white_bg) {
+        const float bg = 1.0f - mo.acc[r];
+        c0 = c0 + bg; c1 = c1 + bg; c2 = c2 + bg;
+    }
+    pre[(size_t)r * 3] = c0; pre[(size_t)r * 3 + 1] = c1; pre[(size_t)r * 3 + 2] = c2;
+    rgb_map[(size_t)r * 3] = fminf(fmaxf(c0, 0.f), 1.f);
+    rgb_map[(size_t)r * 3 + 1] = fminf(fmaxf(c1, 0.f), 1.f);
+    rgb_map[(size_t)r * 3 + 2] = fminf(fmaxf(c2, 0.f), 1.f);
+    if (with_pen) pen_ray[r] = pn;
+}
+
+// one thread per queue entry (launch sized for the capacity); amax_bits: max over entries of |gradient entering the network| as a uint (floats >= 0 order as
+// their bit patterns), the basis of the power-of-two scale of the fused backward
+__global__ __launch_bounds__(256) void composite_train_backward_kernel(const MarchOut mo, const long long cap, const float *__restrict__ rgb, const float *__restrict__ feats32,
+                                                                       const float *__restrict__ g8, const float *__restrict__ pre, const float *__restrict__ g_map,
+                                                                       const float *__restrict__ g_pen, float *__restrict__ grgb, float *__restrict__ gin0,
+                                                                       float *__restrict__ grad_w, unsigned *__restrict__ amax_bits)
+{
+    const long long mq = (long long)*mo.counter, m = mq < cap ? mq : cap;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.0f;
+    if (e < m) {
+        const unsigned r = mo.q_ray[e];
+        float gm[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float p = pre[(size_t)r * 3 + c];
+            gm[c] = (p >= 0.0f && p <= 1.0f) ? g_map[(size_t)r * 3 + c] : 0.0f;
+        }
+        const float w = mo.q_pos[e].w;
+        const float x0 = rgb[e * 3], x1 = rgb[e * 3 + 1], x2 = rgb[e * 3 + 2];
+        const float a0 = w * gm[0], a1 = w * gm[1], a2 = w * gm[2];
+        grgb[e * 3] = a0; grgb[e * 3 + 1] = a1; grgb[e * 3 + 2] = a2;
+        float gw = (x0 * gm[0] + x1 * gm[1]) + x2 * gm[2];
+        float scale = 1.0f;
+        if (g8) {                                              // REFTensoRF: the colour is relu(tint) * rgb_s + rgb_d; the penalty term
+            scale = fmaxf(g8[e * 8 + 3], 0.0f);
+            const float q = fmaxf(feats32[e * 32 + 30], 0.0f);
+            const float gp = g_pen ? g_pen[r] : 0.0f;
+            gw = gw + gp * (q * q);
+            gin0[e] = gp * w * (2.0f * q);
+        }
+        grad_w[e] = gw;
+        v = fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fabsf(a2)) * scale;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(amax_bits, __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void composite_train_backward_rays_kernel(const int n_rays, const int white_bg, const float *__restrict__ pre, const float *__restrict__ g_map,
+                                                                            float *__restrict__ grad_acc)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    float s = 0.0f;
+    if (white_bg) {
+        float gm[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float p = pre[(size_t)r * 3 + c];
+            gm[c] = (p >= 0.0f && p <= 1.0f) ? g_map[(size_t)r * 3 + c] : 0.0f;
+        }
+        s = -((gm[0] + gm[1]) + gm[2]);
+    }
+    grad_acc[r] = s;
+}
+
+// gscale = 2^floor(log2(target / (0.25 max))) in [2^-60, 2^60] (autograd_ops.py's host formula, on the device); the max word is cleared for the next step
+__global__ void grad_scale_kernel(unsigned *__restrict__ amax_bits, const float target, float *__restrict__ gscale)
+{
+    const float gmax = fmaxf(__uint_as_float(*amax_bits) * 0.25f, 1e-30f);
+    float e = floorf(log2f(target / gmax));
+    e = fminf(fmaxf(e, -60.0f), 60.0f);
+    *gscale = exp2f(e);
+    *amax_bits = 0u;
+}
+
+// column sums of A [M, K] (row stride lda, K <= 128), M on the device: workgroup b sums its slab of rows, thread (row lane, column), partials summed by
+// gemm_tn's fixed-order reduction
+#define CS_GRID 512
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ A, const int lda, const int K, const long long m_cap, const unsigned *__restrict__ m_dev,
+                                                             float *__restrict__ P)
+{
+    __shared__ float red[128];
+    const long long M = m_dev ? ((long long)*m_dev < m_cap ? (long long)*m_dev : m_cap) : m_cap;
+    const long long rpb = (M + CS_GRID - 1) / CS_GRID;
+    const long long m0 = (long long)blockIdx.x * rpb, m1 = m0 + rpb < M ? m0 + rpb : M;
+    const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
+    float s = 0.0f;
+    if (c < K)
+        for (long long r = m0 + rl; r < m1; r += 2) s = s + A[r * lda + c];
+    if (rl == 1) red[c] = s;
+    __syncthreads();
+    if (rl == 0 && c < K) P[(size_t)blockIdx.x * K + c] = s + red[c];
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ P, const int K, float *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t >> 4, l = t & 15;
+    float s = 0.0f;
+    if (e < K)
+        for (int b = l; b < CS_GRID; b += 16) s = s + P[(size_t)b * K + e];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) s = s + __shfl_xor(s, off);
+    if (e < K && l == 0) out[e] = s;
+}
+
+hipError_t launch_composite_train_forward(const MarchOut &mo, int n_rays, long long cap, int white_bg, const float *rgb, const float *feats32, int with_pen, float *rgb_map,
+                                          float *pre, float *pen_ray, hipStream_t stream)
+{
+    const long long threads = (long long)n_rays * CT_LANES;
+    hipLaunchKernelGGL(composite_train_forward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, mo, n_rays, cap, white_bg, rgb, feats32, with_pen, rgb_map,
+                       pre, pen_ray);
+    return hipGetLastError();
+}
+
+hipError_t launch_composite_train_backward(const MarchOut &mo, int n_rays, long long cap, int white_bg, const float *rgb, const float *feats32, const float *g8, const float *pre,
+                                           const float *g_map, const float *g_pen, float *grgb, float *gin0, float *grad_w, float *grad_acc, unsigned *amax_bits,
+                                           float target, float *gscale, hipStream_t stream)
+{
+    hipLaunchKernelGGL(composite_train_backward_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, mo, cap, rgb, feats32, g8, pre, g_map, g_pen, grgb, gin0,
+                       grad_w, amax_bits);
+    hipLaunchKernelGGL(composite_train_backward_rays_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, stream, n_rays, white_bg, pre, g_map, grad_acc);
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, stream, amax_bits, target, gscale);
+    return hipGetLastError();
+}
+
+size_t colsum_scratch_bytes() { return (size_t)CS_GRID * 128 * sizeof(float); }
+
+hipError_t launch_colsum(const float *A, int lda, int K, long long m_cap, const unsigned *m_dev, float *out, float *scratch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(CS_GRID), dim3(256), 0, stream, A, lda, K, m_cap, m_dev, scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((K * 16 + 255) / 256), dim3(256), 0, stream, scratch, K, out);
+    return hipGetLastError();
+}

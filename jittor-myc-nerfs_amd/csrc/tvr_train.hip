@@ -367,14 +367,18 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
 }
 
 // one thread per (entry, plane, float4 channel group): h[entry][48*plane + 4*q .. +3]
-__global__ __launch_bounds__(256) void app_h_forward_kernel(const SceneDev sc, const float *__restrict__ xyz, const long long m, float *__restrict__ h)
+// xs: floats between consecutive positions (3: xyz [m,3]; 4: the march queue's {xyz, w} entries).  m_dev (optional): the entry count lives on the
+// device (the queue length of a training step) and m is the capacity the buffers were sized for: min(*m_dev, m) entries are processed.
+__global__ __launch_bounds__(256) void app_h_forward_kernel(const SceneDev sc, const float *__restrict__ xyz, const int xs, const long long m_cap,
+                                                            const unsigned *__restrict__ m_dev, float *__restrict__ h)
 {
+    const long long m = m_dev ? ((long long)*m_dev < m_cap ? (long long)*m_dev : m_cap) : m_cap;
     const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= m * 36) return;
     const long long ent = item / 36;
     const int rem = (int)(item - ent * 36), pl = rem / 12, q = rem - pl * 12;
     const int ax = kMat[pl][0], bx = kMat[pl][1], vx = kVec[pl];
-    const float fx = unnorm(xyz[ent * 3 + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * 3 + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * 3 + vx], sc.gm1[vx]);
+    const float fx = unnorm(xyz[ent * xs + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * xs + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * xs + vx], sc.gm1[vx]);
     const float x0 = floorf(fx), y0 = floorf(fy), l0 = floorf(fl);
     const VmTerm t = vm_eval<12>(sc.aplane[pl], sc.aline[pl], sc.grid[ax], (int)x0, (int)y0, (int)l0, fx - x0, fy - y0, fl - l0, q);
     *(float4 *)(h + ent * TVR_KAPP + pl * TVR_CA + q * 4) = make_float4(t.P.x * t.Q.x, t.P.y * t.Q.y, t.P.z * t.Q.z, t.P.w * t.Q.w);
@@ -384,10 +388,12 @@ __global__ __launch_bounds__(256) void app_h_forward_kernel(const SceneDev sc, c
 // One lane per CHANNEL (48 consecutive lanes = one entry): a wave's atomic instruction then covers whole 64-B lines of a texel
 // (16 dwords per L2 request) instead of 4 scattered dwords per line with a lane per float4.
 template <bool LINE_LDS>
-__global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const SceneDev sc, const float *__restrict__ xyz, const long long m,
-                                                                     const float *__restrict__ dh, TrainGrads tg)
+__global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const SceneDev sc, const float *__restrict__ xyz, const int xs, const long long m_cap,
+                                                                     const unsigned *__restrict__ m_dev, const float *__restrict__ dh, TrainGrads tg)
 {
     extern __shared__ __attribute__((aligned(16))) float glds[];
+    const long long m = m_dev ? ((long long)*m_dev < m_cap ? (long long)*m_dev : m_cap) : m_cap;
+    if ((long long)blockIdx.x * AHB_ENTRIES >= m) return;           // (workgroup-uniform: a launch sized for the capacity)
     const int pl = blockIdx.y;
     const int ax = kMat[pl][0], bx = kMat[pl][1], vx = kVec[pl];
     const int ln = (sc.grid[vx] + 1) * TVR_CA;
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const Scene
     long long key = -1;
     float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
     for (long long ent = g0; ent < g1; ++ent) {
-        const float fx = unnorm(xyz[ent * 3 + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * 3 + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * 3 + vx], sc.gm1[vx]);
+        const float fx = unnorm(xyz[ent * xs + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * xs + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * xs + vx], sc.gm1[vx]);
         const float x0f = floorf(fx), y0f = floorf(fy), l0f = floorf(fl);
         const float wx = fx - x0f, wy = fy - y0f, wl = fl - l0f, ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
         const long long t00 = (((long long)(int)y0f * Wp + (int)x0f)) * TVR_CA + c, t10 = t00 + (long long)Wp * TVR_CA;
@@ -483,13 +489,14 @@ hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_ra
     return hipGetLastError();
 }
 
-hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream)
+hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream, int xyz_stride, const unsigned *m_dev)
 {
-    hipLaunchKernelGGL(app_h_forward_kernel, dim3((unsigned)((m * 36 + 255) / 256)), dim3(256), 0, stream, sc, xyz, m, h);
+    hipLaunchKernelGGL(app_h_forward_kernel, dim3((unsigned)((m * 36 + 255) / 256)), dim3(256), 0, stream, sc, xyz, xyz_stride, m, m_dev, h);
     return hipGetLastError();
 }
 
-hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream)
+hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream, int xyz_stride,
+                                 const unsigned *m_dev)
 {
     int gmax = sc.grid[0] > sc.grid[1] ? sc.grid[0] : sc.grid[1];
     gmax = gmax > sc.grid[2] ? gmax : sc.grid[2];
@@ -498,9 +505,9 @@ hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long
     if (lds <= 150 * 1024) {
         hipError_t rc = hipFuncSetAttribute((const void *)app_h_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (rc != hipSuccess) return rc;
-        hipLaunchKernelGGL(app_h_backward_kernel<true>, grid, dim3(AHB_THREADS), lds, stream, sc, xyz, m, dh, tg);
+        hipLaunchKernelGGL(app_h_backward_kernel<true>, grid, dim3(AHB_THREADS), lds, stream, sc, xyz, xyz_stride, m, m_dev, dh, tg);
     } else {
-        hipLaunchKernelGGL(app_h_backward_kernel<false>, grid, dim3(AHB_THREADS), 0, stream, sc, xyz, m, dh, tg);
+        hipLaunchKernelGGL(app_h_backward_kernel<false>, grid, dim3(AHB_THREADS), 0, stream, sc, xyz, xyz_stride, m, m_dev, dh, tg);
     }
     return hipGetLastError();
 }
@@ -518,17 +525,20 @@ hipError_t launch_unpack_grad(const float *in, float *out, int Cout, int C, int 
 // ---- fused training helpers: the MLP input assembly and the TV regulariser (each replaces a dozen elementwise library launches) ----------
 // MLPRender_Fea's input (tensorBase.py:76-82): X = [f (27), d (3), sin(f 2^k), cos(f 2^k) (k < 2, index 2c + k), sin(d 2^k), cos(d 2^k)];
 // MLPRender_Fea_Ref (REFTensoRF.py:19-24) puts dot_product in front (with_dot = 1, 151 columns).  One thread per (entry, base value).
-__global__ __launch_bounds__(256) void pe_concat_forward_kernel(const float *__restrict__ feat, const float *__restrict__ dir,
-                                                                const float *__restrict__ dot, const long long m, const int with_dot,
-                                                                float *__restrict__ X)
+// Strided sources (the fused training step reads them where the forward kernel left them): feat row stride fs, dir row stride ds (or, with q_ray, the
+// direction of entry e is rays[q_ray[e]][3..5]), dot row stride dts; m_dev as in app_h_forward_kernel.
+struct PeSrc { const float *feat, *dir, *dot, *rays; const unsigned *q_ray, *m_dev; int fs, ds, dts; };
+__global__ __launch_bounds__(256) void pe_concat_forward_kernel(const PeSrc p, const long long m_cap, const int with_dot, float *__restrict__ X)
 {
+    const long long m = p.m_dev ? ((long long)*p.m_dev < m_cap ? (long long)*p.m_dev : m_cap) : m_cap;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m * 30) return;
     const long long ent = t / 30;
     const int c = (int)(t - ent * 30);
     const int n = 150 + with_dot;
     float *x = X + ent * n + with_dot;
-    const float v = c < 27 ? feat[ent * 27 + c] : dir[ent * 3 + (c - 27)];
+    const float *__restrict__ feat = p.feat, *__restrict__ dot = p.dot;
+    const float v = c < 27 ? feat[ent * p.fs + c] : (p.q_ray ? p.rays[(size_t)p.q_ray[ent] * 6 + 3 + (c - 27)] : p.dir[ent * p.ds + (c - 27)]);
     float s1, c1, s2, c2;
     sincosf(v, &s1, &c1);
     sincosf(v * 2.0f, &s2, &c2);
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(256) void pe_concat_forward_kernel(const float *__r
         const int j = c - 27;
         x[138 + 2 * j] = s1; x[139 + 2 * j] = s2; x[144 + 2 * j] = c1; x[145 + 2 * j] = c2;
     }
-    if (with_dot && c == 0) X[ent * n] = dot[ent];
+    if (with_dot && c == 0) X[ent * n] = dot[ent * p.dts];
 }
 
 // d/dv of the five columns a base value feeds: gX[v] + sum_k 2^k (gX[sin] cos(v 2^k) - gX[cos] sin(v 2^k))
@@ -566,7 +576,16 @@ __global__ __launch_bounds__(256) void pe_concat_backward_kernel(const float *__
 
 hipError_t launch_pe_concat(const float *feat, const float *dir, const float *dot, long long m, float *X, hipStream_t stream)
 {
-    hipLaunchKernelGGL(pe_concat_forward_kernel, dim3((unsigned)((m * 30 + 255) / 256)), dim3(256), 0, stream, feat, dir, dot, m, dot ? 1 : 0, X);
+    PeSrc p = {feat, dir, dot, nullptr, nullptr, nullptr, 27, 3, 1};
+    hipLaunchKernelGGL(pe_concat_forward_kernel, dim3((unsigned)((m * 30 + 255) / 256)), dim3(256), 0, stream, p, m, dot ? 1 : 0, X);
+    return hipGetLastError();
+}
+
+hipError_t launch_pe_concat_strided(const float *feat, int fs, const float *dir, int ds, const float *rays, const unsigned *q_ray, const float *dot, int dts,
+                                    long long m_cap, const unsigned *m_dev, float *X, hipStream_t stream)
+{
+    PeSrc p = {feat, dir, dot, rays, q_ray, m_dev, fs, ds, dts};
+    hipLaunchKernelGGL(pe_concat_forward_kernel, dim3((unsigned)((m_cap * 30 + 255) / 256)), dim3(256), 0, stream, p, m_cap, dot ? 1 : 0, X);
     return hipGetLastError();
 }
 

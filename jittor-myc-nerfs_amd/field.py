@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .autograd_ops import _MlpTrainFn, _AppHFn, _MarchFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
+from .autograd_ops import _FusedStepFn, _MlpTrainFn, _AppHFn, _MarchFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
 
 
 class AlphaGridMask:
@@ -343,6 +343,11 @@ class TensorBase(torch.nn.Module):
         rays = _f32c(rays_chunk, self.device)
         S = int(N_samples) if N_samples > 0 else self.nSamples
         eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
+        if self._fused_step_ok() and type(self.renderModule) is MLPRender_Fea and getattr(self, "_variant", 0) == 0:
+            m = self.renderModule.mlp                         # two C-ABI calls, no host read, fixed launch sequence (autograd_ops._FusedStepFn)
+            rgb_map, depth, _ = _FusedStepFn.apply(self, rays, jitter, S, eps_T, white_bg, *self.density_plane, *self.density_line, *self.app_plane, *self.app_line,
+                                                   self.basis_mat.weight, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
+            return rgb_map, depth
         w, acc, xyz, ray_id, depth, _ = _MarchFn.apply(self, rays, jitter, S, eps_T, None, *self.density_plane, *self.density_line)
         h = self._app_h_autograd(xyz)
         rgb = self._shade_autograd(h, rays[ray_id, 3:6])                                      # tensoRF.py:244 + tensorBase.py:517
@@ -404,6 +409,51 @@ class TensorBase(torch.nn.Module):
         f.zero_()
         self.grad_scale_target = max(self.grad_scale_target / 16.0, 2.0 ** -20)
         return True
+
+    # ---- the training step without a host read (autograd_ops._FusedStepFn) ----
+    static_training = True        # False: the eager chain of autograd Functions (one host read of the queue length per step; kept as a second opinion in tests)
+    train_app_samples_per_ray = 192   # capacity of the appearance workspace per ray of the batch (the bench scene averages 87; a step that needs more is
+                                      # flagged by the kernels, check_training_faults() doubles this and the loop repeats the step)
+
+    def _train_buffers(self, n: int, S: int) -> dict:
+        """Forward scratch (the march queue) and the appearance workspace of the fused training step, allocated once per (batch, samples, capacity) and
+        reused by every step: static addresses (hipGraph capture) and no allocator traffic."""
+        cap = int(min(n * S, max(4096, self.train_app_samples_per_ray * n)))
+        cap = min(cap, ((1 << 32) - 1) // 576)
+        key = (n, S, cap)
+        b = getattr(self, "_train_buf", None)
+        if b is None or b["key"] != key:
+            lib = L.lib()
+            sc = self._ensure_scene()
+            self._train_buf = None
+            b = dict(key=key, cap=cap,
+                     scratch=torch.zeros(lib.tvr_render_scratch_bytes(sc, n, S), dtype=torch.uint8, device=self.device),
+                     work=torch.zeros(lib.tvr_train_work_bytes(sc, n, S, cap), dtype=torch.uint8, device=self.device))
+            self._train_buf = b
+        return b
+
+    def check_training_faults(self):
+        """None, or why the last training step(s) must not be applied — read where the loop reads the loss (two tiny host reads):
+        'overflow'  the step's appearance samples exceeded the workspace: train_app_samples_per_ray is doubled, the buffers are re-made;
+        'march'     the march kernel raised its fault flag (include/tvr.h, tvr_scratch_layout);
+        'saturated' a gradient reached fp16's range inside the fused backward: grad_scale_target is lowered (check_gradient_saturation)."""
+        b = getattr(self, "_train_buf", None)
+        if b is not None:
+            lay = L.ScratchLayout()
+            L.check(L.lib().tvr_scratch_describe(b["key"][0], b["key"][1], C.byref(lay)), "tvr_scratch_describe")
+            hdr = b["scratch"][lay.counter:lay.counter + 16].view(torch.int32).tolist()
+            if hdr[2] != 0:
+                raise L.TvrError(f"the march kernel raised its fault flag ({hdr[2]}): a wave gave up waiting for its tile number (include/tvr.h)")
+            if hdr[3] != 0:
+                self.train_app_samples_per_ray *= 2
+                self._train_buf = None
+                return "overflow"
+        return "saturated" if self.check_gradient_saturation() else None
+
+    def _fused_step_ok(self) -> bool:
+        rm = self.renderModule
+        return (self.static_training and self.fused_mlp_training and list(self.app_n_comp) == [48, 48, 48] and self.app_dim == 27
+                and getattr(rm, "feape", 0) == 2 and getattr(rm, "viewpe", 0) == 2 and rm.mlp[0].out_features == 128 and str(self.device).startswith("cuda"))
 
     def _get_scratch(self, nbytes: int) -> torch.Tensor:
         if self._scratch is None or self._scratch.numel() < nbytes:

@@ -235,8 +235,9 @@ def reconstruction(args, device="cuda", log=print):
             total_loss = total_loss + pen_w * tensorf.penalty
             tensorf.penalty = torch.zeros((), device=device)
         total_loss.backward()
-        if tensorf.check_gradient_saturation():       # the fused backward clipped a gradient at fp16's range (field.py): drop this update; the scale is already lowered
-            log(f"Iteration {iteration:05d}: gradient scale lowered to {tensorf.grad_scale_target:g} (fp16 operand range reached); update skipped")
+        fault = tensorf.check_training_faults()        # read beside the loss: workspace overflow / fp16-range saturation inside the fused step (field.py)
+        if fault is not None:                          # the step's gradients are void: drop the update; capacity / scale are already adjusted
+            log(f"Iteration {iteration:05d}: training step dropped ({fault}); samples per ray {tensorf.train_app_samples_per_ray}, scale {tensorf.grad_scale_target:g}")
             optimizer.zero_grad(set_to_none=True)
         else:
             optimizer.step()

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .autograd_ops import _AppHFn, _MarchFn, _RefMlpTrainFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
+from .autograd_ops import _AppHFn, _FusedStepFn, _MarchFn, _RefMlpTrainFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
 from .field import TensorVMSplit
 
 
@@ -123,6 +123,14 @@ class REFTensoRF(TensorVMSplit):
         rays = _f32c(rays_chunk, self.device)
         S = int(N_samples) if N_samples > 0 else self.nSamples
         eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
+        if self._fused_step_ok():                             # two C-ABI calls, no host read, fixed launch sequence (autograd_ops._FusedStepFn)
+            mlp = self.renderModule.mlp
+            rgb_map, depth, pen_ray = _FusedStepFn.apply(
+                self, rays, jitter, S, eps_T, white_bg, *self.density_plane, *self.density_line, *self.app_plane, *self.app_line, self.basis_mat.weight,
+                mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, mlp[4].weight, mlp[4].bias, self.normal_linear.weight, self.normal_linear.bias,
+                self.diffuse_linear.weight, self.diffuse_linear.bias, self.specular_linear.weight, self.specular_linear.bias, self.rho_linear.weight, self.rho_linear.bias)
+            self.penalty = pen_ray.sum()                                                      # :236-239: sum_i w_i relu(-dot_i)^2, summed per ray on the device
+            return rgb_map, depth
         w, acc, xyz, ray_id, depth, _ = _MarchFn.apply(self, rays, jitter, S, eps_T, None, *self.density_plane, *self.density_line)
         h = _AppHFn.apply(self, xyz, *self.app_plane, *self.app_line)
         rm = self.renderModule

@@ -80,11 +80,13 @@ def _oracle_with_grads(arrs, hyper):
     return sc, leaves
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_ref_gradients_match_oracle_autograd(fused, tiny_ref, tiny_ref_arrays, hyper_tiny):
+@pytest.mark.parametrize("mode", ["static", "eager", "library"])
+def test_ref_gradients_match_oracle_autograd(mode, tiny_ref, tiny_ref_arrays, hyper_tiny):
     """train.py:225-257 with model_name = REFTensoRF: loss = sum(rgb_map * c) + 0.5 * penalty (normal_vector_penalty_weight, Scar.txt:7).
-    fused = True: heads, normalisation, reflection, MLPRender_Fea_Ref and the colour mix run as tvr_mlp_train_forward_ref / _backward_ref (no library GEMM);
-    fused = False: the same algebra as torch ops over library GEMMs (the round-2 path, kept as a second opinion)."""
+    static : the whole step as tvr_train_forward / tvr_train_backward (device-side counts, no host read, fixed-order compositing sums);
+    eager  : heads, normalisation, reflection, MLPRender_Fea_Ref and the colour mix as tvr_mlp_train_forward_ref / _backward_ref inside the eager autograd chain;
+    library: the same algebra as torch ops over library GEMMs (the round-2 path, kept as a second opinion)."""
+    fused = mode != "library"
     from oracle import tensorf_oracle as TO
     rays_np = tiny_ref["rays"]
     S = TINY["N_samples"]
@@ -95,6 +97,7 @@ def test_ref_gradients_match_oracle_autograd(fused, tiny_ref, tiny_ref_arrays, h
     m = make_model(tiny_ref_arrays, hyper_tiny)
     m.eps_T = 0.0
     m.fused_mlp_training = fused
+    m.static_training = mode == "static"
     rgb, depth = m.render_rays_autograd(torch.tensor(rays_np, device="cuda"), white_bg=True, N_samples=S)
     assert np.abs(_np(rgb) - rgb_o.detach().numpy()).max() < 2e-4
     if fused:                                            # the training forward IS the evaluation kernel (per-sample colours bit for bit); the pixels differ

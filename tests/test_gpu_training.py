@@ -25,8 +25,10 @@ def _oracle_with_grads(arrs, hyper):
     return sc, leaves
 
 
+@pytest.mark.parametrize("static", [True, False])
 @pytest.mark.parametrize("white_bg,use_jitter", [(True, False), (False, True)])
-def test_gradients_match_oracle_autograd(tiny_dump, tiny_arrays, hyper_tiny, white_bg, use_jitter):
+def test_gradients_match_oracle_autograd(tiny_dump, tiny_arrays, hyper_tiny, white_bg, use_jitter, static):
+    """static = True: the step as tvr_train_forward / tvr_train_backward (device-side counts, no host read); False: the eager chain of autograd Functions."""
     from oracle import tensorf_oracle as TO
     rays_np = tiny_dump["rays"]
     S = TINY["N_samples"]
@@ -39,9 +41,11 @@ def test_gradients_match_oracle_autograd(tiny_dump, tiny_arrays, hyper_tiny, whi
     # HIP path
     m = make_model(tiny_arrays, hyper_tiny)
     m.eps_T = 0.0
+    m.static_training = static
     rays = torch.tensor(rays_np, device="cuda")
     jitter = None if jit_np is None else torch.tensor(jit_np, device="cuda")
     rgb, depth = m.render_rays_autograd(rays, white_bg=white_bg, N_samples=S, jitter=jitter)
+    assert (getattr(m, "_train_buf", None) is not None) == static
     assert np.abs(rgb.detach().cpu().numpy() - rgb_o.detach().numpy()).max() < 2e-4
     (rgb * cw.cuda()).sum().backward()
     mlp = m.renderModule.mlp

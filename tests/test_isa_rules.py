@@ -26,8 +26,9 @@ def report():
 
 
 def test_every_shade_kernel_variant_is_audited(report):
-    # {queue, xyz->features, features->rgb} x {TensorVMSplit, REFTensoRF} + the training forward (h -> rgb + activations) + the two backward kernels
-    assert len(report) == 9
+    # {queue, xyz->features, features->rgb, training forward (h -> rgb + activations)} x {TensorVMSplit, REFTensoRF} + the backward kernels
+    # (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps)
+    assert len(report) == 12, sorted(report)
     assert all(v["mfma"] >= 27 for v in report.values())
 
 
