@@ -349,7 +349,7 @@ class _RefMlpTrainFn(torch.autograd.Function):
         grgb = torch.zeros((m, 3), device=dev) if grgb is None else grgb.contiguous().float()
         gin0 = None if gin0 is None else gin0.contiguous().float()
         tint = g8[:, 3].clamp_min(0)
-        gmax = ((grgb * tint[:, None]).abs().max() * 0.25).clamp_min(1e-30)                   # the gradient that enters the network is tint * grad
+        gmax = ((grgb * tint[:, None]).abs().max() * 0.25).clamp_min(1e-30)                   # tint * grad enters the network (the heads' product scales itself)
         gscale = torch.exp2(torch.floor(torch.log2(float(ctx.model.grad_scale_target) / gmax))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1).float()
         sat = ctx.model._get_sat_flag()
         d_out = torch.empty((m, 4), dtype=torch.float32, device=dev)

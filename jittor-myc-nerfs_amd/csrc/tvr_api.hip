@@ -747,28 +747,28 @@ int tvr_train_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     else HIP_TRY(launch_pe_concat_strided(F(W.feats32), 32, nullptr, 0, rays, mo.q_ray, nullptr, 0, app_cap, mdev, F(W.X), stream));
     float *tmp = F(W.tmp), *gsc = F(W.gemm), *csc = F(W.colsum);
     HIP_TRY(launch_gemm_tn(F(W.d_out4), 4, 4, F(W.h2), TVR_FEATC, TVR_FEATC, app_cap, tmp, gsc, stream, mdev));
-    HIP_TRY(hipMemcpyAsync(mo_->W3, tmp, 3 * TVR_FEATC * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(launch_copy_f32(mo_->W3, tmp, 3 * TVR_FEATC, stream));
     HIP_TRY(launch_gemm_tn(F(W.dh2), TVR_FEATC, TVR_FEATC, F(W.h1), TVR_FEATC, TVR_FEATC, app_cap, mo_->W2, gsc, stream, mdev));
     HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X), nin, nin, app_cap, mo_->W1, gsc, stream, mdev));
     HIP_TRY(launch_gemm_tn(F(W.dfeats32), 32, 32, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev));
-    HIP_TRY(hipMemcpyAsync(mo_->basis, tmp, TVR_APPDIM * TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(launch_copy_f32(mo_->basis, tmp, TVR_APPDIM * TVR_KAPP, stream));
     if (ref) {
         HIP_TRY(launch_gemm_tn(F(W.dg8), 8, 8, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev));      // rows: normal 0..2, specular 3, diffuse 4..6, rho 7
-        HIP_TRY(hipMemcpyAsync(mo_->heads_W[0], tmp, 3 * TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(mo_->heads_W[2], tmp + 3 * TVR_KAPP, TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(mo_->heads_W[1], tmp + 4 * TVR_KAPP, 3 * TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(mo_->heads_W[3], tmp + 7 * TVR_KAPP, TVR_KAPP * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(launch_copy_f32(mo_->heads_W[0], tmp, 3 * TVR_KAPP, stream));
+        HIP_TRY(launch_copy_f32(mo_->heads_W[2], tmp + 3 * TVR_KAPP, TVR_KAPP, stream));
+        HIP_TRY(launch_copy_f32(mo_->heads_W[1], tmp + 4 * TVR_KAPP, 3 * TVR_KAPP, stream));
+        HIP_TRY(launch_copy_f32(mo_->heads_W[3], tmp + 7 * TVR_KAPP, TVR_KAPP, stream));
         float *bs = tmp + 32 * TVR_KAPP;
         HIP_TRY(launch_colsum(F(W.dg8), 8, 8, app_cap, mdev, bs, csc, stream));
-        HIP_TRY(hipMemcpyAsync(mo_->heads_b[0], bs, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(mo_->heads_b[2], bs + 3, sizeof(float), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(mo_->heads_b[1], bs + 4, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(mo_->heads_b[3], bs + 7, sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(launch_copy_f32(mo_->heads_b[0], bs, 3, stream));
+        HIP_TRY(launch_copy_f32(mo_->heads_b[2], bs + 3, 1, stream));
+        HIP_TRY(launch_copy_f32(mo_->heads_b[1], bs + 4, 3, stream));
+        HIP_TRY(launch_copy_f32(mo_->heads_b[3], bs + 7, 1, stream));
     }
     {
         float *bs = tmp + 32 * TVR_KAPP + 16;
         HIP_TRY(launch_colsum(F(W.d_out4), 4, 4, app_cap, mdev, bs, csc, stream));
-        HIP_TRY(hipMemcpyAsync(mo_->b3, bs, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(launch_copy_f32(mo_->b3, bs, 3, stream));
         HIP_TRY(launch_colsum(F(W.dh2), TVR_FEATC, TVR_FEATC, app_cap, mdev, mo_->b2, csc, stream));
         HIP_TRY(launch_colsum(F(W.dh1), TVR_FEATC, TVR_FEATC, app_cap, mdev, mo_->b1, csc, stream));
     }

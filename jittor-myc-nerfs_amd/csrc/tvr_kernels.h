@@ -95,7 +95,7 @@ hipError_t launch_pack_train_image(const float *W1, const float *W2, const float
 // REFTensoRF's additions to the backward: raw head outputs, view directions, optional gradient of the -dot output; dg8 [m,8] is written
 struct MlpRefBwd { const float *g8, *viewdirs, *grad_in0; float *dg8; const float *rays; const unsigned *q_ray; };   // q_ray set: the direction of entry e is rays[q_ray[e]][3..5]
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
-                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, const MlpRefBwd *ref,
+                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, void *image, const MlpRefBwd *ref,
                                      hipStream_t stream, const unsigned *m_dev = nullptr);
 hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, float *value, float *grad, float *part, hipStream_t stream);
 hipError_t launch_alpha_bits(const float *vol, long long n, unsigned *bits, hipStream_t stream);
@@ -108,3 +108,4 @@ hipError_t launch_composite_train_backward(const MarchOut &mo, int n_rays, long 
                                            float target, float *gscale, hipStream_t stream);
 size_t colsum_scratch_bytes();
 hipError_t launch_colsum(const float *A, int lda, int K, long long m_cap, const unsigned *m_dev, float *out, float *scratch, hipStream_t stream);
+hipError_t launch_copy_f32(float *dst, const float *src, int n, hipStream_t stream);

@@ -29,7 +29,8 @@
 #define TI_LDS_BYTES (TI_W3 + 3 * 128 * 4)           // 158 208 B
 #define TI_BAST (TI_LDS_BYTES)                       // Bas^T fragments [5 row blocks][KS k-steps][2 halves][32 rows][hi 8 | lo 8] fp16 (not copied to LDS);
                                                      // KS = 2 (27 features, padded to 32); REFTensoRF: KS = 3, k 32..39 = the eight head outputs
-#define TI_BYTES (TI_BAST + 5 * 3 * 2 * 32 * 32)     // 188 928 B (sized for KS = 3)
+#define TI_SCAL (TI_BAST + 5 * 3 * 2 * 32 * 32)      // REFTensoRF: {max |dg8| bits, the heads' own gradient scale} (the normal's gradient carries 1 / |n|: its range is not the network's)
+#define TI_BYTES (TI_SCAL + 64)                      // 188 992 B (sized for KS = 3)
 
 #define MT_WAVES 8
 #define MT_THREADS (64 * MT_WAVES)
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__re
                                                                const float *__restrict__ Bas, const HeadPtrs hp, const int ref, unsigned char *__restrict__ img)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *(unsigned *)(img + TI_SCAL) = 0u;
     const int KB = ref ? 48 : 32;
     const int n_w2 = 128 * 128, n_w1 = 160 * 128, n_w3 = 3 * 128, n_b = 160 * KB;
     if (i < n_w2) {
@@ -327,11 +329,12 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
 __global__ __launch_bounds__(256) void ref_heads_backward_kernel(const float *__restrict__ grad_rgb, const float *__restrict__ rgb_s, const float *__restrict__ g8,
                                                                  const float *__restrict__ viewdirs, const float *__restrict__ rays, const unsigned *__restrict__ q_ray,
                                                                  const float *__restrict__ dfeats, const float *__restrict__ grad_in0, const long long m_cap,
-                                                                 const unsigned *__restrict__ m_dev, float *__restrict__ dg8)
+                                                                 const unsigned *__restrict__ m_dev, float *__restrict__ dg8, unsigned *__restrict__ amax_h)
 {
     const long long m = m_dev ? ((long long)*m_dev < m_cap ? (long long)*m_dev : m_cap) : m_cap;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+    float vmax = 0.0f;
+    if (i < m) {
     const float4 ga = *(const float4 *)(g8 + i * 8), gb = *(const float4 *)(g8 + i * 8 + 4);
     const float n[3] = {ga.x, ga.y, ga.z};
     const float nn = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
@@ -360,6 +363,21 @@ __global__ __launch_bounds__(256) void ref_heads_backward_kernel(const float *__
     *(float4 *)(dg8 + i * 8) = make_float4(dn[0], dn[1], dn[2], dt);
     *(float4 *)(dg8 + i * 8 + 4) = make_float4(g0, g1, g2, 0.0f);
     (void)gb;
+    vmax = fmaxf(fmaxf(fmaxf(fabsf(dn[0]), fabsf(dn[1])), fmaxf(fabsf(dn[2]), fabsf(dt))), fmaxf(fmaxf(fabsf(g0), fabsf(g1)), fabsf(g2)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(amax_h, __float_as_uint(vmax));
+}
+
+// the heads' gradient scale: 2^floor(log2(target / max |dg8|)) (their operands go straight into the transpose product: no 0.25 headroom for a chain)
+__global__ void heads_scale_kernel(unsigned *__restrict__ amax_h, const float target, float *__restrict__ gscale_h)
+{
+    const float gmax = fmaxf(__uint_as_float(*amax_h), 1e-30f);
+    float e = floorf(log2f(target / gmax));
+    e = fminf(fmaxf(e, -60.0f), 60.0f);
+    *gscale_h = exp2f(e);
+    *amax_h = 0u;
 }
 
 // dh^T [144 x 32e] = Bas^T [144 x 32] dF^T [32 x 32e]  (gscale as above; dF is stored unscaled).  KS = 3 (REFTensoRF): a third k-step adds
@@ -369,6 +387,9 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
                                                                 const float *__restrict__ gscale_p, const unsigned char *__restrict__ image, float *__restrict__ dh, unsigned *sat)
 {
     const long long m = m_dev ? ((long long)*m_dev < m_cap ? (long long)*m_dev : m_cap) : m_cap;
+    // the heads' k-step has its OWN power-of-two scale (and accumulators): d normal carries 1 / |n| and d rgb_d is the colour gradient itself, neither
+    // shares the range of the gradients that went through the network
+    const float gscale_h = KS == 3 ? *((const float *)(image + TI_SCAL) + 1) : 1.0f, inv_scale_h = 1.0f / gscale_h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = lane & 31, h = lane >> 5;
     const long long n_tiles = (m + 31) / 32;
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
         }
         if (KS == 3) {
             const float4 g4 = *(const float4 *)(dg8 + le * 8 + 4 * h);
-            x[16] = g4.x * gscale; x[17] = g4.y * gscale; x[18] = g4.z * gscale; x[19] = g4.w * gscale;
+            x[16] = g4.x * gscale_h; x[17] = g4.y * gscale_h; x[18] = g4.z * gscale_h; x[19] = g4.w * gscale_h;
             x[20] = 0.f; x[21] = 0.f; x[22] = 0.f; x[23] = 0.f;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -409,8 +430,23 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
         f32x16 acc[5];
 #pragma unroll
         for (int rb = 0; rb < 5; ++rb) acc[rb] = f32x16{0};
+        if (KS == 3) {
+            // the heads' k-step first, at its own scale; then the accumulators are moved to the network's scale (a power of two: exact) and the two
+            // feature k-steps accumulate on top — one set of accumulators (a second set spills: 160 + 120 fragment registers)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+            for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(al[rb][KS - 1], b[KS - 1].hi, acc[rb]);
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][KS - 1], b[KS - 1].lo, acc[rb]);
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(ah[rb][KS - 1], b[KS - 1].hi, acc[rb]);
+            const float ratio = gscale * inv_scale_h;
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][r] = acc[rb][r] * ratio;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int rb = 0; rb < 5; ++rb) acc[rb] = MFMAH(al[rb][s], b[s].hi, acc[rb]);
 #pragma unroll
@@ -447,7 +483,7 @@ hipError_t launch_pack_train_image(const float *W1, const float *W2, const float
 }
 
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
-                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, const void *image, const MlpRefBwd *ref,
+                                     float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, void *image, const MlpRefBwd *ref,
                                      hipStream_t stream, const unsigned *m_dev)
 {
     hipError_t rc = hipFuncSetAttribute(ref ? (const void *)mlp_train_backward_kernel<true> : (const void *)mlp_train_backward_kernel<false>,
@@ -467,7 +503,8 @@ hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, co
     const unsigned grid2 = (unsigned)(g2 < 1024 ? (g2 > 0 ? g2 : 1) : 1024);
     if (ref) {
         hipLaunchKernelGGL(ref_heads_backward_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, grad_rgb, rgb, ref->g8, ref->viewdirs, ref->rays, ref->q_ray,
-                           dfeats, ref->grad_in0, m, m_dev, ref->dg8);
+                           dfeats, ref->grad_in0, m, m_dev, ref->dg8, (unsigned *)((unsigned char *)image + TI_SCAL));
+        hipLaunchKernelGGL(heads_scale_kernel, dim3(1), dim3(1), 0, stream, (unsigned *)((unsigned char *)image + TI_SCAL), 4096.0f, (float *)((unsigned char *)image + TI_SCAL) + 1);
         rc = hipGetLastError();
         if (rc != hipSuccess) return rc;
         hipLaunchKernelGGL(basis_backward_kernel<3>, dim3(grid2), dim3(256), 0, stream, dfeats, ref->dg8, m, m_dev, gscale, (const unsigned char *)image, dh, sat_flag);

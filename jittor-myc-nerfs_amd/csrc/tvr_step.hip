@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void composite_train_backward_kernel(const Mar
             gin0[e] = gp * w * (2.0f * q);
         }
         grad_w[e] = gw;
-        v = fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fabsf(a2)) * scale;
+        v = fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fabsf(a2)) * scale;       // (the heads' transpose product has its own scale: tvr_mlp_train.hip)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
@@ -170,6 +170,21 @@ hipError_t launch_composite_train_backward(const MarchOut &mo, int n_rays, long 
                        grad_w, amax_bits);
     hipLaunchKernelGGL(composite_train_backward_rays_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, stream, n_rays, white_bg, pre, g_map, grad_acc);
     hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, stream, amax_bits, target, gscale);
+    return hipGetLastError();
+}
+
+// small device-to-device copies as a kernel (pieces of a gemm_tn / column-sum result into the gradient tensors they belong to): inside a captured graph a
+// kernel node; hipMemcpyAsync nodes of 4..12 bytes from unaligned sources crashed hipGraphInstantiate on this ROCm (tests/test_gpu_fused_step.py, REFTensoRF case)
+__global__ __launch_bounds__(256) void copy_f32_kernel(float *__restrict__ dst, const float *__restrict__ src, const int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+hipError_t launch_copy_f32(float *dst, const float *src, int n, hipStream_t stream)
+{
+    int grid = (n + 255) / 256;
+    if (grid > 64) grid = 64;
+    hipLaunchKernelGGL(copy_f32_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, stream, dst, src, n);
     return hipGetLastError();
 }
 
