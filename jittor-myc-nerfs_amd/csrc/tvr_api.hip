@@ -188,13 +188,15 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
     for (int i = 0; i < 3; ++i) { sh.app_n_comp[i] = d.app_n_comp[i]; sh.app_off[i] = sh.k_app; sh.k_app += d.app_n_comp[i]; }
     HIP_TRY(launch_pack_mlp(p->W1, p->b1, img + TVR_IMG_W1H, img + TVR_IMG_W1L, d.variant == 1 ? 4 : 0, sh, stream));
     HIP_TRY(launch_pack_mlp(p->W2, nullptr, img + TVR_IMG_W2H, img + TVR_IMG_W2L, 1, sh, stream));
-    HIP_TRY(hipMemsetAsync(img + TVR_IMG_B1, 0, 2 * 512 + 4 * TVR_IMG_W3_ROW, stream));       // b3 slot, b2, W3 + zero row: hidden units >= featureC stay zero
-    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(img + TVR_IMG_B2, p->b2, d.featureC * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    // (clears and small copies as KERNELS: tvr_scene_update runs inside a captured training step, and memset / memcpy nodes of a graph replayed back to back
+    //  were observed to run ahead of the previous replay's kernels — tvr_step.hip)
+    HIP_TRY(launch_zero_f32((float *)(img + TVR_IMG_B1), (2 * 512 + 4 * TVR_IMG_W3_ROW) / 4, stream));       // b3 slot, b2, W3 + zero row: hidden units >= featureC stay zero
+    HIP_TRY(launch_copy_f32((float *)(img + TVR_IMG_B3), p->b3, 3, stream));
+    HIP_TRY(launch_copy_f32((float *)(img + TVR_IMG_B2), p->b2, d.featureC, stream));
     HIP_TRY(launch_pack_mlp(p->basis_mat, nullptr, img + TVR_IMG_BASH, s->packed + s->lay.basis_frag, 2, sh, stream));
-    HIP_TRY(hipMemcpy2DAsync(img + TVR_IMG_W3, TVR_IMG_W3_ROW, p->W3, d.featureC * sizeof(float), d.featureC * sizeof(float), 3, hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(s->packed + s->lay.b3, p->b3, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemsetAsync(img + TVR_MLP_IMAGE_BYTES, 0, TVR_MLP_IMAGE_BYTES_REF - TVR_MLP_IMAGE_BYTES, stream));
+    for (int r = 0; r < 3; ++r) HIP_TRY(launch_copy_f32((float *)(img + TVR_IMG_W3 + r * TVR_IMG_W3_ROW), p->W3 + (size_t)r * d.featureC, d.featureC, stream));
+    HIP_TRY(launch_copy_f32((float *)(s->packed + s->lay.b3), p->b3, 3, stream));
+    HIP_TRY(launch_zero_f32((float *)(img + TVR_MLP_IMAGE_BYTES), (TVR_MLP_IMAGE_BYTES_REF - TVR_MLP_IMAGE_BYTES) / 4, stream));
     if (d.variant == 1) {
         for (int i = 0; i < 4; ++i)
             if (!p->ref_W[i] || !p->ref_b[i]) return fail(TVR_ERR_INVALID, "REFTensoRF linear %d (normal, diffuse, specular, rho) is NULL", i);
@@ -299,7 +301,7 @@ static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     mo.lam6 = lam6_out;
 
     hipEvent_t *ev = prof ? &prof->ev[(size_t)prof->n_calls * 4] : nullptr;
-    HIP_TRY(hipMemsetAsync(mo.counter, 0, 16, stream));                // [0] queue length, [1] the march's tile counter, [2] its fault flag
+    HIP_TRY(launch_zero_header(mo.counter, stream));                   // [0] queue length, [1] the march's tile counter, [2] its fault flag, [3] unused here
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, dense, stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
@@ -396,7 +398,7 @@ static int march_forward_impl(tvr_scene *s, const float *rays, int64_t n_rays, i
     hipStream_t stream = (hipStream_t)stream_;
     MarchOut mo = carve_scratch((char *)scratch, L, depth_out);
     mo.lam6 = lam6_out;
-    HIP_TRY(hipMemsetAsync(mo.counter, 0, 16, stream));                // [0] queue length, [1] the march's tile counter, [2] its fault flag
+    HIP_TRY(launch_zero_header(mo.counter, stream));                   // [0] queue length, [1] the march's tile counter, [2] its fault flag, [3] workspace overflow
     HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, nullptr, stream));
     return TVR_OK;
 }
@@ -454,8 +456,8 @@ static int march_backward_impl(tvr_scene *s, const float *rays, int64_t n_rays, 
     TrainGrads tg = carve_grads(s, g);
     for (int i = 0; i < 3; ++i) {
         const size_t W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
-        HIP_TRY(hipMemsetAsync(tg.dplane[i], 0, (H + 1) * (W + 1) * TVR_CD * sizeof(float), stream));
-        HIP_TRY(hipMemsetAsync(tg.dline[i], 0, (Ln + 1) * TVR_CD * sizeof(float), stream));
+        HIP_TRY(launch_zero_f32(tg.dplane[i], (long long)((H + 1) * (W + 1) * TVR_CD), stream));       // (channel counts are multiples of 4, blocks 256-B aligned)
+        HIP_TRY(launch_zero_f32(tg.dline[i], (long long)((Ln + 1) * TVR_CD), stream));
     }
     MarchOut mo = carve_scratch((char *)fwd_scratch, L, nullptr);
     HIP_TRY(launch_march_backward(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, grad_w, grad_acc, lam6, grad_lam6, tg, stream));
@@ -620,8 +622,8 @@ static int app_h_backward_impl(tvr_scene *s, const float *xyz, int xyz_stride, i
     TrainGrads tg = carve_grads(s, (char *)grad_scratch);
     for (int i = 0; i < 3; ++i) {
         const size_t W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
-        HIP_TRY(hipMemsetAsync(tg.aplane[i], 0, (H + 1) * (W + 1) * TVR_CA * sizeof(float), stream));
-        HIP_TRY(hipMemsetAsync(tg.aline[i], 0, (Ln + 1) * TVR_CA * sizeof(float), stream));
+        HIP_TRY(launch_zero_f32(tg.aplane[i], (long long)((H + 1) * (W + 1) * TVR_CA), stream));
+        HIP_TRY(launch_zero_f32(tg.aline[i], (long long)((Ln + 1) * TVR_CA), stream));
     }
     if (m > 0) HIP_TRY(launch_app_h_backward(s->dev, xyz, m, dh, tg, stream, xyz_stride, m_dev));
     for (int i = 0; i < 3; ++i) {

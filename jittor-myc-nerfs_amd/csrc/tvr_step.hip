@@ -188,6 +188,29 @@ hipError_t launch_copy_f32(float *dst, const float *src, int n, hipStream_t stre
     return hipGetLastError();
 }
 
+// zero fill as a kernel.  Inside a captured training step every clear is a KERNEL node: hipMemsetAsync nodes of a graph that is replayed back to back
+// were observed to run ahead of the previous replay's kernels on this ROCm (the scratch header held garbage, the step diverged), round 3.
+__global__ __launch_bounds__(256) void zero_f32_kernel(float4 *__restrict__ p, const long long n4)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+hipError_t launch_zero_f32(float *p, long long n, hipStream_t stream)       // p 16-byte aligned, n a multiple of 4
+{
+    const long long n4 = n / 4;
+    long long grid = (n4 + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)(grid > 0 ? grid : 1)), dim3(256), 0, stream, (float4 *)p, n4);
+    return hipGetLastError();
+}
+
+// the scratch header's four words {queue length, tile counter, fault, overflow} cleared by a kernel (a kernel node inside a captured step)
+__global__ void zero_header_kernel(unsigned *__restrict__ c) { if (threadIdx.x < 4) c[threadIdx.x] = 0u; }
+hipError_t launch_zero_header(unsigned *counter, hipStream_t stream)
+{
+    hipLaunchKernelGGL(zero_header_kernel, dim3(1), dim3(64), 0, stream, counter);
+    return hipGetLastError();
+}
+
 size_t colsum_scratch_bytes() { return (size_t)CS_GRID * 128 * sizeof(float); }
 
 hipError_t launch_colsum(const float *A, int lda, int K, long long m_cap, const unsigned *m_dev, float *out, float *scratch, hipStream_t stream)

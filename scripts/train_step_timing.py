@@ -15,6 +15,8 @@ if world > 1:
 MODEL = os.environ.get("TVR_MODEL", "TensorVMSplit")        # REFTensoRF: what configs/Scar.txt:28 trains (+ the normal penalty, train.py:253-257)
 m, arrs, A = bench.build_model(torch.device("cuda"), MODEL)
 m.fused_mlp_training = bool(int(os.environ.get("TVR_FUSED_MLP", "1")))      # 0: round-1 path (library GEMMs for the MLP forward / dX)
+m.static_training = bool(int(os.environ.get("TVR_STATIC", "1")))           # 1: tvr_train_forward / _backward (no host read); 0: the eager chain of autograd Functions
+GRAPH = bool(int(os.environ.get("TVR_GRAPH", "0")))                        # 1: the whole step (forward, backward, regularisers, Adam) captured once, replayed
 with torch.no_grad():                                  # start from a perturbed copy so that gradients are non-trivial
     for p in m.parameters():
         p.mul_(0.9)
@@ -25,9 +27,9 @@ with torch.no_grad():
     allrgbs = torch.cat([teacher.render_rays(allrays[i:i + 640000], N_samples=512)[0] for i in range(0, allrays.shape[0], 640000)])
     del teacher
 nS = int(np.linalg.norm(A["gridSize"]) / 0.5)
-opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99), fused=bool(int(os.environ.get("TVR_FUSED_ADAM", "1"))))
+opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99), fused=bool(int(os.environ.get("TVR_FUSED_ADAM", "1"))), capturable=GRAPH)
 tv = TVLoss()
-g = torch.Generator(device="cuda").manual_seed(0)
+g = None if GRAPH else torch.Generator(device="cuda").manual_seed(0)       # (under capture: the default generator, whose state torch registers with the graph)
 bucket = GradBucket(m) if (world > 1 or os.environ.get("TVR_BUCKET")) else None    # all gradients in one 70 MB buffer: one all-reduce per step
 def step():
     idx = torch.randint(0, allrays.shape[0], (4096,), device="cuda", generator=g)[shard_batch(4096, rank, world)]
@@ -42,9 +44,37 @@ def step():
     if bucket: bucket.all_reduce_mean()
     opt.step()
     return loss
-for _ in range(3): step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
 N = 20
-for _ in range(N): l = step()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
-if rank == 0: print(f"{MODEL} (fused MLP kernels {int(m.fused_mlp_training)}) train step ({world} rank(s), {4096 // world} rays each): {dt * 1e3:.2f} ms  ({1 / dt:.1f} it/s), batch 4096 rays x {nS} samples, loss {float(l.detach()):.3e}")
+if GRAPH:
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3): step()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    if os.environ.get("TVR_DEBUG_HDR"):
+        import ctypes as C
+        from jittor_myc_nerfs_amd import _lib as L
+        def hdr():
+            b = m._train_buf
+            lay = L.ScratchLayout(); L.check(L.lib().tvr_scratch_describe(b["key"][0], b["key"][1], C.byref(lay)), "d")
+            torch.cuda.synchronize()
+            return b["key"], b["scratch"].data_ptr(), b["scratch"][lay.counter:lay.counter + 32].view(torch.int32).tolist()
+        print("after warm-up", hdr(), flush=True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        l = step()
+    if os.environ.get("TVR_DEBUG_HDR"):
+        print("after capture", hdr(), flush=True)
+        for i in range(4):
+            graph.replay(); print("replay", i, hdr(), flush=True)
+    for _ in range(3): graph.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(N): graph.replay()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
+    fault = m.check_training_faults()                 # (None on a healthy run; 'overflow' means the timed steps worked on a truncated queue)
+    if fault is not None: print("WARNING: check_training_faults() ->", fault)
+else:
+    for _ in range(3): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(N): l = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
+if rank == 0: print(f"{MODEL} (fused MLP kernels {int(m.fused_mlp_training)}, static step {int(m.static_training)}, hipGraph {int(GRAPH)}) train step ({world} rank(s), {4096 // world} rays each): {dt * 1e3:.2f} ms  ({1 / dt:.1f} it/s), batch 4096 rays x {nS} samples, loss {float(l.detach()):.3e}")
