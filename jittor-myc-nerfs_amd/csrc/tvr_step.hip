@@ -122,23 +122,33 @@ __global__ void grad_scale_kernel(unsigned *__restrict__ amax_bits, const float 
     *amax_bits = 0u;
 }
 
-// column sums of A [M, K] (row stride lda, K <= 128), M on the device: workgroup b sums its slab of rows, thread (row lane, column), partials summed by
-// gemm_tn's fixed-order reduction
+// column sums of A [M, K] (row stride lda, K <= 128), M on the device: workgroup b sums its slab of rows — KP = K rounded up to a power of two columns x
+// 256 / KP row lanes, four rows in flight per thread, the row lanes added in a fixed order through LDS — partials summed by colsum_final_kernel.
 #define CS_GRID 512
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ A, const int lda, const int K, const long long m_cap, const unsigned *__restrict__ m_dev,
-                                                             float *__restrict__ P)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ A, const int lda, const int K, const int KP, const long long m_cap,
+                                                             const unsigned *__restrict__ m_dev, float *__restrict__ P)
 {
-    __shared__ float red[128];
+    __shared__ float red[256];
     const long long M = m_dev ? ((long long)*m_dev < m_cap ? (long long)*m_dev : m_cap) : m_cap;
     const long long rpb = (M + CS_GRID - 1) / CS_GRID;
     const long long m0 = (long long)blockIdx.x * rpb, m1 = m0 + rpb < M ? m0 + rpb : M;
-    const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
-    float s = 0.0f;
-    if (c < K)
-        for (long long r = m0 + rl; r < m1; r += 2) s = s + A[r * lda + c];
-    if (rl == 1) red[c] = s;
+    const int RL = 256 / KP, c = threadIdx.x % KP, rl = threadIdx.x / KP;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (c < K) {
+        long long r = m0 + rl;
+        for (; r + 3LL * RL < m1; r += 4LL * RL) {
+            const float a0 = A[r * lda + c], a1 = A[(r + RL) * lda + c], a2 = A[(r + 2LL * RL) * lda + c], a3 = A[(r + 3LL * RL) * lda + c];
+            s0 = s0 + a0; s1 = s1 + a1; s2 = s2 + a2; s3 = s3 + a3;
+        }
+        for (; r < m1; r += RL) s0 = s0 + A[r * lda + c];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (rl == 0 && c < K) P[(size_t)blockIdx.x * K + c] = s + red[c];
+    if (rl == 0 && c < K) {
+        float s = red[c];
+        for (int j = 1; j < RL; ++j) s = s + red[j * KP + c];
+        P[(size_t)blockIdx.x * K + c] = s;
+    }
 }
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ P, const int K, float *__restrict__ out)
@@ -215,7 +225,9 @@ size_t colsum_scratch_bytes() { return (size_t)CS_GRID * 128 * sizeof(float); }
 
 hipError_t launch_colsum(const float *A, int lda, int K, long long m_cap, const unsigned *m_dev, float *out, float *scratch, hipStream_t stream)
 {
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(CS_GRID), dim3(256), 0, stream, A, lda, K, m_cap, m_dev, scratch);
+    int KP = 1;
+    while (KP < K) KP <<= 1;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(CS_GRID), dim3(256), 0, stream, A, lda, K, KP, m_cap, m_dev, scratch);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((K * 16 + 255) / 256), dim3(256), 0, stream, scratch, K, out);
     return hipGetLastError();
 }
