@@ -162,3 +162,34 @@ def test_workspace_overflow_is_flagged_not_truncated(tiny_dump, tiny_arrays, hyp
     with torch.no_grad():
         ref, _ = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
     assert float((rgb2.detach() - ref).abs().max()) < 2e-6
+
+
+def test_saturation_flag_rises_and_the_lowered_scale_gives_right_gradients(tiny_dump, tiny_arrays, hyper_tiny):
+    """The fused backward scales gradients by a power of two (max |grad_rgb| -> grad_scale_target, default 64) on their way through fp16 operands, whose
+    conversion saturates silently at 65 504; |dH1| <= 128 |W2| 3 |W3| target, so large weights — or, here, a target set far too high — run the chain into
+    that limit.  The kernels must SAY so (device flag -> check_training_faults() == 'saturated', target lowered by 2^4 per call), and once the flag stays
+    clear the step must agree with the library-GEMM path."""
+    rays = _batch(tiny_dump, 8)
+    cw = torch.randn((rays.shape[0], 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+
+    def grads(m):
+        for p in _params(m):
+            p.grad = None
+        rgb, _ = m.render_rays_autograd(rays, white_bg=True, N_samples=TINY["N_samples"])
+        (rgb * cw).sum().backward()
+        return [p.grad.clone() for p in _params(m)]
+    m = make_model(tiny_arrays, hyper_tiny)
+    m.grad_scale_target = 2.0 ** 24
+    grads(m)
+    assert m.check_training_faults() == "saturated" and m.grad_scale_target == 2.0 ** 20
+    for _ in range(8):
+        g = grads(m)
+        if m.check_training_faults() is None:
+            break
+    else:
+        raise AssertionError("the saturation flag did not clear")
+    assert 1.0 <= m.grad_scale_target < 2.0 ** 20
+    lib = make_model(tiny_arrays, hyper_tiny)
+    lib.static_training = lib.fused_mlp_training = False
+    for x, y in zip(g, grads(lib)):
+        assert bool(torch.isfinite(x).all()) and _close(x, y, 2e-4)
