@@ -56,6 +56,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SH_TILE 32
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+#ifndef TVR_PRIO_F
+#define TVR_PRIO_F 0      // s_setprio of finish_tile (layer 3 + store), see the call site
+#endif
 #ifndef TVR_PRIO_G
 #define TVR_PRIO_G 2      // s_setprio while a wave is in its gather phase / its matrix phase.  The gather phase is a dependent chain of loads and
 #define TVR_PRIO_M 0      // short VALU bursts: when its instructions win arbitration against the partner's MFMA stream the tile takes 6 % less
@@ -703,7 +706,11 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         cur.ent = ent; cur.live = live; cur.wq = wq;
         cur.g[0] = G[3]; cur.g[1] = G[4]; cur.g[2] = G[5]; cur.g[3] = G[6];
         TVR_LEAVE_MATRIX();
+        // layer 3 + store run at the LOWEST priority: their 320 VALU ops need no particular moment, the partner's matrix phase needs every issue slot it
+        // can get (12.66 vs 12.75 ms against running them at the gather's priority, two interleaved rounds; priorities 1 and 3: 12.73 / 12.75)
+        __builtin_amdgcn_s_setprio(TVR_PRIO_F);
         finish_tile<DST, REF, HAVE_G>(cur, smem, a, h);
+        __builtin_amdgcn_s_setprio(TVR_PRIO_G);
         TVR_STAMP(tg4);
 #if TVR_TIMING
         tsum[0] += tgF - tgD; tsum[5] += tgD - tg0; tsum[1] += tg1 - tgF; tsum[6] += tgW - tg1; tsum[2] += tg2 - tgW; tsum[3] += tg3 - tg2; tsum[4] += tg4 - tg3;
