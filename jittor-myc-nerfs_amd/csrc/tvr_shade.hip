@@ -779,9 +779,31 @@ __global__ __launch_bounds__(256) void pack_plane_kernel(const float *__restrict
     }
 }
 
+// planes: one workgroup per (row y, 64 columns): the reads run along x of each channel, the writes along the packed row — both coalesced through an LDS tile
+// (the element-per-thread kernel above reads with a stride of H*W floats: 9.6 us per plane, 12 planes per training step)
+#define PK_TILE 64
+__global__ __launch_bounds__(256) void pack_plane_tiled_kernel(const float *__restrict__ in, float *__restrict__ out, int Cin, int C, int H, int W, int Wp)
+{
+    __shared__ float tile[PK_TILE][TVR_CA + 1];
+    const int y = blockIdx.y, x0 = blockIdx.x * PK_TILE;
+    for (int k = threadIdx.x; k < C * PK_TILE; k += 256) {
+        const int c = k / PK_TILE, xx = k - c * PK_TILE, x = x0 + xx;
+        tile[xx][c] = (y < H && x < W && c < Cin) ? in[((size_t)c * H + y) * W + x] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C * PK_TILE; k += 256) {
+        const int xx = k / C, c = k - xx * C, x = x0 + xx;
+        if (x < Wp) out[((size_t)y * Wp + x) * C + c] = tile[xx][c];
+    }
+}
+
 hipError_t launch_pack_plane(const float *in, float *out, int Cin, int C, int H, int W, hipStream_t stream)
 {
     const int Wp = (W == 1) ? 1 : W + 1;
+    if (W > 1 && C <= TVR_CA) {
+        hipLaunchKernelGGL(pack_plane_tiled_kernel, dim3((unsigned)((Wp + PK_TILE - 1) / PK_TILE), (unsigned)(H + 1)), dim3(256), 0, stream, in, out, Cin, C, H, W, Wp);
+        return hipGetLastError();
+    }
     const long long total = (long long)(H + 1) * Wp * C;
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
