@@ -36,7 +36,11 @@
 #define MARCH_MAX_WAVES 16
 #define MARCH_TILE 16                     // rays per tile
 #define MARCH_SPIN_LIMIT (1u << 22)       // s_sleep(1) each: ~0.15 s, against a legitimate wait of microseconds
-#define MARCH_HDR 304                     // LDS header: ray cursor (16 B) + 32 slots of {local tile number + 1, global tile} (dynamic tile queue) + 3 u64 statistics sums + pad
+#define MARCH_SLOTS 64u                   // ring of published handouts (a waiter's slot is reused 64 local tiles = 1024 cursor draws later)
+#ifndef MARCH_TAIL
+#define MARCH_TAIL 4u                     // rays per handout at the end of a launch (16u = off)
+#endif
+#define MARCH_HDR 560                     // LDS header: ray cursor (16 B) + 64 slots of {local tile number + 1 | tail bit, first ray} (dynamic queue) + 3 u64 statistics sums + pad
 #ifndef TVR_MARCH_DYN
 #define TVR_MARCH_DYN 1                   // 1: workgroups take 16-ray tiles from ONE global counter (in order), not a fixed stride: no tail when a launch has few tiles per group
 #endif
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
 #endif
     if (threadIdx.x == 0) *cursor = 0u;
     unsigned long long *slots = (unsigned long long *)(lds_raw + 16);
-    if (threadIdx.x < 32) slots[threadIdx.x] = 0ull;
-    unsigned long long *gstat = (unsigned long long *)(lds_raw + 272);       // per-group sums of the three counters: ONE global atomic each per group
+    if (threadIdx.x < MARCH_SLOTS) slots[threadIdx.x] = 0ull;
+    unsigned long long *gstat = (unsigned long long *)(lds_raw + 16 + 8 * MARCH_SLOTS);       // per-group sums of the three counters: ONE global atomic each per group
     if (threadIdx.x < 3) gstat[threadIdx.x] = 0ull;                           // (4096 same-address atomics per launch cost a 4096-ray call ~100 us)
     if (LDSL) {
         float4 *dst = (float4 *)(lds_raw + MARCH_HDR);
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
 
     // this group's tiles: XCD x (groups x, x+8, ...: observed round-robin dispatch) owns a contiguous tile range; speed only
     const int n_tiles = (n_rays + MARCH_TILE - 1) / MARCH_TILE;
+    (void)n_tiles;
 #if !TVR_MARCH_RASTER
     const int nx = gridDim.x < 8u ? (int)gridDim.x : 8;
     const int xcd = blockIdx.x % nx, bi = blockIdx.x / nx, nbx = ((int)gridDim.x - xcd + nx - 1) / nx;
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
 #endif
 
     unsigned long long st_eval = 0, st_bbox = 0, st_term = 0;
+    int last_start = 0;                                  // first ray of this wave's previous handout (dynamic queue: picks the tail granularity)
 
     for (;;) {
         unsigned ci = 0;
@@ -147,30 +153,44 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
 #if TVR_MARCH_DYN
         // the wave that draws the first ray of local tile k takes the next global tile and publishes it {k + 1, tile} in slot k & 31; the others
         // wait for the slot's generation to become k + 1.  Why the wait ends: the publisher stores right behind its draw (one global atomic,
-        // ~2 us), and the slot is only overwritten by the publisher of local tile k + 32, which needs the group's cursor to advance by 512 rays
-        // first — 34 rays per partner wave, >= 1 us each even when they miss the box.  The wait is nevertheless BOUNDED and a miss is LOUD:
+        // ~2 us), and the slot is only overwritten by the publisher of local tile k + 64, which needs the group's cursor to advance by 1024 draws
+        // and 64 later publishers to have finished their own global atomic first.  The wait is nevertheless BOUNDED and a miss is LOUD:
         // a waiter that finds a later generation in its slot (it was overtaken) or spins MARCH_SPIN_LIMIT times raises mo.counter[2], stops
         // drawing rays, and the composite kernel then writes NaN to every pixel of the call (tvr.h: tvr_scratch_layout.counter).
-        int tile;
+        // Round 3: the counter counts RAYS, and a handout is 16 rays (a tile: concurrent neighbours share texels in L1) until the launch's last
+        // 2 x 16 x groups rays, which go out 4 at a time: the groups then end within one ray of each other instead of two (a group that draws a
+        // whole tile just before the counter runs out works 2 x 60 us after everybody else stopped drawing).  Measured on rank 0's share of an 8-way
+        // split (81 920 rays, interleaved A/B on one box): 1.03 - 1.06 ms against 1.06 - 1.07 — about 1 %; the rest of that share's loss against 1/8
+        // of a frame (0.98 ms) is the ramp at both ends of a launch whose unit of work is a whole ray.  Local tiles keep 16 cursor positions;
+        // positions >= the handout's length are no-ops.
+        int ray_start, ray_len;
         {
-            const unsigned k = ci / MARCH_TILE, slot = k & 31u;
+            const unsigned k = ci / MARCH_TILE, slot = k & (MARCH_SLOTS - 1u);
             if ((ci % MARCH_TILE) == 0u) {
-                unsigned t = 0;
+                unsigned t = 0, len = MARCH_TILE;
                 if (lane == 0) {
-                    t = atomicAdd(mo.counter + 1, 1u);
+                    // how far the launch is: the first ray of THIS wave's previous handout (a register; one ray-time stale, the tail zone is two tiles per
+                    // group wide).  Not a fresh look at the counter: an agent-scope load of that line between the atomics of 4096 waves cost the kernel
+                    // 30 % (10.1 vs 7.7 ms: every system-coherent read forces the line the queue-length atomics hammer out of L2).
+                    // (launches of fewer than 8 tiles per group keep whole tiles: there the 16 concurrent neighbours' shared texels matter more than the tail)
+                    if ((long long)n_rays >= 8LL * MARCH_TILE * (long long)gridDim.x && (long long)last_start + 2LL * MARCH_TILE * (long long)gridDim.x >= (long long)n_rays)
+                        len = MARCH_TAIL;
+                    t = atomicAdd(mo.counter + 1, len);
+                    const unsigned long long genw = (unsigned long long)(k + 1u) | (len == MARCH_TAIL ? 0x80000000ull : 0ull);
 #ifdef TVR_FAULT_INJECT_MARCH                          // test build only (tests/test_gpu_faults.py): the publisher of local tile 3 of group 0 skips a generation
-                    if (blockIdx.x == 0 && k == 3u) __hip_atomic_store(&slots[slot], ((unsigned long long)(k + 33u) << 32) | t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (blockIdx.x == 0 && k == 3u) __hip_atomic_store(&slots[slot], ((unsigned long long)(k + 1u + MARCH_SLOTS) << 32) | t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else
 #endif
-                    __hip_atomic_store(&slots[slot], ((unsigned long long)(k + 1u) << 32) | t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&slots[slot], (genw << 32) | t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                tile = (int)__builtin_amdgcn_readfirstlane(t);
+                ray_start = (int)__builtin_amdgcn_readfirstlane(t);
+                ray_len = (int)__builtin_amdgcn_readfirstlane(len);
             } else {
                 unsigned long long v;
                 unsigned spins = 0u, fault = 0u;
                 for (;;) {
                     v = __hip_atomic_load(&slots[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const unsigned gen = (unsigned)(v >> 32);
+                    const unsigned gen = (unsigned)(v >> 32) & 0x7fffffffu;
                     if (gen == k + 1u) break;
                     if (gen > k + 1u) { fault = 1u; break; }                       // overtaken: this tile's number is gone
                     if (++spins > MARCH_SPIN_LIMIT) { fault = 2u; break; }         // the publisher never stored
@@ -180,19 +200,26 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
                     if (lane == 0) atomicOr(mo.counter + 2, fault);
                     break;
                 }
-                tile = (int)(unsigned)v;
+                ray_start = (int)(unsigned)v;
+                ray_len = (v >> 63) ? MARCH_TAIL : MARCH_TILE;
             }
         }
-        if (tile >= n_tiles) break;
+        if (ray_start >= n_rays) break;
+        if ((int)(ci % MARCH_TILE) >= ray_len) continue;
+        last_start = ray_start;
+        const int ray = ray_start + (int)(ci % MARCH_TILE);
+        if (ray >= n_rays) continue;
 #elif TVR_MARCH_RASTER
         const int tile = (int)(ci / MARCH_TILE) * (int)gridDim.x + (int)blockIdx.x;     // all groups sweep the image together
         if (tile >= n_tiles) break;
+        const int ray = tile * MARCH_TILE + (int)(ci % MARCH_TILE);
+        if (ray >= n_rays) continue;
 #else
         const int tile = t0 + (int)(ci / MARCH_TILE) * nbx + bi;
         if (tile >= t1) break;
-#endif
         const int ray = tile * MARCH_TILE + (int)(ci % MARCH_TILE);
         if (ray >= n_rays) continue;
+#endif
         float o[3], d[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
