@@ -37,6 +37,9 @@
 #define MARCH_TILE 16                     // rays per tile
 #define MARCH_SPIN_LIMIT (1u << 22)       // s_sleep(1) each: ~0.15 s, against a legitimate wait of microseconds
 #define MARCH_SLOTS 64u                   // ring of published handouts (a waiter's slot is reused 64 local tiles = 1024 cursor draws later)
+#ifndef MARCH_CTR_WORD
+#define MARCH_CTR_WORD 1                  // word of the scratch header that counts handed-out rays (its own 128-B line, word 32, measured the same: 7.55 vs 7.58 ms)
+#endif
 #ifndef MARCH_TAIL
 #define MARCH_TAIL 4u                     // rays per handout at the end of a launch (16u = off)
 #endif
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
                     // (launches of fewer than 8 tiles per group keep whole tiles: there the 16 concurrent neighbours' shared texels matter more than the tail)
                     if ((long long)n_rays >= 8LL * MARCH_TILE * (long long)gridDim.x && (long long)last_start + 2LL * MARCH_TILE * (long long)gridDim.x >= (long long)n_rays)
                         len = MARCH_TAIL;
-                    t = atomicAdd(mo.counter + 1, len);
+                    t = atomicAdd(mo.counter + MARCH_CTR_WORD, len);
                     const unsigned long long genw = (unsigned long long)(k + 1u) | (len == MARCH_TAIL ? 0x80000000ull : 0ull);
 #ifdef TVR_FAULT_INJECT_MARCH                          // test build only (tests/test_gpu_faults.py): the publisher of local tile 3 of group 0 skips a generation
                     if (blockIdx.x == 0 && k == 3u) __hip_atomic_store(&slots[slot], ((unsigned long long)(k + 1u + MARCH_SLOTS) << 32) | t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -214,7 +214,7 @@ hipError_t launch_zero_f32(float *p, long long n, hipStream_t stream)       // p
 }
 
 // the scratch header's four words {queue length, tile counter, fault, overflow} cleared by a kernel (a kernel node inside a captured step)
-__global__ void zero_header_kernel(unsigned *__restrict__ c) { if (threadIdx.x < 4) c[threadIdx.x] = 0u; }
+__global__ void zero_header_kernel(unsigned *__restrict__ c) { c[threadIdx.x] = 0u; }       // the whole 256-B header (64 words; word 32: the march's ray counter)
 hipError_t launch_zero_header(unsigned *counter, hipStream_t stream)
 {
     hipLaunchKernelGGL(zero_header_kernel, dim3(1), dim3(64), 0, stream, counter);
