@@ -324,11 +324,22 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
         have_tok = !got_;                                                                   \
     } while (0)
 #define TVR_TOKEN_GIVE(t) do { if (have_tok && lane == 0) atomicExch((t), 0); } while (0)
+#ifndef TVR_TOKEN_PHASE
+#define TVR_TOKEN_PHASE 1     // which phase the per-SIMD token makes mutually exclusive: 1 the matrix phase (shipped); 2 the GATHER phase (experiment: the two
+#endif                        // waves' matrix phases may then overlap — one's splits / sin / cos under the other's MFMAs — and "both gathering, pipe idle" cannot happen)
+#if TVR_TOKEN_PHASE == 1
 #define TVR_ENTER_MATRIX() do { TVR_TOKEN_TAKE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_M); } while (0)
 #define TVR_LEAVE_MATRIX() do { TVR_TOKEN_GIVE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_G); } while (0)
+#define TVR_ENTER_GATHER()
+#else
+#define TVR_ENTER_MATRIX() do { TVR_TOKEN_GIVE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_M); } while (0)
+#define TVR_LEAVE_MATRIX() __builtin_amdgcn_s_setprio(TVR_PRIO_G)
+#define TVR_ENTER_GATHER() TVR_TOKEN_TAKE(mtok)
+#endif
 #else
 #define TVR_ENTER_MATRIX() __builtin_amdgcn_s_setprio(TVR_PRIO_M)
 #define TVR_LEAVE_MATRIX() __builtin_amdgcn_s_setprio(TVR_PRIO_G)
+#define TVR_ENTER_GATHER()
 #endif
 // REFTensoRF's second row block on the same h fragments (REFTensoRF.py:126-132): A from the LDS image (8 weight rows; lanes 4..6 re-read the
 // normal rows so that both lane halves hold the normal, every other lane reads the zero row), biases as the initial accumulator.
@@ -437,6 +448,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         unsigned long long tg0 = 0, tgD = 0, tgF = 0, tg1 = 0, tgW = 0, tg2 = 0, tg3 = 0, tg4 = 0;
 #endif
         TVR_STAMP(tg0);
+        TVR_ENTER_GATHER();
         // ---------------------------------------------------------------- GATHER phase: global loads + VALU + LDS, no MFMA ----
         TVR_STAMP(tgD);
         // queue entry: fetched one tile ahead (the loads are issued in the previous tile's gather phase and have landed by its phase
