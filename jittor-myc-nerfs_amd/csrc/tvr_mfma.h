@@ -16,7 +16,9 @@ __device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__f
 // fp32 pair -> packed fp16 hi and lo words (x = hi + lo up to ~2^-22 |x|; round-toward-zero never overflows to inf).  x - hi is one
 // v_fma_mix_f32 reading the packed half in place (exact in fp32), then one v_cvt_pkrtz per pair: 4 VALU per pair.  (Measured alternative:
 // v_fma_mixlo_f16 + v_fma_mixhi_f16 write the rounded residuals straight into the two halves of the lo word, 3 VALU per pair, -108 VALU per
-// shade tile — and 1 % SLOWER, 12.89 -> 13.0 ms: the second op depends on the first through the destination register.)
+// shade tile — and 1 % SLOWER, 12.89 -> 13.0 ms: the second op depends on the first through the destination register.  Round 3: the same with the
+// four low halves first and the four high halves behind them in one asm block, no op following the one whose destination it completes: 13.20 vs 12.72 ms —
+// the mixlo / mixhi forms are half rate, scripts/hwprobe/valu_rate.hip.)
 // The residuals come out of inline asm; gfx950 needs ONE instruction between a VALU write and an MFMA read of the register
 // (scripts/hwprobe/mfma_raw2.hip); here they pass through the compiler-visible v_cvt_pkrtz, and scripts/isa_check.py (R4) checks the shipped ISA.
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
