@@ -258,6 +258,27 @@ def collect_pmc(extra_args, budget_s=420.0, passes=None):
                  "; traffic = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B; gfx950 tallies 128-B reads at 64 B, MI355X_MICROARCH.md HBM section)")
 
 
+def other_configs(budget_s=240.0):
+    import subprocess
+    out, t0 = {}, time.time()
+    for key, extra in (("configs[3]: TensorVMSplit 300^3, 800x800 x 512 as 157 tvr_render calls of 4096 rays", ["--chunk", "4096"]),
+                       ("configs[4]: JNeRF Instant-NGP inference, 800x800, fused frame path", ["--model", "NGPNetworks"])):
+        if time.time() - t0 > budget_s:
+            out[key] = "skipped: time budget"
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--pmc", "off", *extra]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=200, env=dict(os.environ))
+            d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            out[key] = {k: d[k] for k in ("value", "unit", "ms_per_step", "rays_per_sec", "steps", "kernel_ms") if k in d}
+            if not any(v for k, v in out[key].get("kernel_ms", {}).items() if k != "calls"):
+                out[key].pop("kernel_ms", None)                       # chunked calls are not timed per kernel
+            out[key]["command"] = "python bench.py " + " ".join(cmd[2:])
+        except Exception as e:                                      # never let an extra line break the contract line
+            out[key] = f"failed: {type(e).__name__}"
+    return out
+
+
 def _pmc_kernel(pmc, prefix):
     for k, v in pmc.items():
         if k.startswith(prefix):
@@ -284,6 +305,7 @@ def main():
                          "(per-GPU work fixed)")
     ap.add_argument("--emulate-world", type=int, default=0, help="single GPU: render only rank 0's share of an N-way strong split (no exchange)")
     ap.add_argument("--check", action="store_true", help="N > 1: every rank also renders the whole batch alone and compares the gathered pixels bit for bit")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1 default workload: do not append the BASELINE configs[3] / configs[4] lines (child runs of this script)")
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto", help="auto: rank 0 at N = 1 measures roofline.traffic with rocprofv3 --pmc child passes")
     ap.add_argument("--img", type=int, default=int(os.environ.get("TVR_BENCH_IMG", "800")), help="frame edge in pixels (800 = the BASELINE workload; "
                                                                                               "smaller only for rehearsals / tests)")
@@ -582,6 +604,11 @@ def main():
         result["cpu_baseline"] = cpu_baseline(arrs, A, fr[0], with_c=(args.model == "TensorVMSplit"))
     elif rank == 0:
         result["cpu_baseline"] = None
+    # The other single-GPU lines of BASELINE.json, measured by THIS run (child processes of this script, after the timed region, so that whoever runs the
+    # default command also gets them): configs[3] = the same frame as 157 direct 4096-ray tvr_render calls (train.py's batch size, no chunk merging),
+    # configs[4] = the JNeRF Instant-NGP alt path.  Informational: `value` above is configs[1].
+    if rank == 0 and world == 1 and default_workload and not args.no_extras and not args.no_cpu_baseline:
+        result["other_configs"] = other_configs()
     L.lib().tvr_profile_destroy(prof)
     L.lib().tvr_profile_destroy(prof_w)
     if rank == 0:
