@@ -111,6 +111,29 @@ def cpu_baseline(arrs, A, rays_cpu, budget_s=15.0, with_c=True):
     return out
 
 
+_JSON_FD = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner on stdout at communicator
+    creation): point fd 1 at stderr for the run and keep the real stdout for the line."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(result):
+    line = (json.dumps(result) + "\n").encode()
+    sys.stdout.flush()
+    if _JSON_FD is None:
+        sys.stdout.buffer.write(line)
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def bench_ngp(args, world, rank, device):
     """BASELINE configs[4]: JNeRF Instant-NGP inference, one 800x800 frame per step through the fused frame path (tvr_ngp_render).  The
     path has no exchange step: for N > 1 every rank renders its own frames (replicas only)."""
@@ -201,7 +224,7 @@ def bench_ngp(args, world, rank, device):
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     if world > 1:
         dist.destroy_process_group()
 
@@ -305,11 +328,14 @@ def main():
                          "(per-GPU work fixed)")
     ap.add_argument("--emulate-world", type=int, default=0, help="single GPU: render only rank 0's share of an N-way strong split (no exchange)")
     ap.add_argument("--check", action="store_true", help="N > 1: every rank also renders the whole batch alone and compares the gathered pixels bit for bit")
+    ap.add_argument("--one-rank-exchange", action="store_true", help="N = 1 rehearsal of the N > 1 step on the RCCL backend: a one-rank `nccl` process group, the send "
+                                                                      "buffer, all_gather_into_tensor and the un-permute, with --check (the only way one card can run the nccl branch)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 default workload: do not append the BASELINE configs[3] / configs[4] lines (child runs of this script)")
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto", help="auto: rank 0 at N = 1 measures roofline.traffic with rocprofv3 --pmc child passes")
     ap.add_argument("--img", type=int, default=int(os.environ.get("TVR_BENCH_IMG", "800")), help="frame edge in pixels (800 = the BASELINE workload; "
                                                                                               "smaller only for rehearsals / tests)")
     args = ap.parse_args()
+    quiet_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -321,7 +347,7 @@ def main():
     if torch.cuda.device_count() == 0:                              # (counting devices does not initialise the GPU)
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
     pmc, pmc_source = {}, "not collected (--pmc off, N > 1, or a non-default workload)"
-    default_workload = args.model == "TensorVMSplit" and args.chunk == 0 and args.emulate_world == 0 and args.img == 800
+    default_workload = args.model == "TensorVMSplit" and args.chunk == 0 and args.emulate_world == 0 and args.img == 800 and not args.one_rank_exchange
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()              # (rehearsals may put several ranks on one card)
@@ -330,8 +356,12 @@ def main():
     import torch.distributed as dist
     if args.model == "NGPNetworks":
         return bench_ngp(args, world, rank, device)
-    if world > 1:
+    dist_on = world > 1 or args.one_rank_exchange                   # the exchange path runs (one-rank rehearsal: world stays 1)
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(36100 + os.getpid() % 2000)), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         backend = os.environ.get("TVR_BENCH_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm; "gloo" only for 1-GPU rehearsals
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -348,7 +378,7 @@ def main():
         A = dict(A, img_wh=(args.img, args.img))
     fr = frames(A)                                                  # 8 poses x [img*img,6] on the host
     R1 = fr[0].shape[0]
-    strong = args.scaling == "strong" and world > 1
+    strong = args.scaling == "strong" and dist_on
     split = world if world > 1 else max(args.emulate_world, 1)      # ways the step's batch is cut (emulation: only rank 0's share is rendered)
     frames_per_step = 1 if (strong or world == 1) else world
     R_step = frames_per_step * R1                                   # rays per step, whole job
@@ -361,14 +391,14 @@ def main():
         batch = torch.cat([fr[(pat * frames_per_step + r) % N_POSES] for r in range(frames_per_step)]) if frames_per_step > 1 else fr[pat % N_POSES]
         idx = shard_indices(R_step, rank, split, TILE)
         step_rays.append(batch[idx].contiguous().to(device))
-        if world > 1 and (args.check or strong):
+        if dist_on and (args.check or strong):
             full_rays.append(batch.to(device))
     n_mine = step_rays[0].shape[0]
     # the send buffer of the exchange: [rgb block 3 cap | depth block cap] fp32; the render kernels write straight into views of it
     mine = torch.zeros((4 * cap,), device=device)
-    send_views = shard_send_views(mine, cap, n_mine) if world > 1 else None
-    gathered = torch.empty((world * 4 * cap,), device=device) if world > 1 else None
-    gloo = world > 1 and dist.get_backend() == "gloo"
+    send_views = shard_send_views(mine, cap, n_mine) if dist_on else None
+    gathered = torch.empty((world * 4 * cap,), device=device) if dist_on else None
+    gloo = dist_on and dist.get_backend() == "gloo"
 
     prof = C.c_void_p()
     L.check(L.lib().tvr_profile_create(max(args.steps, 1), C.byref(prof)), "tvr_profile_create")
@@ -381,7 +411,7 @@ def main():
             rgb, depth = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
         else:
             rgb, depth = model.render_rays(rays, white_bg=True, N_samples=S, eps_T=args.eps_T, stats=stats, profile=profile, out=send_views)
-        if world > 1:
+        if dist_on:
             if args.chunk > 0:
                 send_views[0].copy_(rgb)
                 send_views[1].copy_(depth)
@@ -402,7 +432,7 @@ def main():
     for s in range(args.warmup):
         step(s, profile=prof_w if prof_in_region else None)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     # the interpreter's cyclic collector is parked for the timed region: a full collection of this process's heap takes ~40 ms of host time
@@ -420,7 +450,7 @@ def main():
     torch.cuda.synchronize()
     if trace is not None:
         print("host time after each step call (ms):", [round(t * 1e3, 2) for t in trace], "after sync: %.2f" % ((time.perf_counter() - t0) * 1e3), file=sys.stderr)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -429,7 +459,7 @@ def main():
         for s in range(args.steps):
             step(args.warmup + s, profile=prof)
         torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -442,7 +472,7 @@ def main():
         k_ms = [0.0, 0.0, 0.0]
 
     check = None
-    if args.check and world > 1:                                   # outside the timed region
+    if args.check and dist_on:                                     # outside the timed region
         ok = True
         for pat in range(n_patterns):
             rgb_g, depth_g = step(pat)
@@ -596,6 +626,8 @@ def main():
         "roofline": dominant,
         "roofline_all": {"march": roof_march, "shade": roof_shade},
     }
+    if dist_on:
+        result["exchange_backend"] = dist.get_backend() + (" (one-rank rehearsal: the process group has ONE member)" if world == 1 else "")
     if check is not None:
         result["check"] = check
     if strong_split is not None:
@@ -612,8 +644,8 @@ def main():
     L.lib().tvr_profile_destroy(prof)
     L.lib().tvr_profile_destroy(prof_w)
     if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+        emit(result)
+    if dist_on:
         dist.destroy_process_group()
 
 

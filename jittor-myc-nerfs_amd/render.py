@@ -111,16 +111,18 @@ def shard_unpermute(gathered: torch.Tensor, n_rays: int, world: int, cap: int, t
 
 
 def render_sharded(rays: torch.Tensor, render_fn: Callable[..., Tuple[torch.Tensor, torch.Tensor]],
-                   rank: int, world: int, tile: int = 4096, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                   rank: int, world: int, tile: int = 4096, group=None, exchange_at_world1: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Render `rays` [R,6] (the full batch, present on every rank) across `world` ranks.
 
     render_fn(rays_subset, out=(rgb [n,3], depth [n])) renders on this rank's device INTO `out` (field.render_rays does; a render_fn without
     an `out` parameter is called plainly and its result copied).  Returns the full (rgb [R,3], depth [R]) on every rank after ONE all_gather of
-    the [4 cap] fp32 send buffers (rgb block, then depth block) and two strided copies that undo the tile interleave (shard_unpermute)."""
+    the [4 cap] fp32 send buffers (rgb block, then depth block) and two strided copies that undo the tile interleave (shard_unpermute).
+    world == 1 renders plainly — unless `exchange_at_world1` (a rehearsal: send buffer, all_gather and un-permute run on a one-member group,
+    which is how a single card exercises the RCCL branch)."""
     import inspect
     import torch.distributed as dist
     R = rays.shape[0]
-    if world == 1:
+    if world == 1 and not exchange_at_world1:
         return render_fn(rays)
     idx = shard_indices(R, rank, world, tile).to(rays.device)
     cap = shard_capacity(R, world, tile)

@@ -134,6 +134,72 @@ def test_bench_step_world2_on_one_card(scaling, img, tmp_path):
         assert d["config"]["rays_per_rank"] <= (img * img + 4095) // 4096 // 2 * 4096 + 4096
 
 
+# ---- the RCCL backend itself, as far as ONE card can run it: a one-member `nccl` process group -----------------------------------------
+def _rccl_worker(port, arrs, hyper, rays_np, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from conftest import make_model as mk
+    from jittor_myc_nerfs_amd import render_sharded
+    from jittor_myc_nerfs_amd.training import GradBucket
+    m = mk(arrs, hyper)
+    m.eps_T = 0.0
+    rays = torch.tensor(rays_np, device="cuda")
+    rgb1, depth1 = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
+    out = {"backend": dist.get_backend()}
+    for tile in (16, 4096):
+        rgb, depth = render_sharded(rays, lambda r, out=None: m.render_rays(r, white_bg=True, N_samples=TINY["N_samples"], out=out), 0, 1, tile=tile,
+                                    exchange_at_world1=True)
+        out[tile] = bool(torch.equal(rgb, rgb1) and torch.equal(depth, depth1))
+    # the training side's one collective: the flat gradient bucket through an RCCL all_reduce (a one-member SUM returns its input)
+    b = GradBucket(m)
+    b.flat.copy_(torch.arange(b.numel, device="cuda", dtype=torch.float32) % 97)
+    want = b.flat.clone()
+    dist.all_reduce(b.flat, op=dist.ReduceOp.SUM)
+    b.all_reduce_mean()
+    out["bucket"] = bool(torch.equal(b.flat, want))
+    torch.cuda.synchronize()
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_render_sharded_over_rccl_with_one_rank(tiny_arrays, hyper_tiny, tiny_dump, tiny_edge):
+    """`backend="nccl"` IS RCCL on ROCm.  Two ranks cannot share a card under RCCL, so the branch the 8-GPU run takes (device-side
+    all_gather_into_tensor on the send buffer, no host staging) is run here with ONE rank: same code, a one-member communicator."""
+    base = np.concatenate([tiny_dump["rays"], tiny_edge["rays"]])
+    rays = np.concatenate([base] * 140)[:9001].copy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(33500 + os.getpid() % 2000, tiny_arrays, hyper_tiny, rays, q))
+    p.start()
+    out = q.get(timeout=400)
+    p.join(120)
+    assert p.exitcode == 0
+    assert out["backend"] == "nccl" and out[16] and out[4096] and out["bucket"], out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_exchange_over_rccl_with_one_rank():
+    """bench.py's N > 1 step (send buffer, RCCL all_gather_into_tensor, un-permute, barriers, max-over-ranks) on the full 800x800 frame with a
+    one-member `nccl` group, `--check`ed bit for bit against the plain render."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TVR_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--one-rank-exchange", "--check", "--no-cpu-baseline", "--pmc", "off"],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["exchange_backend"].startswith("nccl") and d["check"] == "gathered == single-rank render, bit for bit"
+    assert d["n_gpus"] == 1 and d["config"]["rays_per_step"] == 640000 and d["strong_split"]["N"] == 1
+
+
 def test_shard_gather_index_is_the_inverse_of_the_tile_interleave():
     """CPU: image[i] = gathered[inv[i]] for every (rays, world, tile) — ragged last tiles, more ranks than tiles, one rank; and the strided
     un-permute of the [rgb block | depth block] send buffers (shard_send_views / shard_unpermute) returns the same frame."""
