@@ -17,7 +17,11 @@
 
 #define TB_WAVES 16                      // march_backward: one ray per wave, 16 rays per workgroup
 #define TB_THREADS (64 * TB_WAVES)
-#define AHB_THREADS 192                  // 4 entries x 48 channels per pass
+#ifndef TB_DIAG
+#define TB_DIAG 0                        // timing experiments only: 1 no line atomics, 2 no pass C, 4 no plane atomics, 8 no pass A
+#endif
+#define TB_STAGE (2 * 3 * 16 * TVR_CD)   // floats per wave: [Q | P] of 3 pairs x 16 samples x 16 channels (pass A -> pass C)
+#define AHB_THREADS 1024                 // 16 waves, each walking AHB_ENTRIES / 16 consecutive entries with one lane per channel
 #define AHB_ENTRIES 2048                 // app_h_backward: queue entries per workgroup (per plane)
 
 template <int CTRL>
@@ -131,55 +135,146 @@ __device__ __forceinline__ void scatter_ch(const float *__restrict__ Pl, const f
     atomicAdd(q + TVR_CD, wl * gQ);
 }
 
-// Run-length accumulation of the plane gradients: consecutive samples of a ray (half a voxel apart) mostly fall into the same cell of
-// a plane, so their four tap contributions are summed in registers and written with ONE set of atomics when the cell changes.
-struct TapRun {
-    long long key;               // element offset of the (x0, y0) texel's channel, -1 = empty
-    float a00, a01, a10, a11;
+// The plane gradients of consecutive samples of a ray accumulate in a 2 x 2 WINDOW of taps that slides with the ray: a step into the neighbouring cell
+// retires the two taps that leave the window and keeps the two that stay (a run that flushed all four taps at every cell change issued twice the atomics).
+// What is charged is the 64-B line request, not the dword (scripts/hwprobe/atomic_rate.hip), so every retired tap costs one request per 16 channels.
+// One lane per channel c of a C-channel texel; all lanes of a sample take the same branches.
+template <int C>
+struct TapWin {
+    int kx, ky;                  // the window's (x0, y0); an empty window holds zeros, which are never written
+    float a00, a01, a10, a11;    // taps (kx, ky), (kx+1, ky), (kx, ky+1), (kx+1, ky+1)
+    __device__ __forceinline__ void reset() { kx = 0; ky = 0; a00 = a01 = a10 = a11 = 0.0f; }
+    __device__ __forceinline__ static void put(float *__restrict__ g, int Wp, int c, int x, int y, float v)
+    {
+        if (v != 0.0f) atomicAdd(g + ((long long)y * Wp + x) * C + c, v);
+    }
+    __device__ __forceinline__ void flush(float *__restrict__ g, int Wp, int c)
+    {
+        put(g, Wp, c, kx, ky, a00); put(g, Wp, c, kx + 1, ky, a01); put(g, Wp, c, kx, ky + 1, a10); put(g, Wp, c, kx + 1, ky + 1, a11);
+        a00 = a01 = a10 = a11 = 0.0f;
+    }
+    __device__ __forceinline__ void move(float *__restrict__ g, int Wp, int c, int x0, int y0)
+    {
+        const int dx = x0 - kx;
+        if (dx != 0) {
+            if (dx == 1) { put(g, Wp, c, kx, ky, a00); put(g, Wp, c, kx, ky + 1, a10); a00 = a01; a10 = a11; a01 = a11 = 0.0f; }
+            else if (dx == -1) { put(g, Wp, c, kx + 1, ky, a01); put(g, Wp, c, kx + 1, ky + 1, a11); a01 = a00; a11 = a10; a00 = a10 = 0.0f; }
+            else flush(g, Wp, c);
+            kx = x0;
+        }
+        const int dy = y0 - ky;
+        if (dy != 0) {
+            if (dy == 1) { put(g, Wp, c, kx, ky, a00); put(g, Wp, c, kx + 1, ky, a01); a00 = a10; a01 = a11; a10 = a11 = 0.0f; }
+            else if (dy == -1) { put(g, Wp, c, kx, ky + 1, a10); put(g, Wp, c, kx + 1, ky + 1, a11); a10 = a00; a11 = a01; a00 = a01 = 0.0f; }
+            else flush(g, Wp, c);
+            ky = y0;
+        }
+    }
 };
 
-__device__ __forceinline__ void run_flush(TapRun &r, float *__restrict__ gPl, int Wp)
-{
-    if (r.key >= 0) {
-        float *p = gPl + r.key;
-        atomicAdd(p, r.a00);
-        atomicAdd(p + TVR_CD, r.a01);
-        atomicAdd(p + (size_t)Wp * TVR_CD, r.a10);
-        atomicAdd(p + (size_t)Wp * TVR_CD + TVR_CD, r.a11);
+// the line's two taps (l0, l0 + 1) slide the same way; g is the LDS image of the line (or the global one when it does not fit)
+template <int C>
+struct LineWin {
+    int lk;
+    float b0, b1;
+    __device__ __forceinline__ void reset() { lk = 0; b0 = b1 = 0.0f; }
+    __device__ __forceinline__ void flush(float *g, int c)
+    {
+        if (b0 != 0.0f) atomicAdd(g + (size_t)lk * C + c, b0);
+        if (b1 != 0.0f) atomicAdd(g + (size_t)(lk + 1) * C + c, b1);
+        b0 = b1 = 0.0f;
     }
-    r.key = -1;
-    r.a00 = r.a01 = r.a10 = r.a11 = 0.0f;
+    __device__ __forceinline__ void move(float *g, int c, int l0)
+    {
+        const int dl = l0 - lk;
+        if (dl != 0) {
+            if (dl == 1) { if (b0 != 0.0f) atomicAdd(g + (size_t)lk * C + c, b0); b0 = b1; b1 = 0.0f; }
+            else if (dl == -1) { if (b1 != 0.0f) atomicAdd(g + (size_t)(lk + 1) * C + c, b1); b1 = b0; b0 = 0.0f; }
+            else flush(g, c);
+            lk = l0;
+        }
+    }
+};
+
+__device__ __forceinline__ float rdlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// march_backward, pass A: one quad lane's 4 channels of one (plane, line) pair of one sample — P, Q as phase 1 computes them, staged in LDS for pass C
+// (sq: this sample's 16-channel row of the pair's Q block; the P block follows TB_STAGE / 2 floats later).
+__device__ __forceinline__ void pass_a(const float4 *__restrict__ Pl, const float4 *__restrict__ Ln, int W, int x0, int y0, int l0, float wx, float wy,
+                                       float wl, int sub, float *sq)
+{
+    const VmTerm t = vm_eval<TVR_CD / 4>(Pl, Ln, W, x0, y0, l0, wx, wy, wl, sub);
+    *(float4 *)sq = t.Q;
+    *(float4 *)(sq + TB_STAGE / 2) = t.P;
 }
 
-// one density channel of one (plane, line) pair: re-evaluate P, Q; gs*Q joins the plane's run, gs*P goes to the 2 line taps
-template <bool LINE_LDS>
-__device__ __forceinline__ void scatter_run(TapRun &run, const float *__restrict__ Pl, const float *__restrict__ Ln, float *__restrict__ gPl,
-                                            float *__restrict__ gLn, float *gLds, int W, int x0, int y0, int l0, float wx, float wy, float wl,
-                                            int c, float gs)
-{
-    const float ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
-    const int Wp = W + 1;
-    const long long t00 = ((long long)y0 * Wp + x0) * TVR_CD + c, t10 = t00 + (long long)Wp * TVR_CD;
-    const size_t q0 = (size_t)l0 * TVR_CD + c;
-    float P = (ux * uy) * Pl[t00];
-    P = __builtin_fmaf(wx * uy, Pl[t00 + TVR_CD], P);
-    P = __builtin_fmaf(ux * wy, Pl[t10], P);
-    P = __builtin_fmaf(wx * wy, Pl[t10 + TVR_CD], P);
-    float Q = ul * Ln[q0];
-    Q = __builtin_fmaf(wl, Ln[q0 + TVR_CD], Q);
-    const float gP = gs * Q, gQ = gs * P;
-    if (t00 != run.key) {
-        run_flush(run, gPl, Wp);
-        run.key = t00;
+// march_backward, pass C: the 2 x 2 tap window of one plane, spread over the wave — lane (ti, tj, ch) owns tap (kx + ti, ky + tj), channel ch.  The
+// window's position is wave-uniform (scalar registers); a step to the neighbouring cell retires one column or row with ONE atomic instruction (32
+// lanes, 2 line requests) and hands the staying column / row over by a lane exchange.
+struct RayWin {
+    int kx, ky;
+    float a;
+    __device__ __forceinline__ void reset() { kx = 0; ky = 0; a = 0.0f; }
+    __device__ __forceinline__ void put(float *__restrict__ g, int Wp, int ch, int ti, int tj) const
+    {
+        if (!(TB_DIAG & 4) && a != 0.0f) atomicAdd(g + ((long long)(ky + tj) * Wp + (kx + ti)) * TVR_CD + ch, a);
     }
-    run.a00 += (ux * uy) * gP;
-    run.a01 += (wx * uy) * gP;
-    run.a10 += (ux * wy) * gP;
-    run.a11 += (wx * wy) * gP;
-    float *q = (LINE_LDS ? gLds : gLn) + q0;
-    atomicAdd(q, ul * gQ);
-    atomicAdd(q + TVR_CD, wl * gQ);
-}
+    __device__ __forceinline__ void flush(float *__restrict__ g, int Wp, int ch, int ti, int tj) { put(g, Wp, ch, ti, tj); a = 0.0f; }
+    // x0, y0, wx, wy are wave-uniform; v = gs * Q[ch]
+    __device__ __forceinline__ void add(float *__restrict__ g, int Wp, int ch, int ti, int tj, int x0, int y0, float wx, float wy, float v)
+    {
+        const int dx = x0 - kx;
+        if (dx != 0) {
+            if (dx == 1 || dx == -1) {
+                const bool leaving = ti == (dx == 1 ? 0 : 1);
+                if (leaving) put(g, Wp, ch, ti, tj);
+                const float o = __shfl_xor(a, 16);
+                a = leaving ? o : 0.0f;                              // the staying column moves to the leaving column's lanes
+            } else flush(g, Wp, ch, ti, tj);
+            kx = x0;
+        }
+        const int dy = y0 - ky;
+        if (dy != 0) {
+            if (dy == 1 || dy == -1) {
+                const bool leaving = tj == (dy == 1 ? 0 : 1);
+                if (leaving) put(g, Wp, ch, ti, tj);
+                const float o = __shfl_xor(a, 32);
+                a = leaving ? o : 0.0f;
+            } else flush(g, Wp, ch, ti, tj);
+            ky = y0;
+        }
+        const float fx = ti ? wx : 1.0f - wx, fy = tj ? wy : 1.0f - wy;
+        a += (fx * fy) * v;
+    }
+};
+
+// the line's two taps the same way: lanes with tj == 0 own tap lk + ti, channel ch.  Consecutive samples of a ray mostly share l0 — as LDS atomics issued per
+// sample those were same-address conflicts that serialised (0.93 ms of the kernel's 1.5 ms, measured by leaving them out); the window issues one
+// conflict-free 16-lane atomic per tap that leaves.
+struct RayLine {
+    int lk;
+    float b;
+    __device__ __forceinline__ void reset() { lk = 0; b = 0.0f; }
+    __device__ __forceinline__ void put(float *g, int ch, int ti, int tj) const
+    {
+        if (!(TB_DIAG & 1) && tj == 0 && b != 0.0f) atomicAdd(g + (size_t)(lk + ti) * TVR_CD + ch, b);
+    }
+    __device__ __forceinline__ void flush(float *g, int ch, int ti, int tj) { put(g, ch, ti, tj); b = 0.0f; }
+    __device__ __forceinline__ void add(float *g, int ch, int ti, int tj, int l0, float wl, float v)
+    {
+        const int dl = l0 - lk;
+        if (dl != 0) {
+            if (dl == 1 || dl == -1) {
+                const bool leaving = ti == (dl == 1 ? 0 : 1);
+                if (leaving) put(g, ch, ti, tj);
+                const float o = __shfl_xor(b, 16);
+                b = leaving ? o : 0.0f;
+            } else flush(g, ch, ti, tj);
+            lk = l0;
+        }
+        b += (ti ? wl : 1.0f - wl) * v;
+    }
+};
 
 __device__ __forceinline__ float wave_sum_f(float v)
 {
@@ -195,16 +290,21 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
                                                                     const float *__restrict__ grad_acc, const float *__restrict__ lam6,
                                                                     const float *__restrict__ grad_lam6, TrainGrads tg)
 {
-    extern __shared__ __attribute__((aligned(16))) float glds[];      // [line 0 | line 1 | line 2] gradient accumulators, (L+1) x 16 each
+    // LDS: [per-wave stage: 3 planes x 16 samples x 16 channels of Q][line 0 | line 1 | line 2 gradient accumulators, (L+1) x 16 each]
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane & 3;
+    float *const stage = smem_f + wave * TB_STAGE;
+    float *const glds = smem_f + TB_WAVES * TB_STAGE;
     const int ln0 = (sc.grid[2] + 1) * TVR_CD, ln1 = (sc.grid[1] + 1) * TVR_CD, ln2 = (sc.grid[0] + 1) * TVR_CD;
     float *const gl0 = glds, *const gl1 = glds + ln0, *const gl2 = glds + ln0 + ln1;
     if (LINE_LDS) {
         for (int i = threadIdx.x; i < ln0 + ln1 + ln2; i += TB_THREADS) glds[i] = 0.0f;
         __syncthreads();
     }
+    // pass C's lane: tap (ti, tj) of the 2 x 2 window, channel ch
+    const int ch = lane & 15, ti = (lane >> 4) & 1, tj = lane >> 5;
     for (int it = wave; it < rays_per_block; it += TB_WAVES) {
         const int ray = blockIdx.x * rays_per_block + it;
         if (ray >= n_rays) break;
@@ -230,6 +330,10 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
         float T = 1.0f, prefix = 0.0f;
         unsigned napp = 0;
         bool seen = false;
+        RayWin win0, win1, win2;                                     // the three pairs' tap windows live for the whole ray
+        RayLine lw0, lw1, lw2;
+        win0.reset(); win1.reset(); win2.reset();
+        lw0.reset(); lw1.reset(); lw2.reset();
         for (int c = 0; c * 64 < S; ++c) {
             const int j = c * 64 + lane;
             const bool inr = j < S;
@@ -330,33 +434,53 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
             T = T * __shfl(incl, 63);
 
             // ---- phase 2: scatter dL/dsf into the density planes / lines (re-gather: the texels are L1/L2 hot) ----
-            // one lane per CHANNEL: an atomic instruction covers whole 64-B texels (16 dwords per L2 request; with the quad-per-sample
-            // layout of phase 1 a request carried 4 scattered dwords).  Each 16-lane group walks 16 CONSECUTIVE samples of the chunk, so
-            // that the contributions to a plane's cell accumulate in registers until the ray leaves the cell (TapRun).
-            const int ch = lane & 15;
-            TapRun run0, run1, run2;
-            run0.key = run1.key = run2.key = -1;
-            run0.a00 = run0.a01 = run0.a10 = run0.a11 = 0.0f;
-            run1 = run0; run2 = run0;
-#pragma unroll 2
-            for (int t = 0; t < 16; ++t) {
-                const int src = 16 * (lane >> 4) + t;
-                const float gs = __shfl(dLdsf, src);
-                if (__ballot(gs != 0.0f) == 0ull) continue;
-                const int ix = __shfl(i0[0], src), iy = __shfl(i0[1], src), iz = __shfl(i0[2], src);
-                const float wx = __shfl(w[0], src), wy = __shfl(w[1], src), wz = __shfl(w[2], src);
-                if (gs != 0.0f) {
-                    // sf = sum_i sum_c P_i[c] Q_i[c]  ->  dP_i[c] = gs Q_i[c], dQ_i[c] = gs P_i[c]
-                    scatter_run<LINE_LDS>(run0, (const float *)sc.dplane[0], (const float *)sc.dline[0], tg.dplane[0], tg.dline[0], gl0, sc.grid[0], ix, iy, iz, wx, wy, wz, ch, gs);
-                    scatter_run<LINE_LDS>(run1, (const float *)sc.dplane[1], (const float *)sc.dline[1], tg.dplane[1], tg.dline[1], gl1, sc.grid[0], ix, iz, iy, wx, wz, wy, ch, gs);
-                    scatter_run<LINE_LDS>(run2, (const float *)sc.dplane[2], (const float *)sc.dline[2], tg.dplane[2], tg.dline[2], gl2, sc.grid[1], iy, iz, ix, wy, wz, wx, ch, gs);
+            // Round 3, second form.  The first form walked the samples with one lane per channel, re-gathered with 4-byte loads (288 wave-level loads per
+            // chunk against phase 1's 72) and issued the line-tap LDS atomics per sample — consecutive samples share l0, so those were same-address
+            // conflicts that serialised: 0.93 ms of a 1.5 ms kernel (0.11 ms forward).  Now, per 16 consecutive samples:
+            //   pass A (quad per sample, float4 per lane — phase 1's loads): P, Q of the three pairs, staged in LDS (6 KB per wave);
+            //   pass C (ONE sample at a time; lane = (tap of the 2 x 2 window, channel)): every lane owns ONE accumulator per plane and (tj == 0) one per
+            //          line; the windows slide with the ray for the WHOLE ray (no flush at chunk ends), a retiring column / row is ONE atomic instruction
+            //          of 2 line requests, a retiring line tap one conflict-free 16-lane LDS atomic; cell and weights are wave-uniform (readlane).
+            for (int it = 0; it < 4; ++it) {
+                if (__builtin_amdgcn_readfirstlane((int)((__ballot(dLdsf != 0.0f) >> (16 * it)) & 0xFFFFull)) == 0) continue;
+                {
+                    const int src = 16 * it + (lane >> 2);
+                    const float gs = __shfl(dLdsf, src);
+                    const int ix = __shfl(i0[0], src), iy = __shfl(i0[1], src), iz = __shfl(i0[2], src);
+                    const float wx = __shfl(w[0], src), wy = __shfl(w[1], src), wz = __shfl(w[2], src);
+                    if (!(TB_DIAG & 8) && gs != 0.0f) {
+                        float *sq = stage + (lane >> 2) * TVR_CD + 4 * sub;
+                        pass_a(sc.dplane[0], sc.dline[0], sc.grid[0], ix, iy, iz, wx, wy, wz, sub, sq);
+                        pass_a(sc.dplane[1], sc.dline[1], sc.grid[0], ix, iz, iy, wx, wz, wy, sub, sq + 16 * TVR_CD);
+                        pass_a(sc.dplane[2], sc.dline[2], sc.grid[1], iy, iz, ix, wy, wz, wx, sub, sq + 32 * TVR_CD);
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();
+                for (int u = 0; u < ((TB_DIAG & 2) ? 0 : 16); ++u) {
+                    const int src = 16 * it + u;
+                    const float gs = rdlane_f(dLdsf, src);
+                    if (gs == 0.0f) continue;
+                    const int ix = __builtin_amdgcn_readlane(i0[0], src), iy = __builtin_amdgcn_readlane(i0[1], src), iz = __builtin_amdgcn_readlane(i0[2], src);
+                    const float wx = rdlane_f(w[0], src), wy = rdlane_f(w[1], src), wz = rdlane_f(w[2], src);
+                    const float *sq = stage + u * TVR_CD + ch;
+                    // sf = sum_i sum_c P_i[c] Q_i[c]  ->  dP_i[c] = gs Q_i[c] (tap-weighted into the plane), dQ_i[c] = gs P_i[c] (into the line)
+                    win0.add(tg.dplane[0], sc.grid[0] + 1, ch, ti, tj, ix, iy, wx, wy, gs * sq[0]);
+                    win1.add(tg.dplane[1], sc.grid[0] + 1, ch, ti, tj, ix, iz, wx, wz, gs * sq[16 * TVR_CD]);
+                    win2.add(tg.dplane[2], sc.grid[1] + 1, ch, ti, tj, iy, iz, wy, wz, gs * sq[32 * TVR_CD]);
+                    lw0.add(LINE_LDS ? gl0 : tg.dline[0], ch, ti, tj, iz, wz, gs * sq[TB_STAGE / 2]);
+                    lw1.add(LINE_LDS ? gl1 : tg.dline[1], ch, ti, tj, iy, wy, gs * sq[TB_STAGE / 2 + 16 * TVR_CD]);
+                    lw2.add(LINE_LDS ? gl2 : tg.dline[2], ch, ti, tj, ix, wx, gs * sq[TB_STAGE / 2 + 32 * TVR_CD]);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            run_flush(run0, tg.dplane[0], sc.grid[0] + 1);
-            run_flush(run1, tg.dplane[1], sc.grid[0] + 1);
-            run_flush(run2, tg.dplane[2], sc.grid[1] + 1);
             if (T < eps_T) break;
         }
+        win0.flush(tg.dplane[0], sc.grid[0] + 1, ch, ti, tj);
+        win1.flush(tg.dplane[1], sc.grid[0] + 1, ch, ti, tj);
+        win2.flush(tg.dplane[2], sc.grid[1] + 1, ch, ti, tj);
+        lw0.flush(LINE_LDS ? gl0 : tg.dline[0], ch, ti, tj);
+        lw1.flush(LINE_LDS ? gl1 : tg.dline[1], ch, ti, tj);
+        lw2.flush(LINE_LDS ? gl2 : tg.dline[2], ch, ti, tj);
     }
     if (LINE_LDS) {
         __syncthreads();
@@ -385,11 +509,17 @@ __global__ __launch_bounds__(256) void app_h_forward_kernel(const SceneDev sc, c
 }
 
 // grid = (entry chunks, 3 planes): a workgroup owns AHB_ENTRIES entries of ONE plane/line pair and keeps that line's gradient in LDS.
-// One lane per CHANNEL (48 consecutive lanes = one entry): a wave's atomic instruction then covers whole 64-B lines of a texel
-// (16 dwords per L2 request) instead of 4 scattered dwords per line with a lane per float4.
+// One WAVE per run of AHB_ENTRIES / 16 consecutive queue entries (consecutive appearance samples of a ray), one lane per CHANNEL (48 of the 64 lanes):
+//   * an atomic instruction then covers whole 64-B lines of a texel — the fabric charges a no-return atomic per LINE request, 21 G requests/s chip-wide
+//     whether the line carries 1, 4 or 16 dwords (scripts/hwprobe/atomic_rate.hip, profiles/r03_atomic_rate_probe.txt); a float4-per-lane layout, whose
+//     .x/.y/.z/.w atomics each touch every line of the texel, was measured at 1.47 ms against 0.97;
+//   * the entry's position is wave-uniform: scalar loads, scalar branches in the window logic;
+//   * the plane contributions accumulate in a 2 x 2 tap WINDOW that slides with the ray (TapWin), the line contributions in a 2-tap window;
+//   * 1024-thread workgroups: two fit a CU beside their 58 KB line images = 32 waves per CU (the first form, 192 threads, ran 6 waves per CU and was
+//     latency-bound).
 template <bool LINE_LDS>
-__global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const SceneDev sc, const float *__restrict__ xyz, const int xs, const long long m_cap,
-                                                                     const unsigned *__restrict__ m_dev, const float *__restrict__ dh, TrainGrads tg)
+__global__ __launch_bounds__(AHB_THREADS, 2) void app_h_backward_kernel(const SceneDev sc, const float *__restrict__ xyz, const int xs, const long long m_cap,
+                                                                        const unsigned *__restrict__ m_dev, const float *__restrict__ dh, TrainGrads tg)
 {
     extern __shared__ __attribute__((aligned(16))) float glds[];
     const long long m = m_dev ? ((long long)*m_dev < m_cap ? (long long)*m_dev : m_cap) : m_cap;
@@ -408,49 +538,52 @@ __global__ __launch_bounds__(AHB_THREADS) void app_h_backward_kernel(const Scene
     float *__restrict__ gPl = tg.aplane[pl];
     float *gLn = LINE_LDS ? glds : tg.aline[pl];
     const int Wp = sc.grid[ax] + 1;
-    // each 48-lane group walks a contiguous run of queue entries (consecutive appearance samples of a ray: mostly the same cell), and
-    // the four tap contributions accumulate in registers until the cell changes (as in march_backward)
-    const int grp = threadIdx.x / TVR_CA, c = threadIdx.x - grp * TVR_CA;
-    const long long per = (AHB_ENTRIES + AHB_THREADS / TVR_CA - 1) / (AHB_THREADS / TVR_CA);
-    const long long g0 = e0 + grp * per, g1 = (g0 + per < e1) ? g0 + per : e1;
-    long long key = -1;
-    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
-    for (long long ent = g0; ent < g1; ++ent) {
-        const float fx = unnorm(xyz[ent * xs + ax], sc.gm1[ax]), fy = unnorm(xyz[ent * xs + bx], sc.gm1[bx]), fl = unnorm(xyz[ent * xs + vx], sc.gm1[vx]);
-        const float x0f = floorf(fx), y0f = floorf(fy), l0f = floorf(fl);
-        const float wx = fx - x0f, wy = fy - y0f, wl = fl - l0f, ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
-        const long long t00 = (((long long)(int)y0f * Wp + (int)x0f)) * TVR_CA + c, t10 = t00 + (long long)Wp * TVR_CA;
-        const size_t q0 = (size_t)(int)l0f * TVR_CA + c;
-        float P = (ux * uy) * Pl[t00];
-        P = __builtin_fmaf(wx * uy, Pl[t00 + TVR_CA], P);
-        P = __builtin_fmaf(ux * wy, Pl[t10], P);
-        P = __builtin_fmaf(wx * wy, Pl[t10 + TVR_CA], P);
-        float Q = ul * Ln[q0];
-        Q = __builtin_fmaf(wl, Ln[q0 + TVR_CA], Q);
-        const float g = dh[ent * TVR_KAPP + pl * TVR_CA + c];
-        const float gP = g * Q, gQ = g * P;                       // h = P*Q  ->  dP = g*Q, dQ = g*P
-        if (t00 != key) {
-            if (key >= 0) {
-                atomicAdd(gPl + key, a00);
-                atomicAdd(gPl + key + TVR_CA, a01);
-                atomicAdd(gPl + key + (long long)Wp * TVR_CA, a10);
-                atomicAdd(gPl + key + (long long)Wp * TVR_CA + TVR_CA, a11);
+    const float gma = sc.gm1[ax], gmb = sc.gm1[bx], gmv = sc.gm1[vx];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = threadIdx.x & 63;
+    constexpr long long per = AHB_ENTRIES / (AHB_THREADS / 64);
+    const long long g0 = e0 + wave * per, g1 = (g0 + per < e1) ? g0 + per : e1;
+    if (c < TVR_CA) {
+        TapWin<TVR_CA> win;
+        win.reset();
+        int lk = 0;
+        float b0 = 0.f, b1 = 0.f;
+        for (long long ent = g0; ent < g1; ++ent) {
+            const float fx = unnorm(xyz[ent * xs + ax], gma), fy = unnorm(xyz[ent * xs + bx], gmb), fl = unnorm(xyz[ent * xs + vx], gmv);
+            const float x0f = floorf(fx), y0f = floorf(fy), l0f = floorf(fl);
+            const float wx = fx - x0f, wy = fy - y0f, wl = fl - l0f, ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
+            const int x0 = (int)x0f, y0 = (int)y0f, l0 = (int)l0f;
+            const long long t00 = ((long long)y0 * Wp + x0) * TVR_CA + c, t10 = t00 + (long long)Wp * TVR_CA;
+            const size_t q0 = (size_t)l0 * TVR_CA + c;
+            float P = (ux * uy) * Pl[t00];
+            P = __builtin_fmaf(wx * uy, Pl[t00 + TVR_CA], P);
+            P = __builtin_fmaf(ux * wy, Pl[t10], P);
+            P = __builtin_fmaf(wx * wy, Pl[t10 + TVR_CA], P);
+            float Q = ul * Ln[q0];
+            Q = __builtin_fmaf(wl, Ln[q0 + TVR_CA], Q);
+            const float g = dh[ent * TVR_KAPP + pl * TVR_CA + c];
+            const float gP = g * Q, gQ = g * P;                       // h = P*Q  ->  dP = g*Q, dQ = g*P
+            win.move(gPl, Wp, c, x0, y0);
+            win.a00 += (ux * uy) * gP;
+            win.a01 += (wx * uy) * gP;
+            win.a10 += (ux * wy) * gP;
+            win.a11 += (wx * wy) * gP;
+            const int dl = l0 - lk;
+            if (dl != 0) {                                            // the line's 2-tap window
+                if (dl == 1) { if (b0 != 0.0f) atomicAdd(gLn + (size_t)lk * TVR_CA + c, b0); b0 = b1; b1 = 0.0f; }
+                else if (dl == -1) { if (b1 != 0.0f) atomicAdd(gLn + (size_t)(lk + 1) * TVR_CA + c, b1); b1 = b0; b0 = 0.0f; }
+                else {
+                    if (b0 != 0.0f) atomicAdd(gLn + (size_t)lk * TVR_CA + c, b0);
+                    if (b1 != 0.0f) atomicAdd(gLn + (size_t)(lk + 1) * TVR_CA + c, b1);
+                    b0 = b1 = 0.0f;
+                }
+                lk = l0;
             }
-            key = t00;
-            a00 = a01 = a10 = a11 = 0.f;
+            b0 += ul * gQ;
+            b1 += wl * gQ;
         }
-        a00 += (ux * uy) * gP;
-        a01 += (wx * uy) * gP;
-        a10 += (ux * wy) * gP;
-        a11 += (wx * wy) * gP;
-        atomicAdd(gLn + q0, ul * gQ);
-        atomicAdd(gLn + q0 + TVR_CA, wl * gQ);
-    }
-    if (key >= 0) {
-        atomicAdd(gPl + key, a00);
-        atomicAdd(gPl + key + TVR_CA, a01);
-        atomicAdd(gPl + key + (long long)Wp * TVR_CA, a10);
-        atomicAdd(gPl + key + (long long)Wp * TVR_CA + TVR_CA, a11);
+        win.flush(gPl, Wp, c);
+        if (b0 != 0.0f) atomicAdd(gLn + (size_t)lk * TVR_CA + c, b0);
+        if (b1 != 0.0f) atomicAdd(gLn + (size_t)(lk + 1) * TVR_CA + c, b1);
     }
     if (LINE_LDS) {
         __syncthreads();
@@ -475,15 +608,16 @@ hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_ra
                                  hipStream_t stream)
 {
     const int rpb = TB_WAVES;
-    const size_t lds = ((size_t)sc.grid[0] + sc.grid[1] + sc.grid[2] + 3) * TVR_CD * sizeof(float);
+    const size_t stage = (size_t)TB_WAVES * TB_STAGE * sizeof(float);
+    const size_t lds = stage + ((size_t)sc.grid[0] + sc.grid[1] + sc.grid[2] + 3) * TVR_CD * sizeof(float);
     const unsigned grid = (unsigned)((n_rays + rpb - 1) / rpb);
-    if (lds <= 150 * 1024) {
+    if (lds <= 160 * 1024) {
         hipError_t rc = hipFuncSetAttribute((const void *)march_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (rc != hipSuccess) return rc;
         hipLaunchKernelGGL(march_backward_kernel<true>, dim3(grid), dim3(TB_THREADS), lds, stream, sc, rays, n_rays, S, sm, eps_T, rpb, mo,
                            grad_w, grad_acc, lam6, grad_lam6, tg);
     } else {
-        hipLaunchKernelGGL(march_backward_kernel<false>, dim3(grid), dim3(TB_THREADS), 0, stream, sc, rays, n_rays, S, sm, eps_T, rpb, mo,
+        hipLaunchKernelGGL(march_backward_kernel<false>, dim3(grid), dim3(TB_THREADS), stage, stream, sc, rays, n_rays, S, sm, eps_T, rpb, mo,
                            grad_w, grad_acc, lam6, grad_lam6, tg);
     }
     return hipGetLastError();
