@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 111
+#define TVR_VERSION 112
 
 typedef enum {
     TVR_OK = 0,
@@ -300,6 +300,20 @@ int tvr_pe_concat_backward(const float *features, const float *viewdirs, const f
  * grad (C,H,W) = d value / d x in the same pass; fixed summation order.  scratch: 2048 bytes. */
 int tvr_tv_loss(const float *x, int32_t C, int32_t H, int32_t W, float weight, float *value, float *grad, void *scratch, size_t scratch_bytes,
                 void *stream);
+
+/* The two parameter-only regularisers of train.py:237-244 that are not TV, each ONE launch forward and ONE backward, fixed summation order; the
+ * backward reads the upstream gradient grad_value[0] from the device.  Up to 8 tensors per call (host arrays of device pointers / sizes).
+ *   tvr_l1_mean:    value[0] = sum_t mean |xs[t]|                         TensorVMSplit.density_L1, tensoRF.py:190-194 (3 planes + 3 lines)
+ *   tvr_line_ortho: value[0] = sum_t mean |offdiag(V_t V_t^T)|, V_t = vs[t] as (n_comp[t], n_size[t]), 2..48 components
+ *                                                                          TensorVMSplit.vector_comp_diffs / vectorDiffs, tensoRF.py:178-188
+ * scratch: tvr_l1_mean_scratch_bytes(counts, n) / 32 bytes. */
+size_t tvr_l1_mean_scratch_bytes(const int64_t *counts, int32_t n);
+int tvr_l1_mean(const float *const *xs, const int64_t *counts, int32_t n, float *value, void *scratch, size_t scratch_bytes, void *stream);
+int tvr_l1_mean_backward(const float *const *xs, float *const *grads, const int64_t *counts, int32_t n, const float *grad_value, void *stream);
+int tvr_line_ortho(const float *const *vs, const int32_t *n_comp, const int32_t *n_size, int32_t n, float *value, void *scratch, size_t scratch_bytes,
+                   void *stream);
+int tvr_line_ortho_backward(const float *const *vs, float *const *grads, const int32_t *n_comp, const int32_t *n_size, int32_t n,
+                            const float *grad_value, void *stream);
 
 /* Per-kernel HIP-event timing of tvr_render calls (march / shade / composite), for bench.py's roofline. */
 int tvr_profile_create(int32_t max_calls, tvr_profile **out);

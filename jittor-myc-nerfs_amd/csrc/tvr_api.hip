@@ -817,6 +817,85 @@ int tvr_tv_loss(const float *x, int32_t C, int32_t H, int32_t W, float weight, f
     return TVR_OK;
 }
 
+static int reg_list(RegList &L, const float *const *xs, float *const *grads, const int64_t *counts, const int32_t *rows, int32_t n, bool need_grads)
+{
+    if (n < 1 || n > TVR_REG_MAX) return fail(TVR_ERR_INVALID, "1..%d tensors per call", TVR_REG_MAX);
+    if (!xs || !counts || (need_grads && !grads)) return fail(TVR_ERR_INVALID, "xs/counts/grads NULL");
+    L.n = n;
+    for (int t = 0; t < n; ++t) {
+        if (!xs[t] || counts[t] < 1 || (need_grads && !grads[t])) return fail(TVR_ERR_INVALID, "tensor %d: NULL pointer or empty", t);
+        L.x[t] = xs[t];
+        L.grad[t] = need_grads ? grads[t] : nullptr;
+        L.count[t] = counts[t];
+        L.rows[t] = rows ? rows[t] : 1;
+        L.blocks[t] = 0;
+    }
+    return TVR_OK;
+}
+
+size_t tvr_l1_mean_scratch_bytes(const int64_t *counts, int32_t n)
+{
+    RegList L;
+    if (!counts || n < 1 || n > TVR_REG_MAX) return 0;
+    L.n = n;
+    for (int t = 0; t < n; ++t) L.count[t] = counts[t] < 1 ? 1 : counts[t];
+    return reg_l1_scratch_bytes(L);
+}
+
+int tvr_l1_mean(const float *const *xs, const int64_t *counts, int32_t n, float *value, void *scratch, size_t scratch_bytes, void *stream)
+{
+    RegList L;
+    int rc = reg_list(L, xs, nullptr, counts, nullptr, n, false);
+    if (rc != TVR_OK) return rc;
+    if (!value) return fail(TVR_ERR_INVALID, "value NULL");
+    if (!scratch || scratch_bytes < reg_l1_scratch_bytes(L)) return fail(TVR_ERR_SCRATCH, "scratch too small (tvr_l1_mean_scratch_bytes)");
+    HIP_TRY(launch_l1_forward(L, value, (float *)scratch, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_l1_mean_backward(const float *const *xs, float *const *grads, const int64_t *counts, int32_t n, const float *grad_value, void *stream)
+{
+    RegList L;
+    int rc = reg_list(L, xs, grads, counts, nullptr, n, true);
+    if (rc != TVR_OK) return rc;
+    if (!grad_value) return fail(TVR_ERR_INVALID, "grad_value NULL");
+    HIP_TRY(launch_l1_backward(L, grad_value, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+static int ortho_list(RegList &L, const float *const *vs, float *const *grads, const int32_t *n_comp, const int32_t *n_size, int32_t n, bool need_grads)
+{
+    if (!n_comp || !n_size) return fail(TVR_ERR_INVALID, "n_comp/n_size NULL");
+    int64_t counts[TVR_REG_MAX];
+    if (n < 1 || n > TVR_REG_MAX) return fail(TVR_ERR_INVALID, "1..%d line factors per call", TVR_REG_MAX);
+    for (int t = 0; t < n; ++t) {
+        if (n_comp[t] < 2 || n_comp[t] > 48 || n_size[t] < 1) return fail(TVR_ERR_UNSUPPORTED, "line factor %d: %d components x %d (2..48 components)", t, n_comp[t], n_size[t]);
+        counts[t] = (int64_t)n_comp[t] * n_size[t];
+    }
+    return reg_list(L, vs, grads, counts, n_comp, n, need_grads);
+}
+
+int tvr_line_ortho(const float *const *vs, const int32_t *n_comp, const int32_t *n_size, int32_t n, float *value, void *scratch, size_t scratch_bytes, void *stream)
+{
+    RegList L;
+    int rc = ortho_list(L, vs, nullptr, n_comp, n_size, n, false);
+    if (rc != TVR_OK) return rc;
+    if (!value) return fail(TVR_ERR_INVALID, "value NULL");
+    if (!scratch || scratch_bytes < TVR_REG_MAX * sizeof(float)) return fail(TVR_ERR_SCRATCH, "tvr_line_ortho needs %d bytes of scratch", (int)(TVR_REG_MAX * sizeof(float)));
+    HIP_TRY(launch_ortho(L, nullptr, value, (float *)scratch, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_line_ortho_backward(const float *const *vs, float *const *grads, const int32_t *n_comp, const int32_t *n_size, int32_t n, const float *grad_value, void *stream)
+{
+    RegList L;
+    int rc = ortho_list(L, vs, grads, n_comp, n_size, n, true);
+    if (rc != TVR_OK) return rc;
+    if (!grad_value) return fail(TVR_ERR_INVALID, "grad_value NULL");
+    HIP_TRY(launch_ortho(L, grad_value, nullptr, nullptr, (hipStream_t)stream));
+    return TVR_OK;
+}
+
 static int gemm_tn_check(int32_t Ka, int32_t Kb, int64_t M)
 {
     if (M < 0 || Ka < 1 || Kb < 1) return fail(TVR_ERR_INVALID, "bad Ka/Kb/M");

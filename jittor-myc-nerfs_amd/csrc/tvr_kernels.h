@@ -97,6 +97,20 @@ struct MlpRefBwd { const float *g8, *viewdirs, *grad_in0; float *dg8; const floa
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
                                      float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, void *image, const MlpRefBwd *ref,
                                      hipStream_t stream, const unsigned *m_dev = nullptr);
+// up to 8 parameter tensors of a regulariser (tvr_reg.hip): x / grad pointers, element counts, rows (line factors: n_comp), launch blocks
+#define TVR_REG_MAX 8
+struct RegList {
+    const float *x[TVR_REG_MAX];
+    float *grad[TVR_REG_MAX];
+    long long count[TVR_REG_MAX];
+    int rows[TVR_REG_MAX];
+    int blocks[TVR_REG_MAX];
+    int n;
+};
+size_t reg_l1_scratch_bytes(const RegList &L);
+hipError_t launch_l1_forward(const RegList &L, float *value, float *scratch, hipStream_t stream);
+hipError_t launch_l1_backward(const RegList &L, const float *g, hipStream_t stream);
+hipError_t launch_ortho(const RegList &L, const float *g, float *value, float *scratch, hipStream_t stream);
 hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, float *value, float *grad, float *part, hipStream_t stream);
 hipError_t launch_alpha_bits(const float *vol, long long n, unsigned *bits, hipStream_t stream);
 

@@ -732,9 +732,17 @@ class TensorVMSplit(TensorBase):
         return total
 
     def vector_comp_diffs(self):
+        from .losses import _LineOrthoFn, fusable
+        lines = list(self.density_line) + list(self.app_line)
+        if fusable(lines) and all(2 <= v.shape[1] <= 48 for v in lines):        # one launch each way (tvr_line_ortho) instead of ~60 torch kernels
+            return _LineOrthoFn.apply(*lines)
         return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
 
     def density_L1(self):
+        from .losses import _L1MeanFn, fusable
+        ts = [t for pair in zip(self.density_plane, self.density_line) for t in pair]
+        if fusable(ts):                                                          # one launch each way (tvr_l1_mean) instead of ~40 torch kernels
+            return _L1MeanFn.apply(*ts)
         total = 0
         for idx in range(len(self.density_plane)):
             total = total + torch.mean(torch.abs(self.density_plane[idx])) + torch.mean(torch.abs(self.density_line[idx]))

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(l, n), f"libtvr.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and include/*.h disagree"
-    assert _lib.lib().tvr_version() == 111
+    assert _lib.lib().tvr_version() == 112
 
 
 def test_abi_argument_errors_without_gpu():
@@ -53,6 +53,18 @@ def test_abi_argument_errors_without_gpu():
     assert lib.tvr_scene_create(C.byref(d), None, 0, C.byref(h)) == -3  # TVR_ERR_SCRATCH
     assert lib.tvr_render(None, None, 0, 0, 0, None, 0.0, None, None, None, 0, None, None, None, None) == -1
     assert lib.tvr_render_scratch_bytes(None, 4096, 512) > 4096 * 512 * 20
+    # the fused regularisers: 1..8 tensors, non-NULL pointers, 2..48 line components — refused before any launch
+    one = (C.c_void_p * 1)(0x1000)
+    cnt = (C.c_int64 * 1)(16)
+    assert lib.tvr_l1_mean(one, cnt, 0, 0x1000, 0x1000, 64, None) == -1 and lib.tvr_l1_mean(one, cnt, 9, 0x1000, 0x1000, 64, None) == -1
+    assert lib.tvr_l1_mean((C.c_void_p * 1)(None), cnt, 1, 0x1000, 0x1000, 64, None) == -1 and b"tensor 0" in lib.tvr_last_error()
+    assert lib.tvr_l1_mean(one, cnt, 1, 0x1000, 0x1000, 0, None) == -3 and lib.tvr_l1_mean_scratch_bytes(cnt, 1) == 4
+    assert lib.tvr_l1_mean_backward(one, None, cnt, 1, 0x1000, None) == -1
+    nc, ns = (C.c_int32 * 1)(49), (C.c_int32 * 1)(300)
+    assert lib.tvr_line_ortho(one, nc, ns, 1, 0x1000, 0x1000, 32, None) == -4 and b"components" in lib.tvr_last_error()
+    nc[0] = 16
+    assert lib.tvr_line_ortho(one, nc, ns, 1, 0x1000, 0x1000, 8, None) == -3
+    assert lib.tvr_line_ortho_backward(one, one, nc, ns, 1, None, None) == -1
     d.variant = 2
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"variant" in lib.tvr_last_error()
     d.variant = 1                                                       # REFTensoRF: same packed size (the LDS image has room for both)

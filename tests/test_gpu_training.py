@@ -184,6 +184,59 @@ def test_fused_pe_concat_and_tv_loss_match_torch():
         assert float((gx.cpu().double() - gr).abs().max()) < 1e-6
 
 
+@pytest.mark.gpu
+def test_fused_regularisers_match_the_torch_formulations(tiny_arrays, hyper_tiny):
+    """tvr_l1_mean / tvr_line_ortho (density_L1, vector_comp_diffs; tensoRF.py:178-194) against the torch expressions they replace: values, the gradients of
+    every factor under a non-trivial upstream weight, bit-reproducible sums, and the model methods taking the fused path."""
+    from jittor_myc_nerfs_amd.losses import _L1MeanFn, _LineOrthoFn
+    from conftest import make_model
+    g = torch.Generator(device="cuda").manual_seed(3)
+    planes = [torch.randn((1, 16, h, w), device="cuda", generator=g) * 0.1 for h, w in ((300, 300), (37, 53), (129, 64))]
+    lines = [torch.randn((1, 16, n, 1), device="cuda", generator=g) * 0.1 for n in (300, 53, 129)]
+    planes[0].view(-1)[:5] = 0.0                                       # exact zeros: sign(0) = 0 as torch.abs' gradient has it
+    xs = [t.clone().requires_grad_(True) for pair in zip(planes, lines) for t in pair]
+    ref = [t.detach().clone().requires_grad_(True) for t in xs]
+    v = _L1MeanFn.apply(*xs)
+    (8e-5 * v).backward()
+    vr = sum(torch.mean(torch.abs(t)) for t in ref)
+    (8e-5 * vr).backward()
+    assert abs(float(v) - float(vr)) <= 2e-6 * abs(float(vr))
+    for a, b in zip(xs, ref):
+        assert torch.equal(a.grad, b.grad)                             # +-(8e-5 / n) or 0: the same single rounding in both
+    assert float(_L1MeanFn.apply(*xs)) == float(v)                     # fixed order
+
+    def vector_diffs(vs):                                              # the torch form kept in field.vectorDiffs
+        total = 0
+        for x in vs:
+            n_comp, n_size = x.shape[1:-1]
+            m = x.view(n_comp, n_size)
+            dotp = m @ m.t()
+            nd = dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]
+            total = total + torch.mean(torch.abs(nd))
+        return total
+    vs = [torch.randn((1, c, n, 1), device="cuda", generator=g).requires_grad_(True) for c, n in ((16, 300), (16, 53), (48, 300), (48, 129), (5, 7), (2, 301))]
+    rs = [t.detach().double().requires_grad_(True) for t in vs]
+    v = _LineOrthoFn.apply(*vs)
+    (1e-4 * v).backward()
+    vr = vector_diffs(rs)
+    (1e-4 * vr).backward()
+    assert abs(float(v) - float(vr)) <= 1e-5 * abs(float(vr))
+    for a, b in zip(vs, rs):
+        err = float((a.grad.double() - b.grad).abs().max()) / float(b.grad.abs().max())
+        # (a Gram entry within rounding of zero may flip its sign between fp32 and fp64: measure against the largest entry)
+        assert err < 1e-4, err
+    assert float(_LineOrthoFn.apply(*vs)) == float(v)
+
+    # the model's methods take the fused path on the device and agree with the torch loop they keep for other devices
+    m = make_model(tiny_arrays, hyper_tiny)
+    l1 = m.density_L1()
+    od = m.vector_comp_diffs()
+    assert type(l1.grad_fn).__name__.startswith("_L1MeanFn") and type(od.grad_fn).__name__.startswith("_LineOrthoFn")
+    l1_ref = sum(torch.mean(torch.abs(m.density_plane[i])) + torch.mean(torch.abs(m.density_line[i])) for i in range(3))
+    od_ref = m.vectorDiffs(m.density_line) + m.vectorDiffs(m.app_line)
+    assert abs(float(l1) - float(l1_ref)) <= 2e-6 * abs(float(l1_ref)) and abs(float(od) - float(od_ref)) <= 1e-5 * abs(float(od_ref))
+
+
 def test_fixed_order_reductions_are_bit_reproducible():
     """tvr_gemm_tn and tvr_tv_loss sum in a fixed order: repeated calls return identical bits (the scatter kernels use fp32 atomics and do not)."""
     from jittor_myc_nerfs_amd import TVLoss, _lib as L
