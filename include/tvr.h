@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 112
+#define TVR_VERSION 113
 
 typedef enum {
     TVR_OK = 0,
@@ -350,6 +350,38 @@ int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *params
 /* pts [n,4] (inverted-sphere points, depth2pts_outside), viewdirs [ceil(n / samples_per_ray), 3] -> rgb [n,3] (sigmoid applied), sigma [n] (abs applied) */
 int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
                        void *sigma, void *stream);
+/* Training (`optimizer.backward(loss)` through MLPNet, train.py:258): the same kernel also saves what the backward needs, all fp32,
+ * caller-owned, 16-B aligned, with byte counts that are checked before the launch:
+ *   act[l] [n,128] = relu output of base layer l; rgb_hidden [n,64] = relu output of rgb_layers[0]; sigma_pre [n] = the sigma head before `abs`;
+ *   embed_pos [n, 4 + 8 pos_freqs] and embed_view [n,16] (15 values + a zero) = the two Embedder outputs as matrices (operands of dW = dY^T E).
+ * tvr_mlpnet_repack: the fragment image again from the tensors the table inside `packed` already points at (tvr_mlpnet_pack ran once with the same
+ * pointers; their values change every optimizer step) — no host synchronisation. */
+typedef struct tvr_mlpnet_saved {
+    void *act[4];
+    size_t act_bytes;                /* of EACH act[l] */
+    void *rgb_hidden;
+    size_t rgb_hidden_bytes;
+    void *sigma_pre;
+    size_t sigma_pre_bytes;
+    void *embed_pos;
+    size_t embed_pos_bytes;
+    void *embed_view;
+    size_t embed_view_bytes;
+} tvr_mlpnet_saved;
+int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
+                             void *sigma, const tvr_mlpnet_saved *saved, void *stream);
+int tvr_mlpnet_repack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *params, void *packed, size_t packed_bytes, void *stream);
+/* The input gradient of a Linear over a tall batch with the ReLU mask in front of it fused in (fp32-input MFMAs, W staged in LDS):
+ *   dX[m, k] = (sum_{n < N} dY[m, n] W[n, k]) * (mask[m, k] > 0 ? 1 : 0)     (mask NULL: no mask)
+ * dY [M, ldy] with N a multiple of 8 in [8,128] (columns n_valid..N-1 of dY must be finite, rows n_valid.. of W are taken as zero), W row-major
+ * [n_valid, ldw] = a torch / Jittor Linear weight [out, in] (the reduction runs over its rows), K in {32, 64, 96, 128} columns of W / dX / mask;
+ * ldy, ldx, ldm multiples of 4 and all pointers 16-B aligned.  What autograd computes for `relu(Linear(x))` chains (MLPNet.forward, nerfplusplus.py:119-140). */
+int tvr_linear_dx(const float *dY, int32_t ldy, int32_t N, const float *W, int32_t ldw, int32_t n_valid, int32_t K, const float *mask, int32_t ldm,
+                  float *dX, int32_t ldx, size_t dX_bytes, int64_t M, void *stream);
+/* out[k] = sum_m A[m, k], k < K <= 128, fixed summation order (the bias gradients of the same Linears).  scratch: tvr_colsum_scratch_bytes(). */
+size_t tvr_colsum_scratch_bytes(void);
+int tvr_colsum(const float *A, int32_t lda, int32_t K, int64_t M, float *out, void *scratch, size_t scratch_bytes, void *stream);
+
 /* The background of NerfPlusPlus.execute around that network (nerfplusplus.py:280-308).
  * tvr_npp_bg_points: z_lin [n_samples] (the `linspace(0, radii, N)` depths), t_rand [n_rays,n_samples] (the `rand_like` draw of
  *   `perturb_samples`, :196-205) -> pts [n_rays,n_samples,4] = `depth2pts_outside` (:207-237) of the perturbed depths and z

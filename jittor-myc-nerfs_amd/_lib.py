@@ -58,6 +58,12 @@ class MlpnetParams(C.Structure):         # tvr_mlpnet_params
                 ("rgbh_W_view", C.c_void_p), ("rgbh_b", C.c_void_p), ("rgbo_W", C.c_void_p), ("rgbo_b", C.c_void_p)]
 
 
+class MlpnetSaved(C.Structure):          # tvr_mlpnet_saved
+    _fields_ = [("act", C.c_void_p * 4), ("act_bytes", C.c_size_t), ("rgb_hidden", C.c_void_p), ("rgb_hidden_bytes", C.c_size_t),
+                ("sigma_pre", C.c_void_p), ("sigma_pre_bytes", C.c_size_t), ("embed_pos", C.c_void_p), ("embed_pos_bytes", C.c_size_t),
+                ("embed_view", C.c_void_p), ("embed_view_bytes", C.c_size_t)]
+
+
 class NgpMarchCfg(C.Structure):          # tvr_ngp_march_cfg (include/tvr_ngp.h)
     _fields_ = [("aabb_lo", C.c_float * 3), ("aabb_hi", C.c_float * 3), ("near_distance", C.c_float), ("cone_angle", C.c_float),
                 ("const_dt", C.c_int32), ("rng_state", C.c_uint64), ("rng_inc", C.c_uint64), ("slab_rays", C.c_uint32)]
@@ -137,6 +143,13 @@ SYMBOLS = {
     "tvr_mlpnet_packed_bytes": (C.c_size_t, [C.POINTER(MlpnetDesc)]),
     "tvr_mlpnet_pack": (C.c_int, [C.POINTER(MlpnetDesc), C.POINTER(MlpnetParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_mlpnet_forward": (C.c_int, [C.POINTER(MlpnetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvr_mlpnet_train_forward": (C.c_int, [C.POINTER(MlpnetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(MlpnetSaved),
+                                           C.c_void_p]),
+    "tvr_mlpnet_repack": (C.c_int, [C.POINTER(MlpnetDesc), C.POINTER(MlpnetParams), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tvr_linear_dx": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                C.c_size_t, C.c_int64, C.c_void_p]),
+    "tvr_colsum_scratch_bytes": (C.c_size_t, []),
+    "tvr_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_npp_bg_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tvr_npp_bg_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     # include/tvr_ngp.h

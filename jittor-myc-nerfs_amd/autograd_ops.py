@@ -92,6 +92,116 @@ def _colsum(gy: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _colsum_call(a, lda, K, M, a_off=0):
+    """out[k] = sum_m a[m, a_off + k] through tvr_colsum (fixed order)."""
+    out = torch.empty(K, dtype=torch.float32, device=a.device)
+    scratch = torch.empty(L.lib().tvr_colsum_scratch_bytes(), dtype=torch.uint8, device=a.device)
+    L.check(L.lib().tvr_colsum(a.data_ptr() + 4 * a_off, lda, K, M, out.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream_ptr(a.device)), "tvr_colsum")
+    return out
+
+
+def _linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, w_off=0):
+    """dX[:, :K] = (dY[:, :N] @ W[:n_valid, w_off : w_off + K]) * (mask > 0) through tvr_linear_dx."""
+    L.check(L.lib().tvr_linear_dx(dY.data_ptr(), ldy, N, W.data_ptr() + 4 * w_off, ldw, n_valid, K, mask.data_ptr() if mask is not None else None, ldm,
+                                  dX.data_ptr(), ldx, dX.numel() * 4, M, _stream_ptr(dY.device)), "tvr_linear_dx")
+
+
+class _BgNetFn(torch.autograd.Function):
+    """NerfPlusPlus's background network under autograd WITHOUT a library GEMM (nerfplusplus.py:66-140 through train.py:258).
+    Forward: the fused inference kernel, which also saves every layer's relu output (tvr_mlpnet_train_forward).  Backward: the heads' elementwise part,
+    then one tvr_linear_dx per Linear (input gradient with the ReLU mask of the layer in front fused in), weight gradients by tvr_gemm_tn, bias gradients by
+    tvr_colsum.  `base_remap_layers` (Linear 128 -> 256, no activation) stays folded into the first rgb layer in both directions: with
+    G1 = dH^T base [64,128] and c = colsum(dH),  dW_rgb0[:, :256] = G1 W_remap^T + c b_remap^T,  dW_remap = W_rgb0[:, :256]^T G1,  db_remap = W_rgb0[:, :256]^T c,
+    and the gradient that reaches `base` is dH (W_rgb0[:, :256] W_remap) — no [M,256] tensor exists in either pass.
+    params = (base W_0, b_0, ..., W_{D-1}, b_{D-1}, sigma W, b, remap W, b, rgb0 W, b, rgbo W, b)."""
+
+    @staticmethod
+    def forward(ctx, owner, desc, pts, viewdirs, *params):
+        dev = pts.device
+        D = desc.D
+        n, N = pts.shape[:2]
+        M = n * N
+        P = [p.detach() for p in params]
+        Wr, br, W0, b0 = P[2 * D + 2], P[2 * D + 3], P[2 * D + 4], P[2 * D + 5]
+        st = owner._bg_train_state(desc, P)                       # persistent folded weights + the fragment image (stable pointers: repack, no sync)
+        W0b = W0[:, :256].contiguous()
+        st["W_eff"].copy_(_gemm_tn_call(W0b.t().contiguous(), 64, 64, Wr, 128, 128, 256))          # [64,128] = W0b @ Wr
+        st["b_eff"].copy_((W0b * br.unsqueeze(0)).sum(1) + b0)
+        st["W_view"].copy_(W0[:, 256:])
+        owner._bg_train_pack(desc, st)
+        input_ch = 4 + 8 * desc.pos_freqs
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        acts = [f(M, 128) for _ in range(D)]
+        Hrgb, sig_pre, Epos, Eview = f(M, 64), f(M), f(M, input_ch), f(M, 16)
+        rgb, sigma = f(n, N, 3), f(n, N)
+        sv = L.MlpnetSaved()
+        for l in range(D):
+            sv.act[l] = acts[l].data_ptr()
+        sv.act_bytes = M * 128 * 4
+        sv.rgb_hidden, sv.rgb_hidden_bytes = Hrgb.data_ptr(), M * 64 * 4
+        sv.sigma_pre, sv.sigma_pre_bytes = sig_pre.data_ptr(), M * 4
+        sv.embed_pos, sv.embed_pos_bytes = Epos.data_ptr(), M * input_ch * 4
+        sv.embed_view, sv.embed_view_bytes = Eview.data_ptr(), M * 16 * 4
+        p4 = pts.detach().to(torch.float32).contiguous()
+        vd = viewdirs.detach().to(torch.float32).contiguous()
+        L.check(L.lib().tvr_mlpnet_train_forward(C.byref(desc), st["image"].data_ptr(), p4.data_ptr(), vd.data_ptr(), M, rgb.data_ptr(), sigma.data_ptr(),
+                                                 C.byref(sv), _stream_ptr(dev)), "tvr_mlpnet_train_forward")
+        ctx.save_for_backward(rgb, sig_pre, Hrgb, Epos, Eview, W0b, *acts, *P)
+        ctx.meta = (D, M, input_ch, owner._bg_layer_inputs(desc), st)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        D, M, input_ch, layer_in, st = ctx.meta
+        sv = ctx.saved_tensors
+        rgb, sig_pre, Hrgb, Epos, Eview, W0b = sv[:6]
+        acts, P = sv[6:6 + D], sv[6 + D:]
+        Ws, bs = P[2 * D], P[2 * D + 1]
+        Wr, br = P[2 * D + 2], P[2 * D + 3]
+        Wo = P[2 * D + 6]
+        dev = rgb.device
+        # heads, elementwise: sigmoid' on rgb, sign of the sigma head (sigma = |pre|)
+        dO = torch.zeros((M, 8), dtype=torch.float32, device=dev)
+        r = rgb.view(M, 3)
+        dO[:, :3] = d_rgb.reshape(M, 3) * r * (1.0 - r)
+        dHS = torch.zeros((M, 72), dtype=torch.float32, device=dev)
+        dHS[:, 64] = d_sigma.reshape(M) * torch.sign(sig_pre)
+        _linear_dx(dO, 8, 8, Wo.contiguous(), 64, 3, 64, Hrgb, 64, dHS, 72, M)                       # dH = (dO W_rgbo) * relu'
+        Wcat = st["W_cat"]
+        Wcat[:64].copy_(st["W_eff"])
+        Wcat[64].copy_(Ws.view(128))
+        dP = [None] * D
+        dP[D - 1] = torch.empty((M, 128), dtype=torch.float32, device=dev)
+        _linear_dx(dHS, 72, 72, Wcat, 128, 65, 128, acts[D - 1], 128, dP[D - 1], 128, M)              # d pre_{D-1}
+        for l in range(D - 1, 0, -1):
+            prev, pe = layer_in[l]
+            Wl = P[2 * l].contiguous()
+            dP[l - 1] = torch.empty((M, 128), dtype=torch.float32, device=dev)
+            _linear_dx(dP[l], 128, 128, Wl, Wl.shape[1], 128, 128, acts[l - 1], 128, dP[l - 1], 128, M, w_off=input_ch if pe else 0)
+        grads = []
+        for l in range(D):
+            prev, pe = layer_in[l]
+            parts = []
+            if pe:
+                parts.append(_gemm_tn_call(dP[l], 128, 128, Epos, input_ch, input_ch, M))
+            if prev:
+                parts.append(_gemm_tn_call(dP[l], 128, 128, acts[l - 1], 128, 128, M))
+            grads += [parts[0] if len(parts) == 1 else torch.cat(parts, dim=1), _colsum_call(dP[l], 128, 128, M)]
+        base = acts[D - 1]
+        g_ws = _gemm_tn_call(dHS, 72, 1, base, 128, 128, M, a_off=64)                                  # [1,128]
+        g_bs = _colsum_call(dHS, 72, 1, M, a_off=64)
+        G1 = _gemm_tn_call(dHS, 72, 64, base, 128, 128, M)                                             # dH^T base [64,128]
+        Gv = _gemm_tn_call(dHS, 72, 64, Eview, 16, 15, M)                                              # [64,15]
+        cH = _colsum_call(dHS, 72, 64, M)
+        g_w0_base = _gemm_tn_call(G1.t().contiguous(), 64, 64, Wr.t().contiguous(), 256, 256, 128) + cH.unsqueeze(1) * br.unsqueeze(0)      # [64,256]
+        g_wr = torch.cat([_gemm_tn_call(W0b, 256, 128, G1, 128, 128, 64, a_off=o) for o in (0, 128)], dim=0)                              # [256,128]
+        g_br = (W0b * cH.unsqueeze(1)).sum(0)
+        g_wo = _gemm_tn_call(dO, 8, 3, Hrgb, 64, 64, M)
+        g_bo = _colsum_call(dO, 8, 3, M)
+        grads += [g_ws, g_bs.view_as(bs), g_wr, g_br, torch.cat([g_w0_base, Gv], dim=1), cH, g_wo, g_bo]
+        return (None, None, None, None) + tuple(grads)
+
+
 def _linear(lin: torch.nn.Linear, x):
     return _LinearFn.apply(x, lin.weight, lin.bias)
 

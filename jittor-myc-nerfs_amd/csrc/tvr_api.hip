@@ -896,6 +896,31 @@ int tvr_line_ortho_backward(const float *const *vs, float *const *grads, const i
     return TVR_OK;
 }
 
+int tvr_linear_dx(const float *dY, int32_t ldy, int32_t N, const float *W, int32_t ldw, int32_t n_valid, int32_t K, const float *mask, int32_t ldm, float *dX,
+                  int32_t ldx, size_t dX_bytes, int64_t M, void *stream)
+{
+    if (M < 0) return fail(TVR_ERR_INVALID, "M < 0");
+    if (N < 8 || N > 128 || (N & 7) || n_valid < 1 || n_valid > N) return fail(TVR_ERR_UNSUPPORTED, "N = %d (a multiple of 8 in [8,128]) / n_valid = %d", N, n_valid);
+    if (K != 32 && K != 64 && K != 96 && K != 128) return fail(TVR_ERR_UNSUPPORTED, "K = %d (32, 64, 96 or 128)", K);
+    if (ldy < N || ldx < K || ldw < K || (mask && ldm < K) || (ldy & 3) || (ldx & 3) || (mask && (ldm & 3))) return fail(TVR_ERR_INVALID, "row strides: >= the row length and multiples of 4");
+    if (M == 0) return TVR_OK;
+    if (!dY || !W || !dX || ((uintptr_t)dY & 15) || ((uintptr_t)dX & 15) || ((uintptr_t)mask & 15)) return fail(TVR_ERR_INVALID, "dY / W / dX NULL or not 16-B aligned");
+    if (dX_bytes < ((size_t)(M - 1) * ldx + K) * sizeof(float)) return fail(TVR_ERR_SCRATCH, "dX holds fewer than M rows");
+    HIP_TRY(launch_linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+size_t tvr_colsum_scratch_bytes(void) { return colsum_scratch_bytes(); }
+
+int tvr_colsum(const float *A, int32_t lda, int32_t K, int64_t M, float *out, void *scratch, size_t scratch_bytes, void *stream)
+{
+    if (M < 0 || K < 1 || K > 128 || lda < K) return fail(TVR_ERR_INVALID, "bad M / K / lda (K <= 128)");
+    if (!out || (M > 0 && !A)) return fail(TVR_ERR_INVALID, "A / out NULL");
+    if (!scratch || scratch_bytes < colsum_scratch_bytes()) return fail(TVR_ERR_SCRATCH, "scratch too small (tvr_colsum_scratch_bytes)");
+    HIP_TRY(launch_colsum(A, lda, K, M, nullptr, out, (float *)scratch, (hipStream_t)stream));
+    return TVR_OK;
+}
+
 static int gemm_tn_check(int32_t Ka, int32_t Kb, int64_t M)
 {
     if (M < 0 || Ka < 1 || Kb < 1) return fail(TVR_ERR_INVALID, "bad Ka/Kb/M");

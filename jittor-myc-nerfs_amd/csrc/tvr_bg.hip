@@ -31,6 +31,14 @@
 #define TVR_BG_APF 0
 #endif
 
+// training forward: what the backward needs (all optional, NULL = inference) — relu outputs of the base layers [M,128] each, of the rgb hidden layer
+// [M,64], and the sigma head's value before `abs` [M]
+struct BgTrain {
+    float *A[4];
+    float *Hrgb;
+    float *sig_pre;
+};
+
 struct BgProgram {
     int D, n_pe_steps, input_ch, split;       // base layers [0, split) run from stage A, the rest and the heads from stage B
     int blocksA, blocksB;                     // blocks per stage (<= BG_MAX_BLOCKS); stage B's image follows stage A's in global memory
@@ -143,8 +151,19 @@ __device__ __forceinline__ void load_stage(uint4 *__restrict__ lds4, const uint4
 }
 
 // base layers [l0, l1) on one 32-sample tile: act in (unused when l0 == 0) -> act out
+// relu(act) of this lane's sample: accumulator register 4q + i of block mb <-> neuron 32 mb + 8 q + 4 h + i
+__device__ __forceinline__ void store_relu128(float *__restrict__ out, long long s, int hh, const f32x16 (&act)[4])
+{
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(float4 *)(out + s * 128 + 32 * mb + 8 * q + 4 * hh) =
+                make_float4(relu_f(act[mb][4 * q]), relu_f(act[mb][4 * q + 1]), relu_f(act[mb][4 * q + 2]), relu_f(act[mb][4 * q + 3]));
+}
+
 __device__ __forceinline__ void base_layers(const BgProgram &P, int l0, int l1, const uint4 *__restrict__ w4, const float *__restrict__ lbias, int hh,
-                                            const float x[4], f32x16 (&act)[4])
+                                            const float x[4], f32x16 (&act)[4], const BgTrain &T, long long s_store)
 {
     for (int l = l0; l < l1; ++l) {
         f32x16 out[4];
@@ -187,13 +206,14 @@ __device__ __forceinline__ void base_layers(const BgProgram &P, int l0, int l1, 
         }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) act[mb] = out[mb];
+        if (T.A[0] && s_store >= 0) store_relu128(T.A[l], s_store, hh, act);
     }
 }
 
 // heads on one tile: sigma and the 64-wide rgb hidden layer share the fragments of `base`; returns (rgb, sigma) of sample col in the
 // lanes with hh == 0
 __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restrict__ w4, const float *__restrict__ lbias, int hh, const float d[3],
-                                        const f32x16 (&act)[4])
+                                        const f32x16 (&act)[4], const BgTrain &T, long long s_store)
 {
     f32x16 hd[3] = {{0}, bias_acc(lbias + 512, hh), bias_acc(lbias + 512 + 32, hh)};      // sigma, rgb hidden block 0 / 1
 #pragma unroll
@@ -212,6 +232,15 @@ __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restr
         for (int j = 0; j < 8; ++j) v[j] = hh ? v1[j] : v0[j];
         const int blk[2] = {P.rgbh_block0 + 8, P.rgbh_block0 + 9 + 8};
         kstep<2>(w4, blk, split8(v), rh);
+    }
+    if (T.Hrgb && s_store >= 0) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4 *)(T.Hrgb + s_store * 64 + 32 * mb + 8 * q + 4 * hh) =
+                    make_float4(relu_f(rh[mb][4 * q]), relu_f(rh[mb][4 * q + 1]), relu_f(rh[mb][4 * q + 2]), relu_f(rh[mb][4 * q + 3]));
+        if (hh == 0) T.sig_pre[s_store] = hd[0][0] + lbias[576];
     }
     f32x16 eo[1] = {{0}};
 #pragma unroll
@@ -232,7 +261,7 @@ __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restr
 
 __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, const uint4 *__restrict__ image, const float *__restrict__ bias,
                                                                  const float *__restrict__ pts, const float *__restrict__ viewdirs, long long M,
-                                                                 float *__restrict__ rgb, float *__restrict__ sigma)
+                                                                 float *__restrict__ rgb, float *__restrict__ sigma, const BgTrain T)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *lds4 = reinterpret_cast<uint4 *>(smem);
@@ -255,10 +284,10 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
         __syncthreads();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const long long sr = min(((super * NT + nt) * BG_WAVES + wave) * 32 + col, M - 1);
+            const long long s = ((super * NT + nt) * BG_WAVES + wave) * 32 + col, sr = min(s, M - 1);
             const float4 p = *reinterpret_cast<const float4 *>(pts + 4 * sr);
             const float x[4] = {p.x, p.y, p.z, p.w};
-            base_layers(P, 0, la, w4, lbias, hh, x, act[nt]);
+            base_layers(P, 0, la, w4, lbias, hh, x, act[nt], T, s < M ? s : -1);
         }
         // ---------------- stage B: the remaining base layers and the heads
         __syncthreads();
@@ -271,8 +300,8 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
             const float x[4] = {p.x, p.y, p.z, p.w};
             const float *v = viewdirs + 3 * (sr / P.samples_per_ray);
             const float d[3] = {v[0], v[1], v[2]};
-            base_layers(P, la, P.D, w4, lbias, hh, x, act[nt]);
-            const float4 r = heads(P, w4, lbias, hh, d, act[nt]);
+            base_layers(P, la, P.D, w4, lbias, hh, x, act[nt], T, s < M ? s : -1);
+            const float4 r = heads(P, w4, lbias, hh, d, act[nt], T, s < M ? s : -1);
             if (h == 0 && s < M) {
                 sigma[s] = r.w;
                 rgb[3 * s] = r.x;
@@ -357,6 +386,26 @@ __global__ void __launch_bounds__(256) bg_composite_kernel(const float *__restri
         out[3 * ray + 1] = c1;
         out[3 * ray + 2] = c2;
     }
+}
+
+// The embedded inputs as matrices, for the weight gradients of the layers that read them (dW = dY^T E): E_pos [M, input_ch] = Embedder(pts) and
+// E_view [M, 16] = Embedder(viewdirs) of the sample's ray (15 values + a zero), with the network kernel's own functions and column order.
+__global__ void __launch_bounds__(256) bg_embed_kernel(const float *__restrict__ pts, const float *__restrict__ viewdirs, long long M, int input_ch, int samples_per_ray,
+                                                       float *__restrict__ Epos, float *__restrict__ Eview)
+{
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= M) return;
+    const float4 p = *reinterpret_cast<const float4 *>(pts + 4 * s);
+    const float x[4] = {p.x, p.y, p.z, p.w};
+    for (int f = 0; f < input_ch; f += 4)
+        *(float4 *)(Epos + s * input_ch + f) = make_float4(pe_feature(f, x), pe_feature(f + 1, x), pe_feature(f + 2, x), pe_feature(f + 3, x));
+    const float *v = viewdirs + 3 * (s / samples_per_ray);
+    const float d[3] = {v[0], v[1], v[2]};
+    float *e = Eview + s * 16;
+    *(float4 *)(e) = make_float4(d[0], d[1], d[2], __sinf(d[0]));
+    *(float4 *)(e + 4) = make_float4(__sinf(d[1]), __sinf(d[2]), __cosf(d[0]), __cosf(d[1]));
+    *(float4 *)(e + 8) = make_float4(__cosf(d[2]), __sinf(2.f * d[0]), __sinf(2.f * d[1]), __sinf(2.f * d[2]));
+    *(float4 *)(e + 12) = make_float4(__cosf(2.f * d[0]), __cosf(2.f * d[1]), __cosf(2.f * d[2]), 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI
@@ -466,8 +515,8 @@ int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *p, voi
     return TVR_OK;
 }
 
-int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
-                       void *stream)
+static int mlpnet_forward_impl(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
+                               const BgTrain &T, void *stream)
 {
     BgLayout L;
     if (int rc = plan(desc, L)) return rc;
@@ -484,7 +533,62 @@ int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const vo
     const char *base = static_cast<const char *>(packed);
     hipLaunchKernelGGL(bg_mlp_kernel, dim3(blocks), dim3(BG_WAVES * 64), BG_LDS_BYTES, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
                        reinterpret_cast<const float *>(base + (size_t)L.total_blocks * 2048), static_cast<const float *>(pts), static_cast<const float *>(viewdirs),
-                       (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma));
+                       (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma), T);
+    HIP_TRY(hipGetLastError());
+    return TVR_OK;
+}
+
+int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
+                       void *stream)
+{
+    BgTrain T = {};
+    return mlpnet_forward_impl(desc, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream);
+}
+
+int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
+                             const tvr_mlpnet_saved *saved, void *stream)
+{
+    if (!desc || !saved) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_train_forward: desc / saved NULL");
+    const size_t rows = n_samples < 0 ? 0 : (size_t)n_samples;
+    BgTrain T = {};
+    for (int l = 0; l < desc->D && l < 4; ++l) {
+        if (!saved->act[l] || misaligned(saved->act[l]) || saved->act_bytes < rows * 128 * 4)
+            return tvr_set_error(saved->act[l] ? TVR_ERR_SCRATCH : TVR_ERR_INVALID, "tvr_mlpnet_train_forward: act[%d] NULL, misaligned or smaller than n_samples x 128 floats", l);
+        T.A[l] = static_cast<float *>(saved->act[l]);
+    }
+    if (!saved->rgb_hidden || !saved->sigma_pre || !saved->embed_pos || !saved->embed_view || misaligned(saved->rgb_hidden) || misaligned(saved->embed_pos) ||
+        misaligned(saved->embed_view))
+        return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_train_forward: rgb_hidden / sigma_pre / embed_pos / embed_view NULL or misaligned");
+    const int input_ch = 4 + 8 * desc->pos_freqs;
+    if (saved->rgb_hidden_bytes < rows * 64 * 4 || saved->sigma_pre_bytes < rows * 4 || saved->embed_pos_bytes < rows * input_ch * 4 || saved->embed_view_bytes < rows * 16 * 4)
+        return tvr_set_error(TVR_ERR_SCRATCH, "tvr_mlpnet_train_forward: a saved buffer is smaller than its n_samples rows");
+    T.Hrgb = static_cast<float *>(saved->rgb_hidden);
+    T.sig_pre = static_cast<float *>(saved->sigma_pre);
+    if (int rc = mlpnet_forward_impl(desc, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream)) return rc;
+    if (n_samples > 0) {
+        hipLaunchKernelGGL(bg_embed_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float *>(pts),
+                           static_cast<const float *>(viewdirs), (long long)n_samples, input_ch, (int)desc->samples_per_ray, static_cast<float *>(saved->embed_pos),
+                           static_cast<float *>(saved->embed_view));
+        HIP_TRY(hipGetLastError());
+    }
+    return TVR_OK;
+}
+
+// The image again from the weights the table in `packed` already points at (same tensors, new values: every training step) — no host synchronisation.
+int tvr_mlpnet_repack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *p, void *packed, size_t packed_bytes, void *stream)
+{
+    BgLayout L;
+    if (int rc = plan(desc, L)) return rc;
+    if (!p || !packed || misaligned(packed) || packed_bytes < tvr_mlpnet_packed_bytes(desc)) return tvr_set_error(TVR_ERR_SCRATCH, "tvr_mlpnet_repack: packed buffer NULL, too small or misaligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *base = static_cast<char *>(packed);
+    float *bias = reinterpret_cast<float *>(base + (size_t)L.total_blocks * 2048);
+    PackBlock *dtab = reinterpret_cast<PackBlock *>(base + (size_t)L.total_blocks * 2048 + BG_BIAS_FLOATS * 4);
+    for (int l = 0; l < L.P.D; ++l) HIP_TRY(hipMemcpyAsync(bias + l * 128, p->base_b[l], 128 * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bias + 512, p->rgbh_b, 64 * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bias + 576, p->sigma_b, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bias + 580, p->rgbo_b, 12, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(bg_pack_kernel, dim3((unsigned)L.total_blocks), dim3(64), 0, st, dtab, reinterpret_cast<uint4 *>(base));
     HIP_TRY(hipGetLastError());
     return TVR_OK;
 }

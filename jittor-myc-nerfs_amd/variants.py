@@ -360,6 +360,51 @@ class NerfPlusPlus(TensorVMSplit):
         self._bg_image, self._bg_sig = img, sig
         return img
 
+    # ---- training through the HIP kernels (autograd_ops._BgNetFn) ----
+    fused_bg_training = True
+
+    @staticmethod
+    def _bg_layer_inputs(desc):
+        """(reads the previous activations, reads the point embedding) per base layer — MLPNet.__init__'s `if i in skips and i != D-1: dim += input_ch`."""
+        return [(l > 0, l == 0 or (l - 1 == desc.skip and l - 1 != desc.D - 1)) for l in range(desc.D)]
+
+    def _bg_net_params(self):
+        net = self.bg_net
+        ps = []
+        for layer in net.base_layers:
+            ps += [layer[0].weight, layer[0].bias]
+        return ps + [net.sigma_layers[0].weight, net.sigma_layers[0].bias, net.base_remap_layers[0].weight, net.base_remap_layers[0].bias,
+                     net.rgb_layers[0].weight, net.rgb_layers[0].bias, net.rgb_layers[2].weight, net.rgb_layers[2].bias]
+
+    def _bg_train_state(self, desc, P):
+        """Persistent buffers of the training path: the folded first rgb layer, [W_eff; w_sigma] for the backward, and the fragment image whose block table
+        points at the parameter tensors themselves (optimizers update those in place: the image is re-packed every step without a host sync)."""
+        key = tuple(p.data_ptr() for p in P) + (desc.D, desc.skip, desc.pos_freqs)
+        st = getattr(self, "_bg_tstate", None)
+        if st is None or st["key"] != key:
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
+            nbytes = L.lib().tvr_mlpnet_packed_bytes(C.byref(desc))
+            if nbytes == 0:
+                raise L.TvrError("tvr_mlpnet_packed_bytes: " + L.lib().tvr_last_error().decode(errors="replace"))
+            st = {"key": key, "W_eff": z(64, 128), "b_eff": z(64), "W_view": z(64, 15), "W_cat": z(72, 128),
+                  "image": torch.empty(nbytes, dtype=torch.uint8, device=self.device), "packed": False, "P": P}
+            p = L.MlpnetParams()
+            for l in range(desc.D):
+                p.base_W[l], p.base_b[l] = P[2 * l].data_ptr(), P[2 * l + 1].data_ptr()
+            D = desc.D
+            p.sigma_W, p.sigma_b = P[2 * D].data_ptr(), P[2 * D + 1].data_ptr()
+            p.rgbh_W_base, p.rgbh_W_view, p.rgbh_b = st["W_eff"].data_ptr(), st["W_view"].data_ptr(), st["b_eff"].data_ptr()
+            p.rgbo_W, p.rgbo_b = P[2 * D + 6].data_ptr(), P[2 * D + 7].data_ptr()
+            st["params"] = p
+            self._bg_tstate = st
+        return st
+
+    def _bg_train_pack(self, desc, st):
+        img = st["image"]
+        fn = L.lib().tvr_mlpnet_repack if st["packed"] else L.lib().tvr_mlpnet_pack
+        L.check(fn(C.byref(desc), C.byref(st["params"]), img.data_ptr(), img.numel(), _stream_ptr(self.device)), "tvr_mlpnet_(re)pack")
+        st["packed"] = True
+
     def _mlpnet(self, bg_pts, viewdirs):
         """`self.bg_net(cat(embed(pts), embed(viewdirs)))` for pts [n, N, 4] and per-ray viewdirs [n, 3]: dict(rgb [n,N,3], sigma [n,N])."""
         n, N = bg_pts.shape[:2]
@@ -368,7 +413,14 @@ class NerfPlusPlus(TensorVMSplit):
             self._bg_sig = None       # an optimizer step follows; fused optimizers do not bump the version counters `_bg_packed` watches
         # torch modules: under autograd, for shapes the kernel is not built for, and for host-logic checks of this class on a CPU device
         # (the foreground has no such path: it raises without the GPU)
-        desc = None if training or bg_pts.device.type != "cuda" else self._bg_kernel_desc()
+        desc = None if bg_pts.device.type != "cuda" else self._bg_kernel_desc()
+        if training and desc is not None and N == self.BG_SAMPLES and self.fused_bg_training and all(
+                p.is_contiguous() and p.dtype == torch.float32 for p in self._bg_net_params()):
+            from .autograd_ops import _BgNetFn
+            rgb, sigma = _BgNetFn.apply(self, desc, bg_pts, viewdirs, *self._bg_net_params())
+            return {'rgb': rgb, 'sigma': sigma}
+        if training:
+            desc = None
         if desc is None or N != self.BG_SAMPLES:
             inp = torch.cat((self.bg_embedder_position(bg_pts), self.bg_embedder_viewdir(viewdirs.unsqueeze(-2).expand(n, N, 3))), dim=-1)
             return self.bg_net(inp)

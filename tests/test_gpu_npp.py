@@ -177,6 +177,62 @@ def test_background_network_kernel_matches_torch(tiny_npp_arrays, hyper_tiny, bg
     assert m._bg_kernel_desc() is None
 
 
+@pytest.mark.parametrize("bg_freq,bg_D", [(4, 4), (2, 3), (1, 2)])
+def test_background_network_training_kernels_match_float64_autograd(tiny_npp_arrays, hyper_tiny, bg_freq, bg_D):
+    """The background network's training path without a library GEMM (autograd_ops._BgNetFn: fused forward that saves the activations, tvr_linear_dx per Linear,
+    tvr_gemm_tn / tvr_colsum for the weight / bias gradients, base_remap folded in both directions) against float64 autograd through the torch modules:
+    outputs and the gradient of every parameter (2 D + 8 tensors), on a sample count that is not a multiple of any tile."""
+    import copy
+    m = make_model(tiny_npp_arrays, hyper_tiny)
+    m.set_nerfplusplus(bg_freq=bg_freq, bg_view_freq=2, bg_D=bg_D, radii=6.0)
+    g = torch.Generator(device="cpu").manual_seed(bg_freq * 10 + bg_D)
+    with torch.no_grad():
+        for p in m.bg_net.parameters():
+            p.copy_((torch.rand(p.shape, generator=g) - 0.5).to(p.device) * (4.0 / max(p.shape[-1], 8) ** 0.5))
+    n, N = 19, m.BG_SAMPLES
+    u = torch.randn(n, N, 3, generator=g)
+    pts = torch.cat([u / u.norm(dim=-1, keepdim=True), torch.rand(n, N, 1, generator=g)], -1).cuda()
+    v = torch.randn(n, 3, generator=g)
+    v = (v / v.norm(dim=-1, keepdim=True)).cuda()
+    # positive loss weights: the per-sample contributions to a weight gradient then add up instead of cancelling, so the one-in-a-million sample whose
+    # pre-activation sits within rounding of zero (and takes the other side of the relu in fp32 than in fp64) stays ~1e-4 of the sum
+    w_rgb, w_sig = torch.rand(n, N, 3, generator=g).cuda() + 0.1, torch.rand(n, N, generator=g).cuda() + 0.1
+    ref_net = copy.deepcopy(m.bg_net).double()
+    inp = torch.cat((m.bg_embedder_position(pts), m.bg_embedder_viewdir(v.unsqueeze(-2).expand(n, N, 3))), dim=-1).double()
+    # (MLPNet.forward routes its Linears through _LinearFn; the float64 reference uses the plain module arithmetic)
+    x = inp.reshape(-1, inp.shape[-1])
+    ipts = x[:, :ref_net.input_ch]
+    base = torch.relu(torch.nn.functional.linear(ipts, ref_net.base_layers[0][0].weight, ref_net.base_layers[0][0].bias))
+    for i in range(len(ref_net.base_layers) - 1):
+        if i in ref_net.skips:
+            base = torch.cat((ipts, base), dim=-1)
+        lin = ref_net.base_layers[i + 1][0]
+        base = torch.relu(torch.nn.functional.linear(base, lin.weight, lin.bias))
+    sig_ref = torch.abs(torch.nn.functional.linear(base, ref_net.sigma_layers[0].weight, ref_net.sigma_layers[0].bias)).reshape(n, N)
+    remap = torch.nn.functional.linear(base, ref_net.base_remap_layers[0].weight, ref_net.base_remap_layers[0].bias)
+    hid = torch.relu(torch.nn.functional.linear(torch.cat((remap, x[:, -ref_net.input_ch_viewdirs:]), dim=-1), ref_net.rgb_layers[0].weight, ref_net.rgb_layers[0].bias))
+    rgb_ref = torch.sigmoid(torch.nn.functional.linear(hid, ref_net.rgb_layers[2].weight, ref_net.rgb_layers[2].bias)).reshape(n, N, 3)
+    ((rgb_ref * w_rgb.double()).sum() + (sig_ref * w_sig.double()).sum()).backward()
+
+    assert m.fused_bg_training
+    out = m._mlpnet(pts, v)
+    assert type(out["rgb"].grad_fn).__name__.startswith("_BgNetFn"), "the HIP training path did not run"
+    assert (out["rgb"].double() - rgb_ref).abs().max().item() < 2e-5 and (out["sigma"].double() - sig_ref).abs().max().item() < 2e-5 * max(1.0, sig_ref.max().item())
+    ((out["rgb"] * w_rgb).sum() + (out["sigma"] * w_sig).sum()).backward()
+    worst = 0.0
+    for (name, p), q in zip(m.bg_net.named_parameters(), ref_net.parameters()):
+        assert p.grad is not None and p.grad.shape == q.grad.shape, name
+        err = (p.grad.double() - q.grad).abs().max().item() / max(q.grad.abs().max().item(), 1e-12)
+        worst = max(worst, err)
+        assert err < 3e-3, f"{name}: gradient off by {err:.2e} of its largest entry"
+    print(f"bg training D={bg_D} freq={bg_freq}: worst relative gradient error {worst:.2e}")
+    # a second step after an in-place weight update goes through the re-pack (no table upload) and sees the new weights
+    with torch.no_grad():
+        m.bg_net.sigma_layers[0].bias.add_(1.0)
+    again = m._mlpnet(pts, v)["sigma"]
+    assert (again.detach() - out["sigma"].detach()).abs().max().item() > 0.5
+
+
 def test_background_fused_matches_torch_path(tiny_npp_arrays, hyper_tiny):
     """tvr_npp_bg_points + tvr_mlpnet_forward + tvr_npp_bg_composite against the op-for-op torch restatement of nerfplusplus.py:280-308
     (the path training uses), same injected draws."""
