@@ -188,15 +188,17 @@ class _BgNetFn(torch.autograd.Function):
                 parts.append(_gemm_tn_call(dP[l], 128, 128, acts[l - 1], 128, 128, M))
             grads += [parts[0] if len(parts) == 1 else torch.cat(parts, dim=1), _colsum_call(dP[l], 128, 128, M)]
         base = acts[D - 1]
-        g_ws = _gemm_tn_call(dHS, 72, 1, base, 128, 128, M, a_off=64)                                  # [1,128]
-        g_bs = _colsum_call(dHS, 72, 1, M, a_off=64)
-        G1 = _gemm_tn_call(dHS, 72, 64, base, 128, 128, M)                                             # dH^T base [64,128]
-        Gv = _gemm_tn_call(dHS, 72, 64, Eview, 16, 15, M)                                              # [64,15]
-        cH = _colsum_call(dHS, 72, 64, M)
+        # one pass over [dH | d sigma_pre | 0] and base: rows 0..63 = G1 = dH^T base, row 64 = the sigma head's weight gradient; likewise the column sums
+        # (row lengths are multiples of 4 thanks to the buffers' zero columns: tvr_gemm_tn then stages with 16-B loads)
+        GS = _gemm_tn_call(dHS, 72, 72, base, 128, 128, M)                                             # [72,128]
+        G1, g_ws = GS[:64].contiguous(), GS[64:65]
+        cS = _colsum_call(dHS, 72, 72, M)
+        cH, g_bs = cS[:64].contiguous(), cS[64:65]
+        Gv = _gemm_tn_call(dHS, 72, 64, Eview, 16, 16, M)[:, :15]                                      # [64,15]
         g_w0_base = _gemm_tn_call(G1.t().contiguous(), 64, 64, Wr.t().contiguous(), 256, 256, 128) + cH.unsqueeze(1) * br.unsqueeze(0)      # [64,256]
         g_wr = torch.cat([_gemm_tn_call(W0b, 256, 128, G1, 128, 128, 64, a_off=o) for o in (0, 128)], dim=0)                              # [256,128]
         g_br = (W0b * cH.unsqueeze(1)).sum(0)
-        g_wo = _gemm_tn_call(dO, 8, 3, Hrgb, 64, 64, M)
+        g_wo = _gemm_tn_call(dO, 8, 4, Hrgb, 64, 64, M)[:3]
         g_bo = _colsum_call(dO, 8, 3, M)
         grads += [g_ws, g_bs.view_as(bs), g_wr, g_br, torch.cat([g_w0_base, Gv], dim=1), cH, g_wo, g_bo]
         return (None, None, None, None) + tuple(grads)

@@ -109,7 +109,9 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
 #endif
 #define TL_PF ((TL_ROWS * 320 + 255) / 256)          // floats (or float4s / 4) per thread and chunk, at most: 20 tiles = 320 columns
 
-template <bool VEC4>
+// MODE 0: dword staging (any strides); 1: float4 staging of contiguous rows (lda == Ka, ldb == Kb: a chunk is one flat run of floats, any K);
+// 2: float4 staging of strided rows (Ka, Kb, lda, ldb multiples of 4 — operands that are column blocks of wider matrices)
+template <int MODE>
 __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float *__restrict__ A, const int lda, const int Ka,
                                                                      const float *__restrict__ B, const int ldb, const int Kb,
                                                                      const long long M_cap, float *__restrict__ P, const long long rpb_host, const unsigned *__restrict__ m_dev)
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
         rows_per_block = ((M + (long long)gridDim.x - 1) / (long long)gridDim.x + 15) / 16 * 16;
         if (rows_per_block < 64) rows_per_block = 64;
     }
+    constexpr bool VEC4 = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, k = lane >> 5;
@@ -143,6 +146,20 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
     float preA[NPRE];                                                  // (prefetch distance 2 with a second register set measured slower: 0.32 vs 0.23 ms)
     // dword staging: element e = tid + 256 j of a chunk is (row erow[j], column c) of A or B whatever the chunk — the division is done once
     int eoff[VEC4 ? 1 : TL_PF], erow[VEC4 ? 1 : TL_PF];
+    // strided float4 staging: float4 j of a thread is (row vrow[j], columns voff[j] .. + 3) of A or B — the division is done once here too
+    constexpr int NV = (TL_PF + 3) / 4;
+    int voff[MODE == 2 ? NV : 1], vrow[MODE == 2 ? NV : 1];
+    if (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = 4 * (tid + 256 * j);                          // a float4 never straddles rows or A | B: Ka, Kb are multiples of 4
+            const bool isa = e < na;
+            const int el = isa ? e : e - na, K = isa ? Ka : Kb;
+            const int r = el / K, c = el - r * K;
+            vrow[j] = e < nab ? r : TL_ROWS;
+            voff[j] = r * (isa ? lda : ldb) + c;
+        }
+    }
     if (!VEC4) {
 #pragma unroll
         for (int j = 0; j < TL_PF; ++j) {
@@ -156,7 +173,16 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
     }
     auto fetch = [&](long long m, float (&pre)[NPRE]) {
         const long long rows = m1 - m < TL_ROWS ? m1 - m : TL_ROWS;    // may be <= 0 past the end
-        if (VEC4) {
+        if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const bool in = vrow[j] < rows;
+                const bool isa = 4 * (tid + 256 * j) < na;
+                const float *base = isa ? A : B;
+                const float4 v = *(const float4 *)(base + (in ? m * (long long)(isa ? lda : ldb) + voff[j] : 0));      // unconditional load, clamped address
+                pre[4 * j] = in ? v.x : 0.0f; pre[4 * j + 1] = in ? v.y : 0.0f; pre[4 * j + 2] = in ? v.z : 0.0f; pre[4 * j + 3] = in ? v.w : 0.0f;
+            }
+        } else if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < (TL_PF + 3) / 4; ++j) {
                 const int e = 4 * (tid + 256 * j);                      // a float4 never straddles A | B: na is a multiple of 4
@@ -426,9 +452,12 @@ hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int l
     if (TVR_GEMM_F32 && TVR_GEMM_LDS && TL_ROWS * (Ka + Kb) <= 256 * TL_PF) {          // (a 20 x 1 tile product, e.g. a column sum, has up to 672 columns: old kernel)
         const int lds2 = 2 * ((TL_ROWS * (Ka + Kb) + 3) & ~3) * (int)sizeof(float);       // <= 40 KB
         // 16-B loads need contiguous rows (a chunk is then one flat run of floats) and 16-B aligned chunk starts (TL_ROWS * K * 4 B is)
-        const bool vec4 = lda == Ka && ldb == Kb && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
-        if (vec4) hipLaunchKernelGGL((gemm_tn_lds_kernel<true>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
-        else hipLaunchKernelGGL((gemm_tn_lds_kernel<false>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
+        const bool al = ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
+        if (al && lda == Ka && ldb == Kb)
+            hipLaunchKernelGGL((gemm_tn_lds_kernel<1>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
+        else if (al && !((Ka | Kb | lda | ldb) & 3))
+            hipLaunchKernelGGL((gemm_tn_lds_kernel<2>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
+        else hipLaunchKernelGGL((gemm_tn_lds_kernel<0>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
     } else if (TVR_GEMM_F32) {
         hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
     } else {

@@ -184,7 +184,8 @@ class Embedder(torch.nn.Module):
 
 
 class MLPNet(torch.nn.Module):
-    """nerfplusplus.py:66-140: the NeRF++ background network (library GEMMs; it is not on the TensoRF gather path)."""
+    """nerfplusplus.py:66-140: the NeRF++ background network as torch modules.  On the HIP device NerfPlusPlus evaluates and trains it through its own kernels
+    (tvr_mlpnet_forward / autograd_ops._BgNetFn); this `forward` is what remains for shapes those are not built for and for CPU-side host-logic checks."""
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_viewdirs=3, skips=(4,), use_viewdirs=False):
         super().__init__()

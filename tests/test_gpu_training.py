@@ -114,10 +114,13 @@ def test_gemm_tn_matches_fp64(M, Ka, Kb):
 
 
 @pytest.mark.parametrize("M,Ka,Kb,lda,ldb,offa,offb", [(60_001, 128, 123, 128, 283, 0, 160), (33_333, 96, 160, 200, 283, 7, 0), (20_011, 640, 1, 640, 1, 0, 0),
-                                                        (5_003, 150, 128, 150, 128, 0, 0), (16, 150, 128, 150, 128, 0, 0), (31, 30, 2, 30, 2, 0, 0)])
+                                                        (5_003, 150, 128, 150, 128, 0, 0), (16, 150, 128, 150, 128, 0, 0), (31, 30, 2, 30, 2, 0, 0),
+                                                        (40_007, 64, 128, 72, 128, 0, 0), (40_007, 8, 128, 72, 128, 64, 0), (9_001, 64, 16, 72, 16, 0, 0),
+                                                        (9_001, 4, 64, 8, 64, 0, 0), (21, 128, 36, 128, 36, 0, 0)])
 def test_gemm_tn_strided_blocks_and_column_sums(M, Ka, Kb, lda, ldb, offa, offb):
-    """The shapes autograd_ops._gemm_tn / _colsum hand over: column blocks of wider matrices (row stride > row length, unaligned starts: the dword
-    staging path), a 20 x 1 tile column sum (the direct-load kernel), and short / odd row counts through the 16-B staging path's ragged end."""
+    """The shapes autograd_ops._gemm_tn / _colsum / _BgNetFn hand over: column blocks of wider matrices (row stride > row length, unaligned starts: the dword
+    staging path; multiples of 4 and aligned: the strided 16-B staging path), a 20 x 1 tile column sum (the direct-load kernel), and short / odd row counts
+    through the 16-B staging paths' ragged ends."""
     from jittor_myc_nerfs_amd import _lib as L
     g = torch.Generator(device="cuda").manual_seed(M + Ka + lda)
     A = torch.randn((M, lda), device="cuda", generator=g)
