@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 113
+#define TVR_VERSION 114
 
 typedef enum {
     TVR_OK = 0,
@@ -183,6 +183,12 @@ int tvr_march_forward(tvr_scene *scene, const float *rays, int64_t n_rays, int32
 /* Explicit-depth variant (NerfPlusPlus foreground under autograd); t_last_tiny_out [n] or NULL as in tvr_render_z. */
 int tvr_march_forward_z(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *z_vals, float eps_T,
                         float *depth_out, float *t_last_tiny_out, void *scratch, size_t scratch_bytes, void *stream);
+
+/* TensorBase.filtering_rays (tensorBase.py:411-441; train.py:196-199, 296) in one pass: mask[i] = 1 if ray i is kept.  bbox_only: the slab test against the
+ * scene's aabb (t_max > t_min, zero direction components replaced by 1e-6).  Otherwise: any of the N_samples evaluation-mode samples of sample_ray
+ * (entry distance clamped to [near, far], j * stepSize) has alpha > 0 in the scene's alpha mask — all samples are looked up, as the reference does. */
+int tvr_filter_rays(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t N_samples, int32_t bbox_only, uint8_t *mask, size_t mask_bytes,
+                    void *stream);
 
 /* Gradient outputs in the REFERENCE parameter layout ((1,C,H,W) planes, (1,C,L,1) lines); each call overwrites its six. */
 typedef struct { float *density_plane[3], *density_line[3], *app_plane[3], *app_line[3]; } tvr_vm_grads;

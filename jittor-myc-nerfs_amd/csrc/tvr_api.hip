@@ -420,6 +420,18 @@ int tvr_march_forward_z(tvr_scene *s, const float *rays, int64_t n_rays, int32_t
     return march_forward_impl(s, rays, n_rays, S, sm, eps_T, depth_out, t_last_tiny_out, scratch, scratch_bytes, stream);
 }
 
+int tvr_filter_rays(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t bbox_only, uint8_t *mask, size_t mask_bytes, void *stream)
+{
+    if (!s) return fail(TVR_ERR_INVALID, "scene is NULL");
+    if (n_rays < 0 || (!bbox_only && S < 1)) return fail(TVR_ERR_INVALID, "n_rays < 0 or N_samples < 1");
+    if (n_rays == 0) return TVR_OK;
+    if (!rays || !mask) return fail(TVR_ERR_INVALID, "rays / mask NULL");
+    if (mask_bytes < (size_t)n_rays) return fail(TVR_ERR_SCRATCH, "mask holds fewer than n_rays bytes");
+    if (!bbox_only && !s->dev.avol) return fail(TVR_ERR_INVALID, "the scene has no alpha mask (tvr_scene_set_alpha): only bbox_only filtering is defined");
+    HIP_TRY(launch_filter_rays(s->dev, rays, n_rays, S, bbox_only ? 1 : 0, mask, (hipStream_t)stream));
+    return TVR_OK;
+}
+
 size_t tvr_grad_scratch_bytes(const tvr_scene *s)
 {
     if (!s) return 0;

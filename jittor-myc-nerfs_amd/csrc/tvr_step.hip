@@ -215,6 +215,53 @@ hipError_t launch_zero_f32(float *p, long long n, hipStream_t stream)       // p
 
 // the scratch header's four words {queue length, tile counter, fault, overflow} cleared by a kernel (a kernel node inside a captured step)
 __global__ void zero_header_kernel(unsigned *__restrict__ c) { c[threadIdx.x] = 0u; }       // the whole 256-B header (64 words; word 32: the march's ray counter)
+// TensorBase.filtering_rays (tensorBase.py:411-441) as one pass, one lane per ray.  bbox_only: the slab test with the reference's `1e-6` for zero direction
+// components, mask = t_max > t_min.  Otherwise: the evaluation-mode samples of sample_ray (:340-360: entry distance clamped to [near, far], j * stepSize) looked
+// up in the alpha volume — ALL of them, as the reference does (it ignores sample_ray's own bbox mask here; a point outside the volume reads zero) —
+// mask = any(alpha > 0), with the march kernel's arithmetic and the same bit-volume / float lookup.  The reference's form materialises [chunk, N_samples, 3] points per
+// 51 200-ray chunk and copies every chunk's mask to the host: 12 s for a 64 M-ray training set against 2 minutes of training.
+__global__ __launch_bounds__(256) void filter_rays_kernel(const SceneDev sc, const float *__restrict__ rays, const long long n, const int S, const int bbox_only,
+                                                          unsigned char *__restrict__ mask)
+{
+    const long long ray = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= n) return;
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = rays[ray * 6 + k];
+        d[k] = rays[ray * 6 + 3 + k];
+    }
+    if (bbox_only) {
+        float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = (d[k] == 0.0f) ? 1e-6f : d[k];
+            const float ra = (sc.hi[k] - o[k]) / v, rb = (sc.lo[k] - o[k]) / v;
+            const float lo = ra < rb ? ra : rb, hi = ra > rb ? ra : rb;
+            tmin = lo > tmin ? lo : tmin;
+            tmax = hi < tmax ? hi : tmax;
+        }
+        mask[ray] = tmax > tmin ? 1 : 0;
+        return;
+    }
+    const float tmin = ray_tmin(sc, o, d);
+    unsigned char hit = 0;
+    for (int j = 0; j < S; ++j) {
+        const float z = tmin + sc.step * (float)j;
+        float p[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = o[k] + d[k] * z;
+        if (sc.abits ? alpha_positive(sc, p) : (alpha_lookup(sc, p) > 0.0f)) { hit = 1; break; }
+    }
+    mask[ray] = hit;
+}
+
+hipError_t launch_filter_rays(const SceneDev &sc, const float *rays, long long n, int S, int bbox_only, unsigned char *mask, hipStream_t stream)
+{
+    hipLaunchKernelGGL(filter_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sc, rays, n, S, bbox_only, mask);
+    return hipGetLastError();
+}
+
 hipError_t launch_zero_header(unsigned *counter, hipStream_t stream)
 {
     hipLaunchKernelGGL(zero_header_kernel, dim3(1), dim3(64), 0, stream, counter);

@@ -554,12 +554,34 @@ class TensorBase(torch.nn.Module):
 
     @torch.no_grad()
     def filtering_rays(self, all_rays, all_rgbs, N_samples=256, chunk=10240 * 5, bbox_only=False):   # :411-441
+        """The reference's two ray filters (train.py:196-199, 296).  On the HIP device ONE kernel pass per 8 M rays (tvr_filter_rays: slab test, or the
+        evaluation-mode samples looked up in the alpha mask with early exit) and one mask per call; inputs may live on the host or on the device and are
+        returned where they were.  `chunk` is the reference's parameter, used by the torch formulation that remains for other devices."""
+        N = int(np.prod(all_rays.shape[:-1]))
+        flat = all_rays.reshape(N, all_rays.shape[-1])
+        if self.device.type == "cuda" and flat.shape[-1] == 6 and (bbox_only or self.alphaMask is not None):
+            sc = self._ensure_scene()
+            mask = torch.empty(N, dtype=torch.uint8, device=self.device)
+            big = 8 << 20
+            for i0 in range(0, N, big):
+                r = _f32c(flat[i0:i0 + big], self.device)
+                L.check(L.lib().tvr_filter_rays(sc, r.data_ptr(), r.shape[0], int(N_samples), 1 if bbox_only else 0, mask.data_ptr() + i0, r.shape[0],
+                                                _stream_ptr(self.device)), "tvr_filter_rays")
+                if not flat.is_cuda:
+                    torch.cuda.synchronize(self.device)                # the staging copy `r` is released before the next one is made
+            mask_filtered = mask.bool().to(all_rays.device).view(all_rgbs.shape[:-1])
+            return all_rays[mask_filtered], all_rgbs[mask_filtered]
+        mask_filtered = self._filtering_mask_torch(all_rays, N_samples, chunk, bbox_only).view(all_rgbs.shape[:-1])
+        return all_rays[mask_filtered], all_rgbs[mask_filtered]
+
+    def _filtering_mask_torch(self, all_rays, N_samples=256, chunk=10240 * 5, bbox_only=False):
+        """filtering_rays' mask in the reference's own formulation (op for op; host mask): the path for other devices, and what the tests hold the kernel against."""
         N = int(np.prod(all_rays.shape[:-1]))
         flat = all_rays.reshape(N, all_rays.shape[-1])
         aabb = self.aabb.to(self.device)
         masks = []
         for idx_chunk in torch.split(torch.arange(N), chunk):
-            rays_chunk = flat[idx_chunk].to(self.device)
+            rays_chunk = flat[idx_chunk.to(flat.device)].to(self.device)
             rays_o, rays_d = rays_chunk[..., :3], rays_chunk[..., 3:6]
             if bbox_only:
                 vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
@@ -572,8 +594,7 @@ class TensorBase(torch.nn.Module):
                 xyz_sampled, _, _ = self.sample_ray(rays_o, rays_d, N_samples=N_samples, is_train=False)
                 mask_inbbox = (self.alphaMask.sample_alpha(xyz_sampled).view(xyz_sampled.shape[:-1]) > 0).any(-1)
             masks.append(mask_inbbox.cpu())
-        mask_filtered = torch.cat(masks).view(all_rgbs.shape[:-1])
-        return all_rays[mask_filtered], all_rgbs[mask_filtered]
+        return torch.cat(masks)
 
     def render_rays(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None, eps_T=None, dense=False,
                     stats: Optional[torch.Tensor] = None, profile=None, out=None):

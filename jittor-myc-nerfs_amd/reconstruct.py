@@ -204,8 +204,8 @@ def reconstruction(args, device="cuda", log=print):
                                                                           len(upsamp_list) + 1))).long().tolist()][1:]
     PSNRs, PSNRs_test = [], [0]
     allrays, allrgbs = train_dataset.all_rays, train_dataset.all_rgbs
-    allrays, allrgbs = tensorf.filtering_rays(allrays, allrgbs, bbox_only=True)
     allrays, allrgbs = allrays.to(device), allrgbs.to(device)              # 288 GB of HBM: the whole training set lives on the device
+    allrays, allrgbs = tensorf.filtering_rays(allrays, allrgbs, bbox_only=True)
     sampler = SimpleSampler(allrays.shape[0], args.batch_size)
     Ortho_w, L1_w = args.Ortho_weight, args.L1_weight_inital
     TV_d, TV_a = args.TV_weight_density, args.TV_weight_app

@@ -252,6 +252,32 @@ def test_full_size_properties_config2():
     assert bool((rgb_e == 1.0).all()) and torch.equal(depth_e, rays[:, 5])
 
 
+def test_filter_rays_kernel_equals_the_reference_formulation(tiny_arrays, hyper_tiny, tiny_dump, tiny_edge):
+    """tvr_filter_rays (one pass per call) against filtering_rays in the reference's own torch formulation (tensorBase.py:411-441, restated op for op in
+    field._filtering_mask_torch): identical masks for both filters on 40 k perturbed rays — grazing rays, rays that miss the box, axis-parallel
+    rays with zero direction components, origins inside the box — with the inputs on the host and on the device; and the kept rays are the masked rays."""
+    m = make_model(tiny_arrays, hyper_tiny)
+    m.updateAlphaMask((9, 8, 7))
+    rng = np.random.default_rng(11)
+    base = np.concatenate([tiny_dump["rays"], tiny_edge["rays"]]).astype(np.float32)
+    rays = np.concatenate([base] * (40000 // base.shape[0] + 1))[:40000].copy()
+    rays[:, :3] += 0.15 * rng.standard_normal((rays.shape[0], 3)).astype(np.float32)
+    rays[:, 3:] += 0.05 * rng.standard_normal((rays.shape[0], 3)).astype(np.float32)
+    rays[::17, 3] = 0.0                                                        # zero direction components: the reference divides by 1e-6 instead
+    rays[::29, 4:6] = 0.0
+    rays[::31, :3] = 0.05 * rng.standard_normal((rays[::31].shape[0], 3)).astype(np.float32)       # origins inside the box
+    rays[-1] = [5, 5, 5, 0, 0, 1]
+    host = torch.tensor(rays)
+    rgbs = torch.arange(rays.shape[0], dtype=torch.float32).view(-1, 1).expand(-1, 3).contiguous()
+    for bbox_only, S in ((True, 256), (False, 48), (False, 256)):
+        want = m._filtering_mask_torch(host, N_samples=S, bbox_only=bbox_only)
+        assert 0 < int(want.sum()) < rays.shape[0]
+        for src in (host, host.cuda()):
+            kept, kept_rgb = m.filtering_rays(src, rgbs.to(src.device), N_samples=S, bbox_only=bbox_only)
+            assert kept.device == src.device and kept.shape[0] == int(want.sum())
+            assert torch.equal(kept_rgb[:, 0].cpu(), rgbs[want][:, 0]), f"bbox_only={bbox_only}, N_samples={S}: the kernel keeps other rays than the reference's formulas"
+
+
 def test_scene_maintenance_ops(tiny_arrays, hyper_tiny, tiny_dump):
     """getDenseAlpha / updateAlphaMask / filtering_rays / upsample_volume_grid / shrink feed the render path."""
     from oracle import c_oracle as CO, tensorf_oracle as TO
