@@ -299,6 +299,24 @@ def other_configs(budget_s=240.0):
             out[key]["command"] = "python bench.py " + " ".join(cmd[2:])
         except Exception as e:                                      # never let an extra line break the contract line
             out[key] = f"failed: {type(e).__name__}"
+    # the training step of the three models (train.py:225-261 at the reference's settings: 4096 rays, nSamples = 1039 at 300^3, MSE +
+    # regularisers + fused Adam), timed by the scripts under scripts/ in child processes
+    import re
+    root = os.path.dirname(os.path.abspath(__file__))
+    for key, script, env in (("training step: TensorVMSplit 300^3, 4096 rays x 1039 samples", "train_step_timing.py", {"TVR_MODEL": "TensorVMSplit"}),
+                             ("training step: REFTensoRF 300^3 (configs/Scar.txt), 4096 rays x 1039 samples", "train_step_timing.py", {"TVR_MODEL": "REFTensoRF"}),
+                             ("training step: NerfPlusPlus 300^3 (configs/Scarf.txt), 4096 rays x (1039 + 512 background) samples", "npp_train_step_timing.py", {})):
+        if time.time() - t0 > budget_s:
+            out[key] = "skipped: time budget"
+            continue
+        try:
+            r = subprocess.run([sys.executable, os.path.join(root, "scripts", script)], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+            mt = re.search(r"train step[^:]*: *([0-9.]+) ms", r.stdout)
+            ms = float(mt.group(1))
+            out[key] = {"ms_per_step": ms, "iterations_per_sec": 1e3 / ms, "rays_per_sec": 4096e3 / ms,
+                        "command": " ".join(f"{k}={v}" for k, v in env.items()) + (" " if env else "") + "python scripts/" + script}
+        except Exception as e:
+            out[key] = f"failed: {type(e).__name__}"
     return out
 
 
