@@ -42,6 +42,7 @@ def step():
         m.penalty = torch.zeros((), device="cuda")
     total.backward()
     if bucket: bucket.all_reduce_mean()
+    if int(os.environ.get("TVR_LOOP_SYNC", "0")) == 2: opt.found_inf = m.training_fault_flag()
     opt.step()
     return loss
 N = 20
@@ -73,8 +74,13 @@ if GRAPH:
     fault = m.check_training_faults()                 # (None on a healthy run; 'overflow' means the timed steps worked on a truncated queue)
     if fault is not None: print("WARNING: check_training_faults() ->", fault)
 else:
+    SYNC = int(os.environ.get("TVR_LOOP_SYNC", "0"))          # 1: read the loss and the fault flags on the host after every step, as train.py:262 does;
+                                                              # 2: reconstruct.py's loop — the flags guard the fused Adam on the device, no host read
     for _ in range(3): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(N): l = step()
+    for _ in range(N):
+        l = step()
+        if SYNC == 1:
+            m.check_training_faults(); float(l.detach())
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
 if rank == 0: print(f"{MODEL} (fused MLP kernels {int(m.fused_mlp_training)}, static step {int(m.static_training)}, hipGraph {int(GRAPH)}) train step ({world} rank(s), {4096 // world} rays each): {dt * 1e3:.2f} ms  ({1 / dt:.1f} it/s), batch 4096 rays x {nS} samples, loss {float(l.detach()):.3e}")

@@ -193,3 +193,38 @@ def test_saturation_flag_rises_and_the_lowered_scale_gives_right_gradients(tiny_
     lib.static_training = lib.fused_mlp_training = False
     for x, y in zip(g, grads(lib)):
         assert bool(torch.isfinite(x).all()) and _close(x, y, 2e-4)
+
+
+def test_fault_flag_guards_the_fused_optimizer_on_the_device(tiny_dump, tiny_arrays, hyper_tiny):
+    """The loop without a host read per step (reconstruct.py): `optimizer.found_inf = model.training_fault_flag()` — torch's fused Adam kernel skips the update
+    of a step that raised a fault flag, by itself; a healthy step is applied; and check_training_faults() later reports, from the accumulator, what was
+    skipped in between (and adjusts the capacity) — also after a healthy step has overwritten the scratch header."""
+    rays = _batch(tiny_dump, 64)
+    m = make_model(tiny_arrays, hyper_tiny)
+    opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99), fused=True)
+    net, vm = _net_and_vm(m)
+
+    def one_step():
+        opt.zero_grad()
+        rgb, _ = m.render_rays_autograd(rays, white_bg=True, N_samples=TINY["N_samples"])
+        ((rgb - 0.3) ** 2).mean().backward()
+        opt.found_inf = m.training_fault_flag()
+        flag = opt.found_inf.clone()
+        before = [p.detach().clone() for p in net + vm]
+        opt.step()
+        return float(flag), [float((p.detach() - q).abs().max()) for p, q in zip(net + vm, before)]
+
+    flag, moved = one_step()
+    assert flag == 0.0 and max(moved) > 0.0                            # a healthy step is applied
+    m.train_app_samples_per_ray = 1                                    # the next step overflows its workspace
+    m._train_buf = None
+    flag, moved = one_step()
+    assert flag == 1.0 and max(moved) == 0.0, "the fused optimizer applied a step whose gradients are void"
+    steps = {float(st["step"]) for st in opt.state.values()}
+    assert steps == {1.0}                                              # ... and did not count it
+    m.train_app_samples_per_ray = 192
+    m._train_buf = None
+    flag, moved = one_step()                                           # healthy again (its march has zeroed the header words)
+    assert flag == 0.0 and max(moved) > 0.0
+    assert m.check_training_faults() == "overflow"                     # the accumulator remembers the skipped step
+    assert m.check_training_faults() is None
