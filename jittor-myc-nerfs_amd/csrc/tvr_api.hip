@@ -663,7 +663,7 @@ static WorkLayout work_layout(int64_t n_rays, int32_t S, int64_t cap)
     L.d_out4 = take(c * 4); L.dh2 = take(c * TVR_FEATC); L.dh1 = take(c * TVR_FEATC); L.dfeats32 = take(c * 32); L.dg8 = take(c * 8); L.dh = take(c * TVR_KAPP);
     L.X = take(c * TVR_NIN_REF);
     L.tmp = take(32 * TVR_KAPP + 128);                        // gemm_tn results that are wider than the gradient they feed ([4,128], [32,144], [8,144]) and bias sums
-    size_t g = gemm_tn_scratch_bytes(TVR_FEATC, TVR_NIN_REF, cap);
+    size_t g = gemm_tn_scratch_bytes(TVR_FEATC, TVR_NIN_REF + 1, cap);        // (+ 1: the ones column that carries the bias gradient)
     L.gemm = take(g / sizeof(float) + 64);
     L.colsum = take(colsum_scratch_bytes() / sizeof(float));
     L.image = take(mlp_train_image_bytes() / sizeof(float) + 64);
@@ -760,10 +760,13 @@ int tvr_train_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     if (ref) HIP_TRY(launch_pe_concat_strided(F(W.feats32), 32, F(W.feats32) + 27, 32, nullptr, nullptr, F(W.feats32) + 30, 32, app_cap, mdev, F(W.X), stream));
     else HIP_TRY(launch_pe_concat_strided(F(W.feats32), 32, nullptr, 0, rays, mo.q_ray, nullptr, 0, app_cap, mdev, F(W.X), stream));
     float *tmp = F(W.tmp), *gsc = F(W.gemm), *csc = F(W.colsum);
-    HIP_TRY(launch_gemm_tn(F(W.d_out4), 4, 4, F(W.h2), TVR_FEATC, TVR_FEATC, app_cap, tmp, gsc, stream, mdev));
+    // (the bias gradients ride along as a virtual ones column of the second operand: no second pass over d_out / dh2 / dh1)
+    float *bs3 = tmp + 32 * TVR_KAPP + 16;
+    HIP_TRY(launch_gemm_tn(F(W.d_out4), 4, 4, F(W.h2), TVR_FEATC, TVR_FEATC, app_cap, tmp, gsc, stream, mdev, bs3));
     HIP_TRY(launch_copy_f32(mo_->W3, tmp, 3 * TVR_FEATC, stream));
-    HIP_TRY(launch_gemm_tn(F(W.dh2), TVR_FEATC, TVR_FEATC, F(W.h1), TVR_FEATC, TVR_FEATC, app_cap, mo_->W2, gsc, stream, mdev));
-    HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X), nin, nin, app_cap, mo_->W1, gsc, stream, mdev));
+    HIP_TRY(launch_copy_f32(mo_->b3, bs3, 3, stream));
+    HIP_TRY(launch_gemm_tn(F(W.dh2), TVR_FEATC, TVR_FEATC, F(W.h1), TVR_FEATC, TVR_FEATC, app_cap, mo_->W2, gsc, stream, mdev, mo_->b2));
+    HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X), nin, nin, app_cap, mo_->W1, gsc, stream, mdev, mo_->b1));
     HIP_TRY(launch_gemm_tn(F(W.dfeats32), 32, 32, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev));
     HIP_TRY(launch_copy_f32(mo_->basis, tmp, TVR_APPDIM * TVR_KAPP, stream));
     if (ref) {
@@ -778,13 +781,6 @@ int tvr_train_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
         HIP_TRY(launch_copy_f32(mo_->heads_b[2], bs + 3, 1, stream));
         HIP_TRY(launch_copy_f32(mo_->heads_b[1], bs + 4, 3, stream));
         HIP_TRY(launch_copy_f32(mo_->heads_b[3], bs + 7, 1, stream));
-    }
-    {
-        float *bs = tmp + 32 * TVR_KAPP + 16;
-        HIP_TRY(launch_colsum(F(W.d_out4), 4, 4, app_cap, mdev, bs, csc, stream));
-        HIP_TRY(launch_copy_f32(mo_->b3, bs, 3, stream));
-        HIP_TRY(launch_colsum(F(W.dh2), TVR_FEATC, TVR_FEATC, app_cap, mdev, mo_->b2, csc, stream));
-        HIP_TRY(launch_colsum(F(W.dh1), TVR_FEATC, TVR_FEATC, app_cap, mdev, mo_->b1, csc, stream));
     }
     // 4. scatter dh into the appearance planes / lines, then the march backward for the density factors
     rc = app_h_backward_impl(s, (const float *)mo.q_pos, 4, app_cap, mdev, F(W.dh), grad_scratch, grad_scratch_bytes, vm_out, stream_);

@@ -114,9 +114,12 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
 template <int MODE>
 __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float *__restrict__ A, const int lda, const int Ka,
                                                                      const float *__restrict__ B, const int ldb, const int Kb,
-                                                                     const long long M_cap, float *__restrict__ P, const long long rpb_host, const unsigned *__restrict__ m_dev)
+                                                                     const long long M_cap, float *__restrict__ P, const long long rpb_host, const unsigned *__restrict__ m_dev,
+                                                                     const int ones)
 {
     // m_dev: the row count lives on the device (M_cap = capacity, the grid is sized for it); the slabs are then cut from the true count here
+    // ones = 1: B has one more, VIRTUAL, column of ones (never read from memory): column Kb of the result is A^T 1 = the column sums of A — the bias
+    // gradient of the Linear whose weight gradient this product is, without a second pass over A
     const long long M = m_dev ? ((long long)*m_dev < M_cap ? (long long)*m_dev : M_cap) : M_cap;
     long long rows_per_block = rpb_host;
     if (m_dev) {
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, k = lane >> 5;
-    const int nrb = (Ka + 31) >> 5, ncb = (Kb + 31) >> 5, ntiles = nrb * ncb;
+    const int Kc = Kb + ones;                                           // columns of the result
+    const int nrb = (Ka + 31) >> 5, ncb = (Kc + 31) >> 5, ntiles = nrb * ncb;
     const int na = TL_ROWS * Ka, nab = TL_ROWS * (Ka + Kb);             // floats of A / of A and B in one chunk (both multiples of 4)
     int offA[TG_MAXT], offB[TG_MAXT];
     f32x16 acc[TG_MAXT];
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
         const int t = wave + q * TG_WAVES;
         const int rb = t / ncb, cb = t - rb * ncb;
         offA[q] = (t < ntiles && rb * 32 + i < Ka) ? rb * 32 + i : -1;
-        offB[q] = (t < ntiles && cb * 32 + i < Kb) ? cb * 32 + i : -1;
+        offB[q] = (t < ntiles && cb * 32 + i < Kb) ? cb * 32 + i : ((t < ntiles && cb * 32 + i < Kc) ? -2 : -1);      // -2: the virtual ones column
         acc[q] = f32x16{0};
     }
     const long long m0 = (long long)blockIdx.x * rows_per_block;
@@ -263,7 +267,8 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
 #pragma unroll
             for (int q = 0; q < TG_MAXT; ++q)
                 if (q < nq)                                             // wave-uniform: tiles this wave does not have cost no matrix-pipe time
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(offA[q] >= 0 ? va[u & 1][q] : 0.0f, offB[q] >= 0 ? vb[u & 1][q] : 0.0f, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(offA[q] >= 0 ? va[u & 1][q] : 0.0f, offB[q] >= 0 ? vb[u & 1][q] : (offB[q] == -2 ? 1.0f : 0.0f),
+                                                                  acc[q], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * k;
-            if (row < Ka && col < Kb) P[((size_t)blockIdx.x * Ka + row) * Kb + col] = acc[q][r];
+            if (row < Ka && col < Kc) P[((size_t)blockIdx.x * Ka + row) * Kc + col] = acc[q][r];
         }
     }
 }
@@ -415,6 +420,24 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
     if (e < n && l == 0) C[e] = s;
 }
 
+// the same for a [Ka, Kb + 1] product whose last column is the bias gradient: columns < Kb go to C (row stride Kb), column Kb to bias
+__global__ __launch_bounds__(256) void gemm_tn_reduce_bias_kernel(const float *__restrict__ P, const int n_slabs, const int Ka, const int Kb, float *__restrict__ C,
+                                                                  float *__restrict__ bias)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t >> 4, l = t & 15, n = Ka * (Kb + 1);
+    float s = 0.0f;
+    if (e < n)
+        for (int b = l; b < n_slabs; b += 16) s = s + P[(size_t)b * n + e];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) s = s + __shfl_xor(s, off);
+    if (e < n && l == 0) {
+        const int row = e / (Kb + 1), col = e - row * (Kb + 1);
+        if (col < Kb) C[row * Kb + col] = s;
+        else bias[row] = s;
+    }
+}
+
 static int cu_count()
 {
     static int cus = 0;
@@ -441,11 +464,17 @@ size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M)
 }
 
 hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream,
-                          const unsigned *m_dev)
+                          const unsigned *m_dev, float *bias_out)
 {
     long long grid, rpb;
     gemm_tn_shape(M, grid, rpb);
-    if (grid == 0) return hipMemsetAsync(C, 0, (size_t)Ka * Kb * sizeof(float), stream);
+    const int ones = bias_out ? 1 : 0;
+    if (grid == 0) {
+        hipError_t rc = hipMemsetAsync(C, 0, (size_t)Ka * Kb * sizeof(float), stream);
+        if (rc == hipSuccess && bias_out) rc = hipMemsetAsync(bias_out, 0, (size_t)Ka * sizeof(float), stream);
+        return rc;
+    }
+    if (ones && !(TVR_GEMM_F32 && TVR_GEMM_LDS && TL_ROWS * (Ka + Kb) <= 256 * TL_PF)) return hipErrorInvalidValue;      // (only the LDS-staged kernel has the ones column)
     const int lds = 64 * 1024;                                     // unused; caps the CU at two workgroups (see header)
     hipError_t rc = hipFuncSetAttribute((const void *)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
@@ -454,10 +483,10 @@ hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int l
         // 16-B loads need contiguous rows (a chunk is then one flat run of floats) and 16-B aligned chunk starts (TL_ROWS * K * 4 B is)
         const bool al = ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
         if (al && lda == Ka && ldb == Kb)
-            hipLaunchKernelGGL((gemm_tn_lds_kernel<1>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
+            hipLaunchKernelGGL((gemm_tn_lds_kernel<1>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev, ones);
         else if (al && !((Ka | Kb | lda | ldb) & 3))
-            hipLaunchKernelGGL((gemm_tn_lds_kernel<2>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
-        else hipLaunchKernelGGL((gemm_tn_lds_kernel<0>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
+            hipLaunchKernelGGL((gemm_tn_lds_kernel<2>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev, ones);
+        else hipLaunchKernelGGL((gemm_tn_lds_kernel<0>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev, ones);
     } else if (TVR_GEMM_F32) {
         hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
     } else {
@@ -465,7 +494,8 @@ hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int l
         if (rc != hipSuccess) return rc;
         hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
     }
-    const int n = Ka * Kb;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, scratch, (int)grid, n, C);
+    const int n = Ka * (Kb + ones);
+    if (ones) hipLaunchKernelGGL(gemm_tn_reduce_bias_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, scratch, (int)grid, Ka, Kb, C, bias_out);
+    else hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, scratch, (int)grid, n, C);
     return hipGetLastError();
 }

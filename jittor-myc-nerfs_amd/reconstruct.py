@@ -147,19 +147,23 @@ def render_test(args, device="cuda"):
     return out
 
 
-def reconstruction(args, device="cuda", log=print):
-    """train.py:113-371.  Returns (tensorf, logfolder, PSNRs_test of the last visualisation or final test)."""
+def reconstruction(args, device="cuda", log=print, train_dataset=None, val_dataset=None):
+    """train.py:113-371.  Returns (tensorf, logfolder, PSNRs_test of the last visualisation or final test).
+    `train_dataset` / `val_dataset`: ready-made datasets (objects with all_rays, all_rgbs, scene_bbox, white_bg, near_far as BlenderRays has them) instead of the
+    Blender folder under args.datadir — synthetic training sets (scripts/reconstruction_timing.py)."""
     if args.dataset_name != "blender":
         raise NotImplementedError("only the Blender loader exists in the reference (dataLoader/__init__.py)")
     if args.model_name not in MODELS:
         raise NotImplementedError(f"model_name {args.model_name!r} is outside the accelerated path (TensorVMSplit, REFTensoRF, NerfPlusPlus)")
     if args.ndc_ray:
         raise NotImplementedError("ndc_ray datasets are not part of the reference's loaders")
-    train_dataset = BlenderRays(args.datadir, split="train", downsample=args.downsample_train, is_stack=False, bbox=_bbox(args), near=args.near,
-                                far=args.far, white_bg=args.white_bkgd)
-    val_split = "val" if os.path.exists(os.path.join(args.datadir, "transforms_val.json")) else "train"
-    val_dataset = BlenderRays(args.datadir, split=val_split, downsample=args.downsample_train, is_stack=True, bbox=_bbox(args), near=args.near,
-                              far=args.far, white_bg=args.white_bkgd)
+    if train_dataset is None:
+        train_dataset = BlenderRays(args.datadir, split="train", downsample=args.downsample_train, is_stack=False, bbox=_bbox(args), near=args.near,
+                                    far=args.far, white_bg=args.white_bkgd)
+    if val_dataset is None:
+        val_split = "val" if os.path.exists(os.path.join(args.datadir, "transforms_val.json")) else "train"
+        val_dataset = BlenderRays(args.datadir, split=val_split, downsample=args.downsample_train, is_stack=True, bbox=_bbox(args), near=args.near,
+                                  far=args.far, white_bg=args.white_bkgd)
     white_bg, near_far = train_dataset.white_bg, train_dataset.near_far
     upsamp_list = list(args.upsamp_list or [])
     update_AlphaMask_list = list(args.update_AlphaMask_list or [])

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""GPU box: the reference's WHOLE reconstruction run (tensorf-myc/train.py:113-371 through reconstruct.reconstruction — the real loop, not a step in isolation)
+at the schedule of configs/Coffee.txt: 30 000 iterations of 4096 rays, 128^3 -> 300^3 with five upsamplings, two alpha-mask updates (shrink, ray filtering),
+TV + L1 regularisers, fused Adam with per-group lr decay.  The training set is synthetic: scene A rendered by a teacher model from `--views`
+poses at --img x --img (100 x 800 x 800 = 64 M rays, all resident in HBM).
+
+    python3 scripts/reconstruction_timing.py [--iters 30000] [--views 100] [--img 800] [--model TensorVMSplit]
+Prints the wall time of every phase (teacher render, both ray filters, every 1000 iterations with their it/s) and the PSNR on a held-out pose."""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+from jittor_myc_nerfs_amd import rays as R
+from jittor_myc_nerfs_amd.reconstruct import config_parser, reconstruction
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=30000)
+ap.add_argument("--views", type=int, default=100)
+ap.add_argument("--img", type=int, default=800)
+ap.add_argument("--model", default="TensorVMSplit", choices=["TensorVMSplit", "REFTensoRF"])
+a = ap.parse_args()
+dev = torch.device("cuda")
+t_all = time.perf_counter()
+teacher, arrs, A = bench.build_model(dev, a.model)
+poses = []                                                   # four rings of elevations; the last pose is held out
+per = (a.views + 1 + 3) // 4
+for el in (30.0, 55.0, 5.0, -20.0):
+    poses += R.sphere_poses(per, A["cam_radius"], elevation_deg=el)
+poses = poses[:a.views + 1]
+t0 = time.perf_counter()
+with torch.no_grad():
+    frames = [R.frame_rays(M, a.img, a.img, A["camera_angle_x"]).to(dev) for M in poses]
+    rgbs = [teacher.render_rays(f, white_bg=True, N_samples=A["N_samples"])[0] for f in frames]
+torch.cuda.synchronize()
+print("teacher: %d views of %d x %d rendered in %.2f s" % (len(poses), a.img, a.img, time.perf_counter() - t0), flush=True)
+del teacher
+
+
+class Set:
+    pass
+
+
+train, val = Set(), Set()
+train.all_rays, train.all_rgbs = torch.cat(frames[:-1]), torch.cat(rgbs[:-1])
+val.all_rays, val.all_rgbs = frames[-1].view(a.img, a.img, 6)[None], rgbs[-1].view(a.img, a.img, 3)[None]
+for d in (train, val):
+    d.scene_bbox = torch.tensor(np.asarray(A["aabb"], dtype=np.float32)).reshape(2, 3)
+    d.white_bg, d.near_far = True, list(A["near_far"])
+del frames, rgbs
+
+tmp = tempfile.mkdtemp(prefix="recon_")
+cmd = ["--dataset_name", "blender", "--expname", "timing", "--basedir", tmp, "--n_iters", str(a.iters), "--batch_size", "4096",
+       "--N_voxel_init", str(128 ** 3), "--N_voxel_final", str(300 ** 3), "--N_vis", "0", "--vis_every", "100000", "--progress_refresh_rate", "10",
+       "--model_name", a.model, "--shadingMode", "MLP_Fea", "--fea2denseAct", "softplus", "--view_pe", "2", "--fea_pe", "2",
+       "--L1_weight_inital", "4e-5", "--L1_weight_rest", "2e-5", "--TV_weight_density", "0.3", "--TV_weight_app", "0.3", "--rm_weight_mask_thre", "1e-3",
+       "--white_bkgd"]
+for v in (16, 16, 16):
+    cmd += ["--n_lamb_sigma", str(v)]
+for v in (48, 48, 48):
+    cmd += ["--n_lamb_sh", str(v)]
+scale = a.iters / 30000.0
+for v in (2000, 3000, 4000, 5500, 7000):
+    cmd += ["--upsamp_list", str(int(v * scale))]
+for v in (2000, 4000):
+    cmd += ["--update_AlphaMask_list", str(int(v * scale))]
+if a.model == "REFTensoRF":
+    cmd += ["--normal_vector_penalty_weight", "1e-3"]
+args = config_parser(cmd)
+
+marks = []
+
+
+def log(msg):
+    if msg.startswith("Iteration"):
+        it = int(msg.split()[1].rstrip(":"))
+        if it % 1000 == 0:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            if marks:
+                print("  %s | %.1f it/s over the last 1000" % (msg, 1000.0 / (now - marks[-1])), flush=True)
+            else:
+                print("  " + msg, flush=True)
+            marks.append(now)
+    else:
+        print("  " + msg, flush=True)
+
+
+t0 = time.perf_counter()
+model, folder, _ = reconstruction(args, device="cuda", log=log, train_dataset=train, val_dataset=val)
+torch.cuda.synchronize()
+t_train = time.perf_counter() - t0
+with torch.no_grad():
+    out, _ = model(val.all_rays.view(-1, 6), is_train=False, white_bg=True, N_samples=-1)[:2]
+psnr = float(-10 * torch.log10(torch.mean((out - val.all_rgbs.view(-1, 3)) ** 2)))
+print("reconstruction(%s): %d iterations in %.1f s (%.1f it/s over the whole run, everything included), held-out PSNR %.2f dB, final grid %s"
+      % (a.model, a.iters, t_train, a.iters / t_train, psnr, model.gridSize.tolist()), flush=True)
+print("whole script: %.1f s" % (time.perf_counter() - t_all))
