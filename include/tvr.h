@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 114
+#define TVR_VERSION 115
 
 typedef enum {
     TVR_OK = 0,
@@ -294,6 +294,10 @@ int tvr_train_backward(tvr_scene *scene, const float *rays, int64_t n_rays, int3
 size_t tvr_gemm_tn_scratch_bytes(int32_t Ka, int32_t Kb, int64_t M);
 int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C,
                 void *scratch, size_t scratch_bytes, void *stream);
+/* The same product plus colsum_A [Ka] = A^T 1 in the same pass (a virtual ones column of B): the weight and the bias gradient of a Linear from one read of dY.
+ * Ka x (Kb + 1) must fit the 20 tiles, Ka + Kb <= 320; scratch: tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M). */
+int tvr_gemm_tn_bias(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C, float *colsum_A,
+                     void *scratch, size_t scratch_bytes, void *stream);
 
 /* The MLP input of the training step in one pass: X [m,150] = [features 27, viewdirs 3, PE(features), PE(viewdirs)] (MLPRender_Fea.execute,
  * tensorBase.py:76-82; positional_encoding :9-15), or X [m,151] with dot_product [m] in front (MLPRender_Fea_Ref, REFTensoRF.py:19-24) when

@@ -60,6 +60,16 @@ def _gemm_tn_call(a, lda, Ka, b, ldb, Kb, M, a_off=0, b_off=0):
     return out
 
 
+def _gemm_tn_bias_call(a, lda, Ka, b, ldb, Kb, M, a_off=0, b_off=0):
+    """(a^T b [Ka,Kb], colsum(a) [Ka]) from ONE pass over a (tvr_gemm_tn_bias: the bias gradient rides along as a virtual ones column)."""
+    out = torch.empty((Ka, Kb), dtype=torch.float32, device=a.device)
+    cs = torch.empty(Ka, dtype=torch.float32, device=a.device)
+    scratch = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M), dtype=torch.uint8, device=a.device)
+    L.check(L.lib().tvr_gemm_tn_bias(a.data_ptr() + 4 * a_off, lda, Ka, b.data_ptr() + 4 * b_off, ldb, Kb, M, out.data_ptr(), cs.data_ptr(), scratch.data_ptr(),
+                                     scratch.numel(), _stream_ptr(a.device)), "tvr_gemm_tn_bias")
+    return out, cs
+
+
 def _gemm_tn(gy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """dW [Ka,Kb] = gy^T x for contiguous fp32 gy [M,Ka], x [M,Kb] through tvr_gemm_tn (deterministic).  The kernel takes at most 20
     32x32 output tiles per call: wider products are cut into column blocks of gy and x (pointer offsets, same row strides)."""
@@ -181,25 +191,29 @@ class _BgNetFn(torch.autograd.Function):
         grads = []
         for l in range(D):
             prev, pe = layer_in[l]
-            parts = []
+            parts, gb = [], None                                    # (the bias gradient rides along in the first product: no extra pass over dP[l])
             if pe:
-                parts.append(_gemm_tn_call(dP[l], 128, 128, Epos, input_ch, input_ch, M))
+                g, gb = _gemm_tn_bias_call(dP[l], 128, 128, Epos, input_ch, input_ch, M)
+                parts.append(g)
             if prev:
-                parts.append(_gemm_tn_call(dP[l], 128, 128, acts[l - 1], 128, 128, M))
-            grads += [parts[0] if len(parts) == 1 else torch.cat(parts, dim=1), _colsum_call(dP[l], 128, 128, M)]
+                if gb is None:
+                    g, gb = _gemm_tn_bias_call(dP[l], 128, 128, acts[l - 1], 128, 128, M)
+                else:
+                    g = _gemm_tn_call(dP[l], 128, 128, acts[l - 1], 128, 128, M)
+                parts.append(g)
+            grads += [parts[0] if len(parts) == 1 else torch.cat(parts, dim=1), gb]
         base = acts[D - 1]
         # one pass over [dH | d sigma_pre | 0] and base: rows 0..63 = G1 = dH^T base, row 64 = the sigma head's weight gradient; likewise the column sums
         # (row lengths are multiples of 4 thanks to the buffers' zero columns: tvr_gemm_tn then stages with 16-B loads)
-        GS = _gemm_tn_call(dHS, 72, 72, base, 128, 128, M)                                             # [72,128]
+        GS, cS = _gemm_tn_bias_call(dHS, 72, 72, base, 128, 128, M)                                    # [72,128], [72]
         G1, g_ws = GS[:64].contiguous(), GS[64:65]
-        cS = _colsum_call(dHS, 72, 72, M)
         cH, g_bs = cS[:64].contiguous(), cS[64:65]
         Gv = _gemm_tn_call(dHS, 72, 64, Eview, 16, 16, M)[:, :15]                                      # [64,15]
         g_w0_base = _gemm_tn_call(G1.t().contiguous(), 64, 64, Wr.t().contiguous(), 256, 256, 128) + cH.unsqueeze(1) * br.unsqueeze(0)      # [64,256]
         g_wr = torch.cat([_gemm_tn_call(W0b, 256, 128, G1, 128, 128, 64, a_off=o) for o in (0, 128)], dim=0)                              # [256,128]
         g_br = (W0b * cH.unsqueeze(1)).sum(0)
-        g_wo = _gemm_tn_call(dO, 8, 4, Hrgb, 64, 64, M)[:3]
-        g_bo = _colsum_call(dO, 8, 3, M)
+        g_wo, g_bo = _gemm_tn_bias_call(dO, 8, 4, Hrgb, 64, 64, M)
+        g_wo, g_bo = g_wo[:3], g_bo[:3]
         grads += [g_ws, g_bs.view_as(bs), g_wr, g_br, torch.cat([g_w0_base, Gv], dim=1), cH, g_wo, g_bo]
         return (None, None, None, None) + tuple(grads)
 

@@ -954,6 +954,19 @@ int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t
     return TVR_OK;
 }
 
+int tvr_gemm_tn_bias(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C, float *colsum_A, void *scratch,
+                     size_t scratch_bytes, void *stream)
+{
+    int rc = gemm_tn_check(Ka, Kb + 1, M);
+    if (rc != TVR_OK) return rc;
+    if (!C || !colsum_A || (M > 0 && (!A || !B))) return fail(TVR_ERR_INVALID, "A/B/C/colsum_A NULL");
+    if (lda < Ka || ldb < Kb) return fail(TVR_ERR_INVALID, "lda/ldb smaller than the row length");
+    if (16 * (Ka + Kb) > 256 * 20) return fail(TVR_ERR_UNSUPPORTED, "Ka + Kb = %d exceeds the 320 staged columns of the kernel that carries the ones column", Ka + Kb);
+    if (M > 0 && (!scratch || scratch_bytes < gemm_tn_scratch_bytes(Ka, Kb + 1, M))) return fail(TVR_ERR_SCRATCH, "scratch too small (tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M))");
+    HIP_TRY(launch_gemm_tn(A, lda, Ka, B, ldb, Kb, M, C, (float *)scratch, (hipStream_t)stream, nullptr, colsum_A));
+    return TVR_OK;
+}
+
 int tvr_density_feature(tvr_scene *s, const float *xyz, int64_t m, float *out, size_t out_bytes, void *stream)
 {
     if (m > 0) NEED("out [m]", out_bytes, m, 1);

@@ -134,6 +134,15 @@ def test_gemm_tn_strided_blocks_and_column_sums(M, Ka, Kb, lda, ldb, offa, offb)
     out2 = torch.empty_like(out)
     L.check(L.lib().tvr_gemm_tn(A.data_ptr() + 4 * offa, lda, Ka, B.data_ptr() + 4 * offb, ldb, Kb, M, out2.data_ptr(), sc.data_ptr(), sc.numel(), None), "tvr_gemm_tn")
     assert torch.equal(out, out2)
+    # the same product with the column sums of A riding along as a virtual ones column of B (weight + bias gradient from one pass over dY)
+    if ((Ka + 31) // 32) * ((Kb + 1 + 31) // 32) <= 20 and Ka + Kb <= 320:
+        out3, cs = torch.full((Ka, Kb), float("nan"), device="cuda"), torch.full((Ka,), float("nan"), device="cuda")
+        sc3 = torch.empty(max(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M), 1), dtype=torch.uint8, device="cuda")
+        L.check(L.lib().tvr_gemm_tn_bias(A.data_ptr() + 4 * offa, lda, Ka, B.data_ptr() + 4 * offb, ldb, Kb, M, out3.data_ptr(), cs.data_ptr(), sc3.data_ptr(), sc3.numel(),
+                                         None), "tvr_gemm_tn_bias")
+        assert torch.equal(out3, out), "the ones column changed the product"
+        ref_cs = A[:, offa:offa + Ka].double().sum(0)
+        assert float((cs.double() - ref_cs).abs().max()) / max(1.0, float(ref_cs.abs().max())) < 2e-6
 
 
 def test_fused_adam_updates_reach_the_packed_scene(tiny_arrays, hyper_tiny, tiny_dump):
