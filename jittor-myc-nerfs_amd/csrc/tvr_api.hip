@@ -762,12 +762,14 @@ int tvr_train_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     float *tmp = F(W.tmp), *gsc = F(W.gemm), *csc = F(W.colsum);
     // (the bias gradients ride along as a virtual ones column of the second operand: no second pass over d_out / dh2 / dh1)
     float *bs3 = tmp + 32 * TVR_KAPP + 16;
-    HIP_TRY(launch_gemm_tn(F(W.d_out4), 4, 4, F(W.h2), TVR_FEATC, TVR_FEATC, app_cap, tmp, gsc, stream, mdev, bs3));
+    // The products run on the fp16-split MFMAs at the backward's own gradient scale (the same values went through fp16 at that scale inside
+    // mlp_train_backward / basis_backward, which raise the saturation flag if they do not fit): the kernel then runs at its staging rate.
+    HIP_TRY(launch_gemm_tn(F(W.d_out4), 4, 4, F(W.h2), TVR_FEATC, TVR_FEATC, app_cap, tmp, gsc, stream, mdev, bs3, gscale));
     HIP_TRY(launch_copy_f32(mo_->W3, tmp, 3 * TVR_FEATC, stream));
     HIP_TRY(launch_copy_f32(mo_->b3, bs3, 3, stream));
-    HIP_TRY(launch_gemm_tn(F(W.dh2), TVR_FEATC, TVR_FEATC, F(W.h1), TVR_FEATC, TVR_FEATC, app_cap, mo_->W2, gsc, stream, mdev, mo_->b2));
-    HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X), nin, nin, app_cap, mo_->W1, gsc, stream, mdev, mo_->b1));
-    HIP_TRY(launch_gemm_tn(F(W.dfeats32), 32, 32, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev));
+    HIP_TRY(launch_gemm_tn(F(W.dh2), TVR_FEATC, TVR_FEATC, F(W.h1), TVR_FEATC, TVR_FEATC, app_cap, mo_->W2, gsc, stream, mdev, mo_->b2, gscale));
+    HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X), nin, nin, app_cap, mo_->W1, gsc, stream, mdev, mo_->b1, gscale));
+    HIP_TRY(launch_gemm_tn(F(W.dfeats32), 32, 32, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev, nullptr, gscale));
     HIP_TRY(launch_copy_f32(mo_->basis, tmp, TVR_APPDIM * TVR_KAPP, stream));
     if (ref) {
         HIP_TRY(launch_gemm_tn(F(W.dg8), 8, 8, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev));      // rows: normal 0..2, specular 3, diffuse 4..6, rho 7

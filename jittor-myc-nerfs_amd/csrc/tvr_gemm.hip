@@ -107,15 +107,26 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_kernel(const float *__r
 #ifndef TL_ROWS
 #define TL_ROWS 16
 #endif
+#ifndef TVR_GEMM_SPLIT16
+#define TVR_GEMM_SPLIT16 1        // 0: the fused step's weight gradients keep the fp32 products (A/B switch)
+#endif
+#ifndef TG_DIAG
+#define TG_DIAG 0                 // timing experiments only: 1 no MFMAs (memory + staging alone), 2 no global fetch after the first chunk (matrix pipe alone)
+#endif
 #define TL_PF ((TL_ROWS * 320 + 255) / 256)          // floats (or float4s / 4) per thread and chunk, at most: 20 tiles = 320 columns
 
 // MODE 0: dword staging (any strides); 1: float4 staging of contiguous rows (lda == Ka, ldb == Kb: a chunk is one flat run of floats, any K);
 // 2: float4 staging of strided rows (Ka, Kb, lda, ldb multiples of 4 — operands that are column blocks of wider matrices)
-template <int MODE>
+// F16: the products run on v_mfma_f32_32x32x16_f16 with both operands split into fp16 hi + lo (three products, fp32-grade; tvr_mfma.h) and A multiplied by
+// the power of two *scale first — for operands whose range is KNOWN to fit fp16 at that scale: the fused training step's gradients, which its backward kernels
+// already carried through fp16 at the same scale (and flag if they saturate).  A 16-row chunk is then ONE k-step: 3 MFMAs of 32 cycles per tile instead of 8 of
+// 64, and the kernel runs at the staging path's rate (measured by leaving the MFMAs out: 4.9 TB/s of operand reads against 2.3 TB/s with the fp32 products).
+// Wave w owns row block w of the result (Ka <= 128) and walks the column blocks: per chunk one A fragment and <= 5 B fragments are read from LDS and split.
+template <int MODE, bool F16>
 __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float *__restrict__ A, const int lda, const int Ka,
                                                                      const float *__restrict__ B, const int ldb, const int Kb,
                                                                      const long long M_cap, float *__restrict__ P, const long long rpb_host, const unsigned *__restrict__ m_dev,
-                                                                     const int ones)
+                                                                     const int ones, const float *__restrict__ scale)
 {
     // m_dev: the row count lives on the device (M_cap = capacity, the grid is sized for it); the slabs are then cut from the true count here
     // ones = 1: B has one more, VIRTUAL, column of ones (never read from memory): column Kb of the result is A^T 1 = the column sums of A — the bias
@@ -234,6 +245,64 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
     fetch(m0, preA);
     stash(sm, preA);
     __syncthreads();
+    if constexpr (F16) {
+        static_assert(TL_ROWS == 16, "one fp16 k-step per chunk");
+        const float sc = scale ? *scale : 1.0f;
+        const bool has = wave < nrb;                                    // (wave-uniform)
+        const int colA = wave * 32 + i;
+        const bool okA = has && colA < Ka;
+        f32x16 acc16[TG_MAXT];
+#pragma unroll
+        for (int q = 0; q < TG_MAXT; ++q) acc16[q] = f32x16{0};
+        float drain16 = 0.0f;
+        int cur16 = 0;
+        for (long long m = m0; m < m1; m += TL_ROWS) {
+            const bool more = m + TL_ROWS < m1;
+            if (more) fetch(m + TL_ROWS, preA);
+            __builtin_amdgcn_sched_barrier(0);
+            const float *c_s = sm + cur16 * bufsz;
+            if (has) {
+                float a8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = okA ? c_s[(8 * k + j) * Ka + colA] * sc : 0.0f;       // rows 8 h .. 8 h + 7 of column colA (rows past m1 hold zeros)
+                const Frag fa = split8(a8);
+#pragma unroll
+                for (int q = 0; q < TG_MAXT; ++q) {
+                    if (q < ncb) {
+                        const int col = q * 32 + i;
+                        float b8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) b8[j] = col < Kb ? c_s[na + (8 * k + j) * Kb + col] : ((ones && col == Kb) ? 1.0f : 0.0f);
+                        const Frag fb = split8(b8);
+                        acc16[q] = MFMAH(fa.lo, fb.hi, acc16[q]);
+                        acc16[q] = MFMAH(fa.hi, fb.lo, acc16[q]);
+                        acc16[q] = MFMAH(fa.hi, fb.hi, acc16[q]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < TG_MAXT; ++q) drain16 += acc16[q][15];  // every MFMA of the chunk has completed before the next chunk's staging writes
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) stash(sm + (cur16 ^ 1) * bufsz, preA);
+            __syncthreads();
+            cur16 ^= 1;
+        }
+        if (drain16 == 1.2345e-30f && P == nullptr) P[0] = drain16;
+        if (has) {
+#pragma unroll
+            for (int q = 0; q < TG_MAXT; ++q) {
+                if (q >= ncb) continue;
+                const int col = q * 32 + i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * k;
+                    if (row < Ka && col < Kc) P[((size_t)blockIdx.x * Ka + row) * Kc + col] = acc16[q][r];
+                }
+            }
+        }
+        return;
+    }
     float drain = 0.0f;
     int cur = 0;
     // LDS word offsets of this lane's operands (row k of a 2-row step; 0 and a zero mask for tiles / columns that do not exist)
@@ -246,7 +315,7 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
     }
     for (long long m = m0; m < m1; m += TL_ROWS) {
         const bool more = m + TL_ROWS < m1;
-        if (more) fetch(m + TL_ROWS, preA);                             // global loads of the next chunk: in flight during this chunk's MFMAs
+        if (more && !((TG_DIAG & 2) && m > m0)) fetch(m + TL_ROWS, preA);   // global loads of the next chunk: in flight during this chunk's MFMAs
         __builtin_amdgcn_sched_barrier(0);
         const float *c_s = sm + cur * bufsz;
         // the operands of step u + 1 are read from LDS while the MFMAs of step u run (an MFMA that waits for its own ds_read costs the LDS
@@ -266,7 +335,7 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_lds_kernel(const float 
             __builtin_amdgcn_sched_barrier(0);                          // (hipcc would sink the reads behind this step's MFMAs and wait for them at once)
 #pragma unroll
             for (int q = 0; q < TG_MAXT; ++q)
-                if (q < nq)                                             // wave-uniform: tiles this wave does not have cost no matrix-pipe time
+                if (q < nq && !(TG_DIAG & 1))                           // wave-uniform: tiles this wave does not have cost no matrix-pipe time
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(offA[q] >= 0 ? va[u & 1][q] : 0.0f, offB[q] >= 0 ? vb[u & 1][q] : (offB[q] == -2 ? 1.0f : 0.0f),
                                                                   acc[q], 0, 0, 0);
         }
@@ -408,7 +477,8 @@ __global__ __launch_bounds__(64 * TG_WAVES) void gemm_tn_f16_kernel(const float 
 }
 
 // C[e] = sum over the slabs in a fixed order: 16 lanes per element (lane l adds slabs l, l+16, ... in order), then a fixed butterfly
-__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__restrict__ P, const int n_slabs, const int n, float *__restrict__ C)
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__restrict__ P, const int n_slabs, const int n, float *__restrict__ C,
+                                                             const float *__restrict__ scale)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = t >> 4, l = t & 15;
@@ -417,12 +487,12 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
         for (int b = l; b < n_slabs; b += 16) s = s + P[(size_t)b * n + e];
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) s = s + __shfl_xor(s, off);
-    if (e < n && l == 0) C[e] = s;
+    if (e < n && l == 0) C[e] = scale ? s / *scale : s;               // (a power of two: the division is exact)
 }
 
 // the same for a [Ka, Kb + 1] product whose last column is the bias gradient: columns < Kb go to C (row stride Kb), column Kb to bias
 __global__ __launch_bounds__(256) void gemm_tn_reduce_bias_kernel(const float *__restrict__ P, const int n_slabs, const int Ka, const int Kb, float *__restrict__ C,
-                                                                  float *__restrict__ bias)
+                                                                  float *__restrict__ bias, const float *__restrict__ scale)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = t >> 4, l = t & 15, n = Ka * (Kb + 1);
@@ -431,6 +501,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_bias_kernel(const float *_
         for (int b = l; b < n_slabs; b += 16) s = s + P[(size_t)b * n + e];
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) s = s + __shfl_xor(s, off);
+    if (scale) s = s / *scale;
     if (e < n && l == 0) {
         const int row = e / (Kb + 1), col = e - row * (Kb + 1);
         if (col < Kb) C[row * Kb + col] = s;
@@ -464,7 +535,7 @@ size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M)
 }
 
 hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream,
-                          const unsigned *m_dev, float *bias_out)
+                          const unsigned *m_dev, float *bias_out, const float *scale_f16)
 {
     long long grid, rpb;
     gemm_tn_shape(M, grid, rpb);
@@ -482,20 +553,25 @@ hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int l
         const int lds2 = 2 * ((TL_ROWS * (Ka + Kb) + 3) & ~3) * (int)sizeof(float);       // <= 40 KB
         // 16-B loads need contiguous rows (a chunk is then one flat run of floats) and 16-B aligned chunk starts (TL_ROWS * K * 4 B is)
         const bool al = ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
-        if (al && lda == Ka && ldb == Kb)
-            hipLaunchKernelGGL((gemm_tn_lds_kernel<1>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev, ones);
-        else if (al && !((Ka | Kb | lda | ldb) & 3))
-            hipLaunchKernelGGL((gemm_tn_lds_kernel<2>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev, ones);
-        else hipLaunchKernelGGL((gemm_tn_lds_kernel<0>), dim3((unsigned)grid), dim3(64 * TG_WAVES), lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev, ones);
+        const int mode = (al && lda == Ka && ldb == Kb) ? 1 : ((al && !((Ka | Kb | lda | ldb) & 3)) ? 2 : 0);
+        const bool f16 = scale_f16 != nullptr && Ka <= 32 * TG_WAVES && TVR_GEMM_SPLIT16;
+        const dim3 g((unsigned)grid), b(64 * TG_WAVES);
+#define TG_GO(MODE_, F16_) hipLaunchKernelGGL((gemm_tn_lds_kernel<MODE_, F16_>), g, b, lds2, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev, ones, scale_f16)
+        if (f16) { if (mode == 1) TG_GO(1, true); else if (mode == 2) TG_GO(2, true); else TG_GO(0, true); }
+        else { if (mode == 1) TG_GO(1, false); else if (mode == 2) TG_GO(2, false); else TG_GO(0, false); }
+#undef TG_GO
+        if (!f16) scale_f16 = nullptr;
     } else if (TVR_GEMM_F32) {
+        scale_f16 = nullptr;                                        // (the direct-load kernels keep the fp32 products)
         hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
     } else {
+        scale_f16 = nullptr;
         rc = hipFuncSetAttribute((const void *)gemm_tn_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (rc != hipSuccess) return rc;
         hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3((unsigned)grid), dim3(64 * TG_WAVES), lds, stream, A, lda, Ka, B, ldb, Kb, M, scratch, rpb, m_dev);
     }
     const int n = Ka * (Kb + ones);
-    if (ones) hipLaunchKernelGGL(gemm_tn_reduce_bias_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, scratch, (int)grid, Ka, Kb, C, bias_out);
-    else hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, scratch, (int)grid, n, C);
+    if (ones) hipLaunchKernelGGL(gemm_tn_reduce_bias_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, scratch, (int)grid, Ka, Kb, C, bias_out, scale_f16);
+    else hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, scratch, (int)grid, n, C, scale_f16);
     return hipGetLastError();
 }

@@ -82,7 +82,8 @@ hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long
 hipError_t launch_unpack_grad(const float *in, float *out, int Cout, int C, int H, int W, hipStream_t stream);
 // m_dev: optional device-side row count; M is then the capacity (the grid is sized for it, the slabs are cut from min(*m_dev, M) on the device)
 hipError_t launch_gemm_tn(const float *A, int lda, int Ka, const float *B, int ldb, int Kb, long long M, float *C, float *scratch, hipStream_t stream,
-                          const unsigned *m_dev = nullptr, float *bias_out = nullptr);      // bias_out [Ka]: also the column sums of A (scratch sized for Kb + 1)
+                          const unsigned *m_dev = nullptr, float *bias_out = nullptr,       // bias_out [Ka]: also the column sums of A (scratch sized for Kb + 1)
+                          const float *scale_f16 = nullptr);   // device scalar s (a power of two): products on the fp16-split MFMAs with A * s (operands known to fit fp16 at that scale)
 size_t gemm_tn_scratch_bytes(int Ka, int Kb, long long M);
 hipError_t launch_pe_concat(const float *feat, const float *dir, const float *dot, long long m, float *X, hipStream_t stream);
 hipError_t launch_pe_concat_strided(const float *feat, int fs, const float *dir, int ds, const float *rays, const unsigned *q_ray, const float *dot, int dts,

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from jittor_myc_nerfs_amd import _lib as L
-for M, Ka, Kb in ((356_123, 128, 150), (356_123, 128, 128), (356_123, 3, 128), (356_123, 27, 144), (2_100_000, 128, 128)):
+for M, Ka, Kb in ((356_123, 128, 150), (356_123, 128, 128), (700_000, 128, 150), (700_000, 128, 128), (356_123, 3, 128), (356_123, 27, 144), (2_100_000, 128, 128)):
     A = torch.randn((M, Ka), device="cuda"); B = torch.randn((M, Kb), device="cuda")
     out = torch.empty((Ka, Kb), device="cuda")
     sc = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb, M), dtype=torch.uint8, device="cuda")
