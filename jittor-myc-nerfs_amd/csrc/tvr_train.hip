@@ -757,22 +757,51 @@ hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const 
 // w_tv likewise along x, count_h = C (H-1) W, count_w = C H (W-1); and its gradient, in one pass.  Partial sums go to `part` (one float per
 // workgroup, summed in order by tv_finish_kernel): deterministic.
 #define TV_THREADS 256
+// VEC: W is a multiple of 4 — a thread takes four consecutive elements of a row (float4 loads of the row and of its two neighbours, one index division per
+// four elements).  Round 3: the first form divided a 64-bit index twice per element and ran at 1.1 TB/s; 32-bit indices (a plane has < 2^31 elements).
+template <bool VEC>
 __global__ __launch_bounds__(TV_THREADS) void tv_loss_kernel(const float *__restrict__ x, const int C, const int H, const int W,
                                                              const float ch, const float cw, float *__restrict__ grad, float *__restrict__ part)
 {
     __shared__ float red[TV_THREADS / 64];
-    const long long total = (long long)C * H * W;
+    const int total = C * H * W;
     float acc = 0.0f;
-    for (long long i = (long long)blockIdx.x * TV_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * TV_THREADS) {
-        const int xx = (int)(i % W);
-        const int yy = (int)((i / W) % H);
-        const float v = x[i];
-        float g = 0.0f;
-        if (yy + 1 < H) { const float d = x[i + W] - v; acc += ch * d * d; g -= 2.0f * ch * d; }
-        if (yy > 0) g += 2.0f * ch * (v - x[i - W]);
-        if (xx + 1 < W) { const float d = x[i + 1] - v; acc += cw * d * d; g -= 2.0f * cw * d; }
-        if (xx > 0) g += 2.0f * cw * (v - x[i - 1]);
-        grad[i] = g;
+    if (VEC) {
+        const int W4 = W >> 2, n4 = total >> 2;
+        for (int q = blockIdx.x * TV_THREADS + threadIdx.x; q < n4; q += gridDim.x * TV_THREADS) {
+            const int row = q / W4, x4 = q - row * W4, yy = row % H, i = q << 2;
+            const float4 v = *(const float4 *)(x + i);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            float dn[4] = {0.f, 0.f, 0.f, 0.f}, up[4] = {0.f, 0.f, 0.f, 0.f};
+            const bool hd = yy + 1 < H, hu = yy > 0;
+            if (hd) { const float4 t = *(const float4 *)(x + i + W); dn[0] = t.x; dn[1] = t.y; dn[2] = t.z; dn[3] = t.w; }
+            if (hu) { const float4 t = *(const float4 *)(x + i - W); up[0] = t.x; up[1] = t.y; up[2] = t.z; up[3] = t.w; }
+            const bool hl = x4 > 0, hr = x4 + 1 < W4;
+            const float left = hl ? x[i - 1] : 0.0f, right = hr ? x[i + 4] : 0.0f;
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float ge = 0.0f;
+                if (hd) { const float d = dn[e] - vv[e]; acc += ch * d * d; ge -= 2.0f * ch * d; }
+                if (hu) ge += 2.0f * ch * (vv[e] - up[e]);
+                const bool has_r = e < 3 || hr, has_l = e > 0 || hl;
+                if (has_r) { const float d = (e < 3 ? vv[e < 3 ? e + 1 : 3] : right) - vv[e]; acc += cw * d * d; ge -= 2.0f * cw * d; }
+                if (has_l) ge += 2.0f * cw * (vv[e] - (e > 0 ? vv[e > 0 ? e - 1 : 0] : left));
+                g[e] = ge;
+            }
+            *(float4 *)(grad + i) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+    } else {
+        for (int i = blockIdx.x * TV_THREADS + threadIdx.x; i < total; i += gridDim.x * TV_THREADS) {
+            const int r = i / W, xx = i - r * W, yy = r % H;
+            const float v = x[i];
+            float g = 0.0f;
+            if (yy + 1 < H) { const float d = x[i + W] - v; acc += ch * d * d; g -= 2.0f * ch * d; }
+            if (yy > 0) g += 2.0f * ch * (v - x[i - W]);
+            if (xx + 1 < W) { const float d = x[i + 1] - v; acc += cw * d * d; g -= 2.0f * cw * d; }
+            if (xx > 0) g += 2.0f * cw * (v - x[i - 1]);
+            grad[i] = g;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
@@ -800,7 +829,9 @@ hipError_t launch_tv_loss(const float *x, int C, int H, int W, float weight, flo
 {
     const float count_h = (float)C * (float)(H - 1) * (float)W, count_w = (float)C * (float)H * (float)(W - 1);
     const float ch = (H > 1) ? weight * 2.0f / count_h : 0.0f, cw = (W > 1) ? weight * 2.0f / count_w : 0.0f;
-    hipLaunchKernelGGL(tv_loss_kernel, dim3(TV_BLOCKS), dim3(TV_THREADS), 0, stream, x, C, H, W, ch, cw, grad, part);
+    if ((long long)C * H * W >= (1ll << 31)) return hipErrorInvalidValue;
+    if (!(W & 3) && !((uintptr_t)x & 15) && !((uintptr_t)grad & 15)) hipLaunchKernelGGL(tv_loss_kernel<true>, dim3(TV_BLOCKS), dim3(TV_THREADS), 0, stream, x, C, H, W, ch, cw, grad, part);
+    else hipLaunchKernelGGL(tv_loss_kernel<false>, dim3(TV_BLOCKS), dim3(TV_THREADS), 0, stream, x, C, H, W, ch, cw, grad, part);
     hipLaunchKernelGGL(tv_finish_kernel, dim3(1), dim3(64), 0, stream, part, TV_BLOCKS, value);
     return hipGetLastError();
 }

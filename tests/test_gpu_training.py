@@ -185,7 +185,7 @@ def test_fused_pe_concat_and_tv_loss_match_torch():
         for a, b in zip(got, want):
             assert a.shape == b.shape and float((a - b).abs().max()) < 2e-5
     tv = TVLoss(0.7)
-    for shape in ((1, 16, 33, 47), (1, 48, 5, 1), (1, 3, 2, 9)):
+    for shape in ((1, 16, 33, 47), (1, 48, 5, 1), (1, 3, 2, 9), (1, 16, 33, 48), (1, 5, 7, 4), (1, 48, 300, 300)):        # W % 4 == 0: the float4 form
         x = torch.randn(shape, device="cuda", generator=g).requires_grad_(True)
         val = tv(x)
         xr = x.detach().cpu().double().requires_grad_(True)
