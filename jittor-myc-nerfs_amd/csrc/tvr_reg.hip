@@ -71,13 +71,21 @@ __global__ __launch_bounds__(REG_THREADS) void l1_backward_kernel(const RegList 
 // value_t = sum_{i != j} |G_ij| / (nc (nc - 1));  d value_t / d V_i = 2 / (nc (nc - 1)) * sum_{j != i} sign(G_ij) V_j.
 // g == nullptr: forward (part[t] = value_t; ortho_final_kernel adds them in order); else backward with the upstream gradient g[0].
 #define ORTHO_MAXC 48
+#define ORTHO_LDS_FLOATS (ORTHO_MAXC * 320)                           // V staged in LDS when it fits (48 x 301 does): every element is read ~100 times
 __global__ __launch_bounds__(1024) void ortho_kernel(const RegList L, const float *__restrict__ g, float *__restrict__ part)
 {
     __shared__ float G[ORTHO_MAXC * ORTHO_MAXC];
     __shared__ float red[16];
+    __shared__ float Vs[ORTHO_LDS_FLOATS];
     const int t = blockIdx.x;
-    const float *__restrict__ V = L.x[t];
+    const float *__restrict__ Vg = L.x[t];
     const int nc = L.rows[t], ns = (int)(L.count[t] / nc);
+    const bool in_lds = nc * ns <= ORTHO_LDS_FLOATS;                  // (round 3: from global memory the six workgroups took 136 us per launch, latency-bound)
+    if (in_lds) {
+        for (int e = threadIdx.x; e < nc * ns; e += 1024) Vs[e] = Vg[e];
+        __syncthreads();
+    }
+    const float *V = in_lds ? (const float *)Vs : Vg;
     // G_ij: one wave per (i, j) pair in turn, lanes over ns, fixed butterfly
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int p = wave; p < nc * nc; p += 16) {
