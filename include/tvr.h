@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 115
+#define TVR_VERSION 116
 
 typedef enum {
     TVR_OK = 0,
@@ -298,6 +298,10 @@ int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t
  * Ka x (Kb + 1) must fit the 20 tiles, Ka + Kb <= 320; scratch: tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M). */
 int tvr_gemm_tn_bias(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C, float *colsum_A,
                      void *scratch, size_t scratch_bytes, void *stream);
+/* The same on the fp16-split MFMAs with A * s (s = *scale_dev, a power of two; the result is divided by s again): for operands whose range is known to fit fp16
+ * at that scale (a caller-chosen gradient scale).  colsum_A optional.  Ka <= 128, Ka + Kb <= 320. */
+int tvr_gemm_tn_scaled(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C, float *colsum_A,
+                       const float *scale_dev, void *scratch, size_t scratch_bytes, void *stream);
 
 /* The MLP input of the training step in one pass: X [m,150] = [features 27, viewdirs 3, PE(features), PE(viewdirs)] (MLPRender_Fea.execute,
  * tensorBase.py:76-82; positional_encoding :9-15), or X [m,151] with dot_product [m] in front (MLPRender_Fea_Ref, REFTensoRF.py:19-24) when
@@ -385,9 +389,11 @@ int tvr_mlpnet_repack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *para
  *   dX[m, k] = (sum_{n < N} dY[m, n] W[n, k]) * (mask[m, k] > 0 ? 1 : 0)     (mask NULL: no mask)
  * dY [M, ldy] with N a multiple of 8 in [8,128] (columns n_valid..N-1 of dY must be finite, rows n_valid.. of W are taken as zero), W row-major
  * [n_valid, ldw] = a torch / Jittor Linear weight [out, in] (the reduction runs over its rows), K in {32, 64, 96, 128} columns of W / dX / mask;
- * ldy, ldx, ldm multiples of 4 and all pointers 16-B aligned.  What autograd computes for `relu(Linear(x))` chains (MLPNet.forward, nerfplusplus.py:119-140). */
+ * ldy, ldx, ldm multiples of 4 and all pointers 16-B aligned.  What autograd computes for `relu(Linear(x))` chains (MLPNet.forward, nerfplusplus.py:119-140).
+ * scale_dev (optional; N then a multiple of 16): a device scalar s, a power of two — the products run on the fp16-split MFMAs with dY * s (three products,
+ * fp32-grade) for callers that know dY's range at that scale, ~3x the rate of the fp32 form; a non-finite result raises *sat_flag_dev (optional). */
 int tvr_linear_dx(const float *dY, int32_t ldy, int32_t N, const float *W, int32_t ldw, int32_t n_valid, int32_t K, const float *mask, int32_t ldm,
-                  float *dX, int32_t ldx, size_t dX_bytes, int64_t M, void *stream);
+                  float *dX, int32_t ldx, size_t dX_bytes, int64_t M, const float *scale_dev, uint32_t *sat_flag_dev, void *stream);
 /* out[k] = sum_m A[m, k], k < K <= 128, fixed summation order (the bias gradients of the same Linears).  scratch: tvr_colsum_scratch_bytes(). */
 size_t tvr_colsum_scratch_bytes(void);
 int tvr_colsum(const float *A, int32_t lda, int32_t K, int64_t M, float *out, void *scratch, size_t scratch_bytes, void *stream);

@@ -150,7 +150,9 @@ SYMBOLS = {
                                            C.c_void_p]),
     "tvr_mlpnet_repack": (C.c_int, [C.POINTER(MlpnetDesc), C.POINTER(MlpnetParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_linear_dx": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
-                                C.c_size_t, C.c_int64, C.c_void_p]),
+                                C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvr_gemm_tn_scaled": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     "tvr_colsum_scratch_bytes": (C.c_size_t, []),
     "tvr_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_npp_bg_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

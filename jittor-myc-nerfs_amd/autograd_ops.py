@@ -110,10 +110,21 @@ def _colsum_call(a, lda, K, M, a_off=0):
     return out
 
 
-def _linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, w_off=0):
-    """dX[:, :K] = (dY[:, :N] @ W[:n_valid, w_off : w_off + K]) * (mask > 0) through tvr_linear_dx."""
+def _linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, w_off=0, scale=None, sat=None):
+    """dX[:, :K] = (dY[:, :N] @ W[:n_valid, w_off : w_off + K]) * (mask > 0) through tvr_linear_dx; `scale` (device scalar, a power of two): the fp16-split form."""
     L.check(L.lib().tvr_linear_dx(dY.data_ptr(), ldy, N, W.data_ptr() + 4 * w_off, ldw, n_valid, K, mask.data_ptr() if mask is not None else None, ldm,
-                                  dX.data_ptr(), ldx, dX.numel() * 4, M, _stream_ptr(dY.device)), "tvr_linear_dx")
+                                  dX.data_ptr(), ldx, dX.numel() * 4, M, scale.data_ptr() if scale is not None else None,
+                                  sat.data_ptr() if sat is not None else None, _stream_ptr(dY.device)), "tvr_linear_dx")
+
+
+def _gemm_tn_scaled_call(a, lda, Ka, b, ldb, Kb, M, scale, bias=True, a_off=0):
+    """(a^T b, colsum(a) or None) on the fp16-split MFMAs with a * scale (tvr_gemm_tn_scaled)."""
+    out = torch.empty((Ka, Kb), dtype=torch.float32, device=a.device)
+    cs = torch.empty(Ka, dtype=torch.float32, device=a.device) if bias else None
+    scratch = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M), dtype=torch.uint8, device=a.device)
+    L.check(L.lib().tvr_gemm_tn_scaled(a.data_ptr() + 4 * a_off, lda, Ka, b.data_ptr(), ldb, Kb, M, out.data_ptr(), cs.data_ptr() if bias else None, scale.data_ptr(),
+                                       scratch.data_ptr(), scratch.numel(), _stream_ptr(a.device)), "tvr_gemm_tn_scaled")
+    return out, cs
 
 
 class _BgNetFn(torch.autograd.Function):
@@ -157,12 +168,12 @@ class _BgNetFn(torch.autograd.Function):
         L.check(L.lib().tvr_mlpnet_train_forward(C.byref(desc), st["image"].data_ptr(), p4.data_ptr(), vd.data_ptr(), M, rgb.data_ptr(), sigma.data_ptr(),
                                                  C.byref(sv), _stream_ptr(dev)), "tvr_mlpnet_train_forward")
         ctx.save_for_backward(rgb, sig_pre, Hrgb, Epos, Eview, W0b, *acts, *P)
-        ctx.meta = (D, M, input_ch, owner._bg_layer_inputs(desc), st)
+        ctx.meta = (D, M, input_ch, owner._bg_layer_inputs(desc), st, owner.bg_grad_scale_target, owner._get_sat_flag())
         return rgb, sigma
 
     @staticmethod
     def backward(ctx, d_rgb, d_sigma):
-        D, M, input_ch, layer_in, st = ctx.meta
+        D, M, input_ch, layer_in, st, owner_scale, sat_flag = ctx.meta
         sv = ctx.saved_tensors
         rgb, sig_pre, Hrgb, Epos, Eview, W0b = sv[:6]
         acts, P = sv[6:6 + D], sv[6 + D:]
@@ -171,48 +182,60 @@ class _BgNetFn(torch.autograd.Function):
         Wo = P[2 * D + 6]
         dev = rgb.device
         # heads, elementwise: sigmoid' on rgb, sign of the sigma head (sigma = |pre|)
-        dO = torch.zeros((M, 8), dtype=torch.float32, device=dev)
+        dO = torch.zeros((M, 16), dtype=torch.float32, device=dev)                                   # (row lengths in multiples of 16: one fp16 k-step)
         r = rgb.view(M, 3)
         dO[:, :3] = d_rgb.reshape(M, 3) * r * (1.0 - r)
-        dHS = torch.zeros((M, 72), dtype=torch.float32, device=dev)
+        dHS = torch.zeros((M, 80), dtype=torch.float32, device=dev)
         dHS[:, 64] = d_sigma.reshape(M) * torch.sign(sig_pre)
-        _linear_dx(dO, 8, 8, Wo.contiguous(), 64, 3, 64, Hrgb, 64, dHS, 72, M)                       # dH = (dO W_rgbo) * relu'
+        # The products below run on the fp16-split MFMAs (3 products, fp32-grade) at ONE power-of-two scale chosen on the device from the incoming gradients:
+        # max |dY| * scale ~ owner.bg_grad_scale_target.  Every kernel multiplies its dY by it and divides its result by it again; a result that leaves fp16's
+        # range raises the model's saturation flag (field.training_fault_flag -> the optimizer skips the step, check_training_faults lowers the target).
+        scale, sat = None, None
+        if owner_scale is not None:
+            amax = torch.maximum(dO.abs().max(), dHS[:, 64].abs().max()).clamp_min(1e-30)
+            scale = torch.exp2(torch.floor(torch.log2(owner_scale / amax))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1).contiguous()
+            sat = sat_flag
+        _linear_dx(dO, 16, 16, Wo.contiguous(), 64, 3, 64, Hrgb, 64, dHS, 80, M, scale=scale, sat=sat)    # dH = (dO W_rgbo) * relu'
         Wcat = st["W_cat"]
         Wcat[:64].copy_(st["W_eff"])
         Wcat[64].copy_(Ws.view(128))
         dP = [None] * D
         dP[D - 1] = torch.empty((M, 128), dtype=torch.float32, device=dev)
-        _linear_dx(dHS, 72, 72, Wcat, 128, 65, 128, acts[D - 1], 128, dP[D - 1], 128, M)              # d pre_{D-1}
+        _linear_dx(dHS, 80, 80, Wcat, 128, 65, 128, acts[D - 1], 128, dP[D - 1], 128, M, scale=scale, sat=sat)   # d pre_{D-1}
         for l in range(D - 1, 0, -1):
             prev, pe = layer_in[l]
             Wl = P[2 * l].contiguous()
             dP[l - 1] = torch.empty((M, 128), dtype=torch.float32, device=dev)
-            _linear_dx(dP[l], 128, 128, Wl, Wl.shape[1], 128, 128, acts[l - 1], 128, dP[l - 1], 128, M, w_off=input_ch if pe else 0)
+            _linear_dx(dP[l], 128, 128, Wl, Wl.shape[1], 128, 128, acts[l - 1], 128, dP[l - 1], 128, M, w_off=input_ch if pe else 0, scale=scale, sat=sat)
+
+        def gtn(a, lda, Ka, b, ldb, Kb, bias=True, a_off=0):           # a^T b (+ colsum a): the scaled fp16-split form when a scale exists
+            if scale is not None:
+                return _gemm_tn_scaled_call(a, lda, Ka, b, ldb, Kb, M, scale, bias=bias, a_off=a_off)
+            if bias:
+                return _gemm_tn_bias_call(a, lda, Ka, b, ldb, Kb, M, a_off=a_off)
+            return _gemm_tn_call(a, lda, Ka, b, ldb, Kb, M, a_off=a_off), None
         grads = []
         for l in range(D):
             prev, pe = layer_in[l]
             parts, gb = [], None                                    # (the bias gradient rides along in the first product: no extra pass over dP[l])
             if pe:
-                g, gb = _gemm_tn_bias_call(dP[l], 128, 128, Epos, input_ch, input_ch, M)
+                g, gb = gtn(dP[l], 128, 128, Epos, input_ch, input_ch)
                 parts.append(g)
             if prev:
-                if gb is None:
-                    g, gb = _gemm_tn_bias_call(dP[l], 128, 128, acts[l - 1], 128, 128, M)
-                else:
-                    g = _gemm_tn_call(dP[l], 128, 128, acts[l - 1], 128, 128, M)
+                g, gb2 = gtn(dP[l], 128, 128, acts[l - 1], 128, 128, bias=gb is None)
+                gb = gb if gb is not None else gb2
                 parts.append(g)
             grads += [parts[0] if len(parts) == 1 else torch.cat(parts, dim=1), gb]
         base = acts[D - 1]
         # one pass over [dH | d sigma_pre | 0] and base: rows 0..63 = G1 = dH^T base, row 64 = the sigma head's weight gradient; likewise the column sums
-        # (row lengths are multiples of 4 thanks to the buffers' zero columns: tvr_gemm_tn then stages with 16-B loads)
-        GS, cS = _gemm_tn_bias_call(dHS, 72, 72, base, 128, 128, M)                                    # [72,128], [72]
+        GS, cS = gtn(dHS, 80, 80, base, 128, 128)                                                      # [80,128], [80]
         G1, g_ws = GS[:64].contiguous(), GS[64:65]
         cH, g_bs = cS[:64].contiguous(), cS[64:65]
-        Gv = _gemm_tn_call(dHS, 72, 64, Eview, 16, 16, M)[:, :15]                                      # [64,15]
+        Gv = gtn(dHS, 80, 64, Eview, 16, 16, bias=False)[0][:, :15]                                    # [64,15]
         g_w0_base = _gemm_tn_call(G1.t().contiguous(), 64, 64, Wr.t().contiguous(), 256, 256, 128) + cH.unsqueeze(1) * br.unsqueeze(0)      # [64,256]
         g_wr = torch.cat([_gemm_tn_call(W0b, 256, 128, G1, 128, 128, 64, a_off=o) for o in (0, 128)], dim=0)                              # [256,128]
         g_br = (W0b * cH.unsqueeze(1)).sum(0)
-        g_wo, g_bo = _gemm_tn_bias_call(dO, 8, 4, Hrgb, 64, 64, M)
+        g_wo, g_bo = gtn(dO, 16, 16, Hrgb, 64, 64)
         g_wo, g_bo = g_wo[:3], g_bo[:3]
         grads += [g_ws, g_bs.view_as(bs), g_wr, g_br, torch.cat([g_w0_base, Gv], dim=1), cH, g_wo, g_bo]
         return (None, None, None, None) + tuple(grads)

@@ -907,8 +907,9 @@ int tvr_line_ortho_backward(const float *const *vs, float *const *grads, const i
 }
 
 int tvr_linear_dx(const float *dY, int32_t ldy, int32_t N, const float *W, int32_t ldw, int32_t n_valid, int32_t K, const float *mask, int32_t ldm, float *dX,
-                  int32_t ldx, size_t dX_bytes, int64_t M, void *stream)
+                  int32_t ldx, size_t dX_bytes, int64_t M, const float *scale_dev, uint32_t *sat_flag_dev, void *stream)
 {
+    if (scale_dev && (N & 15)) return fail(TVR_ERR_INVALID, "the fp16-split form (scale_dev) takes N in multiples of 16 (N = %d)", N);
     if (M < 0) return fail(TVR_ERR_INVALID, "M < 0");
     if (N < 8 || N > 128 || (N & 7) || n_valid < 1 || n_valid > N) return fail(TVR_ERR_UNSUPPORTED, "N = %d (a multiple of 8 in [8,128]) / n_valid = %d", N, n_valid);
     if (K != 32 && K != 64 && K != 96 && K != 128) return fail(TVR_ERR_UNSUPPORTED, "K = %d (32, 64, 96 or 128)", K);
@@ -916,7 +917,7 @@ int tvr_linear_dx(const float *dY, int32_t ldy, int32_t N, const float *W, int32
     if (M == 0) return TVR_OK;
     if (!dY || !W || !dX || ((uintptr_t)dY & 15) || ((uintptr_t)dX & 15) || ((uintptr_t)mask & 15)) return fail(TVR_ERR_INVALID, "dY / W / dX NULL or not 16-B aligned");
     if (dX_bytes < ((size_t)(M - 1) * ldx + K) * sizeof(float)) return fail(TVR_ERR_SCRATCH, "dX holds fewer than M rows");
-    HIP_TRY(launch_linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, (hipStream_t)stream));
+    HIP_TRY(launch_linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, (hipStream_t)stream, scale_dev, sat_flag_dev));
     return TVR_OK;
 }
 
@@ -953,6 +954,20 @@ int tvr_gemm_tn(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t
     if (lda < Ka || ldb < Kb) return fail(TVR_ERR_INVALID, "lda/ldb smaller than the row length");
     if (M > 0 && (!scratch || scratch_bytes < gemm_tn_scratch_bytes(Ka, Kb, M))) return fail(TVR_ERR_SCRATCH, "scratch too small (tvr_gemm_tn_scratch_bytes)");
     HIP_TRY(launch_gemm_tn(A, lda, Ka, B, ldb, Kb, M, C, (float *)scratch, (hipStream_t)stream));
+    return TVR_OK;
+}
+
+int tvr_gemm_tn_scaled(const float *A, int32_t lda, int32_t Ka, const float *B, int32_t ldb, int32_t Kb, int64_t M, float *C, float *colsum_A, const float *scale_dev,
+                       void *scratch, size_t scratch_bytes, void *stream)
+{
+    const int ones = colsum_A ? 1 : 0;
+    int rc = gemm_tn_check(Ka, Kb + ones, M);
+    if (rc != TVR_OK) return rc;
+    if (!C || !scale_dev || (M > 0 && (!A || !B))) return fail(TVR_ERR_INVALID, "A/B/C/scale_dev NULL");
+    if (lda < Ka || ldb < Kb) return fail(TVR_ERR_INVALID, "lda/ldb smaller than the row length");
+    if (Ka > 128 || 16 * (Ka + Kb) > 256 * 20) return fail(TVR_ERR_UNSUPPORTED, "the fp16-split form takes Ka <= 128 and Ka + Kb <= 320 (Ka = %d, Kb = %d)", Ka, Kb);
+    if (M > 0 && (!scratch || scratch_bytes < gemm_tn_scratch_bytes(Ka, Kb + ones, M))) return fail(TVR_ERR_SCRATCH, "scratch too small (tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M))");
+    HIP_TRY(launch_gemm_tn(A, lda, Ka, B, ldb, Kb, M, C, (float *)scratch, (hipStream_t)stream, nullptr, colsum_A, scale_dev));
     return TVR_OK;
 }
 

@@ -408,6 +408,8 @@ class TensorBase(torch.nn.Module):
             return False
         f.zero_()
         self.grad_scale_target = max(self.grad_scale_target / 16.0, 2.0 ** -20)
+        if getattr(self, "bg_grad_scale_target", None) is not None:     # (NerfPlusPlus: the background backward's scale shares the flag)
+            self.bg_grad_scale_target = max(self.bg_grad_scale_target / 16.0, 2.0 ** -20)
         return True
 
     # ---- the training step without a host read (autograd_ops._FusedStepFn) ----
@@ -471,6 +473,8 @@ class TensorBase(torch.nn.Module):
                 return "overflow"
             if sat:
                 self.grad_scale_target = max(self.grad_scale_target / 16.0, 2.0 ** -20)
+                if getattr(self, "bg_grad_scale_target", None) is not None:
+                    self.bg_grad_scale_target = max(self.bg_grad_scale_target / 16.0, 2.0 ** -20)
                 return "saturated"
         b = getattr(self, "_train_buf", None)
         if b is not None:

@@ -363,6 +363,10 @@ class NerfPlusPlus(TensorVMSplit):
 
     # ---- training through the HIP kernels (autograd_ops._BgNetFn) ----
     fused_bg_training = True
+    # max |incoming gradient| * scale ~ this (a power of two on the device): the background backward's products then run on the fp16-split MFMAs.  16 leaves
+    # 2^12 of growth through the layers below fp16's 65 504; a saturated step raises the model's flag (check_training_faults lowers grad_scale_target — the
+    # foreground's — and this one alike).  None: the fp32-input MFMAs, no scale.
+    bg_grad_scale_target = 16.0
 
     @staticmethod
     def _bg_layer_inputs(desc):
