@@ -15,8 +15,8 @@
 // F16: the products on v_mfma_f32_32x32x16_f16 with both operands split into fp16 hi + lo (three products, fp32-grade; tvr_mfma.h) and dY multiplied by the
 // power of two *scale first (unscaled again on the way out) — for callers that know their gradients' range at that scale.  W is split ONCE per workgroup into an
 // LDS image of A fragments (k-step-major, hi and lo as separate 1 KB blocks: two ds_read_b128 per fragment); a 16-column step of dY is two float4 loads per lane.
-// 96 MFMAs of 32 cycles per 128 x 128 tile instead of 256 of 64: the layer then runs at the rate of its three [M,128] streams.  A result that is not finite
-// (dY * scale left fp16's range) raises *sat_flag.
+// 96 MFMAs of 32 cycles per 128 x 128 tile instead of 256 of 64: the layer then runs at the rate of its three [M,128] streams.  An operand dY * scale or a
+// result (before it is unscaled) at or beyond fp16's 65 504 raises *sat_flag: results are the next product's operands at the same scale.
 template <int KB, bool F16>                                          // 32-column blocks of dX
 __global__ __launch_bounds__(64 * LDX_WAVES, 2) void linear_dx_kernel(const float *__restrict__ dY, const int ldy, const int N, const float *__restrict__ W, const int ldw,
                                                                      const int n_valid, const float *__restrict__ mask, const int ldm, float *__restrict__ dX,
@@ -61,6 +61,9 @@ __global__ __launch_bounds__(64 * LDX_WAVES, 2) void linear_dx_kernel(const floa
             float4 c0 = *(const float4 *)(row), c1 = *(const float4 *)(row + 4);
             for (int st = 0; st < N / 16; ++st) {
                 const float v[8] = {c0.x * sc, c0.y * sc, c0.z * sc, c0.w * sc, c1.x * sc, c1.y * sc, c1.z * sc, c1.w * sc};
+                // (the round-toward-zero split saturates at 65 504 instead of overflowing: an operand at the limit must be SAID, it would be clipped silently)
+                const float am = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+                bad |= (int)!(am < 65504.0f);
                 if (st + 1 < N / 16) { c0 = *(const float4 *)(row + 16 * (st + 1)); c1 = *(const float4 *)(row + 16 * (st + 1) + 4); }    // next step's columns in flight
                 const Frag fb = split8(v);
 #pragma unroll
@@ -96,7 +99,8 @@ __global__ __launch_bounds__(64 * LDX_WAVES, 2) void linear_dx_kernel(const floa
                 for (int q = 0; q < 4; ++q) {
                     const int k = 32 * kb + 8 * q + 4 * h;
                     float4 v = make_float4(acc[kb][4 * q] * inv_sc, acc[kb][4 * q + 1] * inv_sc, acc[kb][4 * q + 2] * inv_sc, acc[kb][4 * q + 3] * inv_sc);
-                    if (F16) bad |= (int)!(fabsf(v.x) < INFINITY) | (int)!(fabsf(v.y) < INFINITY) | (int)!(fabsf(v.z) < INFINITY) | (int)!(fabsf(v.w) < INFINITY);
+                    // the result is the next product's operand at the same scale (the layer below, the weight gradient): it must fit fp16 there as well
+                    if (F16) bad |= (int)!(fmaxf(fmaxf(fabsf(acc[kb][4 * q]), fabsf(acc[kb][4 * q + 1])), fmaxf(fabsf(acc[kb][4 * q + 2]), fabsf(acc[kb][4 * q + 3]))) < 65504.0f);
                     if (mask) {
                         const float4 mk = *(const float4 *)(mask + s * ldm + k);
                         v.x = mk.x > 0.0f ? v.x : 0.0f; v.y = mk.y > 0.0f ? v.y : 0.0f; v.z = mk.z > 0.0f ? v.z : 0.0f; v.w = mk.w > 0.0f ? v.w : 0.0f;

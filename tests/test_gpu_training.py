@@ -369,3 +369,55 @@ def test_fused_mlp_training_kernels_match_float64_autograd(tiny_arrays, hyper_ti
     with torch.no_grad():                                                # tvr_mlp_render on the features the training forward saved... recomputed by a library product
         rgb_inf = m.renderModule(None, vd, (h.detach() @ m.basis_mat.weight.t()))
     assert float((rgb_inf - rgb.detach()).abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,n_valid,K,w_off", [(40_003, 128, 128, 128, 0), (9_001, 80, 65, 128, 0), (9_001, 16, 3, 64, 0), (20_011, 128, 128, 128, 36), (33, 32, 32, 32, 0),
+                                                  (5_000, 64, 64, 96, 0)])
+def test_linear_dx_matches_float64(M, N, n_valid, K, w_off):
+    """tvr_linear_dx — dX = (dY W) * (mask > 0), the input gradient of `relu(Linear(x))` over a tall batch — in its fp32-input form and in the fp16-split form at a
+    power-of-two scale, against float64; strided operands, a column block of a wider weight, rows of W beyond n_valid taken as zero; and the saturation flag."""
+    from jittor_myc_nerfs_amd.autograd_ops import _linear_dx
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    ldw = K + w_off + 4
+    dY = torch.randn((M, N), device="cuda", generator=g) * 1e-4
+    dY[:, n_valid:] = 0.0
+    W = torch.randn((n_valid, ldw), device="cuda", generator=g)
+    mask = torch.randn((M, K), device="cuda", generator=g)
+    ref = (dY[:, :n_valid].double() @ W[:, w_off:w_off + K].double()) * (mask > 0)
+    for scaled in (False, True):
+        out = torch.full((M, K), float("nan"), device="cuda")
+        scale = torch.tensor([2.0 ** 18], device="cuda") if scaled else None
+        sat = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _linear_dx(dY, N, N, W, ldw, n_valid, K, mask, K, out, K, M, w_off=w_off, scale=scale, sat=sat if scaled else None)
+        err = float((out.double() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-6, (scaled, err)
+        assert int(sat.item()) == 0
+    # no mask; and a scale that drives dY out of fp16's range must raise the flag instead of returning garbage silently
+    out = torch.empty((M, K), device="cuda")
+    _linear_dx(dY, N, N, W, ldw, n_valid, K, None, 0, out, K, M, w_off=w_off)
+    ref2 = dY[:, :n_valid].double() @ W[:, w_off:w_off + K].double()
+    assert float((out.double() - ref2).abs().max()) / float(ref2.abs().max()) < 2e-6
+    sat = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _linear_dx(dY, N, N, W, ldw, n_valid, K, None, 0, out, K, M, w_off=w_off, scale=torch.tensor([2.0 ** 40], device="cuda"), sat=sat)
+    assert int(sat.item()) == 1
+
+
+@pytest.mark.gpu
+def test_gemm_tn_scaled_matches_the_fp32_form():
+    """tvr_gemm_tn_scaled (fp16-split products of A * scale, divided by the scale again) against float64 and the fp32-input form, with the column sums riding along."""
+    from jittor_myc_nerfs_amd.autograd_ops import _gemm_tn_bias_call, _gemm_tn_scaled_call
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for M, Ka, Kb, lda in ((60_001, 128, 128, 128), (20_011, 80, 128, 80), (9_001, 64, 16, 80), (5_003, 16, 64, 16), (9_001, 128, 36, 128)):
+        A = torch.randn((M, lda), device="cuda", generator=g) * 3e-5
+        B = torch.randn((M, Kb), device="cuda", generator=g) * 2.0
+        scale = torch.tensor([2.0 ** 16], device="cuda")
+        C1, cs1 = _gemm_tn_scaled_call(A, lda, Ka, B, Kb, Kb, M, scale)
+        C0, cs0 = _gemm_tn_bias_call(A, lda, Ka, B, Kb, Kb, M)
+        ref = A[:, :Ka].double().t() @ B.double()
+        rcs = A[:, :Ka].double().sum(0)
+        for C, cs in ((C1, cs1), (C0, cs0)):
+            assert float((C.double() - ref).abs().max()) / float(ref.abs().max()) < 3e-6
+            assert float((cs.double() - rcs).abs().max()) / float(rcs.abs().max()) < 3e-6
+        C2, none = _gemm_tn_scaled_call(A, lda, Ka, B, Kb, Kb, M, scale, bias=False)
+        assert none is None and torch.equal(C2, C1)                    # fixed order: the ones column does not change the product
