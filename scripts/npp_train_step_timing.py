@@ -31,4 +31,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 N = 10
 for _ in range(N): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
+fault = m.check_training_faults()                  # (None on a healthy run: no workspace overflow, no fp16-range saturation in either backward)
+if fault is not None: print("WARNING: check_training_faults() ->", fault)
 print(f"NerfPlusPlus train step: {dt * 1e3:.1f} ms ({1 / dt:.1f} it/s), 4096 rays x {nS} fg samples + 512 bg samples, loss {float(l.detach()):.3e}")
