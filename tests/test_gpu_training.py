@@ -421,3 +421,24 @@ def test_gemm_tn_scaled_matches_the_fp32_form():
             assert float((cs.double() - rcs).abs().max()) / float(rcs.abs().max()) < 3e-6
         C2, none = _gemm_tn_scaled_call(A, lda, Ka, B, Kb, Kb, M, scale, bias=False)
         assert none is None and torch.equal(C2, C1)                    # fixed order: the ones column does not change the product
+
+
+@pytest.mark.gpu
+def test_colsum_and_empty_inputs_of_the_new_entry_points():
+    """tvr_colsum against float64 (strided, offset columns, one row, fixed order); and the zero-size cases of the round-3 entry points return cleanly."""
+    from jittor_myc_nerfs_amd import _lib as L
+    from jittor_myc_nerfs_amd.autograd_ops import _colsum_call, _linear_dx
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for M, lda, K, off in ((100_003, 80, 72, 0), (9_001, 128, 128, 0), (5_000, 80, 1, 64), (1, 16, 3, 0)):
+        A = torch.randn((M, lda), device="cuda", generator=g)
+        cs = _colsum_call(A, lda, K, M, a_off=off)
+        ref = A[:, off:off + K].double().sum(0)
+        assert float((cs.double() - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+        assert torch.equal(cs, _colsum_call(A, lda, K, M, a_off=off))
+    lib = L.lib()
+    out = torch.zeros((4, 32), device="cuda")
+    _linear_dx(out, 32, 32, out, 32, 4, 32, None, 0, out, 32, 0)                       # M = 0: nothing launched
+    z = torch.zeros(8, device="cuda")
+    assert lib.tvr_colsum(None, 4, 4, 0, z.data_ptr(), z.data_ptr(), 32, None) == -3                                         # scratch too small: refused
+    sc = torch.empty(lib.tvr_colsum_scratch_bytes(), dtype=torch.uint8, device="cuda")
+    assert lib.tvr_colsum(None, 4, 4, 0, z.data_ptr(), sc.data_ptr(), sc.numel(), None) == 0 and float(z[:4].abs().max()) == 0.0   # M = 0: zeros
