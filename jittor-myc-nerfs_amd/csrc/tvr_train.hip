@@ -684,28 +684,58 @@ hipError_t launch_unpack_grad(const float *in, float *out, int Cout, int C, int 
 // Strided sources (the fused training step reads them where the forward kernel left them): feat row stride fs, dir row stride ds (or, with q_ray, the
 // direction of entry e is rays[q_ray[e]][3..5]), dot row stride dts; m_dev as in app_h_forward_kernel.
 struct PeSrc { const float *feat, *dir, *dot, *rays; const unsigned *q_ray, *m_dev; int fs, ds, dts; };
+// A workgroup builds the rows of 32 entries in LDS and writes them as ONE contiguous run of float4s (32 rows of 150 / 151 floats start 16-B aligned):
+// the first form stored five scattered floats per thread (0.19 ms per step of the real loop, store-path-bound).
+// FAST: sin / cos as the shade kernel's layer 1 takes them (sincos of v through the hardware unit behind a Cody-Waite reduction, the double angle by
+// 2 s c and 1 - 2 s^2) — the fused training step, whose X must be the forward kernel's own layer-1 input; otherwise libm's sincosf (the C-ABI entry point).
+#define PE_TILE 32
+template <bool FAST>
 __global__ __launch_bounds__(256) void pe_concat_forward_kernel(const PeSrc p, const long long m_cap, const int with_dot, float *__restrict__ X)
 {
+    __shared__ __attribute__((aligned(16))) float tile[PE_TILE * 152];
     const long long m = p.m_dev ? ((long long)*p.m_dev < m_cap ? (long long)*p.m_dev : m_cap) : m_cap;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m * 30) return;
-    const long long ent = t / 30;
-    const int c = (int)(t - ent * 30);
-    const int n = 150 + with_dot;
-    float *x = X + ent * n + with_dot;
+    const long long e0 = (long long)blockIdx.x * PE_TILE;
+    if (e0 >= m) return;
+    const int rows = (int)(m - e0 < PE_TILE ? m - e0 : PE_TILE), n = 150 + with_dot;
     const float *__restrict__ feat = p.feat, *__restrict__ dot = p.dot;
-    const float v = c < 27 ? feat[ent * p.fs + c] : (p.q_ray ? p.rays[(size_t)p.q_ray[ent] * 6 + 3 + (c - 27)] : p.dir[ent * p.ds + (c - 27)]);
-    float s1, c1, s2, c2;
-    sincosf(v, &s1, &c1);
-    sincosf(v * 2.0f, &s2, &c2);
-    x[c] = v;
-    if (c < 27) {
-        x[30 + 2 * c] = s1; x[31 + 2 * c] = s2; x[84 + 2 * c] = c1; x[85 + 2 * c] = c2;
-    } else {
-        const int j = c - 27;
-        x[138 + 2 * j] = s1; x[139 + 2 * j] = s2; x[144 + 2 * j] = c1; x[145 + 2 * j] = c2;
+    for (int it = threadIdx.x; it < rows * 30; it += 256) {
+        const int r = it / 30, c = it - r * 30;
+        const long long ent = e0 + r;
+        float *x = tile + r * n + with_dot;
+        const float v = c < 27 ? feat[ent * p.fs + c] : (p.q_ray ? p.rays[(size_t)p.q_ray[ent] * 6 + 3 + (c - 27)] : p.dir[ent * p.ds + (c - 27)]);
+        float s1, c1, s2, c2;
+        if (FAST) {
+            const float k = rintf(v * 0.15915494309189535f);
+            float rr = __builtin_fmaf(k, -6.2831854820251465f, v);
+            rr = __builtin_fmaf(k, 1.7484555e-7f, rr);
+            const float t = rr * 0.15915494309189535f;
+            s1 = __builtin_amdgcn_sinf(t);
+            c1 = __builtin_amdgcn_cosf(t);
+            s2 = 2.0f * s1 * c1;
+            c2 = __builtin_fmaf(-2.0f * s1, s1, 1.0f);
+        } else {
+            sincosf(v, &s1, &c1);
+            sincosf(v * 2.0f, &s2, &c2);
+        }
+        x[c] = v;
+        if (c < 27) {
+            x[30 + 2 * c] = s1; x[31 + 2 * c] = s2; x[84 + 2 * c] = c1; x[85 + 2 * c] = c2;
+        } else {
+            const int j = c - 27;
+            x[138 + 2 * j] = s1; x[139 + 2 * j] = s2; x[144 + 2 * j] = c1; x[145 + 2 * j] = c2;
+        }
+        if (with_dot && c == 0) tile[r * n] = dot[ent * p.dts];
     }
-    if (with_dot && c == 0) X[ent * n] = dot[ent * p.dts];
+    __syncthreads();
+    float *__restrict__ dst = X + e0 * n;
+    const int total = rows * n;
+    if (!((uintptr_t)dst & 15)) {
+        const int n4 = total >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) ((float4 *)dst)[i] = ((const float4 *)tile)[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < total; i += 256) dst[i] = tile[i];
+    } else {
+        for (int i = threadIdx.x; i < total; i += 256) dst[i] = tile[i];
+    }
 }
 
 // d/dv of the five columns a base value feeds: gX[v] + sum_k 2^k (gX[sin] cos(v 2^k) - gX[cos] sin(v 2^k))
@@ -733,7 +763,7 @@ __global__ __launch_bounds__(256) void pe_concat_backward_kernel(const float *__
 hipError_t launch_pe_concat(const float *feat, const float *dir, const float *dot, long long m, float *X, hipStream_t stream)
 {
     PeSrc p = {feat, dir, dot, nullptr, nullptr, nullptr, 27, 3, 1};
-    hipLaunchKernelGGL(pe_concat_forward_kernel, dim3((unsigned)((m * 30 + 255) / 256)), dim3(256), 0, stream, p, m, dot ? 1 : 0, X);
+    hipLaunchKernelGGL(pe_concat_forward_kernel<false>, dim3((unsigned)((m + PE_TILE - 1) / PE_TILE)), dim3(256), 0, stream, p, m, dot ? 1 : 0, X);
     return hipGetLastError();
 }
 
@@ -741,7 +771,7 @@ hipError_t launch_pe_concat_strided(const float *feat, int fs, const float *dir,
                                     long long m_cap, const unsigned *m_dev, float *X, hipStream_t stream)
 {
     PeSrc p = {feat, dir, dot, rays, q_ray, m_dev, fs, ds, dts};
-    hipLaunchKernelGGL(pe_concat_forward_kernel, dim3((unsigned)((m_cap * 30 + 255) / 256)), dim3(256), 0, stream, p, m_cap, dot ? 1 : 0, X);
+    hipLaunchKernelGGL(pe_concat_forward_kernel<true>, dim3((unsigned)((m_cap + PE_TILE - 1) / PE_TILE)), dim3(256), 0, stream, p, m_cap, dot ? 1 : 0, X);
     return hipGetLastError();
 }
 
