@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 116
+#define TVR_VERSION 117
 
 typedef enum {
     TVR_OK = 0,
@@ -381,6 +381,11 @@ typedef struct tvr_mlpnet_saved {
     size_t embed_pos_bytes;
     void *embed_view;
     size_t embed_view_bytes;
+    /* optional (mask_bytes = 0: not written): the ReLU masks of act[l] / rgb_hidden as BITS, [n][2] 64-bit words each — word h of sample s holds at bit
+     * 16 b + 4 q + i whether unit 32 b + 8 q + 4 h + i is positive, the order tvr_linear_dx's `mask_bits` takes (16 B per sample instead of 512) */
+    void *act_mask[4];
+    void *rgb_hidden_mask;
+    size_t mask_bytes;               /* of EACH mask buffer: >= n x 16 */
 } tvr_mlpnet_saved;
 int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
                              void *sigma, const tvr_mlpnet_saved *saved, void *stream);
@@ -391,9 +396,10 @@ int tvr_mlpnet_repack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *para
  * [n_valid, ldw] = a torch / Jittor Linear weight [out, in] (the reduction runs over its rows), K in {32, 64, 96, 128} columns of W / dX / mask;
  * ldy, ldx, ldm multiples of 4 and all pointers 16-B aligned.  What autograd computes for `relu(Linear(x))` chains (MLPNet.forward, nerfplusplus.py:119-140).
  * scale_dev (optional; N then a multiple of 16): a device scalar s, a power of two — the products run on the fp16-split MFMAs with dY * s (three products,
- * fp32-grade) for callers that know dY's range at that scale, ~3x the rate of the fp32 form; a non-finite result raises *sat_flag_dev (optional). */
+ * fp32-grade) for callers that know dY's range at that scale, ~3x the rate of the fp32 form; a non-finite result raises *sat_flag_dev (optional).
+ * mask_bits (optional, instead of mask): the same mask as bits, [M][2] 64-bit words in the layout tvr_mlpnet_train_forward writes (above). */
 int tvr_linear_dx(const float *dY, int32_t ldy, int32_t N, const float *W, int32_t ldw, int32_t n_valid, int32_t K, const float *mask, int32_t ldm,
-                  float *dX, int32_t ldx, size_t dX_bytes, int64_t M, const float *scale_dev, uint32_t *sat_flag_dev, void *stream);
+                  const uint64_t *mask_bits, float *dX, int32_t ldx, size_t dX_bytes, int64_t M, const float *scale_dev, uint32_t *sat_flag_dev, void *stream);
 /* out[k] = sum_m A[m, k], k < K <= 128, fixed summation order (the bias gradients of the same Linears).  scratch: tvr_colsum_scratch_bytes(). */
 size_t tvr_colsum_scratch_bytes(void);
 int tvr_colsum(const float *A, int32_t lda, int32_t K, int64_t M, float *out, void *scratch, size_t scratch_bytes, void *stream);

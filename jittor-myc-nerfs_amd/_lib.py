@@ -61,7 +61,8 @@ class MlpnetParams(C.Structure):         # tvr_mlpnet_params
 class MlpnetSaved(C.Structure):          # tvr_mlpnet_saved
     _fields_ = [("act", C.c_void_p * 4), ("act_bytes", C.c_size_t), ("rgb_hidden", C.c_void_p), ("rgb_hidden_bytes", C.c_size_t),
                 ("sigma_pre", C.c_void_p), ("sigma_pre_bytes", C.c_size_t), ("embed_pos", C.c_void_p), ("embed_pos_bytes", C.c_size_t),
-                ("embed_view", C.c_void_p), ("embed_view_bytes", C.c_size_t)]
+                ("embed_view", C.c_void_p), ("embed_view_bytes", C.c_size_t), ("act_mask", C.c_void_p * 4), ("rgb_hidden_mask", C.c_void_p),
+                ("mask_bytes", C.c_size_t)]
 
 
 class NgpMarchCfg(C.Structure):          # tvr_ngp_march_cfg (include/tvr_ngp.h)
@@ -149,8 +150,8 @@ SYMBOLS = {
     "tvr_mlpnet_train_forward": (C.c_int, [C.POINTER(MlpnetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(MlpnetSaved),
                                            C.c_void_p]),
     "tvr_mlpnet_repack": (C.c_int, [C.POINTER(MlpnetDesc), C.POINTER(MlpnetParams), C.c_void_p, C.c_size_t, C.c_void_p]),
-    "tvr_linear_dx": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
-                                C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvr_linear_dx": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                C.c_int32, C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tvr_gemm_tn_scaled": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
     "tvr_colsum_scratch_bytes": (C.c_size_t, []),

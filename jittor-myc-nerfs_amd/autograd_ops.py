@@ -110,9 +110,11 @@ def _colsum_call(a, lda, K, M, a_off=0):
     return out
 
 
-def _linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, w_off=0, scale=None, sat=None):
-    """dX[:, :K] = (dY[:, :N] @ W[:n_valid, w_off : w_off + K]) * (mask > 0) through tvr_linear_dx; `scale` (device scalar, a power of two): the fp16-split form."""
+def _linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, w_off=0, scale=None, sat=None, mask_bits=None):
+    """dX[:, :K] = (dY[:, :N] @ W[:n_valid, w_off : w_off + K]) * (mask > 0) through tvr_linear_dx; `scale` (device scalar, a power of two): the fp16-split form;
+    `mask_bits` [M,2] int64: the mask as bits (tvr_mlpnet_train_forward's layout) instead of the float matrix."""
     L.check(L.lib().tvr_linear_dx(dY.data_ptr(), ldy, N, W.data_ptr() + 4 * w_off, ldw, n_valid, K, mask.data_ptr() if mask is not None else None, ldm,
+                                  mask_bits.data_ptr() if mask_bits is not None else None,
                                   dX.data_ptr(), ldx, dX.numel() * 4, M, scale.data_ptr() if scale is not None else None,
                                   sat.data_ptr() if sat is not None else None, _stream_ptr(dY.device)), "tvr_linear_dx")
 
@@ -163,11 +165,15 @@ class _BgNetFn(torch.autograd.Function):
         sv.sigma_pre, sv.sigma_pre_bytes = sig_pre.data_ptr(), M * 4
         sv.embed_pos, sv.embed_pos_bytes = Epos.data_ptr(), M * input_ch * 4
         sv.embed_view, sv.embed_view_bytes = Eview.data_ptr(), M * 16 * 4
+        masks = [torch.empty((M, 2), dtype=torch.int64, device=dev) for _ in range(D + 1)]       # relu masks as bits: 16 B per sample and layer for the backward
+        for l in range(D):
+            sv.act_mask[l] = masks[l].data_ptr()
+        sv.rgb_hidden_mask, sv.mask_bytes = masks[D].data_ptr(), M * 16
         p4 = pts.detach().to(torch.float32).contiguous()
         vd = viewdirs.detach().to(torch.float32).contiguous()
         L.check(L.lib().tvr_mlpnet_train_forward(C.byref(desc), st["image"].data_ptr(), p4.data_ptr(), vd.data_ptr(), M, rgb.data_ptr(), sigma.data_ptr(),
                                                  C.byref(sv), _stream_ptr(dev)), "tvr_mlpnet_train_forward")
-        ctx.save_for_backward(rgb, sig_pre, Hrgb, Epos, Eview, W0b, *acts, *P)
+        ctx.save_for_backward(rgb, sig_pre, Hrgb, Epos, Eview, W0b, *acts, *masks, *P)
         ctx.meta = (D, M, input_ch, owner._bg_layer_inputs(desc), st, owner.bg_grad_scale_target, owner._get_sat_flag())
         return rgb, sigma
 
@@ -176,7 +182,7 @@ class _BgNetFn(torch.autograd.Function):
         D, M, input_ch, layer_in, st, owner_scale, sat_flag = ctx.meta
         sv = ctx.saved_tensors
         rgb, sig_pre, Hrgb, Epos, Eview, W0b = sv[:6]
-        acts, P = sv[6:6 + D], sv[6 + D:]
+        acts, masks, P = sv[6:6 + D], sv[6 + D:7 + 2 * D], sv[7 + 2 * D:]
         Ws, bs = P[2 * D], P[2 * D + 1]
         Wr, br = P[2 * D + 2], P[2 * D + 3]
         Wo = P[2 * D + 6]
@@ -195,18 +201,19 @@ class _BgNetFn(torch.autograd.Function):
             amax = torch.maximum(dO.abs().max(), dHS[:, 64].abs().max()).clamp_min(1e-30)
             scale = torch.exp2(torch.floor(torch.log2(owner_scale / amax))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1).contiguous()
             sat = sat_flag
-        _linear_dx(dO, 16, 16, Wo.contiguous(), 64, 3, 64, Hrgb, 64, dHS, 80, M, scale=scale, sat=sat)    # dH = (dO W_rgbo) * relu'
+        _linear_dx(dO, 16, 16, Wo.contiguous(), 64, 3, 64, None, 0, dHS, 80, M, scale=scale, sat=sat, mask_bits=masks[D])    # dH = (dO W_rgbo) * relu'
         Wcat = st["W_cat"]
         Wcat[:64].copy_(st["W_eff"])
         Wcat[64].copy_(Ws.view(128))
         dP = [None] * D
         dP[D - 1] = torch.empty((M, 128), dtype=torch.float32, device=dev)
-        _linear_dx(dHS, 80, 80, Wcat, 128, 65, 128, acts[D - 1], 128, dP[D - 1], 128, M, scale=scale, sat=sat)   # d pre_{D-1}
+        _linear_dx(dHS, 80, 80, Wcat, 128, 65, 128, None, 0, dP[D - 1], 128, M, scale=scale, sat=sat, mask_bits=masks[D - 1])   # d pre_{D-1}
         for l in range(D - 1, 0, -1):
             prev, pe = layer_in[l]
             Wl = P[2 * l].contiguous()
             dP[l - 1] = torch.empty((M, 128), dtype=torch.float32, device=dev)
-            _linear_dx(dP[l], 128, 128, Wl, Wl.shape[1], 128, 128, acts[l - 1], 128, dP[l - 1], 128, M, w_off=input_ch if pe else 0, scale=scale, sat=sat)
+            _linear_dx(dP[l], 128, 128, Wl, Wl.shape[1], 128, 128, None, 0, dP[l - 1], 128, M, w_off=input_ch if pe else 0, scale=scale, sat=sat,
+                       mask_bits=masks[l - 1])
 
         def gtn(a, lda, Ka, b, ldb, Kb, bias=True, a_off=0):           # a^T b (+ colsum a): the scaled fp16-split form when a scale exists
             if scale is not None:

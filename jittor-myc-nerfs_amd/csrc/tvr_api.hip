@@ -906,9 +906,11 @@ int tvr_line_ortho_backward(const float *const *vs, float *const *grads, const i
     return TVR_OK;
 }
 
-int tvr_linear_dx(const float *dY, int32_t ldy, int32_t N, const float *W, int32_t ldw, int32_t n_valid, int32_t K, const float *mask, int32_t ldm, float *dX,
-                  int32_t ldx, size_t dX_bytes, int64_t M, const float *scale_dev, uint32_t *sat_flag_dev, void *stream)
+int tvr_linear_dx(const float *dY, int32_t ldy, int32_t N, const float *W, int32_t ldw, int32_t n_valid, int32_t K, const float *mask, int32_t ldm,
+                  const uint64_t *mask_bits, float *dX, int32_t ldx, size_t dX_bytes, int64_t M, const float *scale_dev, uint32_t *sat_flag_dev, void *stream)
 {
+    if (mask && mask_bits) return fail(TVR_ERR_INVALID, "mask and mask_bits are alternatives");
+    if ((uintptr_t)mask_bits & 7) return fail(TVR_ERR_INVALID, "mask_bits is not 8-B aligned");
     if (scale_dev && (N & 15)) return fail(TVR_ERR_INVALID, "the fp16-split form (scale_dev) takes N in multiples of 16 (N = %d)", N);
     if (M < 0) return fail(TVR_ERR_INVALID, "M < 0");
     if (N < 8 || N > 128 || (N & 7) || n_valid < 1 || n_valid > N) return fail(TVR_ERR_UNSUPPORTED, "N = %d (a multiple of 8 in [8,128]) / n_valid = %d", N, n_valid);
@@ -917,7 +919,8 @@ int tvr_linear_dx(const float *dY, int32_t ldy, int32_t N, const float *W, int32
     if (M == 0) return TVR_OK;
     if (!dY || !W || !dX || ((uintptr_t)dY & 15) || ((uintptr_t)dX & 15) || ((uintptr_t)mask & 15)) return fail(TVR_ERR_INVALID, "dY / W / dX NULL or not 16-B aligned");
     if (dX_bytes < ((size_t)(M - 1) * ldx + K) * sizeof(float)) return fail(TVR_ERR_SCRATCH, "dX holds fewer than M rows");
-    HIP_TRY(launch_linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, (hipStream_t)stream, scale_dev, sat_flag_dev));
+    HIP_TRY(launch_linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, (hipStream_t)stream, scale_dev, sat_flag_dev,
+                             (const unsigned long long *)mask_bits));
     return TVR_OK;
 }
 

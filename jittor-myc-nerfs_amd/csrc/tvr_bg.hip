@@ -37,6 +37,8 @@ struct BgTrain {
     float *A[4];
     float *Hrgb;
     float *sig_pre;
+    unsigned long long *MA[4];   // relu masks as bits, [n][2] 64-bit words: word h of sample s holds, at bit 16 mb + 4 q + i, whether unit 32 mb + 8 q + 4 h + i
+    unsigned long long *MH;      // is positive — the accumulator order of the lane that owns them, which is also tvr_linear_dx's epilogue order
 };
 
 struct BgProgram {
@@ -152,6 +154,17 @@ __device__ __forceinline__ void load_stage(uint4 *__restrict__ lds4, const uint4
 
 // base layers [l0, l1) on one 32-sample tile: act in (unused when l0 == 0) -> act out
 // relu(act) of this lane's sample: accumulator register 4q + i of block mb <-> neuron 32 mb + 8 q + 4 h + i
+template <int NB>
+__device__ __forceinline__ void store_mask(unsigned long long *__restrict__ out, long long s, int hh, const f32x16 (&act)[NB])
+{
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m |= (unsigned long long)(act[mb][r] > 0.0f) << (16 * mb + r);
+    out[2 * s + hh] = m;
+}
+
 __device__ __forceinline__ void store_relu128(float *__restrict__ out, long long s, int hh, const f32x16 (&act)[4])
 {
 #pragma unroll
@@ -206,7 +219,10 @@ __device__ __forceinline__ void base_layers(const BgProgram &P, int l0, int l1, 
         }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) act[mb] = out[mb];
-        if (T.A[0] && s_store >= 0) store_relu128(T.A[l], s_store, hh, act);
+        if (T.A[0] && s_store >= 0) {
+            store_relu128(T.A[l], s_store, hh, act);
+            if (T.MA[l]) store_mask<4>(T.MA[l], s_store, hh, act);
+        }
     }
 }
 
@@ -241,6 +257,7 @@ __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restr
                 *(float4 *)(T.Hrgb + s_store * 64 + 32 * mb + 8 * q + 4 * hh) =
                     make_float4(relu_f(rh[mb][4 * q]), relu_f(rh[mb][4 * q + 1]), relu_f(rh[mb][4 * q + 2]), relu_f(rh[mb][4 * q + 3]));
         if (hh == 0) T.sig_pre[s_store] = hd[0][0] + lbias[576];
+        if (T.MH) store_mask<2>(T.MH, s_store, hh, rh);
     }
     f32x16 eo[1] = {{0}};
 #pragma unroll
@@ -564,6 +581,15 @@ int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, co
         return tvr_set_error(TVR_ERR_SCRATCH, "tvr_mlpnet_train_forward: a saved buffer is smaller than its n_samples rows");
     T.Hrgb = static_cast<float *>(saved->rgb_hidden);
     T.sig_pre = static_cast<float *>(saved->sigma_pre);
+    if (saved->mask_bytes) {                                         // optional: the relu masks as bits
+        if (saved->mask_bytes < rows * 16) return tvr_set_error(TVR_ERR_SCRATCH, "tvr_mlpnet_train_forward: a mask buffer is smaller than n_samples x 16 bytes");
+        for (int l = 0; l < desc->D && l < 4; ++l) {
+            if (!saved->act_mask[l] || misaligned(saved->act_mask[l])) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_train_forward: act_mask[%d] NULL or misaligned", l);
+            T.MA[l] = static_cast<unsigned long long *>(saved->act_mask[l]);
+        }
+        if (!saved->rgb_hidden_mask || misaligned(saved->rgb_hidden_mask)) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_train_forward: rgb_hidden_mask NULL or misaligned");
+        T.MH = static_cast<unsigned long long *>(saved->rgb_hidden_mask);
+    }
     if (int rc = mlpnet_forward_impl(desc, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream)) return rc;
     if (n_samples > 0) {
         hipLaunchKernelGGL(bg_embed_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float *>(pts),

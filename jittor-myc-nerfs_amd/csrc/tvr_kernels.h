@@ -122,7 +122,7 @@ hipError_t launch_composite_train_backward(const MarchOut &mo, int n_rays, long 
                                            const float *g_map, const float *g_pen, float *grgb, float *gin0, float *grad_w, float *grad_acc, unsigned *amax_bits,
                                            float target, float *gscale, hipStream_t stream);
 hipError_t launch_linear_dx(const float *dY, int ldy, int N, const float *W, int ldw, int n_valid, int K, const float *mask, int ldm, float *dX, int ldx, long long M,
-                            hipStream_t stream, const float *scale = nullptr, unsigned *sat_flag = nullptr);
+                            hipStream_t stream, const float *scale = nullptr, unsigned *sat_flag = nullptr, const unsigned long long *mask_bits = nullptr);
 hipError_t launch_filter_rays(const SceneDev &sc, const float *rays, long long n, int S, int bbox_only, unsigned char *mask, hipStream_t stream);
 size_t colsum_scratch_bytes();
 hipError_t launch_colsum(const float *A, int lda, int K, long long m_cap, const unsigned *m_dev, float *out, float *scratch, hipStream_t stream);

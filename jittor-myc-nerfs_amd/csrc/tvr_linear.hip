@@ -20,7 +20,8 @@
 template <int KB, bool F16>                                          // 32-column blocks of dX
 __global__ __launch_bounds__(64 * LDX_WAVES, 2) void linear_dx_kernel(const float *__restrict__ dY, const int ldy, const int N, const float *__restrict__ W, const int ldw,
                                                                      const int n_valid, const float *__restrict__ mask, const int ldm, float *__restrict__ dX,
-                                                                     const int ldx, const long long M, const float *__restrict__ scale, unsigned *__restrict__ sat_flag)
+                                                                     const int ldx, const long long M, const float *__restrict__ scale, unsigned *__restrict__ sat_flag,
+                                                                     const unsigned long long *__restrict__ mask_bits)
 {
     extern __shared__ __attribute__((aligned(16))) float wl[];       // fp32: [N][32 KB];  F16: uint4 [(N / 16) * KB * 2][64]
     constexpr int K = 32 * KB;
@@ -93,6 +94,8 @@ __global__ __launch_bounds__(64 * LDX_WAVES, 2) void linear_dx_kernel(const floa
             }
         }
         if (s < M) {
+            // the mask as bits: this lane's 16 KB results are bits 16 kb + 4 q + i of word h of its sample (the order of the kernel that wrote them)
+            const unsigned long long mbits = mask_bits ? mask_bits[2 * s + h] : ~0ull;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -101,7 +104,10 @@ __global__ __launch_bounds__(64 * LDX_WAVES, 2) void linear_dx_kernel(const floa
                     float4 v = make_float4(acc[kb][4 * q] * inv_sc, acc[kb][4 * q + 1] * inv_sc, acc[kb][4 * q + 2] * inv_sc, acc[kb][4 * q + 3] * inv_sc);
                     // the result is the next product's operand at the same scale (the layer below, the weight gradient): it must fit fp16 there as well
                     if (F16) bad |= (int)!(fmaxf(fmaxf(fabsf(acc[kb][4 * q]), fabsf(acc[kb][4 * q + 1])), fmaxf(fabsf(acc[kb][4 * q + 2]), fabsf(acc[kb][4 * q + 3]))) < 65504.0f);
-                    if (mask) {
+                    if (mask_bits) {
+                        const unsigned b4 = (unsigned)(mbits >> (16 * kb + 4 * q)) & 15u;
+                        v.x = (b4 & 1u) ? v.x : 0.0f; v.y = (b4 & 2u) ? v.y : 0.0f; v.z = (b4 & 4u) ? v.z : 0.0f; v.w = (b4 & 8u) ? v.w : 0.0f;
+                    } else if (mask) {
                         const float4 mk = *(const float4 *)(mask + s * ldm + k);
                         v.x = mk.x > 0.0f ? v.x : 0.0f; v.y = mk.y > 0.0f ? v.y : 0.0f; v.z = mk.z > 0.0f ? v.z : 0.0f; v.w = mk.w > 0.0f ? v.w : 0.0f;
                     }
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(64 * LDX_WAVES, 2) void linear_dx_kernel(const floa
 }
 
 hipError_t launch_linear_dx(const float *dY, int ldy, int N, const float *W, int ldw, int n_valid, int K, const float *mask, int ldm, float *dX, int ldx, long long M,
-                            hipStream_t stream, const float *scale, unsigned *sat_flag)
+                            hipStream_t stream, const float *scale, unsigned *sat_flag, const unsigned long long *mask_bits)
 {
     const bool f16 = scale != nullptr && !(N & 15);
     const size_t lds = (size_t)N * K * sizeof(float);               // (the fragment image of the fp16 form has the same size)
@@ -126,7 +132,7 @@ hipError_t launch_linear_dx(const float *dY, int ldy, int N, const float *W, int
         hipError_t rc = hipFuncSetAttribute((const void *)linear_dx_kernel<KB_, F16_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         if (rc != hipSuccess) return rc;                                                                                                          \
         hipLaunchKernelGGL((linear_dx_kernel<KB_, F16_>), dim3((unsigned)blocks), dim3(64 * LDX_WAVES), lds, stream, dY, ldy, N, W, ldw, n_valid, mask, ldm, dX, ldx, M, \
-                           scale, sat_flag);                                                                                                      \
+                           scale, sat_flag, mask_bits);                                                                                           \
     } while (0)
     switch ((K / 32) * 2 + (f16 ? 1 : 0)) {
     case 2: LDX_GO(1, false); break;
