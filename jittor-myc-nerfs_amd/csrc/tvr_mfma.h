@@ -19,15 +19,17 @@ __device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__f
 // shade tile — and 1 % SLOWER, 12.89 -> 13.0 ms: the second op depends on the first through the destination register.  Round 3: the same with the
 // four low halves first and the four high halves behind them in one asm block, no op following the one whose destination it completes: 13.20 vs 12.72 ms —
 // the mixlo / mixhi forms are half rate, scripts/hwprobe/valu_rate.hip.)
-// The residuals come out of inline asm; gfx950 needs ONE instruction between a VALU write and an MFMA read of the register
-// (scripts/hwprobe/mfma_raw2.hip); here they pass through the compiler-visible v_cvt_pkrtz, and scripts/isa_check.py (R4) checks the shipped ISA.
+// Round 4: the v_fma_mix_f32 is the COMPILER's (rounds 1-3 wrote it as inline asm, which the scheduler cannot classify: in the shade kernel's pipelined matrix
+// phase those 8 instructions per fragment drifted to the end of their k-step).  hipcc selects it for fma(fpext(half), m, x) as long as it cannot fold the
+// multiplier: m = -1.0 sits in an SGPR behind an empty asm (a literal -1 turns the fma into a subtraction with a separate v_cvt_f32_f16).
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
 {
-    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-    float ra, rb;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hb), "v"(b));
-    hi = hb;
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    float m1 = -1.0f;
+    asm("" : "+s"(m1));
+    const fp16x2 hb = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const float ra = __builtin_fmaf((float)hb.x, m1, a), rb = __builtin_fmaf((float)hb.y, m1, b);
+    hi = __builtin_bit_cast(unsigned, hb);
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 struct Frag {   // one 8-element fp16 operand fragment, hi and lo parts

@@ -36,9 +36,26 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define TVR_SB __builtin_amdgcn_sched_barrier(0)
-#ifndef TVR_PF
-#define TVR_PF 1          // gather prefetch distance in k-steps (ring of TVR_PF + 1 tap sets)
+// the split is plain arithmetic: without a use in the gather phase hipcc sinks all nine of them (144 VALU) behind the matrix token
+// TVR_SPLIT_LATE 1 (round-4 experiment, measured and NOT shipped): only k-step 0's fragment is split (fp32 -> fp16 hi / lo) in the gather phase; k-steps 1..8 keep
+// their fp32 values (the same 72 registers) and are split under the basis product's MFMAs, whose windows are empty — 128 VALU instructions leave the gather
+// phase (-700 cycles per tile) and the token is held 250 cycles longer: 12.73 ms against 12.62 with all nine splits in the gather phase (gpurun_out/r4j).
+#ifndef TVR_SPLIT_LATE
+#define TVR_SPLIT_LATE 0
 #endif
+#define TVR_PIN8(v) asm volatile("" : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]), "+v"((v)[4]), "+v"((v)[5]), "+v"((v)[6]), "+v"((v)[7]))
+#define TVR_GATHER_KEEP(s_)                                                                            \
+    do {                                                                                               \
+        if (!TVR_SPLIT_LATE || !TVR_SCHED || (s_) == 0) { hf[s_] = split8(hvv[s_]); TVR_PIN_FRAG(hf[s_]); } \
+        else TVR_PIN8(hvv[s_]);                                                                        \
+    } while (0)
+#define TVR_PIN_FRAG(f) asm volatile("" : "+v"((f).hi.x), "+v"((f).hi.y), "+v"((f).hi.z), "+v"((f).hi.w), "+v"((f).lo.x), "+v"((f).lo.y), "+v"((f).lo.z), "+v"((f).lo.w))
+#ifndef TVR_PF
+#define TVR_PF 1          // gather prefetch distance in k-steps (ring of TVR_PF + 1 tap sets) ...
+#endif
+#ifndef TVR_PF_SHALLOW
+#define TVR_PF_SHALLOW 5  // ... for k-steps below this one; 1 from here on (see the gather loop).  Round 4 measured 2 / {3, 4, 5, 6} against 1: 12.42-12.51 ms
+#endif                    // against 12.41 (gpurun_out/r4e) — no gain: with two waves per SIMD the gather phase hides under the partner's matrix phase
 #define TVR_CHK (SRC != SH_SRC_QUEUE)
 #ifndef TVR_TIMING
 #define TVR_TIMING 0      // diagnostic build: per-phase s_memtime sums into stats[8..14] (scripts/phase_timing.py passes 16 slots)
@@ -60,9 +77,11 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 #define TVR_PRIO_F 0      // s_setprio of finish_tile (layer 3 + store), see the call site
 #endif
 #ifndef TVR_PRIO_G
-#define TVR_PRIO_G 2      // s_setprio while a wave is in its gather phase / its matrix phase.  The gather phase is a dependent chain of loads and
-#define TVR_PRIO_M 0      // short VALU bursts: when its instructions win arbitration against the partner's MFMA stream the tile takes 6 % less
-#endif                    // time (15.55 -> 14.75 ms); the opposite polarity costs 2 % (15.9).  Measured on one box, interleaved rounds.
+#define TVR_PRIO_G 0      // s_setprio while a wave is in its gather phase / its matrix phase.  Rounds 1-3 ran the gather ABOVE the matrix phase (2 / 0: hipcc's
+#endif                    // schedule of the matrix phase left its own VALU work outside the MFMAs' shadow anyway, and the gather's dependent load chains gained
+#ifndef TVR_PRIO_M        // 6 %).  With the matrix phase as an explicit pipeline (TVR_SCHED) every issue slot it loses to the partner is matrix-pipe idle time:
+#define TVR_PRIO_M 2      // matrix 2 / gather 0 takes 12.17 ms against 12.48 for 0 / 2 (gpurun_out/r4d, two interleaved rounds; 2 / 1: 12.28, 3 / 0: 12.18;
+#endif                    // round 3's schedule at 2 / 0: 12.81 against its own 12.62 at 0 / 2).
 // (the packed forms v_pk_fma_f32 / v_pk_mul_f32: half the instructions and 2 % SLOWER — beside the partner wave's MFMA stream a packed fp32 op takes
 // 52.7 cycles instead of 4.6, scripts/hwprobe/valu_rate.hip)
 // two plain v_fma_f32 / v_mul_f32, each pinned by an empty asm (without the pins, and with the SLP vectoriser off: 12.92 vs 12.75 ms)
@@ -102,6 +121,100 @@ __device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag &b, f32x16 a
     for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h[rb]), __builtin_bit_cast(h8, b.hi), acc[rb], 0, 0, 0);
 }
 
+// ---- round 4: the matrix phase as an explicit software pipeline (TVR_SCHED) ------------------------------------------------------------
+// hipcc's own schedule of the hidden layers (round 3; scripts/isa_trace.py shows it) issued a k-step's A-fragment reads right in front of the MFMAs that
+// consume them (ds_read x4, s_waitcnt, MFMA: 70 exposed LDS round trips per tile) and clumped MFMAs (8 back to back) apart from the VALU work of the next
+// fragment.  What a wave's own stream can put under its MFMAs was measured (scripts/hwprobe/mfma_issue.hip, mfma_issue2.hip -> profiles/r04_mfma_issue_probe.txt,
+// one wave per SIMD, one asm block per iteration): an MFMA holds the pipe for 32 cycles and the wave's issue for 8; up to FIVE independent VALU instructions
+// behind every MFMA are free (32.0 - 32.3 cycles per MFMA, one accumulation chain or four, arch or Acc VGPRs alike), the sixth is not (34.0); a ds_read_b128
+// costs a window about as much as two or three of them (3 VALU per MFMA + 2 reads per 3 MFMAs: 36.1; 2 VALU: 33.5; reads alone: 32.0).  Round 3's statement
+// that a wave's VALU work does not run under its own MFMAs described hipcc's clumps, not the hardware.  Now:
+//   * the MFMAs of a k-step go row block by row block (l*hi, h*lo, h*hi on one accumulator: a dependent chain issues back to back at 32 cycles), so an A
+//     fragment lives for three MFMAs and a ring of TVR_PD + 2 {hi, lo} pairs, read TVR_PD row blocks ahead, replaces the two whole-k-step fragment sets
+//     (64 -> 32 registers; the kernel went from 246 to 210 VGPRs);
+//   * __builtin_amdgcn_sched_group_barrier pins the order inside a k-step (one scheduling region): per row block {read} M V0 {read} M V1 M V2, the VALU
+//     instructions being the NEXT k-step's B fragment (positional encoding / relu + fp16 split); the windows that carry a read carry fewer of them;
+//   * the fp16 split's v_fma_mix_f32 is the compiler's own instruction now (tvr_mfma.h), so that the scheduler can classify it;
+//   * layer 1's last k-step carries layer 2's prologue, the basis product is one accumulation chain with its A fragments two k-steps ahead.
+// Per accumulator the order of the additions in the hidden layers is the one mfma3x4 has: their results are bit-identical to round 3's.
+// What it bought, honestly (profiles/r04_shade_schedule_ab.txt, interleaved rounds on one box each): the token is held 9.4 k cycles instead of 10.9 k, the tile
+// takes 23.0 k cycles per wave instead of 24.8 k, the kernel 12.2 - 12.6 ms instead of 12.6 - 13.0 (-3 %): with two in-order waves per SIMD the gather phase, the
+// token wait and layer 3 are on the same critical chain as the matrix phase, and a lone wave's hidden layers run at 39 cycles per MFMA whatever the order of their
+// instructions (32.5 without the fragment derivation, 32.1 without the fragment reads, 38.8 with both: gpurun_out/r4f) — issue-bound, not pipe-bound.
+#ifndef TVR_SCHED
+#define TVR_SCHED 1
+#endif
+#ifndef TVR_DIAG
+#define TVR_DIAG 0        // diagnostic builds only (wrong pictures): 1 = no fragment derivation in the hidden layers, 2 = no A-fragment reads
+#endif
+#define TVR_NV1 3         // VALU (+ transcendental) instructions behind each MFMA of layer 1's last k-step (layer 2's first fragment)
+// The three MFMA windows of a row block: TVR_PIPE 1 puts one fragment read in each of the first two windows and V0 / V1 / V2 VALU instructions behind the three
+// MFMAs (layer 1: 1 / 3 / 5, layer 2: 0 / 2 / 4; 2 / 3 / 4 and 1 / 4 / 4 measured 5 % slower, 0 / 3 / 6 and 0 / 4 / 5 equal); TVR_PIPE 0: both reads in front of
+// the row block and 3 / 3 / 3 (2 / 2 / 2): 3 % slower.
+#ifndef TVR_PIPE
+#define TVR_PIPE 1
+#endif
+#ifndef TVR_PD
+#define TVR_PD 2          // A fragments are read this many row blocks ahead of their MFMAs, into a ring of TVR_PD + 2 {hi, lo} pairs
+#endif
+#define TVR_RN (TVR_PD + 2)
+#if TVR_PIPE == 0
+#define TVR_L1_V0 3
+#define TVR_L1_V1 3
+#define TVR_L1_V2 3
+#define TVR_L2_V0 2
+#define TVR_L2_V1 2
+#define TVR_L2_V2 2
+#define TVR_PIPE_RB(has_read, v0, v1, v2)                                                              \
+    do {                                                                                               \
+        if (has_read) TVR_SG_DSR(2);                                                                   \
+        TVR_SG_MFMA(1); if (v0) TVR_SG_VALU(v0);                                                       \
+        TVR_SG_MFMA(1); if (v1) TVR_SG_VALU(v1);                                                       \
+        TVR_SG_MFMA(1); if (v2) TVR_SG_VALU(v2);                                                       \
+    } while (0)
+#else
+#ifndef TVR_L1_V0
+#define TVR_L1_V0 1
+#define TVR_L1_V1 3
+#define TVR_L1_V2 5
+#endif
+#ifndef TVR_L2_V0
+#define TVR_L2_V0 0
+#define TVR_L2_V1 2
+#define TVR_L2_V2 4
+#endif
+#define TVR_PIPE_RB(has_read, v0, v1, v2)                                                              \
+    do {                                                                                               \
+        if (has_read) TVR_SG_DSR(1);                                                                   \
+        TVR_SG_MFMA(1); if (v0) TVR_SG_VALU(v0);                                                       \
+        if (has_read) TVR_SG_DSR(1);                                                                   \
+        TVR_SG_MFMA(1); if (v1) TVR_SG_VALU(v1);                                                       \
+        TVR_SG_MFMA(1); if (v2) TVR_SG_VALU(v2);                                                       \
+    } while (0)
+#endif
+#define TVR_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
+#define TVR_SG_VALU(n) __builtin_amdgcn_sched_group_barrier(0x402, (n), 0)      // VALU | TRANS
+#define TVR_SG_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
+struct AF { uint4 h, l; };
+__device__ __forceinline__ void load_af(AF &A, const unsigned char *WH, const unsigned char *WL, int off)
+{
+    A.h = *(const uint4 *)(WH + off);
+    A.l = *(const uint4 *)(WL + off);
+}
+__device__ __forceinline__ void mfma3(const AF &A, const Frag &b, f32x16 &acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.l), __builtin_bit_cast(h8, b.hi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h), __builtin_bit_cast(h8, b.lo), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h), __builtin_bit_cast(h8, b.hi), acc, 0, 0, 0);
+}
+// byte offset of the A fragment of row block q & 3 of k-step q >> 2 inside a weight image
+#define TVR_AOFF(q) (((q) >> 2) * TVR_IMG_STEP + ((q) & 3) * TVR_IMG_RB)
+// an LDS pointer held in ONE register the compiler cannot see through (so that it addresses base + immediate instead of folding the base away)
+#define TVR_LDS_BASE(name, expr)                                                                                    \
+    unsigned name##_a = (unsigned)(size_t)(expr);                                                                   \
+    asm volatile("" : "+v"(name##_a));                                                                              \
+    const unsigned char *name = (const unsigned char *)(const void __attribute__((address_space(3))) *)(size_t)name##_a
+
 // the 6 taps (4 plane texels, 2 line texels) x 8 channels of one entry for one k-step
 struct Taps {
     float4 t[4][2], lv[2][2];
@@ -138,28 +251,22 @@ __device__ __forceinline__ void load_taps(Taps &T, const float4 *__restrict__ P,
         T.lv[0][0] = q[0]; T.lv[0][1] = q[1];
         T.lv[1][0] = q[12]; T.lv[1][1] = q[13];
     } else {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool xi[2] = {(x0 >= 0) && (x0 < W), (x0 + 1 >= 0) && (x0 + 1 < W)};
-        const bool yi[2] = {(y0 >= 0) && (y0 < H), (y0 + 1 >= 0) && (y0 + 1 < H)};
-        const bool li[2] = {(l0 >= 0) && (l0 < L), (l0 + 1 >= 0) && (l0 + 1 < L)};
-        const int xc[2] = {min(max(x0, 0), W - 1), min(max(x0 + 1, 0), W - 1)};
-        const int yc[2] = {min(max(y0, 0), H - 1), min(max(y0 + 1, 0), H - 1)};
-        const int lc[2] = {min(max(l0, 0), L - 1), min(max(l0 + 1, 0), L - 1)};
-#pragma unroll
-        for (int ty = 0; ty < 2; ++ty)
-#pragma unroll
-            for (int tx = 0; tx < 2; ++tx) {
-                const float4 *p = P + ((size_t)yc[ty] * Wp + xc[tx]) * 12 + q0;
-                const bool in = xi[tx] && yi[ty];
-                T.t[ty * 2 + tx][0] = in ? p[0] : z;
-                T.t[ty * 2 + tx][1] = in ? p[1] : z;
-            }
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            const float4 *q = Ln + (size_t)lc[tl] * 12 + q0;
-            T.lv[tl][0] = li[tl] ? q[0] : z;
-            T.lv[tl][1] = li[tl] ? q[1] : z;
-        }
+        // arbitrary coordinates (the API's lookups): every tap is fetched from a CLAMPED cell with the same 32-bit offsets, and taps_eval<true> gives the taps
+        // that lie outside the grid the weight zero — grid_sample's zeros padding without a select per fetched value.  (Rounds 1-3 selected the 12 float4 of
+        // every k-step against zero behind 64-bit per-tap addresses: 256 registers, spills, 25 us per tile.)
+        const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+        const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+        const int lc0 = min(max(l0, 0), L - 1), lc1 = min(max(l0 + 1, 0), L - 1);
+        const unsigned r0 = (unsigned)yc0 * (unsigned)Wp, r1 = (unsigned)yc1 * (unsigned)Wp;
+        const float4 *p00 = P + ((r0 + (unsigned)xc0) * 12u + (unsigned)q0), *p01 = P + ((r0 + (unsigned)xc1) * 12u + (unsigned)q0);
+        const float4 *p10 = P + ((r1 + (unsigned)xc0) * 12u + (unsigned)q0), *p11 = P + ((r1 + (unsigned)xc1) * 12u + (unsigned)q0);
+        T.t[0][0] = p00[0]; T.t[0][1] = p00[1];
+        T.t[1][0] = p01[0]; T.t[1][1] = p01[1];
+        T.t[2][0] = p10[0]; T.t[2][1] = p10[1];
+        T.t[3][0] = p11[0]; T.t[3][1] = p11[1];
+        const float4 *q0p = Ln + ((unsigned)lc0 * 12u + (unsigned)q0), *q1p = Ln + ((unsigned)lc1 * 12u + (unsigned)q0);
+        T.lv[0][0] = q0p[0]; T.lv[0][1] = q0p[1];
+        T.lv[1][0] = q1p[0]; T.lv[1][1] = q1p[1];
     }
 }
 
@@ -175,9 +282,19 @@ __device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, fl
     } else {
         x0f = floorf(fx); y0f = floorf(fy); l0f = floorf(fl);
     }
-    const float wx = fx - x0f, wy = fy - y0f, wlf = fl - l0f;
-    const float ux = 1.0f - wx, uy = 1.0f - wy, ulf = 1.0f - wlf;
-    const float a00 = ux * uy, a01 = wx * uy, a10 = ux * wy, a11 = wx * wy;
+    const float wx = fx - x0f, wy = fy - y0f;
+    float wlf = fl - l0f, ulf = 1.0f - wlf;
+    const float ux = 1.0f - wx, uy = 1.0f - wy;
+    float a00 = ux * uy, a01 = wx * uy, a10 = ux * wy, a11 = wx * wy;
+    if (CHECK) {                                                    // taps outside the grid: weight zero (load_taps<true> fetched a clamped cell for them)
+        const int x0 = (int)x0f, y0 = (int)y0f, l0 = (int)l0f;
+        const bool xi0 = (x0 >= 0) && (x0 < W), xi1 = (x0 + 1 >= 0) && (x0 + 1 < W);
+        const bool yi0 = (y0 >= 0) && (y0 < H), yi1 = (y0 + 1 >= 0) && (y0 + 1 < H);
+        a00 = (xi0 && yi0) ? a00 : 0.0f; a01 = (xi1 && yi0) ? a01 : 0.0f;
+        a10 = (xi0 && yi1) ? a10 : 0.0f; a11 = (xi1 && yi1) ? a11 : 0.0f;
+        ulf = ((l0 >= 0) && (l0 < L)) ? ulf : 0.0f;
+        wlf = ((l0 + 1 >= 0) && (l0 + 1 < L)) ? wlf : 0.0f;
+    }
     const f32x2 w00 = {a00, a00}, w01 = {a01, a01}, w10 = {a10, a10}, w11 = {a11, a11};
     const f32x2 ul = {ulf, ulf}, wl = {wlf, wlf};
 #pragma unroll
@@ -362,6 +479,62 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
         _Pragma("unroll") for (int r = 0; r < 8; ++r) G[r] = (accA[r] + accB[r]) + accC[r];                                         \
     } while (0)
 
+// The phase boundary and the basis product  F^T[32 x 32e] = Bas[32 x 144] . h^T  (27 MFMAs).  Uses hf[], bal[], F[], bashp, baslp, NLO, have_tok, mtok, lane of
+// the enclosing scope.  Phase boundary: every global load of this tile has landed before the first MFMA issues, and the compiler may not move loads
+// below it.  TVR_SCHED: ONE accumulation chain (l*hi, h*lo, h*hi per k-step, as the hidden layers do — round 3 summed three chains with 32 VALU adds behind
+// the last MFMA, pipe idle), the A fragments in a ring of four read two k-steps ahead of their use, the first two BEFORE the wave waits for its loads and
+// for the matrix token.
+#if TVR_SCHED
+#define TVR_BASIS_BLOCK()                                                                                                            \
+    do {                                                                                                                            \
+        constexpr int BST_ = 2 * TVR_IMG_BASH_ROWS * 16;                                                                            \
+        AF br_[4];                                                                                                                  \
+        auto bld_ = [&](int s_) {                                                                                                   \
+            br_[s_ & 3].h = *(const uint4 *)(bashp + s_ * BST_);                                                                    \
+            if (s_ < NLO) br_[s_ & 3].l = *(const uint4 *)(baslp + s_ * BST_);                                                      \
+            else br_[s_ & 3].l = bal[s_];                                                                                           \
+        };                                                                                                                          \
+        bld_(0); bld_(1);                                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                            \
+        TVR_SB;                                                                                                                     \
+        TVR_STAMP(tg1);                                                                                                             \
+        TVR_ENTER_MATRIX();                                                                                                         \
+        TVR_STAMP(tgW);                                                                                                             \
+        f32x16 accF_ = f32x16{0};                                                                                                   \
+        _Pragma("unroll") for (int s_ = 0; s_ < 9; ++s_) {          /* one scheduling region per k-step: reads issued here are consumed two regions on */ \
+            if (s_ + 2 < 9) bld_(s_ + 2);                                                                                           \
+            mfma3(br_[s_ & 3], hf[s_], accF_);                                                                                      \
+            if (TVR_SPLIT_LATE && s_ + 1 < 9) hf[s_ + 1] = split8(hvv[s_ + 1]);                                                     \
+            if (s_ + 2 < 9) { if (s_ + 2 < NLO) TVR_SG_DSR(2); else TVR_SG_DSR(1); }                                                \
+            if (TVR_SPLIT_LATE && s_ + 1 < 9) { TVR_SG_MFMA(1); TVR_SG_VALU(4); TVR_SG_MFMA(1); TVR_SG_VALU(6); TVR_SG_MFMA(1); TVR_SG_VALU(6); } \
+            else TVR_SG_MFMA(3);                                                                                                    \
+            TVR_SB;                                                                                                                 \
+        }                                                                                                                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) F[r_] = accF_[r_];                                                        \
+        TVR_SB;                                                                                                                     \
+        if (REF) { f32x16 accA, accB, accC; TVR_REF_HEADS(); }                                                                      \
+    } while (0)
+#else
+#define TVR_BASIS_BLOCK()                                                                                                            \
+    do {                                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                            \
+        TVR_SB;                                                                                                                     \
+        TVR_STAMP(tg1);                                                                                                             \
+        TVR_ENTER_MATRIX();                                                                                                         \
+        TVR_STAMP(tgW);                                                                                                             \
+        f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};                                                                \
+        _Pragma("unroll") for (int s_ = 0; s_ < 9; ++s_) {                                                                          \
+            const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s_ * (2 * TVR_IMG_BASH_ROWS * 16)));                      \
+            const h8 Al = s_ < NLO ? __builtin_bit_cast(h8, *(const uint4 *)(baslp + s_ * (2 * TVR_IMG_BASH_ROWS * 16))) : __builtin_bit_cast(h8, bal[s_]); \
+            accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s_].hi), accA, 0, 0, 0);                    \
+            accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s_].lo), accB, 0, 0, 0);                    \
+            accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s_].hi), accC, 0, 0, 0);                    \
+        }                                                                                                                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) F[r_] = (accA[r_] + accB[r_]) + accC[r_];                                 \
+        if (REF) { TVR_REF_HEADS(); }                                                                                               \
+    } while (0)
+#endif
+
 template <int SRC, int DST, bool REF>
 __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
@@ -421,8 +594,10 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #if TVR_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#if !TVR_SCHED
     const unsigned char *W1H = smem + TVR_IMG_W1H, *W1L = smem + TVR_IMG_W1L;
     const unsigned char *W2H = smem + TVR_IMG_W2H, *W2L = smem + TVR_IMG_W2L;
+#endif
     constexpr bool HAVE_G = REF && SRC != SH_SRC_FEAT;
     const long long tile_stride = (long long)gridDim.x * SH_WAVES;
     // workgroups b, b + 8, ... share an XCD (and its 4 MB L2): give each XCD a contiguous eighth of every window of tiles, so that its L2
@@ -445,7 +620,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
         for (int r = 0; r < 8; ++r) G[r] = 0.f;
 #if TVR_TIMING
-        unsigned long long tg0 = 0, tgD = 0, tgF = 0, tg1 = 0, tgW = 0, tg2 = 0, tg3 = 0, tg4 = 0;
+        unsigned long long tg0 = 0, tgD = 0, tgF = 0, tg1 = 0, tgW = 0, tg2 = 0, tg3 = 0, tg4 = 0, tgL = 0;
 #endif
         TVR_STAMP(tg0);
         TVR_ENTER_GATHER();
@@ -465,6 +640,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         if (SRC == SH_SRC_H) {
             // training forward: h [n,144] comes from tvr_app_h_forward; this lane's 8 channels of each k-step are 32 contiguous bytes
             Frag hf[9];
+            float hvv[9][8];                           // the fragments' fp32 values: k-step 0 is split in the gather phase, 1..8 under the basis MFMAs
             uint4 bal[9];
             if (live) {                                  // view direction: [n,3] given, or that of the entry's ray (the fused training step)
                 const float *dp = a.q_ray ? a.rays + (size_t)a.q_ray[ent] * 6 + 3 : a.viewdirs + ent * 3;
@@ -483,26 +659,12 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
                     const float hv[8] = {hv4[s][0].x, hv4[s][0].y, hv4[s][0].z, hv4[s][0].w, hv4[s][1].x, hv4[s][1].y, hv4[s][1].z, hv4[s][1].w};
-                    hf[s] = split8(hv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hvv[s][j] = hv[j];
+                    TVR_GATHER_KEEP(s);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            TVR_SB;
-            TVR_STAMP(tg1);
-            TVR_ENTER_MATRIX();
-            TVR_STAMP(tgW);
-            f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};
-#pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s * (2 * TVR_IMG_BASH_ROWS * 16)));
-                const h8 Al = s < NLO ? __builtin_bit_cast(h8, *(const uint4 *)(baslp + s * (2 * TVR_IMG_BASH_ROWS * 16))) : __builtin_bit_cast(h8, bal[s]);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);
-                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) F[r] = (accA[r] + accB[r]) + accC[r];
-            if (REF) { TVR_REF_HEADS(); }
+            TVR_BASIS_BLOCK();
         } else if (SRC != SH_SRC_FEAT) {
             float pn[3] = {0.f, 0.f, 0.f};
             if (SRC == SH_SRC_QUEUE) {
@@ -518,23 +680,26 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             // 9 k-steps of 16 channels (plane p = s/3, channels 16(s%3) + 8h .. +7 of this lane); the B fragments (plane*line products,
             // fp16 hi/lo) stay in registers
             Frag hf[9];
+            float hvv[9][8];                           // the fragments' fp32 values: k-step 0 is split in the gather phase, 1..8 under the basis MFMAs
             uint4 bal[9];
             {
-                Taps T[TVR_PF + 1];                                // ring: taps of k-steps s .. s+TVR_PF in flight
-#pragma unroll
-                for (int s0 = 0; s0 < TVR_PF; ++s0) {
-                    const int p = s0 / 3;
+                // ring: before k-step s is evaluated, the taps of k-steps up to s + depth(s) are in flight.  depth = TVR_PF (2) while the finished
+                // fragments hf[] are few, 1 from k-step TVR_PF_SHALLOW on: registers = 8 s (hf) + 48 per tap set, and a wave has 256.  Round 3 ran depth 1
+                // throughout: a tap set then has one evaluation (~80 VALU, ~400 cycles) to arrive, an L2 / MALL hit takes 500-900 cycles, and the phase
+                // timing of a lone wave showed half of the gather phase's 8.7 k cycles to be that wait.
+                constexpr int PFD = TVR_PF;
+                Taps T[PFD + 1];
+                auto tgt = [](int s) { const int d = s < TVR_PF_SHALLOW ? TVR_PF : 1; return s + d < 8 ? s + d : 8; };   // last k-step issued before k-step s is evaluated
+                auto issue = [&](int s2) {
+                    const int p = s2 / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
-                    load_taps<TVR_CHK>(T[s0], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], TVR_Q0(s0 % 3, h));
-                }
+                    load_taps<TVR_CHK>(T[s2 % (PFD + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], TVR_Q0(s2 % 3, h));
+                };
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
-                    if (s + TVR_PF < 9) {
-                        const int s2 = s + TVR_PF, p = s2 / 3;
-                        const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
-                        load_taps<TVR_CHK>(T[s2 % (TVR_PF + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx],
-                                           TVR_Q0(s2 % 3, h));
-                    } else if (s + TVR_PF == 9 + (REF ? 1 : 0)) {      // (REFTensoRF: after the last evaluation — its extra live values leave no room earlier)
+#pragma unroll
+                    for (int s2 = (s == 0 ? 0 : tgt(s - 1) + 1); s2 <= tgt(s); ++s2) issue(s2);
+                    if (!REF && s == 7) {                              // (REFTensoRF: behind the loop — its extra live values leave no room earlier)
                         // the basis A fragments (the tile's last global loads) ride behind the last taps
                         // (lo parts; the hi parts are in LDS.  Byte offsets against the uniform base, opaque per tile: hoisted per-step 64-bit
                         // addresses would spill)
@@ -545,9 +710,8 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     }
                     const int p = s / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
-                    float hv[8];
-                    taps_eval<TVR_CHK>(T[s % (TVR_PF + 1)], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], hv);
-                    hf[s] = split8(hv);
+                    taps_eval<TVR_CHK>(T[s % (PFD + 1)], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], hvv[s]);
+                    TVR_GATHER_KEEP(s);
                     TVR_SB;
                 }
             }
@@ -557,26 +721,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
                 for (int s3 = NLO; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
             }
-            // phase boundary: every load of this tile has landed before the first MFMA issues, and the compiler may not move loads below it
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            TVR_SB;
-            TVR_STAMP(tg1);
-            TVR_ENTER_MATRIX();
-            TVR_STAMP(tgW);
-            // ------------------------------------------------------------ MATRIX phase: MFMA + LDS + VALU, no global load ----
-            // three independent accumulation chains (hi*lo products) summed at the end: no MFMA directly follows its producer
-            f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};
-#pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s * (2 * TVR_IMG_BASH_ROWS * 16)));
-                const h8 Al = s < NLO ? __builtin_bit_cast(h8, *(const uint4 *)(baslp + s * (2 * TVR_IMG_BASH_ROWS * 16))) : __builtin_bit_cast(h8, bal[s]);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);
-                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) F[r] = (accA[r] + accB[r]) + accC[r];
-            if (REF) { TVR_REF_HEADS(); }
+            TVR_BASIS_BLOCK();
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -645,6 +790,110 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             }
         }
 
+#if TVR_SCHED
+        // ---- layers 1 and 2 as ONE software pipeline (see TVR_SCHED above) ----
+        // layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5; sin / cos of a base value are taken in the step
+        // that first needs them (2-3 per step).  Layer 2: the B fragments are the relu'd layer-1 accumulators, 8 registers per k-step; b2 is the initial
+        // accumulator.  Layer 1's last k-step already carries layer 2's prologue: once row block 0's last MFMA has issued, b2 and W2's first fragments are
+        // read and relu(acc[0]) is split under the MFMAs of row blocks 1..3 (round 3 paid an LDS round trip and 24 VALU ops there with the pipe idle).
+        f32x16 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x16{0};
+        Carry cur;
+        {
+            float S1[16], C1[16];
+            const int rowoff = (h * 128 + e) * 16;
+            auto l1_frag = [&](int s, Frag &b) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * s + j, r = i / 5, t = i % 5;
+                    // first slot of base value r in program order is i = 5r (t = 0): take its sin / cos there
+                    if (t == 0) sincos_pe(F[r], S1[r], C1[r]);
+                    v[j] = t == 0 ? F[r] : (t == 1 ? S1[r] : (t == 2 ? 2.0f * S1[r] * C1[r]                 // sin 2v
+                                  : (t == 3 ? C1[r] : __builtin_fmaf(-2.0f * S1[r], S1[r], 1.0f))));          // cos 2v
+                }
+                b = split8(v);
+            };
+            auto relu_frag = [&](int s, Frag &b) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = relu_f(acc[s >> 1][8 * (s & 1) + j]);
+                if (DST == SH_DST_TRAIN && live) {   // relu(layer 1): element j is hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3)
+                    *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 8 + 4 * h) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                b = split8(v);
+            };
+            // ONE opaque address register per image: every fragment read is base + 16-bit immediate (left to itself hipcc materialises an address
+            // register per read, and those VALU adds take the slots the pipeline means for the fragment derivation)
+            TVR_LDS_BASE(W1Hb, smem + TVR_IMG_W1H + rowoff);
+            TVR_LDS_BASE(W1Lb, smem + TVR_IMG_W1L + rowoff);
+            TVR_LDS_BASE(W2Hb, smem + TVR_IMG_W2H + rowoff);        // W2's lo image starts 32 KB behind its hi image: one base, immediates < 64 KB
+            const unsigned char *W2Lb = W2Hb + (TVR_IMG_W2L - TVR_IMG_W2H);
+            Frag bcur, bnxt;
+            AF ring[TVR_RN], ring2[TVR_RN];
+#pragma unroll
+            for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring[q0], W1Hb, W1Lb, TVR_AOFF(q0));
+            l1_frag(0, bcur);
+            TVR_SB;
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const int q = 4 * s + rb;
+                    if (q + TVR_PD < 40 && !(TVR_DIAG & 2)) load_af(ring[(q + TVR_PD) % TVR_RN], W1Hb, W1Lb, TVR_AOFF(q + TVR_PD));
+                    mfma3(ring[(TVR_DIAG & 2) ? (q & 1) : (q % TVR_RN)], bcur, acc[rb]);
+                    if (s == 9 && rb == 0) {
+                        // layer 2's prologue (acc[0] is complete): b2 -> the initial accumulators, W2's first two fragment pairs, relu(acc[0]) split
+#pragma unroll
+                        for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(q0));
+#pragma unroll
+                        for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) {
+                                const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * r2 + 8 * q4 + 4 * h) * 4);
+                                cur.acc2[r2][4 * q4] = bv.x; cur.acc2[r2][4 * q4 + 1] = bv.y; cur.acc2[r2][4 * q4 + 2] = bv.z; cur.acc2[r2][4 * q4 + 3] = bv.w;
+                            }
+                    }
+                }
+                if (TVR_DIAG & 1) bnxt = bcur;
+                else if (s + 1 < 10) l1_frag(s + 1, bnxt);
+                else relu_frag(0, bnxt);
+                if (s < 9) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) TVR_PIPE_RB(4 * s + rb + TVR_PD < 40, TVR_L1_V0, TVR_L1_V1, TVR_L1_V2);
+                } else {
+                    TVR_SG_MFMA(3);                 // row block 0
+                    TVR_SG_DSR(16 + 2 * TVR_PD);    // W2's first fragments, b2
+                    TVR_SG_MFMA(3);                 // row block 1: relu(acc[0]) may be read 3 MFMAs after its last write
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) { TVR_SG_MFMA(1); TVR_SG_VALU(TVR_NV1); }
+                }
+                bcur = bnxt;
+                TVR_SB;
+            }
+            TVR_STAMP(tg3);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const int q = 4 * s + rb;
+                    if (q + TVR_PD < 32 && !(TVR_DIAG & 2)) load_af(ring2[(q + TVR_PD) % TVR_RN], W2Hb, W2Lb, TVR_AOFF(q + TVR_PD));
+                    mfma3(ring2[(TVR_DIAG & 2) ? (q & 1) : (q % TVR_RN)], bcur, cur.acc2[rb]);
+                }
+                if (TVR_DIAG & 1) bnxt = bcur;
+                else if (s + 1 < 8) relu_frag(s + 1, bnxt);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    if (s + 1 < 8) TVR_PIPE_RB(4 * s + rb + TVR_PD < 32, TVR_L2_V0, TVR_L2_V1, TVR_L2_V2);
+                    else TVR_PIPE_RB(4 * s + rb + TVR_PD < 32, 0, 0, 0);
+                }
+                bcur = bnxt;
+                TVR_SB;
+            }
+        }
+#else
         // ---- layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5.  sin / cos of a base
         //      value are taken in the step that first needs them (2-3 per step), between the MFMAs of the step before ----
         f32x16 acc[4];
@@ -715,6 +964,12 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 TVR_SB;
             }
         }
+#endif
+        TVR_STAMP(tgL);
+#if TVR_SCHED && (TVR_DIAG & 1)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) cur.acc2[rb] += acc[rb];          // keeps layer 1 alive in the build that derives no fragments
+#endif
         cur.ent = ent; cur.live = live; cur.wq = wq;
         cur.g[0] = G[3]; cur.g[1] = G[4]; cur.g[2] = G[5]; cur.g[3] = G[6];
         TVR_LEAVE_MATRIX();
@@ -725,12 +980,12 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         __builtin_amdgcn_s_setprio(TVR_PRIO_G);
         TVR_STAMP(tg4);
 #if TVR_TIMING
-        tsum[0] += tgF - tgD; tsum[5] += tgD - tg0; tsum[1] += tg1 - tgF; tsum[6] += tgW - tg1; tsum[2] += tg2 - tgW; tsum[3] += tg3 - tg2; tsum[4] += tg4 - tg3;
+        tsum[0] += tgF - tgD; tsum[5] += tgD - tg0; tsum[1] += tg1 - tgF; tsum[6] += tgW - tg1; tsum[2] += tg2 - tgW; tsum[3] += tg3 - tg2; tsum[4] += tgL - tg3; tsum[7] += tg4 - tgL;
 #endif
     }
 #if TVR_TIMING
     if (a.stats && lane == 0)
-        for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // finish, gather, basis, L1 (+PE), L2, MFMA drain, wait for the matrix token
+        for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // queue fetch, gather, basis, L1 (+PE), L2, -, wait for the matrix token, hand-over + layer 3 + store
 #endif
     if (a.stats && SRC == SH_SRC_QUEUE && tid == 0) {
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_SHADE_CLK], __builtin_amdgcn_s_memtime() - clk0);

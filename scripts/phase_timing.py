@@ -12,9 +12,9 @@ stats.zero_()
 m.render_rays(rays, N_samples=512, stats=stats)
 torch.cuda.synchronize()
 st = stats.cpu().numpy().astype(float)
-tot = st[8:15].sum()
+tot = st[8:16].sum()
 print("entries", st[2], "tiles", st[2] / 32)
-names = ("queue-entry fetch for the next tile", "gather", "basis", "L1 (+PE)", "L2, token hand-over, layer 3 + store", "-", "wait for the matrix token")      # stamps of a -DTVR_TIMING=1 build (scripts/build_variant.sh timing -DTVR_TIMING=1)
-for n, v in zip(names, st[8:15]):
+names = ("queue-entry fetch for the next tile", "gather", "basis", "L1 (+PE)", "L2", "-", "wait for the matrix token", "token hand-over, layer 3 + store")      # stamps of a -DTVR_TIMING=1 build (scripts/build_variant.sh timing -DTVR_TIMING=1)
+for n, v in zip(names, st[8:16]):
     print(f"{n:26s} {v / (st[2] / 32):9.0f} cycles/tile  {100 * v / tot:5.1f} %")
 print("sum cycles/tile", tot / (st[2] / 32))
