@@ -39,7 +39,7 @@ import torch  # noqa: E402
 
 N_POSES = 8
 TILE = 4096
-SHADE_LOADS_PER_TILE = 123      # tvr_shade.hip, wave-level global loads per 32-entry tile: 108 taps + 9 basis fragments (lo parts) + 6 entry / direction
+SHADE_LOADS_PER_TILE = 114      # tvr_shade.hip, wave-level global loads per 32-entry tile as PMC counts them (SQ_INSTS_VMEM_RD, rounds 3 and 4): 108 taps + 3 basis fragments (lo parts of k-steps 6..8) + 3 entry / direction; fallback only, the live counter is used when the PMC pass ran
 
 
 def build_model(device, name="TensorVMSplit"):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 117
+#define TVR_VERSION 118
 
 typedef enum {
     TVR_OK = 0,
@@ -116,6 +116,12 @@ int tvr_scene_update(tvr_scene *scene, const tvr_scene_params *params, void *str
 size_t tvr_alpha_bits_bytes(const int32_t agrid_xyz[3]);
 int tvr_scene_set_alpha(tvr_scene *scene, const float *alpha_volume_dev, const int32_t agrid_xyz[3],
                         const float alpha_aabb[6], const float alpha_inv_size[3], void *bits, size_t bits_bytes, void *stream);
+/* fp16-range check of the inference entry points (tvr_render(_z), tvr_app_feature(_ref), tvr_mlp_render(_ref)); ON when a scene is created.
+ * ON: every value that enters a matrix product through the fp16 hi / lo split is held against fp16's largest finite value on the way (one v_max3 per two
+ * values, ~1.5 % of the shade kernel's time); an appearance sample with an operand at or beyond 65 504 gets NaN as its colour / features, so its pixel is NaN,
+ * never a silently clipped product.  OFF: no check — for hosts that have PROVEN the range from the parameters (the Python host does, by interval bounds, at
+ * pack time: field.py::TensorVMSplit._fp16_range_proven) and want the last 1.5 %.  Weights are the host's to check (a bound on max|W| needs no kernel). */
+int tvr_scene_set_range_check(tvr_scene *scene, int32_t on);
 int tvr_scene_destroy(tvr_scene *scene);
 
 /* TensorBase.execute over a ray batch (tensorBase.py:476-536, ndc_ray=False; variant 1: REFTensoRF.execute,
@@ -127,8 +133,9 @@ int tvr_scene_destroy(tvr_scene *scene);
  * Arithmetic and its range: everything is fp32 except the matrix products of the appearance network (basis 144->27, layers 1 and 2), which
  * run on the matrix cores as THREE fp16 products per fp32 product (each operand = fp16 hi + fp16 lo, hi*hi + hi*lo + lo*hi, fp32
  * accumulation): ~2^-22 relative error per product, i.e. fp32-class results, but operands pass through fp16's exponent range —
- * |weight|, |appearance feature|, |activation| must stay below 65 504 (conversion saturates there, silently) and parts below 6e-8 are
- * flushed.  Layer 3, the positional encoding, interpolation, density and compositing are plain fp32.  The shipped scenes and the reference's
+ * |weight|, |appearance feature|, |activation| must stay below 65 504 (the conversion saturates there) and parts below 6e-8 are
+ * flushed.  Leaving the range is REPORTED, not silent: with the scene's range check on (the default, tvr_scene_set_range_check) a sample
+ * whose operands reach 65 504 renders as NaN.  Layer 3, the positional encoding, interpolation, density and compositing are plain fp32.  The shipped scenes and the reference's
  * 0.1 * randn initialisation are far inside this range (tests: |feature| up to ~1100, weights at 1e-4 scale). */
 size_t tvr_render_scratch_bytes(const tvr_scene *scene, int64_t n_rays, int32_t n_samples);
 int tvr_render(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, int32_t white_bg,
@@ -169,7 +176,7 @@ int tvr_alpha_sample(const float *alpha_volume_dev, const int32_t agrid_xyz[3], 
 
 /* Byte offsets of the regions of a tvr_render / tvr_march_forward scratch buffer, for hosts that consume the queue:
  * counter u32[4] = {queue length, the march's tile counter, FAULT flag, training-workspace OVERFLOW flag (tvr_train_forward)}: the flag is non-zero if a wave of the march kernel gave up waiting for its
- * tile number (1: overtaken in the 32-slot ring, 2: spin limit; tvr_march.hip) — tvr_render then writes NaN to every pixel and depth of the call,
+ * tile number (1: overtaken in the 64-slot ring, 2: spin limit; tvr_march.hip) — tvr_render then writes NaN to every pixel and depth of the call,
  * hosts that consume the queue read it with the queue length; ray_off/ray_cnt u32[n]; acc f32[n]; q_pos float4[cap] {xyz_norm, weight}; q_out float4[cap] {rgb, weight};
  * q_ray u32[cap]; q_j u32[cap]; cap = n_rays * n_samples.  Each ray's entries are contiguous and in sample order. */
 typedef struct { size_t counter, ray_off, ray_cnt, acc, q_pos, q_out, q_ray, q_j, total; } tvr_scratch_layout;

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -540,12 +542,19 @@ class _RefMlpTrainFn(torch.autograd.Function):
         return (None, dh, None, gB, gH[0:3], gbh[0:3], gH[4:7], gbh[4:7], gH[3:4], gbh[3:4], gH[7:8], gbh[7:8], gW1, gb1, gW2, gb2, gW3, gb3)
 
 
+class _StepToken:
+    """Held by the autograd node of a fused training forward; the model's workspace keeps a weak reference (see _FusedStepFn.forward)."""
+    __slots__ = ("__weakref__",)
+
+
 class _FusedStepFn(torch.autograd.Function):
     """TensorBase.execute / REFTensoRF.execute under autograd (train.py:225-261) as TWO C-ABI calls with no host read in between: tvr_train_forward
     (march -> appearance gather -> basis / heads / MLP -> compositing) and tvr_train_backward (its gradient, weight gradients, scatter into the VM
     factors, march backward).  Every kernel behind the march takes the number of appearance samples from the device; the buffers live in the model
     (model._train_buffers: sized once for `app_cap` samples, reused every step), so the step is a fixed sequence of launches — hipGraph-capturable —
-    and, with fixed-order compositing sums, bit-reproducible.  Outputs: rgb_map [n,3], depth [n] (no gradient), pen_ray [n] (REFTensoRF: per-ray normal
+    and its picture / loss are bit-reproducible (every ray's queue segment is contiguous and sample-ordered, the compositing sums run in a fixed order); the
+    GRADIENTS are reproducible to rounding only (<= 2e-6 of the largest entry: the order of the rays in the queue is the order the march kernel's waves
+    finish in, and the VM-factor gradients are scattered with fp32 atomics — DESIGN.md 7, tests/test_gpu_fused_step.py).  Outputs: rgb_map [n,3], depth [n] (no gradient), pen_ray [n] (REFTensoRF: per-ray normal
     penalty terms; zeros otherwise).  Parameter order: density planes 0..2, density lines 0..2, app planes, app lines, basis, W1, b1, W2, b2, W3, b3
     (+ normal W b, diffuse W b, specular W b, rho W b)."""
 
@@ -563,6 +572,13 @@ class _FusedStepFn(torch.autograd.Function):
                                       B["scratch"].data_ptr(), B["scratch"].numel(), B["work"].data_ptr(), B["work"].numel(), B["cap"], rgb_map.data_ptr(),
                                       depth.data_ptr(), pen.data_ptr() if ref else None, _stream_ptr(model.device)), "tvr_train_forward")
         ctx.model, ctx.rays, ctx.jitter, ctx.S, ctx.eps_T, ctx.white_bg, ctx.buf, ctx.ref = model, rays, jitter, S, eps_T, white_bg, B, ref
+        # The saved state of this step (the march queue, h / h1 / h2 / features / pre-clamp pixels) lives in the model's ONE workspace: a second fused forward
+        # before this one's backward would overwrite it.  Each forward takes a generation number; the backward refuses a workspace that has moved on, and
+        # the dispatchers (field.render_rays_autograd, variants.REFTensoRF) send a forward that arrives while another is outstanding down the eager chain,
+        # whose Functions own their tensors.  `pending` is a weak reference to a token this graph node holds: a graph that was dropped is not outstanding.
+        B["gen"] = B.get("gen", 0) + 1
+        ctx.gen, ctx.token = B["gen"], _StepToken()
+        B["pending"] = weakref.ref(ctx.token)
         ctx.shapes = [p.shape for p in params]
         ctx.save_for_backward(*params[12:])                 # the network parameters: their CURRENT values are packed by the backward call
         ctx.mark_non_differentiable(depth)
@@ -571,6 +587,11 @@ class _FusedStepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_map, _gd, g_pen):
         model, lib, B = ctx.model, L.lib(), ctx.buf
+        if B.get("gen") != ctx.gen:
+            raise RuntimeError("the fused training step's workspace was overwritten by a later forward before this backward ran (gradient accumulation over two "
+                               "batches, or two renders in one loss): its saved activations are gone.  Use model.static_training = False for such loops, or call "
+                               "backward() before the next forward — render_rays_autograd() does the former by itself when it can see the outstanding forward")
+        B["pending"] = None
         sc = model._ensure_scene()
         net = [t.detach().contiguous().float() for t in ctx.saved_tensors]
         dev, n = model.device, ctx.rays.shape[0]

@@ -160,6 +160,7 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
     v.thres = desc->weight_thres;
     v.act = desc->fea2dense_act;
     v.variant = desc->variant;
+    v.range_check = 1;
     v.avol = nullptr;
     *out = s;
     return TVR_OK;
@@ -232,6 +233,13 @@ int tvr_scene_set_alpha(tvr_scene *s, const float *vol, const int32_t ag[3], con
         HIP_TRY(launch_alpha_bits(vol, (long long)ag[0] * ag[1] * ag[2], (unsigned *)bits, (hipStream_t)stream));
         s->dev.abits = (const unsigned *)bits;
     }
+    return TVR_OK;
+}
+
+int tvr_scene_set_range_check(tvr_scene *s, int32_t on)
+{
+    if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_set_range_check: scene is NULL");
+    s->dev.range_check = on ? 1 : 0;
     return TVR_OK;
 }
 
@@ -454,7 +462,7 @@ static TrainGrads carve_grads(const tvr_scene *s, char *g)
 
 static int march_backward_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const MarchSampling &sm, float eps_T, const void *fwd_scratch,
                                size_t fwd_scratch_bytes, const float *grad_w, const float *grad_acc, const float *lam6, const float *grad_lam6,
-                               void *grad_scratch, size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream_)
+                               void *grad_scratch, size_t grad_scratch_bytes, const tvr_vm_grads *out, void *stream_, long long gw_cap = -1)
 {
     int rc = scene_ready(s);
     if (rc != TVR_OK) return rc;
@@ -472,7 +480,7 @@ static int march_backward_impl(tvr_scene *s, const float *rays, int64_t n_rays, 
         HIP_TRY(launch_zero_f32(tg.dline[i], (long long)((Ln + 1) * TVR_CD), stream));
     }
     MarchOut mo = carve_scratch((char *)fwd_scratch, L, nullptr);
-    HIP_TRY(launch_march_backward(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, grad_w, grad_acc, lam6, grad_lam6, tg, stream));
+    HIP_TRY(launch_march_backward(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, grad_w, grad_acc, lam6, grad_lam6, tg, stream, gw_cap));
     for (int i = 0; i < 3; ++i) {
         if (!out->density_plane[i] || !out->density_line[i]) return fail(TVR_ERR_INVALID, "density gradient pointer %d is NULL", i);
         const int W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
@@ -789,7 +797,7 @@ int tvr_train_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     if (rc != TVR_OK) return rc;
     const MarchSampling sm = {jitter, nullptr};
     return march_backward_impl(s, rays, n_rays, S, sm, eps_T, fwd_scratch, fwd_bytes, F(W.grad_w), F(W.grad_acc), nullptr, nullptr, grad_scratch, grad_scratch_bytes, vm_out,
-                               stream_);
+                               stream_, app_cap);
 }
 
 int tvr_app_h_backward(tvr_scene *s, const float *xyz, int64_t m, const float *dh, size_t dh_bytes, void *grad_scratch, size_t grad_scratch_bytes,

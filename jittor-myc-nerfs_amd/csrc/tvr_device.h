@@ -67,6 +67,7 @@ struct SceneDev {
     float near_, far_, step, shift, scale, thres;
     int act;
     int variant;                  // 0 TensorVMSplit, 1 REFTensoRF
+    int range_check;              // 1 (default): the inference shade kernels mark entries whose fp16-split operands leave fp16's range with NaN (tvr_scene_set_range_check)
     const float *avol;            // (gz,gy,gx) or nullptr
     const unsigned *abits;        // optional: bit ((z*gy + y)*gx + x) = (avol > 0), built by tvr_scene_set_alpha
     int ag[3];
@@ -199,6 +200,10 @@ __device__ __forceinline__ float ray_tmin(const SceneDev &sc, const float o[3], 
     }
     return t < sc.near_ ? sc.near_ : (t > sc.far_ ? sc.far_ : t);
 }
+
+// clamp(x, 0, 1) of tensorBase.py:527 with the reference framework's NaN behaviour: a NaN stays a NaN (fminf / fmaxf return the OTHER operand and would turn a
+// NaN sample — the shade kernel's "an operand left fp16's range" mark — into a valid-looking 0)
+__device__ __forceinline__ float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 

@@ -74,7 +74,7 @@ hipError_t launch_pack_mlp(const float *W, const float *bias, void *out_hi, void
 hipError_t launch_pack_ref(const float *const W[4], const float *const b[4], void *rows, float *bias, hipStream_t stream);
 hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T, const MarchOut &mo,
                                  const float *grad_w, const float *grad_acc, const float *lam6, const float *grad_lam6, const TrainGrads &tg,
-                                 hipStream_t stream);
+                                 hipStream_t stream, long long gw_cap = -1);    // gw_cap >= 0: grad_w holds gw_cap entries; a step whose queue is longer (or faulted) scatters nothing
 // xyz_stride: 3 (xyz [m,3]) or 4 (the march queue's {xyz, w}); m_dev: optional device-side entry count, m is then the capacity (min of the two is processed)
 hipError_t launch_app_h_forward(const SceneDev &sc, const float *xyz, long long m, float *h, hipStream_t stream, int xyz_stride = 3, const unsigned *m_dev = nullptr);
 hipError_t launch_app_h_backward(const SceneDev &sc, const float *xyz, long long m, const float *dh, const TrainGrads &tg, hipStream_t stream, int xyz_stride = 3,

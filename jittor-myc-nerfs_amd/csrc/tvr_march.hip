@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
         if (lane == 0) ci = atomicAdd(cursor, 1u);
         ci = __builtin_amdgcn_readfirstlane(ci);
 #if TVR_MARCH_DYN
-        // the wave that draws the first ray of local tile k takes the next global tile and publishes it {k + 1, tile} in slot k & 31; the others
+        // the wave that draws the first ray of local tile k takes the next global tile and publishes it {k + 1, tile} in slot k & (MARCH_SLOTS - 1); the others
         // wait for the slot's generation to become k + 1.  Why the wait ends: the publisher stores right behind its draw (one global atomic,
         // ~2 us), and the slot is only overwritten by the publisher of local tile k + 64, which needs the group's cursor to advance by 1024 draws
         // and 64 later publishers to have finished their own global atomic first.  The wait is nevertheless BOUNDED and a miss is LOUD:
@@ -500,9 +500,9 @@ __global__ __launch_bounds__(256) void composite_kernel(const MarchOut mo, const
         const float bg = 1.0f - acc;
         c0 = c0 + bg; c1 = c1 + bg; c2 = c2 + bg;
     }
-    rgb_out[(size_t)r * 3 + 0] = fminf(fmaxf(c0, 0.f), 1.f);
-    rgb_out[(size_t)r * 3 + 1] = fminf(fmaxf(c1, 0.f), 1.f);
-    rgb_out[(size_t)r * 3 + 2] = fminf(fmaxf(c2, 0.f), 1.f);
+    rgb_out[(size_t)r * 3 + 0] = clamp01(c0);
+    rgb_out[(size_t)r * 3 + 1] = clamp01(c1);
+    rgb_out[(size_t)r * 3 + 2] = clamp01(c2);
 }
 
 // additional_output: scatter per-entry rgb back to the dense [n,S,3] array

@@ -46,6 +46,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define TVR_PIN8(v) asm volatile("" : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]), "+v"((v)[4]), "+v"((v)[5]), "+v"((v)[6]), "+v"((v)[7]))
 #define TVR_GATHER_KEEP(s_)                                                                            \
     do {                                                                                               \
+        if (RC) { _Pragma("unroll") for (int j_ = 0; j_ < 8; j_ += 2) rmax = absmax2(hvv[s_][j_], hvv[s_][j_ + 1], rmax); asm volatile("" : "+v"(rmax)); } \
         if (!TVR_SPLIT_LATE || !TVR_SCHED || (s_) == 0) { hf[s_] = split8(hvv[s_]); TVR_PIN_FRAG(hf[s_]); } \
         else TVR_PIN8(hvv[s_]);                                                                        \
     } while (0)
@@ -335,18 +336,21 @@ __device__ __forceinline__ void sincos_pe(float x, float &s, float &c)
     c = __builtin_amdgcn_cosf(t);
 }
 
+#define TVR_F16_MAX 65504.0f
+__device__ __forceinline__ float absmax2(float a, float b, float m) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), m); }      // one v_max3_f32 |a|, |b|, m
 // what a tile hands from its matrix phase to finish_tile (layer 3 + epilogue)
 struct Carry {
     f32x16 acc2[4];              // layer-2 accumulators (b2 included), hidden unit 32 rb + acc_row(r, h) in acc2[rb][r]
     long long ent;
     float wq;
     float g[4];                  // REFTensoRF: specular tint and rgb_d
+    float rmax;                  // RC: max |x| over this lane's share of the entry's fp16-split operands
     bool live;
 };
 
 // layer 3 (tensorBase.py:83-84: Linear(128 -> 3) on relu(h2), sigmoid) as fp32 FMAs: W3 [3][128] fp32 and b3 sit in the LDS image.
 // Lane (e, h) holds 64 of entry e's 128 hidden units; the two halves are added through the LDS crossbar.  Fixed summation order.
-template <int DST, bool REF, bool HAVE_G>
+template <int DST, bool REF, bool HAVE_G, bool RC>
 __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char *smem, const ShadeArgs &a, int h)
 {
     f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
@@ -390,6 +394,10 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
     if (REF && HAVE_G) {                                         // REFTensoRF.py:232  specular_tint * clamp(rgb_s, 0) + rgb_d
         const float tint = fmaxf(c.g[0], 0.0f);
         r0 = tint * fmaxf(r0, 0.0f) + c.g[1]; r1 = tint * fmaxf(r1, 0.0f) + c.g[2]; r2 = tint * fmaxf(r2, 0.0f) + c.g[3];
+    }
+    if (RC) {                                                    // an operand of this entry left fp16's range: the colour is NaN, not a clipped product
+        const float m = fmaxf(c.rmax, __shfl_xor(c.rmax, 32));
+        if (!(m < TVR_F16_MAX)) r0 = r1 = r2 = __builtin_nanf("");
     }
     if (c.live && h == 0) {
         if (DST == SH_DST_QUEUE) {
@@ -535,7 +543,12 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
     } while (0)
 #endif
 
-template <int SRC, int DST, bool REF>
+// RC (range check, tvr_scene_set_range_check; default ON for the inference entry points): every value that enters an MFMA through the fp16 hi / lo split — the
+// interpolated appearance features, the basis outputs and the layer-1 inputs made of them, relu(layer 1) — feeds a running max|x| (one v_max3_f32 per two
+// values, +4 % VALU); an entry whose maximum reaches fp16's largest finite value (cvt_pkrtz saturates there, silently) gets NaN as its colour / features, so the
+// pixel it belongs to comes out NaN instead of wrong.  Weights are checked by the host (field.py::_fp16_range_proven), which also switches RC off for scenes
+// whose interval bounds prove that nothing can leave the range.
+template <int SRC, int DST, bool REF, bool RC = false>
 __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -617,6 +630,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         float F[16];                               // base values: row c = acc_row(r, h) of the feature tile, column = entry
         float dir[3] = {0.f, 0.f, 0.f}, wq = 0.f, dotin = 0.f;
         float G[8];                                // REF: rows acc_row(r, h) of the second block (h=0: normal, tint, rgb_d, rho; h=1: normal)
+        float rmax = 0.0f;                         // RC: running max |x| of this lane's fp16-split operands
 #pragma unroll
         for (int r = 0; r < 8; ++r) G[r] = 0.f;
 #if TVR_TIMING
@@ -740,6 +754,13 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 
         if (DST == SH_DST_FEAT) {
             TVR_LEAVE_MATRIX();
+            if (RC) {                                  // (the features are fp32 outputs; what is checked is what went IN: the interpolated h)
+                const float m = fmaxf(rmax, __shfl_xor(rmax, 32));
+                if (!(m < TVR_F16_MAX)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) F[r] = __builtin_nanf("");
+                }
+            }
             if (live) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -776,6 +797,11 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         }
         if (h == 0) F[15] = dir[0];
         else { F[12] = dir[1]; F[13] = dir[2]; F[14] = dotin; F[15] = 1.0f; }
+        if (RC) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) rmax = absmax2(F[r], F[r + 1], rmax);
+            asm volatile("" : "+v"(rmax));             // (pure arithmetic: without a pin hipcc sinks the whole max chain, and the values it reads, to the tile's end)
+        }
         if (DST == SH_DST_TRAIN && REF && live) {
             // REFTensoRF training forward: the 31 base values of layer 1 — 27 features, the reflection direction (rows 27..29) and -dot (row 30),
             // both functions of h through the normal head — are what the backward differentiates through; row 31 (the constant) is stored as 0.
@@ -819,6 +845,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = relu_f(acc[s >> 1][8 * (s & 1) + j]);
+                if (RC) { _Pragma("unroll") for (int j = 0; j < 8; j += 2) rmax = fmaxf(fmaxf(v[j], v[j + 1]), rmax); asm volatile("" : "+v"(rmax)); }
                 if (DST == SH_DST_TRAIN && live) {   // relu(layer 1): element j is hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3)
                     *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
                     *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 8 + 4 * h) = make_float4(v[4], v[5], v[6], v[7]);
@@ -944,6 +971,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = relu_f(acc[s >> 1][8 * (s & 1) + j]);
+                if (RC) { _Pragma("unroll") for (int j = 0; j < 8; j += 2) rmax = fmaxf(fmaxf(v[j], v[j + 1]), rmax); asm volatile("" : "+v"(rmax)); }
                 if (DST == SH_DST_TRAIN && live) {   // relu(layer 1): element j is hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3)
                     *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
                     *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 8 + 4 * h) = make_float4(v[4], v[5], v[6], v[7]);
@@ -976,7 +1004,8 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         // layer 3 + store run at the LOWEST priority: their 320 VALU ops need no particular moment, the partner's matrix phase needs every issue slot it
         // can get (12.66 vs 12.75 ms against running them at the gather's priority, two interleaved rounds; priorities 1 and 3: 12.73 / 12.75)
         __builtin_amdgcn_s_setprio(TVR_PRIO_F);
-        finish_tile<DST, REF, HAVE_G>(cur, smem, a, h);
+        cur.rmax = rmax;
+        finish_tile<DST, REF, HAVE_G, RC>(cur, smem, a, h);
         __builtin_amdgcn_s_setprio(TVR_PRIO_G);
         TVR_STAMP(tg4);
 #if TVR_TIMING
@@ -995,14 +1024,14 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
 }
 
-template <int SRC, int DST, bool REF>
+template <int SRC, int DST, bool REF, bool RC>
 static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
     constexpr bool BAS_ONLY = DST == SH_DST_FEAT && !REF;
     constexpr int NLO = REF ? 0 : (BAS_ONLY ? 9 : TVR_NLO_LDS);
     const int lds = (REF ? TVR_MLP_IMAGE_BYTES_REF : (BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : TVR_MLP_IMAGE_BYTES)) + 16 + NLO * 2 * TVR_IMG_BASH_ROWS * 16;
     static_assert((REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES) + 16 + (REF ? 0 : TVR_NLO_LDS) * 2 * TVR_IMG_BASH_ROWS * 16 <= 160 * 1024, "LDS image + tokens + basis lo parts must fit 160 KB");
-    hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
     unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
 #ifdef TVR_EXP_GRID                                             // scripts/overlap_experiment.py only: a build_variant.sh -DTVR_EXP_GRID library
@@ -1012,24 +1041,24 @@ static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStre
         const long long groups = (a.n + SH_TILE * SH_WAVES - 1) / (SH_TILE * SH_WAVES);
         if (groups < grid) grid = (unsigned)(groups > 0 ? groups : 1);
     }
-    hipLaunchKernelGGL((shade_kernel<SRC, DST, REF>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
+    hipLaunchKernelGGL((shade_kernel<SRC, DST, REF, RC>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
     return hipGetLastError();
+}
+
+template <bool REF>
+static hipError_t launch_shade_v(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream)
+{
+    const bool rc = sc.range_check != 0;        // the inference entry points; the training forward has its own saturation flag (tvr_mlp_train.hip)
+    if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, REF, false>(sc, a, stream);
+    if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return rc ? launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, false>(sc, a, stream);
+    if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, REF, false>(sc, a, stream);
+    if (src == SH_SRC_H && dst == SH_DST_TRAIN) return launch_shade_t<SH_SRC_H, SH_DST_TRAIN, REF, false>(sc, a, stream);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream)
 {
-    if (sc.variant == 1) {
-        if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, true>(sc, a, stream);
-        if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, true>(sc, a, stream);
-        if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, true>(sc, a, stream);
-        if (src == SH_SRC_H && dst == SH_DST_TRAIN) return launch_shade_t<SH_SRC_H, SH_DST_TRAIN, true>(sc, a, stream);
-        return hipErrorInvalidValue;
-    }
-    if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false>(sc, a, stream);
-    if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, false>(sc, a, stream);
-    if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false>(sc, a, stream);
-    if (src == SH_SRC_H && dst == SH_DST_TRAIN) return launch_shade_t<SH_SRC_H, SH_DST_TRAIN, false>(sc, a, stream);
-    return hipErrorInvalidValue;
+    return sc.variant == 1 ? launch_shade_v<true>(sc, src, dst, a, stream) : launch_shade_v<false>(sc, src, dst, a, stream);
 }
 
 // ---- scene packing (reference layout -> channels-last, zero-padded) ----

@@ -44,14 +44,24 @@ __global__ __launch_bounds__(256) void composite_train_forward_kernel(const Marc
     }
     if (over) atomicOr(mo.counter + 3, 1u);
     if (!live || l != 0) return;
+    // A VOID step is loud on the device (round 4): the appearance queue outgrew the workspace (counter[0] > cap: entries beyond it were never shaded) or
+    // the march raised its fault flag.  Every pixel of the batch — not only the rays that hit the cap — is NaN, so the loss is NaN for whoever reads it; the
+    // backward (composite_train_backward, march_backward) writes exact zeros, so an optimizer that does not consult model.training_fault_flag() moves nothing.
+    if ((long long)*mo.counter > cap || mo.counter[2] != 0u) {
+        const float q = __builtin_nanf("");
+        pre[(size_t)r * 3] = q; pre[(size_t)r * 3 + 1] = q; pre[(size_t)r * 3 + 2] = q;
+        rgb_map[(size_t)r * 3] = q; rgb_map[(size_t)r * 3 + 1] = q; rgb_map[(size_t)r * 3 + 2] = q;
+        if (with_pen) pen_ray[r] = q;
+        return;
+    }
     if (white_bg) {
         const float bg = 1.0f - mo.acc[r];
         c0 = c0 + bg; c1 = c1 + bg; c2 = c2 + bg;
     }
     pre[(size_t)r * 3] = c0; pre[(size_t)r * 3 + 1] = c1; pre[(size_t)r * 3 + 2] = c2;
-    rgb_map[(size_t)r * 3] = fminf(fmaxf(c0, 0.f), 1.f);
-    rgb_map[(size_t)r * 3 + 1] = fminf(fmaxf(c1, 0.f), 1.f);
-    rgb_map[(size_t)r * 3 + 2] = fminf(fmaxf(c2, 0.f), 1.f);
+    rgb_map[(size_t)r * 3] = clamp01(c0);
+    rgb_map[(size_t)r * 3 + 1] = clamp01(c1);
+    rgb_map[(size_t)r * 3 + 2] = clamp01(c2);
     if (with_pen) pen_ray[r] = pn;
 }
 
@@ -65,7 +75,14 @@ __global__ __launch_bounds__(256) void composite_train_backward_kernel(const Mar
     const long long mq = (long long)*mo.counter, m = mq < cap ? mq : cap;
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float v = 0.0f;
-    if (e < m) {
+    const bool void_step = mq > cap || mo.counter[2] != 0u;       // (see composite_train_forward_kernel): the incoming gradients are NaN, the outgoing ones exact zeros
+    if (void_step) {
+        if (e < cap) {
+            grgb[e * 3] = 0.0f; grgb[e * 3 + 1] = 0.0f; grgb[e * 3 + 2] = 0.0f;
+            grad_w[e] = 0.0f;
+            if (g8) gin0[e] = 0.0f;
+        }
+    } else if (e < m) {
         const unsigned r = mo.q_ray[e];
         float gm[3];
 #pragma unroll
@@ -100,7 +117,7 @@ __global__ __launch_bounds__(256) void composite_train_backward_rays_kernel(cons
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
     float s = 0.0f;
-    if (white_bg) {
+    if (white_bg) {                                            // (a void step left NaN in `pre`: both comparisons fail, the gradient is zero)
         float gm[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

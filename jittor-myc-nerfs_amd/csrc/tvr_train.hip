@@ -288,8 +288,11 @@ __global__ __launch_bounds__(TB_THREADS) void march_backward_kernel(const SceneD
                                                                     const MarchSampling sm, const float eps_T, const int rays_per_block,
                                                                     const MarchOut mo, const float *__restrict__ grad_w,
                                                                     const float *__restrict__ grad_acc, const float *__restrict__ lam6,
-                                                                    const float *__restrict__ grad_lam6, TrainGrads tg)
+                                                                    const float *__restrict__ grad_lam6, TrainGrads tg, const long long gw_cap)
 {
+    // fused training step (gw_cap = the capacity of grad_w): a step whose appearance queue outgrew the workspace, or whose march raised its fault flag, is VOID —
+    // its loss is NaN (composite_train_forward) and every gradient is exactly zero; grad_w holds nothing beyond gw_cap, so nothing is read at all
+    if (gw_cap >= 0 && ((long long)*mo.counter > gw_cap || mo.counter[2] != 0u)) return;
     // LDS: [per-wave stage: 3 planes x 16 samples x 16 channels of Q][line 0 | line 1 | line 2 gradient accumulators, (L+1) x 16 each]
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int lane = threadIdx.x & 63;
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(const float *__restric
 
 hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_rays, int S, const MarchSampling &sm, float eps_T, const MarchOut &mo,
                                  const float *grad_w, const float *grad_acc, const float *lam6, const float *grad_lam6, const TrainGrads &tg,
-                                 hipStream_t stream)
+                                 hipStream_t stream, long long gw_cap)
 {
     const int rpb = TB_WAVES;
     const size_t stage = (size_t)TB_WAVES * TB_STAGE * sizeof(float);
@@ -615,10 +618,10 @@ hipError_t launch_march_backward(const SceneDev &sc, const float *rays, int n_ra
         hipError_t rc = hipFuncSetAttribute((const void *)march_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (rc != hipSuccess) return rc;
         hipLaunchKernelGGL(march_backward_kernel<true>, dim3(grid), dim3(TB_THREADS), lds, stream, sc, rays, n_rays, S, sm, eps_T, rpb, mo,
-                           grad_w, grad_acc, lam6, grad_lam6, tg);
+                           grad_w, grad_acc, lam6, grad_lam6, tg, gw_cap);
     } else {
         hipLaunchKernelGGL(march_backward_kernel<false>, dim3(grid), dim3(TB_THREADS), stage, stream, sc, rays, n_rays, S, sm, eps_T, rpb, mo,
-                           grad_w, grad_acc, lam6, grad_lam6, tg);
+                           grad_w, grad_acc, lam6, grad_lam6, tg, gw_cap);
     }
     return hipGetLastError();
 }

@@ -147,6 +147,9 @@ def render_test(args, device="cuda"):
     return out
 
 
+FAULT_POLL_EVERY = 16        # iterations between two reads of the training-fault accumulator (field.check_training_faults)
+
+
 def reconstruction(args, device="cuda", log=print, train_dataset=None, val_dataset=None):
     """train.py:113-371.  Returns (tensorf, logfolder, PSNRs_test of the last visualisation or final test).
     `train_dataset` / `val_dataset`: ready-made datasets (objects with all_rays, all_rgbs, scene_bbox, white_bg, near_far as BlenderRays has them) instead of the
@@ -258,12 +261,14 @@ def reconstruction(args, device="cuda", log=print, train_dataset=None, val_datas
         loss_hist.append(loss.detach())
         for pg in optimizer.param_groups:
             pg["lr"] = pg["lr"] * lr_factor
+        # the fault accumulator is polled on its own short cadence, not at the log rate: every step between a first fault and the adjustment of capacity / scale
+        # is dropped on the device while the learning-rate decay keeps running (one host read per FAULT_POLL_EVERY steps: <= 0.1 ms per step)
+        if fused_adam and (iteration % FAULT_POLL_EVERY == 0 or iteration % args.progress_refresh_rate == 0):
+            fault = tensorf.check_training_faults()
+            if fault is not None:                      # the flagged steps were skipped on the device; capacity / scale are adjusted now
+                log(f"Iteration {iteration:05d}: training step(s) dropped since the last poll ({fault}); samples per ray "
+                    f"{tensorf.train_app_samples_per_ray}, scale {tensorf.grad_scale_target:g}")
         if iteration % args.progress_refresh_rate == 0:
-            if fused_adam:
-                fault = tensorf.check_training_faults()
-                if fault is not None:                  # the flagged steps were skipped on the device; capacity / scale are adjusted now
-                    log(f"Iteration {iteration:05d}: training step(s) dropped since the last line ({fault}); samples per ray "
-                        f"{tensorf.train_app_samples_per_ray}, scale {tensorf.grad_scale_target:g}")
             hist = torch.stack(loss_hist)
             PSNRs = (-10.0 * torch.log10(hist)).tolist()
             log(f"Iteration {iteration:05d}: train_psnr = {float(np.mean(PSNRs)):.2f} test_psnr = {float(np.mean(PSNRs_test)):.2f} mse = {float(hist[-1]):.6f}")

@@ -123,7 +123,7 @@ class REFTensoRF(TensorVMSplit):
         rays = _f32c(rays_chunk, self.device)
         S = int(N_samples) if N_samples > 0 else self.nSamples
         eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
-        if self._fused_step_ok():                             # two C-ABI calls, no host read, fixed launch sequence (autograd_ops._FusedStepFn)
+        if self._fused_step_ok() and not self._fused_step_outstanding():   # two C-ABI calls, no host read, fixed launch sequence (autograd_ops._FusedStepFn)
             mlp = self.renderModule.mlp
             rgb_map, depth, pen_ray = _FusedStepFn.apply(
                 self, rays, jitter, S, eps_T, white_bg, *self.density_plane, *self.density_line, *self.app_plane, *self.app_line, self.basis_mat.weight,
@@ -308,6 +308,7 @@ class NerfPlusPlus(TensorVMSplit):
 
     def _render_z(self, rays, z_vals, S, eps_T):
         sc, lib = self._ensure_scene(), L.lib()
+        self._settle_range_check()
         n = rays.shape[0]
         rgb = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         depth = torch.empty((n,), dtype=torch.float32, device=self.device)

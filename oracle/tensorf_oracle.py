@@ -45,7 +45,7 @@ class OracleScene:
     def __init__(self, aabb, gridSize, density_plane, density_line, app_plane, app_line,
                  basis_mat, mlp, near_far=(2.0, 6.0), step_ratio=0.5, density_shift=-10.0,
                  distance_scale=25.0, rayMarch_weight_thres=1e-4, fea2denseAct="softplus",
-                 view_pe=2, fea_pe=2, alpha_volume=None, alpha_aabb=None, ref=None, npp=None):
+                 view_pe=2, fea_pe=2, alpha_volume=None, alpha_aabb=None, ref=None, npp=None, jittor_semantics=False):
         self.aabb = _t(aabb).reshape(2, 3)
         self.gridSize = [int(g) for g in gridSize]
         self.density_plane = [_t(p) for p in density_plane]
@@ -55,6 +55,8 @@ class OracleScene:
         self.basis_mat = _t(basis_mat)                      # [app_dim, sum(app_n_comp)]
         self.mlp = {k: _t(v) for k, v in mlp.items()}       # W1,b1,W2,b2,W3,b3 (Linear: y = x W^T + b)
         self.near_far = (float(near_far[0]), float(near_far[1]))
+        # True: raw2alpha / softplus in the formulations Jittor is believed to use instead of torch's — a MODEL of the unverifiable part
+        self.jittor_semantics = bool(jittor_semantics)
         self.step_ratio = float(step_ratio)
         self.density_shift = float(density_shift)
         self.distance_scale = float(distance_scale)
@@ -93,11 +95,22 @@ def positional_encoding(positions, freqs):
 
 
 # tensorf-myc/models/tensorBase.py:17-24
-def raw2alpha(sigma, dist):
+def raw2alpha(sigma, dist, jittor_semantics=False):
     alpha = 1.0 - torch.exp(-sigma * dist)
-    T = torch.cumprod(torch.cat([torch.ones(alpha.shape[0], 1), 1.0 - alpha + 1e-10], -1), -1)
+    t = torch.cat([torch.ones(alpha.shape[0], 1), 1.0 - alpha + 1e-10], -1)
+    if jittor_semantics:
+        # Jittor 1.3.x is believed to evaluate jt.cumprod as exp(cumsum(log(x))) — not verifiable offline; this branch MODELS that
+        # formulation so that a test can bound what it would move (tests/test_oracle.py::test_jittor_formulations_stay_inside_the_parity_bar)
+        T = torch.exp(torch.cumsum(torch.log(t), -1))
+    else:
+        T = torch.cumprod(t, -1)
     weights = alpha * T[:, :-1]
     return alpha, weights, T[:, -1:]
+
+
+def softplus_jittor(x, beta=1.0, threshold=20.0):
+    """jt.nn.softplus is believed to be  log(1 + exp(min(beta x, threshold))) / beta + max(x - threshold / beta, 0)  — no log1p, no branch."""
+    return torch.log(1.0 + torch.exp(torch.clamp(beta * x, max=threshold))) / beta + torch.clamp(x - threshold / beta, min=0.0)
 
 
 # tensorf-myc/models/tensorBase.py:223-224
@@ -169,6 +182,8 @@ def compute_appfeature(sc: OracleScene, xyz, return_h=False):
 # tensorf-myc/models/tensorBase.py:444-448
 def feature2density(sc: OracleScene, x):
     if sc.fea2denseAct == "softplus":
+        if getattr(sc, "jittor_semantics", False):
+            return softplus_jittor(x + sc.density_shift)
         return F.softplus(x + sc.density_shift)
     return F.relu(x)
 
@@ -270,7 +285,7 @@ def execute(sc: OracleScene, rays_chunk, white_bg=True, N_samples=-1, jitter=Non
         sigma[ray_valid] = feature2density(sc, sf)
         sigma_feature_full[ray_valid] = sf
 
-    alpha, weight, bg_weight = raw2alpha(sigma, dists * sc.distance_scale)
+    alpha, weight, bg_weight = raw2alpha(sigma, dists * sc.distance_scale, getattr(sc, "jittor_semantics", False))
     app_mask = weight > sc.thres
     if app_mask.any():
         if sc.ref is not None:
@@ -473,6 +488,28 @@ def updateAlphaMask(sc: OracleScene, gridSize, alphaMask_thres):
     alpha = (alpha >= alphaMask_thres).float()
     valid_xyz = dense_xyz[alpha > 0.5]
     return alpha, torch.stack((valid_xyz.amin(0), valid_xyz.amax(0)))
+
+
+# tensorf-myc/models/tensorBase.py:411-441 — the mask filtering_rays applies (True = the ray is kept); both filters, chunked as the reference chunks
+def filtering_rays_mask(sc: OracleScene, all_rays, N_samples=256, chunk=10240 * 5, bbox_only=False):
+    all_rays = _t(all_rays)
+    flat = all_rays.reshape(-1, all_rays.shape[-1])
+    masks = []
+    for idx_chunk in torch.split(torch.arange(flat.shape[0]), chunk):
+        rays_chunk = flat[idx_chunk]
+        rays_o, rays_d = rays_chunk[..., :3], rays_chunk[..., 3:6]
+        if bbox_only:
+            vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+            rate_a = (sc.aabb[1] - rays_o) / vec
+            rate_b = (sc.aabb[0] - rays_o) / vec
+            t_min = torch.minimum(rate_a, rate_b).max(-1).values          # no clamp to [near, far] here (:425-426)
+            t_max = torch.maximum(rate_a, rate_b).min(-1).values
+            mask_inbbox = t_max > t_min
+        else:
+            xyz_sampled, _, _, _ = sample_ray(sc, rays_o, rays_d, N_samples=N_samples)      # is_train=False: no jitter
+            mask_inbbox = (alpha_sample(sc, xyz_sampled.reshape(-1, 3)).view(xyz_sampled.shape[:-1]) > 0).any(-1)   # ALL samples, no bbox mask (:430-431)
+        masks.append(mask_inbbox)
+    return torch.cat(masks).view(all_rays.shape[:-1])
 
 
 def scene_from_arrays(arrs: Dict[str, np.ndarray], **hyper) -> OracleScene:

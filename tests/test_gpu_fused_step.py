@@ -112,19 +112,37 @@ def test_training_step_is_graph_capturable_and_replay_equals_eager(ref, tiny_dum
         gg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gg):
             lg = step()
-        return mm, gg, lg, l0
-    m2, g2, lg2, l0 = captured_step()
+        return mm, gg, lg, l0, opt
+    m2, g2, lg2, l0, opt2 = captured_step()
     for _ in range(8):
         g2.replay()
     torch.cuda.synchronize()
-    m3, g3, lg3, _ = captured_step()
+    m3, g3, lg3, _, opt3 = captured_step()
     for _ in range(8):
         g3.replay()
         torch.cuda.synchronize()
     a, b = float(lg2.detach()), float(lg3.detach())
     assert m2.check_training_faults() is None and m3.check_training_faults() is None
-    # (the parameters themselves are not compared: Adam's m / sqrt(v) turns the last-bit differences of gradients that are ~0 into lr-sized steps)
     assert a < 0.9 * l0 and abs(a - b) <= 1e-3 * abs(b), (l0, a, b)
+    # ... and the PARAMETERS moved alike wherever a gradient is actually there.  Adam's m / sqrt(v) turns the last-bit differences of a gradient that is ~0 into an
+    # lr-sized step of either sign, and a `weight > 1e-4` flip of one sample changes single texels by a fraction of a step, so the comparison is of the MOVEMENT
+    # vectors over the elements whose first moment is above 1 % of their tensor's largest: per tensor, ||d2 - d3|| <= 5 % of ||d2|| (measured 0.2 - 2 %).
+    # A real divergence of the VM factors (the round-3 memset-node fault moved them by whole steps) fails this; equal losses alone would not show it.
+    p0s = iter([p.detach().clone() for p in _params(make_model(arrs, hyper_tiny))])      # the same start: make_model is deterministic, the groups come in one order
+    checked = 0
+    for g2_, g3_ in zip(opt2.param_groups, opt3.param_groups):
+        for p2, p3 in zip(g2_["params"], g3_["params"]):
+            p0 = next(p0s)
+            assert p0.shape == p2.shape
+            m1a, m1b = opt2.state[p2]["exp_avg"], opt3.state[p3]["exp_avg"]
+            big = (m1a.abs() > 1e-2 * m1a.abs().max()) & (m1b.abs() > 1e-2 * m1b.abs().max())
+            if int(big.sum()) < 8:
+                continue
+            d2, d3 = (p2.detach() - p0)[big], (p3.detach() - p0)[big]
+            rel = float((d2 - d3).norm() / d2.norm())
+            assert rel <= 0.05, f"parameter {tuple(p2.shape)}: back-to-back and one-at-a-time replays moved {rel:.3f} of their own movement apart"
+            checked += int(big.sum())
+    assert checked > 1000, checked
 
 
 def test_static_step_is_reproducible_and_agrees_with_the_eager_chain(tiny_dump, tiny_arrays, hyper_tiny):
@@ -154,6 +172,10 @@ def test_workspace_overflow_is_flagged_not_truncated(tiny_dump, tiny_arrays, hyp
     rgb, _ = m.render_rays_autograd(rays, white_bg=True, N_samples=TINY["N_samples"])
     rgb.sum().backward()
     lay_cap = m._train_buf["cap"]
+    # the void step is loud ON THE DEVICE, for a loop that never polls the flags (INTEGRATION.md's plain `loss.backward(); optimizer.step()`): every pixel of the
+    # batch is NaN — so is any loss made of them — and every gradient it hands back is an exact zero, not a truncated queue's garbage
+    assert bool(torch.isnan(rgb).all())
+    assert all(p.grad is not None and bool((p.grad == 0).all()) for p in _params(m))
     assert m.check_training_faults() == "overflow" and m.train_app_samples_per_ray == 2 and m._train_buf is None
     m.train_app_samples_per_ray = 192
     rgb2, _ = m.render_rays_autograd(rays, white_bg=True, N_samples=TINY["N_samples"])
@@ -228,3 +250,44 @@ def test_fault_flag_guards_the_fused_optimizer_on_the_device(tiny_dump, tiny_arr
     assert flag == 0.0 and max(moved) > 0.0
     assert m.check_training_faults() == "overflow"                     # the accumulator remembers the skipped step
     assert m.check_training_faults() is None
+
+
+def test_a_second_forward_before_the_first_backward_keeps_both_gradients(tiny_dump, tiny_arrays, hyper_tiny):
+    """The fused step keeps its saved state in ONE workspace per model.  Two renders in one loss / gradient accumulation over two batches: the second
+    forward sees the first one outstanding and goes down the eager chain, so both backwards are right; a fused forward forced over an outstanding one is refused
+    in backward instead of differentiating the wrong activations; a dropped graph does not block the workspace."""
+    from jittor_myc_nerfs_amd.autograd_ops import _FusedStepFn
+    ra, rb = _batch(tiny_dump, 8), _batch(tiny_dump, 8).flip(0).contiguous()
+    S = TINY["N_samples"]
+
+    def one(m, r):
+        for p in _params(m):
+            p.grad = None
+        rgb, _ = m.render_rays_autograd(r, white_bg=True, N_samples=S)
+        rgb.square().sum().backward()
+        return [p.grad.clone() for p in _params(m)]
+    m = make_model(tiny_arrays, hyper_tiny)
+    ga, gb = one(m, ra), one(m, rb)
+    for p in _params(m):
+        p.grad = None
+    rgb_a, _ = m.render_rays_autograd(ra, white_bg=True, N_samples=S)
+    assert m._fused_step_outstanding()
+    rgb_b, _ = m.render_rays_autograd(rb, white_bg=True, N_samples=S)           # eager chain: the workspace still belongs to rgb_a's graph
+    (rgb_a.square().sum() + rgb_b.square().sum()).backward()
+    assert not m._fused_step_outstanding()
+    for p, x, y in zip(_params(m), ga, gb):
+        assert _close(p.grad, x + y), f"accumulated gradient of {tuple(p.shape)} differs from the sum of the two single-batch gradients"
+    # a dropped graph frees the workspace
+    tmp, _ = m.render_rays_autograd(ra, white_bg=True, N_samples=S)
+    assert m._fused_step_outstanding()
+    del tmp
+    assert not m._fused_step_outstanding()
+    # forcing the fused Function over an outstanding forward: the first backward is refused
+    mlp = m.renderModule.mlp
+    args = (m, ra, None, S, float(m.rayMarch_weight_thres), True, *m.density_plane, *m.density_line, *m.app_plane, *m.app_line, m.basis_mat.weight,
+            mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, mlp[4].weight, mlp[4].bias)
+    first = _FusedStepFn.apply(*args)[0]
+    second = _FusedStepFn.apply(*args)[0]
+    with pytest.raises(RuntimeError, match="overwritten by a later forward"):
+        first.sum().backward()
+    second.sum().backward()

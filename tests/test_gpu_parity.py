@@ -253,11 +253,17 @@ def test_full_size_properties_config2():
 
 
 def test_filter_rays_kernel_equals_the_reference_formulation(tiny_arrays, hyper_tiny, tiny_dump, tiny_edge):
-    """tvr_filter_rays (one pass per call) against filtering_rays in the reference's own torch formulation (tensorBase.py:411-441, restated op for op in
-    field._filtering_mask_torch): identical masks for both filters on 40 k perturbed rays — grazing rays, rays that miss the box, axis-parallel
-    rays with zero direction components, origins inside the box — with the inputs on the host and on the device; and the kept rays are the masked rays."""
+    """tvr_filter_rays (one pass per call) against the ORACLE's restatement of filtering_rays (tensorBase.py:411-441, oracle/tensorf_oracle.py::filtering_rays_mask;
+    the alpha volume it samples is the oracle's own updateAlphaMask, checked equal to the product's first): identical masks for both filters on 40 k perturbed rays —
+    grazing rays, rays that miss the box, axis-parallel rays with zero direction components, origins inside the box — with the inputs on the host and on the
+    device; and the kept rays are the masked rays."""
+    from oracle import tensorf_oracle as TO
     m = make_model(tiny_arrays, hyper_tiny)
     m.updateAlphaMask((9, 8, 7))
+    sc = TO.scene_from_arrays(tiny_arrays, **hyper_tiny)
+    vol, _ = TO.updateAlphaMask(sc, (9, 8, 7), m.alphaMask_thres)
+    assert torch.equal(vol, m.alphaMask.alpha_volume.cpu().view(vol.shape)), "the product's alpha volume differs from the oracle's: the filter test would compare two masks"
+    sc.alpha_volume, sc.alpha_aabb = vol, sc.aabb.clone()
     rng = np.random.default_rng(11)
     base = np.concatenate([tiny_dump["rays"], tiny_edge["rays"]]).astype(np.float32)
     rays = np.concatenate([base] * (40000 // base.shape[0] + 1))[:40000].copy()
@@ -266,11 +272,16 @@ def test_filter_rays_kernel_equals_the_reference_formulation(tiny_arrays, hyper_
     rays[::17, 3] = 0.0                                                        # zero direction components: the reference divides by 1e-6 instead
     rays[::29, 4:6] = 0.0
     rays[::31, :3] = 0.05 * rng.standard_normal((rays[::31].shape[0], 3)).astype(np.float32)       # origins inside the box
+    lo, hi = np.asarray(tiny_arrays["aabb"], np.float32)
+    graze = np.arange(7, rays.shape[0], 37)                                   # rays that graze the box: origin ON a face plane, direction inside that plane
+    rays[graze, 0] = hi[0]; rays[graze, 3] = 0.0
+    graze2 = np.arange(11, rays.shape[0], 41)                                 # ... and along an edge: two coordinates on faces, one free direction
+    rays[graze2, 1] = lo[1]; rays[graze2, 2] = hi[2]; rays[graze2, 4:6] = 0.0; rays[graze2, 3] = 1.0
     rays[-1] = [5, 5, 5, 0, 0, 1]
     host = torch.tensor(rays)
     rgbs = torch.arange(rays.shape[0], dtype=torch.float32).view(-1, 1).expand(-1, 3).contiguous()
     for bbox_only, S in ((True, 256), (False, 48), (False, 256)):
-        want = m._filtering_mask_torch(host, N_samples=S, bbox_only=bbox_only)
+        want = TO.filtering_rays_mask(sc, host, N_samples=S, bbox_only=bbox_only)
         assert 0 < int(want.sum()) < rays.shape[0]
         for src in (host, host.cuda()):
             kept, kept_rgb = m.filtering_rays(src, rgbs.to(src.device), N_samples=S, bbox_only=bbox_only)
@@ -432,3 +443,47 @@ def test_large_feature_magnitudes(tiny_dump, tiny_arrays, hyper_tiny, scale):
     e_m = np.abs(_np(rgb) - d["rgb_map"].numpy()).max()
     print(f"basis x{scale:g}: max |feature| {fmax:.0f}, per-sample rgb Linf {e_s:.2e}, rgb_map Linf {e_m:.2e}")
     assert e_m < RGB_TOL and e_s < RGB_TOL
+
+
+def test_fp16_range_is_proven_or_reported_never_clipped(tiny_dump, tiny_arrays, hyper_tiny):
+    """include/tvr.h: the appearance network's matrix products take their operands through fp16.  (1) A normal scene: the host's interval bounds prove the
+    range, the in-kernel check is switched off, and switching it on changes no bit.  (2) A scene whose appearance factors are scaled until the interpolated
+    features h reach ~1e6: the bounds fail, the check stays on, every pixel that shades such a sample comes out NaN (never a finite picture made of clipped
+    products), pixels that shade nothing are untouched; tvr_app_feature marks the same samples.  (3) "off" is the caller's vouching: finite, clipped, wrong."""
+    rays = torch.tensor(tiny_dump["rays"], device="cuda")
+    S = TINY["N_samples"]
+    m = make_model(tiny_arrays, hyper_tiny)
+    rep = m.fp16_range_report()
+    assert rep["proven"] and rep["layer2_inputs"] < 6e4, rep
+    rgb_auto, _ = m.render_rays(rays, white_bg=True, N_samples=S)
+    assert m._range_proven is True
+    m.fp16_range_check, m._range_proven = "on", None
+    rgb_on, _, d = m.render_rays(rays, white_bg=True, N_samples=S, dense=True)
+    assert m._range_proven is False and torch.equal(rgb_on, rgb_auto) and bool(torch.isfinite(rgb_on).all())
+
+    arrs = dict(tiny_arrays)
+    for i in range(3):
+        arrs[f"app_plane.{i}"] = tiny_arrays[f"app_plane.{i}"] * 2000.0
+        arrs[f"app_line.{i}"] = tiny_arrays[f"app_line.{i}"] * 2000.0
+    big = make_model(arrs, hyper_tiny)
+    rep = big.fp16_range_report()
+    assert not rep["proven"] and rep["h"] > 65504 and rep["weights"] < 6e4, rep
+    rgb_b, _, db = big.render_rays(rays, white_bg=True, N_samples=S, dense=True)
+    assert big._range_proven is False
+    shades = (db["weight"] > big.rayMarch_weight_thres).any(1)                  # the density field is the same: same shaded samples
+    assert bool(shades.any()) and not bool(shades.all())
+    nan_px = torch.isnan(rgb_b).any(1)
+    assert bool(nan_px.any()) and not bool((nan_px & ~shades).any()), "a pixel that shades no sample must not be touched"
+    assert torch.equal(rgb_b[~shades], rgb_auto[~shades])
+    # which samples: the ones whose interpolated h leaves the range — tvr_app_feature on the shaded positions marks the same set (its inputs are the same h)
+    xyz = m.normalize_coord(rays[:, None, :3] + rays[:, None, 3:6] * db["z"][..., None])
+    sel = db["weight"] > big.rayMarch_weight_thres
+    f_big = big.compute_appfeature(xyz[sel])
+    bad = torch.isnan(f_big).any(1)
+    assert bool(bad.any()) and bool((torch.isnan(f_big).all(1) == bad).all())
+    per_ray_bad = torch.zeros_like(sel, dtype=torch.bool)
+    per_ray_bad[sel] = bad
+    assert torch.equal(per_ray_bad.any(1), nan_px), "NaN pixels are exactly the pixels with an out-of-range sample"
+    big.fp16_range_check, big._range_proven = "off", None
+    rgb_off, _ = big.render_rays(rays, white_bg=True, N_samples=S)
+    assert bool(torch.isfinite(rgb_off).all())                                  # what "silently clipped" looked like: finite and wrong

@@ -26,9 +26,9 @@ def report():
 
 
 def test_every_shade_kernel_variant_is_audited(report):
-    # {queue, xyz->features, features->rgb, training forward (h -> rgb + activations)} x {TensorVMSplit, REFTensoRF} + the backward kernels
-    # (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps)
-    assert len(report) == 12, sorted(report)
+    # {queue, xyz->features, features->rgb} x {fp16 range check on, off} + the training forward (h -> rgb + activations), each x {TensorVMSplit, REFTensoRF},
+    # + the backward kernels (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps)
+    assert len(report) == 18, sorted(report)
     assert all(v["mfma"] >= 27 for v in report.values())
 
 
