@@ -8,5 +8,5 @@ from .variants import Embedder, MLPNet, MLPRender_Fea_Ref, NerfPlusPlus, REFTens
 from .render import OctreeRender_trilinear_fast, N_to_reso, cal_n_samples, render_sharded, shard_indices, shard_capacity, shard_gather_index, shard_send_views, shard_unpermute  # noqa: F401
 from .evaluation import BlenderRays, evaluation, evaluation_path, rgb_ssim, rgb_ssim_torch  # noqa: F401
 from .losses import TVLoss  # noqa: F401
-from .training import GradBucket, shard_batch  # noqa: F401
+from .training import GradBucket, make_graphed_step, shard_batch  # noqa: F401
 from . import ngp, rays, synthetic  # noqa: F401

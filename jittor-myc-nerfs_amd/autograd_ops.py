@@ -561,6 +561,17 @@ class _FusedStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, jitter, S, eps_T, white_bg, *params):
         lib = L.lib()
+        # Whole-step capture: the eager steps before it must have run on a side stream (training.make_graphed_step does that).  An eager step on the legacy
+        # default stream leaves autograd state there; capturing after it ends in a segmentation fault inside hipStreamEndCapture on this ROCm — say so in Python.
+        on_default = torch.cuda.current_stream(model.device).cuda_stream == 0
+        if torch.cuda.is_current_stream_capturing():
+            last = getattr(model, "_last_train_stream_default", None)
+            if last is None or last:
+                raise RuntimeError("hipGraph capture of a training step " + ("with no eager warm-up step before it" if last is None else "whose last eager step ran on the default stream")
+                                   + ": warm up on a side stream first — jittor_myc_nerfs_amd.make_graphed_step(step_fn) does it (the default stream's autograd state "
+                                   "crashes hipStreamEndCapture on this ROCm)")
+        else:
+            model._last_train_stream_default = on_default
         sc = model._ensure_scene(force=True)
         n = rays.shape[0]
         B = model._train_buffers(n, S)

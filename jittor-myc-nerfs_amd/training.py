@@ -71,3 +71,42 @@ def shard_batch(n: int, rank: int, world: int) -> slice:
     """Rank's contiguous share of an n-ray training batch (train.py draws the batch at random, so any fixed split is unbiased)."""
     per = (n + world - 1) // world
     return slice(min(rank * per, n), min((rank + 1) * per, n))
+
+
+def make_graphed_step(step_fn, device=None, warmup: int = 2):
+    """Capture one whole training step — forward, backward, optimizer — as a hipGraph, the safe way, and return a callable that replays it.
+
+        opt = torch.optim.Adam(tensorf.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99), capturable=True, foreach=True)
+        def step():                                   # static tensors in, a static loss tensor out
+            opt.zero_grad(set_to_none=False)
+            rgb, _ = tensorf.render_rays_autograd(rays, white_bg=True, N_samples=S, jitter=jitter)
+            loss = torch.mean((rgb - target) ** 2)
+            loss.backward(); opt.step()
+            return loss
+        replay = make_graphed_step(step)
+        for it in range(n): rays.copy_(...); target.copy_(...); jitter.uniform_(); loss = replay()
+
+    What this does that a bare `with torch.cuda.graph(g): step()` does not: the `warmup` eager steps run on a SIDE stream.  Autograd state created by an eager
+    step on the default stream (the parameters' AccumulateGrad nodes) makes the capture wait on the legacy default stream; on this ROCm that ends in a
+    segmentation fault inside hipStreamEndCapture (gpurun_out/r3k/fused.log).  The fused training forward refuses such a capture with a Python error instead
+    (autograd_ops._FusedStepFn); this helper is how to do it right.  Requirements are PyTorch's own: the step touches only static tensors, the optimizer is
+    `capturable=True`, nothing inside reads the host.  Returns `replay` with attributes `.graph` (the torch.cuda.CUDAGraph) and `.output` (step_fn's static result)."""
+    if warmup < 1:
+        raise ValueError("make_graphed_step needs at least one eager warm-up step (buffers, the packed scene and autograd state are created there)")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            step_fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step_fn()
+
+    def replay():
+        graph.replay()
+        return out
+    replay.graph, replay.output = graph, out
+    return replay

@@ -291,3 +291,49 @@ def test_a_second_forward_before_the_first_backward_keeps_both_gradients(tiny_du
     with pytest.raises(RuntimeError, match="overwritten by a later forward"):
         first.sum().backward()
     second.sum().backward()
+
+
+def test_make_graphed_step_and_the_capture_guard(tiny_dump, tiny_arrays, hyper_tiny):
+    """training.make_graphed_step captures the whole step after warming up on a side stream; its replays train like eager steps.  And the mistake that
+    used to kill the process (round 3: an eager step on the DEFAULT stream, then capture -> segmentation fault inside hipStreamEndCapture) is a Python
+    error now, raised by the fused forward before anything is captured."""
+    from jittor_myc_nerfs_amd import make_graphed_step
+    rays = _batch(tiny_dump, 8)
+    target = torch.rand((rays.shape[0], 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    jitter = torch.rand(rays.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+
+    def build():
+        mm = make_model(tiny_arrays, hyper_tiny)
+        opt = torch.optim.Adam(mm.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99), capturable=True, foreach=True)
+        return mm, opt, _step_fn(mm, rays, target, jitter, opt)
+    ma, _, step_a = build()
+    replay = make_graphed_step(step_a, warmup=2)
+    for _ in range(6):
+        la = replay()
+    torch.cuda.synchronize()
+    mb, _, step_b = build()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2 + 6):                           # the same number of optimizer steps: 2 warm-ups + 6 replays (capturing a step does not run it)
+            lb = step_b()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    a, b = float(la.detach()), float(lb.detach())
+    assert ma.check_training_faults() is None and mb.check_training_faults() is None
+    assert abs(a - b) <= 2e-3 * abs(b), (a, b)
+    assert isinstance(replay.graph, torch.cuda.CUDAGraph) and replay.output is la
+
+    mc, _, step_c = build()
+    step_c()                                             # eager, on the default stream: the state that crashes a capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="make_graphed_step"):
+        with torch.cuda.graph(g):
+            step_c()
+    torch.cuda.synchronize()
+    md, _, step_d = build()
+    with pytest.raises(RuntimeError, match="no eager warm-up"):
+        with torch.cuda.graph(torch.cuda.CUDAGraph()):
+            step_d()
+    torch.cuda.synchronize()
