@@ -38,7 +38,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 N_POSES = 8
-TILE = 4096
+TILE = 512         # rays per shard tile: round 4 (scripts/shard_balance.py): the slowest of 8 ranks carries 1.020 x the mean march work with 4096-ray tiles, 1.0045 x with 512
 SHADE_LOADS_PER_TILE = 114      # tvr_shade.hip, wave-level global loads per 32-entry tile as PMC counts them (SQ_INSTS_VMEM_RD, rounds 3 and 4): 108 taps + 3 basis fragments (lo parts of k-steps 6..8) + 3 entry / direction; fallback only, the live counter is used when the PMC pass ran
 
 
@@ -328,6 +328,7 @@ def _pmc_kernel(pmc, prefix):
 
 
 def main():
+    global TILE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -348,6 +349,12 @@ def main():
     ap.add_argument("--check", action="store_true", help="N > 1: every rank also renders the whole batch alone and compares the gathered pixels bit for bit")
     ap.add_argument("--one-rank-exchange", action="store_true", help="N = 1 rehearsal of the N > 1 step on the RCCL backend: a one-rank `nccl` process group, the send "
                                                                       "buffer, all_gather_into_tensor and the un-permute, with --check (the only way one card can run the nccl branch)")
+    ap.add_argument("--tile", type=int, default=TILE, help="rays per shard tile (tiles are dealt round-robin to the ranks)")
+    ap.add_argument("--no-pipeline", action="store_true", help="split frames (N > 1, --emulate-world, --one-rank-exchange): plain calls per step — four launches, exchange on "
+                                                               "the compute stream — instead of ShardedFramePipeline (hipGraph replay + exchange on a side stream)")
+    ap.add_argument("--graph", action="store_true", help="pipeline WITH the per-rank render replayed as a hipGraph (measured: no gain — the four plain launches already "
+                                                         "run without gaps, gpurun_out/r4m; kept as an A/B switch)")
+    ap.add_argument("--no-overlap-exchange", action="store_true", help="emulation: leave the device-side exchange out of the timed loop (A/B)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 default workload: do not append the BASELINE configs[3] / configs[4] lines (child runs of this script)")
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto", help="auto: rank 0 at N = 1 measures roofline.traffic with rocprofv3 --pmc child passes")
     ap.add_argument("--img", type=int, default=int(os.environ.get("TVR_BENCH_IMG", "800")), help="frame edge in pixels (800 = the BASELINE workload; "
@@ -386,7 +393,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from jittor_myc_nerfs_amd import _lib as L, shard_capacity, shard_indices, shard_send_views, shard_unpermute
+    from jittor_myc_nerfs_amd import _lib as L, shard_capacity, shard_indices, shard_send_views, shard_unpermute, ShardedFramePipeline
+    TILE = args.tile
     import ctypes as C
     model, arrs, A = build_model(device, args.model)
     S = A["N_samples"]
@@ -441,7 +449,19 @@ def main():
             return shard_unpermute(gathered, R_step, world, cap, TILE)      # undo the tile interleave: two strided copies (rgb, depth)
         return rgb, depth
 
-    # kernel durations come from HIP events recorded around each kernel inside tvr_render, in the timed region itself for the full-size frame
+    # A rank's share of a split frame is 2.6 ms at N = 8: the step then runs through ShardedFramePipeline (render.py) — the exchange (all_gather + un-permute) of frame k
+    # on a side stream behind frame k + 1's kernels (two send / receive buffer pairs); optionally (--graph) the four launches of the render replayed as ONE hipGraph
+    # per pose.  Emulation (--emulate-world, one process): the exchange is its device-side half at N-way sizes ("local").
+    use_pipe = split > 1 or args.one_rank_exchange
+    use_pipe = use_pipe and args.chunk == 0 and not args.no_pipeline
+    pipe = None
+    if use_pipe:
+        pipe = ShardedFramePipeline(model, R_step, rank if dist_on else 0, world if dist_on else split, tile=TILE, white_bg=True, N_samples=S, eps_T=args.eps_T,
+                                    exchange=("dist" if dist_on else (None if args.no_overlap_exchange else "local")), graph=args.graph)
+
+        def pipe_step(s):
+            return pipe.submit(s % n_patterns, step_rays[s % n_patterns])
+
     # (20.64 ms per step against 20.62 ms of kernels).  When a rank's share is a fraction of a frame (strong split / --emulate-world: 2.7 ms
     # of kernels at N = 8) the timed region runs without them and the kernel durations are taken in K more steps afterwards.
     prof_in_region = split == 1
@@ -449,6 +469,12 @@ def main():
     L.check(L.lib().tvr_profile_create(max(args.warmup, 1), C.byref(prof_w)), "tvr_profile_create")
     for s in range(args.warmup):
         step(s, profile=prof_w if prof_in_region else None)
+    if pipe is not None:                                            # captures one graph per (pose, send buffer) outside the timed region
+        for pat in range(n_patterns):
+            pipe.prepare(pat, step_rays[pat])
+        for s in range(max(args.warmup, 2)):
+            pipe_step(s)
+        pipe.flush()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -462,9 +488,14 @@ def main():
     t0 = time.perf_counter()
     trace = [] if os.environ.get("TVR_BENCH_TRACE") else None
     for s in range(args.steps):
-        step(args.warmup + s, profile=prof if prof_in_region else None, stats=stats)
+        if pipe is not None:
+            pipe_step(args.warmup + s)
+        else:
+            step(args.warmup + s, profile=prof if prof_in_region else None, stats=stats)
         if trace is not None:
             trace.append(time.perf_counter() - t0)
+    if pipe is not None:
+        pipe.flush()
     torch.cuda.synchronize()
     if trace is not None:
         print("host time after each step call (ms):", [round(t * 1e3, 2) for t in trace], "after sync: %.2f" % ((time.perf_counter() - t0) * 1e3), file=sys.stderr)
@@ -475,7 +506,7 @@ def main():
     gc.enable()
     if not prof_in_region:
         for s in range(args.steps):
-            step(args.warmup + s, profile=prof)
+            step(args.warmup + s, profile=prof, stats=stats if pipe is not None else None)    # (the graph replays carry neither events nor counters)
         torch.cuda.synchronize()
     if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -496,6 +527,14 @@ def main():
             rgb_g, depth_g = step(pat)
             rgb1, depth1 = model.render_rays(full_rays[pat], white_bg=True, N_samples=S, eps_T=args.eps_T)
             ok = ok and torch.equal(rgb_g, rgb1) and torch.equal(depth_g, depth1)
+            if pipe is not None:                                    # ... and the pipelined form (graph replay, exchange on the side stream), one frame behind
+                prev = pipe_step(pat)
+                if pat > 0:
+                    ok = ok and torch.equal(prev[0], last1[0]) and torch.equal(prev[1], last1[1])
+                last1 = (rgb1, depth1)
+        if pipe is not None:
+            fin = pipe.flush()
+            ok = ok and torch.equal(fin[0], last1[0]) and torch.equal(fin[1], last1[1])
         flag = torch.tensor([1 if ok else 0], device=device)
         if gloo:
             flag = flag.cpu()
@@ -629,7 +668,7 @@ def main():
         "vs_baseline": None, "dtype": "f32 (emulated: 3 x f16-split MFMA products, fp32 accumulate; fp32 VALU elsewhere)", "data": "synthetic",
         "config": {"workload": ("TensorVMSplit 300^3 (16/48 comps, MLP_Fea 150-128-128-3)" if args.model == "TensorVMSplit" else
                                 "REFTensoRF 300^3 (16/48 comps, 4 heads on h, MLP_Fea_Ref 151-128-128-3)") +
-                               f", {args.img}x{args.img} rays x 512 samples/ray (BASELINE configs[1]); {mode}, 4096-ray tiles round-robin, one RCCL "
+                               f", {args.img}x{args.img} rays x 512 samples/ray (BASELINE configs[1]); {mode}, {TILE}-ray tiles round-robin, one RCCL "
                                "all_gather of [4 cap] fp32 (rgb block + depth block, written in place by the render) + two strided un-permute copies",
                    "scene": "synthetic scene A (SURVEY 8d), no alpha mask, white_bg",
                    "rays_per_step": rays_job, "samples_per_ray": S, "rays_per_rank": n_mine,
@@ -644,6 +683,10 @@ def main():
         "roofline": dominant,
         "roofline_all": {"march": roof_march, "shade": roof_shade},
     }
+    if pipe is not None:
+        result["split_step"] = {"pipeline": "ShardedFramePipeline", "hipgraph": pipe.use_graph, "exchange": pipe.exchange,
+                                "note": "the exchange of frame k (all_gather + un-permute; 'local' = its device-side half at N-way sizes, one process) runs on a side stream "
+                                        "behind frame k + 1's kernels; hipgraph: the per-rank render replayed as one graph per pose"}
     if dist_on:
         result["exchange_backend"] = dist.get_backend() + (" (one-rank rehearsal: the process group has ONE member)" if world == 1 else "")
     if check is not None:

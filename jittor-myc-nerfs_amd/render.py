@@ -16,6 +16,9 @@ from typing import Callable, Optional, Tuple
 import torch
 
 
+SHARD_TILE = 512                        # rays per shard tile, dealt round-robin to the ranks.  Round 4 (scripts/shard_balance.py, the 8 bench poses, 8 ranks): the slowest
+                                        # rank carries 1.020 x the mean march work with 4096-ray tiles (1.024 x the rays), 1.0045 x with 512; the kernels lose nothing
+                                        # to the shorter runs of consecutive rays (scripts/emulate8_ab.sh)
 _INFER_SCRATCH_BUDGET = 16 << 30        # bytes of queue scratch an inference call may use (40 B per ray-sample, worst case)
 
 
@@ -55,7 +58,7 @@ def cal_n_samples(reso, step_ratio=0.5):
     return int(np.linalg.norm(reso) / step_ratio)
 
 
-def shard_indices(n_rays: int, rank: int, world: int, tile: int = 4096) -> torch.Tensor:
+def shard_indices(n_rays: int, rank: int, world: int, tile: int = SHARD_TILE) -> torch.Tensor:
     """Indices of the rays rank `rank` renders: tiles rank, rank+world, rank+2*world, ... of `tile` rays each."""
     n_tiles = (n_rays + tile - 1) // tile
     if rank >= n_tiles:
@@ -65,7 +68,7 @@ def shard_indices(n_rays: int, rank: int, world: int, tile: int = 4096) -> torch
     return idx[idx < n_rays]
 
 
-def shard_capacity(n_rays: int, world: int, tile: int = 4096) -> int:
+def shard_capacity(n_rays: int, world: int, tile: int = SHARD_TILE) -> int:
     """Rays in the largest shard (rank 0's); every rank pads to this so one equal-size all_gather suffices."""
     n_tiles = (n_rays + tile - 1) // tile
     return ((n_tiles + world - 1) // world) * tile
@@ -74,7 +77,7 @@ def shard_capacity(n_rays: int, world: int, tile: int = 4096) -> int:
 _GATHER_INDEX_CACHE = {}
 
 
-def shard_gather_index(n_rays: int, world: int, tile: int = 4096, device=None) -> torch.Tensor:
+def shard_gather_index(n_rays: int, world: int, tile: int = SHARD_TILE, device=None) -> torch.Tensor:
     """inv [n_rays] with  image[i] = gathered[inv[i]]  for the all_gather layout (rank r's rows at r*cap .. r*cap + its ray count):
     ray i lies in tile t = i // tile, which rank t % world renders as its (t // world)-th tile.  The un-permute after the
     all_gather is then ONE index_select, whatever the world size (cached per shape and device)."""
@@ -99,7 +102,7 @@ def shard_send_views(buf: torch.Tensor, cap: int, n_mine: int):
     return buf[:3 * cap].view(cap, 3)[:n_mine], buf[3 * cap:][:n_mine]
 
 
-def shard_unpermute(gathered: torch.Tensor, n_rays: int, world: int, cap: int, tile: int = 4096):
+def shard_unpermute(gathered: torch.Tensor, n_rays: int, world: int, cap: int, tile: int = SHARD_TILE):
     """gathered [world, 4 cap] (every rank's send buffer, rank-major) -> (rgb [n_rays,3], depth [n_rays]) in ray order.  Rank r's t-th tile is
     tile t * world + r of the frame, so the frame is the [tiles-per-rank, world] transpose of the gathered [world, tiles-per-rank] tile grid:
     two strided copies (rgb, depth), whatever the world size; the padding tiles land behind the last ray and are cut off."""
@@ -111,7 +114,7 @@ def shard_unpermute(gathered: torch.Tensor, n_rays: int, world: int, cap: int, t
 
 
 def render_sharded(rays: torch.Tensor, render_fn: Callable[..., Tuple[torch.Tensor, torch.Tensor]],
-                   rank: int, world: int, tile: int = 4096, group=None, exchange_at_world1: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                   rank: int, world: int, tile: int = SHARD_TILE, group=None, exchange_at_world1: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Render `rays` [R,6] (the full batch, present on every rank) across `world` ranks.
 
     render_fn(rays_subset, out=(rgb [n,3], depth [n])) renders on this rank's device INTO `out` (field.render_rays does; a render_fn without
@@ -145,3 +148,134 @@ def render_sharded(rays: torch.Tensor, render_fn: Callable[..., Tuple[torch.Tens
         dist.all_gather_into_tensor(gathered, mine, group=group)
     rgb, depth = shard_unpermute(gathered, R, world, cap, tile)
     return rgb.contiguous(), depth.contiguous()
+
+
+class ShardedFramePipeline:
+    """A stream of frames, each split over the ranks (render_sharded's layout), with the two things a rank's 2.6 ms share of an 800x800 frame needs at N = 8:
+
+      * the exchange of frame k (ONE all_gather of the [4 cap] send buffers + the two strided un-permute copies) runs on a SIDE stream behind frame k + 1's
+        kernels: two send / receive buffer pairs, events in both directions.  `submit()` therefore returns the frame submitted one call EARLIER (None at
+        the first call); `flush()` returns the last one;
+      * optionally (`graph=True`) the per-rank render (header clear, march, shade, composite: four launches) is captured ONCE per distinct ray set as a hipGraph
+        and replayed.  Measured on one MI355X (scripts/graph_cost.py, scripts/emulate8_ab.sh; profiles/r04_split_step_ab.txt): the four plain launches of a
+        rank's 2.6 ms share already run back to back without gaps (2.538 ms per call against 2.541 ms of kernels), a replay takes 2.51 - 2.54 ms — no gain, hence
+        off by default.  (The "0.12 ms of launch gaps" of round 3's emulation were the statistics atomics and clock probes of the timed launches.)
+
+    Pixels are those of render_sharded — bit for bit the single-rank frame (tests/test_sharding_gloo.py).  `exchange`: "dist" (torch.distributed group),
+    "local" (single process: this rank's buffer is copied into slot 0 of an [N, 4 cap] receive buffer and un-permuted — the device-side cost of the exchange
+    at N-way sizes, scripts/strong_emulation.py) or None (render only)."""
+
+    def __init__(self, model, n_rays: int, rank: int, world: int, tile: int = SHARD_TILE, white_bg: bool = True, N_samples: int = -1, eps_T=None,
+                 group=None, exchange: Optional[str] = "dist", graph: bool = False):
+        import torch.distributed as dist
+        self.model, self.R, self.rank, self.world, self.tile = model, int(n_rays), rank, world, tile
+        self.white_bg, self.S, self.eps_T, self.group, self.exchange, self.use_graph = white_bg, N_samples, eps_T, group, exchange, graph
+        self.dev = model.device
+        self.cap = shard_capacity(self.R, world, tile)
+        self.n_mine = shard_indices(self.R, rank, world, tile).numel()
+        self.mine = [torch.zeros((4 * self.cap,), device=self.dev) for _ in range(2)]
+        self.gathered = [torch.empty((world * 4 * self.cap,), device=self.dev) for _ in range(2)] if exchange else [None, None]
+        self.views = [shard_send_views(m, self.cap, self.n_mine) for m in self.mine]
+        self.side = torch.cuda.Stream(self.dev) if exchange else None
+        self.rendered = [torch.cuda.Event() for _ in range(2)]       # frame in buffer b is rendered (compute stream -> side stream)
+        self.exchanged = [torch.cuda.Event() for _ in range(2)]      # buffer b's exchange has finished (side stream -> compute stream)
+        self.busy = [False, False]
+        # the un-permuted frames land in static (padded) buffers: no allocation on the side stream, and the returned tensors are views that stay valid until
+        # the buffer comes round again, two submits later
+        L_ = self.cap // tile
+        self.out_rgb = [torch.empty((L_ * world * tile, 3), device=self.dev) for _ in range(2)] if exchange else None
+        self.out_depth = [torch.empty((L_ * world * tile,), device=self.dev) for _ in range(2)] if exchange else None
+        self.out = [None, None]
+        self.graphs = {}
+        self.k = 0
+        self._gloo = bool(exchange == "dist" and dist.is_initialized() and dist.get_backend(group) == "gloo")
+
+    def _render(self, sub, b):
+        self.model.render_rays(sub, white_bg=self.white_bg, N_samples=self.S, eps_T=self.eps_T, out=self.views[b])
+
+    def _replay(self, key, sub, b):
+        if not self.use_graph or self.n_mine == 0:
+            if self.n_mine:
+                self._render(sub, b)
+            return
+        g = self.graphs.get((key, b))
+        if g is None:
+            # warm up on a side stream (scratch, packed scene, the fp16-range decision: everything that allocates or reads the host happens here), then capture
+            warm = torch.cuda.Stream(self.dev)
+            warm.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(warm):
+                self._render(sub, b)
+            torch.cuda.current_stream(self.dev).wait_stream(warm)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            # thread_local: a process group's watchdog thread queries events while we capture; under the default (global) mode that call is an error for
+            # it and the capture (one hang in seven runs of the one-rank RCCL test before this)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._render(sub, b)
+            self.graphs[(key, b)] = (g, sub)                          # (the graph reads `sub`'s storage: keep it alive)
+            g = self.graphs[(key, b)]
+        g[0].replay()
+
+    def prepare(self, key, sub_rays):
+        """Capture the graphs of ray set `key` for BOTH send buffers now (a frame stream alternates buffers, so a key meets either); otherwise the first
+        submit() that pairs a key with a buffer pays the capture (a warm-up render, a device synchronise and the capture itself: ~3 ms)."""
+        if self.use_graph and self.n_mine:
+            for b in range(2):
+                if (key, b) not in self.graphs:
+                    if self.busy[b]:
+                        torch.cuda.current_stream(self.dev).wait_event(self.exchanged[b])
+                    self._replay(key, sub_rays, b)
+            torch.cuda.synchronize(self.dev)
+
+    def _exchange(self, b):
+        import torch.distributed as dist
+        if self.exchange == "dist":
+            if self._gloo and self.mine[b].is_cuda:                    # 1-GPU rehearsals: gloo has no all_gather_into_tensor for device tensors
+                parts = [torch.empty_like(self.mine[b]) for _ in range(self.world)]
+                dist.all_gather(parts, self.mine[b], group=self.group)
+                self.gathered[b].copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(self.gathered[b], self.mine[b], group=self.group)
+        else:
+            self.gathered[b][:4 * self.cap].copy_(self.mine[b])
+        # un-permute (shard_unpermute's two strided copies, into the static buffers): the frame is the [tiles-per-rank, world] transpose of the gathered tile grid
+        W_, L_, T_, cap = self.world, self.cap // self.tile, self.tile, self.cap
+        g = self.gathered[b].view(W_, 4 * cap)
+        self.out_rgb[b].view(L_, W_, T_, 3).copy_(g[:, :3 * cap].view(W_, L_, T_, 3).transpose(0, 1))
+        self.out_depth[b].view(L_, W_, T_).copy_(g[:, 3 * cap:].view(W_, L_, T_).transpose(0, 1))
+        self.out[b] = (self.out_rgb[b][:self.R], self.out_depth[b][:self.R])
+
+    def submit(self, key, sub_rays):
+        """Enqueue the frame whose rays of THIS rank are `sub_rays` [n_mine,6] (shard_indices order; a static tensor per `key`: the graph captured for a key
+        reads that storage).  Returns the (rgb [R,3], depth [R]) of the frame submitted one call earlier, or None."""
+        b = self.k % 2
+        cur = torch.cuda.current_stream(self.dev)
+        if self.busy[b]:
+            cur.wait_event(self.exchanged[b])                         # the exchange that last read this send buffer is done before it is rendered into again
+        self._replay(key, sub_rays, b)
+        prev = None
+        if self.exchange:
+            self.rendered[b].record(cur)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.rendered[b])
+                self._exchange(b)
+                self.exchanged[b].record(self.side)
+            self.busy[b] = True
+            pb = 1 - b
+            if self.k > 0:
+                cur.wait_event(self.exchanged[pb])                    # frame k - 1's pixels are complete for whatever the caller enqueues next
+                prev = self.out[pb]
+        else:
+            prev = (self.views[1 - b][0], self.views[1 - b][1]) if self.k > 0 else None
+        self.k += 1
+        return prev
+
+    def flush(self):
+        """The last submitted frame (waits, on the current stream, for its exchange)."""
+        if self.k == 0:
+            return None
+        b = (self.k - 1) % 2
+        if not self.exchange:
+            return self.views[b][0], self.views[b][1]
+        torch.cuda.current_stream(self.dev).wait_event(self.exchanged[b])
+        return self.out[b]

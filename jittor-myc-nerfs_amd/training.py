@@ -102,7 +102,7 @@ def make_graphed_step(step_fn, device=None, warmup: int = 2):
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (other threads — a process group's watchdog — may call the runtime meanwhile)
         out = step_fn()
 
     def replay():

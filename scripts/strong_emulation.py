@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """GPU box (ONE card): what BASELINE configs[2] — the 800x800 frame of scene A split over N ranks — costs a rank, as far as one GPU can say.
 
-    python3 scripts/strong_emulation.py [--steps 20] > profiles/r03_strong_emulation.json
+    python3 scripts/strong_emulation.py [--steps 20] > profiles/r04_strong_emulation.json
 
-  * kernels: `bench.py --emulate-world N` renders rank 0's share of the N-way split (tiles 0, N, 2N, ... of 4096 rays) — N = 1, 2, 4, 8, each in a
+  * kernels: `bench.py --emulate-world N` renders rank 0's share of the N-way split (tiles 0, N, 2N, ... of bench.py's shard tile) — N = 1, 2, 4, 8, each in a
     fresh child process; efficiency_kernels = t_1 / (N t_N) over the whole step (march + shade + composite + launch gaps).
   * exchange, device side: the two strided copies that undo the tile interleave of the gathered [N, 4 cap] buffer (the render writes its pixels
     straight into the send buffer: no pad copy), timed with HIP events at each N's own sizes, beside round 2's single index gather.
@@ -28,10 +28,12 @@ def run_json(cmd, env=None, timeout=900):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
-def device_side_exchange(worlds, R=640000, tile=4096, reps=50):
+def device_side_exchange(worlds, R=640000, tile=None, reps=50):
     import torch
     sys.path.insert(0, ROOT)
     from jittor_myc_nerfs_amd import shard_capacity, shard_gather_index, shard_indices, shard_unpermute
+    from jittor_myc_nerfs_amd.render import SHARD_TILE
+    tile = tile or SHARD_TILE
     dev = torch.device("cuda", 0)
     out = {}
     for w in worlds:
@@ -66,10 +68,12 @@ def main():
     worlds = [1, 2, 4, 8]
     rows = {}
     for w in worlds:
-        d = run_json([sys.executable, BENCH, "--steps", str(args.steps), "--warmup", "3", "--no-cpu-baseline", "--pmc", "off"] +
-                     (["--emulate-world", str(w)] if w > 1 else []))
-        rows[str(w)] = {"rays": d["config"]["rays_per_rank"], "ms_per_step": d["ms_per_step"], "kernel_ms": d["kernel_ms"],
+        base = [sys.executable, BENCH, "--steps", str(args.steps), "--warmup", "3", "--no-cpu-baseline", "--pmc", "off"]
+        d = run_json(base + (["--emulate-world", str(w), "--no-overlap-exchange"] if w > 1 else []))
+        rows[str(w)] = {"rays": d["config"]["rays_per_rank"], "tile": d["config"]["tile"], "ms_per_step": d["ms_per_step"], "kernel_ms": d["kernel_ms"],
                         "clock_GHz": {"march": d["roofline_all"]["march"]["clock_GHz"], "shade": d["roofline_all"]["shade"]["clock_GHz"]}}
+        if w > 1:      # the same step with the device-side half of the exchange (copy into the receive buffer + the two un-permute copies, at N-way sizes) on the side stream
+            rows[str(w)]["ms_per_step_with_overlapped_exchange"] = run_json(base + ["--emulate-world", str(w)])["ms_per_step"]
         print("emulate-world %d: %.3f ms per step, kernels %s" % (w, d["ms_per_step"], d["kernel_ms"]), file=sys.stderr)
     t1 = rows["1"]["ms_per_step"]
     k1 = {k: rows["1"]["kernel_ms"][k] for k in ("march", "shade", "composite")}
@@ -80,7 +84,8 @@ def main():
     ex = device_side_exchange(worlds[1:])
     for w in worlds[1:]:
         r, e = rows[str(w)], ex[str(w)]
-        r["efficiency_step_with_device_side_exchange"] = t1 / (w * (r["ms_per_step"] + e["pad_copy_ms"] + e["unpermute_ms"]))
+        r["efficiency_step_with_device_side_exchange"] = t1 / (w * r["ms_per_step_with_overlapped_exchange"])       # round 4: overlapped on a side stream (ShardedFramePipeline)
+        r["efficiency_step_with_serial_device_side_exchange"] = t1 / (w * (r["ms_per_step"] + e["pad_copy_ms"] + e["unpermute_ms"]))   # round 3's form: behind the render, same stream
     out = {"what": "BASELINE configs[2] on ONE MI355X: rank 0's share of the N-way strong split of the 800x800 frame (kernels, --emulate-world), the device-side "
                    "half of the exchange, and a 2-rank gloo rehearsal; t_1 / (N t_N) per SURVEY 8e.  The RCCL all_gather itself is not measurable on one card.",
            "command": "python3 scripts/strong_emulation.py --steps %d" % args.steps, "emulation": rows, "exchange_device_side": ex}

@@ -153,6 +153,27 @@ def _rccl_worker(port, arrs, hyper, rays_np, q):
         rgb, depth = render_sharded(rays, lambda r, out=None: m.render_rays(r, white_bg=True, N_samples=TINY["N_samples"], out=out), 0, 1, tile=tile,
                                     exchange_at_world1=True)
         out[tile] = bool(torch.equal(rgb, rgb1) and torch.equal(depth, depth1))
+    # the frame STREAM (ShardedFramePipeline): the exchange of frame k on a side stream behind frame k + 1's kernels, frames returned one submit late, with and
+    # without the hipGraph capture of the per-rank render — every frame bit for bit the plain render
+    from jittor_myc_nerfs_amd import ShardedFramePipeline, shard_indices
+    sets = [rays, rays.flip(0).contiguous(), torch.roll(rays, 7, 0).contiguous()]
+    plain = [m.render_rays(r, white_bg=True, N_samples=TINY["N_samples"]) for r in sets]
+    for graph in (False, True):
+        pipe = ShardedFramePipeline(m, rays.shape[0], 0, 1, tile=16, white_bg=True, N_samples=TINY["N_samples"], exchange="dist", graph=graph)
+        subs = [r.index_select(0, shard_indices(r.shape[0], 0, 1, 16).cuda()).contiguous() for r in sets]
+        ok, got = True, []
+        for i in range(7):                                 # more frames than buffers: both send buffers come round several times
+            prev = pipe.submit(i % 3, subs[i % 3])
+            if i == 0:
+                ok = ok and prev is None
+            else:
+                got.append((i - 1, prev[0].clone(), prev[1].clone()))
+        last = pipe.flush()
+        got.append((6, last[0].clone(), last[1].clone()))
+        torch.cuda.synchronize()
+        for i, rgb_i, depth_i in got:
+            ok = ok and bool(torch.equal(rgb_i, plain[i % 3][0]) and torch.equal(depth_i, plain[i % 3][1]))
+        out["pipeline_graph" if graph else "pipeline"] = ok
     # the training side's one collective: the flat gradient bucket through an RCCL all_reduce (a one-member SUM returns its input)
     b = GradBucket(m)
     b.flat.copy_(torch.arange(b.numel, device="cuda", dtype=torch.float32) % 97)
@@ -181,6 +202,7 @@ def test_render_sharded_over_rccl_with_one_rank(tiny_arrays, hyper_tiny, tiny_du
     p.join(120)
     assert p.exitcode == 0
     assert out["backend"] == "nccl" and out[16] and out[4096] and out["bucket"], out
+    assert out["pipeline"] and out["pipeline_graph"], out
 
 
 @pytest.mark.gpu
