@@ -250,7 +250,8 @@ int tvr_scene_destroy(tvr_scene *s)
 }
 
 // scratch carving shared by the size query and tvr_render
-struct ScratchLayout { size_t counter, ray_off, ray_cnt, acc, q_pos, q_out, q_ray, q_j, total; };
+#define TVR_RAY_ORDER_MAX_RAYS 65536      // march_forward_impl: batches up to this many rays get a ray-ordered queue
+struct ScratchLayout { size_t counter, ray_off, ray_cnt, acc, q_pos, q_out, q_ray, q_j, ray_new, total; };
 static ScratchLayout scratch_layout(int64_t n_rays, int32_t S)
 {
     ScratchLayout L;
@@ -265,6 +266,7 @@ static ScratchLayout scratch_layout(int64_t n_rays, int32_t S)
     L.q_out = take(cap * 16);
     L.q_ray = take(cap * 4);
     L.q_j = take(cap * 4);
+    L.ray_new = take(n_rays * 4);          // the training queue's ray-ordered offsets (launch_queue_ray_order); behind everything the public layout names
     L.total = off;
     return L;
 }
@@ -408,6 +410,11 @@ static int march_forward_impl(tvr_scene *s, const float *rays, int64_t n_rays, i
     mo.lam6 = lam6_out;
     HIP_TRY(launch_zero_header(mo.counter, stream));                   // [0] queue length, [1] the march's tile counter, [2] its fault flag, [3] workspace overflow
     HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, nullptr, stream));
+    // a training queue is put into ray order (the q_out / q_j regions are unused on this path): the weight gradients then do not depend on the order the
+    // march kernel's waves finished in.  Small batches only — the training path's own (train.py draws 4096 rays); a caller that marches a whole frame through
+    // this entry point keeps the kernel's order and rounding-level reproducibility.
+    if (n_rays <= TVR_RAY_ORDER_MAX_RAYS)
+        HIP_TRY(launch_queue_ray_order(mo, (unsigned *)((char *)scratch + L.ray_new), mo.q_out, (unsigned *)((char *)scratch + L.q_j), (int)n_rays, stream));
     return TVR_OK;
 }
 

@@ -121,6 +121,8 @@ hipError_t launch_composite_train_forward(const MarchOut &mo, int n_rays, long l
 hipError_t launch_composite_train_backward(const MarchOut &mo, int n_rays, long long cap, int white_bg, const float *rgb, const float *feats32, const float *g8, const float *pre,
                                            const float *g_map, const float *g_pen, float *grgb, float *gin0, float *grad_w, float *grad_acc, unsigned *amax_bits,
                                            float target, float *gscale, hipStream_t stream);
+// the march queue of a training batch put into RAY ORDER (scan of the per-ray counts, gather into tmp_pos / tmp_ray, copy back; ray_off is updated)
+hipError_t launch_queue_ray_order(const MarchOut &mo, unsigned *ray_new, float4 *tmp_pos, unsigned *tmp_ray, int n_rays, hipStream_t stream);
 hipError_t launch_linear_dx(const float *dY, int ldy, int N, const float *W, int ldw, int n_valid, int K, const float *mask, int ldm, float *dX, int ldx, long long M,
                             hipStream_t stream, const float *scale = nullptr, unsigned *sat_flag = nullptr, const unsigned long long *mask_bits = nullptr);
 hipError_t launch_filter_rays(const SceneDev &sc, const float *rays, long long n, int S, int bbox_only, unsigned char *mask, hipStream_t stream);

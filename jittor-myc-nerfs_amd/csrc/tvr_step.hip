@@ -295,3 +295,69 @@ hipError_t launch_colsum(const float *A, int lda, int K, long long m_cap, const 
     hipLaunchKernelGGL(colsum_final_kernel, dim3((K * 16 + 255) / 256), dim3(256), 0, stream, scratch, K, out);
     return hipGetLastError();
 }
+
+
+// ---- the training queue in RAY ORDER (round 4) ---------------------------------------------------------------------------------------------------------
+// The march kernel places a ray's entries where one atomicAdd says, so the order of the rays in the queue is the order its waves finish in: every sum over
+// all appearance samples (the weight-gradient products: fixed order over the rows as they lie) then runs over a run-dependent row order, and the network's
+// gradients are reproducible to rounding only.  For a TRAINING batch (4096 rays, < 1 M entries) putting the queue in ray order afterwards costs three tiny
+// launches (~10 us of a 3.4 ms step): an exclusive scan of the per-ray counts, a gather of every ray's segment to its scanned offset (into the queue's unused
+// q_out / q_j regions), a copy back.  The inference march is untouched (a frame's 55 M entries would cost 0.4 ms to move, and its picture does not depend on
+// the order).  After this pass the weight gradients of two runs on the same batch are bit-identical (tests/test_gpu_fused_step.py).
+__global__ __launch_bounds__(1024) void queue_scan_kernel(const unsigned *__restrict__ ray_cnt, unsigned *__restrict__ ray_new, const int n_rays)
+{
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0u;
+    __syncthreads();
+    for (int base = 0; base < n_rays; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const unsigned v = i < n_rays ? ray_cnt[i] : 0u;
+        unsigned x = v;                                            // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        unsigned before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < n_rays) ray_new[i] = before + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + x;
+        __syncthreads();
+    }
+}
+
+// one wave per ray: its segment [ray_off, ray_off + ray_cnt) -> [ray_new, ...) of the temporary arrays; then the ray's offset is the new one
+__global__ __launch_bounds__(256) void queue_gather_kernel(const MarchOut mo, const unsigned *__restrict__ ray_new, float4 *__restrict__ tmp_pos, unsigned *__restrict__ tmp_ray,
+                                                           const int n_rays)
+{
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ray >= n_rays) return;
+    const unsigned from = mo.ray_off[ray], cnt = mo.ray_cnt[ray], to = ray_new[ray];
+    for (unsigned i = lane; i < cnt; i += 64) {
+        tmp_pos[to + i] = mo.q_pos[from + i];
+        tmp_ray[to + i] = mo.q_ray[from + i];
+    }
+    if (lane == 0) mo.ray_off[ray] = to;
+}
+
+__global__ __launch_bounds__(256) void queue_copyback_kernel(const MarchOut mo, const float4 *__restrict__ tmp_pos, const unsigned *__restrict__ tmp_ray)
+{
+    const unsigned m = *mo.counter;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) {
+        mo.q_pos[e] = tmp_pos[e];
+        mo.q_ray[e] = tmp_ray[e];
+    }
+}
+
+hipError_t launch_queue_ray_order(const MarchOut &mo, unsigned *ray_new, float4 *tmp_pos, unsigned *tmp_ray, int n_rays, hipStream_t stream)
+{
+    hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(1024), 0, stream, mo.ray_cnt, ray_new, n_rays);
+    hipLaunchKernelGGL(queue_gather_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream, mo, ray_new, tmp_pos, tmp_ray, n_rays);
+    hipLaunchKernelGGL(queue_copyback_kernel, dim3(1024), dim3(256), 0, stream, mo, tmp_pos, tmp_ray);
+    return hipGetLastError();
+}

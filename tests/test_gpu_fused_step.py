@@ -159,7 +159,12 @@ def test_static_step_is_reproducible_and_agrees_with_the_eager_chain(tiny_dump, 
     rgb_a, na, va = grads(True)
     rgb_b, nb, vb = grads(True)
     assert torch.equal(rgb_a, rgb_b), "two static steps on the same batch render different pictures"
-    assert all(_close(x, y, 2e-6) for x, y in zip(na + va, nb + vb))
+    # round 4: the training queue is put into RAY ORDER behind the march (tvr_step.hip, queue_*_kernel), so every reduction over the appearance samples — the
+    # weight-gradient products, the bias sums — runs over the same rows in the same order whatever order the march kernel's waves finished in: the NETWORK's
+    # gradients are bit-identical run to run.  The VM factors' gradients are scattered with fp32 atomics and stay reproducible to rounding.
+    for i, (x, y) in enumerate(zip(na, nb)):
+        assert torch.equal(x, y), f"network gradient {i} {tuple(x.shape)} differs between two runs on the same batch: {float((x - y).abs().max()):.3e}"
+    assert all(_close(x, y, 2e-6) for x, y in zip(va, vb))
     rgb_e, ne, ve = grads(False)
     assert float((rgb_a - rgb_e).abs().max()) < 2e-6
     assert all(_close(x, y) for x, y in zip(na + va, ne + ve))
