@@ -49,7 +49,7 @@ static const int kVecH[3] = {2, 1, 0};
 
 struct PackedLayout {
     size_t dplane[3], dline[3], aplane[3], aline[3];
-    size_t mlp_image, basis_frag, b3, total;
+    size_t mlp_image, basis_frag, b3, w1gen, total;
 };
 
 static PackedLayout packed_layout(const tvr_scene_desc &d)
@@ -67,6 +67,8 @@ static PackedLayout packed_layout(const tvr_scene_desc &d)
     L.mlp_image = take(TVR_MLP_IMAGE_BYTES_REF / 4);
     L.basis_frag = take(TVR_BASIS_FRAG_BYTES / 4);
     L.b3 = take(16);
+    // scenes with more than two encoding frequencies (TensorBase's own default is 6 / 6: 390 MLP inputs): layer 1's fragment image, 26 k-steps, streamed through LDS
+    L.w1gen = (d.view_pe > 2 || d.fea_pe > 2) ? take(TVR_W1GEN_BYTES / 4) : 0;
     L.total = off;
     return L;
 }
@@ -96,9 +98,9 @@ static int check_desc(const tvr_scene_desc *d)
             return fail(TVR_ERR_UNSUPPORTED, "appearance_n_comp[%d]=%d; this build supports 1..%d", i, d->app_n_comp[i], TVR_CA);
         if (!(d->aabb[3 + i] > d->aabb[i])) return fail(TVR_ERR_INVALID, "aabb hi <= lo on axis %d", i);
     }
-    if (d->app_dim != TVR_APPDIM || d->featureC < 1 || d->featureC > TVR_FEATC || d->view_pe < 0 || d->view_pe > 2 || d->fea_pe < 0 || d->fea_pe > 2)
-        return fail(TVR_ERR_UNSUPPORTED, "MLP_Fea shape app_dim=%d featureC=%d view_pe=%d fea_pe=%d; this build supports app_dim 27, featureC 1..128, view_pe / fea_pe 0..2",
-                    d->app_dim, d->featureC, d->view_pe, d->fea_pe);
+    if (d->app_dim != TVR_APPDIM || d->featureC < 1 || d->featureC > TVR_FEATC || d->view_pe < 0 || d->view_pe > TVR_GEN_PE || d->fea_pe < 0 || d->fea_pe > TVR_GEN_PE)
+        return fail(TVR_ERR_UNSUPPORTED, "MLP_Fea shape app_dim=%d featureC=%d view_pe=%d fea_pe=%d; this build supports app_dim 27, featureC 1..128, view_pe / fea_pe 0..%d",
+                    d->app_dim, d->featureC, d->view_pe, d->fea_pe, TVR_GEN_PE);
     if (d->variant == 1) {
         bool std_shape = d->featureC == TVR_FEATC && d->view_pe == 2 && d->fea_pe == 2;
         for (int i = 0; i < 3; ++i) std_shape = std_shape && d->density_n_comp[i] == TVR_CD && d->app_n_comp[i] == TVR_CA;
@@ -152,6 +154,8 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
     v.mlp_image = s->packed + L.mlp_image;
     v.basis_frag = s->packed + L.basis_frag;
     v.b3 = (const float *)(s->packed + L.b3);
+    v.gen = (desc->view_pe > 2 || desc->fea_pe > 2) ? 1 : 0;
+    v.w1gen = v.gen ? (const void *)(s->packed + L.w1gen) : nullptr;
     v.near_ = desc->near_;
     v.far_ = desc->far_;
     v.step = desc->step_size;
@@ -187,7 +191,12 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
     sh.n_in = TVR_APPDIM + 3 + 2 * TVR_APPDIM * d.fea_pe + 6 * d.view_pe + (d.variant == 1 ? 1 : 0);
     sh.k_app = 0;
     for (int i = 0; i < 3; ++i) { sh.app_n_comp[i] = d.app_n_comp[i]; sh.app_off[i] = sh.k_app; sh.k_app += d.app_n_comp[i]; }
-    HIP_TRY(launch_pack_mlp(p->W1, p->b1, img + TVR_IMG_W1H, img + TVR_IMG_W1L, d.variant == 1 ? 4 : 0, sh, stream));
+    if (s->dev.gen) {       // more than two frequencies: layer 1's image is the 26-k-step general one in global memory; the LDS image's W1 region is two staging slots
+        HIP_TRY(launch_zero_f32((float *)(img + TVR_IMG_W1H), (TVR_IMG_W2H - TVR_IMG_W1H) / 4, stream));
+        HIP_TRY(launch_pack_mlp(p->W1, p->b1, s->packed + s->lay.w1gen, nullptr, 5, sh, stream));
+    } else {
+        HIP_TRY(launch_pack_mlp(p->W1, p->b1, img + TVR_IMG_W1H, img + TVR_IMG_W1L, d.variant == 1 ? 4 : 0, sh, stream));
+    }
     HIP_TRY(launch_pack_mlp(p->W2, nullptr, img + TVR_IMG_W2H, img + TVR_IMG_W2L, 1, sh, stream));
     // (clears and small copies as KERNELS: tvr_scene_update runs inside a captured training step, and memset / memcpy nodes of a graph replayed back to back
     //  were observed to run ahead of the previous replay's kernels — tvr_step.hip)

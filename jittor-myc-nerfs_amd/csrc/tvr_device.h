@@ -50,6 +50,15 @@
 #define TVR_IMG_REFB (TVR_IMG_REFW + 8 * TVR_IMG_REF_ROW)
 #define TVR_MLP_IMAGE_BYTES_REF (TVR_IMG_REFB + 64)               // 163 552 B (+ 16 B of matrix tokens <= 163 840)
 static_assert(TVR_MLP_IMAGE_BYTES_REF + 16 <= 160 * 1024, "REFTensoRF's LDS image must fit the CU's 160 KB");
+// General encoding frequencies (round 4): TensorBase.__init__'s own defaults are view_pe = fea_pe = 6 (tensorBase.py:141-145; opt.py:84,104) — 390 MLP inputs, a
+// layer-1 image of 213 KB that no LDS holds.  Scenes with more than two frequencies run the same kernel with layer 1 in LOCKSTEP: every base value has
+// TVR_GEN_T = 1 + 2 * 6 derived values {v, sin(2^f v), cos(2^f v)}, a lane's 16 base values fill 26 k-steps, and the workgroup's eight waves stage one k-step
+// (8 KB of fragments) at a time through two LDS slots, with a barrier per k-step.  Slower than the two-frequency kernel (no phase alternation, W1 re-read from
+// L2 for every 256 entries) — it exists so that every shape the reference constructs renders through HIP kernels; the shipped configs all use 2 / 2.
+#define TVR_GEN_PE 6
+#define TVR_GEN_T (1 + 2 * TVR_GEN_PE)
+#define TVR_GEN_KS (2 * TVR_GEN_T)                          // 16 base values x 13 derived / 8 slots per k-step and lane
+#define TVR_W1GEN_BYTES (TVR_GEN_KS * 2 * TVR_IMG_STEP)     // 212 992
 #define TVR_NIN_REF 151  // 1 + 27 + 3 + 2*2*27 + 2*2*3 (MLPRender_Fea_Ref, models/REFTensoRF.py:9)
 #define TVR_BASIS_FRAG_BYTES (9 * 2 * 32 * 16)   // global: the LO parts of the basis fragments [9 k-steps][2 halves][32 rows][16 B] (hi parts: LDS image)
 
@@ -67,6 +76,8 @@ struct SceneDev {
     float near_, far_, step, shift, scale, thres;
     int act;
     int variant;                  // 0 TensorVMSplit, 1 REFTensoRF
+    int gen;                      // 1: more than two encoding frequencies (view_pe / fea_pe up to TVR_GEN_PE): layer 1 runs from the streamed image w1gen
+    const void *w1gen;            // [26 k-steps][hi 4 KB | lo 4 KB], each [2 halves][128 rows][8 halfs]
     int range_check;              // 1 (default): the inference shade kernels mark entries whose fp16-split operands leave fp16's range with NaN (tvr_scene_set_range_check)
     const float *avol;            // (gz,gy,gx) or nullptr
     const unsigned *abits;        // optional: bit ((z*gy + y)*gx + x) = (avol > 0), built by tvr_scene_set_alpha
@@ -237,4 +248,20 @@ __host__ __device__ __forceinline__ int ref_in_index(int c, int t, int fea_pe, i
     return -1;
 }
 __host__ __device__ __forceinline__ int ref_in_index(int c, int t) { return ref_in_index(c, t, 2, 2); }
+// the same for the general slot order: derived value t of base value c is  v (t = 0), sin(2^(t-1) v) (1 <= t <= 6), cos(2^(t-7) v) (7 <= t <= 12)
+__host__ __device__ __forceinline__ int gen_in_index(int c, int t, int fea_pe, int view_pe)
+{
+    const int f = t == 0 ? 0 : (t <= TVR_GEN_PE ? t - 1 : t - 1 - TVR_GEN_PE), is_cos = t > TVR_GEN_PE;
+    const int off1 = TVR_APPDIM + 3, off2 = off1 + 2 * TVR_APPDIM * fea_pe;
+    if (c < TVR_APPDIM) {
+        if (t == 0) return c;
+        return f < fea_pe ? off1 + (is_cos ? TVR_APPDIM * fea_pe : 0) + fea_pe * c + f : -1;
+    }
+    if (c < TVR_APPDIM + 3) {
+        const int d = c - TVR_APPDIM;
+        if (t == 0) return TVR_APPDIM + d;
+        return f < view_pe ? off2 + (is_cos ? 3 * view_pe : 0) + view_pe * d + f : -1;
+    }
+    return -1;
+}
 

@@ -453,8 +453,9 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 #define TVR_TOKEN_PHASE 1     // which phase the per-SIMD token makes mutually exclusive: 1 the matrix phase (shipped); 2 the GATHER phase (experiment: the two
 #endif                        // waves' matrix phases may then overlap — one's splits / sin / cos under the other's MFMAs — and "both gathering, pipe idle" cannot happen)
 #if TVR_TOKEN_PHASE == 1
-#define TVR_ENTER_MATRIX() do { TVR_TOKEN_TAKE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_M); } while (0)
-#define TVR_LEAVE_MATRIX() do { TVR_TOKEN_GIVE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_G); } while (0)
+// (GEN, the lockstep kernel of scenes with more than two encoding frequencies: no token — its waves meet at a barrier per layer-1 k-step anyway)
+#define TVR_ENTER_MATRIX() do { if (!GEN) TVR_TOKEN_TAKE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_M); } while (0)
+#define TVR_LEAVE_MATRIX() do { if (!GEN) TVR_TOKEN_GIVE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_G); } while (0)
 #define TVR_ENTER_GATHER()
 #else
 #define TVR_ENTER_MATRIX() do { TVR_TOKEN_GIVE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_M); } while (0)
@@ -548,7 +549,7 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 // values, +4 % VALU); an entry whose maximum reaches fp16's largest finite value (cvt_pkrtz saturates there, silently) gets NaN as its colour / features, so the
 // pixel it belongs to comes out NaN instead of wrong.  Weights are checked by the host (field.py::_fp16_range_proven), which also switches RC off for scenes
 // whose interval bounds prove that nothing can leave the range.
-template <int SRC, int DST, bool REF, bool RC = false>
+template <int SRC, int DST, bool REF, bool RC = false, bool GEN = false>
 __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -624,7 +625,9 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         qe_next = a.q_pos[le];
         qray_next = a.q_ray[le];
     }
-    for (long long tile = (long long)lblk * SH_WAVES + wave; tile < n_tiles; tile += tile_stride) {
+    // GEN: every wave of the workgroup makes the same number of passes (its layer 1 has workgroup barriers); a pass beyond the last tile works on dead lanes
+    const long long tile_end = GEN ? ((n_tiles - (long long)lblk * SH_WAVES + tile_stride - 1) / tile_stride) * tile_stride + (long long)lblk * SH_WAVES + wave : n_tiles;
+    for (long long tile = (long long)lblk * SH_WAVES + wave; tile < tile_end; tile += tile_stride) {
         const long long ent = tile * SH_TILE + e;
         const bool live = ent < n_total;
         float F[16];                               // base values: row c = acc_row(r, h) of the feature tile, column = entry
@@ -860,6 +863,64 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             const unsigned char *W2Lb = W2Hb + (TVR_IMG_W2L - TVR_IMG_W2H);
             Frag bcur, bnxt;
             AF ring[TVR_RN], ring2[TVR_RN];
+            if constexpr (GEN) {
+                // ---- layer 1 with up to six encoding frequencies (TVR_GEN_*, tvr_device.h): 26 k-steps in LOCKSTEP.  Slot i = 8s + j of this lane is derived value
+                // i % 13 of base value i / 13: v, sin(2^f v) f < 6, cos(2^f v) f < 6 — v_sin / v_cos of the once-reduced argument (revolutions) times 2^f, exact
+                // scalings.  One k-step of W1's fragments (8 KB: hi | lo) sits in an LDS slot; every thread fetches one uint4 of the NEXT k-step at the top of a
+                // step and stores it into the other slot at the bottom, in front of the step's barrier.  (The fetch is a global load between MFMAs: this
+                // instantiation is outside the phase rule of the two-frequency kernels — scripts/isa_check.py exempts it by name; the rule's probes came back
+                // clean in round 2, and this is the general path, not the measured one.)
+                float TR[16];
+                auto gen_frag = [&](int s, Frag &b) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 8 * s + j, r = i / TVR_GEN_T, t = i % TVR_GEN_T;
+                        if (t == 0) {                                   // Cody-Waite reduction as in sincos_pe; the remainder in revolutions, |TR| <= 0.5
+                            const float k = rintf(F[r] * 0.15915494309189535f);
+                            float rr = __builtin_fmaf(k, -6.2831854820251465f, F[r]);
+                            rr = __builtin_fmaf(k, 1.7484555e-7f, rr);
+                            TR[r] = rr * 0.15915494309189535f;
+                        }
+                        v[j] = t == 0 ? F[r] : (t <= TVR_GEN_PE ? __builtin_amdgcn_sinf(TR[r] * (float)(1 << (t > 0 && t <= TVR_GEN_PE ? t - 1 : 0)))
+                                                                : __builtin_amdgcn_cosf(TR[r] * (float)(1 << (t > TVR_GEN_PE ? t - 1 - TVR_GEN_PE : 0))));
+                    }
+                    b = split8(v);
+                };
+                const uint4 *gsrc = (const uint4 *)sc.w1gen + tid;                       // k-step s: uint4 s * 512 + tid of the image (hi 256 | lo 256 uint4)
+                uint4 *slot = (uint4 *)(smem + TVR_IMG_W1H) + tid;                        // two 8 KB staging slots at the head of the (otherwise unused) W1 region
+                slot[0] = gsrc[0];                                                       // (the last readers of slot 0 passed two barriers since)
+                gen_frag(0, bcur);
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < TVR_GEN_KS; ++s) {
+                    uint4 wn = make_uint4(0u, 0u, 0u, 0u);
+                    if (s + 1 < TVR_GEN_KS) wn = gsrc[(s + 1) * 512];
+                    const unsigned char *sb = smem + TVR_IMG_W1H + (s & 1) * 8192 + rowoff;
+                    AFrag4 A;
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) { A.h[rb] = *(const uint4 *)(sb + rb * TVR_IMG_RB); A.l[rb] = *(const uint4 *)(sb + 4096 + rb * TVR_IMG_RB); }
+                    if (s + 1 < TVR_GEN_KS) gen_frag(s + 1, bnxt);
+                    mfma3x4(A, bcur, acc);
+                    if (s + 1 < TVR_GEN_KS) {
+                        slot[((s + 1) & 1) * 512] = wn;
+                        bcur = bnxt;
+                    }
+                    __syncthreads();
+                }
+                // layer 2's prologue: b2 -> the initial accumulators, W2's first fragment pairs, relu(layer 1) of k-step 0
+#pragma unroll
+                for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(q0));
+#pragma unroll
+                for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * r2 + 8 * q4 + 4 * h) * 4);
+                        cur.acc2[r2][4 * q4] = bv.x; cur.acc2[r2][4 * q4 + 1] = bv.y; cur.acc2[r2][4 * q4 + 2] = bv.z; cur.acc2[r2][4 * q4 + 3] = bv.w;
+                    }
+                relu_frag(0, bcur);
+                TVR_SB;
+            } else {
 #pragma unroll
             for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring[q0], W1Hb, W1Lb, TVR_AOFF(q0));
             l1_frag(0, bcur);
@@ -900,6 +961,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 bcur = bnxt;
                 TVR_SB;
             }
+            }           // !GEN
             TVR_STAMP(tg3);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
@@ -1024,14 +1086,14 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
 }
 
-template <int SRC, int DST, bool REF, bool RC>
+template <int SRC, int DST, bool REF, bool RC, bool GEN = false>
 static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
     constexpr bool BAS_ONLY = DST == SH_DST_FEAT && !REF;
     constexpr int NLO = REF ? 0 : (BAS_ONLY ? 9 : TVR_NLO_LDS);
     const int lds = (REF ? TVR_MLP_IMAGE_BYTES_REF : (BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : TVR_MLP_IMAGE_BYTES)) + 16 + NLO * 2 * TVR_IMG_BASH_ROWS * 16;
     static_assert((REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES) + 16 + (REF ? 0 : TVR_NLO_LDS) * 2 * TVR_IMG_BASH_ROWS * 16 <= 160 * 1024, "LDS image + tokens + basis lo parts must fit 160 KB");
-    hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF, RC, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
     unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
 #ifdef TVR_EXP_GRID                                             // scripts/overlap_experiment.py only: a build_variant.sh -DTVR_EXP_GRID library
@@ -1041,7 +1103,7 @@ static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStre
         const long long groups = (a.n + SH_TILE * SH_WAVES - 1) / (SH_TILE * SH_WAVES);
         if (groups < grid) grid = (unsigned)(groups > 0 ? groups : 1);
     }
-    hipLaunchKernelGGL((shade_kernel<SRC, DST, REF, RC>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
+    hipLaunchKernelGGL((shade_kernel<SRC, DST, REF, RC, GEN>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
     return hipGetLastError();
 }
 
@@ -1049,6 +1111,13 @@ template <bool REF>
 static hipError_t launch_shade_v(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream)
 {
     const bool rc = sc.range_check != 0;        // the inference entry points; the training forward has its own saturation flag (tvr_mlp_train.hip)
+    if constexpr (!REF) {
+        if (sc.gen) {                              // more than two encoding frequencies: the lockstep layer 1 (TensorVMSplit scenes only; check_desc refuses the rest)
+            if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false, true, true>(sc, a, stream) : launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false, false, true>(sc, a, stream);
+            if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false, true, true>(sc, a, stream) : launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false, false, true>(sc, a, stream);
+            if (src == SH_SRC_H && dst == SH_DST_TRAIN) return hipErrorInvalidValue;
+        }
+    }
     if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, REF, false>(sc, a, stream);
     if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return rc ? launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, false>(sc, a, stream);
     if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, REF, false>(sc, a, stream);
@@ -1120,8 +1189,8 @@ hipError_t launch_pack_plane(const float *in, float *out, int Cin, int C, int H,
 __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__ W, const float *__restrict__ bias,
                                                        unsigned short *__restrict__ out_hi, unsigned short *__restrict__ out_lo, int mode, const MlpShape sh)
 {
-    const int nrows = (mode <= 1 || mode == 4) ? 128 : (mode == 2 ? 32 : 4);
-    const int K = (mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : 128);
+    const int nrows = (mode <= 1 || mode >= 4) ? 128 : (mode == 2 ? 32 : 4);
+    const int K = (mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : (mode == 5 ? 16 * TVR_GEN_KS : 128));
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrows * K) return;
     const int row = i / K, kpos = i - row * K;
@@ -1137,6 +1206,10 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
         const int idx = (c == TVR_APPDIM + 3) ? (t == 0 ? 0 : -1) : (ref_in_index(c, t) >= 0 ? ref_in_index(c, t) + 1 : -1);
         if (idx >= 0) w = W[(size_t)row * TVR_NIN_REF + idx];
         if (c == 31 && t == 0) w = bias[row];
+    } else if (mode == 5) {                 // general frequencies: slot i = 8s + j of lane half hh is derived value i % 13 of base value acc_row(i / 13, hh)
+        const int ii = 8 * s + j, c = acc_row(ii / TVR_GEN_T, hh), t = ii % TVR_GEN_T, idx = gen_in_index(c, t, sh.fea_pe, sh.view_pe);
+        if (idx >= 0 && row < sh.featureC) w = W[(size_t)row * sh.n_in + idx];
+        if (c == 31 && t == 0 && row < sh.featureC) w = bias[row];
     } else if (mode == 1) {
         const int u = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
         if (row < sh.featureC && u < sh.featureC) w = W[(size_t)row * sh.featureC + u];
@@ -1148,7 +1221,10 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
     }
     unsigned hi, lo;
     split2(w, 0.0f, hi, lo);
-    if (mode == 0 || mode == 1 || mode == 4) {                                   // k-step major weight image: [s][h][row 128][8]
+    if (mode == 5) {                                                             // streamed image: per k-step [hi: [h][row 128][8] | lo: the same], 8 KB
+        out_hi[((s * 2 + 0) * 2 + hh) * 1024 + row * 8 + j] = (unsigned short)hi;
+        out_hi[((s * 2 + 1) * 2 + hh) * 1024 + row * 8 + j] = (unsigned short)lo;
+    } else if (mode == 0 || mode == 1 || mode == 4) {                            // k-step major weight image: [s][h][row 128][8]
         out_hi[((s * 2 + hh) * 128 + row) * 8 + j] = (unsigned short)hi;
         out_lo[((s * 2 + hh) * 128 + row) * 8 + j] = (unsigned short)lo;
     } else if (mode == 2) {                                                      // basis: hi parts -> the LDS image [s][h][27 rows][8], lo parts -> global [s][h][32 rows][8]
@@ -1163,7 +1239,7 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
 
 hipError_t launch_pack_mlp(const float *W, const float *bias, void *out_hi, void *out_lo, int mode, const MlpShape &sh, hipStream_t stream)
 {
-    const int n = ((mode <= 1 || mode == 4) ? 128 : (mode == 2 ? 32 : 4)) * ((mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : 128));
+    const int n = ((mode <= 1 || mode >= 4) ? 128 : (mode == 2 ? 32 : 4)) * ((mode == 0 || mode == 4) ? 160 : (mode == 2 ? 144 : (mode == 5 ? 16 * TVR_GEN_KS : 128)));
     hipLaunchKernelGGL(pack_mlp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, bias, (unsigned short *)out_hi, (unsigned short *)out_lo, mode, sh);
     return hipGetLastError();
 }

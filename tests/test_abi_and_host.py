@@ -40,9 +40,12 @@ def test_abi_argument_errors_without_gpu():
     d.app_n_comp[:] = [48] * 3
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"density_n_comp" in lib.tvr_last_error()
     d.density_n_comp[:] = [16] * 3
-    d.app_dim, d.featureC, d.view_pe, d.fea_pe, d.step_size = 27, 128, 6, 6, 0.005     # opt.py's default frequencies do not fit either
+    d.app_dim, d.featureC, d.view_pe, d.fea_pe, d.step_size = 27, 128, 7, 6, 0.005     # more than six encoding frequencies: refused
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"view_pe" in lib.tvr_last_error()
+    d.view_pe, d.fea_pe = 6, 6                                         # opt.py's / TensorBase's default frequencies: the lockstep layer-1 path, + 213 KB of packed weights
+    n66 = lib.tvr_scene_packed_bytes(C.byref(d))
     d.view_pe, d.fea_pe = 2, 2
+    assert n66 >= lib.tvr_scene_packed_bytes(C.byref(d)) + 26 * 8192
     nbytes = lib.tvr_scene_packed_bytes(C.byref(d))
     d.density_n_comp[:], d.app_n_comp[:], d.featureC, d.view_pe = [8, 8, 8], [24, 24, 24], 64, 0      # fewer / narrower: zero-padded into the same layout
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == nbytes

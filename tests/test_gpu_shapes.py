@@ -1,6 +1,6 @@
 """GPU: scene shapes other than the one the kernels are built for.  TensorBase's own defaults are 8 / 24 components
 (tensorf-myc/models/tensorBase.py:141) and `opt.py` lets featureC / view_pe / fea_pe vary.  Anything that FITS the kernels' shape — up to 16 density
-and 48 appearance components per plane, hidden width up to 128, 0..2 encoding frequencies — is packed with zero padding (exact: a zero channel
+and 48 appearance components per plane, hidden width up to 128, 0..2 encoding frequencies (3..6: the lockstep layer-1 path, inference) — is packed with zero padding (exact: a zero channel
 adds 0, a hidden unit that does not exist outputs relu(0) = 0 into zero columns) and rendered by the same kernels; anything larger is refused."""
 import numpy as np
 import pytest
@@ -14,7 +14,11 @@ SHAPES = [([8, 8, 8], [24, 24, 24], 128, 2, 2),          # TensorBase's default 
           ([5, 16, 9], [48, 7, 30], 64, 0, 0),           # ragged components, narrow MLP, no positional encoding at all
           ([16, 16, 16], [48, 48, 48], 96, 1, 2),
           ([8, 8, 8], [24, 24, 24], 128, 2, 1),
-          ([1, 2, 3], [1, 2, 3], 1, 1, 1)]
+          ([1, 2, 3], [1, 2, 3], 1, 1, 1),
+          # more than two encoding frequencies (round 4): layer 1 runs in lockstep from a streamed 26-k-step image (tvr_device.h TVR_GEN_*)
+          ([8, 8, 8], [24, 24, 24], 128, 6, 6),          # TensorBase.__init__'s own defaults, component counts and frequencies (tensorBase.py:141-145): 390 MLP inputs
+          ([16, 16, 16], [48, 48, 48], 128, 4, 3),
+          ([16, 16, 16], [48, 48, 48], 64, 0, 6)]
 
 
 def _scene(dc, ac, fc, vpe, fpe, hyper_tiny):
@@ -54,7 +58,7 @@ def test_zero_padded_shapes_render_like_the_oracle(tiny_dump, hyper_tiny, dc, ac
     assert float((m._mlp_render(vd.cuda(), feat.cuda()).cpu() - TO.mlp_render_fea(sc, vd, feat)).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("dc,ac,fc,vpe,fpe", [SHAPES[0], SHAPES[1]])
+@pytest.mark.parametrize("dc,ac,fc,vpe,fpe", [SHAPES[0], SHAPES[1], SHAPES[5]])
 def test_zero_padded_shapes_train(tiny_dump, hyper_tiny, dc, ac, fc, vpe, fpe):
     """Gradients of every parameter tensor at its own (unpadded) shape against autograd through the oracle."""
     from oracle import tensorf_oracle as TO
@@ -82,7 +86,7 @@ def test_zero_padded_shapes_train(tiny_dump, hyper_tiny, dc, ac, fc, vpe, fpe):
         assert np.abs(g - r).max() / max(np.abs(r).max(), 1e-6) < 5e-4, k
 
 
-@pytest.mark.parametrize("kw", [dict(density_n_comp=[17, 16, 16]), dict(appearance_n_comp=[48, 49, 48]), dict(featureC=129), dict(view_pe=3), dict(fea_pe=6)])
+@pytest.mark.parametrize("kw", [dict(density_n_comp=[17, 16, 16]), dict(appearance_n_comp=[48, 49, 48]), dict(featureC=129), dict(view_pe=7), dict(fea_pe=8)])
 def test_shapes_that_do_not_fit_are_refused(hyper_tiny, kw):
     from jittor_myc_nerfs_amd import TensorVMSplit, _lib as L
     args = dict(density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], featureC=128, view_pe=2, fea_pe=2)
