@@ -86,16 +86,24 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // (the packed forms v_pk_fma_f32 / v_pk_mul_f32: half the instructions and 2 % SLOWER — beside the partner wave's MFMA stream a packed fp32 op takes
 // 52.7 cycles instead of 4.6, scripts/hwprobe/valu_rate.hip)
 // two plain v_fma_f32 / v_mul_f32, each pinned by an empty asm (without the pins, and with the SLP vectoriser off: 12.92 vs 12.75 ms)
+#ifndef TVR_PIN_PK
+#define TVR_PIN_PK 2      // 2: every fp32 op of the interpolation / layer 3 is pinned by an empty asm (keeps the SLP vectoriser from pairing them, and the ops where they
+#endif                    // are written); 1: one pin per interpolated channel pair (build with -fno-slp-vectorize); 0: none.  Each pin costs an s_nop 0 — hipcc guards
+                          // an inline asm that reads a just-written VGPR — 175 per tile at level 2; level 0 lets hipcc hoist the loads' consumers apart: 256 VGPRs + spills.
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c)
 {
     float x = __builtin_fmaf(a.x, b.x, c.x), y = __builtin_fmaf(a.y, b.y, c.y);
+#if TVR_PIN_PK >= 1
     asm volatile("" : "+v"(x)); asm volatile("" : "+v"(y));
+#endif
     return f32x2{x, y};
 }
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b)
 {
     float x = a.x * b.x, y = a.y * b.y;
+#if TVR_PIN_PK >= 1
     asm volatile("" : "+v"(x)); asm volatile("" : "+v"(y));
+#endif
     return f32x2{x, y};
 }
 
@@ -152,6 +160,12 @@ __device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag &b, f32x16 a
 // The three MFMA windows of a row block: TVR_PIPE 1 puts one fragment read in each of the first two windows and V0 / V1 / V2 VALU instructions behind the three
 // MFMAs (layer 1: 1 / 3 / 5, layer 2: 0 / 2 / 4; 2 / 3 / 4 and 1 / 4 / 4 measured 5 % slower, 0 / 3 / 6 and 0 / 4 / 5 equal); TVR_PIPE 0: both reads in front of
 // the row block and 3 / 3 / 3 (2 / 2 / 2): 3 % slower.
+// TVR_L2RB (round 4, second step): layer 2 runs ROW BLOCK BY ROW BLOCK over eight pre-split fragments of relu(layer 1) (the 64 registers the layer-1 accumulators
+// leave), and layer 3 of row block rb - 1 — 16 relu, 48 FMA, 12 weight reads — runs under the MFMAs of row block rb: only the last row block's share of layer 3 is
+// left behind the token hand-over.  Layer 3 was 3.0 k cycles of every wave's chain (gather -> token -> matrix -> layer 3) with nothing beside it.
+#ifndef TVR_L2RB
+#define TVR_L2RB 1
+#endif
 #ifndef TVR_PIPE
 #define TVR_PIPE 1
 #endif
@@ -216,6 +230,23 @@ __device__ __forceinline__ void mfma3(const AF &A, const Frag &b, f32x16 &acc)
     asm volatile("" : "+v"(name##_a));                                                                              \
     const unsigned char *name = (const unsigned char *)(const void __attribute__((address_space(3))) *)(size_t)name##_a
 
+// the interpolation's own forms: pinned per op at TVR_PIN_PK 2, per channel pair at 1
+__device__ __forceinline__ f32x2 ip_fma(f32x2 a, f32x2 b, f32x2 c)
+{
+#if TVR_PIN_PK >= 2
+    return pk_fma(a, b, c);
+#else
+    return f32x2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
+#endif
+}
+__device__ __forceinline__ f32x2 ip_mul(f32x2 a, f32x2 b)
+{
+#if TVR_PIN_PK >= 2
+    return pk_mul(a, b);
+#else
+    return f32x2{a.x * b.x, a.y * b.y};
+#endif
+}
 // the 6 taps (4 plane texels, 2 line texels) x 8 channels of one entry for one k-step
 struct Taps {
     float4 t[4][2], lv[2][2];
@@ -308,13 +339,16 @@ __device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, fl
             const f32x2 t3 = hh ? f32x2{T.t[3][g].z, T.t[3][g].w} : f32x2{T.t[3][g].x, T.t[3][g].y};
             const f32x2 l0 = hh ? f32x2{T.lv[0][g].z, T.lv[0][g].w} : f32x2{T.lv[0][g].x, T.lv[0][g].y};
             const f32x2 l1 = hh ? f32x2{T.lv[1][g].z, T.lv[1][g].w} : f32x2{T.lv[1][g].x, T.lv[1][g].y};
-            f32x2 p = pk_mul(w00, t0);
-            p = pk_fma(w01, t1, p);
-            p = pk_fma(w10, t2, p);
-            p = pk_fma(w11, t3, p);
-            f32x2 q = pk_mul(ul, l0);
-            q = pk_fma(wl, l1, q);
-            const f32x2 r = pk_mul(p, q);
+            f32x2 p = ip_mul(w00, t0);
+            p = ip_fma(w01, t1, p);
+            p = ip_fma(w10, t2, p);
+            p = ip_fma(w11, t3, p);
+            f32x2 q = ip_mul(ul, l0);
+            q = ip_fma(wl, l1, q);
+            f32x2 r = ip_mul(p, q);
+#if TVR_PIN_PK == 1
+            asm volatile("" : "+v"(r.x), "+v"(r.y));
+#endif
             out[g * 4 + hh * 2] = r.x;
             out[g * 4 + hh * 2 + 1] = r.y;
         }
@@ -345,6 +379,8 @@ struct Carry {
     float wq;
     float g[4];                  // REFTensoRF: specular tint and rgb_d
     float rmax;                  // RC: max |x| over this lane's share of the entry's fp16-split operands
+    f32x2 s0, s1, s2;            // TVR_L2RB: layer 3's partial sums over the row blocks below rb_done (two chains per output)
+    int rb_done;                 // row blocks of acc2 that layer 3 has consumed already (TVR_L2RB: 3 — only acc2[3] is left for finish_tile; else 0)
     bool live;
 };
 
@@ -353,7 +389,7 @@ struct Carry {
 template <int DST, bool REF, bool HAVE_G, bool RC>
 __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char *smem, const ShadeArgs &a, int h)
 {
-    f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+    f32x2 s0 = c.s0, s1 = c.s1, s2 = c.s2;
     // ONE address register (16-bit immediate offsets cover W3's 1.5 KB; the image offset itself does not fit an immediate, and without
     // the opaque base hipcc materialises 48 loop-invariant address registers and spills them)
     unsigned w3a = (unsigned)(size_t)(smem + TVR_IMG_W3) + 16u * (unsigned)h;
@@ -367,9 +403,14 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) d[q * 3 + c3] = *(const float4 *)(W3 + c3 * 128 + 32 * rb + 8 * q);    // hidden units u + 4h .. + 3
     };
-    fetch(0, w[0]);
+#if TVR_SCHED && TVR_L2RB
+    const int rb0 = 3;                                           // (c.rb_done, as a constant): row blocks 0..2 went under layer 2's MFMAs
+#else
+    const int rb0 = 0;
+#endif
+    fetch(rb0, w[rb0 & 1]);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = rb0; rb < 4; ++rb) {
         if (rb + 1 < 4) fetch(rb + 1, w[(rb + 1) & 1]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -855,6 +896,17 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 }
                 b = split8(v);
             };
+#if TVR_L2RB
+            Frag fr[8];                                         // relu(layer 1) as layer 2's eight B fragments (the 64 registers `acc` leaves)
+            f32x16 a2cur, a2nxt;                                // layer-2 accumulators of the row block in flight / its successor's b2
+            auto b2_init = [&](int rb2, f32x16 &dst) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * rb2 + 8 * q4 + 4 * h) * 4);
+                    dst[4 * q4] = bv.x; dst[4 * q4 + 1] = bv.y; dst[4 * q4 + 2] = bv.z; dst[4 * q4 + 3] = bv.w;
+                }
+            };
+#endif
             // ONE opaque address register per image: every fragment read is base + 16-bit immediate (left to itself hipcc materialises an address
             // register per read, and those VALU adds take the slots the pipeline means for the fragment derivation)
             TVR_LDS_BASE(W1Hb, smem + TVR_IMG_W1H + rowoff);
@@ -909,6 +961,13 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     __syncthreads();
                 }
                 // layer 2's prologue: b2 -> the initial accumulators, W2's first fragment pairs, relu(layer 1) of k-step 0
+#if TVR_L2RB
+#pragma unroll
+                for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(4 * q0));
+                b2_init(0, a2cur);
+                relu_frag(0, fr[0]);
+                relu_frag(1, fr[1]);
+#else
 #pragma unroll
                 for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(q0));
 #pragma unroll
@@ -919,6 +978,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         cur.acc2[r2][4 * q4] = bv.x; cur.acc2[r2][4 * q4 + 1] = bv.y; cur.acc2[r2][4 * q4 + 2] = bv.z; cur.acc2[r2][4 * q4 + 3] = bv.w;
                     }
                 relu_frag(0, bcur);
+#endif
                 TVR_SB;
             } else {
 #pragma unroll
@@ -934,6 +994,11 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     mfma3(ring[(TVR_DIAG & 2) ? (q & 1) : (q % TVR_RN)], bcur, acc[rb]);
                     if (s == 9 && rb == 0) {
                         // layer 2's prologue (acc[0] is complete): b2 -> the initial accumulators, W2's first two fragment pairs, relu(acc[0]) split
+#if TVR_L2RB
+#pragma unroll
+                        for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(4 * q0));
+                        b2_init(0, a2cur);
+#else
 #pragma unroll
                         for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(q0));
 #pragma unroll
@@ -943,26 +1008,85 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                                 const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * r2 + 8 * q4 + 4 * h) * 4);
                                 cur.acc2[r2][4 * q4] = bv.x; cur.acc2[r2][4 * q4 + 1] = bv.y; cur.acc2[r2][4 * q4 + 2] = bv.z; cur.acc2[r2][4 * q4 + 3] = bv.w;
                             }
+#endif
                     }
                 }
                 if (TVR_DIAG & 1) bnxt = bcur;
                 else if (s + 1 < 10) l1_frag(s + 1, bnxt);
+#if TVR_L2RB
+                else { relu_frag(0, fr[0]); relu_frag(1, fr[1]); }         // acc[0] holds both k-steps' 16 hidden units
+#else
                 else relu_frag(0, bnxt);
+#endif
                 if (s < 9) {
 #pragma unroll
                     for (int rb = 0; rb < 4; ++rb) TVR_PIPE_RB(4 * s + rb + TVR_PD < 40, TVR_L1_V0, TVR_L1_V1, TVR_L1_V2);
                 } else {
                     TVR_SG_MFMA(3);                 // row block 0
+#if TVR_L2RB
+                    TVR_SG_DSR(4 + 2 * TVR_PD);     // W2's first fragments, b2 of row block 0
+                    TVR_SG_MFMA(3);                 // row block 1: relu(acc[0]) may be read 3 MFMAs after its last write
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) { TVR_SG_MFMA(1); TVR_SG_VALU(5); }
+#else
                     TVR_SG_DSR(16 + 2 * TVR_PD);    // W2's first fragments, b2
                     TVR_SG_MFMA(3);                 // row block 1: relu(acc[0]) may be read 3 MFMAs after its last write
 #pragma unroll
                     for (int m = 0; m < 6; ++m) { TVR_SG_MFMA(1); TVR_SG_VALU(TVR_NV1); }
+#endif
                 }
                 bcur = bnxt;
                 TVR_SB;
             }
             }           // !GEN
             TVR_STAMP(tg3);
+#if TVR_L2RB
+            {
+                f32x16 a2prev = f32x16{0};                          // the finished row block layer 3 is working through
+                f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+                TVR_LDS_BASE(W3b, smem + TVR_IMG_W3 + 16 * h);
+                const float *W3 = (const float *)W3b;
+                float4 w3[3];
+                // layer 3 over the 4 hidden units 32 rb3 + 8 qq + 4 h .. + 3 of this lane (tensorBase.py:83-84: Linear(128 -> 3) on relu(h2)); the same order of
+                // additions as finish_tile's
+                auto l3_quad = [&](const f32x16 &x, int rb3, int qq) {
+                    const f32x2 xa = {relu_f(x[4 * qq]), relu_f(x[4 * qq + 1])};
+                    const f32x2 xb = {relu_f(x[4 * qq + 2]), relu_f(x[4 * qq + 3])};
+                    if (DST == SH_DST_TRAIN && live)
+                        *(float4 *)(a.t_h2 + ent * TVR_FEATC + 32 * rb3 + 8 * qq + 4 * h) = make_float4(xa.x, xa.y, xb.x, xb.y);
+                    s0 = pk_fma(xa, f32x2{w3[0].x, w3[0].y}, s0); s0 = pk_fma(xb, f32x2{w3[0].z, w3[0].w}, s0);
+                    s1 = pk_fma(xa, f32x2{w3[1].x, w3[1].y}, s1); s1 = pk_fma(xb, f32x2{w3[1].z, w3[1].w}, s1);
+                    s2 = pk_fma(xa, f32x2{w3[2].x, w3[2].y}, s2); s2 = pk_fma(xb, f32x2{w3[2].z, w3[2].w}, s2);
+                };
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const int q = 8 * rb + ks;                  // position in the (row block, k-step) sequence; its fragment: TVR_AOFF(4 ks + rb)
+                        if (q + TVR_PD < 32) load_af(ring2[(q + TVR_PD) % TVR_RN], W2Hb, W2Lb, TVR_AOFF(4 * ((q + TVR_PD) & 7) + ((q + TVR_PD) >> 3)));
+                        if (ks == 6 && rb < 3) b2_init(rb + 1, a2nxt);
+                        if (rb > 0 && !(ks & 1)) {
+#pragma unroll
+                            for (int c3 = 0; c3 < 3; ++c3) w3[c3] = *(const float4 *)(W3 + c3 * 128 + 32 * (rb - 1) + 8 * (ks >> 1));
+                        }
+                        mfma3(ring2[q % TVR_RN], fr[ks], a2cur);
+                        if (rb == 0) { if (ks + 2 < 8) relu_frag(ks + 2, fr[ks + 2]); }
+                        else if (ks & 1) l3_quad(a2prev, rb - 1, ks >> 1);
+                        if (q + TVR_PD < 32) TVR_SG_DSR(2);
+                        if (ks == 6 && rb < 3) TVR_SG_DSR(4);
+                        if (rb > 0 && !(ks & 1)) TVR_SG_DSR(3);
+                        if (rb == 0 && ks + 2 < 8) { TVR_SG_MFMA(1); TVR_SG_VALU(8); TVR_SG_MFMA(1); TVR_SG_VALU(8); TVR_SG_MFMA(1); TVR_SG_VALU(8); }
+                        else if (rb > 0 && (ks & 1)) { TVR_SG_MFMA(1); TVR_SG_VALU(5); TVR_SG_MFMA(1); TVR_SG_VALU(5); TVR_SG_MFMA(1); TVR_SG_VALU(6); }
+                        else TVR_SG_MFMA(3);
+                        TVR_SB;
+                    }
+                    a2prev = a2cur;
+                    if (rb < 3) a2cur = a2nxt;
+                }
+                cur.acc2[3] = a2prev;
+                cur.s0 = s0; cur.s1 = s1; cur.s2 = s2;
+            }
+#else
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
 #pragma unroll
@@ -981,6 +1105,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 bcur = bnxt;
                 TVR_SB;
             }
+#endif
         }
 #else
         // ---- layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5.  sin / cos of a base
@@ -1061,6 +1186,9 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         for (int rb = 0; rb < 4; ++rb) cur.acc2[rb] += acc[rb];          // keeps layer 1 alive in the build that derives no fragments
 #endif
         cur.ent = ent; cur.live = live; cur.wq = wq;
+#if !(TVR_SCHED && TVR_L2RB)
+        cur.s0 = f32x2{0.f, 0.f}; cur.s1 = f32x2{0.f, 0.f}; cur.s2 = f32x2{0.f, 0.f};
+#endif
         cur.g[0] = G[3]; cur.g[1] = G[4]; cur.g[2] = G[5]; cur.g[3] = G[6];
         TVR_LEAVE_MATRIX();
         // layer 3 + store run at the LOWEST priority: their 320 VALU ops need no particular moment, the partner's matrix phase needs every issue slot it
