@@ -16,12 +16,16 @@
 //              fragments [v, sin v, sin 2v, cos v, cos 2v] of the 16 base values a lane owns are derived step by step between the
 //              MFMAs (W1's columns are permuted to this order at pack time; b1 is the column of a constant-1 input)
 //     L2       H2^T = W2 · relu(H^T): B = the layer-1 accumulators converted in place ("accumulator tile as the next MFMA's
-//              operand": the k order inside a step is a fixed permutation, folded into the packed weight columns); token handed over
-//   finish     layer 3 + sigmoid + store: plain fp32 FMAs on the layer-2 accumulators (W3 as fp32 in LDS), beside the partner's matrix phase
+//              operand": the k order inside a step is a fixed permutation, folded into the packed weight columns), kept as eight pre-split
+//              fragments; the layer runs ROW BLOCK BY ROW BLOCK, and layer 3 of row block rb - 1 (fp32 FMAs, W3 as fp32 in LDS) runs
+//              under the MFMAs of row block rb; token handed over behind the last MFMA
+//   finish     layer 3 of the last row block + sigmoid + store, beside the partner's matrix phase
+//   The matrix phase is an explicit software pipeline (fragment ring + sched_group_barrier windows, see below); since round 4 the kernel is measured to
+//   be POWER-bound on the full chip (1.67 GHz on 256 CUs, 2.34 GHz on 128).
 // Arithmetic: v_mfma_f32_32x32x16_f16 with every fp32 operand split into fp16 hi + lo and three products per step
 // (hi·hi + hi·lo + lo·hi, fp32 accumulate): ~2^-22 relative error per product — fp32-class accuracy at 16/3 the rate of
 // the fp32-input MFMA.  Range: operands pass through fp16, so |x| <= 65504 (cvt_pkrtz saturates) and parts below 6e-8 flush;
-// features up to |v| ~ 1e3 and the reference's 1e-4-scale initialisation are tested (tests/test_gpu_parity.py).
+// features up to |v| ~ 1e3 and the reference's 1e-4-scale initialisation are tested (tests/test_gpu_parity.py); leaving the range is never silent (template parameter RC, include/tvr.h).
 //
 // Phase rule: a round-1 build that issued global loads between the MFMAs of a tile returned wrong 16-lane groups on
 // some boxes.  The mechanism was not established (round 2: the candidate mechanisms are excluded by probes, and that build renders clean
@@ -47,7 +51,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define TVR_GATHER_KEEP(s_)                                                                            \
     do {                                                                                               \
         if (RC) { _Pragma("unroll") for (int j_ = 0; j_ < 8; j_ += 2) rmax = absmax2(hvv[s_][j_], hvv[s_][j_ + 1], rmax); asm volatile("" : "+v"(rmax)); } \
-        if (!TVR_SPLIT_LATE || !TVR_SCHED || (s_) == 0) { hf[s_] = split8(hvv[s_]); TVR_PIN_FRAG(hf[s_]); } \
+        if (!TVR_SPLIT_LATE || (s_) == 0) { hf[s_] = split8(hvv[s_]); TVR_PIN_FRAG(hf[s_]); } \
         else TVR_PIN8(hvv[s_]);                                                                        \
     } while (0)
 #define TVR_PIN_FRAG(f) asm volatile("" : "+v"((f).hi.x), "+v"((f).hi.y), "+v"((f).hi.z), "+v"((f).hi.w), "+v"((f).lo.x), "+v"((f).lo.y), "+v"((f).lo.z), "+v"((f).lo.w))
@@ -150,9 +154,6 @@ __device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag &b, f32x16 a
 // takes 23.0 k cycles per wave instead of 24.8 k, the kernel 12.2 - 12.6 ms instead of 12.6 - 13.0 (-3 %): with two in-order waves per SIMD the gather phase, the
 // token wait and layer 3 are on the same critical chain as the matrix phase, and a lone wave's hidden layers run at 39 cycles per MFMA whatever the order of their
 // instructions (32.5 without the fragment derivation, 32.1 without the fragment reads, 38.8 with both: gpurun_out/r4f) — issue-bound, not pipe-bound.
-#ifndef TVR_SCHED
-#define TVR_SCHED 1
-#endif
 #ifndef TVR_DIAG
 #define TVR_DIAG 0        // diagnostic builds only (wrong pictures): 1 = no fragment derivation in the hidden layers, 2 = no A-fragment reads
 #endif
@@ -163,9 +164,6 @@ __device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag &b, f32x16 a
 // TVR_L2RB (round 4, second step): layer 2 runs ROW BLOCK BY ROW BLOCK over eight pre-split fragments of relu(layer 1) (the 64 registers the layer-1 accumulators
 // leave), and layer 3 of row block rb - 1 — 16 relu, 48 FMA, 12 weight reads — runs under the MFMAs of row block rb: only the last row block's share of layer 3 is
 // left behind the token hand-over.  Layer 3 was 3.0 k cycles of every wave's chain (gather -> token -> matrix -> layer 3) with nothing beside it.
-#ifndef TVR_L2RB
-#define TVR_L2RB 1
-#endif
 #ifndef TVR_PIPE
 #define TVR_PIPE 1
 #endif
@@ -374,13 +372,12 @@ __device__ __forceinline__ void sincos_pe(float x, float &s, float &c)
 __device__ __forceinline__ float absmax2(float a, float b, float m) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), m); }      // one v_max3_f32 |a|, |b|, m
 // what a tile hands from its matrix phase to finish_tile (layer 3 + epilogue)
 struct Carry {
-    f32x16 acc2[4];              // layer-2 accumulators (b2 included), hidden unit 32 rb + acc_row(r, h) in acc2[rb][r]
+    f32x16 acc2;                 // layer-2 accumulators of row block 3 (b2 included), hidden unit 96 + acc_row(r, h) in acc2[r]
     long long ent;
     float wq;
     float g[4];                  // REFTensoRF: specular tint and rgb_d
     float rmax;                  // RC: max |x| over this lane's share of the entry's fp16-split operands
-    f32x2 s0, s1, s2;            // TVR_L2RB: layer 3's partial sums over the row blocks below rb_done (two chains per output)
-    int rb_done;                 // row blocks of acc2 that layer 3 has consumed already (TVR_L2RB: 3 — only acc2[3] is left for finish_tile; else 0)
+    f32x2 s0, s1, s2;            // layer 3's partial sums over row blocks 0..2, taken under layer 2's MFMAs (two chains per output); acc2[3] is what finish_tile still has to do
     bool live;
 };
 
@@ -395,35 +392,22 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
     unsigned w3a = (unsigned)(size_t)(smem + TVR_IMG_W3) + 16u * (unsigned)h;
     asm volatile("" : "+v"(w3a));
     const float *W3 = (const float *)(const void __attribute__((address_space(3))) *)(size_t)w3a;
-    // the 12 weight quads of a row block are fetched while the previous block's FMAs run (one LDS round trip per block, not per quad)
-    float4 w[2][12];
-    auto fetch = [&](int rb, float4 (&d)[12]) {
+    // row block 3 (hidden units 96..127; row blocks 0..2 were taken under layer 2's MFMAs, same order of additions): its 12 weight quads in one LDS round trip
+    float4 w[12];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int c3 = 0; c3 < 3; ++c3) d[q * 3 + c3] = *(const float4 *)(W3 + c3 * 128 + 32 * rb + 8 * q);    // hidden units u + 4h .. + 3
-    };
-#if TVR_SCHED && TVR_L2RB
-    const int rb0 = 3;                                           // (c.rb_done, as a constant): row blocks 0..2 went under layer 2's MFMAs
-#else
-    const int rb0 = 0;
-#endif
-    fetch(rb0, w[rb0 & 1]);
+        for (int c3 = 0; c3 < 3; ++c3) w[q * 3 + c3] = *(const float4 *)(W3 + c3 * 128 + 32 * 3 + 8 * q);      // hidden units u + 4h .. + 3
 #pragma unroll
-    for (int rb = rb0; rb < 4; ++rb) {
-        if (rb + 1 < 4) fetch(rb + 1, w[(rb + 1) & 1]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 w0 = w[rb & 1][q * 3], w1 = w[rb & 1][q * 3 + 1], w2 = w[rb & 1][q * 3 + 2];
-            const f32x2 xa = {relu_f(c.acc2[rb][4 * q]), relu_f(c.acc2[rb][4 * q + 1])};
-            const f32x2 xb = {relu_f(c.acc2[rb][4 * q + 2]), relu_f(c.acc2[rb][4 * q + 3])};
-            if (DST == SH_DST_TRAIN && c.live)           // relu(layer 2), hidden units 32 rb + 8 q + 4 h .. + 3: the backward's mask and dW3's operand
-                *(float4 *)(a.t_h2 + c.ent * TVR_FEATC + 32 * rb + 8 * q + 4 * h) = make_float4(xa.x, xa.y, xb.x, xb.y);
-            s0 = pk_fma(xa, f32x2{w0.x, w0.y}, s0); s0 = pk_fma(xb, f32x2{w0.z, w0.w}, s0);
-            s1 = pk_fma(xa, f32x2{w1.x, w1.y}, s1); s1 = pk_fma(xb, f32x2{w1.z, w1.w}, s1);
-            s2 = pk_fma(xa, f32x2{w2.x, w2.y}, s2); s2 = pk_fma(xb, f32x2{w2.z, w2.w}, s2);
-        }
-        TVR_SB;
+    for (int q = 0; q < 4; ++q) {
+        const float4 w0 = w[q * 3], w1 = w[q * 3 + 1], w2 = w[q * 3 + 2];
+        const f32x2 xa = {relu_f(c.acc2[4 * q]), relu_f(c.acc2[4 * q + 1])};
+        const f32x2 xb = {relu_f(c.acc2[4 * q + 2]), relu_f(c.acc2[4 * q + 3])};
+        if (DST == SH_DST_TRAIN && c.live)               // relu(layer 2), hidden units 96 + 8 q + 4 h .. + 3: the backward's mask and dW3's operand
+            *(float4 *)(a.t_h2 + c.ent * TVR_FEATC + 96 + 8 * q + 4 * h) = make_float4(xa.x, xa.y, xb.x, xb.y);
+        s0 = pk_fma(xa, f32x2{w0.x, w0.y}, s0); s0 = pk_fma(xb, f32x2{w0.z, w0.w}, s0);
+        s1 = pk_fma(xa, f32x2{w1.x, w1.y}, s1); s1 = pk_fma(xb, f32x2{w1.z, w1.w}, s1);
+        s2 = pk_fma(xa, f32x2{w2.x, w2.y}, s2); s2 = pk_fma(xb, f32x2{w2.z, w2.w}, s2);
     }
     float r0 = s0.x + s0.y, r1 = s1.x + s1.y, r2 = s2.x + s2.y;
     r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
@@ -534,7 +518,6 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 // below it.  TVR_SCHED: ONE accumulation chain (l*hi, h*lo, h*hi per k-step, as the hidden layers do — round 3 summed three chains with 32 VALU adds behind
 // the last MFMA, pipe idle), the A fragments in a ring of four read two k-steps ahead of their use, the first two BEFORE the wave waits for its loads and
 // for the matrix token.
-#if TVR_SCHED
 #define TVR_BASIS_BLOCK()                                                                                                            \
     do {                                                                                                                            \
         constexpr int BST_ = 2 * TVR_IMG_BASH_ROWS * 16;                                                                            \
@@ -564,26 +547,6 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
         TVR_SB;                                                                                                                     \
         if (REF) { f32x16 accA, accB, accC; TVR_REF_HEADS(); }                                                                      \
     } while (0)
-#else
-#define TVR_BASIS_BLOCK()                                                                                                            \
-    do {                                                                                                                            \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                            \
-        TVR_SB;                                                                                                                     \
-        TVR_STAMP(tg1);                                                                                                             \
-        TVR_ENTER_MATRIX();                                                                                                         \
-        TVR_STAMP(tgW);                                                                                                             \
-        f32x16 accA = f32x16{0}, accB = f32x16{0}, accC = f32x16{0};                                                                \
-        _Pragma("unroll") for (int s_ = 0; s_ < 9; ++s_) {                                                                          \
-            const h8 Ah = __builtin_bit_cast(h8, *(const uint4 *)(bashp + s_ * (2 * TVR_IMG_BASH_ROWS * 16)));                      \
-            const h8 Al = s_ < NLO ? __builtin_bit_cast(h8, *(const uint4 *)(baslp + s_ * (2 * TVR_IMG_BASH_ROWS * 16))) : __builtin_bit_cast(h8, bal[s_]); \
-            accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s_].hi), accA, 0, 0, 0);                    \
-            accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s_].lo), accB, 0, 0, 0);                    \
-            accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s_].hi), accC, 0, 0, 0);                    \
-        }                                                                                                                           \
-        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) F[r_] = (accA[r_] + accB[r_]) + accC[r_];                                 \
-        if (REF) { TVR_REF_HEADS(); }                                                                                               \
-    } while (0)
-#endif
 
 // RC (range check, tvr_scene_set_range_check; default ON for the inference entry points): every value that enters an MFMA through the fp16 hi / lo split — the
 // interpolated appearance features, the basis outputs and the layer-1 inputs made of them, relu(layer 1) — feeds a running max|x| (one v_max3_f32 per two
@@ -648,10 +611,6 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     if (a.stats && SRC == SH_SRC_QUEUE && tid == 0) { clk0 = __builtin_amdgcn_s_memtime(); ref0 = __builtin_amdgcn_s_memrealtime(); }
 #if TVR_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-#if !TVR_SCHED
-    const unsigned char *W1H = smem + TVR_IMG_W1H, *W1L = smem + TVR_IMG_W1L;
-    const unsigned char *W2H = smem + TVR_IMG_W2H, *W2L = smem + TVR_IMG_W2L;
 #endif
     constexpr bool HAVE_G = REF && SRC != SH_SRC_FEAT;
     const long long tile_stride = (long long)gridDim.x * SH_WAVES;
@@ -860,7 +819,6 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             }
         }
 
-#if TVR_SCHED
         // ---- layers 1 and 2 as ONE software pipeline (see TVR_SCHED above) ----
         // layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5; sin / cos of a base value are taken in the step
         // that first needs them (2-3 per step).  Layer 2: the B fragments are the relu'd layer-1 accumulators, 8 registers per k-step; b2 is the initial
@@ -896,7 +854,6 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 }
                 b = split8(v);
             };
-#if TVR_L2RB
             Frag fr[8];                                         // relu(layer 1) as layer 2's eight B fragments (the 64 registers `acc` leaves)
             f32x16 a2cur, a2nxt;                                // layer-2 accumulators of the row block in flight / its successor's b2
             auto b2_init = [&](int rb2, f32x16 &dst) {
@@ -906,7 +863,6 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     dst[4 * q4] = bv.x; dst[4 * q4 + 1] = bv.y; dst[4 * q4 + 2] = bv.z; dst[4 * q4 + 3] = bv.w;
                 }
             };
-#endif
             // ONE opaque address register per image: every fragment read is base + 16-bit immediate (left to itself hipcc materialises an address
             // register per read, and those VALU adds take the slots the pipeline means for the fragment derivation)
             TVR_LDS_BASE(W1Hb, smem + TVR_IMG_W1H + rowoff);
@@ -961,24 +917,11 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     __syncthreads();
                 }
                 // layer 2's prologue: b2 -> the initial accumulators, W2's first fragment pairs, relu(layer 1) of k-step 0
-#if TVR_L2RB
 #pragma unroll
                 for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(4 * q0));
                 b2_init(0, a2cur);
                 relu_frag(0, fr[0]);
                 relu_frag(1, fr[1]);
-#else
-#pragma unroll
-                for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(q0));
-#pragma unroll
-                for (int r2 = 0; r2 < 4; ++r2)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * r2 + 8 * q4 + 4 * h) * 4);
-                        cur.acc2[r2][4 * q4] = bv.x; cur.acc2[r2][4 * q4 + 1] = bv.y; cur.acc2[r2][4 * q4 + 2] = bv.z; cur.acc2[r2][4 * q4 + 3] = bv.w;
-                    }
-                relu_frag(0, bcur);
-#endif
                 TVR_SB;
             } else {
 #pragma unroll
@@ -994,53 +937,29 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     mfma3(ring[(TVR_DIAG & 2) ? (q & 1) : (q % TVR_RN)], bcur, acc[rb]);
                     if (s == 9 && rb == 0) {
                         // layer 2's prologue (acc[0] is complete): b2 -> the initial accumulators, W2's first two fragment pairs, relu(acc[0]) split
-#if TVR_L2RB
 #pragma unroll
                         for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(4 * q0));
                         b2_init(0, a2cur);
-#else
-#pragma unroll
-                        for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(q0));
-#pragma unroll
-                        for (int r2 = 0; r2 < 4; ++r2)
-#pragma unroll
-                            for (int q4 = 0; q4 < 4; ++q4) {
-                                const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * r2 + 8 * q4 + 4 * h) * 4);
-                                cur.acc2[r2][4 * q4] = bv.x; cur.acc2[r2][4 * q4 + 1] = bv.y; cur.acc2[r2][4 * q4 + 2] = bv.z; cur.acc2[r2][4 * q4 + 3] = bv.w;
-                            }
-#endif
                     }
                 }
                 if (TVR_DIAG & 1) bnxt = bcur;
                 else if (s + 1 < 10) l1_frag(s + 1, bnxt);
-#if TVR_L2RB
                 else { relu_frag(0, fr[0]); relu_frag(1, fr[1]); }         // acc[0] holds both k-steps' 16 hidden units
-#else
-                else relu_frag(0, bnxt);
-#endif
                 if (s < 9) {
 #pragma unroll
                     for (int rb = 0; rb < 4; ++rb) TVR_PIPE_RB(4 * s + rb + TVR_PD < 40, TVR_L1_V0, TVR_L1_V1, TVR_L1_V2);
                 } else {
                     TVR_SG_MFMA(3);                 // row block 0
-#if TVR_L2RB
                     TVR_SG_DSR(4 + 2 * TVR_PD);     // W2's first fragments, b2 of row block 0
                     TVR_SG_MFMA(3);                 // row block 1: relu(acc[0]) may be read 3 MFMAs after its last write
 #pragma unroll
                     for (int m = 0; m < 6; ++m) { TVR_SG_MFMA(1); TVR_SG_VALU(5); }
-#else
-                    TVR_SG_DSR(16 + 2 * TVR_PD);    // W2's first fragments, b2
-                    TVR_SG_MFMA(3);                 // row block 1: relu(acc[0]) may be read 3 MFMAs after its last write
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) { TVR_SG_MFMA(1); TVR_SG_VALU(TVR_NV1); }
-#endif
                 }
                 bcur = bnxt;
                 TVR_SB;
             }
             }           // !GEN
             TVR_STAMP(tg3);
-#if TVR_L2RB
             {
                 f32x16 a2prev = f32x16{0};                          // the finished row block layer 3 is working through
                 f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
@@ -1083,112 +1002,16 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     a2prev = a2cur;
                     if (rb < 3) a2cur = a2nxt;
                 }
-                cur.acc2[3] = a2prev;
+                cur.acc2 = a2prev;
                 cur.s0 = s0; cur.s1 = s1; cur.s2 = s2;
             }
-#else
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    const int q = 4 * s + rb;
-                    if (q + TVR_PD < 32 && !(TVR_DIAG & 2)) load_af(ring2[(q + TVR_PD) % TVR_RN], W2Hb, W2Lb, TVR_AOFF(q + TVR_PD));
-                    mfma3(ring2[(TVR_DIAG & 2) ? (q & 1) : (q % TVR_RN)], bcur, cur.acc2[rb]);
-                }
-                if (TVR_DIAG & 1) bnxt = bcur;
-                else if (s + 1 < 8) relu_frag(s + 1, bnxt);
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    if (s + 1 < 8) TVR_PIPE_RB(4 * s + rb + TVR_PD < 32, TVR_L2_V0, TVR_L2_V1, TVR_L2_V2);
-                    else TVR_PIPE_RB(4 * s + rb + TVR_PD < 32, 0, 0, 0);
-                }
-                bcur = bnxt;
-                TVR_SB;
-            }
-#endif
         }
-#else
-        // ---- layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5.  sin / cos of a base
-        //      value are taken in the step that first needs them (2-3 per step), between the MFMAs of the step before ----
-        f32x16 acc[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x16{0};
-        {
-            float S1[16], C1[16];
-            const int rowoff = (h * 128 + e) * 16;
-            auto l1_frag = [&](int s, Frag &b) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = 8 * s + j, r = i / 5, t = i % 5;
-                    // first slot of base value r in program order is i = 5r (t = 0): take its sin / cos there
-                    if (t == 0) sincos_pe(F[r], S1[r], C1[r]);
-                    v[j] = t == 0 ? F[r] : (t == 1 ? S1[r] : (t == 2 ? 2.0f * S1[r] * C1[r]                 // sin 2v
-                                  : (t == 3 ? C1[r] : __builtin_fmaf(-2.0f * S1[r], S1[r], 1.0f))));          // cos 2v
-                }
-                b = split8(v);
-            };
-            Frag bcur, bnxt;
-            AFrag4 acur, anxt;
-            l1_frag(0, bcur);
-            load_afrag4(acur, W1H, W1L, rowoff, TVR_IMG_RB);
-#pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                if (s + 1 < 10) load_afrag4(anxt, W1H, W1L, rowoff + (s + 1) * TVR_IMG_STEP, TVR_IMG_RB);
-                if (s + 1 < 10) l1_frag(s + 1, bnxt);
-                mfma3x4(acur, bcur, acc);
-                acur = anxt;
-                bcur = bnxt;
-                TVR_SB;
-            }
-        }
-        TVR_STAMP(tg3);
-        // ---- layer 2: B fragments are the relu'd layer-1 accumulators, 8 registers per k-step; b2 is the initial accumulator ----
-        Carry cur;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bv = *(const float4 *)(smem + TVR_IMG_B2 + (32 * rb + 8 * q + 4 * h) * 4);
-                cur.acc2[rb][4 * q] = bv.x; cur.acc2[rb][4 * q + 1] = bv.y; cur.acc2[rb][4 * q + 2] = bv.z; cur.acc2[rb][4 * q + 3] = bv.w;
-            }
-        {
-            const int rowoff = (h * 128 + e) * 16;
-            auto relu_frag = [&](int s, Frag &b) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = relu_f(acc[s >> 1][8 * (s & 1) + j]);
-                if (RC) { _Pragma("unroll") for (int j = 0; j < 8; j += 2) rmax = fmaxf(fmaxf(v[j], v[j + 1]), rmax); asm volatile("" : "+v"(rmax)); }
-                if (DST == SH_DST_TRAIN && live) {   // relu(layer 1): element j is hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3)
-                    *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
-                    *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 8 + 4 * h) = make_float4(v[4], v[5], v[6], v[7]);
-                }
-                b = split8(v);
-            };
-            Frag bcur, bnxt;
-            AFrag4 acur, anxt;
-            relu_frag(0, bcur);
-            load_afrag4(acur, W2H, W2L, rowoff, TVR_IMG_RB);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s + 1 < 8) load_afrag4(anxt, W2H, W2L, rowoff + (s + 1) * TVR_IMG_STEP, TVR_IMG_RB);
-                if (s + 1 < 8) relu_frag(s + 1, bnxt);
-                mfma3x4(acur, bcur, cur.acc2);
-                acur = anxt;
-                bcur = bnxt;
-                TVR_SB;
-            }
-        }
-#endif
         TVR_STAMP(tgL);
-#if TVR_SCHED && (TVR_DIAG & 1)
+#if TVR_DIAG & 1
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) cur.acc2[rb] += acc[rb];          // keeps layer 1 alive in the build that derives no fragments
+        for (int rb = 0; rb < 4; ++rb) cur.acc2 += acc[rb];              // keeps layer 1 alive in the build that derives no fragments
 #endif
         cur.ent = ent; cur.live = live; cur.wq = wq;
-#if !(TVR_SCHED && TVR_L2RB)
-        cur.s0 = f32x2{0.f, 0.f}; cur.s1 = f32x2{0.f, 0.f}; cur.s2 = f32x2{0.f, 0.f};
-#endif
         cur.g[0] = G[3]; cur.g[1] = G[4]; cur.g[2] = G[5]; cur.g[3] = G[6];
         TVR_LEAVE_MATRIX();
         // layer 3 + store run at the LOWEST priority: their 320 VALU ops need no particular moment, the partner's matrix phase needs every issue slot it
