@@ -327,6 +327,47 @@ def _pmc_kernel(pmc, prefix):
     return {}
 
 
+def arith_modes(model, step_rays, S, eps_T, steps=8):
+    """The opt-in arithmetics of the appearance network (include/tvr.h, tvr_scene_set_arith) on the bench frame, behind the timed region: kernel times
+    (HIP events of the library's own profile, `steps` frames over the poses) and the picture's distance from the default (fp32-class) mode's on ALL rays of
+    every pose.  Informational: `value` is the default mode's."""
+    import ctypes as C
+    from jittor_myc_nerfs_amd import _lib as L
+    out, ref = {}, None
+    try:
+        for mode in ("f32", "f16act", "f16"):
+            model.mlp_arith = mode
+            prof = C.c_void_p()
+            L.check(L.lib().tvr_profile_create(steps, C.byref(prof)), "tvr_profile_create")
+            model.render_rays(step_rays[0], white_bg=True, N_samples=S, eps_T=eps_T)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s in range(steps):
+                model.render_rays(step_rays[s % len(step_rays)], white_bg=True, N_samples=S, eps_T=eps_T, profile=prof)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            ms = (C.c_float * 3)()
+            n = max(L.lib().tvr_profile_read(prof, C.byref(ms)), 1)
+            L.lib().tvr_profile_destroy(prof)
+            pics = [model.render_rays(r, white_bg=True, N_samples=S, eps_T=eps_T)[0] for r in step_rays]
+            o = {"ms_per_frame": dt * 1e3, "kernel_ms": {"march": ms[0] / n, "shade": ms[1] / n, "composite": ms[2] / n},
+                 "ray_samples_per_sec": step_rays[0].shape[0] * S / dt}
+            if ref is None:
+                ref = pics
+            else:
+                d = [(a - b).abs() for a, b in zip(pics, ref)]
+                o["rgb_Linf_vs_f32_mode"] = max(float(x.max()) for x in d)
+                o["rgb_mean_abs_vs_f32_mode"] = float(sum(x.mean() for x in d) / len(d))
+                o["rays_compared"] = int(sum(x.shape[0] for x in d))
+                o["nonfinite_pixels"] = int(sum((~torch.isfinite(a)).sum() for a in pics))
+            out[mode] = o
+    finally:
+        model.mlp_arith = "f32"
+    out["note"] = ("products per k-step of basis / layer 1 / layer 2: f32 = Wlo*xhi + Whi*xlo + Whi*xhi (default, the headline); f16act = Wlo*xhi + Whi*xhi (activations rounded to "
+                   "fp16, nearest even); f16 = Whi*xhi.  north_star's parity bar: RGB L-inf 1e-3")
+    return out
+
+
 def main():
     global TILE
     ap = argparse.ArgumentParser()
@@ -355,6 +396,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="pipeline WITH the per-rank render replayed as a hipGraph (measured: no gain — the four plain launches already "
                                                          "run without gaps, gpurun_out/r4m; kept as an A/B switch)")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="emulation: leave the device-side exchange out of the timed loop (A/B)")
+    ap.add_argument("--arith", choices=["f32", "f16act", "f16"], default="f32",
+                    help="arithmetic of the appearance network's matrix products (tvr_scene_set_arith): f32 = three fp16 products per fp32 product, fp32-class — the headline; "
+                         "f16act / f16 = the opt-in reduced modes (two / one product).  The default run reports all three under `arith_modes`")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 default workload: do not append the BASELINE configs[3] / configs[4] lines (child runs of this script)")
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto", help="auto: rank 0 at N = 1 measures roofline.traffic with rocprofv3 --pmc child passes")
     ap.add_argument("--img", type=int, default=int(os.environ.get("TVR_BENCH_IMG", "800")), help="frame edge in pixels (800 = the BASELINE workload; "
@@ -397,6 +441,8 @@ def main():
     TILE = args.tile
     import ctypes as C
     model, arrs, A = build_model(device, args.model)
+    model.mlp_arith = args.arith
+    n_prod = {"f32": 3, "f16act": 2, "f16": 1}[args.arith]
     S = A["N_samples"]
     if args.alpha_mask > 0:
         model.updateAlphaMask((args.alpha_mask,) * 3)
@@ -581,7 +627,7 @@ def main():
     has_mask = model.alphaMask is not None
     t_march, t_shade = k_ms[0] * 1e-3, k_ms[1] * 1e-3
     FLOP_APP = 8.0e4            # algorithmic FLOP per appearance sample (basis 7 776 + MLP 71 936 + PE)
-    FLOP_APP_EXEC = 3 * 2 * (32 * 144 + 128 * 160 + 128 * 128)             # executed on the matrix cores: 3 fp16 products, padded tiles (layer 3 runs as fp32 VALU FMAs)
+    FLOP_APP_EXEC = n_prod * 2 * (32 * 144 + 128 * 160 + 128 * 128)        # executed on the matrix cores: 3 fp16 products (--arith f32), padded tiles (layer 3 runs as fp32 VALU FMAs)
     if args.model == "REFTensoRF":                                         # + four 144 -> {3,3,1,1} heads, 151-input layer 1
         FLOP_APP += 2 * 8 * 144 + 2 * 128
         FLOP_APP_EXEC += 3 * 2 * 32 * 144
@@ -665,7 +711,9 @@ def main():
         "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak" if (world > 1 and not strong) else "strong",          # default: ONE frame per step at every N (total work fixed)
-        "vs_baseline": None, "dtype": "f32 (emulated: 3 x f16-split MFMA products, fp32 accumulate; fp32 VALU elsewhere)", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"f32": "f32 (emulated: 3 x f16-split MFMA products, fp32 accumulate; fp32 VALU elsewhere)",
+                                       "f16act": "f16 activations x f32-class weights (2 x f16 MFMA products, fp32 accumulate; fp32 VALU elsewhere) - opt-in mode, not the headline",
+                                       "f16": "f16 operands (1 MFMA product, fp32 accumulate; fp32 VALU elsewhere) - opt-in mode, not the headline"}[args.arith], "data": "synthetic",
         "config": {"workload": ("TensorVMSplit 300^3 (16/48 comps, MLP_Fea 150-128-128-3)" if args.model == "TensorVMSplit" else
                                 "REFTensoRF 300^3 (16/48 comps, 4 heads on h, MLP_Fea_Ref 151-128-128-3)") +
                                f", {args.img}x{args.img} rays x 512 samples/ray (BASELINE configs[1]); {mode}, {TILE}-ray tiles round-robin, one RCCL "
@@ -673,7 +721,7 @@ def main():
                    "scene": "synthetic scene A (SURVEY 8d), no alpha mask, white_bg",
                    "rays_per_step": rays_job, "samples_per_ray": S, "rays_per_rank": n_mine,
                    "eps_T": float(model.rayMarch_weight_thres) if args.eps_T is None else args.eps_T, "tile": TILE,
-                   "chunk": args.chunk if args.chunk > 0 else n_mine, "alpha_mask": args.alpha_mask, "emulate_world": args.emulate_world},
+                   "chunk": args.chunk if args.chunk > 0 else n_mine, "alpha_mask": args.alpha_mask, "emulate_world": args.emulate_world, "arith": args.arith},
         "rays_per_sec": rays_job * args.steps / dt,
         "effective": {"density_samples_evaluated_per_sec": m_eval * world * args.steps / dt,
                       "appearance_samples_per_sec": m_app * world * args.steps / dt,
@@ -700,6 +748,8 @@ def main():
     # The other single-GPU lines of BASELINE.json, measured by THIS run (child processes of this script, after the timed region, so that whoever runs the
     # default command also gets them): configs[3] = the same frame as 157 direct 4096-ray tvr_render calls (train.py's batch size, no chunk merging),
     # configs[4] = the JNeRF Instant-NGP alt path.  Informational: `value` above is configs[1].
+    if rank == 0 and world == 1 and default_workload and not args.no_extras and args.arith == "f32":
+        result["arith_modes"] = arith_modes(model, step_rays, S, args.eps_T)
     if rank == 0 and world == 1 and default_workload and not args.no_extras and not args.no_cpu_baseline:
         result["other_configs"] = other_configs()
     L.lib().tvr_profile_destroy(prof)

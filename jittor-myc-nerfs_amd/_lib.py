@@ -89,6 +89,8 @@ SYMBOLS = {
     "tvr_scene_set_alpha": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_float * 6),
                                       C.POINTER(C.c_float * 3), C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_scene_set_range_check": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tvr_scene_set_arith": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tvr_scene_get_arith": (C.c_int, [C.c_void_p]),
     "tvr_scene_destroy": (C.c_int, [C.c_void_p]),
     "tvr_render_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "tvr_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float,

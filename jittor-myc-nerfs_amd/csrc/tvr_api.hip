@@ -165,6 +165,7 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
     v.act = desc->fea2dense_act;
     v.variant = desc->variant;
     v.range_check = 1;
+    v.arith = TVR_ARITH_F32;
     v.avol = nullptr;
     *out = s;
     return TVR_OK;
@@ -250,6 +251,20 @@ int tvr_scene_set_range_check(tvr_scene *s, int32_t on)
     if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_set_range_check: scene is NULL");
     s->dev.range_check = on ? 1 : 0;
     return TVR_OK;
+}
+
+int tvr_scene_set_arith(tvr_scene *s, int32_t mode)
+{
+    if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_set_arith: scene is NULL");
+    if (mode != TVR_ARITH_F32 && mode != TVR_ARITH_F16ACT && mode != TVR_ARITH_F16) return fail(TVR_ERR_INVALID, "tvr_scene_set_arith: mode %d is none of TVR_ARITH_*", (int)mode);
+    s->dev.arith = mode;
+    return TVR_OK;
+}
+
+int tvr_scene_get_arith(const tvr_scene *s)
+{
+    if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_get_arith: scene is NULL");
+    return s->dev.arith;
 }
 
 int tvr_scene_destroy(tvr_scene *s)

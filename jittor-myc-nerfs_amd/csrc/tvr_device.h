@@ -79,6 +79,7 @@ struct SceneDev {
     int gen;                      // 1: more than two encoding frequencies (view_pe / fea_pe up to TVR_GEN_PE): layer 1 runs from the streamed image w1gen
     const void *w1gen;            // [26 k-steps][hi 4 KB | lo 4 KB], each [2 halves][128 rows][8 halfs]
     int range_check;              // 1 (default): the inference shade kernels mark entries whose fp16-split operands leave fp16's range with NaN (tvr_scene_set_range_check)
+    int arith;                    // TVR_ARITH_*: the products per k-step of the render / mlp_render shade kernels (tvr_scene_set_arith); 0 = three (fp32-class)
     const float *avol;            // (gz,gy,gx) or nullptr
     const unsigned *abits;        // optional: bit ((z*gy + y)*gx + x) = (avol > 0), built by tvr_scene_set_alpha
     int ag[3];

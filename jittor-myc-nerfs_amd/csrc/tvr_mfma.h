@@ -44,4 +44,23 @@ __device__ __forceinline__ Frag split8(const float v[8])
     split2(v[6], v[7], f.hi.w, f.lo.w);
     return f;
 }
-
+// the one-part form of the reduced-product arithmetics (tvr_shade.hip, AR < 3): round to nearest even, one v_cvt_pk_f16_f32 per pair; no lo part.
+// (|x| > 65504 becomes inf here, not 65504: the range check / the host's proof keeps such values out, include/tvr.h)
+__device__ __forceinline__ Frag round8(const float v[8])
+{
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    Frag f;
+    f.hi.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[0], v[1]}, f16x2));
+    f.hi.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[2], v[3]}, f16x2));
+    f.hi.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[4], v[5]}, f16x2));
+    f.hi.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[6], v[7]}, f16x2));
+    f.lo = make_uint4(0u, 0u, 0u, 0u);
+    return f;
+}
+template <int AR>
+__device__ __forceinline__ Frag frag8(const float v[8])
+{
+    if constexpr (AR >= 3) return split8(v);
+    else return round8(v);
+}

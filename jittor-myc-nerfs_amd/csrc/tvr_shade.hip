@@ -51,10 +51,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define TVR_GATHER_KEEP(s_)                                                                            \
     do {                                                                                               \
         if (RC) { _Pragma("unroll") for (int j_ = 0; j_ < 8; j_ += 2) rmax = absmax2(hvv[s_][j_], hvv[s_][j_ + 1], rmax); asm volatile("" : "+v"(rmax)); } \
-        if (!TVR_SPLIT_LATE || (s_) == 0) { hf[s_] = split8(hvv[s_]); TVR_PIN_FRAG(hf[s_]); } \
+        if (!TVR_SPLIT_LATE || (s_) == 0) { hf[s_] = frag8<ARB>(hvv[s_]); TVR_PIN_FRAG(hf[s_]); } \
         else TVR_PIN8(hvv[s_]);                                                                        \
     } while (0)
-#define TVR_PIN_FRAG(f) asm volatile("" : "+v"((f).hi.x), "+v"((f).hi.y), "+v"((f).hi.z), "+v"((f).hi.w), "+v"((f).lo.x), "+v"((f).lo.y), "+v"((f).lo.z), "+v"((f).lo.w))
+#define TVR_PIN_FRAG(f)                                                                                \
+    do {                                                                                               \
+        if constexpr (ARB >= 3) asm volatile("" : "+v"((f).hi.x), "+v"((f).hi.y), "+v"((f).hi.z), "+v"((f).hi.w), "+v"((f).lo.x), "+v"((f).lo.y), "+v"((f).lo.z), "+v"((f).lo.w)); \
+        else asm volatile("" : "+v"((f).hi.x), "+v"((f).hi.y), "+v"((f).hi.z), "+v"((f).hi.w));       /* one-product mode: the lo part has no consumer and is never computed */ \
+    } while (0)
 #ifndef TVR_PF
 #define TVR_PF 1          // gather prefetch distance in k-steps (ring of TVR_PF + 1 tap sets) ...
 #endif
@@ -205,19 +209,43 @@ __device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag &b, f32x16 a
         TVR_SG_MFMA(1); if (v2) TVR_SG_VALU(v2);                                                       \
     } while (0)
 #endif
+#ifndef TVR_L1A2_V0
+#define TVR_L1A2_V0 2     // layer-1 windows of the two-product arithmetic (two MFMAs per row block) ...
+#define TVR_L1A2_V1 4
+#endif
+#ifndef TVR_L1A1_V0
+#define TVR_L1A1_V0 6     // ... and of the one-product arithmetic
+#endif
+// the same windows for the reduced-product arithmetics (AR 2: two MFMAs and two reads per row block; AR 1: one and one)
+#define TVR_PIPE_RB2(has_read, v0, v1)                                                                 \
+    do {                                                                                               \
+        if (has_read) TVR_SG_DSR(1);                                                                   \
+        TVR_SG_MFMA(1); if (v0) TVR_SG_VALU(v0);                                                       \
+        if (has_read) TVR_SG_DSR(1);                                                                   \
+        TVR_SG_MFMA(1); if (v1) TVR_SG_VALU(v1);                                                       \
+    } while (0)
+#define TVR_PIPE_RB1(has_read, v0)                                                                     \
+    do {                                                                                               \
+        if (has_read) TVR_SG_DSR(1);                                                                   \
+        TVR_SG_MFMA(1); if (v0) TVR_SG_VALU(v0);                                                       \
+    } while (0)
 #define TVR_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
 #define TVR_SG_VALU(n) __builtin_amdgcn_sched_group_barrier(0x402, (n), 0)      // VALU | TRANS
 #define TVR_SG_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
 struct AF { uint4 h, l; };
+// AR = the products a k-step takes (tvr_scene_set_arith): 3 = Wlo*xhi + Whi*xlo + Whi*xhi (fp32-class, the default); 2 = Wlo*xhi + Whi*xhi (weights keep their
+// 22 bits, activations are rounded to fp16); 1 = Whi*xhi (plain fp16 operands).  Always fp32 accumulation.  What a mode does not multiply is neither read nor derived.
+template <int AR = 3>
 __device__ __forceinline__ void load_af(AF &A, const unsigned char *WH, const unsigned char *WL, int off)
 {
     A.h = *(const uint4 *)(WH + off);
-    A.l = *(const uint4 *)(WL + off);
+    if constexpr (AR >= 2) A.l = *(const uint4 *)(WL + off);
 }
+template <int AR = 3>
 __device__ __forceinline__ void mfma3(const AF &A, const Frag &b, f32x16 &acc)
 {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.l), __builtin_bit_cast(h8, b.hi), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h), __builtin_bit_cast(h8, b.lo), acc, 0, 0, 0);
+    if constexpr (AR >= 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.l), __builtin_bit_cast(h8, b.hi), acc, 0, 0, 0);
+    if constexpr (AR >= 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h), __builtin_bit_cast(h8, b.lo), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h), __builtin_bit_cast(h8, b.hi), acc, 0, 0, 0);
 }
 // byte offset of the A fragment of row block q & 3 of k-step q >> 2 inside a weight image
@@ -524,8 +552,10 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
         AF br_[4];                                                                                                                  \
         auto bld_ = [&](int s_) {                                                                                                   \
             br_[s_ & 3].h = *(const uint4 *)(bashp + s_ * BST_);                                                                    \
-            if (s_ < NLO) br_[s_ & 3].l = *(const uint4 *)(baslp + s_ * BST_);                                                      \
-            else br_[s_ & 3].l = bal[s_];                                                                                           \
+            if constexpr (ARB >= 2) {                                                                                                \
+                if (s_ < NLO) br_[s_ & 3].l = *(const uint4 *)(baslp + s_ * BST_);                                                  \
+                else br_[s_ & 3].l = bal[s_];                                                                                       \
+            }                                                                                                                       \
         };                                                                                                                          \
         bld_(0); bld_(1);                                                                                                           \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                            \
@@ -536,11 +566,11 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
         f32x16 accF_ = f32x16{0};                                                                                                   \
         _Pragma("unroll") for (int s_ = 0; s_ < 9; ++s_) {          /* one scheduling region per k-step: reads issued here are consumed two regions on */ \
             if (s_ + 2 < 9) bld_(s_ + 2);                                                                                           \
-            mfma3(br_[s_ & 3], hf[s_], accF_);                                                                                      \
+            mfma3<ARB>(br_[s_ & 3], hf[s_], accF_);                                                                                  \
             if (TVR_SPLIT_LATE && s_ + 1 < 9) hf[s_ + 1] = split8(hvv[s_ + 1]);                                                     \
-            if (s_ + 2 < 9) { if (s_ + 2 < NLO) TVR_SG_DSR(2); else TVR_SG_DSR(1); }                                                \
+            if (s_ + 2 < 9) { if (s_ + 2 < NLO && ARB >= 2) TVR_SG_DSR(2); else TVR_SG_DSR(1); }                                     \
             if (TVR_SPLIT_LATE && s_ + 1 < 9) { TVR_SG_MFMA(1); TVR_SG_VALU(4); TVR_SG_MFMA(1); TVR_SG_VALU(6); TVR_SG_MFMA(1); TVR_SG_VALU(6); } \
-            else TVR_SG_MFMA(3);                                                                                                    \
+            else TVR_SG_MFMA(ARB);                                                                                                   \
             TVR_SB;                                                                                                                 \
         }                                                                                                                           \
         _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) F[r_] = accF_[r_];                                                        \
@@ -553,9 +583,13 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 // values, +4 % VALU); an entry whose maximum reaches fp16's largest finite value (cvt_pkrtz saturates there, silently) gets NaN as its colour / features, so the
 // pixel it belongs to comes out NaN instead of wrong.  Weights are checked by the host (field.py::_fp16_range_proven), which also switches RC off for scenes
 // whose interval bounds prove that nothing can leave the range.
-template <int SRC, int DST, bool REF, bool RC = false, bool GEN = false>
+template <int SRC, int DST, bool REF, bool RC = false, bool GEN = false, int AR = 3>
 __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
+    static_assert(AR == 3 || (!REF && !GEN && DST != SH_DST_TRAIN && DST != SH_DST_FEAT), "the reduced-product arithmetics exist for the TensorVMSplit render and mlp_render paths");
+    // the basis product F = Bas . h keeps its three products in the two-product mode: F feeds sin / cos (d sin(2F) / dF = 2, an error of F is AMPLIFIED by |F|'s
+    // scale), whereas a rounded input of a linear layer is not (27 of the 243 MFMAs)
+    constexpr int ARB = AR == 1 ? 1 : 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -672,7 +706,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 unsigned boff = (unsigned)((h * 32 + e) * 16);
                 asm volatile("" : "+v"(boff));
 #pragma unroll
-                for (int s3 = NLO; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
+                for (int s3 = NLO; s3 < 9; ++s3) if (ARB >= 2) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
                     const float hv[8] = {hv4[s][0].x, hv4[s][0].y, hv4[s][0].z, hv4[s][0].w, hv4[s][1].x, hv4[s][1].y, hv4[s][1].z, hv4[s][1].w};
@@ -723,7 +757,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                         unsigned boff = (unsigned)((h * 32 + e) * 16);
                         asm volatile("" : "+v"(boff));
 #pragma unroll
-                        for (int s3 = NLO; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
+                        for (int s3 = NLO; s3 < 9; ++s3) if (ARB >= 2) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
                     }
                     const int p = s / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
@@ -736,7 +770,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 unsigned boff = (unsigned)((h * 32 + e) * 16);
                 asm volatile("" : "+v"(boff));
 #pragma unroll
-                for (int s3 = NLO; s3 < 9; ++s3) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
+                for (int s3 = NLO; s3 < 9; ++s3) if (ARB >= 2) bal[s3] = *(const uint4 *)((const unsigned char *)sc.basis_frag + (boff + (unsigned)(s3 * 1024)));
             }
             TVR_BASIS_BLOCK();
         } else {
@@ -841,7 +875,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     v[j] = t == 0 ? F[r] : (t == 1 ? S1[r] : (t == 2 ? 2.0f * S1[r] * C1[r]                 // sin 2v
                                   : (t == 3 ? C1[r] : __builtin_fmaf(-2.0f * S1[r], S1[r], 1.0f))));          // cos 2v
                 }
-                b = split8(v);
+                b = frag8<AR>(v);
             };
             auto relu_frag = [&](int s, Frag &b) {
                 float v[8];
@@ -852,7 +886,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
                     *(float4 *)(a.t_h1 + ent * TVR_FEATC + 16 * s + 8 + 4 * h) = make_float4(v[4], v[5], v[6], v[7]);
                 }
-                b = split8(v);
+                b = frag8<AR>(v);
             };
             Frag fr[8];                                         // relu(layer 1) as layer 2's eight B fragments (the 64 registers `acc` leaves)
             f32x16 a2cur, a2nxt;                                // layer-2 accumulators of the row block in flight / its successor's b2
@@ -925,7 +959,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 TVR_SB;
             } else {
 #pragma unroll
-            for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring[q0], W1Hb, W1Lb, TVR_AOFF(q0));
+            for (int q0 = 0; q0 < TVR_PD; ++q0) load_af<AR>(ring[q0], W1Hb, W1Lb, TVR_AOFF(q0));
             l1_frag(0, bcur);
             TVR_SB;
 #pragma unroll
@@ -933,12 +967,12 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
                     const int q = 4 * s + rb;
-                    if (q + TVR_PD < 40 && !(TVR_DIAG & 2)) load_af(ring[(q + TVR_PD) % TVR_RN], W1Hb, W1Lb, TVR_AOFF(q + TVR_PD));
-                    mfma3(ring[(TVR_DIAG & 2) ? (q & 1) : (q % TVR_RN)], bcur, acc[rb]);
+                    if (q + TVR_PD < 40 && !(TVR_DIAG & 2)) load_af<AR>(ring[(q + TVR_PD) % TVR_RN], W1Hb, W1Lb, TVR_AOFF(q + TVR_PD));
+                    mfma3<AR>(ring[(TVR_DIAG & 2) ? (q & 1) : (q % TVR_RN)], bcur, acc[rb]);
                     if (s == 9 && rb == 0) {
                         // layer 2's prologue (acc[0] is complete): b2 -> the initial accumulators, W2's first two fragment pairs, relu(acc[0]) split
 #pragma unroll
-                        for (int q0 = 0; q0 < TVR_PD; ++q0) load_af(ring2[q0], W2Hb, W2Lb, TVR_AOFF(4 * q0));
+                        for (int q0 = 0; q0 < TVR_PD; ++q0) load_af<AR>(ring2[q0], W2Hb, W2Lb, TVR_AOFF(4 * q0));
                         b2_init(0, a2cur);
                     }
                 }
@@ -947,13 +981,17 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 else { relu_frag(0, fr[0]); relu_frag(1, fr[1]); }         // acc[0] holds both k-steps' 16 hidden units
                 if (s < 9) {
 #pragma unroll
-                    for (int rb = 0; rb < 4; ++rb) TVR_PIPE_RB(4 * s + rb + TVR_PD < 40, TVR_L1_V0, TVR_L1_V1, TVR_L1_V2);
+                    for (int rb = 0; rb < 4; ++rb) {
+                        if constexpr (AR == 3) TVR_PIPE_RB(4 * s + rb + TVR_PD < 40, TVR_L1_V0, TVR_L1_V1, TVR_L1_V2);
+                        else if constexpr (AR == 2) TVR_PIPE_RB2(4 * s + rb + TVR_PD < 40, TVR_L1A2_V0, TVR_L1A2_V1);      // (the fragment is 4 cvt_pk instead of 16 split ops)
+                        else TVR_PIPE_RB1(4 * s + rb + TVR_PD < 40, TVR_L1A1_V0);
+                    }
                 } else {
-                    TVR_SG_MFMA(3);                 // row block 0
-                    TVR_SG_DSR(4 + 2 * TVR_PD);     // W2's first fragments, b2 of row block 0
-                    TVR_SG_MFMA(3);                 // row block 1: relu(acc[0]) may be read 3 MFMAs after its last write
+                    TVR_SG_MFMA(AR);                // row block 0
+                    TVR_SG_DSR(4 + (AR >= 2 ? 2 : 1) * TVR_PD);     // W2's first fragments, b2 of row block 0
+                    TVR_SG_MFMA(AR);                // row block 1: relu(acc[0]) may be read 3 MFMAs after its last write
 #pragma unroll
-                    for (int m = 0; m < 6; ++m) { TVR_SG_MFMA(1); TVR_SG_VALU(5); }
+                    for (int m = 0; m < 2 * AR; ++m) { TVR_SG_MFMA(1); if constexpr (AR == 3) TVR_SG_VALU(5); else if constexpr (AR == 2) TVR_SG_VALU(6); else TVR_SG_VALU(12); }
                 }
                 bcur = bnxt;
                 TVR_SB;
@@ -982,21 +1020,31 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) {
                         const int q = 8 * rb + ks;                  // position in the (row block, k-step) sequence; its fragment: TVR_AOFF(4 ks + rb)
-                        if (q + TVR_PD < 32) load_af(ring2[(q + TVR_PD) % TVR_RN], W2Hb, W2Lb, TVR_AOFF(4 * ((q + TVR_PD) & 7) + ((q + TVR_PD) >> 3)));
+                        if (q + TVR_PD < 32) load_af<AR>(ring2[(q + TVR_PD) % TVR_RN], W2Hb, W2Lb, TVR_AOFF(4 * ((q + TVR_PD) & 7) + ((q + TVR_PD) >> 3)));
                         if (ks == 6 && rb < 3) b2_init(rb + 1, a2nxt);
                         if (rb > 0 && !(ks & 1)) {
 #pragma unroll
                             for (int c3 = 0; c3 < 3; ++c3) w3[c3] = *(const float4 *)(W3 + c3 * 128 + 32 * (rb - 1) + 8 * (ks >> 1));
                         }
-                        mfma3(ring2[q % TVR_RN], fr[ks], a2cur);
+                        mfma3<AR>(ring2[q % TVR_RN], fr[ks], a2cur);
                         if (rb == 0) { if (ks + 2 < 8) relu_frag(ks + 2, fr[ks + 2]); }
                         else if (ks & 1) l3_quad(a2prev, rb - 1, ks >> 1);
-                        if (q + TVR_PD < 32) TVR_SG_DSR(2);
+                        if (q + TVR_PD < 32) TVR_SG_DSR(AR >= 2 ? 2 : 1);
                         if (ks == 6 && rb < 3) TVR_SG_DSR(4);
                         if (rb > 0 && !(ks & 1)) TVR_SG_DSR(3);
-                        if (rb == 0 && ks + 2 < 8) { TVR_SG_MFMA(1); TVR_SG_VALU(8); TVR_SG_MFMA(1); TVR_SG_VALU(8); TVR_SG_MFMA(1); TVR_SG_VALU(8); }
-                        else if (rb > 0 && (ks & 1)) { TVR_SG_MFMA(1); TVR_SG_VALU(5); TVR_SG_MFMA(1); TVR_SG_VALU(5); TVR_SG_MFMA(1); TVR_SG_VALU(6); }
-                        else TVR_SG_MFMA(3);
+                        if constexpr (AR == 3) {
+                            if (rb == 0 && ks + 2 < 8) { TVR_SG_MFMA(1); TVR_SG_VALU(8); TVR_SG_MFMA(1); TVR_SG_VALU(8); TVR_SG_MFMA(1); TVR_SG_VALU(8); }
+                            else if (rb > 0 && (ks & 1)) { TVR_SG_MFMA(1); TVR_SG_VALU(5); TVR_SG_MFMA(1); TVR_SG_VALU(5); TVR_SG_MFMA(1); TVR_SG_VALU(6); }
+                            else TVR_SG_MFMA(3);
+                        } else if constexpr (AR == 2) {       // relu_frag is 8 max + 4 cvt_pk here; layer 3's quad 4 max + 12 FMA as ever
+                            if (rb == 0 && ks + 2 < 8) { TVR_SG_MFMA(1); TVR_SG_VALU(6); TVR_SG_MFMA(1); TVR_SG_VALU(6); }
+                            else if (rb > 0 && (ks & 1)) { TVR_SG_MFMA(1); TVR_SG_VALU(8); TVR_SG_MFMA(1); TVR_SG_VALU(8); }
+                            else TVR_SG_MFMA(2);
+                        } else {
+                            if (rb == 0 && ks + 2 < 8) { TVR_SG_MFMA(1); TVR_SG_VALU(12); }
+                            else if (rb > 0 && (ks & 1)) { TVR_SG_MFMA(1); TVR_SG_VALU(16); }
+                            else TVR_SG_MFMA(1);
+                        }
                         TVR_SB;
                     }
                     a2prev = a2cur;
@@ -1037,14 +1085,14 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_APP], (unsigned long long)n_total);
 }
 
-template <int SRC, int DST, bool REF, bool RC, bool GEN = false>
+template <int SRC, int DST, bool REF, bool RC, bool GEN = false, int AR = 3>
 static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
     constexpr bool BAS_ONLY = DST == SH_DST_FEAT && !REF;
     constexpr int NLO = REF ? 0 : (BAS_ONLY ? 9 : TVR_NLO_LDS);
     const int lds = (REF ? TVR_MLP_IMAGE_BYTES_REF : (BAS_ONLY ? (TVR_MLP_IMAGE_BYTES - TVR_IMG_BASH) : TVR_MLP_IMAGE_BYTES)) + 16 + NLO * 2 * TVR_IMG_BASH_ROWS * 16;
     static_assert((REF ? TVR_MLP_IMAGE_BYTES_REF : TVR_MLP_IMAGE_BYTES) + 16 + (REF ? 0 : TVR_NLO_LDS) * 2 * TVR_IMG_BASH_ROWS * 16 <= 160 * 1024, "LDS image + tokens + basis lo parts must fit 160 KB");
-    hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF, RC, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t rc = hipFuncSetAttribute((const void *)shade_kernel<SRC, DST, REF, RC, GEN, AR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc != hipSuccess) return rc;
     unsigned grid = 256;       // one workgroup per CU (LDS holds the MLP weights), persistent over SH_TILE-entry tiles
 #ifdef TVR_EXP_GRID                                             // scripts/overlap_experiment.py only: a build_variant.sh -DTVR_EXP_GRID library
@@ -1054,8 +1102,17 @@ static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStre
         const long long groups = (a.n + SH_TILE * SH_WAVES - 1) / (SH_TILE * SH_WAVES);
         if (groups < grid) grid = (unsigned)(groups > 0 ? groups : 1);
     }
-    hipLaunchKernelGGL((shade_kernel<SRC, DST, REF, RC, GEN>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
+    hipLaunchKernelGGL((shade_kernel<SRC, DST, REF, RC, GEN, AR>), dim3(grid), dim3(SH_THREADS), lds, stream, sc, a);
     return hipGetLastError();
+}
+
+// the TensorVMSplit render / mlp_render kernels in the scene's arithmetic (tvr_scene_set_arith); every other path computes with three products whatever the mode
+template <int SRC, int DST, bool RC>
+static hipError_t launch_shade_ar(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
+{
+    if (sc.arith == TVR_ARITH_F16ACT) return launch_shade_t<SRC, DST, false, RC, false, 2>(sc, a, stream);
+    if (sc.arith == TVR_ARITH_F16) return launch_shade_t<SRC, DST, false, RC, false, 1>(sc, a, stream);
+    return launch_shade_t<SRC, DST, false, RC, false, 3>(sc, a, stream);
 }
 
 template <bool REF>
@@ -1067,6 +1124,9 @@ static hipError_t launch_shade_v(const SceneDev &sc, int src, int dst, const Sha
             if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false, true, true>(sc, a, stream) : launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false, false, true>(sc, a, stream);
             if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false, true, true>(sc, a, stream) : launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false, false, true>(sc, a, stream);
             if (src == SH_SRC_H && dst == SH_DST_TRAIN) return hipErrorInvalidValue;
+        } else {
+            if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, true>(sc, a, stream) : launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, false>(sc, a, stream);
+            if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_ar<SH_SRC_FEAT, SH_DST_RGB, true>(sc, a, stream) : launch_shade_ar<SH_SRC_FEAT, SH_DST_RGB, false>(sc, a, stream);
         }
     }
     if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, REF, false>(sc, a, stream);

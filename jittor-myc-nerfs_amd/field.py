@@ -302,6 +302,7 @@ class TensorBase(torch.nn.Module):
             self._scene = h
             self._sig = None
             self._alpha_dirty = True
+            self._arith_set = None
         if force or sig != self._sig:
             for p in ps:
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.device != self._packed.device:
@@ -332,7 +333,20 @@ class TensorBase(torch.nn.Module):
                 L.check(lib.tvr_scene_set_alpha(self._scene, am.alpha_volume.data_ptr(), C.byref(ag), C.byref(ab), C.byref(inv),
                                                 self._alpha_bits.data_ptr(), self._alpha_bits.numel(), _stream_ptr(self.device)), "tvr_scene_set_alpha")
             self._alpha_dirty = False
+        if getattr(self, "_arith_set", None) != self.mlp_arith:
+            if self.mlp_arith not in self._ARITH:
+                raise ValueError(f"mlp_arith must be one of {sorted(self._ARITH)}, got {self.mlp_arith!r}")
+            L.check(lib.tvr_scene_set_arith(self._scene, self._ARITH[self.mlp_arith]), "tvr_scene_set_arith")
+            self._arith_set = self.mlp_arith
         return self._scene
+
+    # ---- arithmetic of the appearance network's matrix products at inference (include/tvr.h, tvr_scene_set_arith) ------------------------
+    # "f32" (default): three fp16 products per fp32 product, fp32-class — what every parity number in DESIGN.md is quoted on.  "f16act": activations rounded to
+    # fp16, weights keep 22 bits (two products).  "f16": plain fp16 operands (one product).  fp32 accumulation throughout; the reduced modes are opt-in trades
+    # inside north_star's 1e-3 RGB bar (tests/test_gpu_arith.py) and apply to render_rays / forward(is_train=False) / the renderModule of a
+    # TensorVMSplit scene with at most two encoding frequencies; everything else computes in "f32" whatever this says.
+    mlp_arith = "f32"
+    _ARITH = {"f32": 0, "f16act": 1, "f16": 2}
 
     # ---- fp16 range of the inference kernels (include/tvr.h, tvr_render) --------------------------------------------------------------
     # The appearance network's matrix products take their operands through fp16 (hi + lo parts): |x| must stay below 65 504.  The kernels can check that on

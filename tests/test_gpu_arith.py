@@ -1,0 +1,144 @@
+"""GPU (-m gpu): the opt-in arithmetics of the appearance network's matrix products (include/tvr.h, tvr_scene_set_arith; field.py `mlp_arith`).
+
+The default ("f32": three fp16 products per fp32 product) is what every other parity test holds.  The reduced modes trade matrix work for rounding:
+  "f16act"  layers 1 and 2 take their activations rounded to fp16 (weights keep hi + lo; the basis product keeps three products), two products;
+  "f16"     plain fp16 operands everywhere, one product.
+Both must stay inside north_star's bar (RGB L-inf 1e-3 against the fp32 reference path) with the margin written below, must not move anything
+the march decides (positions, masks, weights, depth: bit-identical to the default mode), and must leave every other entry point alone."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TINY, make_model
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-3                                  # north_star
+BAR = {"f32": 2e-4, "f16act": 3e-4, "f16": 5e-4}  # what the tests hold per mode against the oracle's fp32 pictures (measured: 5e-5 / 7e-5 / 1.2e-4, one weight-threshold flip = 1e-4)
+MODES = ("f32", "f16act", "f16")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_modes_on_the_fixtures_against_the_oracle_pictures(tiny_dump, tiny_arrays, hyper_tiny, config1_golden):
+    from jittor_myc_nerfs_amd import synthetic
+    B = synthetic.SCENE_B
+    arrs1 = synthetic.make_scene_arrays(B["gridSize"], B["aabb"])
+    hyper1 = dict(synthetic.HYPER, near_far=B["near_far"], step_ratio=B["step_ratio"])
+    cases = [("tiny_dump", make_model(tiny_arrays, hyper_tiny), tiny_dump["rays"], TINY["N_samples"], tiny_dump["out.rgb_map"], tiny_dump["out.depth_map"]),
+             ("config1", make_model(arrs1, hyper1), config1_golden["rays"], B["N_samples"], config1_golden["rgb_map"], None)]
+    for name, m, rays, S, want_rgb, want_depth in cases:
+        rays = torch.tensor(rays, device="cuda")
+        base = None
+        for mode in MODES:
+            m.mlp_arith = mode
+            rgb, depth, d = m.render_rays(rays, white_bg=True, N_samples=S, eps_T=0.0, dense=True)
+            err = np.abs(_np(rgb) - want_rgb).max()
+            per_sample = np.abs(_np(d["rgb"]) - tiny_dump["out.rgb"]).max() if name == "tiny_dump" else float("nan")
+            print(f"{name} {mode}: rgb_map L-inf vs oracle {err:.2e}, per-sample rgb {per_sample:.2e}")
+            assert err < BAR[mode] < RGB_TOL, (name, mode, err)
+            assert bool(torch.isfinite(rgb).all())
+            cur = (depth, d["z"], d["valid"], d["weight"], d["acc"])
+            if base is None:
+                base = cur
+            else:                                                   # the march does not know the mode: what it decides is the same bits
+                for a, b in zip(base, cur):
+                    assert torch.equal(a, b)
+        assert L_get(m) == 2
+        m.mlp_arith = "f32"
+        rgb_back, _ = m.render_rays(rays, white_bg=True, N_samples=S, eps_T=0.0)
+        assert L_get(m) == 0 and np.abs(_np(rgb_back) - want_rgb).max() < BAR["f32"]
+
+
+def L_get(m):
+    from jittor_myc_nerfs_amd import _lib as L
+    return L.lib().tvr_scene_get_arith(m._scene)
+
+
+def test_modes_at_full_size_against_the_default_mode_and_the_oracle():
+    """BASELINE configs[1]: the whole 800x800 frame per mode against the default mode's frame (all 640 000 rays), and 4096 random rays against the scalar oracle."""
+    from jittor_myc_nerfs_amd import rays as R, synthetic
+    from oracle import c_oracle as CO, tensorf_oracle as TO
+    A = synthetic.SCENE_A
+    arrs = synthetic.make_scene_arrays(A["gridSize"], A["aabb"])
+    hyper = dict(synthetic.HYPER, near_far=A["near_far"], step_ratio=A["step_ratio"])
+    m = make_model(arrs, hyper)
+    rays = R.frame_rays(R.sphere_poses(8, A["cam_radius"])[0], 800, 800, A["camera_angle_x"]).cuda()
+    sel = torch.randperm(640000, generator=torch.Generator().manual_seed(3))[:4096].cuda()
+    sc = TO.scene_from_arrays(arrs, **hyper)
+    co = CO.COracle(arrs, step=float(sc.stepSize), **hyper)
+    ref = co.render(_np(rays[sel]), A["N_samples"], white_bg=True, nthreads=16)
+    pics = {}
+    for mode in MODES:
+        m.mlp_arith = mode
+        rgb, depth = m.render_rays(rays, white_bg=True, N_samples=A["N_samples"])
+        rgb2, depth2 = m.render_rays(rays, white_bg=True, N_samples=A["N_samples"])
+        assert torch.equal(rgb, rgb2) and torch.equal(depth, depth2)              # deterministic in every mode
+        pics[mode] = (rgb, depth)
+        e_or = np.abs(_np(rgb[sel]) - ref["rgb_map"]).max()
+        e_def = float((rgb - pics["f32"][0]).abs().max())
+        print(f"full size {mode}: RGB L-inf vs oracle (4096 rays) {e_or:.2e}, vs the default mode (640 000 rays) {e_def:.2e}, mean {float((rgb - pics['f32'][0]).abs().mean()):.2e}")
+        assert e_or < BAR[mode] < RGB_TOL
+        assert e_def < BAR[mode]
+        assert torch.equal(depth, pics["f32"][1])
+    # chunk / batch-order invariance holds in the reduced modes too (a sample's arithmetic does not depend on its tile)
+    m.mlp_arith = "f16act"
+    perm = torch.randperm(640000, generator=torch.Generator().manual_seed(7)).cuda()
+    rgb_p, _ = m.render_rays(rays[perm].contiguous(), white_bg=True, N_samples=A["N_samples"])
+    assert torch.equal(rgb_p, pics["f16act"][0][perm])
+
+
+def test_mlp_render_in_every_mode_and_what_the_modes_leave_alone(tiny_dump, tiny_arrays, hyper_tiny):
+    """tvr_mlp_render (MLPRender_Fea.execute, tensorBase.py:76-86) follows the mode; tvr_app_feature and the training forward never do."""
+    m = make_model(tiny_arrays, hyper_tiny)
+    xyz = torch.tensor(tiny_dump["app_xyz_norm"], device="cuda")
+    dirs = torch.tensor(tiny_dump["app_dirs"], device="cuda")
+    feat = torch.tensor(tiny_dump["app_feature"], device="cuda")
+    f0 = m.compute_appfeature(xyz)
+    rays = torch.tensor(tiny_dump["rays"], device="cuda")
+    errs = {}
+    for mode, bar in (("f32", 1e-5), ("f16act", 3e-4), ("f16", 6e-4)):
+        m.mlp_arith = mode
+        with torch.no_grad():
+            rgb = m.renderModule(xyz, dirs, feat)
+        e = np.abs(_np(rgb) - tiny_dump["app_rgb"]).max()
+        print(f"mlp_render {mode}: per-sample rgb L-inf vs oracle {e:.2e}")
+        assert e < bar
+        errs[mode] = e
+        assert torch.equal(m.compute_appfeature(xyz), f0)                         # xyz -> features: three products whatever the mode
+    assert errs["f32"] < errs["f16act"] < errs["f16"]                             # (the modes really are different kernels)
+    m.mlp_arith = "f16"
+    m.train()
+    torch.manual_seed(0)
+    out_a = m(rays, is_train=True, white_bg=True, N_samples=TINY["N_samples"])[0].detach().clone()
+    m.mlp_arith = "f32"
+    torch.manual_seed(0)
+    out_b = m(rays, is_train=True, white_bg=True, N_samples=TINY["N_samples"])[0].detach().clone()
+    assert torch.equal(out_a, out_b)                                              # the training forward computes fp32-class in every mode
+
+
+def test_mode_is_validated_and_survives_a_repack(tiny_arrays, hyper_tiny, tiny_dump):
+    from jittor_myc_nerfs_amd import _lib as L
+    m = make_model(tiny_arrays, hyper_tiny)
+    rays = torch.tensor(tiny_dump["rays"], device="cuda")
+    m.mlp_arith = "bf16"
+    with pytest.raises(ValueError):
+        m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
+    m.mlp_arith = "f16act"
+    a, _ = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
+    assert L.lib().tvr_scene_set_arith(m._scene, 7) == -1 and b"TVR_ARITH" in L.lib().tvr_last_error()     # TVR_ERR_INVALID
+    assert L.lib().tvr_scene_get_arith(m._scene) == 1
+    with torch.no_grad():
+        m.app_plane[0].mul_(1.0)                                                  # bumps the version counter: the scene is re-packed, the mode stays
+    b, _ = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
+    assert torch.equal(a, b) and L.lib().tvr_scene_get_arith(m._scene) == 1
+    # REFTensoRF / more than two encoding frequencies: accepted, and computed with three products (tvr.h)
+    from jittor_myc_nerfs_amd import TensorVMSplit
+    g = TensorVMSplit(tiny_arrays["aabb"], [int(x) for x in tiny_arrays["gridSize"]], "cuda", density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
+                      near_far=hyper_tiny["near_far"], shadingMode="MLP_Fea", pos_pe=6, view_pe=4, fea_pe=4, featureC=128, step_ratio=hyper_tiny["step_ratio"])
+    r0, _ = g.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
+    g.mlp_arith = "f16"
+    r1, _ = g.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
+    assert torch.equal(r0, r1)

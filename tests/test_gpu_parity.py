@@ -123,8 +123,11 @@ def test_feature_apis_against_golden_and_oracle(tiny_dump, tiny_arrays, hyper_ti
     f = m.compute_appfeature(xyz)
     assert f.shape == (xyz.shape[0], 27)
     assert np.abs(_np(f) - tiny_dump["app_feature"]).max() < 1e-4 * max(1.0, np.abs(tiny_dump["app_feature"]).max())
-    rgb = m.renderModule(xyz, torch.tensor(tiny_dump["app_dirs"], device="cuda"), torch.tensor(tiny_dump["app_feature"], device="cuda"))
+    with torch.no_grad():                                          # tvr_mlp_render (with gradients enabled the module runs library GEMMs under autograd instead)
+        rgb = m.renderModule(xyz, torch.tensor(tiny_dump["app_dirs"], device="cuda"), torch.tensor(tiny_dump["app_feature"], device="cuda"))
     assert np.abs(_np(rgb) - tiny_dump["app_rgb"]).max() < 1e-5
+    rgb_ag = m.renderModule(xyz, torch.tensor(tiny_dump["app_dirs"], device="cuda"), torch.tensor(tiny_dump["app_feature"], device="cuda"))
+    assert rgb_ag.requires_grad and np.abs(_np(rgb_ag) - tiny_dump["app_rgb"]).max() < 1e-5
     # arbitrary coordinates incl. outside [-1,1] (zeros padding) and exactly on the faces; ragged + empty sizes
     sc = TO.scene_from_arrays(tiny_arrays, **hyper_tiny)
     co = CO.COracle(tiny_arrays, step=float(sc.stepSize), **hyper_tiny)

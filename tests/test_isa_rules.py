@@ -11,7 +11,7 @@ from conftest import ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 LIB = os.path.join(ROOT, "jittor-myc-nerfs_amd", "lib", "libtvr.so")
-GEN = "Lb1EEv8SceneDev"          # shade_kernel<SRC, DST, REF, RC, GEN = true>: the lockstep layer 1 of scenes with more than two encoding frequencies fetches W1's next
+GEN = "Lb1ELi3EEv8SceneDev"     # shade_kernel<SRC, DST, REF, RC, GEN = true, AR = 3>: the lockstep layer 1 of scenes with more than two encoding frequencies fetches W1's next
                                  # k-step from global memory between its MFMAs — by design outside the phase rule (csrc/tvr_shade.hip), and not the measured path
 
 
@@ -29,8 +29,9 @@ def report():
 
 def test_every_shade_kernel_variant_is_audited(report):
     # {queue, xyz->features, features->rgb} x {fp16 range check on, off} + the training forward (h -> rgb + activations), each x {TensorVMSplit, REFTensoRF},
+    # + the render and mlp_render kernels of TensorVMSplit in the two reduced-product arithmetics (2 kernels x 2 range-check states x 2 modes)
     # + the backward kernels (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps)
-    assert len(report) == 18, sorted(report)
+    assert len(report) == 26, sorted(report)
 
     assert all(v["mfma"] >= 27 for v in report.values())
 
