@@ -327,7 +327,7 @@ def _pmc_kernel(pmc, prefix):
     return {}
 
 
-def arith_modes(model, step_rays, S, eps_T, steps=8):
+def arith_modes(model, step_rays, S, eps_T, m_app, steps=8):
     """The opt-in arithmetics of the appearance network (include/tvr.h, tvr_scene_set_arith) on the bench frame, behind the timed region: kernel times
     (HIP events of the library's own profile, `steps` frames over the poses) and the picture's distance from the default (fp32-class) mode's on ALL rays of
     every pose.  Informational: `value` is the default mode's."""
@@ -351,7 +351,9 @@ def arith_modes(model, step_rays, S, eps_T, steps=8):
             L.lib().tvr_profile_destroy(prof)
             pics = [model.render_rays(r, white_bg=True, N_samples=S, eps_T=eps_T)[0] for r in step_rays]
             o = {"ms_per_frame": dt * 1e3, "kernel_ms": {"march": ms[0] / n, "shade": ms[1] / n, "composite": ms[2] / n},
-                 "ray_samples_per_sec": step_rays[0].shape[0] * S / dt}
+                 "ray_samples_per_sec": step_rays[0].shape[0] * S / dt,
+                 # the same algorithmic 80 kFLOP per appearance sample against the same dense-f16 peak as roofline.shade
+                 "shade_frac_of_dense_f16_peak": (8.0e4 * m_app / (ms[1] / n * 1e-3) / 1e12 / 2500.0) if ms[1] > 0 and m_app > 0 else None}
             if ref is None:
                 ref = pics
             else:
@@ -749,7 +751,7 @@ def main():
     # default command also gets them): configs[3] = the same frame as 157 direct 4096-ray tvr_render calls (train.py's batch size, no chunk merging),
     # configs[4] = the JNeRF Instant-NGP alt path.  Informational: `value` above is configs[1].
     if rank == 0 and world == 1 and default_workload and not args.no_extras and args.arith == "f32":
-        result["arith_modes"] = arith_modes(model, step_rays, S, args.eps_T)
+        result["arith_modes"] = arith_modes(model, step_rays, S, args.eps_T, m_app)
     if rank == 0 and world == 1 and default_workload and not args.no_extras and not args.no_cpu_baseline:
         result["other_configs"] = other_configs()
     L.lib().tvr_profile_destroy(prof)
