@@ -26,6 +26,8 @@
 // (hi·hi + hi·lo + lo·hi, fp32 accumulate): ~2^-22 relative error per product — fp32-class accuracy at 16/3 the rate of
 // the fp32-input MFMA.  Range: operands pass through fp16, so |x| <= 65504 (cvt_pkrtz saturates) and parts below 6e-8 flush;
 // features up to |v| ~ 1e3 and the reference's 1e-4-scale initialisation are tested (tests/test_gpu_parity.py); leaving the range is never silent (template parameter RC, include/tvr.h).
+// Template parameter AR (tvr_scene_set_arith): the render and mlp_render kernels of TensorVMSplit also exist with TWO products in layers 1 and 2 (their inputs
+// rounded to fp16, weights hi + lo; the basis product keeps three) and with ONE product everywhere — opt-in trades inside the 1e-3 RGB bar for a kernel that is power-bound.
 //
 // Phase rule: a round-1 build that issued global loads between the MFMAs of a tile returned wrong 16-lane groups on
 // some boxes.  The mechanism was not established (round 2: the candidate mechanisms are excluded by probes, and that build renders clean
