@@ -128,6 +128,8 @@ int tvr_scene_set_range_check(tvr_scene *scene, int32_t on);
  *   TVR_ARITH_F16ACT layers 1 and 2 take two products — weights keep hi + lo (22 bits), their inputs (features, encoded values, relu outputs) are rounded to
  *                    fp16 (nearest even, 2^-12 relative); the basis product keeps three (its outputs feed sin / cos, where an error is amplified): 0.70 of the matrix work;
  *   TVR_ARITH_F16    one product — weights and activations as plain fp16: 1/3 of the matrix work.
+ * fp16 rounding is RELATIVE: the reduced modes' absolute error grows with the scale of the features and hidden activations (|feature| <= 23: picture within 6.4e-5 / 3.5e-4
+ * of the fp32 path in F16ACT / F16; |feature| ~ 230: 6.5e-4 / 1.5e-3) — a scene with unusually large features keeps the default.
  * The reduced modes are OPT-IN trades inside north_star's parity bar (RGB L-inf 1e-3 against the fp32 path): measured against TVR_ARITH_F32 on the 800x800 bench frame
  * and against the oracle on the fixtures, see DESIGN.md 4.7 and tests/test_gpu_arith.py for the numbers and the bars the tests hold.  Layer 3, encoding, interpolation,
  * density, compositing: fp32 in every mode.  Every other entry point (tvr_app_feature, the training forwards, REFTensoRF scenes, scenes with more than two encoding
