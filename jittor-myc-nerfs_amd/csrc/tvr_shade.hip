@@ -161,7 +161,7 @@ __device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag &b, f32x16 a
 // token wait and layer 3 are on the same critical chain as the matrix phase, and a lone wave's hidden layers run at 39 cycles per MFMA whatever the order of their
 // instructions (32.5 without the fragment derivation, 32.1 without the fragment reads, 38.8 with both: gpurun_out/r4f) — issue-bound, not pipe-bound.
 #ifndef TVR_DIAG
-#define TVR_DIAG 0        // diagnostic builds only (wrong pictures): 1 = no fragment derivation in the hidden layers, 2 = no A-fragment reads
+#define TVR_DIAG 0        // diagnostic builds only (wrong pictures): 1 = no fragment derivation in the hidden layers, 2 = no A-fragment reads in layer 1, 4 = layer 1 reads k-step 0's fragments in every k-step (the same LDS traffic, constant operands)
 #endif
 #define TVR_NV1 3         // VALU (+ transcendental) instructions behind each MFMA of layer 1's last k-step (layer 2's first fragment)
 // The three MFMA windows of a row block: TVR_PIPE 1 puts one fragment read in each of the first two windows and V0 / V1 / V2 VALU instructions behind the three
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
                     const int q = 4 * s + rb;
-                    if (q + TVR_PD < 40 && !(TVR_DIAG & 2)) load_af<AR>(ring[(q + TVR_PD) % TVR_RN], W1Hb, W1Lb, TVR_AOFF(q + TVR_PD));
+                    if (q + TVR_PD < 40 && !(TVR_DIAG & 2)) load_af<AR>(ring[(q + TVR_PD) % TVR_RN], W1Hb, W1Lb, TVR_AOFF((TVR_DIAG & 8) ? 0 : ((TVR_DIAG & 4) ? ((q + TVR_PD) & 3) : q + TVR_PD)));
                     mfma3<AR>(ring[(TVR_DIAG & 2) ? (q & 1) : (q % TVR_RN)], bcur, acc[rb]);
                     if (s == 9 && rb == 0) {
                         // layer 2's prologue (acc[0] is complete): b2 -> the initial accumulators, W2's first two fragment pairs, relu(acc[0]) split
