@@ -188,6 +188,7 @@ class ShardedFramePipeline:
         self.out = [None, None]
         self.graphs = {}
         self.k = 0
+        self._waited = None          # (buffer index, stream) of the exchange event the current stream was last made to wait for, if nothing was enqueued since
         self._gloo = bool(exchange == "dist" and dist.is_initialized() and dist.get_backend(group) == "gloo")
 
     def _render(self, sub, b):
@@ -250,8 +251,9 @@ class ShardedFramePipeline:
         reads that storage).  Returns the (rgb [R,3], depth [R]) of the frame submitted one call earlier, or None."""
         b = self.k % 2
         cur = torch.cuda.current_stream(self.dev)
-        if self.busy[b]:
+        if self.busy[b] and self._waited != (b, cur.cuda_stream):     # (the previous submit already made this stream wait for that very event: one barrier packet less per frame)
             cur.wait_event(self.exchanged[b])                         # the exchange that last read this send buffer is done before it is rendered into again
+        self._waited = None
         self._replay(key, sub_rays, b)
         prev = None
         if self.exchange:
@@ -265,6 +267,7 @@ class ShardedFramePipeline:
             if self.k > 0:
                 cur.wait_event(self.exchanged[pb])                    # frame k - 1's pixels are complete for whatever the caller enqueues next
                 prev = self.out[pb]
+                self._waited = (pb, cur.cuda_stream)
         else:
             prev = (self.views[1 - b][0], self.views[1 - b][1]) if self.k > 0 else None
         self.k += 1
