@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 119
+#define TVR_VERSION 120
 
 typedef enum {
     TVR_OK = 0,
@@ -132,7 +132,7 @@ int tvr_scene_set_range_check(tvr_scene *scene, int32_t on);
  * of the fp32 path in F16ACT / F16; |feature| ~ 230: 6.5e-4 / 1.5e-3) — a scene with unusually large features keeps the default.
  * The reduced modes are OPT-IN trades inside north_star's parity bar (RGB L-inf 1e-3 against the fp32 path): measured against TVR_ARITH_F32 on the 800x800 bench frame
  * and against the oracle on the fixtures, see DESIGN.md 4.7 and tests/test_gpu_arith.py for the numbers and the bars the tests hold.  Layer 3, encoding, interpolation,
- * density, compositing: fp32 in every mode.  Every other entry point (tvr_app_feature, the training forwards, REFTensoRF scenes, scenes with more than two encoding
+ * density, compositing: fp32 in every mode.  (NerfPlusPlus's background network has the same switch in its descriptor: tvr_mlpnet_desc.arith.)  Every other entry point (tvr_app_feature, the training forwards, REFTensoRF scenes, scenes with more than two encoding
  * frequencies) computes with three products whatever the mode says.  Range: as for the default (|x| < 65 504); a rounded activation beyond it becomes inf, and
  * the range check marks its sample NaN as in the default mode. */
 enum { TVR_ARITH_F32 = 0, TVR_ARITH_F16ACT = 1, TVR_ARITH_F16 = 2 };
@@ -370,6 +370,8 @@ typedef struct tvr_mlpnet_desc {
     int32_t pos_freqs;          /* bg_freq: the 4-vector point gets 4 + 8*pos_freqs inputs */
     int32_t view_freqs;         /* bg_view_freq (2): 3 + 6*view_freqs inputs */
     int32_t samples_per_ray;    /* sample s uses viewdirs[s / samples_per_ray] */
+    int32_t arith;              /* TVR_ARITH_* (above) of tvr_mlpnet_forward: 0 = three fp16 products per fp32 product (fp32-class, the default); F16ACT = every layer's inputs
+                                 * rounded to fp16, weights hi + lo; F16 = plain fp16 operands.  tvr_mlpnet_train_forward computes fp32-class whatever this says */
 } tvr_mlpnet_desc;
 
 typedef struct tvr_mlpnet_params {   /* fp32 device pointers, row-major [out,in] as torch / Jittor Linear */

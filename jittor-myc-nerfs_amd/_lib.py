@@ -50,7 +50,7 @@ class DenseOut(C.Structure):
 
 
 class MlpnetDesc(C.Structure):           # tvr_mlpnet_desc
-    _fields_ = [(n, C.c_int32) for n in ("D", "W", "skip", "pos_freqs", "view_freqs", "samples_per_ray")]
+    _fields_ = [(n, C.c_int32) for n in ("D", "W", "skip", "pos_freqs", "view_freqs", "samples_per_ray", "arith")]
 
 
 class MlpnetParams(C.Structure):         # tvr_mlpnet_params

@@ -85,6 +85,7 @@ __device__ __forceinline__ float pe_feature(int f, const float x[4])
     const float a = x[r & 3] * (float)(1 << q);
     return r < 4 ? __sinf(a) : __cosf(a);
 }
+template <int AR>
 __device__ __forceinline__ Frag pe_frag(int t, int hh, const float x[4])
 {
     float v[8];
@@ -93,15 +94,16 @@ __device__ __forceinline__ Frag pe_frag(int t, int hh, const float x[4])
         const float lo = pe_feature(16 * t + j, x), hi = pe_feature(16 * t + 8 + j, x);
         v[j] = hh ? hi : lo;
     }
-    return split8(v);
+    return frag8<AR>(v);
 }
 // B fragment of k-step t (0..7) of a 128-wide activation held in four accumulators, relu applied
+template <int AR>
 __device__ __forceinline__ Frag relu_frag4(const f32x16 a[4], int t)
 {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = relu_f(a[t >> 1][8 * (t & 1) + j]);
-    return split8(v);
+    return frag8<AR>(v);
 }
 __device__ __forceinline__ f32x16 bias_acc(const float *__restrict__ bias32, int hh)
 {
@@ -114,36 +116,42 @@ __device__ __forceinline__ f32x16 bias_acc(const float *__restrict__ bias32, int
     }
     return a;
 }
-// one k-step into NB accumulators (independent blocks: their MFMAs interleave): A fragments from LDS, then 3 products per block
+// one k-step into NB accumulators (independent blocks: their MFMAs interleave): A fragments from LDS, then AR products per block
+// (AR = tvr_mlpnet_desc.arith, include/tvr.h TVR_ARITH_*: 3 = Wlo*xhi + Whi*xlo + Whi*xhi, fp32-class; 2 = Wlo*xhi + Whi*xhi, the layer inputs rounded to fp16;
+// 1 = Whi*xhi.  What a mode does not multiply is neither read nor derived — frag8<AR>, tvr_mfma.h)
 template <int NB>
 struct AFrags {
     uint4 h[NB], l[NB];
 };
-template <int NB>
+template <int NB, int AR>
 __device__ __forceinline__ AFrags<NB> load_a(const uint4 *__restrict__ w4, const int (&blk)[NB])
 {
     AFrags<NB> a;
 #pragma unroll
     for (int m = 0; m < NB; ++m) {
         a.h[m] = w4[(blk[m] * 2 + 0) * 64];
-        a.l[m] = w4[(blk[m] * 2 + 1) * 64];
+        if constexpr (AR >= 2) a.l[m] = w4[(blk[m] * 2 + 1) * 64];
     }
     return a;
 }
-template <int NB>
+template <int NB, int AR>
 __device__ __forceinline__ void mma(const AFrags<NB> &a, const Frag &b, f32x16 (&acc)[NB])
 {
+    if constexpr (AR >= 2) {
 #pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(a.l[m], b.hi, acc[m]);
+        for (int m = 0; m < NB; ++m) acc[m] = MFMAH(a.l[m], b.hi, acc[m]);
+    }
+    if constexpr (AR >= 3) {
 #pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = MFMAH(a.h[m], b.lo, acc[m]);
+        for (int m = 0; m < NB; ++m) acc[m] = MFMAH(a.h[m], b.lo, acc[m]);
+    }
 #pragma unroll
     for (int m = 0; m < NB; ++m) acc[m] = MFMAH(a.h[m], b.hi, acc[m]);
 }
-template <int NB>
+template <int NB, int AR>
 __device__ __forceinline__ void kstep(const uint4 *__restrict__ w4, const int (&blk)[NB], const Frag &b, f32x16 (&acc)[NB])
 {
-    mma<NB>(load_a<NB>(w4, blk), b, acc);
+    mma<NB, AR>(load_a<NB, AR>(w4, blk), b, acc);
 }
 
 __device__ __forceinline__ void load_stage(uint4 *__restrict__ lds4, const uint4 *__restrict__ image, int n_blocks)
@@ -175,6 +183,7 @@ __device__ __forceinline__ void store_relu128(float *__restrict__ out, long long
                 make_float4(relu_f(act[mb][4 * q]), relu_f(act[mb][4 * q + 1]), relu_f(act[mb][4 * q + 2]), relu_f(act[mb][4 * q + 3]));
 }
 
+template <int AR>
 __device__ __forceinline__ void base_layers(const BgProgram &P, int l0, int l1, const uint4 *__restrict__ w4, const float *__restrict__ lbias, int hh,
                                             const float x[4], f32x16 (&act)[4], const BgTrain &T, long long s_store)
 {
@@ -187,22 +196,22 @@ __device__ __forceinline__ void base_layers(const BgProgram &P, int l0, int l1, 
 #if TVR_BG_APF
             // the A fragments of k-step t+1 are fetched from LDS before the MFMAs of k-step t are issued (LDS latency off the MFMA path)
             const int blk0[4] = {b0, b0 + spm, b0 + 2 * spm, b0 + 3 * spm};
-            AFrags<4> a = load_a<4>(w4, blk0);
+            AFrags<4> a = load_a<4, AR>(w4, blk0);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int tn = t < 7 ? t + 1 : 7;
                 const int blk[4] = {b0 + tn, b0 + spm + tn, b0 + 2 * spm + tn, b0 + 3 * spm + tn};
-                const AFrags<4> an = load_a<4>(w4, blk);
-                const Frag b = relu_frag4(act, t);
-                mma<4>(a, b, out);
+                const AFrags<4> an = load_a<4, AR>(w4, blk);
+                const Frag b = relu_frag4<AR>(act, t);
+                mma<4, AR>(a, b, out);
                 a = an;
             }
 #else
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const Frag b = relu_frag4(act, t);
+                const Frag b = relu_frag4<AR>(act, t);
                 const int blk[4] = {b0 + t, b0 + spm + t, b0 + 2 * spm + t, b0 + 3 * spm + t};
-                kstep<4>(w4, blk, b, out);
+                kstep<4, AR>(w4, blk, b, out);
             }
 #endif
         }
@@ -210,10 +219,10 @@ __device__ __forceinline__ void base_layers(const BgProgram &P, int l0, int l1, 
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 if (t < P.n_pe_steps) {
-                    const Frag b = pe_frag(t, hh, x);
+                    const Frag b = pe_frag<AR>(t, hh, x);
                     const int o = b0 + (prev ? 8 : 0) + t;
                     const int blk[4] = {o, o + spm, o + 2 * spm, o + 3 * spm};
-                    kstep<4>(w4, blk, b, out);
+                    kstep<4, AR>(w4, blk, b, out);
                 }
             }
         }
@@ -228,15 +237,16 @@ __device__ __forceinline__ void base_layers(const BgProgram &P, int l0, int l1, 
 
 // heads on one tile: sigma and the 64-wide rgb hidden layer share the fragments of `base`; returns (rgb, sigma) of sample col in the
 // lanes with hh == 0
+template <int AR>
 __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restrict__ w4, const float *__restrict__ lbias, int hh, const float d[3],
                                         const f32x16 (&act)[4], const BgTrain &T, long long s_store)
 {
     f32x16 hd[3] = {{0}, bias_acc(lbias + 512, hh), bias_acc(lbias + 512 + 32, hh)};      // sigma, rgb hidden block 0 / 1
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const Frag b = relu_frag4(act, t);
+        const Frag b = relu_frag4<AR>(act, t);
         const int blk[3] = {P.sig_block0 + t, P.rgbh_block0 + t, P.rgbh_block0 + 9 + t};
-        kstep<3>(w4, blk, b, hd);
+        kstep<3, AR>(w4, blk, b, hd);
     }
     f32x16 rh[2] = {hd[1], hd[2]};
     {
@@ -247,7 +257,7 @@ __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = hh ? v1[j] : v0[j];
         const int blk[2] = {P.rgbh_block0 + 8, P.rgbh_block0 + 9 + 8};
-        kstep<2>(w4, blk, split8(v), rh);
+        kstep<2, AR>(w4, blk, frag8<AR>(v), rh);
     }
     if (T.Hrgb && s_store >= 0) {
 #pragma unroll
@@ -266,7 +276,7 @@ __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = relu_f(t < 2 ? rh[0][8 * (t & 1) + j] : rh[1][8 * (t & 1) + j]);
         const int blk[1] = {P.rgbo_block0 + t};
-        kstep<1>(w4, blk, split8(v), eo);
+        kstep<1, AR>(w4, blk, frag8<AR>(v), eo);
     }
     return make_float4(1.0f / (1.0f + __expf(-(eo[0][0] + lbias[580]))), 1.0f / (1.0f + __expf(-(eo[0][1] + lbias[581]))),
                        1.0f / (1.0f + __expf(-(eo[0][2] + lbias[582]))), fabsf(hd[0][0] + lbias[576]));
@@ -276,6 +286,7 @@ __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restr
 #define TVR_BG_NT 1               // 32-sample tiles a wave carries through each LDS stage (their stage-A activations wait in registers)
 #endif
 
+template <int AR>
 __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, const uint4 *__restrict__ image, const float *__restrict__ bias,
                                                                  const float *__restrict__ pts, const float *__restrict__ viewdirs, long long M,
                                                                  float *__restrict__ rgb, float *__restrict__ sigma, const BgTrain T)
@@ -304,7 +315,7 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
             const long long s = ((super * NT + nt) * BG_WAVES + wave) * 32 + col, sr = min(s, M - 1);
             const float4 p = *reinterpret_cast<const float4 *>(pts + 4 * sr);
             const float x[4] = {p.x, p.y, p.z, p.w};
-            base_layers(P, 0, la, w4, lbias, hh, x, act[nt], T, s < M ? s : -1);
+            base_layers<AR>(P, 0, la, w4, lbias, hh, x, act[nt], T, s < M ? s : -1);
         }
         // ---------------- stage B: the remaining base layers and the heads
         __syncthreads();
@@ -317,8 +328,8 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
             const float x[4] = {p.x, p.y, p.z, p.w};
             const float *v = viewdirs + 3 * (sr / P.samples_per_ray);
             const float d[3] = {v[0], v[1], v[2]};
-            base_layers(P, la, P.D, w4, lbias, hh, x, act[nt], T, s < M ? s : -1);
-            const float4 r = heads(P, w4, lbias, hh, d, act[nt], T, s < M ? s : -1);
+            base_layers<AR>(P, la, P.D, w4, lbias, hh, x, act[nt], T, s < M ? s : -1);
+            const float4 r = heads<AR>(P, w4, lbias, hh, d, act[nt], T, s < M ? s : -1);
             if (h == 0 && s < M) {
                 sigma[s] = r.w;
                 rgb[3 * s] = r.x;
@@ -476,6 +487,24 @@ static int plan(const tvr_mlpnet_desc *d, BgLayout &L)
     return TVR_OK;
 }
 
+template <int AR>
+static int mlpnet_launch(const BgLayout &L, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma, const BgTrain &T, void *stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)bg_mlp_kernel<AR>, hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS_BYTES));
+        attr_set = true;
+    }
+    const long long per_super = 32 * BG_WAVES * TVR_BG_NT, n_super = (n_samples + per_super - 1) / per_super;
+    const unsigned blocks = (unsigned)(n_super < 256 ? n_super : 256);                     // one workgroup per CU (the LDS image)
+    const char *base = static_cast<const char *>(packed);
+    hipLaunchKernelGGL(bg_mlp_kernel<AR>, dim3(blocks), dim3(BG_WAVES * 64), BG_LDS_BYTES, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
+                       reinterpret_cast<const float *>(base + (size_t)L.total_blocks * 2048), static_cast<const float *>(pts), static_cast<const float *>(viewdirs),
+                       (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma), T);
+    HIP_TRY(hipGetLastError());
+    return TVR_OK;
+}
+
 extern "C" {
 
 size_t tvr_mlpnet_packed_bytes(const tvr_mlpnet_desc *desc)
@@ -532,34 +561,26 @@ int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *p, voi
     return TVR_OK;
 }
 
+// arith: TVR_ARITH_* of the INFERENCE call (tvr_mlpnet_desc.arith); the training forward passes TVR_ARITH_F32 whatever the descriptor says
 static int mlpnet_forward_impl(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
-                               const BgTrain &T, void *stream)
+                               const BgTrain &T, void *stream, int arith)
 {
     BgLayout L;
     if (int rc = plan(desc, L)) return rc;
     if (n_samples < 0) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_forward: n_samples < 0");
     if (n_samples == 0) return TVR_OK;
     if (!packed || !pts || !viewdirs || !rgb || !sigma || misaligned(packed) || misaligned(pts)) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_forward: NULL or misaligned argument");
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)bg_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS_BYTES));
-        attr_set = true;
-    }
-    const long long per_super = 32 * BG_WAVES * TVR_BG_NT, n_super = (n_samples + per_super - 1) / per_super;
-    const unsigned blocks = (unsigned)(n_super < 256 ? n_super : 256);                     // one workgroup per CU (the LDS image)
-    const char *base = static_cast<const char *>(packed);
-    hipLaunchKernelGGL(bg_mlp_kernel, dim3(blocks), dim3(BG_WAVES * 64), BG_LDS_BYTES, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
-                       reinterpret_cast<const float *>(base + (size_t)L.total_blocks * 2048), static_cast<const float *>(pts), static_cast<const float *>(viewdirs),
-                       (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma), T);
-    HIP_TRY(hipGetLastError());
-    return TVR_OK;
+    if (arith != TVR_ARITH_F32 && arith != TVR_ARITH_F16ACT && arith != TVR_ARITH_F16) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_forward: desc.arith %d is none of TVR_ARITH_*", arith);
+    if (arith == TVR_ARITH_F16ACT) return mlpnet_launch<2>(L, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream);
+    if (arith == TVR_ARITH_F16) return mlpnet_launch<1>(L, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream);
+    return mlpnet_launch<3>(L, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream);
 }
 
 int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
                        void *stream)
 {
     BgTrain T = {};
-    return mlpnet_forward_impl(desc, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream);
+    return mlpnet_forward_impl(desc, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream, desc ? desc->arith : 0);
 }
 
 int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
@@ -590,7 +611,7 @@ int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, co
         if (!saved->rgb_hidden_mask || misaligned(saved->rgb_hidden_mask)) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_train_forward: rgb_hidden_mask NULL or misaligned");
         T.MH = static_cast<unsigned long long *>(saved->rgb_hidden_mask);
     }
-    if (int rc = mlpnet_forward_impl(desc, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream)) return rc;
+    if (int rc = mlpnet_forward_impl(desc, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream, TVR_ARITH_F32)) return rc;
     if (n_samples > 0) {
         hipLaunchKernelGGL(bg_embed_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float *>(pts),
                            static_cast<const float *>(viewdirs), (long long)n_samples, input_ch, (int)desc->samples_per_ray, static_cast<float *>(saved->embed_pos),

@@ -332,7 +332,8 @@ class NerfPlusPlus(TensorVMSplit):
               and net.base_layers[0][0].out_features == 128 and self.bg_view_freq == 2 and 1 <= self.bg_freq <= 4)
         if not ok:
             return None
-        return L.MlpnetDesc(len(net.base_layers), 128, int(net.skips[0]), int(self.bg_freq), int(self.bg_view_freq), self.BG_SAMPLES)
+        # (arith: the inference call follows the model's `mlp_arith`, field.py; the training forward computes fp32-class whatever it says)
+        return L.MlpnetDesc(len(net.base_layers), 128, int(net.skips[0]), int(self.bg_freq), int(self.bg_view_freq), self.BG_SAMPLES, self._ARITH[self.mlp_arith])
 
     def _bg_packed(self, desc):
         """Fragment image of the background network.  `base_remap_layers` (Linear 128->256, no activation) is folded into the first rgb

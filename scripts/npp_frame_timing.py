@@ -14,6 +14,24 @@ m = NerfPlusPlus(arrs["aabb"], A["gridSize"], "cuda", density_n_comp=[16] * 3, a
 m.load_arrays(arrs)
 rays = bench.frames(A)[0].cuda()
 S = A["N_samples"]
+MODES = ("f32", "f16act", "f16")          # model.mlp_arith (include/tvr.h TVR_ARITH_*): products per k-step of the appearance network AND of the background network
+ref_pic = None
+for mode in MODES[1:] + MODES[:1]:        # (the default mode last: the detailed lines below are its)
+    m.mlp_arith = mode
+    with torch.no_grad():
+        OctreeRender_trilinear_fast(rays[:65536], m, chunk=4096, N_samples=S, white_bg=False)
+        torch.manual_seed(0); torch.cuda.synchronize(); t0 = time.perf_counter()
+        pic = OctreeRender_trilinear_fast(rays, m, chunk=4096, N_samples=S, white_bg=False)[0]
+        torch.cuda.synchronize(); t_mode = time.perf_counter() - t0
+        n = 65536
+        u = torch.randn(n, 512, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+        pts = torch.cat([u / u.norm(dim=-1, keepdim=True), torch.rand(n, 512, 1, device="cuda")], -1)
+        v = rays[:n, 3:6] / rays[:n, 3:6].norm(dim=-1, keepdim=True)
+        out = m._mlpnet(pts, v); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3): m._mlpnet(pts, v)
+        torch.cuda.synchronize(); t_bg = (time.perf_counter() - t0) / 3
+    print(f"mlp_arith {mode:7s}: {t_mode * 1e3:6.1f} ms / frame; background network kernel {n * 512 / t_bg / 1e9:.2f} G samples/s ({t_bg * 1e3:.1f} ms per {n * 512 / 1e6:.1f} M samples)")
+m.mlp_arith = "f32"
 with torch.no_grad():
     OctreeRender_trilinear_fast(rays[:65536], m, chunk=4096, N_samples=S, white_bg=False)
     torch.cuda.synchronize(); t0 = time.perf_counter()

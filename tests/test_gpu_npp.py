@@ -177,6 +177,48 @@ def test_background_network_kernel_matches_torch(tiny_npp_arrays, hyper_tiny, bg
     assert m._bg_kernel_desc() is None
 
 
+def test_background_network_arithmetic_modes(tiny_npp_arrays, hyper_tiny, tiny_npp):
+    """`model.mlp_arith` (include/tvr.h TVR_ARITH_*, tvr_mlpnet_desc.arith) also selects the products per k-step of the background network's inference kernel:
+    "f16act" = every layer's inputs rounded to fp16 (weights hi + lo, two products), "f16" = one product.  Against the torch modules (fp32), configs/Scarf.txt's
+    shape: the per-sample outputs per mode, then the whole picture per mode against the default mode's (tiny_npp's rays and injected random draws)."""
+    m = make_model(tiny_npp_arrays, hyper_tiny)
+    m.set_nerfplusplus(bg_freq=2, bg_view_freq=2, bg_D=3, radii=6.0)
+    g = torch.Generator(device="cpu").manual_seed(23)
+    with torch.no_grad():
+        for p in m.bg_net.parameters():
+            p.copy_((torch.rand(p.shape, generator=g) - 0.5).to(p.device) * (4.0 / max(p.shape[-1], 8) ** 0.5))
+    n, N = 37, m.BG_SAMPLES
+    u = torch.randn(n, N, 3, generator=g)
+    pts = torch.cat([u / u.norm(dim=-1, keepdim=True), torch.rand(n, N, 1, generator=g)], -1).cuda()
+    v = torch.randn(n, 3, generator=g)
+    v = (v / v.norm(dim=-1, keepdim=True)).cuda()
+    errs = {}
+    with torch.no_grad():
+        inp = torch.cat((m.bg_embedder_position(pts), m.bg_embedder_viewdir(v.unsqueeze(-2).expand(n, N, 3))), dim=-1)
+        want = m.bg_net(inp)
+        for mode in ("f32", "f16act", "f16"):
+            m.mlp_arith = mode
+            got = m._mlpnet(pts, v)
+            errs[mode] = ((got["sigma"] - want["sigma"]).abs().max().item() / max(1.0, want["sigma"].abs().max().item()), (got["rgb"] - want["rgb"]).abs().max().item())
+            print(f"bg net {mode}: sigma err (relative to its maximum) {errs[mode][0]:.2e}, rgb err {errs[mode][1]:.2e}")
+    assert errs["f32"][1] < 2e-5 and errs["f16act"][1] < 1e-3 and errs["f16"][1] < 2e-3
+    assert errs["f32"][0] < 2e-5 and errs["f16act"][0] < 1e-3 and errs["f16"][0] < 2e-3
+    assert errs["f32"][1] < errs["f16act"][1] < errs["f16"][1]                  # three different kernels
+    # the picture: foreground and background both follow the mode
+    m2 = make_model(tiny_npp_arrays, hyper_tiny)
+    rays = torch.tensor(tiny_npp["rays"], device="cuda")
+    rf, rb = torch.tensor(tiny_npp["rand_fg"], device="cuda"), torch.tensor(tiny_npp["rand_bg"], device="cuda")
+    pics = {}
+    with torch.no_grad():
+        for mode in ("f32", "f16act", "f16"):
+            m2.mlp_arith = mode
+            pics[mode] = m2(rays, is_train=False, N_samples=TINY["N_samples"], rand_fg=rf, rand_bg=rb)[0]
+    e32 = np.abs(pics["f32"].cpu().numpy() - tiny_npp["out.rgb_map"]).max()
+    e2, e1 = float((pics["f16act"] - pics["f32"]).abs().max()), float((pics["f16"] - pics["f32"]).abs().max())
+    print(f"NerfPlusPlus picture: f32 vs oracle {e32:.2e}; f16act vs f32 {e2:.2e}; f16 vs f32 {e1:.2e}")
+    assert e32 < 1e-4 and 0 < e2 < 3e-4 and 0 < e1 < 1e-3
+
+
 @pytest.mark.parametrize("bg_freq,bg_D", [(4, 4), (2, 3), (1, 2)])
 def test_background_network_training_kernels_match_float64_autograd(tiny_npp_arrays, hyper_tiny, bg_freq, bg_D):
     """The background network's training path without a library GEMM (autograd_ops._BgNetFn: fused forward that saves the activations, tvr_linear_dx per Linear,
