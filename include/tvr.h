@@ -122,17 +122,17 @@ int tvr_scene_set_alpha(tvr_scene *scene, const float *alpha_volume_dev, const i
  * never a silently clipped product.  OFF: no check — for hosts that have PROVEN the range from the parameters (the Python host does, by interval bounds, at
  * pack time: field.py::TensorVMSplit._fp16_range_proven) and want the last 1.5 %.  Weights are the host's to check (a bound on max|W| needs no kernel). */
 int tvr_scene_set_range_check(tvr_scene *scene, int32_t on);
-/* Arithmetic of the appearance network's matrix products (basis 144->27, layers 1 and 2) in tvr_render(_z) and tvr_mlp_render of a TensorVMSplit scene with
- * at most two encoding frequencies.  The reference computes them in fp32 (tensorBase.py:76-86, tensoRF.py:243); fp32 accumulation in every mode:
+/* Arithmetic of the appearance network's matrix products (basis 144->27 and REFTensoRF's heads, layers 1 and 2) in tvr_render(_z) and tvr_mlp_render(_ref) of a scene
+ * with at most two encoding frequencies.  The reference computes them in fp32 (tensorBase.py:76-86, tensoRF.py:243); fp32 accumulation in every mode:
  *   TVR_ARITH_F32    (default) three fp16 products per fp32 product — weights AND activations as fp16 hi + lo: ~2^-22 per product, fp32-class;
  *   TVR_ARITH_F16ACT layers 1 and 2 take two products — weights keep hi + lo (22 bits), their inputs (features, encoded values, relu outputs) are rounded to
- *                    fp16 (nearest even, 2^-12 relative); the basis product keeps three (its outputs feed sin / cos, where an error is amplified): 0.70 of the matrix work;
+ *                    fp16 (nearest even, 2^-12 relative); the basis product and REFTensoRF's heads keep three (their outputs feed sin / cos, where an error is amplified): 0.70 of the matrix work;
  *   TVR_ARITH_F16    one product — weights and activations as plain fp16: 1/3 of the matrix work.
  * fp16 rounding is RELATIVE: the reduced modes' absolute error grows with the scale of the features and hidden activations (|feature| <= 23: picture within 6.4e-5 / 3.5e-4
  * of the fp32 path in F16ACT / F16; |feature| ~ 230: 6.5e-4 / 1.5e-3) — a scene with unusually large features keeps the default.
  * The reduced modes are OPT-IN trades inside north_star's parity bar (RGB L-inf 1e-3 against the fp32 path): measured against TVR_ARITH_F32 on the 800x800 bench frame
  * and against the oracle on the fixtures, see DESIGN.md 4.7 and tests/test_gpu_arith.py for the numbers and the bars the tests hold.  Layer 3, encoding, interpolation,
- * density, compositing: fp32 in every mode.  (NerfPlusPlus's background network has the same switch in its descriptor: tvr_mlpnet_desc.arith.)  Every other entry point (tvr_app_feature, the training forwards, REFTensoRF scenes, scenes with more than two encoding
+ * density, compositing: fp32 in every mode.  (NerfPlusPlus's background network has the same switch in its descriptor: tvr_mlpnet_desc.arith.)  Every other entry point (tvr_app_feature(_ref), the training forwards, scenes with more than two encoding
  * frequencies) computes with three products whatever the mode says.  Range: as for the default (|x| < 65 504); a rounded activation beyond it becomes inf, and
  * the range check marks its sample NaN as in the default mode. */
 enum { TVR_ARITH_F32 = 0, TVR_ARITH_F16ACT = 1, TVR_ARITH_F16 = 2 };

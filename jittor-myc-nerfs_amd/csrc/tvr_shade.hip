@@ -536,8 +536,10 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
         _Pragma("unroll") for (int s = 0; s < 9; ++s) {                                                                             \
             const uint4 *ap = (const uint4 *)(rowp + (s * 2 + h) * 32);                                                             \
             const h8 Ah = __builtin_bit_cast(h8, ap[0]), Al = __builtin_bit_cast(h8, ap[1]);                                        \
-            accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);                     \
-            accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);                     \
+            if constexpr (ARB >= 2) {                               /* (one-product mode: accA keeps the biases, accB stays zero) */   \
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(h8, hf[s].hi), accA, 0, 0, 0);                 \
+                accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].lo), accB, 0, 0, 0);                 \
+            }                                                                                                                       \
             accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(h8, hf[s].hi), accC, 0, 0, 0);                     \
         }                                                                                                                           \
         _Pragma("unroll") for (int r = 0; r < 8; ++r) G[r] = (accA[r] + accB[r]) + accC[r];                                         \
@@ -588,7 +590,7 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 template <int SRC, int DST, bool REF, bool RC = false, bool GEN = false, int AR = 3>
 __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneDev sc, const ShadeArgs a)
 {
-    static_assert(AR == 3 || (!REF && !GEN && DST != SH_DST_TRAIN && DST != SH_DST_FEAT), "the reduced-product arithmetics exist for the TensorVMSplit render and mlp_render paths");
+    static_assert(AR == 3 || (!GEN && DST != SH_DST_TRAIN && DST != SH_DST_FEAT), "the reduced-product arithmetics exist for the render and mlp_render paths of scenes with at most two encoding frequencies");
     // the basis product F = Bas . h keeps its three products in the two-product mode: F feeds sin / cos (d sin(2F) / dF = 2, an error of F is AMPLIFIED by |F|'s
     // scale), whereas a rounded input of a linear layer is not (27 of the 243 MFMAs)
     constexpr int ARB = AR == 1 ? 1 : 3;
@@ -1108,13 +1110,13 @@ static hipError_t launch_shade_t(const SceneDev &sc, const ShadeArgs &a, hipStre
     return hipGetLastError();
 }
 
-// the TensorVMSplit render / mlp_render kernels in the scene's arithmetic (tvr_scene_set_arith); every other path computes with three products whatever the mode
-template <int SRC, int DST, bool RC>
+// the render / mlp_render kernels in the scene's arithmetic (tvr_scene_set_arith); every other path computes with three products whatever the mode
+template <int SRC, int DST, bool REF, bool RC>
 static hipError_t launch_shade_ar(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
-    if (sc.arith == TVR_ARITH_F16ACT) return launch_shade_t<SRC, DST, false, RC, false, 2>(sc, a, stream);
-    if (sc.arith == TVR_ARITH_F16) return launch_shade_t<SRC, DST, false, RC, false, 1>(sc, a, stream);
-    return launch_shade_t<SRC, DST, false, RC, false, 3>(sc, a, stream);
+    if (sc.arith == TVR_ARITH_F16ACT) return launch_shade_t<SRC, DST, REF, RC, false, 2>(sc, a, stream);
+    if (sc.arith == TVR_ARITH_F16) return launch_shade_t<SRC, DST, REF, RC, false, 1>(sc, a, stream);
+    return launch_shade_t<SRC, DST, REF, RC, false, 3>(sc, a, stream);
 }
 
 template <bool REF>
@@ -1126,14 +1128,11 @@ static hipError_t launch_shade_v(const SceneDev &sc, int src, int dst, const Sha
             if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false, true, true>(sc, a, stream) : launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false, false, true>(sc, a, stream);
             if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false, true, true>(sc, a, stream) : launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false, false, true>(sc, a, stream);
             if (src == SH_SRC_H && dst == SH_DST_TRAIN) return hipErrorInvalidValue;
-        } else {
-            if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, true>(sc, a, stream) : launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, false>(sc, a, stream);
-            if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_ar<SH_SRC_FEAT, SH_DST_RGB, true>(sc, a, stream) : launch_shade_ar<SH_SRC_FEAT, SH_DST_RGB, false>(sc, a, stream);
         }
     }
-    if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, REF, false>(sc, a, stream);
+    if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, REF, true>(sc, a, stream) : launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, REF, false>(sc, a, stream);
     if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return rc ? launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, false>(sc, a, stream);
-    if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, REF, false>(sc, a, stream);
+    if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_ar<SH_SRC_FEAT, SH_DST_RGB, REF, true>(sc, a, stream) : launch_shade_ar<SH_SRC_FEAT, SH_DST_RGB, REF, false>(sc, a, stream);
     if (src == SH_SRC_H && dst == SH_DST_TRAIN) return launch_shade_t<SH_SRC_H, SH_DST_TRAIN, REF, false>(sc, a, stream);
     return hipErrorInvalidValue;
 }

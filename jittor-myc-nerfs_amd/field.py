@@ -344,7 +344,8 @@ class TensorBase(torch.nn.Module):
     # "f32" (default): three fp16 products per fp32 product, fp32-class — what every parity number in DESIGN.md is quoted on.  "f16act": activations rounded to
     # fp16, weights keep 22 bits (two products).  "f16": plain fp16 operands (one product).  fp32 accumulation throughout; the reduced modes are opt-in trades
     # inside north_star's 1e-3 RGB bar (tests/test_gpu_arith.py) and apply to render_rays / forward(is_train=False) / the renderModule of a
-    # TensorVMSplit scene with at most two encoding frequencies; everything else computes in "f32" whatever this says.
+    # TensorVMSplit, REFTensoRF or NerfPlusPlus (foreground and background network) scene with at most two encoding frequencies; everything else — training,
+    # compute_appfeature, six-frequency scenes — computes in "f32" whatever this says.
     mlp_arith = "f32"
     _ARITH = {"f32": 0, "f16act": 1, "f16": 2}
 

@@ -135,7 +135,7 @@ def test_mode_is_validated_and_survives_a_repack(tiny_arrays, hyper_tiny, tiny_d
         m.app_plane[0].mul_(1.0)                                                  # bumps the version counter: the scene is re-packed, the mode stays
     b, _ = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
     assert torch.equal(a, b) and L.lib().tvr_scene_get_arith(m._scene) == 1
-    # REFTensoRF / more than two encoding frequencies: accepted, and computed with three products (tvr.h)
+    # more than two encoding frequencies: accepted, and computed with three products (tvr.h)
     from jittor_myc_nerfs_amd import TensorVMSplit
     g = TensorVMSplit(tiny_arrays["aabb"], [int(x) for x in tiny_arrays["gridSize"]], "cuda", density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
                       near_far=hyper_tiny["near_far"], shadingMode="MLP_Fea", pos_pe=6, view_pe=4, fea_pe=4, featureC=128, step_ratio=hyper_tiny["step_ratio"])

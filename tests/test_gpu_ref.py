@@ -195,3 +195,36 @@ def test_ref_config1_and_full_size_properties():
     e2 = np.abs(_np(rgb[sel.cuda()]) - want.numpy()).max()
     print(f"REF config2 subset rgb_map Linf {e2:.2e}")
     assert e2 < 3e-4 < RGB_TOL
+
+
+def test_ref_arithmetic_modes(tiny_ref, tiny_ref_arrays, hyper_tiny):
+    """`mlp_arith` (include/tvr.h TVR_ARITH_*) on the REFTensoRF render: "f16act" rounds the inputs of layers 1 and 2 (the basis product AND the four heads, whose normal
+    feeds the reflection direction and its encoding, keep three products); "f16" takes one product everywhere.  Against the golden picture and per-sample colours;
+    what the march decides is bit-identical; at full size each mode against the default mode's frame."""
+    m = make_model(tiny_ref_arrays, hyper_tiny)
+    rays = torch.tensor(tiny_ref["rays"], device="cuda")
+    base, errs = None, {}
+    for mode in ("f32", "f16act", "f16"):
+        m.mlp_arith = mode
+        rgb_map, depth_map, d = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"], eps_T=0.0, dense=True)
+        errs[mode] = (np.abs(_np(d["rgb"]) - tiny_ref["rgb"]).max(), np.abs(_np(rgb_map) - tiny_ref["rgb_map"]).max())
+        cur = (depth_map, d["weight"], d["valid"])
+        if base is None:
+            base = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(base, cur))
+    print("REF modes, per-sample rgb / rgb_map L-inf vs oracle: " + ", ".join(f"{k} {v[0]:.2e} / {v[1]:.2e}" for k, v in errs.items()))
+    assert errs["f32"][1] < 2e-4 and errs["f16act"][1] < 3e-4 and errs["f16"][1] < 5e-4 < RGB_TOL
+    assert errs["f32"][0] < errs["f16act"][0] < errs["f16"][0] < RGB_TOL
+    from jittor_myc_nerfs_amd import rays as R, synthetic
+    A = synthetic.SCENE_A
+    arrs = synthetic.make_scene_arrays(A["gridSize"], A["aabb"], ref=True)
+    big = make_model(arrs, dict(synthetic.HYPER, near_far=A["near_far"], step_ratio=A["step_ratio"]))
+    fr = R.frame_rays(R.sphere_poses(8, A["cam_radius"])[0], 800, 800, A["camera_angle_x"]).cuda()
+    pics = {}
+    for mode in ("f32", "f16act", "f16"):
+        big.mlp_arith = mode
+        pics[mode] = big.render_rays(fr, white_bg=True, N_samples=A["N_samples"])
+    e2, e1 = float((pics["f16act"][0] - pics["f32"][0]).abs().max()), float((pics["f16"][0] - pics["f32"][0]).abs().max())
+    print(f"REF full size vs the default mode (640 000 rays): f16act {e2:.2e}, f16 {e1:.2e}")
+    assert 0 < e2 < 3e-4 and 0 < e1 < 1e-3 and torch.equal(pics["f16"][1], pics["f32"][1])

@@ -29,9 +29,9 @@ def report():
 
 def test_every_shade_kernel_variant_is_audited(report):
     # {queue, xyz->features, features->rgb} x {fp16 range check on, off} + the training forward (h -> rgb + activations), each x {TensorVMSplit, REFTensoRF},
-    # + the render and mlp_render kernels of TensorVMSplit in the two reduced-product arithmetics (2 kernels x 2 range-check states x 2 modes)
+    # + the render and mlp_render kernels in the two reduced-product arithmetics (2 kernels x 2 models x 2 range-check states x 2 modes)
     # + the backward kernels (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps)
-    assert len(report) == 26, sorted(report)
+    assert len(report) == 34, sorted(report)
 
     assert all(v["mfma"] >= 27 for v in report.values())
 
