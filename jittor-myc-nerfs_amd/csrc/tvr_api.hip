@@ -49,6 +49,7 @@ static const int kVecH[3] = {2, 1, 0};
 
 struct PackedLayout {
     size_t dplane[3], dline[3], aplane[3], aline[3];
+    size_t aplane16[3], aline16[3];            // fp16 copies of the appearance factors (TVR_ARITH_F16's gather), floats / 2
     size_t mlp_image, basis_frag, b3, w1gen, total;
 };
 
@@ -69,6 +70,11 @@ static PackedLayout packed_layout(const tvr_scene_desc &d)
     L.b3 = take(16);
     // scenes with more than two encoding frequencies (TensorBase's own default is 6 / 6: 390 MLP inputs): layer 1's fragment image, 26 k-steps, streamed through LDS
     L.w1gen = (d.view_pe > 2 || d.fea_pe > 2) ? take(TVR_W1GEN_BYTES / 4) : 0;
+    for (int i = 0; i < 3; ++i) {
+        const size_t W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
+        L.aplane16[i] = take((H + 1) * (W + 1) * TVR_CA / 2);
+        L.aline16[i] = take((Ln + 1) * TVR_CA / 2);
+    }
     L.total = off;
     return L;
 }
@@ -79,12 +85,26 @@ struct tvr_scene {
     char *packed;
     SceneDev dev;
     bool params_set;
+    bool h16_stale;            // the fp16 copies of the appearance factors are older than the fp32 images
 };
 
 struct tvr_profile {
     std::vector<hipEvent_t> ev;   // 4 per call
     int max_calls, n_calls;
 };
+
+// the appearance factors as fp16, from the packed fp32 images (the one-product arithmetic gathers these: half the bytes through L1)
+static int refresh_h16(tvr_scene *s, hipStream_t stream)
+{
+    const tvr_scene_desc &d = s->desc;
+    for (int i = 0; i < 3; ++i) {
+        const long long W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
+        HIP_TRY(launch_f32_to_f16((const float *)(s->packed + s->lay.aplane[i]), s->packed + s->lay.aplane16[i], (H + 1) * (W + 1) * TVR_CA, stream));
+        HIP_TRY(launch_f32_to_f16((const float *)(s->packed + s->lay.aline[i]), s->packed + s->lay.aline16[i], (Ln + 1) * TVR_CA, stream));
+    }
+    s->h16_stale = false;
+    return TVR_OK;
+}
 
 static int check_desc(const tvr_scene_desc *d)
 {
@@ -138,6 +158,7 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
     s->lay = L;
     s->packed = (char *)packed_dev;
     s->params_set = false;
+    s->h16_stale = true;
     SceneDev &v = s->dev;
     memset(&v, 0, sizeof(v));
     for (int k = 0; k < 3; ++k) {
@@ -150,6 +171,8 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
         v.dline[k] = (const float4 *)(s->packed + L.dline[k]);
         v.aplane[k] = (const float4 *)(s->packed + L.aplane[k]);
         v.aline[k] = (const float4 *)(s->packed + L.aline[k]);
+        v.aplane16[k] = (const uint4 *)(s->packed + L.aplane16[k]);
+        v.aline16[k] = (const uint4 *)(s->packed + L.aline16[k]);
     }
     v.mlp_image = s->packed + L.mlp_image;
     v.basis_frag = s->packed + L.basis_frag;
@@ -214,6 +237,8 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
         HIP_TRY(launch_pack_ref(p->ref_W, p->ref_b, img + TVR_IMG_REFW, (float *)(img + TVR_IMG_REFB), stream));
     }
     s->params_set = true;
+    s->h16_stale = true;
+    if (s->dev.arith == TVR_ARITH_F16) return refresh_h16(s, (hipStream_t)stream);      // (otherwise the first render in that mode converts)
     return TVR_OK;
 }
 
@@ -334,6 +359,10 @@ static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     mo.stats = (unsigned long long *)stats;
     mo.lam6 = lam6_out;
 
+    if (s->dev.arith == TVR_ARITH_F16 && !s->dev.gen && s->h16_stale) {        // the mode was set after the last tvr_scene_update
+        int rc16 = refresh_h16(s, stream);
+        if (rc16 != TVR_OK) return rc16;
+    }
     hipEvent_t *ev = prof ? &prof->ev[(size_t)prof->n_calls * 4] : nullptr;
     HIP_TRY(launch_zero_header(mo.counter, stream));                   // [0] queue length, [1] the march's tile counter, [2] its fault flag, [3] unused here
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));

@@ -70,6 +70,8 @@ struct SceneDev {
     const float4 *dline[3];
     const float4 *aplane[3];
     const float4 *aline[3];
+    const uint4 *aplane16[3];     // the appearance factors once more as fp16 (same channels-last layout, 96 B per texel): what the one-product arithmetic (TVR_ARITH_F16) gathers;
+    const uint4 *aline16[3];      // converted from the fp32 images by tvr_scene_update / the first render in that mode (tvr_api.hip: h16_stale)
     const void *mlp_image;        // TVR_MLP_IMAGE_BYTES(_REF), copied to LDS by the shade kernel
     const void *basis_frag;       // lo parts of the basis fragments [9][2][32][8] fp16 (hi parts: mlp_image + TVR_IMG_BASH)
     const float *b3;              // [3]

@@ -130,4 +130,5 @@ size_t colsum_scratch_bytes();
 hipError_t launch_colsum(const float *A, int lda, int K, long long m_cap, const unsigned *m_dev, float *out, float *scratch, hipStream_t stream);
 hipError_t launch_copy_f32(float *dst, const float *src, int n, hipStream_t stream);
 hipError_t launch_zero_header(unsigned *counter, hipStream_t stream);
+hipError_t launch_f32_to_f16(const float *in, void *out, long long n, hipStream_t stream);      // n a multiple of 4; round to nearest even
 hipError_t launch_zero_f32(float *p, long long n, hipStream_t stream);

@@ -384,6 +384,45 @@ __device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, fl
 }
 
 
+// ---- the gather of the one-product arithmetic (AR == 1, queue source): the appearance factors as fp16 (SceneDev::aplane16 / aline16, 96 B per texel) — one 16-B load
+// per tap and lane instead of two, half the bytes through the L1 return path that bounds this mode; the interpolation itself stays fp32 (v_fma_mix_f32 reads the
+// halves in place: no conversion instructions).  Queue entries lie inside the grid: no bounds handling here.
+struct Taps16 {
+    uint4 t[4], lv[2];
+};
+__device__ __forceinline__ void load_taps16(Taps16 &T, const uint4 *__restrict__ P, const uint4 *__restrict__ Ln, int W, float fx, float fy, float fl, int q0)
+{
+    const int x0 = (int)floorf(fx), y0 = (int)floorf(fy), l0 = (int)floorf(fl);
+    const unsigned Wp = (unsigned)W + 1u;
+    const unsigned o0 = ((unsigned)y0 * Wp + (unsigned)x0) * 6u + (unsigned)q0, o1 = o0 + Wp * 6u;       // a texel = 48 halves = 6 uint4
+    const uint4 *p = P + o0, *p2 = P + o1;
+    T.t[0] = p[0]; T.t[1] = p[6];
+    T.t[2] = p2[0]; T.t[3] = p2[6];
+    const uint4 *q = Ln + ((unsigned)l0 * 6u + (unsigned)q0);
+    T.lv[0] = q[0]; T.lv[1] = q[6];
+}
+__device__ __forceinline__ void taps_eval16(const Taps16 &T, float fx, float fy, float fl, float out[8])
+{
+    const float x0f = floorf(fx), y0f = floorf(fy), l0f = floorf(fl);
+    const float wx = fx - x0f, wy = fy - y0f, wl = fl - l0f, ul = 1.0f - wl;
+    const float ux = 1.0f - wx, uy = 1.0f - wy;
+    const float a00 = ux * uy, a01 = wx * uy, a10 = ux * wy, a11 = wx * wy;
+    const h8 t0 = __builtin_bit_cast(h8, T.t[0]), t1 = __builtin_bit_cast(h8, T.t[1]), t2 = __builtin_bit_cast(h8, T.t[2]), t3 = __builtin_bit_cast(h8, T.t[3]);
+    const h8 l0 = __builtin_bit_cast(h8, T.lv[0]), l1 = __builtin_bit_cast(h8, T.lv[1]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                                  // the same order of operations as taps_eval
+        float p = __builtin_fmaf((float)t0[j], a00, 0.0f);
+        p = __builtin_fmaf((float)t1[j], a01, p);
+        p = __builtin_fmaf((float)t2[j], a10, p);
+        p = __builtin_fmaf((float)t3[j], a11, p);
+        float q = __builtin_fmaf((float)l0[j], ul, 0.0f);
+        q = __builtin_fmaf((float)l1[j], wl, q);
+        float r = p * q;
+        asm volatile("" : "+v"(r));
+        out[j] = r;
+    }
+}
+
 // sine / cosine for the positional encoding: v_sin_f32 / v_cos_f32 (they take revolutions) behind a two-term Cody-Waite reduction
 // x - k*2pi, 7 instructions per pair and no branch (a branch per value kept hipcc from interleaving layer 1's VALU work with its MFMAs).
 // The reduction is exact to an ulp of the remainder for |x| < ~1e4 (k has <= 11 bits), so the error is the hardware's (~1e-6 abs),
@@ -743,12 +782,15 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 // throughout: a tap set then has one evaluation (~80 VALU, ~400 cycles) to arrive, an L2 / MALL hit takes 500-900 cycles, and the phase
                 // timing of a lone wave showed half of the gather phase's 8.7 k cycles to be that wait.
                 constexpr int PFD = TVR_PF;
-                Taps T[PFD + 1];
+                constexpr bool H16 = (AR == 1) && (SRC == SH_SRC_QUEUE);        // the one-product arithmetic gathers the fp16 images
+                Taps T[H16 ? 1 : PFD + 1];
+                Taps16 T16[H16 ? PFD + 1 : 1];
                 auto tgt = [](int s) { const int d = s < TVR_PF_SHALLOW ? TVR_PF : 1; return s + d < 8 ? s + d : 8; };   // last k-step issued before k-step s is evaluated
                 auto issue = [&](int s2) {
                     const int p = s2 / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;      // matMode / vecMode
-                    load_taps<TVR_CHK>(T[s2 % (PFD + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], TVR_Q0(s2 % 3, h));
+                    if constexpr (H16) load_taps16(T16[s2 % (PFD + 1)], sc.aplane16[p], sc.aline16[p], sc.grid[ax], fc[ax], fc[bx], fc[vx], 2 * (s2 % 3) + h);
+                    else load_taps<TVR_CHK>(T[s2 % (PFD + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], TVR_Q0(s2 % 3, h));
                 };
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
@@ -765,7 +807,8 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     }
                     const int p = s / 3;
                     const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;
-                    taps_eval<TVR_CHK>(T[s % (PFD + 1)], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], hvv[s]);
+                    if constexpr (H16) taps_eval16(T16[s % (PFD + 1)], fc[ax], fc[bx], fc[vx], hvv[s]);
+                    else taps_eval<TVR_CHK>(T[s % (PFD + 1)], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], hvv[s]);
                     TVR_GATHER_KEEP(s);
                     TVR_SB;
                 }

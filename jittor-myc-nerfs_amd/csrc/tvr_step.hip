@@ -279,6 +279,30 @@ hipError_t launch_filter_rays(const SceneDev &sc, const float *rays, long long n
     return hipGetLastError();
 }
 
+// fp32 -> fp16 (round to nearest even), four values per thread: the appearance factors' second image (tvr_api.hip refresh_h16)
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float4 *__restrict__ in, uint2 *__restrict__ out, long long n4)
+{
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = in[i];
+        uint2 o;
+        o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v.x, v.y}, f16x2));
+        o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v.z, v.w}, f16x2));
+        out[i] = o;
+    }
+}
+
+hipError_t launch_f32_to_f16(const float *in, void *out, long long n, hipStream_t stream)
+{
+    const long long n4 = n / 4;
+    if (n4 <= 0) return hipSuccess;
+    unsigned grid = (unsigned)((n4 + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, stream, (const float4 *)in, (uint2 *)out, n4);
+    return hipGetLastError();
+}
+
 hipError_t launch_zero_header(unsigned *counter, hipStream_t stream)
 {
     hipLaunchKernelGGL(zero_header_kernel, dim3(1), dim3(64), 0, stream, counter);

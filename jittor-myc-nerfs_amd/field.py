@@ -365,7 +365,10 @@ class TensorBase(torch.nn.Module):
         <= 1}; layer-2 inputs relu(h1) <= |W1| . in1max + |b1|; and the weights themselves.  One host read."""
         if self._variant != 0:
             return dict(proven=False, why="REFTensoRF: the reflection / head inputs are not bounded here; the in-kernel check stays on")
-        hmax = torch.cat([self.app_plane[i].detach().abs().amax(dim=(0, 2, 3)) * self.app_line[i].detach().abs().amax(dim=(0, 2, 3)) for i in range(3)])
+        pmax = [self.app_plane[i].detach().abs().amax(dim=(0, 2, 3)) for i in range(3)]
+        lmax = [self.app_line[i].detach().abs().amax(dim=(0, 2, 3)) for i in range(3)]
+        hmax = torch.cat([pmax[i] * lmax[i] for i in range(3)])
+        tmax = torch.stack([t.max() for t in pmax + lmax]).max()           # the texels themselves: the "f16" arithmetic gathers them from fp16 copies
         Fmax = self.basis_mat.weight.detach().abs() @ hmax
         m = self.renderModule.mlp
         W1, b1, W2 = m[0].weight.detach(), m[0].bias.detach(), m[2].weight.detach()
@@ -374,8 +377,8 @@ class TensorBase(torch.nn.Module):
         in1[self.app_dim:self.app_dim + 3] = float(self.fp16_dir_bound)
         h1max = W1.abs() @ in1 + b1.abs()
         wmax = torch.stack([W1.abs().max(), W2.abs().max(), self.basis_mat.weight.detach().abs().max()]).max()
-        b = torch.stack([hmax.max(), Fmax.max(), h1max.max(), wmax]).tolist()
-        rep = dict(zip(("h", "features", "layer2_inputs", "weights"), b))
+        b = torch.stack([hmax.max(), Fmax.max(), h1max.max(), wmax, tmax]).tolist()
+        rep = dict(zip(("h", "features", "layer2_inputs", "weights", "texels"), b))
         rep["proven"] = all(x == x and x < self._FP16_SAFE for x in b)
         return rep
 

@@ -50,8 +50,8 @@ def test_abi_argument_errors_without_gpu():
     d.density_n_comp[:], d.app_n_comp[:], d.featureC, d.view_pe = [8, 8, 8], [24, 24, 24], 64, 0      # fewer / narrower: zero-padded into the same layout
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == nbytes
     d.density_n_comp[:], d.app_n_comp[:], d.featureC, d.view_pe = [16] * 3, [48] * 3, 128, 2
-    # 3 planes x 301x301 x (16+48) ch + lines + MLP, fp32, 256-B aligned blocks (DESIGN.md "data layout")
-    assert 69.5e6 < nbytes < 70.5e6
+    # 3 planes x 301x301 x (16+48) ch + lines + MLP, fp32, 256-B aligned blocks, + the appearance factors once more as fp16 (DESIGN.md "data layout")
+    assert 69.5e6 + 26.0e6 < nbytes < 70.5e6 + 26.5e6
     h = C.c_void_p()
     assert lib.tvr_scene_create(C.byref(d), None, 0, C.byref(h)) == -3  # TVR_ERR_SCRATCH
     assert lib.tvr_render(None, None, 0, 0, 0, None, 0.0, None, None, None, 0, None, None, None, None) == -1

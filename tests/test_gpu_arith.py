@@ -168,3 +168,31 @@ def test_feature_magnitude_is_where_the_modes_differ(tiny_dump, tiny_arrays, hyp
     print(f"basis x{scale:g}: max |feature| {fmax:.0f}; per-sample rgb / rgb_map L-inf vs oracle: " + ", ".join(f"{k} {v[0]:.2e} / {v[1]:.2e}" for k, v in err.items()))
     assert err["f32"][1] < RGB_TIGHT and err["f16act"][1] < RGB_TOL           # the picture (north_star's quantity) stays inside the bar in "f16act" ...
     assert err["f16"][0] > err["f16act"][0] > err["f32"][0]                    # ... with less margin the larger the activations: every reduced mode's error is RELATIVE to them
+
+
+def test_fp16_factor_copies_follow_the_parameters(tiny_arrays, hyper_tiny, tiny_dump):
+    """The "f16" arithmetic gathers fp16 COPIES of the appearance planes / lines (include/tvr.h).  They are converted by the first render in the mode, and again by every
+    tvr_scene_update while the mode is set: an in-place edit of a factor must show in the next picture exactly as in a model built with the edited factor."""
+    rays = torch.tensor(tiny_dump["rays"], device="cuda")
+    S = TINY["N_samples"]
+    m = make_model(tiny_arrays, hyper_tiny)
+    f32_0, _ = m.render_rays(rays, white_bg=True, N_samples=S)          # packs the scene in the default mode: no fp16 copies yet
+    m.mlp_arith = "f16"
+    a, _ = m.render_rays(rays, white_bg=True, N_samples=S)              # the mode was set after the update: this render converts
+    assert 0 < float((a - f32_0).abs().max()) < 5e-4
+    with torch.no_grad():
+        m.app_plane[1].mul_(1.5)
+        m.app_line[2].add_(0.05)
+    b, _ = m.render_rays(rays, white_bg=True, N_samples=S)              # re-pack in "f16": tvr_scene_update converts
+    arrs2 = dict(tiny_arrays)
+    arrs2["app_plane.1"] = tiny_arrays["app_plane.1"] * np.float32(1.5)
+    arrs2["app_line.2"] = tiny_arrays["app_line.2"] + np.float32(0.05)
+    m2 = make_model(arrs2, hyper_tiny)
+    m2.mlp_arith = "f16"
+    c, _ = m2.render_rays(rays, white_bg=True, N_samples=S)
+    assert torch.equal(b, c) and float((b - a).abs().max()) > 1e-3
+    m.mlp_arith = "f32"                                                  # and back: the fp32 images were never touched
+    m2.mlp_arith = "f32"
+    assert torch.equal(m.render_rays(rays, white_bg=True, N_samples=S)[0], m2.render_rays(rays, white_bg=True, N_samples=S)[0])
+    rep = m.fp16_range_report()
+    assert rep["proven"] and 0 < rep["texels"] < 10
