@@ -130,6 +130,7 @@ int tvr_scene_set_range_check(tvr_scene *scene, int32_t on);
  *   TVR_ARITH_F16    one product — weights and activations as plain fp16: 1/3 of the matrix work; and the gather of tvr_render(_z) reads fp16 COPIES of the appearance
  *                    planes / lines (kept in the packed buffer, converted from the fp32 images with round-to-nearest-even by tvr_scene_update when this mode is set, else
  *                    by the first render in the mode): half the bytes through the L1 return path, interpolation still in fp32.
+ *                    (A hipGraph that captured a render bakes in the mode and whether a conversion was due: capture again after switching modes.)
  * fp16 rounding is RELATIVE: the reduced modes' absolute error grows with the scale of the features and hidden activations (|feature| <= 23: picture within 6.4e-5 / 3.5e-4
  * of the fp32 path in F16ACT / F16; |feature| ~ 230: 6.5e-4 / 1.5e-3) — a scene with unusually large features keeps the default.
  * The reduced modes are OPT-IN trades inside north_star's parity bar (RGB L-inf 1e-3 against the fp32 path): measured against TVR_ARITH_F32 on the 800x800 bench frame
