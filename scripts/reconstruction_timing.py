@@ -104,4 +104,19 @@ with torch.no_grad():
 psnr = float(-10 * torch.log10(torch.mean((out - val.all_rgbs.view(-1, 3)) ** 2)))
 print("reconstruction(%s): %d iterations in %.1f s (%.1f it/s over the whole run, everything included), held-out PSNR %.2f dB, final grid %s"
       % (a.model, a.iters, t_train, a.iters / t_train, psnr, model.gridSize.tolist()), flush=True)
+# the TRAINED scene in the opt-in arithmetics of the appearance network (include/tvr.h TVR_ARITH_*): the held-out view's PSNR per mode, the picture's distance
+# from the default mode's, and the magnitudes its features really have (the reduced modes' error is relative to them)
+with torch.no_grad():
+    rays_v, gt = val.all_rays.view(-1, 6), val.all_rgbs.view(-1, 3)
+    rep = model.fp16_range_report() if hasattr(model, "fp16_range_report") else {}
+    ref = None
+    for mode in ("f32", "f16act", "f16"):
+        model.mlp_arith = mode
+        pic = model(rays_v, is_train=False, white_bg=True, N_samples=-1)[0]
+        if ref is None:
+            ref = pic
+        print("  mlp_arith %-7s held-out PSNR %.3f dB, RGB L-inf vs the default mode %.2e (mean %.2e)" %
+              (mode, float(-10 * torch.log10(torch.mean((pic - gt) ** 2))), float((pic - ref).abs().max()), float((pic - ref).abs().mean())), flush=True)
+    model.mlp_arith = "f32"
+    print("  interval bounds of the trained scene (fp16_range_report): " + ", ".join("%s %.3g" % (k, v) for k, v in rep.items() if k != "proven"), flush=True)
 print("whole script: %.1f s" % (time.perf_counter() - t_all))
