@@ -5,6 +5,8 @@ import torch, numpy as np
 import bench
 if os.environ.get('TVR_LIB_PATH') is None: print('note: set TVR_LIB_PATH to a -DTVR_TIMING=1 build')
 m, arrs, A = bench.build_model(torch.device("cuda"))
+m.mlp_arith = os.environ.get("TVR_ARITH", "f32")             # TVR_ARITH=f16act / f16: the opt-in arithmetics
+print("mlp_arith", m.mlp_arith)
 rays = bench.frames(A)[0].cuda()
 stats = torch.zeros(16, dtype=torch.int64, device="cuda")
 for _ in range(2): m.render_rays(rays, N_samples=512)
