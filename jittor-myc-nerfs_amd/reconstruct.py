@@ -69,6 +69,8 @@ def config_parser(cmd: Optional[List[str]] = None) -> argparse.Namespace:
                                ("N_vis", int, 5), ("vis_every", int, 10000)):
         p.add_argument("--" + name, type=typ, default=default)
     p.add_argument("--model_name", type=str, default="TensorVMSplit", choices=["TensorVMSplit", "TensorCP", "NerfPlusPlus", "REFTensoRF"])
+    # (not a reference option) arithmetic of the appearance network in the evaluation renders: field.py `mlp_arith`, include/tvr.h TVR_ARITH_*; training is fp32-class always
+    p.add_argument("--mlp_arith", type=str, default="f32", choices=["f32", "f16act", "f16"])
     p.add_argument("--dataset_name", type=str, default="blender", choices=["blender", "llff", "nsvf", "dtu", "tankstemple", "own_data"])
     for name in ("with_depth", "lindisp", "white_bkgd"):
         p.add_argument("--" + name, action="store_true")
@@ -120,6 +122,7 @@ def _build_from_ckpt(args, ckpt, device):
     if bg:
         tensorf.set_nerfplusplus(bg["bg_freq"], bg["bg_view_freq"], bg["bg_D"], bg["radii"])
     tensorf.load(ckpt)
+    tensorf.mlp_arith = getattr(args, "mlp_arith", "f32")
     return tensorf, kwargs
 
 
@@ -194,6 +197,7 @@ def reconstruction(args, device="cuda", log=print, train_dataset=None, val_datas
                                           featureC=args.featureC, step_ratio=args.step_ratio, fea2denseAct=args.fea2denseAct)
         if isinstance(tensorf, NerfPlusPlus):
             tensorf.set_nerfplusplus(bg_freq=args.bg_freq, bg_view_freq=args.bg_view_freq, bg_D=args.bg_D, radii=args.radii)
+        tensorf.mlp_arith = getattr(args, "mlp_arith", "f32")            # (the evaluation renders of the run; the training steps compute fp32-class whatever it says)
 
     if args.lr_decay_iters > 0:
         lr_factor = args.lr_decay_target_ratio ** (1 / args.lr_decay_iters)
