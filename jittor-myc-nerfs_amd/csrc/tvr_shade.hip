@@ -43,18 +43,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define TVR_SB __builtin_amdgcn_sched_barrier(0)
 // the split is plain arithmetic: without a use in the gather phase hipcc sinks all nine of them (144 VALU) behind the matrix token
-// TVR_SPLIT_LATE 1 (round-4 experiment, measured and NOT shipped): only k-step 0's fragment is split (fp32 -> fp16 hi / lo) in the gather phase; k-steps 1..8 keep
-// their fp32 values (the same 72 registers) and are split under the basis product's MFMAs, whose windows are empty — 128 VALU instructions leave the gather
-// phase (-700 cycles per tile) and the token is held 250 cycles longer: 12.73 ms against 12.62 with all nine splits in the gather phase (gpurun_out/r4j).
-#ifndef TVR_SPLIT_LATE
-#define TVR_SPLIT_LATE 0
-#endif
-#define TVR_PIN8(v) asm volatile("" : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]), "+v"((v)[4]), "+v"((v)[5]), "+v"((v)[6]), "+v"((v)[7]))
+// (round-4 experiment, measured and not kept: only k-step 0's fragment split in the gather phase, k-steps 1..8 under the basis product's MFMAs, whose windows are
+// empty — 128 VALU instructions leave the gather phase, -700 cycles per tile, and the token is held 250 cycles longer: 12.73 ms against 12.62, profiles/r04_shade_schedule_ab.txt)
 #define TVR_GATHER_KEEP(s_)                                                                            \
     do {                                                                                               \
         if (RC) { _Pragma("unroll") for (int j_ = 0; j_ < 8; j_ += 2) rmax = absmax2(hvv[s_][j_], hvv[s_][j_ + 1], rmax); asm volatile("" : "+v"(rmax)); } \
-        if (!TVR_SPLIT_LATE || (s_) == 0) { hf[s_] = frag8<ARB>(hvv[s_]); TVR_PIN_FRAG(hf[s_]); } \
-        else TVR_PIN8(hvv[s_]);                                                                        \
+        hf[s_] = frag8<ARB>(hvv[s_]);                                                                  \
+        TVR_PIN_FRAG(hf[s_]);                                                                          \
     } while (0)
 #define TVR_PIN_FRAG(f)                                                                                \
     do {                                                                                               \
@@ -90,7 +85,7 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 #ifndef TVR_PRIO_G
 #define TVR_PRIO_G 0      // s_setprio while a wave is in its gather phase / its matrix phase.  Rounds 1-3 ran the gather ABOVE the matrix phase (2 / 0: hipcc's
 #endif                    // schedule of the matrix phase left its own VALU work outside the MFMAs' shadow anyway, and the gather's dependent load chains gained
-#ifndef TVR_PRIO_M        // 6 %).  With the matrix phase as an explicit pipeline (TVR_SCHED) every issue slot it loses to the partner is matrix-pipe idle time:
+#ifndef TVR_PRIO_M        // 6 %).  With the matrix phase as an explicit pipeline (round 4) every issue slot it loses to the partner is matrix-pipe idle time:
 #define TVR_PRIO_M 2      // matrix 2 / gather 0 takes 12.17 ms against 12.48 for 0 / 2 (gpurun_out/r4d, two interleaved rounds; 2 / 1: 12.28, 3 / 0: 12.18;
 #endif                    // round 3's schedule at 2 / 0: 12.81 against its own 12.62 at 0 / 2).
 // (the packed forms v_pk_fma_f32 / v_pk_mul_f32: half the instructions and 2 % SLOWER — beside the partner wave's MFMA stream a packed fp32 op takes
@@ -140,7 +135,7 @@ __device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag &b, f32x16 a
     for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h[rb]), __builtin_bit_cast(h8, b.hi), acc[rb], 0, 0, 0);
 }
 
-// ---- round 4: the matrix phase as an explicit software pipeline (TVR_SCHED) ------------------------------------------------------------
+// ---- round 4: the matrix phase as an explicit software pipeline (round 4) ------------------------------------------------------------
 // hipcc's own schedule of the hidden layers (round 3; scripts/isa_trace.py shows it) issued a k-step's A-fragment reads right in front of the MFMAs that
 // consume them (ds_read x4, s_waitcnt, MFMA: 70 exposed LDS round trips per tile) and clumped MFMAs (8 back to back) apart from the VALU work of the next
 // fragment.  What a wave's own stream can put under its MFMAs was measured (scripts/hwprobe/mfma_issue.hip, mfma_issue2.hip -> profiles/r04_mfma_issue_probe.txt,
@@ -167,7 +162,7 @@ __device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag &b, f32x16 a
 // The three MFMA windows of a row block: TVR_PIPE 1 puts one fragment read in each of the first two windows and V0 / V1 / V2 VALU instructions behind the three
 // MFMAs (layer 1: 1 / 3 / 5, layer 2: 0 / 2 / 4; 2 / 3 / 4 and 1 / 4 / 4 measured 5 % slower, 0 / 3 / 6 and 0 / 4 / 5 equal); TVR_PIPE 0: both reads in front of
 // the row block and 3 / 3 / 3 (2 / 2 / 2): 3 % slower.
-// TVR_L2RB (round 4, second step): layer 2 runs ROW BLOCK BY ROW BLOCK over eight pre-split fragments of relu(layer 1) (the 64 registers the layer-1 accumulators
+// Round 4, second step: layer 2 runs ROW BLOCK BY ROW BLOCK over eight pre-split fragments of relu(layer 1) (the 64 registers the layer-1 accumulators
 // leave), and layer 3 of row block rb - 1 — 16 relu, 48 FMA, 12 weight reads — runs under the MFMAs of row block rb: only the last row block's share of layer 3 is
 // left behind the token hand-over.  Layer 3 was 3.0 k cycles of every wave's chain (gather -> token -> matrix -> layer 3) with nothing beside it.
 #ifndef TVR_PIPE
@@ -586,7 +581,7 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 
 // The phase boundary and the basis product  F^T[32 x 32e] = Bas[32 x 144] . h^T  (27 MFMAs).  Uses hf[], bal[], F[], bashp, baslp, NLO, have_tok, mtok, lane of
 // the enclosing scope.  Phase boundary: every global load of this tile has landed before the first MFMA issues, and the compiler may not move loads
-// below it.  TVR_SCHED: ONE accumulation chain (l*hi, h*lo, h*hi per k-step, as the hidden layers do — round 3 summed three chains with 32 VALU adds behind
+// below it.  Round 4: ONE accumulation chain (l*hi, h*lo, h*hi per k-step, as the hidden layers do — round 3 summed three chains with 32 VALU adds behind
 // the last MFMA, pipe idle), the A fragments in a ring of four read two k-steps ahead of their use, the first two BEFORE the wave waits for its loads and
 // for the matrix token.
 #define TVR_BASIS_BLOCK()                                                                                                            \
@@ -610,10 +605,8 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
         _Pragma("unroll") for (int s_ = 0; s_ < 9; ++s_) {          /* one scheduling region per k-step: reads issued here are consumed two regions on */ \
             if (s_ + 2 < 9) bld_(s_ + 2);                                                                                           \
             mfma3<ARB>(br_[s_ & 3], hf[s_], accF_);                                                                                  \
-            if (TVR_SPLIT_LATE && s_ + 1 < 9) hf[s_ + 1] = split8(hvv[s_ + 1]);                                                     \
             if (s_ + 2 < 9) { if (s_ + 2 < NLO && ARB >= 2) TVR_SG_DSR(2); else TVR_SG_DSR(1); }                                     \
-            if (TVR_SPLIT_LATE && s_ + 1 < 9) { TVR_SG_MFMA(1); TVR_SG_VALU(4); TVR_SG_MFMA(1); TVR_SG_VALU(6); TVR_SG_MFMA(1); TVR_SG_VALU(6); } \
-            else TVR_SG_MFMA(ARB);                                                                                                   \
+            TVR_SG_MFMA(ARB);                                                                                                        \
             TVR_SB;                                                                                                                 \
         }                                                                                                                           \
         _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) F[r_] = accF_[r_];                                                        \
@@ -900,7 +893,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
             }
         }
 
-        // ---- layers 1 and 2 as ONE software pipeline (see TVR_SCHED above) ----
+        // ---- layers 1 and 2 as ONE software pipeline (see "round 4: the matrix phase as an explicit software pipeline" above) ----
         // layer 1: 10 k-steps; slot i = 8s + j of this lane is derived value (i % 5) of base value i / 5; sin / cos of a base value are taken in the step
         // that first needs them (2-3 per step).  Layer 2: the B fragments are the relu'd layer-1 accumulators, 8 registers per k-step; b2 is the initial
         // accumulator.  Layer 1's last k-step already carries layer 2's prologue: once row block 0's last MFMA has issued, b2 and W2's first fragments are
