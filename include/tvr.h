@@ -50,7 +50,9 @@ typedef struct {
     int32_t app_n_comp[3];         /* 1..48 per plane (built for 48; zero-padded likewise) */
     int32_t app_dim;               /* 27 */
     int32_t featureC;              /* 1..128 (built for 128; hidden units that do not exist are zero weights) */
-    int32_t view_pe, fea_pe;       /* 0..2 each (shadingMode MLP_Fea; built for 2, 2).  variant 1 (REFTensoRF): the built-for shape only.
+    int32_t view_pe, fea_pe;       /* 0..6 each (shadingMode MLP_Fea).  0..2: the fused kernels (built for 2, 2; every shipped config).  3..6 — TensorBase's own constructor
+                                    * defaults are 6, 6 (tensorBase.py:141-145) — render through the lockstep layer-1 form (+213 KB of packed weights, ~1.6 x the frame time)
+                                    * and TRAIN through the eager chain (tvr_train_forward / tvr_mlp_train_forward refuse them).  variant 1 (REFTensoRF): 2, 2 only.
                                     * Anything larger: TVR_ERR_UNSUPPORTED from tvr_scene_packed_bytes / tvr_scene_create */
     float near_, far_;             /* near_far */
     float step_size;               /* stepSize = mean(units)*step_ratio, computed by the host in fp32 */
@@ -110,6 +112,12 @@ const char *tvr_last_error(void);
 size_t tvr_scene_packed_bytes(const tvr_scene_desc *desc);
 int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed_bytes, tvr_scene **out);
 int tvr_scene_update(tvr_scene *scene, const tvr_scene_params *params, void *stream);
+/* tvr_scene_update captured into a hipGraph (a whole training step, tvr_train_forward's host does that): every REPLAY re-packs the fp32 images on the device and runs no
+ * host code, so whatever the host derived from "the parameters as last packed" is stale afterwards — (a) a range proof that switched the fp16-range check off
+ * (tvr_scene_set_range_check(scene, 0)): switch it back on, or prove again, before rendering; (b) the fp16 copies of the appearance factors that TVR_ARITH_F16 gathers
+ * (converted by an un-captured update or by the first render in that mode): call tvr_scene_touch() before the next render, which then converts first.
+ * tvr_scene_touch: "the packed fp32 images were rewritten behind the host's back" — marks every derived copy stale.  Host-only, no launch. */
+int tvr_scene_touch(tvr_scene *scene);
 /* AlphaGridMask (tensorBase.py:39-59): volume (gz,gy,gx) fp32 (non-negative) in device memory, kept by reference; NULL clears.
  * bits (optional, tvr_alpha_bits_bytes() of device memory, kept by reference): the march then tests `sample_alpha(p) > 0` (:491-496) on a
  * bit volume built here from the float one — same result, 1/32 of the footprint; NULL keeps the 8-tap float lookup. */

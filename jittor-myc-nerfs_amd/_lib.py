@@ -90,6 +90,7 @@ SYMBOLS = {
                                       C.POINTER(C.c_float * 3), C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_scene_set_range_check": (C.c_int, [C.c_void_p, C.c_int32]),
     "tvr_scene_set_arith": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tvr_scene_touch": (C.c_int, [C.c_void_p]),
     "tvr_scene_get_arith": (C.c_int, [C.c_void_p]),
     "tvr_scene_destroy": (C.c_int, [C.c_void_p]),
     "tvr_render_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),

@@ -552,9 +552,11 @@ class _FusedStepFn(torch.autograd.Function):
     (march -> appearance gather -> basis / heads / MLP -> compositing) and tvr_train_backward (its gradient, weight gradients, scatter into the VM
     factors, march backward).  Every kernel behind the march takes the number of appearance samples from the device; the buffers live in the model
     (model._train_buffers: sized once for `app_cap` samples, reused every step), so the step is a fixed sequence of launches — hipGraph-capturable —
-    and its picture / loss are bit-reproducible (every ray's queue segment is contiguous and sample-ordered, the compositing sums run in a fixed order); the
-    GRADIENTS are reproducible to rounding only (<= 2e-6 of the largest entry: the order of the rays in the queue is the order the march kernel's waves
-    finish in, and the VM-factor gradients are scattered with fp32 atomics — DESIGN.md 7, tests/test_gpu_fused_step.py).  Outputs: rgb_map [n,3], depth [n] (no gradient), pen_ray [n] (REFTensoRF: per-ray normal
+    and its picture / loss are bit-reproducible (every ray's queue segment is contiguous and sample-ordered, the compositing sums run in a fixed order).  GRADIENTS:
+    for batches of at most 65 536 rays (TVR_RAY_ORDER_MAX_RAYS: the march queue is put into ray order behind the march, using the q_out / q_j regions of the scratch
+    as temporaries) the network's gradients — basis, W1..W3, biases, REFTensoRF's heads — are BIT-IDENTICAL run to run (torch.equal in tests/test_gpu_fused_step.py);
+    the VM factors' gradients are scattered with fp32 atomics and are reproducible to rounding (<= 2e-6 of the largest entry).  Larger batches keep the order the
+    march kernel's waves finished in: every gradient then reproducible to rounding only.  Outputs: rgb_map [n,3], depth [n] (no gradient), pen_ray [n] (REFTensoRF: per-ray normal
     penalty terms; zeros otherwise).  Parameter order: density planes 0..2, density lines 0..2, app planes, app lines, basis, W1, b1, W2, b2, W3, b3
     (+ normal W b, diffuse W b, specular W b, rho W b)."""
 

@@ -62,6 +62,40 @@ static_assert(TVR_MLP_IMAGE_BYTES_REF + 16 <= 160 * 1024, "REFTensoRF's LDS imag
 #define TVR_NIN_REF 151  // 1 + 27 + 3 + 2*2*27 + 2*2*3 (MLPRender_Fea_Ref, models/REFTensoRF.py:9)
 #define TVR_BASIS_FRAG_BYTES (9 * 2 * 32 * 16)   // global: the LO parts of the basis fragments [9 k-steps][2 halves][32 rows][16 B] (hi parts: LDS image)
 
+// ---- round 5: the render path's MLP on v_mfma_f32_16x16x32_f16 (csrc/tvr_shade16.hip) -----------------------------------------------------------------
+// A fragment of that shape = 16 rows x 32 k = 64 lanes x 16 B = 1 KB, lane (i = lane & 15, g = lane >> 4) holding row i, k = 8g .. 8g+7 of the k-step; stored as the
+// lanes read it ([fragment][lane][8 halves]: a ds_read_b128 of 64 consecutive 16-B slots is conflict-free).  One {hi, lo} pair feeds SIX MFMAs: two 16-column B tiles
+// x three products — the LDS bytes per FLOP of the 32x32x16 form, on the shape that delivers 1.10 x its FLOP/s at the chip's power limit (profiles/r05_mfma_shape_probe.txt).
+//   W1  [5 k-steps][8 row blocks] fragments, hi | lo;  k slot 8s + j of lane group g  <->  derived value (8s + j) % 5 of base value (8s + j) / 5, base value r of group g
+//       = row 4g + r (r < 4) or 16 + 4g + r - 4 of the 32-row feature tile (rows 27..29 view direction, 31 the constant 1 whose column is b1)
+//   W2  [4][8] fragments, hi | lo;  k slot j of k-step s, group g  <->  hidden unit 32s + 4g + j (j < 4) or 32s + 16 + 4g + j - 4 (the layer-1 accumulators as they lie)
+//   b2 [128], b3 [3 + pad], W3 [3][128] fp32, 16 zero bytes
+//   basis (27 x 144): per k-step s < 4 {row block 0: 64 lanes x 16 B; row block 1: rows 16..26 only, [g][11][16 B]} = 1728 B, k-step 4 (k = 128..143: groups 0, 1
+//       only; groups 2, 3 read the zero bytes) 864 B; hi parts all five k-steps, lo parts k-steps 0, 1, 2, 4 — the lo parts of k-step 3 (2 KB as two full fragments)
+//       stay in global memory and are fetched once per tile: 160 KB of LDS hold no more
+#define TVR16_FRAG 1024
+#define TVR16_W1H 0
+#define TVR16_W1L (40 * TVR16_FRAG)
+#define TVR16_W2H (80 * TVR16_FRAG)
+#define TVR16_W2L (112 * TVR16_FRAG)
+#define TVR16_B2 (144 * TVR16_FRAG)
+#define TVR16_B3 (TVR16_B2 + 512)
+#define TVR16_W3 (TVR16_B3 + 16)
+#define TVR16_ZERO (TVR16_W3 + 3 * 512)
+#define TVR16_BASH (TVR16_ZERO + 16)
+#define TVR16_BAS_STEP 1728
+#define TVR16_BAS_RB1 1024
+#define TVR16_BAS_ROWS1 11                           // rows 16..26 of the basis: row block 1 keeps these
+#define TVR16_BAS_S4 (4 * TVR16_BAS_STEP)
+#define TVR16_BAS_S4_RB1 512
+#define TVR16_BAS_BYTES (TVR16_BAS_S4 + 864)         // 7776 = 27 x 144 x 2
+#define TVR16_BASL (TVR16_BASH + TVR16_BAS_BYTES)    // lo parts: k-steps 0..2 at s * 1728, k-step 4 at 3 * 1728
+#define TVR16_BASL_S4 (3 * TVR16_BAS_STEP)
+#define TVR16_IMAGE_BYTES (TVR16_BASL + TVR16_BAS_BYTES - TVR16_BAS_STEP)       // 163 360 B (+ 16 B of matrix tokens <= 163 840)
+#define TVR16_BASG_BYTES (2 * TVR16_FRAG)            // global: lo parts of basis k-step 3, row blocks 0 and 1 as full fragments (rows >= 27 zero)
+static_assert(TVR16_IMAGE_BYTES + 16 <= 160 * 1024, "the 16x16x32 LDS image must fit the CU's 160 KB");
+static_assert(TVR16_W3 % 16 == 0 && TVR16_BASH % 16 == 0, "float4 / uint4 reads need 16-B alignment");
+
 struct SceneDev {
     float lo[3], hi[3], inv[3];
     float gm1[3];                 // float(grid-1)
@@ -75,6 +109,8 @@ struct SceneDev {
     const void *mlp_image;        // TVR_MLP_IMAGE_BYTES(_REF), copied to LDS by the shade kernel
     const void *basis_frag;       // lo parts of the basis fragments [9][2][32][8] fp16 (hi parts: mlp_image + TVR_IMG_BASH)
     const float *b3;              // [3]
+    const void *img16;            // TVR16_IMAGE_BYTES: the LDS image of the 16x16x32 render kernel (TensorVMSplit scenes with at most two encoding frequencies), or nullptr
+    const void *basg16;           // TVR16_BASG_BYTES
     float near_, far_, step, shift, scale, thres;
     int act;
     int variant;                  // 0 TensorVMSplit, 1 REFTensoRF

@@ -64,6 +64,11 @@ hipError_t launch_scatter_rgb(const MarchOut &mo, int S, float *rgb_dense, hipSt
 hipError_t launch_density_feature(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream);
 hipError_t launch_alpha_sample(const SceneDev &sc, const float *xyz, long long m, float *out, hipStream_t stream);
 hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a, hipStream_t stream);
+// tvr_shade16.hip: the render path (queue -> queue, TensorVMSplit, default arithmetic, at most two encoding frequencies) on 16x16x32 tiles, and its fragment images
+hipError_t launch_shade16(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream);
+struct MlpShape;
+hipError_t launch_pack16(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3, const float *basis, void *img, void *basg,
+                         const MlpShape &sh, hipStream_t stream);
 hipError_t launch_pack_plane(const float *in, float *out, int Cin, int C, int H, int W, hipStream_t stream);
 // the scene's MLP_Fea / basis shape as the reference holds it (<= the shape the kernels are built for; packed with zero padding)
 struct MlpShape {

@@ -38,8 +38,8 @@
 #include "tvr_device.h"
 #include "tvr_kernels.h"
 #include "tvr_mfma.h"       // split2 / split8 / Frag / relu_f: the fp16 hi/lo split idioms shared with tvr_bg.hip, tvr_ngp.hip, tvr_mlp_train.hip
+#include "tvr_shade_common.h"   // Taps / load_taps / taps_eval, pk_fma / pk_mul, sincos_pe, sigmoid_f, absmax2 (shared with tvr_shade16.hip)
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define TVR_SB __builtin_amdgcn_sched_barrier(0)
 // the split is plain arithmetic: without a use in the gather phase hipcc sinks all nine of them (144 VALU) behind the matrix token
@@ -71,6 +71,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #else
 #define TVR_STAMP(x)
 #endif
+#ifndef TVR_PHASE_FREE
+#define TVR_PHASE_FREE 0  // experiment (round 5): 1 = the render kernel fetches the NEXT tile's k-step-0 taps (12 global loads per lane) between layer 1 and
+#endif                    // layer 2 of the current tile, i.e. INSIDE the matrix phase — the build that settles whether the phase rule protects anything (scripts/phase_rule_test.sh)
 #ifndef SH_WAVES
 #define SH_WAVES 8        // two waves per SIMD
 #endif
@@ -78,7 +81,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SH_MINW (SH_WAVES / 4)
 #define SH_TILE 32
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 #ifndef TVR_PRIO_F
 #define TVR_PRIO_F 0      // s_setprio of finish_tile (layer 3 + store), see the call site
 #endif
@@ -88,29 +90,6 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 #ifndef TVR_PRIO_M        // 6 %).  With the matrix phase as an explicit pipeline (round 4) every issue slot it loses to the partner is matrix-pipe idle time:
 #define TVR_PRIO_M 2      // matrix 2 / gather 0 takes 12.17 ms against 12.48 for 0 / 2 (gpurun_out/r4d, two interleaved rounds; 2 / 1: 12.28, 3 / 0: 12.18;
 #endif                    // round 3's schedule at 2 / 0: 12.81 against its own 12.62 at 0 / 2).
-// (the packed forms v_pk_fma_f32 / v_pk_mul_f32: half the instructions and 2 % SLOWER — beside the partner wave's MFMA stream a packed fp32 op takes
-// 52.7 cycles instead of 4.6, scripts/hwprobe/valu_rate.hip)
-// two plain v_fma_f32 / v_mul_f32, each pinned by an empty asm (without the pins, and with the SLP vectoriser off: 12.92 vs 12.75 ms)
-#ifndef TVR_PIN_PK
-#define TVR_PIN_PK 2      // 2: every fp32 op of the interpolation / layer 3 is pinned by an empty asm (keeps the SLP vectoriser from pairing them, and the ops where they
-#endif                    // are written); 1: one pin per interpolated channel pair (build with -fno-slp-vectorize); 0: none.  Each pin costs an s_nop 0 — hipcc guards
-                          // an inline asm that reads a just-written VGPR — 175 per tile at level 2; level 0 lets hipcc hoist the loads' consumers apart: 256 VGPRs + spills.
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c)
-{
-    float x = __builtin_fmaf(a.x, b.x, c.x), y = __builtin_fmaf(a.y, b.y, c.y);
-#if TVR_PIN_PK >= 1
-    asm volatile("" : "+v"(x)); asm volatile("" : "+v"(y));
-#endif
-    return f32x2{x, y};
-}
-__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b)
-{
-    float x = a.x * b.x, y = a.y * b.y;
-#if TVR_PIN_PK >= 1
-    asm volatile("" : "+v"(x)); asm volatile("" : "+v"(y));
-#endif
-    return f32x2{x, y};
-}
 
 // A fragments (hi, lo) of the four 32-row blocks of one k-step, from the LDS weight image
 struct AFrag4 { uint4 h[4], l[4]; };
@@ -226,7 +205,11 @@ __device__ __forceinline__ void mfma3x4(const AFrag4 &A, const Frag &b, f32x16 a
         if (has_read) TVR_SG_DSR(1);                                                                   \
         TVR_SG_MFMA(1); if (v0) TVR_SG_VALU(v0);                                                       \
     } while (0)
+#if TVR_DIAG & 16
+#define TVR_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, 2 * (n), 0)
+#else
 #define TVR_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
+#endif
 #define TVR_SG_VALU(n) __builtin_amdgcn_sched_group_barrier(0x402, (n), 0)      // VALU | TRANS
 #define TVR_SG_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
 struct AF { uint4 h, l; };
@@ -241,6 +224,23 @@ __device__ __forceinline__ void load_af(AF &A, const unsigned char *WH, const un
 template <int AR = 3>
 __device__ __forceinline__ void mfma3(const AF &A, const Frag &b, f32x16 &acc)
 {
+#if TVR_DIAG & 16
+    // timing experiment (round 5, wrong pictures): what the 16x16x32 shape would cost / save IN this kernel — every 32x32x16 MFMA becomes two v_mfma_f32_16x16x32_f16 (the
+    // same cycles, FLOPs, operand registers and LDS bytes: one {hi, lo} A pair per six MFMAs, as two 16-column B tiles sharing each A fragment would issue them)
+    if constexpr (AR == 3) {
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        f32x4_ q0 = __builtin_shufflevector(acc, acc, 0, 1, 2, 3), q1 = __builtin_shufflevector(acc, acc, 4, 5, 6, 7);
+        const h8 al = __builtin_bit_cast(h8, A.l), ah = __builtin_bit_cast(h8, A.h), bh = __builtin_bit_cast(h8, b.hi), bl = __builtin_bit_cast(h8, b.lo);
+        q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bl, q1, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, q1, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, q1, 0, 0, 0);
+        acc = __builtin_shufflevector(__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(acc, acc, 8, 9, 10, 11, 12, 13, 14, 15), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        return;
+    }
+#endif
     if constexpr (AR >= 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.l), __builtin_bit_cast(h8, b.hi), acc, 0, 0, 0);
     if constexpr (AR >= 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h), __builtin_bit_cast(h8, b.lo), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, A.h), __builtin_bit_cast(h8, b.hi), acc, 0, 0, 0);
@@ -253,130 +253,6 @@ __device__ __forceinline__ void mfma3(const AF &A, const Frag &b, f32x16 &acc)
     asm volatile("" : "+v"(name##_a));                                                                              \
     const unsigned char *name = (const unsigned char *)(const void __attribute__((address_space(3))) *)(size_t)name##_a
 
-// the interpolation's own forms: pinned per op at TVR_PIN_PK 2, per channel pair at 1
-__device__ __forceinline__ f32x2 ip_fma(f32x2 a, f32x2 b, f32x2 c)
-{
-#if TVR_PIN_PK >= 2
-    return pk_fma(a, b, c);
-#else
-    return f32x2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
-#endif
-}
-__device__ __forceinline__ f32x2 ip_mul(f32x2 a, f32x2 b)
-{
-#if TVR_PIN_PK >= 2
-    return pk_mul(a, b);
-#else
-    return f32x2{a.x * b.x, a.y * b.y};
-#endif
-}
-// the 6 taps (4 plane texels, 2 line texels) x 8 channels of one entry for one k-step
-struct Taps {
-    float4 t[4][2], lv[2][2];
-};
-
-// first float4 of the two this lane fetches from a texel (12 float4 = 48 channels) in k-step t of a plane.  (Measured alternative: lane half 0
-// takes float4s 0..5 and half 1 float4s 6..11 of the texel, so that a load instruction touches every 64-B segment once instead of from both
-// halves of the wave — 12.77 vs 12.70 ms, no gain: the ray-sorted queue already coalesces.)
-#define TVR_Q0(t, h) (4 * (t) + 2 * (h))
-template <bool CHECK>
-__device__ __forceinline__ void load_taps(Taps &T, const float4 *__restrict__ P, const float4 *__restrict__ Ln, int W, int H, int L,
-                                          float fx, float fy, float fl, int q0)
-{
-    float x0f, y0f, l0f;
-    if (CHECK) {
-        x0f = floorf(fminf(fmaxf(fx, -2.0f), (float)W + 1.0f));
-        y0f = floorf(fminf(fmaxf(fy, -2.0f), (float)H + 1.0f));
-        l0f = floorf(fminf(fmaxf(fl, -2.0f), (float)L + 1.0f));
-    } else {
-        x0f = floorf(fx); y0f = floorf(fy); l0f = floorf(fl);
-    }
-    const int x0 = (int)x0f, y0 = (int)y0f, l0 = (int)l0f;
-    const int Wp = W + 1;
-    if (!CHECK) {
-        // 32-bit texel offsets against the (wave-uniform) plane base: SGPR-base addressing, no 64-bit per-lane address registers (measured:
-        // 15.4 vs 15.8 ms with 64-bit per-lane addresses)
-        const unsigned o0 = ((unsigned)y0 * (unsigned)Wp + (unsigned)x0) * 12u + (unsigned)q0, o1 = o0 + (unsigned)Wp * 12u;
-        const float4 *p = P + o0, *p2 = P + o1;
-        T.t[0][0] = p[0]; T.t[0][1] = p[1];
-        T.t[1][0] = p[12]; T.t[1][1] = p[13];
-        T.t[2][0] = p2[0]; T.t[2][1] = p2[1];
-        T.t[3][0] = p2[12]; T.t[3][1] = p2[13];
-        const float4 *q = Ln + ((unsigned)l0 * 12u + (unsigned)q0);
-        T.lv[0][0] = q[0]; T.lv[0][1] = q[1];
-        T.lv[1][0] = q[12]; T.lv[1][1] = q[13];
-    } else {
-        // arbitrary coordinates (the API's lookups): every tap is fetched from a CLAMPED cell with the same 32-bit offsets, and taps_eval<true> gives the taps
-        // that lie outside the grid the weight zero — grid_sample's zeros padding without a select per fetched value.  (Rounds 1-3 selected the 12 float4 of
-        // every k-step against zero behind 64-bit per-tap addresses: 256 registers, spills, 25 us per tile.)
-        const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
-        const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
-        const int lc0 = min(max(l0, 0), L - 1), lc1 = min(max(l0 + 1, 0), L - 1);
-        const unsigned r0 = (unsigned)yc0 * (unsigned)Wp, r1 = (unsigned)yc1 * (unsigned)Wp;
-        const float4 *p00 = P + ((r0 + (unsigned)xc0) * 12u + (unsigned)q0), *p01 = P + ((r0 + (unsigned)xc1) * 12u + (unsigned)q0);
-        const float4 *p10 = P + ((r1 + (unsigned)xc0) * 12u + (unsigned)q0), *p11 = P + ((r1 + (unsigned)xc1) * 12u + (unsigned)q0);
-        T.t[0][0] = p00[0]; T.t[0][1] = p00[1];
-        T.t[1][0] = p01[0]; T.t[1][1] = p01[1];
-        T.t[2][0] = p10[0]; T.t[2][1] = p10[1];
-        T.t[3][0] = p11[0]; T.t[3][1] = p11[1];
-        const float4 *q0p = Ln + ((unsigned)lc0 * 12u + (unsigned)q0), *q1p = Ln + ((unsigned)lc1 * 12u + (unsigned)q0);
-        T.lv[0][0] = q0p[0]; T.lv[0][1] = q0p[1];
-        T.lv[1][0] = q1p[0]; T.lv[1][1] = q1p[1];
-    }
-}
-
-// bilinear(plane) * linear(line) for the 8 channels held in T (packed fp32 math: two channels per VALU op)
-template <bool CHECK>
-__device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, float fx, float fy, float fl, float out[8])
-{
-    float x0f, y0f, l0f;
-    if (CHECK) {
-        x0f = floorf(fminf(fmaxf(fx, -2.0f), (float)W + 1.0f));
-        y0f = floorf(fminf(fmaxf(fy, -2.0f), (float)H + 1.0f));
-        l0f = floorf(fminf(fmaxf(fl, -2.0f), (float)L + 1.0f));
-    } else {
-        x0f = floorf(fx); y0f = floorf(fy); l0f = floorf(fl);
-    }
-    const float wx = fx - x0f, wy = fy - y0f;
-    float wlf = fl - l0f, ulf = 1.0f - wlf;
-    const float ux = 1.0f - wx, uy = 1.0f - wy;
-    float a00 = ux * uy, a01 = wx * uy, a10 = ux * wy, a11 = wx * wy;
-    if (CHECK) {                                                    // taps outside the grid: weight zero (load_taps<true> fetched a clamped cell for them)
-        const int x0 = (int)x0f, y0 = (int)y0f, l0 = (int)l0f;
-        const bool xi0 = (x0 >= 0) && (x0 < W), xi1 = (x0 + 1 >= 0) && (x0 + 1 < W);
-        const bool yi0 = (y0 >= 0) && (y0 < H), yi1 = (y0 + 1 >= 0) && (y0 + 1 < H);
-        a00 = (xi0 && yi0) ? a00 : 0.0f; a01 = (xi1 && yi0) ? a01 : 0.0f;
-        a10 = (xi0 && yi1) ? a10 : 0.0f; a11 = (xi1 && yi1) ? a11 : 0.0f;
-        ulf = ((l0 >= 0) && (l0 < L)) ? ulf : 0.0f;
-        wlf = ((l0 + 1 >= 0) && (l0 + 1 < L)) ? wlf : 0.0f;
-    }
-    const f32x2 w00 = {a00, a00}, w01 = {a01, a01}, w10 = {a10, a10}, w11 = {a11, a11};
-    const f32x2 ul = {ulf, ulf}, wl = {wlf, wlf};
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const f32x2 t0 = hh ? f32x2{T.t[0][g].z, T.t[0][g].w} : f32x2{T.t[0][g].x, T.t[0][g].y};
-            const f32x2 t1 = hh ? f32x2{T.t[1][g].z, T.t[1][g].w} : f32x2{T.t[1][g].x, T.t[1][g].y};
-            const f32x2 t2 = hh ? f32x2{T.t[2][g].z, T.t[2][g].w} : f32x2{T.t[2][g].x, T.t[2][g].y};
-            const f32x2 t3 = hh ? f32x2{T.t[3][g].z, T.t[3][g].w} : f32x2{T.t[3][g].x, T.t[3][g].y};
-            const f32x2 l0 = hh ? f32x2{T.lv[0][g].z, T.lv[0][g].w} : f32x2{T.lv[0][g].x, T.lv[0][g].y};
-            const f32x2 l1 = hh ? f32x2{T.lv[1][g].z, T.lv[1][g].w} : f32x2{T.lv[1][g].x, T.lv[1][g].y};
-            f32x2 p = ip_mul(w00, t0);
-            p = ip_fma(w01, t1, p);
-            p = ip_fma(w10, t2, p);
-            p = ip_fma(w11, t3, p);
-            f32x2 q = ip_mul(ul, l0);
-            q = ip_fma(wl, l1, q);
-            f32x2 r = ip_mul(p, q);
-#if TVR_PIN_PK == 1
-            asm volatile("" : "+v"(r.x), "+v"(r.y));
-#endif
-            out[g * 4 + hh * 2] = r.x;
-            out[g * 4 + hh * 2 + 1] = r.y;
-        }
-    }
-}
 
 
 // ---- the gather of the one-product arithmetic (AR == 1, queue source): the appearance factors as fp16 (SceneDev::aplane16 / aline16, 96 B per texel) — one 16-B load
@@ -418,22 +294,6 @@ __device__ __forceinline__ void taps_eval16(const Taps16 &T, float fx, float fy,
     }
 }
 
-// sine / cosine for the positional encoding: v_sin_f32 / v_cos_f32 (they take revolutions) behind a two-term Cody-Waite reduction
-// x - k*2pi, 7 instructions per pair and no branch (a branch per value kept hipcc from interleaving layer 1's VALU work with its MFMAs).
-// The reduction is exact to an ulp of the remainder for |x| < ~1e4 (k has <= 11 bits), so the error is the hardware's (~1e-6 abs),
-// the same as round 1's fract() form had for small |x| (scripts/accuracy_report.py), and smaller than that form's for |x| > 100.
-__device__ __forceinline__ void sincos_pe(float x, float &s, float &c)
-{
-    const float k = rintf(x * 0.15915494309189535f);
-    float r = __builtin_fmaf(k, -6.2831854820251465f, x);
-    r = __builtin_fmaf(k, 1.7484555e-7f, r);                   // 2pi = 6.2831854820251465 - 1.7484555e-7
-    const float t = r * 0.15915494309189535f;
-    s = __builtin_amdgcn_sinf(t);
-    c = __builtin_amdgcn_cosf(t);
-}
-
-#define TVR_F16_MAX 65504.0f
-__device__ __forceinline__ float absmax2(float a, float b, float m) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), m); }      // one v_max3_f32 |a|, |b|, m
 // what a tile hands from its matrix phase to finish_tile (layer 3 + epilogue)
 struct Carry {
     f32x16 acc2;                 // layer-2 accumulators of row block 3 (b2 included), hidden unit 96 + acc_row(r, h) in acc2[r]
@@ -695,6 +555,18 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         qe_next = a.q_pos[le];
         qray_next = a.q_ray[le];
     }
+#if TVR_PHASE_FREE
+    constexpr bool PFREE = SRC == SH_SRC_QUEUE && !GEN && AR == 3;
+    Taps Tpre;
+    auto prefetch_next = [&]() {                                // taps of k-step 0 (plane 0, channels 8h..8h+7) of the entry in qe_next
+        float fcn[3];
+        const float pnn[3] = {qe_next.x, qe_next.y, qe_next.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fcn[k] = unnorm(pnn[k], sc.gm1[k]);
+        load_taps<false>(Tpre, sc.aplane[0], sc.aline[0], sc.grid[0], sc.grid[1], sc.grid[2], fcn[0], fcn[1], fcn[2], TVR_Q0(0, h));
+    };
+    if constexpr (PFREE) { if (n_total > 0) prefetch_next(); }
+#endif
     // GEN: every wave of the workgroup makes the same number of passes (its layer 1 has workgroup barriers); a pass beyond the last tile works on dead lanes
     const long long tile_end = GEN ? ((n_tiles - (long long)lblk * SH_WAVES + tile_stride - 1) / tile_stride) * tile_stride + (long long)lblk * SH_WAVES + wave : n_tiles;
     for (long long tile = (long long)lblk * SH_WAVES + wave; tile < tile_end; tile += tile_stride) {
@@ -785,10 +657,18 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     if constexpr (H16) load_taps16(T16[s2 % (PFD + 1)], sc.aplane16[p], sc.aline16[p], sc.grid[ax], fc[ax], fc[bx], fc[vx], 2 * (s2 % 3) + h);
                     else load_taps<TVR_CHK>(T[s2 % (PFD + 1)], sc.aplane[p], sc.aline[p], sc.grid[ax], sc.grid[bx], sc.grid[vx], fc[ax], fc[bx], fc[vx], TVR_Q0(s2 % 3, h));
                 };
+#if TVR_PHASE_FREE
+                if constexpr (PFREE) T[0] = Tpre;                // issued in the previous tile's matrix phase (or in front of the loop)
+#endif
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
 #pragma unroll
-                    for (int s2 = (s == 0 ? 0 : tgt(s - 1) + 1); s2 <= tgt(s); ++s2) issue(s2);
+                    for (int s2 = (s == 0 ? 0 : tgt(s - 1) + 1); s2 <= tgt(s); ++s2) {
+#if TVR_PHASE_FREE
+                        if (PFREE && s2 == 0) continue;
+#endif
+                        issue(s2);
+                    }
                     if (!REF && s == 7) {                              // (REFTensoRF: behind the loop — its extra live values leave no room earlier)
                         // the basis A fragments (the tile's last global loads) ride behind the last taps
                         // (lo parts; the hi parts are in LDS.  Byte offsets against the uniform base, opaque per tile: hoisted per-step 64-bit
@@ -1037,6 +917,9 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                 TVR_SB;
             }
             }           // !GEN
+#if TVR_PHASE_FREE
+            if constexpr (PFREE) { TVR_SB; prefetch_next(); TVR_SB; }      // 12 global loads per lane between the MFMAs of layer 1 and those of layer 2
+#endif
             TVR_STAMP(tg3);
             {
                 f32x16 a2prev = f32x16{0};                          // the finished row block layer 3 is working through
@@ -1166,6 +1049,13 @@ static hipError_t launch_shade_v(const SceneDev &sc, int src, int dst, const Sha
             if (src == SH_SRC_H && dst == SH_DST_TRAIN) return hipErrorInvalidValue;
         }
     }
+#ifndef TVR_SHADE16
+#define TVR_SHADE16 1      // 0: A/B builds — the render path stays on this file's 32x32x16 kernel
+#endif
+#if TVR_SHADE16
+    // round 5: the render path of TensorVMSplit scenes in the default arithmetic runs on 16x16x32 tiles (tvr_shade16.hip); every other mode stays here
+    if constexpr (!REF) { if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE && sc.arith == TVR_ARITH_F32 && sc.img16) return launch_shade16(sc, a, stream); }
+#endif
     if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, REF, true>(sc, a, stream) : launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, REF, false>(sc, a, stream);
     if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return rc ? launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, false>(sc, a, stream);
     if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_ar<SH_SRC_FEAT, SH_DST_RGB, REF, true>(sc, a, stream) : launch_shade_ar<SH_SRC_FEAT, SH_DST_RGB, REF, false>(sc, a, stream);

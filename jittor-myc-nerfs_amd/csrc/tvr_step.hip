@@ -328,11 +328,15 @@ hipError_t launch_colsum(const float *A, int lda, int K, long long m_cap, const 
 // launches (~10 us of a 3.4 ms step): an exclusive scan of the per-ray counts, a gather of every ray's segment to its scanned offset (into the queue's unused
 // q_out / q_j regions), a copy back.  The inference march is untouched (a frame's 55 M entries would cost 0.4 ms to move, and its picture does not depend on
 // the order).  After this pass the weight gradients of two runs on the same batch are bit-identical (tests/test_gpu_fused_step.py).
-__global__ __launch_bounds__(1024) void queue_scan_kernel(const unsigned *__restrict__ ray_cnt, unsigned *__restrict__ ray_new, const int n_rays)
+// A march that raised its fault flag (counter[2] != 0: a wave gave up in the tile wait and never wrote ray_off / ray_cnt for its rays) leaves those words as they
+// lay — uninitialised scratch for all this pass knows.  The step is void then (composite_train_forward writes NaN, the backward zeros): all three kernels return
+// at once, and the gather clamps every segment to the queue's length besides, so that no count or offset it reads can carry an access out of the buffers.
+__global__ __launch_bounds__(1024) void queue_scan_kernel(const unsigned *__restrict__ counter, const unsigned *__restrict__ ray_cnt, unsigned *__restrict__ ray_new, const int n_rays)
 {
     __shared__ unsigned wsum[16];
     __shared__ unsigned carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (counter[2] != 0u) return;                                  // (uniform over the workgroup: nobody reaches a barrier)
     if (threadIdx.x == 0) carry_s = 0u;
     __syncthreads();
     for (int base = 0; base < n_rays; base += 1024) {
@@ -360,8 +364,11 @@ __global__ __launch_bounds__(256) void queue_gather_kernel(const MarchOut mo, co
                                                            const int n_rays)
 {
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (ray >= n_rays) return;
-    const unsigned from = mo.ray_off[ray], cnt = mo.ray_cnt[ray], to = ray_new[ray];
+    if (ray >= n_rays || mo.counter[2] != 0u) return;
+    const unsigned m = *mo.counter;
+    const unsigned from = mo.ray_off[ray], to = ray_new[ray];
+    unsigned cnt = mo.ray_cnt[ray];
+    if (from > m || to > m || cnt > m - from || cnt > m - to) cnt = 0u;      // never true behind a sound march (the scan of the counts ends at m)
     for (unsigned i = lane; i < cnt; i += 64) {
         tmp_pos[to + i] = mo.q_pos[from + i];
         tmp_ray[to + i] = mo.q_ray[from + i];
@@ -371,6 +378,7 @@ __global__ __launch_bounds__(256) void queue_gather_kernel(const MarchOut mo, co
 
 __global__ __launch_bounds__(256) void queue_copyback_kernel(const MarchOut mo, const float4 *__restrict__ tmp_pos, const unsigned *__restrict__ tmp_ray)
 {
+    if (mo.counter[2] != 0u) return;
     const unsigned m = *mo.counter;
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) {
         mo.q_pos[e] = tmp_pos[e];
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(256) void queue_copyback_kernel(const MarchOut mo, 
 
 hipError_t launch_queue_ray_order(const MarchOut &mo, unsigned *ray_new, float4 *tmp_pos, unsigned *tmp_ray, int n_rays, hipStream_t stream)
 {
-    hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(1024), 0, stream, mo.ray_cnt, ray_new, n_rays);
+    hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(1024), 0, stream, mo.counter, mo.ray_cnt, ray_new, n_rays);
     hipLaunchKernelGGL(queue_gather_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream, mo, ray_new, tmp_pos, tmp_ray, n_rays);
     hipLaunchKernelGGL(queue_copyback_kernel, dim3(1024), dim3(256), 0, stream, mo, tmp_pos, tmp_ray);
     return hipGetLastError();

@@ -152,6 +152,7 @@ class TensorBase(torch.nn.Module):
         self._scratch = None
         self._sig = None
         self._range_proven = None    # fp16 range of the inference kernels: None = not decided for the current parameters (fp16_range_report)
+        self._captured_update = False  # a tvr_scene_update of this model was captured into a hipGraph (see _ensure_scene)
         self._alphaMask = None
         self.update_stepSize(gridSize)
         self.init_svd_volume(gridSize[0], device)
@@ -319,6 +320,11 @@ class TensorBase(torch.nn.Module):
             for i, lin in enumerate(self._extra_linears()):
                 sp.ref_W[i], sp.ref_b[i] = lin.weight.data_ptr(), lin.bias.data_ptr()
             L.check(lib.tvr_scene_update(self._scene, C.byref(sp), _stream_ptr(self.device)), "tvr_scene_update")
+            if torch.cuda.is_current_stream_capturing():
+                # This update is being CAPTURED (a whole training step as a hipGraph): every replay re-packs the images on the device and runs no host code, so
+                # nothing the host caches about "the parameters as packed" — the fp16-range proof, the freshness of the fp16 factor copies — can be trusted from
+                # here on.  _settle_range_check keeps the in-kernel check on and marks the copies stale before every inference call of such a model.
+                self._captured_update = True
             self._sig = sig
             self._range_proven = None                  # new parameters: the fp16-range proof (below) is void until an inference call asks again
             L.check(lib.tvr_scene_set_range_check(self._scene, 1), "tvr_scene_set_range_check")
@@ -384,6 +390,14 @@ class TensorBase(torch.nn.Module):
 
     def _settle_range_check(self):
         """Called by the inference entry points after _ensure_scene(): decide once per parameter state whether the kernels must check the fp16 range."""
+        if getattr(self, "_captured_update", False):
+            # hipGraph replays of a captured training step move the parameters behind the host's back: no proof made on earlier values holds, and the fp16
+            # copies the "f16" arithmetic gathers may be older than the fp32 images — check in the kernel, convert before the next "f16" render
+            L.check(L.lib().tvr_scene_touch(self._scene), "tvr_scene_touch")
+            if self.fp16_range_check != "off":
+                self._range_proven = False
+                L.check(L.lib().tvr_scene_set_range_check(self._scene, 1), "tvr_scene_set_range_check")
+                return
         if self._range_proven is not None:
             return
         mode = self.fp16_range_check

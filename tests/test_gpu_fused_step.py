@@ -342,3 +342,35 @@ def test_make_graphed_step_and_the_capture_guard(tiny_dump, tiny_arrays, hyper_t
         with torch.cuda.graph(torch.cuda.CUDAGraph()):
             step_d()
     torch.cuda.synchronize()
+
+
+def test_graph_replays_do_not_leave_stale_host_caches(tiny_dump, tiny_arrays, hyper_tiny):
+    """hipGraph replays of a captured training step re-pack the fp32 images on the device and run no host code.  What the host had cached about the
+    parameters must not survive them: (a) the fp16 copies of the appearance factors the "f16" arithmetic gathers — an f16 render BEFORE the replays converted
+    them; an f16 render AFTER must see the moved parameters; (b) the fp16-range proof — the in-kernel check stays on for such a model.  Compared against a
+    fresh model loaded with the replayed model's parameters."""
+    from jittor_myc_nerfs_amd import make_graphed_step
+    rays = _batch(tiny_dump, 8)
+    target = torch.rand((rays.shape[0], 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    jitter = torch.rand(rays.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    m = make_model(tiny_arrays, hyper_tiny)
+    opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99), capturable=True, foreach=True)
+    replay = make_graphed_step(_step_fn(m, rays, target, jitter, opt), warmup=2)          # captured with mlp_arith == "f32"
+    assert m._captured_update
+    eval_rays = torch.tensor(tiny_dump["rays"], device="cuda")
+    m.mlp_arith = "f16"
+    rgb0, _ = m.render_rays(eval_rays, white_bg=True, N_samples=TINY["N_samples"])       # converts the fp16 copies from the current images
+    rgb0 = rgb0.clone()
+    for _ in range(12):
+        replay()
+    torch.cuda.synchronize()
+    rgb1, _ = m.render_rays(eval_rays, white_bg=True, N_samples=TINY["N_samples"])       # (render_rays re-packs only if a version counter moved: fused Adam moves none)
+    assert m._range_proven is False                                                      # the kernel checks the range: no proof was carried over the replays
+    fresh = make_model(tiny_arrays, hyper_tiny)
+    with torch.no_grad():
+        for pf, pm in zip(_params(fresh), _params(m)):
+            pf.copy_(pm)
+    fresh.mlp_arith = "f16"
+    rgb2, _ = fresh.render_rays(eval_rays, white_bg=True, N_samples=TINY["N_samples"])
+    assert float((rgb1 - rgb0).abs().max()) > 1e-3                                       # twelve Adam steps at lr 0.02 moved the picture
+    assert torch.equal(rgb1, rgb2), float((rgb1 - rgb2).abs().max())
