@@ -10,11 +10,10 @@
 //
 // Tile: 32 queue entries per wave as TWO 16-column B tiles that share every A fragment.  Lane (c = lane & 15, g = lane >> 4) serves entries eA = 32 tile + c
 // and eB = eA + 16 and holds, of each, k-group g (8 of the 32 k values of a k-step) as B operand and rows 4g .. 4g+3 of every 16-row block as accumulators.
-//   GATHER phase  nine units of 6 taps x 2 float4 per lane (the 32x32 kernel's count), every unit inside ONE plane: six units (plane 0..2) x (entry A | B) fetch channels
-//                 8g .. 8g+7 (k-steps 0..2 = channels 0..31 of plane 0 / 1 / 2), three PACKED units fetch channels 32 + 8 (g & 1) .. of plane 0 / 1 / 2 for the lane's own
-//                 entry (groups 0, 1: A; groups 2, 3: B); v_permlane32_swap of the plane-0 and plane-1 packed fragments IS k-step 3's B operand of both tiles, the two
-//                 halves of the plane-2 one are k-step 4's (the A operand of groups 2, 3 is zero there).  The k order is the packed basis image's, nobody else sees it.
-//                 Offsets and weights are computed once per (entry, plane); the interpolation is tvr_shade_common.h's taps_eval op for op: the same h values.
+//   GATHER phase  every lane gathers for ITS OWN entry (groups 0, 1: A; groups 2, 3: B): nine units of 6 taps x 2 float4 (the 32x32 kernel's count), unit u = channels
+//                 16u + 8 (g & 1) .. + 7 of the 144 = of plane u / 3; offsets and weights once per plane.  A unit's fragment holds {A | B} in its lower | upper half, and
+//                 v_permlane32_swap(unit 2s, unit 2s+1) IS k-step s's B operand of tile A | tile B in the natural k order; unit 8's halves are k-step 4's (the A operand of
+//                 groups 2, 3 is zero there).  The interpolation is tvr_shade_common.h's taps_eval op for op: the same h values as the 32x32 kernel's.
 //   MATRIX phase  (behind the SIMD's matrix token, as before)  basis 60 MFMAs -> F (8 base values per lane and entry) -> layer 1: 5 k-steps x 8 row blocks x 6
 //                 MFMAs, the next k-step's [v, sin v, sin 2v, cos v, cos 2v] fragments derived under them -> layer 2: B = relu(layer-1 accumulators) as they lie
 //                 (row blocks 2s, 2s+1 of lane group g = k-step s), row block by row block, layer 3 (fp32 FMAs) of row block rb-1 under the MFMAs of row block rb.
@@ -49,6 +48,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef S16_TOKEN_SPINS
 #define S16_TOKEN_SPINS 4096
+#endif
+#ifndef S16_MTOKEN
+#define S16_MTOKEN 1      // the per-SIMD matrix token (tvr_shade.hip: without it the two waves of a SIMD convoy); 0: A/B builds
 #endif
 #ifndef S16_TIMING
 #define S16_TIMING 0      // diagnostic build: per-phase s_memtime sums into stats[8..15] (scripts/phase_timing.py)
@@ -187,9 +189,10 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
             qray_next = a.q_ray[le];
         }
         float dA[3], dB[3];
-        // what a unit needs of (entry, plane): texel offsets (float4 units against the plane's / line's base), the four bilinear weights, the two line weights.
-        // Computed ONCE per entry and plane (the 32x32 kernel's per-k-step recomputation was folded by hipcc; here three position sets are live — entry A, entry B and
-        // the lane's own entry for the packed units — and it is written out)
+        // Every lane gathers for ITS OWN entry only (groups 0, 1: entry A; groups 2, 3: entry B): unit u = channels 16u + 8 (g & 1) .. + 7 of the 144, i.e. of plane
+        // u / 3 — nine units per lane, each inside one plane, one set of offsets / weights per plane.  A unit's fragment X therefore holds {entry A | entry B} in its
+        // lower | upper half, and v_permlane32_swap(X_2s, X_2s+1) = {X_2s.lo, X_2s+1.lo} | {X_2s.hi, X_2s+1.hi} IS k-step s's B operand of tile A | of tile B, in the natural
+        // k order 32 s + 8 g + j.  Unit 8 (channels 128..143) stands alone: its halves are k-step 4's operands, whose A fragments are zero in groups 2, 3.
         struct PP { unsigned o0, o1, ol; float a00, a01, a10, a11, ul, wl; };
         auto plane_params = [&](const float f[3], int p, PP &P) {
             const int ax = (p == 2) ? 1 : 0, bx = (p == 0) ? 1 : 2, vx = 2 - p;            // matMode / vecMode (tensorBase.py:168-169)
@@ -237,68 +240,62 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
 #endif
             }
         };
-        PP ppA[3], ppB[3], ppM[3];
+        PP pp[3];
         {
             const float *rp = a.rays + (size_t)qray * 6 + 3;
             const float d0 = rp[0], d1 = rp[1], d2 = rp[2];
-            float pA[3], pB[3], fA[3], fB[3], fM[3];
-            halves_f(qe.x, pA[0], pB[0]); halves_f(qe.y, pA[1], pB[1]); halves_f(qe.z, pA[2], pB[2]);
-            halves_f(d0, dA[0], dB[0]); halves_f(d1, dA[1], dB[1]); halves_f(d2, dA[2], dB[2]);
+            halves_f(d0, dA[0], dB[0]); halves_f(d1, dA[1], dB[1]); halves_f(d2, dA[2], dB[2]);       // (rows 27..29 of BOTH tiles sit in groups 2, 3)
+            const float f[3] = {unnorm(qe.x, sc.gm1[0]), unnorm(qe.y, sc.gm1[1]), unnorm(qe.z, sc.gm1[2])};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                fA[k] = unnorm(pA[k], sc.gm1[k]);
-                fB[k] = unnorm(pB[k], sc.gm1[k]);
-                fM[k] = unnorm(k == 0 ? qe.x : (k == 1 ? qe.y : qe.z), sc.gm1[k]);         // this lane's own entry (A below, B above): the packed units
-            }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) { plane_params(fA, p, ppA[p]); plane_params(fB, p, ppB[p]); plane_params(fM, p, ppM[p]); }
+            for (int p = 0; p < 3; ++p) plane_params(f, p, pp[p]);
         }
-        float rmaxA = 0.0f, rmaxB = 0.0f;              // RC: running max |x| of this lane's fp16-split operands, per entry
-        // units 0..5: (plane n >> 1, entry n & 1), channels 8g .. 8g+7 of the plane; units 6..8: plane n - 6, channels 32 + 8 (g & 1) .. of the lane's OWN entry
+        float rmax = 0.0f;                             // RC: running max |x| of this lane's fp16-split operands (its own entry's in the gather, both tiles' below)
         Frag hf[9];
         uint4 balg0, balg1;                           // lo parts of basis k-step 3 (global)
         {
             Taps T[2];
-            const unsigned q_lo = 32u * (unsigned)g, q_hi = 32u * (4u + (unsigned)(g & 1));      // bytes: two float4 per lane group
-            auto issue = [&](int n) {
-                if (n < 6) load_unit(T[n & 1], n >> 1, (n & 1) ? ppB[n >> 1] : ppA[n >> 1], q_lo);
-                else load_unit(T[n & 1], n - 6, ppM[n - 6], q_hi);
-            };
+            const unsigned qb0 = 32u * (unsigned)(g & 1);                                  // bytes: unit u reads float4s 4 (u % 3) + 2 (g & 1), + 1 of the texel
+            auto issue = [&](int u) { load_unit(T[u & 1], u / 3, pp[u / 3], qb0 + 64u * (unsigned)(u % 3)); };
             issue(0);
 #pragma unroll
-            for (int n = 0; n < 9; ++n) {
-                if (n + 1 < 9) issue(n + 1);
-                if (n == 7) {                          // the tile's last global loads ride behind the last taps
+            for (int u = 0; u < 9; ++u) {
+                if (u + 1 < 9) issue(u + 1);
+                if (u == 7) {                          // the tile's last global loads ride behind the last taps
                     unsigned boff = (unsigned)(lane * 16);
                     asm volatile("" : "+v"(boff));
                     balg0 = *(const uint4 *)((const unsigned char *)sc.basg16 + boff);
                     balg1 = *(const uint4 *)((const unsigned char *)sc.basg16 + (boff + TVR16_FRAG));
                 }
                 float hv[8];
-                eval_unit(T[n & 1], n < 6 ? ((n & 1) ? ppB[n >> 1] : ppA[n >> 1]) : ppM[n - 6], hv);
+                eval_unit(T[u & 1], pp[u / 3], hv);
                 if (RC) {
-                    float m = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) m = absmax2(hv[j], hv[j + 1], m);
-                    if (n >= 6) { rmaxA = up ? rmaxA : fmaxf(rmaxA, m); rmaxB = up ? fmaxf(rmaxB, m) : rmaxB; }
-                    else if (n & 1) rmaxB = fmaxf(rmaxB, m);
-                    else rmaxA = fmaxf(rmaxA, m);
-                    asm volatile("" : "+v"(rmaxA), "+v"(rmaxB));
+                    for (int j = 0; j < 8; j += 2) rmax = absmax2(hv[j], hv[j + 1], rmax);
+                    asm volatile("" : "+v"(rmax));
                 }
-                hf[n] = split8(hv);
-                asm volatile("" : "+v"(hf[n].hi.x), "+v"(hf[n].hi.y), "+v"(hf[n].hi.z), "+v"(hf[n].hi.w), "+v"(hf[n].lo.x), "+v"(hf[n].lo.y), "+v"(hf[n].lo.z), "+v"(hf[n].lo.w));
+                hf[u] = split8(hv);
+                asm volatile("" : "+v"(hf[u].hi.x), "+v"(hf[u].hi.y), "+v"(hf[u].hi.z), "+v"(hf[u].hi.w), "+v"(hf[u].lo.x), "+v"(hf[u].lo.y), "+v"(hf[u].lo.z), "+v"(hf[u].lo.w));
                 S16_SB;
             }
         }
-        // k-steps 3 and 4 from the packed units X = hf[6] (plane 0), Y = hf[7] (plane 1), Z = hf[8] (plane 2), each {entry A in the lower half | entry B in the upper}:
-        // v_permlane32_swap(X, Y) = {X.lo, Y.lo} | {X.hi, Y.hi} = k-step 3's B operand of tile A | of tile B; Z's halves = k-step 4's (groups 2, 3 meet zero weights)
-        Frag h3A, h3B, h4A, h4B;
+        // the B operands of the basis product: k-step s < 4 of tile A | B = the lower | upper halves of units 2s and 2s + 1 side by side; k-step 4 = unit 8's halves
+        Frag hA[5], hB[5];
         {
             auto sw = [](unsigned x, unsigned y, unsigned &o0, unsigned &o1) { const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false); o0 = r[0]; o1 = r[1]; };
-            sw(hf[6].hi.x, hf[7].hi.x, h3A.hi.x, h3B.hi.x); sw(hf[6].hi.y, hf[7].hi.y, h3A.hi.y, h3B.hi.y); sw(hf[6].hi.z, hf[7].hi.z, h3A.hi.z, h3B.hi.z); sw(hf[6].hi.w, hf[7].hi.w, h3A.hi.w, h3B.hi.w);
-            sw(hf[6].lo.x, hf[7].lo.x, h3A.lo.x, h3B.lo.x); sw(hf[6].lo.y, hf[7].lo.y, h3A.lo.y, h3B.lo.y); sw(hf[6].lo.z, hf[7].lo.z, h3A.lo.z, h3B.lo.z); sw(hf[6].lo.w, hf[7].lo.w, h3A.lo.w, h3B.lo.w);
-            halves_u(hf[8].hi.x, h4A.hi.x, h4B.hi.x); halves_u(hf[8].hi.y, h4A.hi.y, h4B.hi.y); halves_u(hf[8].hi.z, h4A.hi.z, h4B.hi.z); halves_u(hf[8].hi.w, h4A.hi.w, h4B.hi.w);
-            halves_u(hf[8].lo.x, h4A.lo.x, h4B.lo.x); halves_u(hf[8].lo.y, h4A.lo.y, h4B.lo.y); halves_u(hf[8].lo.z, h4A.lo.z, h4B.lo.z); halves_u(hf[8].lo.w, h4A.lo.w, h4B.lo.w);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const Frag &X = hf[2 * s4], &Y = hf[2 * s4 + 1];
+                sw(X.hi.x, Y.hi.x, hA[s4].hi.x, hB[s4].hi.x); sw(X.hi.y, Y.hi.y, hA[s4].hi.y, hB[s4].hi.y); sw(X.hi.z, Y.hi.z, hA[s4].hi.z, hB[s4].hi.z); sw(X.hi.w, Y.hi.w, hA[s4].hi.w, hB[s4].hi.w);
+                sw(X.lo.x, Y.lo.x, hA[s4].lo.x, hB[s4].lo.x); sw(X.lo.y, Y.lo.y, hA[s4].lo.y, hB[s4].lo.y); sw(X.lo.z, Y.lo.z, hA[s4].lo.z, hB[s4].lo.z); sw(X.lo.w, Y.lo.w, hA[s4].lo.w, hB[s4].lo.w);
+            }
+            const Frag &Z = hf[8];
+            halves_u(Z.hi.x, hA[4].hi.x, hB[4].hi.x); halves_u(Z.hi.y, hA[4].hi.y, hB[4].hi.y); halves_u(Z.hi.z, hA[4].hi.z, hB[4].hi.z); halves_u(Z.hi.w, hA[4].hi.w, hB[4].hi.w);
+            halves_u(Z.lo.x, hA[4].lo.x, hB[4].lo.x); halves_u(Z.lo.y, hA[4].lo.y, hB[4].lo.y); halves_u(Z.lo.z, hA[4].lo.z, hB[4].lo.z); halves_u(Z.lo.w, hA[4].lo.w, hB[4].lo.w);
+        }
+        float rmaxA = 0.0f, rmaxB = 0.0f;
+        if (RC) {                                      // the gather's maximum belongs to the lane's own entry
+            rmaxA = up ? 0.0f : rmax;
+            rmaxB = up ? rmax : 0.0f;
         }
 
         // ---------------------------------------------------------------- phase boundary + basis product ----
@@ -323,6 +320,7 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
             S16_SB;
             S16_STAMP(tg1);
             {                                          // take the SIMD's matrix token (bounded: a stuck token costs speed, never a hang or a pixel)
+#if S16_MTOKEN
                 int got, n = 0;
                 do {
                     int r = 1;
@@ -331,6 +329,7 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
                     if (got) __builtin_amdgcn_s_sleep(S16_MSLEEP);
                 } while (got && ++n < S16_TOKEN_SPINS);
                 have_tok = !got;
+#endif
                 __builtin_amdgcn_s_setprio(S16_PRIO_M);
             }
             S16_STAMP(tgW);
@@ -339,9 +338,7 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
             for (int q = 0; q < 10; ++q) {
                 const int s = q >> 1, rb = q & 1;
                 if (q + 2 < 10) bld(q + 2);
-                if (s < 3) mfma6(br[q & 3], hf[2 * s], hf[2 * s + 1], aF[rb][0], aF[rb][1]);
-                else if (s == 3) mfma6(br[q & 3], h3A, h3B, aF[rb][0], aF[rb][1]);
-                else mfma6(br[q & 3], h4A, h4B, aF[rb][0], aF[rb][1]);
+                mfma6(br[q & 3], hA[s], hB[s], aF[rb][0], aF[rb][1]);
 #if S16_SCHED
                 if (q + 2 < 10) { if (((q + 2) >> 1) == 3) S16_SG_DSR(1); else S16_SG_DSR(2); }
                 S16_SG_MFMA(6);
@@ -597,11 +594,12 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float *__restrict__ W
         ph = (unsigned short *)(img + TVR16_W2H + fr * TVR16_FRAG + lane * 16) + j;
         pl = (unsigned short *)(img + TVR16_W2L + fr * TVR16_FRAG + lane * 16) + j;
     } else {
-        // k slot (s, g, j) -> (plane, channel): k-steps 0..2 = channels 0..31 of plane s; k-step 3 = channels 32..47 of plane 0 (groups 0, 1) and of plane 1 (groups
-        // 2, 3); k-step 4 = channels 32..47 of plane 2 in groups 0, 1 (groups 2, 3: no such k — the kernel reads zeros there)
-        const int s = fr >> 1, rb = fr & 1, row = 16 * rb + ci;
-        const int pl_ = s < 3 ? s : (s == 3 ? (g >> 1) : 2), ch = s < 3 ? 8 * g + j : 32 + 8 * (g & 1) + j;
-        if ((s < 4 || g < 2) && row < TVR_APPDIM && ch < sh.app_n_comp[pl_]) w = W[(size_t)row * sh.k_app + sh.app_off[pl_] + ch];
+        // k slot (s, g, j) = 32 s + 8 g + j, the kernels' natural k = 48 * plane + channel (k-step 4: groups 0, 1 only — the kernel reads zeros in groups 2, 3)
+        const int s = fr >> 1, rb = fr & 1, row = 16 * rb + ci, k = 32 * s + 8 * g + j;
+        if (k < TVR_KAPP && row < TVR_APPDIM) {
+            const int pl_ = k / TVR_CA, ch = k - pl_ * TVR_CA;                  // basis_mat's column = its plane's offset + channel
+            if (ch < sh.app_n_comp[pl_]) w = W[(size_t)row * sh.k_app + sh.app_off[pl_] + ch];
+        }
         const bool in_img = (rb == 0 || ci < TVR16_BAS_ROWS1) && (s < 4 || g < 2);
         const int off = (s < 4 ? s * TVR16_BAS_STEP : TVR16_BAS_S4) + (rb == 0 ? (g * 16 + ci) * 16 : (s < 4 ? TVR16_BAS_RB1 : TVR16_BAS_S4_RB1) + (g * TVR16_BAS_ROWS1 + ci) * 16);
         if (in_img) {

@@ -8,5 +8,6 @@ for v in "$@"; do
   python3 $R/bench.py --steps 10 --warmup 3 --pmc off --no-cpu-baseline ${AB_ARGS} 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms']
-print('%-14s round $round  ms/step %.2f  march %.2f  shade %.2f  composite %.3f' % ('$v', d['ms_per_step'], k['march'], k['shade'], k['composite']))"
+ra=d.get('roofline_all',{}); cm=(ra.get('march') or {}).get('clock_GHz') or 0.0; cs=(d.get('roofline') or {}).get('clock_GHz') or 0.0
+print('%-14s round $round  ms/step %.2f  march %.2f  shade %.2f  composite %.3f   clock GHz march %.3f shade %.3f' % ('$v', d['ms_per_step'], k['march'], k['shade'], k['composite'], cm, cs))"
 done; done
