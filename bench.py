@@ -293,7 +293,7 @@ def other_configs(budget_s=240.0):
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=200, env=dict(os.environ))
             d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-            out[key] = {k: d[k] for k in ("value", "unit", "ms_per_step", "rays_per_sec", "steps", "kernel_ms") if k in d}
+            out[key] = {k: d[k] for k in ("value", "unit", "ms_per_step", "rays_per_sec", "steps", "kernel_ms", "roofline") if k in d}
             if not any(v for k, v in out[key].get("kernel_ms", {}).items() if k != "calls"):
                 out[key].pop("kernel_ms", None)                       # chunked calls are not timed per kernel
             out[key]["command"] = "python bench.py " + " ".join(cmd[2:])
@@ -315,6 +315,18 @@ def other_configs(budget_s=240.0):
             ms = float(mt.group(1))
             out[key] = {"ms_per_step": ms, "iterations_per_sec": 1e3 / ms, "rays_per_sec": 4096e3 / ms,
                         "command": " ".join(f"{k}={v}" for k, v in env.items()) + (" " if env else "") + "python scripts/" + script}
+        except Exception as e:
+            out[key] = f"failed: {type(e).__name__}"
+    # NerfPlusPlus inference: the background network's kernel (512 samples per ray: the bulk of a NerfPlusPlus frame) with its roofline (scripts/npp_roofline.py)
+    key = "NerfPlusPlus inference (configs/Scarf.txt): background network kernel, 65 536 rays x 512 samples per launch"
+    if time.time() - t0 > budget_s:
+        out[key] = "skipped: time budget"
+    else:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(root, "scripts", "npp_roofline.py")], capture_output=True, text=True, timeout=120, env=dict(os.environ))
+            d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            out[key] = {"ms_per_launch": d["ms_per_launch"], "G_samples_per_s": d["G_samples_per_s"], "ms_per_800x800_frame_of_this_kernel": d["ms_per_800x800_frame_of_this_kernel"],
+                        "roofline": d, "command": "python scripts/npp_roofline.py"}
         except Exception as e:
             out[key] = f"failed: {type(e).__name__}"
     return out
@@ -353,7 +365,9 @@ def arith_modes(model, step_rays, S, eps_T, m_app, steps=8):
             o = {"ms_per_frame": dt * 1e3, "kernel_ms": {"march": ms[0] / n, "shade": ms[1] / n, "composite": ms[2] / n},
                  "ray_samples_per_sec": step_rays[0].shape[0] * S / dt,
                  # the same algorithmic 80 kFLOP per appearance sample against the same dense-f16 peak as roofline.shade
-                 "shade_frac_of_dense_f16_peak": (8.0e4 * m_app / (ms[1] / n * 1e-3) / 1e12 / 2500.0) if ms[1] > 0 and m_app > 0 else None}
+                 "shade_frac_of_dense_f16_peak": (8.0e4 * m_app / (ms[1] / n * 1e-3) / 1e12 / 2500.0) if ms[1] > 0 and m_app > 0 else None,
+                 # the gate (tvr_scene_validate_arith): the mode the kernels really ran in, and what the gate measured on its probe rays before letting it run
+                 "in_effect": model.arith_in_effect, "gate_max_diff_on_probe_rays": (model.arith_max_diff if mode != "f32" else None), "gate_tolerance": model.mlp_arith_tol}
             if ref is None:
                 ref = pics
             else:
@@ -366,7 +380,8 @@ def arith_modes(model, step_rays, S, eps_T, m_app, steps=8):
     finally:
         model.mlp_arith = "f32"
     out["note"] = ("products per k-step of basis / layer 1 / layer 2: f32 = Wlo*xhi + Whi*xlo + Whi*xhi (default, the headline); f16act = Wlo*xhi + Whi*xhi (activations rounded to "
-                   "fp16, nearest even); f16 = Whi*xhi.  north_star's parity bar: RGB L-inf 1e-3")
+                   "fp16, nearest even); f16 = Whi*xhi.  north_star's parity bar: RGB L-inf 1e-3.  A reduced mode runs only after the library has measured it on this scene's own "
+                   "rays against the default mode (`in_effect`; refused beyond `gate_tolerance`)")
     return out
 
 

@@ -145,10 +145,27 @@ int tvr_scene_set_range_check(tvr_scene *scene, int32_t on);
  * and against the oracle on the fixtures, see DESIGN.md 4.7 and tests/test_gpu_arith.py for the numbers and the bars the tests hold.  Layer 3, encoding, interpolation,
  * density, compositing: fp32 in every mode.  (NerfPlusPlus's background network has the same switch in its descriptor: tvr_mlpnet_desc.arith.)  Every other entry point (tvr_app_feature(_ref), the training forwards, scenes with more than two encoding
  * frequencies) computes with three products whatever the mode says.  Range: as for the default (|x| < 65 504); a rounded activation beyond it becomes inf, and
- * the range check marks its sample NaN as in the default mode. */
+ * the range check marks its sample NaN as in the default mode.
+ * GATE (round 5): a reduced mode never runs on parameters it has not been MEASURED on.  fp16 rounding is relative, so no bound from the parameters alone is useful
+ * (interval bounds on |W| |x| overestimate the error a thousandfold and would refuse every scene); instead tvr_scene_validate_arith renders a caller-chosen probe batch
+ * of rays in TVR_ARITH_F32 and in the requested mode and compares the pictures:
+ *   tvr_scene_set_arith(scene, mode)   records the REQUEST; the kernels keep computing in TVR_ARITH_F32 (tvr_last_error() says so, the call returns TVR_OK) unless
+ *                                      the mode is already validated for the parameters as packed;
+ *   tvr_scene_validate_arith(...)      max |rgb_mode - rgb_f32| over the probe rays <= tol: the mode is IN EFFECT from here on; otherwise the scene stays in
+ *                                      TVR_ARITH_F32 and tvr_last_error() carries the measured difference (TVR_OK either way: *max_diff_out and tvr_scene_get_arith tell).
+ *                                      One host synchronisation.  work: (8 n_rays) floats + 256 B of device memory, 16-byte aligned.  The Python host calls it with up to 8192 rays of the
+ *                                      first inference batch after every parameter change and a tolerance of 2.5e-4 (a quarter of the parity bar);
+ *   tvr_scene_update / tvr_scene_touch void the validation (new parameters): TVR_ARITH_F32 until validated again;
+ *   tvr_scene_get_arith                the mode IN EFFECT (what the next render computes in); tvr_scene_get_arith_requested the request.
+ * So tvr_render(_z) / tvr_mlp_render(_ref) cannot leave the parity bar silently through a reduced mode: either the mode was measured on this scene's own rays, or it does not run.
+ * (tvr_mlpnet_desc.arith, NerfPlusPlus's background network, is a field of a stateless descriptor: the library cannot gate it — the Python host measures it the same way,
+ *  variants.py::NerfPlusPlus._settle_bg_arith, and a C host must do likewise.) */
 enum { TVR_ARITH_F32 = 0, TVR_ARITH_F16ACT = 1, TVR_ARITH_F16 = 2 };
 int tvr_scene_set_arith(tvr_scene *scene, int32_t mode);
 int tvr_scene_get_arith(const tvr_scene *scene);
+int tvr_scene_get_arith_requested(const tvr_scene *scene);
+int tvr_scene_validate_arith(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, int32_t white_bg, float eps_T, float tol,
+                             void *scratch, size_t scratch_bytes, float *work, size_t work_bytes, float *max_diff_out, void *stream);
 int tvr_scene_destroy(tvr_scene *scene);
 
 /* TensorBase.execute over a ray batch (tensorBase.py:476-536, ndc_ray=False; variant 1: REFTensoRF.execute,

@@ -92,6 +92,9 @@ SYMBOLS = {
     "tvr_scene_set_arith": (C.c_int, [C.c_void_p, C.c_int32]),
     "tvr_scene_touch": (C.c_int, [C.c_void_p]),
     "tvr_scene_get_arith": (C.c_int, [C.c_void_p]),
+    "tvr_scene_get_arith_requested": (C.c_int, [C.c_void_p]),
+    "tvr_scene_validate_arith": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                           C.POINTER(C.c_float), C.c_void_p]),
     "tvr_scene_destroy": (C.c_int, [C.c_void_p]),
     "tvr_render_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "tvr_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float,

@@ -90,6 +90,8 @@ struct tvr_scene {
     SceneDev dev;
     bool params_set;
     bool h16_stale;            // the fp16 copies of the appearance factors are older than the fp32 images
+    int arith_req;             // what tvr_scene_set_arith asked for; dev.arith is what the kernels RUN: arith_req once tvr_scene_validate_arith has measured it inside
+    int arith_valid;           // its tolerance for the parameters as packed (0 = nothing validated), TVR_ARITH_F32 until then
 };
 
 struct tvr_profile {
@@ -163,6 +165,8 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
     s->packed = (char *)packed_dev;
     s->params_set = false;
     s->h16_stale = true;
+    s->arith_req = TVR_ARITH_F32;
+    s->arith_valid = 0;
     SceneDev &v = s->dev;
     memset(&v, 0, sizeof(v));
     for (int k = 0; k < 3; ++k) {
@@ -245,8 +249,9 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
         HIP_TRY(launch_pack_ref(p->ref_W, p->ref_b, img + TVR_IMG_REFW, (float *)(img + TVR_IMG_REFB), stream));
     }
     s->params_set = true;
-    s->h16_stale = true;
-    if (s->dev.arith == TVR_ARITH_F16) return refresh_h16(s, (hipStream_t)stream);      // (otherwise the first render in that mode converts)
+    s->h16_stale = true;                  // (the first render in TVR_ARITH_F16 converts the fp16 copies: nothing is converted for steps that never read them)
+    s->arith_valid = 0;                   // new parameters: a reduced arithmetic has to be measured again before it runs (tvr_scene_validate_arith)
+    s->dev.arith = TVR_ARITH_F32;
     return TVR_OK;
 }
 
@@ -290,6 +295,8 @@ int tvr_scene_touch(tvr_scene *s)
 {
     if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_touch: scene is NULL");
     s->h16_stale = true;         // the next TVR_ARITH_F16 render converts the fp32 images first
+    s->arith_valid = 0;          // and a reduced arithmetic has to be validated again
+    s->dev.arith = TVR_ARITH_F32;
     return TVR_OK;
 }
 
@@ -297,7 +304,11 @@ int tvr_scene_set_arith(tvr_scene *s, int32_t mode)
 {
     if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_set_arith: scene is NULL");
     if (mode != TVR_ARITH_F32 && mode != TVR_ARITH_F16ACT && mode != TVR_ARITH_F16) return fail(TVR_ERR_INVALID, "tvr_scene_set_arith: mode %d is none of TVR_ARITH_*", (int)mode);
-    s->dev.arith = mode;
+    s->arith_req = mode;
+    s->dev.arith = (mode == TVR_ARITH_F32 || s->arith_valid == mode) ? mode : TVR_ARITH_F32;
+    if (s->dev.arith != mode)
+        tvr_set_error(TVR_OK, "tvr_scene_set_arith: mode %d is requested but NOT in effect — the kernels compute in TVR_ARITH_F32 until tvr_scene_validate_arith has measured "
+                              "the mode inside its tolerance for the current parameters", (int)mode);
     return TVR_OK;
 }
 
@@ -305,6 +316,12 @@ int tvr_scene_get_arith(const tvr_scene *s)
 {
     if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_get_arith: scene is NULL");
     return s->dev.arith;
+}
+
+int tvr_scene_get_arith_requested(const tvr_scene *s)
+{
+    if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_get_arith_requested: scene is NULL");
+    return s->arith_req;
 }
 
 int tvr_scene_destroy(tvr_scene *s)
@@ -487,6 +504,64 @@ static int march_forward_impl(tvr_scene *s, const float *rays, int64_t n_rays, i
 }
 
 extern "C" {
+
+// max |a - b| over n floats -> out[0] (as the bits of a non-negative float: integer max); a NaN on either side counts as +inf
+__global__ __launch_bounds__(256) void maxdiff_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n, unsigned *__restrict__ out)
+{
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = fabsf(a[i] - b[i]);
+        m = (d == d) ? fmaxf(m, d) : INFINITY;
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+int tvr_scene_validate_arith(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, float eps_T, float tol, void *scratch, size_t scratch_bytes,
+                             float *work, size_t work_bytes, float *max_diff_out, void *stream_)
+{
+    if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "tvr_scene_validate_arith: scene is NULL or tvr_scene_update has not run");
+    if (!max_diff_out) return fail(TVR_ERR_INVALID, "tvr_scene_validate_arith: max_diff_out is NULL");
+    *max_diff_out = 0.0f;
+    if (s->arith_req == TVR_ARITH_F32) return TVR_OK;                                    // nothing to validate
+    if (s->dev.gen) {                                   // more than two encoding frequencies: the lockstep kernels compute with three products whatever the mode says
+        tvr_set_error(TVR_OK, "tvr_scene_validate_arith: scenes with more than two encoding frequencies compute in TVR_ARITH_F32 whatever the mode says");
+        return TVR_OK;
+    }
+    if (n_rays <= 0 || !rays || !work) return fail(TVR_ERR_INVALID, "tvr_scene_validate_arith: rays / work NULL or n_rays <= 0");
+    if ((uintptr_t)work % 16) return fail(TVR_ERR_SCRATCH, "tvr_scene_validate_arith: work must be 16-byte aligned");
+    if (!(tol > 0.0f)) return fail(TVR_ERR_INVALID, "tvr_scene_validate_arith: tol must be positive");
+    if (work_bytes < (size_t)n_rays * 8 * sizeof(float) + 256) return fail(TVR_ERR_SCRATCH, "tvr_scene_validate_arith: work %zu B < required %zu B", work_bytes, (size_t)n_rays * 32 + 256);
+    hipStream_t stream = (hipStream_t)stream_;
+    float *rgb0 = work, *dep0 = work + 3 * n_rays, *rgb1 = work + 4 * n_rays, *dep1 = work + 7 * n_rays;
+    unsigned *mx = (unsigned *)(work + 8 * n_rays);
+    const MarchSampling sm = {nullptr, nullptr};
+    s->dev.arith = TVR_ARITH_F32;
+    int rc = render_impl(s, rays, n_rays, S, white_bg, sm, eps_T, rgb0, dep0, nullptr, scratch, scratch_bytes, nullptr, nullptr, nullptr, stream_);
+    if (rc != TVR_OK) return rc;
+    s->dev.arith = s->arith_req;
+    rc = render_impl(s, rays, n_rays, S, white_bg, sm, eps_T, rgb1, dep1, nullptr, scratch, scratch_bytes, nullptr, nullptr, nullptr, stream_);
+    s->dev.arith = TVR_ARITH_F32;
+    if (rc != TVR_OK) return rc;
+    HIP_TRY(launch_zero_f32((float *)mx, 4, stream));                                   // (float4 granules: the 256 B behind the eight arrays are for this)
+    hipLaunchKernelGGL(maxdiff_kernel, dim3(256), dim3(256), 0, stream, rgb0, rgb1, (long long)n_rays * 3, mx);
+    HIP_TRY(hipGetLastError());
+    unsigned bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, mx, sizeof(bits), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float d;
+    memcpy(&d, &bits, sizeof(d));
+    *max_diff_out = d;
+    if (d <= tol) {
+        s->arith_valid = s->arith_req;
+        s->dev.arith = s->arith_req;
+        return TVR_OK;
+    }
+    s->arith_valid = 0;
+    tvr_set_error(TVR_OK, "tvr_scene_validate_arith: mode %d REFUSED for these parameters — its picture differs from TVR_ARITH_F32's by %.3g on the %lld probe rays, the tolerance is %.3g; "
+                          "the scene computes in TVR_ARITH_F32", s->arith_req, (double)d, (long long)n_rays, (double)tol);
+    return TVR_OK;
+}
 
 int tvr_march_forward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, const float *jitter, float eps_T, float *depth_out,
                       void *scratch, size_t scratch_bytes, void *stream)

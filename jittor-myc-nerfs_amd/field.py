@@ -280,6 +280,11 @@ class TensorBase(torch.nn.Module):
                              "There is no CPU fallback.")
         ps = self._param_list()
         sig = tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in ps)
+        if getattr(self, "_captured_update", False) and not torch.cuda.is_current_stream_capturing():
+            # a hipGraph replay of a captured training step packs the parameters at the START of the step and updates them at its end, bumping no version counter
+            # and running no host code: the packed images are one optimizer step behind whatever the host sees.  Every host-driven call of such a model re-packs
+            # (0.1 ms for 70 MB), which also voids the library's derived state — fp16 copies, the validated arithmetic (tvr_scene_update)
+            force = True
         if self._scene is None:
             d = L.SceneDesc()
             d.aabb[:] = [float(x) for x in self.aabb.reshape(-1)]
@@ -342,9 +347,52 @@ class TensorBase(torch.nn.Module):
         if getattr(self, "_arith_set", None) != self.mlp_arith:
             if self.mlp_arith not in self._ARITH:
                 raise ValueError(f"mlp_arith must be one of {sorted(self._ARITH)}, got {self.mlp_arith!r}")
-            L.check(lib.tvr_scene_set_arith(self._scene, self._ARITH[self.mlp_arith]), "tvr_scene_set_arith")
+            L.check(lib.tvr_scene_set_arith(self._scene, self._ARITH[self.mlp_arith]), "tvr_scene_set_arith")      # a REQUEST: see _settle_arith
             self._arith_set = self.mlp_arith
         return self._scene
+
+    # ---- the gate of the reduced arithmetics (include/tvr.h, tvr_scene_validate_arith) -----------------------------------------------------
+    # `mlp_arith` is a request.  The library runs a reduced mode only on parameters it has been MEASURED on: the first inference call after every parameter change
+    # hands up to `arith_probe_rays` of its own rays (an even stride over the batch) to tvr_scene_validate_arith, which renders them in "f32" and in the mode and
+    # compares.  max |difference| <= `mlp_arith_tol` (default 2.5e-4: a quarter of north_star's 1e-3 bar): the mode is in effect; otherwise the scene keeps computing
+    # in "f32", a RuntimeWarning says so once per parameter state, and `arith_in_effect` / `arith_max_diff` tell.  No interval bound from the parameters can do this
+    # job: |W| |x| bounds overestimate the error a thousandfold (scripts: DESIGN.md 4.7), a measurement on the scene's own rays does not.
+    mlp_arith_tol = 2.5e-4
+    arith_probe_rays = 8192
+    arith_in_effect = "f32"
+    arith_max_diff = None
+
+    def _settle_arith(self, rays, S, white_bg, eps_T):
+        """Called by the inference entry points behind _ensure_scene(): bring the requested arithmetic into effect (or not) for the current parameters."""
+        if self.mlp_arith == "f32" or self.view_pe > 2 or self.fea_pe > 2:        # (more than two encoding frequencies: three products whatever the mode says, tvr.h)
+            self.arith_in_effect = "f32"
+            return
+        lib = L.lib()
+        names = {v: k for k, v in self._ARITH.items()}
+        if getattr(self, "_captured_update", False):
+            L.check(lib.tvr_scene_touch(self._scene), "tvr_scene_touch")            # replays moved the parameters: whatever was validated is void
+        if lib.tvr_scene_get_arith(self._scene) == self._ARITH[self.mlp_arith]:
+            self.arith_in_effect = self.mlp_arith
+            return
+        if getattr(self, "_arith_refused_sig", None) == (self._sig, self.mlp_arith, float(self.mlp_arith_tol)) and not getattr(self, "_captured_update", False):
+            return                                                                  # measured and refused for exactly these parameters: "f32" stays
+        n = rays.shape[0]
+        if n == 0:
+            return
+        k = min(int(self.arith_probe_rays), n)
+        probe = rays if k == n else rays[torch.linspace(0, n - 1, k, device=rays.device).long()].contiguous()
+        scratch = self._get_scratch(lib.tvr_render_scratch_bytes(self._scene, k, S))
+        work = torch.empty(8 * k + 64, dtype=torch.float32, device=self.device)
+        md = C.c_float(0.0)
+        L.check(lib.tvr_scene_validate_arith(self._scene, probe.data_ptr(), k, S, int(bool(white_bg)), float(eps_T), float(self.mlp_arith_tol), scratch.data_ptr(),
+                                             scratch.numel(), work.data_ptr(), work.numel() * 4, C.byref(md), _stream_ptr(self.device)), "tvr_scene_validate_arith")
+        self.arith_max_diff = float(md.value)
+        self.arith_in_effect = names[lib.tvr_scene_get_arith(self._scene)]
+        if self.arith_in_effect != self.mlp_arith:
+            self._arith_refused_sig = (self._sig, self.mlp_arith, float(self.mlp_arith_tol))
+            import warnings
+            warnings.warn(f"mlp_arith={self.mlp_arith!r} REFUSED for the current parameters: on {k} probe rays its picture differs from the fp32-class arithmetic's by "
+                          f"{self.arith_max_diff:.3g} (tolerance mlp_arith_tol={self.mlp_arith_tol:g}); rendering in 'f32'", RuntimeWarning, stacklevel=3)
 
     # ---- arithmetic of the appearance network's matrix products at inference (include/tvr.h, tvr_scene_set_arith) ------------------------
     # "f32" (default): three fp16 products per fp32 product, fp32-class — what every parity number in DESIGN.md is quoted on.  "f16act": activations rounded to
@@ -733,6 +781,7 @@ class TensorBase(torch.nn.Module):
             return (rgb, depth, {}) if dense else (rgb, depth)
         if eps_T is None:
             eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
+        self._settle_arith(rays, S, white_bg, eps_T)
         nbytes = lib.tvr_render_scratch_bytes(sc, n, S)
         scratch = self._get_scratch(nbytes)
         jit = None if jitter is None else _f32c(jitter, self.device).view(-1)

@@ -309,6 +309,7 @@ class NerfPlusPlus(TensorVMSplit):
     def _render_z(self, rays, z_vals, S, eps_T):
         sc, lib = self._ensure_scene(), L.lib()
         self._settle_range_check()
+        self._settle_arith(rays, S, False, eps_T)         # the foreground's reduced arithmetic, measured on these rays (uniform sampling: the network's arithmetic is what is probed)
         n = rays.shape[0]
         rgb = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         depth = torch.empty((n,), dtype=torch.float32, device=self.device)
@@ -332,8 +333,55 @@ class NerfPlusPlus(TensorVMSplit):
               and net.base_layers[0][0].out_features == 128 and self.bg_view_freq == 2 and 1 <= self.bg_freq <= 4)
         if not ok:
             return None
-        # (arith: the inference call follows the model's `mlp_arith`, field.py; the training forward computes fp32-class whatever it says)
-        return L.MlpnetDesc(len(net.base_layers), 128, int(net.skips[0]), int(self.bg_freq), int(self.bg_view_freq), self.BG_SAMPLES, self._ARITH[self.mlp_arith])
+        # (arith: the inference call follows the model's `mlp_arith` once _settle_bg_arith has measured it on this network — until then, and if refused, fp32-class;
+        #  the training forward computes fp32-class whatever it says)
+        return L.MlpnetDesc(len(net.base_layers), 128, int(net.skips[0]), int(self.bg_freq), int(self.bg_view_freq), self.BG_SAMPLES, self._ARITH[getattr(self, "bg_arith_in_effect", "f32")])
+
+    bg_arith_in_effect = "f32"
+    bg_arith_max_diff = None
+
+    def _settle_bg_arith(self, pts, vd, n_pts, z=None):
+        """The gate of field.py::_settle_arith for the background network (tvr_mlpnet_desc.arith is a field of a stateless descriptor: the library cannot hold a
+        validation state for it).  Once per parameter state: up to 128 of this call's own rays (65 536 samples) through the kernel in "f32" and in the requested
+        mode.  With the samples' depths at hand (the inference path, _background_fused) what is compared is what the picture gets — the COMPOSITED background colour
+        per ray; a bare _mlpnet call compares the raw outputs (rgb absolutely, sigma relative to max(|sigma|, 1)), which is stricter.  <= `mlp_arith_tol`: the mode
+        is in effect; otherwise the kernel computes in "f32" and a RuntimeWarning says so."""
+        if self.mlp_arith == "f32":
+            self.bg_arith_in_effect = "f32"
+            return
+        sig = (tuple((p.data_ptr(), p._version) for p in self.bg_net.parameters()), self.mlp_arith, float(self.mlp_arith_tol))
+        if getattr(self, "_bg_arith_sig", None) == sig:
+            return
+        N = self.BG_SAMPLES
+        k = max(min(int(n_pts), 65536) // N, 1) * N                # whole rays: the kernel takes the view direction of sample i from ray i // N
+        out = {}
+        for mode in ("f32", self.mlp_arith):
+            self.bg_arith_in_effect = mode
+            desc = self._bg_kernel_desc()
+            img = self._bg_packed(desc)
+            rgb = torch.empty(k, 3, device=self.device)
+            sigma = torch.empty(k, device=self.device)
+            L.check(L.lib().tvr_mlpnet_forward(C.byref(desc), img.data_ptr(), pts.data_ptr(), vd.data_ptr(), k, rgb.data_ptr(), sigma.data_ptr(),
+                                               _stream_ptr(self.device)), "tvr_mlpnet_forward")
+            if z is not None:
+                col = torch.empty(k // N, 3, device=self.device)
+                L.check(L.lib().tvr_npp_bg_composite(rgb.data_ptr(), sigma.data_ptr(), z.data_ptr(), k // N, N, col.data_ptr(), _stream_ptr(self.device)), "tvr_npp_bg_composite")
+                out[mode] = (col,)
+            else:
+                out[mode] = (rgb, sigma)
+        if z is not None:
+            d = float((out[self.mlp_arith][0] - out["f32"][0]).abs().max())
+        else:
+            (r0, s0), (r1, s1) = out["f32"], out[self.mlp_arith]
+            d = max(float((r1 - r0).abs().max()), float(((s1 - s0).abs() / s0.abs().clamp_min(1.0)).max()))
+        self.bg_arith_max_diff = d
+        ok = d <= float(self.mlp_arith_tol)                      # (a NaN compares false)
+        self.bg_arith_in_effect = self.mlp_arith if ok else "f32"
+        self._bg_arith_sig = sig
+        if not ok:
+            import warnings
+            warnings.warn(f"mlp_arith={self.mlp_arith!r} REFUSED for the background network: {d:.3g} off the fp32-class arithmetic on {k} probe samples "
+                          f"(tolerance {self.mlp_arith_tol:g}); its kernel computes in 'f32'", RuntimeWarning, stacklevel=3)
 
     def _bg_packed(self, desc):
         """Fragment image of the background network.  `base_remap_layers` (Linear 128->256, no activation) is folded into the first rgb
@@ -431,9 +479,11 @@ class NerfPlusPlus(TensorVMSplit):
         if desc is None or N != self.BG_SAMPLES:
             inp = torch.cat((self.bg_embedder_position(bg_pts), self.bg_embedder_viewdir(viewdirs.unsqueeze(-2).expand(n, N, 3))), dim=-1)
             return self.bg_net(inp)
-        img = self._bg_packed(desc)
         pts = bg_pts.detach().to(torch.float32).contiguous()
         vd = viewdirs.detach().to(torch.float32).contiguous()
+        self._settle_bg_arith(pts, vd, n * N)
+        desc = self._bg_kernel_desc()
+        img = self._bg_packed(desc)
         rgb = torch.empty(n, N, 3, device=self.device)
         sigma = torch.empty(n, N, device=self.device)
         L.check(L.lib().tvr_mlpnet_forward(C.byref(desc), img.data_ptr(), pts.data_ptr(), vd.data_ptr(), n * N, rgb.data_ptr(), sigma.data_ptr(),
@@ -451,7 +501,10 @@ class NerfPlusPlus(TensorVMSplit):
         st = _stream_ptr(self.device)
         L.check(lib.tvr_npp_bg_points(o.data_ptr(), d.data_ptr(), n, z_lin.data_ptr(), N, t_rand.data_ptr(), float(self.radii), pts.data_ptr(), z.data_ptr(), st),
                 "tvr_npp_bg_points")
-        raw = self._mlpnet(pts, d / torch.norm(d, dim=-1, keepdim=True))
+        vdn = (d / torch.norm(d, dim=-1, keepdim=True)).contiguous()
+        if desc is not None and self.mlp_arith != "f32":
+            self._settle_bg_arith(pts, vdn, n * N, z=z)           # the gate, on what the picture gets: the composited background colour of this call's first rays
+        raw = self._mlpnet(pts, vdn)
         out = torch.empty(n, 3, device=self.device)
         L.check(lib.tvr_npp_bg_composite(raw['rgb'].data_ptr(), raw['sigma'].data_ptr(), z.data_ptr(), n, N, out.data_ptr(), st), "tvr_npp_bg_composite")
         return out

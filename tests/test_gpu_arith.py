@@ -102,6 +102,8 @@ def test_mlp_render_in_every_mode_and_what_the_modes_leave_alone(tiny_dump, tiny
     errs = {}
     for mode, bar in (("f32", 1e-5), ("f16act", 3e-4), ("f16", 6e-4)):
         m.mlp_arith = mode
+        m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])           # the gate: a reduced mode runs only once a render has measured it on this scene's rays
+        assert m.arith_in_effect == mode
         with torch.no_grad():
             rgb = m.renderModule(xyz, dirs, feat)
         e = np.abs(_np(rgb) - tiny_dump["app_rgb"]).max()
@@ -148,9 +150,10 @@ def test_mode_is_validated_and_survives_a_repack(tiny_arrays, hyper_tiny, tiny_d
 @pytest.mark.parametrize("scale", [20.0, 200.0])
 def test_feature_magnitude_is_where_the_modes_differ(tiny_dump, tiny_arrays, hyper_tiny, scale):
     """fp16 rounding is RELATIVE: a scene whose features and activations are 20x / 200x larger than the synthetic scene's (|F| up to ~220, hidden activations ~50)
-    carries absolute errors that much larger into the sigmoid.  "f16act" keeps the basis product at three products (F feeds sin(2^f F), where an error is amplified
-    once more) and its PICTURE stays inside the 1e-3 bar at both scales, with little margin at 200x; "f16" rounds the basis product's operands too and is only
-    REPORTED here.  include/tvr.h says so: a caller with unusually large features keeps "f32"."""
+    carries absolute errors that much larger into the sigmoid: at 200x "f16" leaves north_star's 1e-3 bar (1.45e-3) and "f16act" has a sample 1.8e-3 off.  Round 5:
+    neither can happen SILENTLY — the gate (tvr_scene_validate_arith; field.py::_settle_arith) measures a requested mode on the call's own rays against the fp32-class
+    arithmetic and REFUSES it beyond mlp_arith_tol = 2.5e-4: at 200x both reduced modes are refused (the picture is the "f32" one, a RuntimeWarning says so), at 20x
+    "f16act" runs and "f16" is refused.  With the gate forced open (mlp_arith_tol = 1) the raw errors are still what round 4 measured."""
     from oracle import tensorf_oracle as TO
     arrs = dict(tiny_arrays)
     arrs["basis_mat"] = tiny_arrays["basis_mat"] * np.float32(scale)
@@ -159,15 +162,38 @@ def test_feature_magnitude_is_where_the_modes_differ(tiny_dump, tiny_arrays, hyp
     fmax = float(TO.compute_appfeature(sc, d["xyz_norm"][d["app_mask"]]).abs().max())
     m = make_model(arrs, hyper_tiny)
     rays = torch.tensor(tiny_dump["rays"], device="cuda")
+    # (1) the gate as shipped: what runs, and what the caller is told
+    import warnings
+    f32_pic, _ = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"], eps_T=0.0)
+    f32_pic = f32_pic.clone()
+    expect = {20.0: {"f16act": "f16act", "f16": "f32"}, 200.0: {"f16act": "f32", "f16": "f32"}}[scale]
+    for mode in ("f16act", "f16"):
+        m.mlp_arith = mode
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            rgb, _ = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"], eps_T=0.0)
+        refused = expect[mode] == "f32"
+        assert m.arith_in_effect == expect[mode], (mode, m.arith_in_effect, m.arith_max_diff)
+        assert L_get(m) == {"f32": 0, "f16act": 1, "f16": 2}[expect[mode]]
+        assert any("REFUSED" in str(w.message) for w in wlist) == refused
+        assert (m.arith_max_diff > m.mlp_arith_tol) == refused
+        if refused:
+            assert torch.equal(rgb, f32_pic)                                    # the picture the caller gets is the fp32-class one
+        else:
+            assert float((rgb - f32_pic).abs().max()) <= m.mlp_arith_tol
+        assert np.abs(_np(rgb) - d["rgb_map"].numpy()).max() < 4e-4 < RGB_TOL   # whatever ran, the picture is well inside the bar
+    # (2) the gate forced open: the modes' raw errors on this scene
+    m.mlp_arith_tol = 1.0
     err = {}
     for mode in MODES:
         m.mlp_arith = mode
         rgb, _, dd = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"], eps_T=0.0, dense=True)
+        assert m.arith_in_effect == mode
         err[mode] = (np.abs(_np(dd["rgb"]) - d["rgb"].numpy()).max(), np.abs(_np(rgb) - d["rgb_map"].numpy()).max())
         assert bool(torch.isfinite(rgb).all())
     print(f"basis x{scale:g}: max |feature| {fmax:.0f}; per-sample rgb / rgb_map L-inf vs oracle: " + ", ".join(f"{k} {v[0]:.2e} / {v[1]:.2e}" for k, v in err.items()))
-    assert err["f32"][1] < RGB_TIGHT and err["f16act"][1] < RGB_TOL           # the picture (north_star's quantity) stays inside the bar in "f16act" ...
-    assert err["f16"][0] > err["f16act"][0] > err["f32"][0]                    # ... with less margin the larger the activations: every reduced mode's error is RELATIVE to them
+    assert err["f32"][1] < RGB_TIGHT
+    assert err["f16"][0] > err["f16act"][0] > err["f32"][0]                    # every reduced mode's error is RELATIVE to the activations
 
 
 def test_fp16_factor_copies_follow_the_parameters(tiny_arrays, hyper_tiny, tiny_dump):
@@ -178,7 +204,8 @@ def test_fp16_factor_copies_follow_the_parameters(tiny_arrays, hyper_tiny, tiny_
     m = make_model(tiny_arrays, hyper_tiny)
     f32_0, _ = m.render_rays(rays, white_bg=True, N_samples=S)          # packs the scene in the default mode: no fp16 copies yet
     m.mlp_arith = "f16"
-    a, _ = m.render_rays(rays, white_bg=True, N_samples=S)              # the mode was set after the update: this render converts
+    a, _ = m.render_rays(rays, white_bg=True, N_samples=S)              # the mode was set after the update: this render converts (behind the gate's measurement)
+    assert m.arith_in_effect == "f16"
     assert 0 < float((a - f32_0).abs().max()) < 5e-4
     with torch.no_grad():
         m.app_plane[1].mul_(1.5)

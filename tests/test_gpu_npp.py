@@ -183,7 +183,8 @@ def test_background_network_arithmetic_modes(tiny_npp_arrays, hyper_tiny, tiny_n
     shape: the per-sample outputs per mode, then the whole picture per mode against the default mode's (tiny_npp's rays and injected random draws)."""
     m = make_model(tiny_npp_arrays, hyper_tiny)
     m.set_nerfplusplus(bg_freq=2, bg_view_freq=2, bg_D=3, radii=6.0)
-    g = torch.Generator(device="cpu").manual_seed(23)
+    m.mlp_arith_tol = 1.0            # the gate forced open (variants.py::_settle_bg_arith, field.py::_settle_arith): this part MEASURES the modes' raw errors on a network
+    g = torch.Generator(device="cpu").manual_seed(23)                      # four times wider than the default initialisation; the gate itself is exercised below
     with torch.no_grad():
         for p in m.bg_net.parameters():
             p.copy_((torch.rand(p.shape, generator=g) - 0.5).to(p.device) * (4.0 / max(p.shape[-1], 8) ** 0.5))
@@ -217,6 +218,20 @@ def test_background_network_arithmetic_modes(tiny_npp_arrays, hyper_tiny, tiny_n
     e2, e1 = float((pics["f16act"] - pics["f32"]).abs().max()), float((pics["f16"] - pics["f32"]).abs().max())
     print(f"NerfPlusPlus picture: f32 vs oracle {e32:.2e}; f16act vs f32 {e2:.2e}; f16 vs f32 {e1:.2e}")
     assert e32 < 1e-4 and 0 < e2 < 3e-4 and 0 < e1 < 1e-3
+    assert m2.arith_in_effect == "f16" and m2.bg_arith_in_effect == "f16"          # the default tolerance let both networks' modes through on this scene (2.9e-5 / 8e-5)
+    # and the gate of the background network at its default tolerance on the WIDE network of the first part: "f16" (rgb 5e-4 off) is refused there, loudly
+    import warnings
+    m.mlp_arith_tol = 2.5e-4
+    m.mlp_arith = "f16"
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            got = m._mlpnet(pts, v)
+    if m.bg_arith_max_diff > m.mlp_arith_tol:
+        assert m.bg_arith_in_effect == "f32" and any("REFUSED" in str(w.message) for w in wl)
+        assert (got["rgb"] - want["rgb"]).abs().max().item() < 2e-5
+    else:
+        assert m.bg_arith_in_effect == "f16"
 
 
 @pytest.mark.parametrize("bg_freq,bg_D", [(4, 4), (2, 3), (1, 2)])

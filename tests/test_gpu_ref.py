@@ -202,6 +202,7 @@ def test_ref_arithmetic_modes(tiny_ref, tiny_ref_arrays, hyper_tiny):
     feeds the reflection direction and its encoding, keep three products); "f16" takes one product everywhere.  Against the golden picture and per-sample colours;
     what the march decides is bit-identical; at full size each mode against the default mode's frame."""
     m = make_model(tiny_ref_arrays, hyper_tiny)
+    m.mlp_arith_tol = 1.0            # the gate (field.py::_settle_arith) forced open: this test MEASURES the modes' raw errors; the gate itself: tests/test_gpu_arith.py
     rays = torch.tensor(tiny_ref["rays"], device="cuda")
     base, errs = None, {}
     for mode in ("f32", "f16act", "f16"):
@@ -220,11 +221,13 @@ def test_ref_arithmetic_modes(tiny_ref, tiny_ref_arrays, hyper_tiny):
     A = synthetic.SCENE_A
     arrs = synthetic.make_scene_arrays(A["gridSize"], A["aabb"], ref=True)
     big = make_model(arrs, dict(synthetic.HYPER, near_far=A["near_far"], step_ratio=A["step_ratio"]))
+    big.mlp_arith_tol = 1.0
     fr = R.frame_rays(R.sphere_poses(8, A["cam_radius"])[0], 800, 800, A["camera_angle_x"]).cuda()
     pics = {}
     for mode in ("f32", "f16act", "f16"):
         big.mlp_arith = mode
         pics[mode] = big.render_rays(fr, white_bg=True, N_samples=A["N_samples"])
+        assert big.arith_in_effect == mode
     e2, e1 = float((pics["f16act"][0] - pics["f32"][0]).abs().max()), float((pics["f16"][0] - pics["f32"][0]).abs().max())
     print(f"REF full size vs the default mode (640 000 rays): f16act {e2:.2e}, f16 {e1:.2e}")
     assert 0 < e2 < 3e-4 and 0 < e1 < 1e-3 and torch.equal(pics["f16"][1], pics["f32"][1])

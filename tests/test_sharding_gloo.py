@@ -55,6 +55,58 @@ def test_render_sharded_world2_equals_single(tiny_arrays, hyper_tiny, tiny_edge)
         assert np.array_equal(depth, single["depth_map"])
 
 
+def _worker_cases(rank, world, port, arrs, hyper, rays_np, cases, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jittor_myc_nerfs_amd import render_sharded
+    from oracle import c_oracle as CO, tensorf_oracle as TO
+    sc = TO.scene_from_arrays(arrs, **hyper)
+    co = CO.COracle(arrs, step=float(sc.stepSize), **hyper)
+
+    def render_fn(r):
+        if r.shape[0] == 0:                                          # a rank that owns no tile of this frame
+            return torch.zeros((0, 3)), torch.zeros((0,))
+        o = co.render(r.numpy(), TINY["N_samples"])
+        return torch.from_numpy(o["rgb_map"]), torch.from_numpy(o["depth_map"])
+
+    out = {}
+    for n, tile in cases:
+        rgb, depth = render_sharded(torch.from_numpy(rays_np[:n]), render_fn, rank, world, tile=tile)
+        out[(n, tile)] = (rgb.numpy(), depth.numpy())
+    out_q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_render_sharded_world8_ragged_tiles_equal_single(tiny_arrays, hyper_tiny, tiny_edge, tiny_dump):
+    """EIGHT ranks as eight processes over gloo (the driver's N = 8 layout), host logic only — the per-rank renderer is the C oracle:
+    ragged frames whose tiles do not divide among the ranks (20 tiles of 4 over 8 ranks with a short last tile; 9 tiles of 16: one rank renders two, the rest
+    one; 2 tiles for 8 ranks: six ranks render nothing and still take part in the ONE all_gather) all come back as the single-process image, on every rank."""
+    from oracle import c_oracle as CO, tensorf_oracle as TO
+    rays = np.concatenate([tiny_edge["rays"], tiny_dump["rays"]] * 3)[:130]
+    cases = [(77, 4), (130, 16), (5, 4), (64, 8)]
+    sc = TO.scene_from_arrays(tiny_arrays, **hyper_tiny)
+    single = CO.COracle(tiny_arrays, step=float(sc.stepSize), **hyper_tiny).render(rays, TINY["N_samples"])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_cases, args=(r, 8, port, tiny_arrays, hyper_tiny, rays, cases, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == list(range(8))
+    for rank, out in res:
+        for (n, tile), (rgb, depth) in out.items():
+            assert rgb.shape == (n, 3) and depth.shape == (n,)
+            assert np.array_equal(rgb, single["rgb_map"][:n]), f"rank {rank}, {n} rays in tiles of {tile}: gathered image != single-process image"
+            assert np.array_equal(depth, single["depth_map"][:n])
+
+
 # ---- the HIP renderer behind render_sharded (BASELINE configs[2]; SURVEY 8e) ------------------------------------------------------------
 def _hip_worker(rank, world, port, arrs, hyper, rays_np, tiles, q):
     sys.path.insert(0, ROOT)
