@@ -648,7 +648,9 @@ def main():
     if args.model == "REFTensoRF":                                         # + four 144 -> {3,3,1,1} heads, 151-input layer 1
         FLOP_APP += 2 * 8 * 144 + 2 * 128
         FLOP_APP_EXEC += 3 * 2 * 32 * 144
-    pm, ps = _pmc_kernel(pmc, "march_kernel<false"), _pmc_kernel(pmc, "shade_kernel<0, 0")
+    # the render path's shade kernel: tvr_shade16.hip's shade16_kernel (16x16x32 tiles) for TensorVMSplit in the default arithmetic, else tvr_shade.hip's
+    on16 = args.model == "TensorVMSplit" and args.arith == "f32"
+    pm, ps = _pmc_kernel(pmc, "march_kernel<false"), (_pmc_kernel(pmc, "shade16_kernel") if on16 else _pmc_kernel(pmc, "shade_kernel<0, 0"))
 
     def hbm(c):
         return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if ("FETCH_SIZE" in c and "WRITE_SIZE" in c) else None
@@ -688,7 +690,9 @@ def main():
     SHADE_L1_B = loads_per_tile * 1024 / 32.0
     ck_s = ck_shade_probe or clock_ghz(ps, ps.get("_dur_s", 0.0)) or 1.7
     ach_shade = FLOP_APP * m_app / t_shade / 1e12 if t_shade > 0 else None
-    roof_shade = {"kernel": "shade_kernel<0,0,%s>" % ("true" if args.model == "REFTensoRF" else "false"), "bound": "mfma", "achieved": ach_shade,
+    if on16:                    # executed on the 16x16x32 tiles: basis 32 rows x 160 k, layer 1 128 x 160, layer 2 128 x 128, three products each
+        FLOP_APP_EXEC = 3 * 2 * (32 * 160 + 128 * 160 + 128 * 128)
+    roof_shade = {"kernel": "shade16_kernel<false>" if on16 else "shade_kernel<0,0,%s>" % ("true" if args.model == "REFTensoRF" else "false"), "bound": "mfma", "achieved": ach_shade,
                   "peak": 2500.0, "unit": "TFLOP/s", "frac": ach_shade / 2500.0 if ach_shade else None,
                   "frac_vs_fp32class_ceiling": ach_shade / (2500.0 / 3.0) if ach_shade else None,
                   # what the matrix pipe sustains on toggling operands (power envelope): scripts/hwprobe/mfma_clock.hip, profiles/r02_mfma_clock_probe.txt
