@@ -77,14 +77,29 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// vm_term<4, false> with the line taps taken from the LDS copy (same arithmetic, same order)
+// vm_term<4, false> with the line taps taken from the LDS copy (same arithmetic, same order).
+// Round 5: the plane taps are addressed as wave-uniform base + 32-BIT byte offset (global_load ... v_off, s[base] offset:imm): the 64-bit per-lane address
+// arithmetic this replaced (v_mad_i64_i32, v_lshlrev_b64, 2 x v_lshl_add_u64 per plane and sub-step: multi-pass instructions) was a tenth of the kernel's VALU
+// issue time.  A density plane of the largest grid the ABI admits (4097^2 texels x 64 B) is 1.07 GB: the offsets fit 32 bits.
+#ifndef MARCH_ADDR32
+#define MARCH_ADDR32 1
+#endif
 __device__ __forceinline__ float4 vm_term_lds(const float4 *__restrict__ P, const float4 *Ls, int W, int x0, int y0, int l0,
                                               float wx, float wy, float wl, int sub)
 {
     const float ux = 1.0f - wx, uy = 1.0f - wy, ul = 1.0f - wl;
     const int Wp = W + 1;
+#if MARCH_ADDR32
+    const unsigned cell = __umul24((unsigned)y0, (unsigned)Wp) + (unsigned)x0;            // both factors below 2^24 (grid <= 4096)
+    unsigned o0 = (cell << 6) + ((unsigned)sub << 4), o1 = o0 + ((unsigned)Wp << 6);
+    asm volatile("" : "+v"(o0), "+v"(o1));                                                // opaque: hipcc otherwise widens the sums back into 64-bit arithmetic
+    const unsigned char *pb = (const unsigned char *)P;
+    const float4 t00 = *(const float4 *)(pb + (size_t)o0), t01 = *(const float4 *)(pb + (size_t)o0 + 64);
+    const float4 t10 = *(const float4 *)(pb + (size_t)o1), t11 = *(const float4 *)(pb + (size_t)o1 + 64);
+#else
     const float4 *p = P + ((size_t)y0 * Wp + x0) * 4 + sub;
     const float4 t00 = p[0], t01 = p[4], t10 = p[(size_t)Wp * 4], t11 = p[(size_t)Wp * 4 + 4];
+#endif
     const float4 *q = Ls + l0 * MARCH_LSTRIDE + sub;
     const float4 l0v = q[0], l1v = q[MARCH_LSTRIDE];
     float4 p4 = f4_mul(ux * uy, t00);

@@ -64,6 +64,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define S16_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
 #define S16_SG_VALU(n) __builtin_amdgcn_sched_group_barrier(0x402, (n), 0)      // VALU | TRANS
 #define S16_SG_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
+#ifndef S16_FAST_SIGMOID
+#define S16_FAST_SIGMOID 1    // v_exp_f32 / v_rcp_f32 instead of expf + an IEEE division: -63 instructions per tile, 12.16 -> 11.97 ms (profiles/r05_shade16_ab.txt)
+#endif
+#ifndef S16_FAST_SINCOS
+#define S16_FAST_SINCOS 1     // sin / cos of the encoding from fract(v / 2 pi) (two VALU instructions) instead of the two-term Cody-Waite reduction (six)
+#endif
+// The kernel is bound by its SIMD's vector-issue port (492 MFMAs x 8 + ~1800 VALU x 4 cycles per tile against ~12 k cycles per tile and SIMD): every instruction
+// removed is time.  v_sin_f32 / v_cos_f32 take revolutions; v * (1 / 2 pi) carries fp32's relative rounding, i.e. a phase error of |v| * 6e-8 rad — 2e-6 at the
+// |v| <= 30 of a trained scene, 7e-5 at the |v| ~ 1100 that tests/test_gpu_parity.py::test_large_feature_magnitudes holds to the 1e-3 bar (its docstring prices exactly
+// this error); fract keeps the argument inside the instructions' domain for any magnitude.  tvr_shade.hip's other modes keep sincos_pe's Cody-Waite form.
+__device__ __forceinline__ void sincos_pe16(float x, float &s, float &c)
+{
+#if S16_FAST_SINCOS
+    const float t = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
+    s = __builtin_amdgcn_sinf(t);
+    c = __builtin_amdgcn_cosf(t);
+#else
+    sincos_pe(x, s, c);
+#endif
+}
 #ifndef S16_PIN
 #define S16_PIN 1         // 1: one empty-asm pin per interpolated float4 (keeps hipcc from spreading a tap set's consumers over the phase); 0: none
 #endif
@@ -372,7 +392,7 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int i = 8 * s + j, r = i / 5, t = i % 5;
-                    if (t == 0) sincos_pe(F[r], S1[r], C1[r]);
+                    if (t == 0) sincos_pe16(F[r], S1[r], C1[r]);
                     v[j] = t == 0 ? F[r] : (t == 1 ? S1[r] : (t == 2 ? 2.0f * S1[r] * C1[r] : (t == 3 ? C1[r] : __builtin_fmaf(-2.0f * S1[r], S1[r], 1.0f))));
                 }
                 b = split8(v);
@@ -529,7 +549,14 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
             // (the order above interleaves c3 outermost where l3_block has r outermost: per sum s3X[c3] the additions run r = 0..3 either way)
             const float4 b3 = *(const float4 *)(smem + TVR16_B3);
             float r0 = group_sum2(s3A[0], s3B[0]), r1 = group_sum2(s3A[1], s3B[1]), r2 = group_sum2(s3A[2], s3B[2]);
+#if S16_FAST_SIGMOID
+            // 1 / (1 + exp(-x)) with v_exp_f32 / v_rcp_f32 (1 ulp each) instead of expf + an IEEE division: ~25 fewer VALU instructions per tile, < 2e-7 in the colour
+            r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (r0 + b3.x)));
+            r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (r1 + b3.y)));
+            r2 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (r2 + b3.z)));
+#else
             r0 = sigmoid_f(r0 + b3.x); r1 = sigmoid_f(r1 + b3.y); r2 = sigmoid_f(r2 + b3.z);
+#endif
             if (RC) {                                  // an operand of this entry left fp16's range: the colour is NaN, not a clipped product
                 const float m = group_max2(rmaxA, rmaxB);
                 if (!(m < TVR_F16_MAX)) r0 = r1 = r2 = __builtin_nanf("");

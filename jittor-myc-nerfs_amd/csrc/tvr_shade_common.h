@@ -6,7 +6,17 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef TVR_FAST_SIGMOID
+#define TVR_FAST_SIGMOID 0    // experiment (round 5): tvr_shade.hip's kernels with tvr_shade16.hip's v_exp_f32 / v_rcp_f32 sigmoid
+#endif
+#ifndef TVR_FAST_SINCOS
+#define TVR_FAST_SINCOS 0     // experiment (round 5): ... and its fract-based sin / cos argument
+#endif
+#if TVR_FAST_SIGMOID
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+#else
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+#endif
 // (the packed forms v_pk_fma_f32 / v_pk_mul_f32: half the instructions and 2 % SLOWER — beside the partner wave's MFMA stream a packed fp32 op takes
 // 52.7 cycles instead of 4.6, scripts/hwprobe/valu_rate.hip)
 // two plain v_fma_f32 / v_mul_f32, each pinned by an empty asm (without the pins, and with the SLP vectoriser off: 12.92 vs 12.75 ms)
@@ -162,6 +172,12 @@ __device__ __forceinline__ void taps_eval(const Taps &T, int W, int H, int L, fl
 // the same as round 1's fract() form had for small |x| (scripts/accuracy_report.py), and smaller than that form's for |x| > 100.
 __device__ __forceinline__ void sincos_pe(float x, float &s, float &c)
 {
+#if TVR_FAST_SINCOS
+    const float tf = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
+    s = __builtin_amdgcn_sinf(tf);
+    c = __builtin_amdgcn_cosf(tf);
+    return;
+#endif
     const float k = rintf(x * 0.15915494309189535f);
     float r = __builtin_fmaf(k, -6.2831854820251465f, x);
     r = __builtin_fmaf(k, 1.7484555e-7f, r);                   // 2pi = 6.2831854820251465 - 1.7484555e-7
