@@ -135,7 +135,8 @@ int tvr_scene_set_range_check(tvr_scene *scene, int32_t on);
  *   TVR_ARITH_F32    (default) three fp16 products per fp32 product — weights AND activations as fp16 hi + lo: ~2^-22 per product, fp32-class;
  *   TVR_ARITH_F16ACT layers 1 and 2 take two products — weights keep hi + lo (22 bits), their inputs (features, encoded values, relu outputs) are rounded to
  *                    fp16 (nearest even, 2^-12 relative); the basis product and REFTensoRF's heads keep three (their outputs feed sin / cos, where an error is amplified): 0.70 of the matrix work;
- *   TVR_ARITH_F16    one product — weights and activations as plain fp16: 1/3 of the matrix work; and the gather of tvr_render(_z) reads fp16 COPIES of the appearance
+ *   TVR_ARITH_F16    one product — activations as fp16 (nearest even), weights as the HI image of the default mode, i.e. truncated toward zero to fp16 (a one-sided
+ *                    2^-11 per weight instead of an unbiased 2^-12: the measured errors below include it): 1/3 of the matrix work; and the gather of tvr_render(_z) reads fp16 COPIES of the appearance
  *                    planes / lines (kept in the packed buffer, converted from the fp32 images with round-to-nearest-even by tvr_scene_update when this mode is set, else
  *                    by the first render in the mode): half the bytes through the L1 return path, interpolation still in fp32.
  *                    (A hipGraph that captured a render bakes in the mode and whether a conversion was due: capture again after switching modes.)
@@ -227,7 +228,12 @@ typedef struct { size_t counter, ray_off, ray_cnt, acc, q_pos, q_out, q_ray, q_j
 int tvr_scratch_describe(int64_t n_rays, int32_t n_samples, tvr_scratch_layout *out);
 
 /* The march alone (sample_ray .. raw2alpha, tensorBase.py:487-513): fills the queue (q_pos, q_ray, ray_off, ray_cnt, counter),
- * acc [n] and depth_out [n].  Same arithmetic as tvr_render. */
+ * acc [n] and depth_out [n].  Same arithmetic as tvr_render.
+ * RAY ORDER: for n_rays <= 65 536 (TVR_RAY_ORDER_MAX_RAYS: every training batch of the reference) the queue is put into ray order behind the march — ray_off
+ * ascends with the ray index — so that every reduction over the appearance samples (the weight-gradient products) runs in the same order run to run: the network's
+ * gradients of tvr_train_backward are bit-identical run to run for such batches, the VM factors' (fp32 atomic scatter) reproducible to rounding.  The pass uses the
+ * scratch's q_out and q_j regions as temporaries: their contents are undefined afterwards.  Larger batches keep the order the march kernel's waves finished in
+ * (every gradient reproducible to rounding only).  A march that raised its fault flag leaves the queue as it lies (the pass returns at once). */
 int tvr_march_forward(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *jitter, float eps_T,
                       float *depth_out, void *scratch, size_t scratch_bytes, void *stream);
 
