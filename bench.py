@@ -45,12 +45,14 @@ SHADE_LOADS_PER_TILE = 114      # tvr_shade.hip, wave-level global loads per 32-
 def build_model(device, name="TensorVMSplit"):
     from jittor_myc_nerfs_amd import REFTensoRF, TensorVMSplit, synthetic
     A = synthetic.SCENE_A
-    arrs = synthetic.make_scene_arrays(A["gridSize"], A["aabb"], ref=(name == "REFTensoRF"))
+    pe = int(os.environ.get("TVR_PE", "2"))               # encoding frequencies (view_pe = fea_pe): 6 = TensorBase.__init__'s own default (scripts/train_step_timing.py)
+    arrs = synthetic.make_scene_arrays(A["gridSize"], A["aabb"], ref=(name == "REFTensoRF")) if pe == 2 else \
+        synthetic.make_scene_arrays(A["gridSize"], A["aabb"], view_pe=pe, fea_pe=pe)
     H = synthetic.HYPER
     m = (REFTensoRF if name == "REFTensoRF" else TensorVMSplit)(arrs["aabb"], A["gridSize"], device, density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, app_dim=27,
                       near_far=A["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=H["density_shift"],
                       distance_scale=H["distance_scale"], rayMarch_weight_thres=H["rayMarch_weight_thres"], pos_pe=6,
-                      view_pe=2, fea_pe=2, featureC=128, step_ratio=A["step_ratio"], fea2denseAct=H["fea2denseAct"])
+                      view_pe=pe, fea_pe=pe, featureC=128, step_ratio=A["step_ratio"], fea2denseAct=H["fea2denseAct"])
     m.load_arrays(arrs)
     return m, arrs, A
 

@@ -26,21 +26,55 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def _hip_mm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x [M, N] @ w [N, K] for a tall fp32 batch on the device, through tvr_linear_dx's fp32-INPUT MFMAs (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
+    accumulation — a library GEMM's arithmetic without the library).  The kernel takes a reduction of at most 128 (multiples of 8) and 32 / 64 / 96 / 128 output
+    columns per call: wider products are cut into blocks, padded with zeros where a block is ragged, and the reduction blocks are added in a fixed order.
+    Round 5: the network of a scene with more than two encoding frequencies (390 inputs at TensorBase's default 6 / 6) trains through this instead of rocBLAS."""
+    M, N = x.shape
+    K = w.shape[1]
+    lib = L.lib()
+    Np, Kp = (N + 7) // 8 * 8, (K + 31) // 32 * 32
+    xp = x if (Np == N and x.is_contiguous()) else torch.nn.functional.pad(x, (0, Np - N)).contiguous()
+    wp = w if (Kp == K and w.is_contiguous()) else torch.nn.functional.pad(w, (0, Kp - K)).contiguous()
+    out = None
+    st = _stream_ptr(x.device)
+    for n0 in range(0, Np, 128):
+        nn = min(128, Np - n0)
+        part = torch.empty((M, Kp), dtype=torch.float32, device=x.device)
+        for k0 in range(0, Kp, 128):
+            kk = min(128, Kp - k0)
+            L.check(lib.tvr_linear_dx(xp.data_ptr() + 4 * n0, Np, nn, wp.data_ptr() + 4 * (n0 * Kp + k0), Kp, min(nn, N - n0), kk, None, 0, None,
+                                      part.data_ptr() + 4 * k0, Kp, (part.numel() - k0) * 4, M, None, None, st), "tvr_linear_dx")
+        out = part if out is None else out + part
+    return out if Kp == K else out[:, :K]
+
+
+_HIP_MM_MIN_ROWS = 4096     # below this a library GEMM is as good (and the small fixtures of the gradient tests keep exercising it)
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b over the M appearance samples of a batch.  Forward and dX are library GEMMs; the weight gradient dW = dY^T X is the
-    tall-skinny reduction tvr_gemm_tn (M ~ 3.5e5 rows, <= 160 columns) that the library runs at ~15 TFLOP/s."""
+    """y = x W^T + b over the M appearance samples of a batch.  Tall batches on the device (M >= 4096, fp32): forward and dX through tvr_linear_dx's fp32-input
+    MFMAs (_hip_mm), the weight gradient dW = dY^T X through the tall-skinny reduction tvr_gemm_tn — no library GEMM in the step (round 5; before: forward and
+    dX were rocBLAS calls).  Small batches and CPU tensors: torch."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= _HIP_MM_MIN_ROWS:
+            y = _hip_mm(x, weight.t().contiguous())
+            return y + bias if bias is not None else y
         return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
 
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
-        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        tall = gy.is_cuda and gy.dtype == torch.float32 and weight.dtype == torch.float32 and gy.shape[0] >= _HIP_MM_MIN_ROWS
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = _hip_mm(gy, weight.contiguous()) if tall else gy @ weight
         gw = None
         if ctx.needs_input_grad[1]:
             gw = _gemm_tn(gy, x.contiguous()) if (x.is_cuda and x.shape[0] >= 4096 and x.dtype == torch.float32) else gy.t() @ x

@@ -58,11 +58,16 @@ def test_zero_padded_shapes_render_like_the_oracle(tiny_dump, hyper_tiny, dc, ac
     assert float((m._mlp_render(vd.cuda(), feat.cuda()).cpu() - TO.mlp_render_fea(sc, vd, feat)).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("dc,ac,fc,vpe,fpe", [SHAPES[0], SHAPES[1], SHAPES[5]])
-def test_zero_padded_shapes_train(tiny_dump, hyper_tiny, dc, ac, fc, vpe, fpe):
-    """Gradients of every parameter tensor at its own (unpadded) shape against autograd through the oracle."""
+@pytest.mark.parametrize("dc,ac,fc,vpe,fpe,hip_mm", [SHAPES[0] + (False,), SHAPES[1] + (False,), SHAPES[5] + (False,), SHAPES[5] + (True,), SHAPES[6] + (True,)])
+def test_zero_padded_shapes_train(tiny_dump, hyper_tiny, monkeypatch, dc, ac, fc, vpe, fpe, hip_mm):
+    """Gradients of every parameter tensor at its own (unpadded) shape against autograd through the oracle.  hip_mm: the eager chain's Linears forced onto the HIP
+    kernels whatever the batch size (round 5: what a 4096-ray training batch of a six-frequency scene runs — tvr_linear_dx forward and dX, tvr_gemm_tn dW; no
+    library GEMM, scripts/pe6_train_trace.sh)."""
     from oracle import tensorf_oracle as TO
     from test_gpu_training import _oracle_with_grads
+    if hip_mm:
+        from jittor_myc_nerfs_amd import autograd_ops
+        monkeypatch.setattr(autograd_ops, "_HIP_MM_MIN_ROWS", 1)
     arrs, hyper, m = _scene(dc, ac, fc, vpe, fpe, hyper_tiny)
     rays_np = tiny_dump["rays"]
     S = TINY["N_samples"]
@@ -94,3 +99,29 @@ def test_shapes_that_do_not_fit_are_refused(hyper_tiny, kw):
     m = TensorVMSplit(TINY["aabb"], TINY["gridSize"], "cuda", app_dim=27, near_far=TINY["near_far"], shadingMode="MLP_Fea", step_ratio=TINY["step_ratio"], **args)
     with pytest.raises(L.TvrError, match="supports"):
         m.render_rays(torch.zeros((4, 6), device="cuda"))
+
+
+@pytest.mark.parametrize("n_in,n_out,bias", [(144, 27, False), (390, 128, True), (128, 128, True), (128, 3, True), (151, 128, True), (6, 1, True)])
+def test_linear_fn_tall_batches_run_on_hip_kernels(n_in, n_out, bias):
+    """autograd_ops._LinearFn on a tall batch (the network of a scene with more than two encoding frequencies trains through it: 390 -> 128 -> 128 -> 3 at
+    TensorBase's default 6 / 6, and the 144 -> 27 basis): forward and dX through tvr_linear_dx's fp32-input MFMAs (_hip_mm: blocks of 128 in the reduction,
+    ragged blocks zero-padded), dW through tvr_gemm_tn — against float64 torch."""
+    from jittor_myc_nerfs_amd.autograd_ops import _LinearFn, _HIP_MM_MIN_ROWS
+    g = torch.Generator().manual_seed(n_in * 131 + n_out)
+    M = _HIP_MM_MIN_ROWS + 905                                                # not a multiple of any tile
+    x = torch.randn((M, n_in), generator=g).cuda().requires_grad_(True)
+    w = (torch.randn((n_out, n_in), generator=g) / n_in ** 0.5).cuda().requires_grad_(True)
+    b = torch.randn((n_out,), generator=g).cuda().requires_grad_(True) if bias else None
+    gy = torch.randn((M, n_out), generator=g).cuda()
+    y = _LinearFn.apply(x, w, b)
+    y.backward(gy)
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    b64 = b.detach().double().requires_grad_(True) if bias else None
+    y64 = torch.nn.functional.linear(x64, w64, b64)
+    y64.backward(gy.double())
+    def close(a, ref, tol=2e-6):
+        return float((a.double() - ref).abs().max()) <= tol * max(float(ref.abs().max()), 1.0)
+    assert y.shape == (M, n_out) and close(y, y64)
+    assert close(x.grad, x64.grad) and close(w.grad, w64.grad, 2e-5)
+    if bias:
+        assert close(b.grad, b64.grad, 2e-5)
