@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 120
+#define TVR_VERSION 130
 
 typedef enum {
     TVR_OK = 0,
