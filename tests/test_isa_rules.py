@@ -22,6 +22,7 @@ def report():
     if not os.path.exists(LIB):
         g.build()
     rep = {k: v for k, v in isa_check.audit(LIB, "shade_kernel").items() if not k.endswith("E" + GEN + "9ShadeArgs")}
+    rep.update(isa_check.audit(LIB, "shade16_kernel"))            # round 5: the render path's kernel on 16x16x32 tiles (it happens to satisfy the phase rule too)
     rep.update(isa_check.audit(LIB, "mlp_train_backward_kernel"))
     rep.update(isa_check.audit(LIB, "basis_backward_kernel"))
     return rep
@@ -30,8 +31,8 @@ def report():
 def test_every_shade_kernel_variant_is_audited(report):
     # {queue, xyz->features, features->rgb} x {fp16 range check on, off} + the training forward (h -> rgb + activations), each x {TensorVMSplit, REFTensoRF},
     # + the render and mlp_render kernels in the two reduced-product arithmetics (2 kernels x 2 models x 2 range-check states x 2 modes)
-    # + the backward kernels (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps)
-    assert len(report) == 34, sorted(report)
+    # + the backward kernels (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps) + shade16_kernel x 2 range-check states
+    assert len(report) == 36, sorted(report)
 
     assert all(v["mfma"] >= 27 for v in report.values())
 
