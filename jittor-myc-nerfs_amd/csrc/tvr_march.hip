@@ -111,6 +111,72 @@ __device__ __forceinline__ float4 vm_term_lds(const float4 *__restrict__ P, cons
     return make_float4(p4.x * q4.x, p4.y * q4.y, p4.z * q4.z, p4.w * q4.w);
 }
 
+// Round 5: the same term with everything that depends on the SAMPLE alone — the four bilinear weights, the two line weights, the texel byte offset, the LDS
+// offset of the line texel — computed once per chunk by the lane that owns the sample (W4, WL, off, loff) and taken from it here by quad_perm DPP
+// (quad_bcast_*(x, k4)): written as one broadcast per use so that hipcc's DPP combine folds it into the consuming v_mul_f32 / v_fmac_f32 / v_add_u32 (VOP2 with a
+// DPP source: no v_mov_b32_dpp, no instruction at all).  Per sub-step that removes 6 broadcasts, 3 (1 - w), 12 weight products and the cell arithmetic of three
+// planes: 182 -> ~150 instructions.  Same products, same order of the FMAs: bit-identical sigma features.
+// MEASURED AND NOT ENABLED (profiles/r05_shade16_ab.txt, blocks r5r / r5s): -93 VALU instructions per chunk (-8 %), frames bit-identical (sha256), and the kernel
+// 1.8 % SLOWER in both forms (7.86 - 7.97 against 7.71 - 7.83 ms, interleaved on two boxes) — the march is bound by its 48 wave-level loads per chunk on the L1 path
+// (r05_ta_mask_probe.txt), not by its VALU count, and the 18 extra live registers per lane cost more than the instructions saved.  Kept as a build option.
+#ifndef MARCH_PRECOMP
+#define MARCH_PRECOMP 0
+#endif
+#ifndef MARCH_DPP_ASM
+#define MARCH_DPP_ASM 1       // 1: the weight operand of every interpolation op is read through quad_perm DPP by the op itself (v_mul_f32_dpp / v_fmac_f32_dpp as inline asm:
+#endif                        // hipcc's DPP combine folds a broadcast into v_mul_f32 only, and only in src0 position — 15 v_mov_b32_dpp per sub-step stayed); 0: builtins
+// r = w[quad lane K] * t   /   acc += w[quad lane K] * t   (VOP2 with a DPP source; the asm is not volatile: a pure function of its operands, free to be scheduled)
+template <int K>
+__device__ __forceinline__ float mul_q(float w, float t)
+{
+#if MARCH_DPP_ASM
+    float r;
+    asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(w), "v"(t), "n"(K));
+    return r;
+#else
+    return quad_bcast_f(w, K) * t;
+#endif
+}
+template <int K>
+__device__ __forceinline__ float fma_q(float w, float t, float acc)
+{
+#if MARCH_DPP_ASM
+    asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(w), "v"(t), "n"(K));
+    return acc;
+#else
+    return __builtin_fmaf(quad_bcast_f(w, K), t, acc);
+#endif
+}
+template <int K>
+__device__ __forceinline__ float4 vm_term_pre(const float4 *__restrict__ P, const unsigned char *Lbytes, unsigned Wp64, const float W4[4], const float WL[2], unsigned off,
+                                              unsigned loff, unsigned sub16)
+{
+    const unsigned o0 = quad_bcast_i((int)off, K) + sub16, o1 = o0 + Wp64;
+    const unsigned char *pb = (const unsigned char *)P;
+    const float4 t00 = *(const float4 *)(pb + (size_t)o0), t01 = *(const float4 *)(pb + (size_t)o0 + 64);
+    const float4 t10 = *(const float4 *)(pb + (size_t)o1), t11 = *(const float4 *)(pb + (size_t)o1 + 64);
+    const unsigned lo = quad_bcast_i((int)loff, K) + sub16;
+    const float4 l0v = *(const float4 *)(Lbytes + lo), l1v = *(const float4 *)(Lbytes + lo + 16 * MARCH_LSTRIDE);
+    float4 p4, q4;
+    p4.x = mul_q<K>(W4[0], t00.x); p4.y = mul_q<K>(W4[0], t00.y); p4.z = mul_q<K>(W4[0], t00.z); p4.w = mul_q<K>(W4[0], t00.w);
+    p4.x = fma_q<K>(W4[1], t01.x, p4.x); p4.y = fma_q<K>(W4[1], t01.y, p4.y); p4.z = fma_q<K>(W4[1], t01.z, p4.z); p4.w = fma_q<K>(W4[1], t01.w, p4.w);
+    p4.x = fma_q<K>(W4[2], t10.x, p4.x); p4.y = fma_q<K>(W4[2], t10.y, p4.y); p4.z = fma_q<K>(W4[2], t10.z, p4.z); p4.w = fma_q<K>(W4[2], t10.w, p4.w);
+    p4.x = fma_q<K>(W4[3], t11.x, p4.x); p4.y = fma_q<K>(W4[3], t11.y, p4.y); p4.z = fma_q<K>(W4[3], t11.z, p4.z); p4.w = fma_q<K>(W4[3], t11.w, p4.w);
+    q4.x = mul_q<K>(WL[0], l0v.x); q4.y = mul_q<K>(WL[0], l0v.y); q4.z = mul_q<K>(WL[0], l0v.z); q4.w = mul_q<K>(WL[0], l0v.w);
+    q4.x = fma_q<K>(WL[1], l1v.x, q4.x); q4.y = fma_q<K>(WL[1], l1v.y, q4.y); q4.z = fma_q<K>(WL[1], l1v.z, q4.z); q4.w = fma_q<K>(WL[1], l1v.w, q4.w);
+    return make_float4(p4.x * q4.x, p4.y * q4.y, p4.z * q4.z, p4.w * q4.w);
+}
+// the three planes of one sub-step (K a constant after unrolling)
+template <int K>
+__device__ __forceinline__ float vm_sum_pre(const SceneDev &sc, const unsigned char *l0, const unsigned char *l1, const unsigned char *l2, const float Wq[3][4], const float Wl[3][2],
+                                            const unsigned offp[3], const unsigned offl[3], unsigned sub16)
+{
+    const float4 a = vm_term_pre<K>(sc.dplane[0], l0, ((unsigned)sc.grid[0] + 1u) << 6, Wq[0], Wl[0], offp[0], offl[0], sub16);
+    const float4 b = vm_term_pre<K>(sc.dplane[1], l1, ((unsigned)sc.grid[0] + 1u) << 6, Wq[1], Wl[1], offp[1], offl[1], sub16);
+    const float4 cc = vm_term_pre<K>(sc.dplane[2], l2, ((unsigned)sc.grid[1] + 1u) << 6, Wq[2], Wl[2], offp[2], offl[2], sub16);
+    return ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((cc.x + cc.y) + (cc.z + cc.w));
+}
+
 template <bool DENSE, bool LDSL>
 __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const SceneDev sc, const float *__restrict__ rays,
                                                                      const int n_rays, const int S, const int s_cap,
@@ -318,10 +384,44 @@ __global__ __launch_bounds__(64 * MARCH_MAX_WAVES) void march_kernel(const Scene
 
             // ---- density feature: 4 sub-steps, quad-per-sample gather ----
             float sf = 0.0f;
+#if MARCH_PRECOMP
+            // what the sub-steps need of this lane's sample, once per chunk (vm_term_pre): plane p's weights in vm_term_lds's order for its (a, b | line) axes —
+            // plane 0 (x, y | z), plane 1 (x, z | y), plane 2 (y, z | x) — and the byte offsets of its first texel and of its line texel in LDS
+            float Wq[3][4], Wl[3][2];
+            unsigned offp[3], offl[3];
+            if (LDSL) {
+                const float ux = 1.0f - w[0], uy = 1.0f - w[1], uz = 1.0f - w[2];
+                Wq[0][0] = ux * uy; Wq[0][1] = w[0] * uy; Wq[0][2] = ux * w[1]; Wq[0][3] = w[0] * w[1];
+                Wq[1][0] = ux * uz; Wq[1][1] = w[0] * uz; Wq[1][2] = ux * w[2]; Wq[1][3] = w[0] * w[2];
+                Wq[2][0] = uy * uz; Wq[2][1] = w[1] * uz; Wq[2][2] = uy * w[2]; Wq[2][3] = w[1] * w[2];
+                Wl[0][0] = uz; Wl[0][1] = w[2]; Wl[1][0] = uy; Wl[1][1] = w[1]; Wl[2][0] = ux; Wl[2][1] = w[0];
+                const unsigned Wp0 = (unsigned)sc.grid[0] + 1u, Wp2 = (unsigned)sc.grid[1] + 1u;
+                offp[0] = (__umul24((unsigned)i0[1], Wp0) + (unsigned)i0[0]) << 6;
+                offp[1] = (__umul24((unsigned)i0[2], Wp0) + (unsigned)i0[0]) << 6;
+                offp[2] = (__umul24((unsigned)i0[2], Wp2) + (unsigned)i0[1]) << 6;
+                offl[0] = (unsigned)i0[2] * (16u * MARCH_LSTRIDE); offl[1] = (unsigned)i0[1] * (16u * MARCH_LSTRIDE); offl[2] = (unsigned)i0[0] * (16u * MARCH_LSTRIDE);
+                if (!valid) { offp[0] = offp[1] = offp[2] = 0u; offl[0] = offl[1] = offl[2] = 0u; }       // (samples outside the box: their lanes' offsets are never used, keep them harmless)
+            }
+            const unsigned sub16 = (unsigned)sub << 4;
+#endif
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
                 const bool v = quad_bcast_i((int)valid, k4) != 0;
                 if (__ballot(v) == 0ull) continue;
+#if MARCH_PRECOMP
+                if (LDSL) {
+                    float part = 0.0f;
+                    if (v) {
+                        const unsigned char *l0b = (const unsigned char *)ls0, *l1b = (const unsigned char *)ls1, *l2b = (const unsigned char *)ls2;
+                        part = k4 == 0 ? vm_sum_pre<0>(sc, l0b, l1b, l2b, Wq, Wl, offp, offl, sub16) : (k4 == 1 ? vm_sum_pre<1>(sc, l0b, l1b, l2b, Wq, Wl, offp, offl, sub16)
+                             : (k4 == 2 ? vm_sum_pre<2>(sc, l0b, l1b, l2b, Wq, Wl, offp, offl, sub16) : vm_sum_pre<3>(sc, l0b, l1b, l2b, Wq, Wl, offp, offl, sub16)));
+                    }
+                    part += quad_perm_f<QUAD_XOR1>(part);
+                    part += quad_perm_f<QUAD_XOR2>(part);
+                    if (sub == k4) sf = part;
+                    continue;
+                }
+#endif
                 const int ix = quad_bcast_i(i0[0], k4), iy = quad_bcast_i(i0[1], k4), iz = quad_bcast_i(i0[2], k4);
                 const float wx = quad_bcast_f(w[0], k4), wy = quad_bcast_f(w[1], k4), wz = quad_bcast_f(w[2], k4);
                 float part = 0.0f;
