@@ -341,6 +341,28 @@ def _pmc_kernel(pmc, prefix):
     return {}
 
 
+def frame_stream(model, step_rays, S, eps_T, frames_n=24):
+    """Throughput of a STREAM of frames with two in flight (render.FrameStream: frame k on stream k % 2, own scratch and outputs), behind the timed region.
+    Informational — `value` is the serial loop's, one frame at a time, whose kernels can be timed one by one."""
+    from jittor_myc_nerfs_amd import FrameStream
+    fs = FrameStream(model, white_bg=True, N_samples=S, eps_T=eps_T)
+    for s in range(4):
+        fs.submit(step_rays[s % len(step_rays)])
+    fs.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(frames_n):
+        fs.submit(step_rays[s % len(step_rays)])
+    last = fs.flush()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames_n
+    ref = model.render_rays(step_rays[(frames_n - 1) % len(step_rays)], white_bg=True, N_samples=S, eps_T=eps_T)
+    return {"ms_per_frame": dt * 1e3, "ray_samples_per_sec": step_rays[0].shape[0] * S / dt, "frames": frames_n,
+            "last_frame_equals_serial_render": bool(torch.equal(last[0], ref[0]) and torch.equal(last[1], ref[1])),
+            "note": "two frames in flight on two HIP streams (FrameStream): the persistent kernels of one frame fill the CUs the other frame's kernels leave as they drain; "
+                    "not the headline — a frame's latency is not shortened and its kernels cannot be timed one by one"}
+
+
 def arith_modes(model, step_rays, S, eps_T, m_app, steps=8):
     """The opt-in arithmetics of the appearance network (include/tvr.h, tvr_scene_set_arith) on the bench frame, behind the timed region: kernel times
     (HIP events of the library's own profile, `steps` frames over the poses) and the picture's distance from the default (fp32-class) mode's on ALL rays of
@@ -773,6 +795,7 @@ def main():
     # configs[4] = the JNeRF Instant-NGP alt path.  Informational: `value` above is configs[1].
     if rank == 0 and world == 1 and default_workload and not args.no_extras and args.arith == "f32":
         result["arith_modes"] = arith_modes(model, step_rays, S, args.eps_T, m_app)
+        result["frame_stream_two_in_flight"] = frame_stream(model, step_rays, S, args.eps_T)
     if rank == 0 and world == 1 and default_workload and not args.no_extras and not args.no_cpu_baseline:
         result["other_configs"] = other_configs()
     L.lib().tvr_profile_destroy(prof)

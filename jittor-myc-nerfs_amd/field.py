@@ -630,11 +630,17 @@ class TensorBase(torch.nn.Module):
         return (self.static_training and self.fused_mlp_training and list(self.app_n_comp) == [48, 48, 48] and self.app_dim == 27
                 and getattr(rm, "feape", 0) == 2 and getattr(rm, "viewpe", 0) == 2 and rm.mlp[0].out_features == 128 and str(self.device).startswith("cuda"))
 
-    def _get_scratch(self, nbytes: int) -> torch.Tensor:
-        if self._scratch is None or self._scratch.numel() < nbytes:
-            self._scratch = None
-            self._scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._scratch
+    def _get_scratch(self, nbytes: int, slot: int = 0) -> torch.Tensor:
+        """The render scratch (march queue etc.).  slot > 0: a second buffer for a second frame in flight on another stream (render.FrameStream)."""
+        if slot == 0:
+            if self._scratch is None or self._scratch.numel() < nbytes:
+                self._scratch = None
+                self._scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            return self._scratch
+        extra = self.__dict__.setdefault("_scratch_slots", {})
+        if slot not in extra or extra[slot].numel() < nbytes:
+            extra[slot] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return extra[slot]
 
     # ---- compute entry points ----------------------------------------------------------------------------
     def compute_densityfeature(self, xyz_sampled):                                            # tensoRF.py:209-225
@@ -756,7 +762,7 @@ class TensorBase(torch.nn.Module):
         raise RuntimeError("filtering_rays(bbox_only=False) needs an alpha mask (tensorBase.py:430 reads self.alphaMask): call updateAlphaMask first")
 
     def render_rays(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None, eps_T=None, dense=False,
-                    stats: Optional[torch.Tensor] = None, profile=None, out=None):
+                    stats: Optional[torch.Tensor] = None, profile=None, out=None, scratch_slot: int = 0):
         """One tvr_render call.  Returns (rgb_map [N,3], depth_map [N]) or, with dense=True, additionally a dict
         of per-sample tensors.  `stats`: uint64/int64[8] device tensor the kernels add counters to.
         `out` = (rgb [N,3], depth [N]): contiguous fp32 device tensors the kernels write instead of fresh ones (render_sharded hands in
@@ -783,7 +789,7 @@ class TensorBase(torch.nn.Module):
             eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
         self._settle_arith(rays, S, white_bg, eps_T)
         nbytes = lib.tvr_render_scratch_bytes(sc, n, S)
-        scratch = self._get_scratch(nbytes)
+        scratch = self._get_scratch(nbytes, scratch_slot)
         jit = None if jitter is None else _f32c(jitter, self.device).view(-1)
         if jit is not None and jit.shape[0] != n:
             raise ValueError("jitter must hold one value per ray")

@@ -150,6 +150,54 @@ def render_sharded(rays: torch.Tensor, render_fn: Callable[..., Tuple[torch.Tens
     return rgb.contiguous(), depth.contiguous()
 
 
+class FrameStream:
+    """A stream of frames on ONE card with two frames in flight (round 5).  Frame k is rendered on stream k % 2 into its own scratch and output buffers; the four launches of
+    a frame stay in order on their stream, and the persistent kernels of the OTHER frame fill the CUs this frame's kernels leave as they drain (and the chip's power budget
+    while this frame is in its march).  Measured (scripts/overlap_stream.py, profiles/r05_overlap_stream.txt): 18.8 ms per frame against 19.7 for the serial loop on the
+    bench frame, -4.4 %; limiting the kernels' grids to disjoint CU sets is WORSE (19.8 - 31.5 ms).  Pixels are those of render_rays, bit for bit (the kernels and their
+    per-ray orders are the same; tests/test_gpu_parity.py::test_frame_stream_two_in_flight).  `submit()` returns the frame submitted one call earlier (None at the first
+    call), `flush()` the last one: the returned tensors stay valid until the same slot is submitted again, two calls later.  A throughput device: a single frame's latency
+    is not shortened."""
+
+    def __init__(self, model, white_bg: bool = True, N_samples: int = -1, eps_T=None):
+        self.model, self.white_bg, self.S, self.eps_T = model, white_bg, N_samples, eps_T
+        self.dev = model.device
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(2)]
+        self.done = [torch.cuda.Event() for _ in range(2)]
+        self.out = [None, None]
+        self.busy = [False, False]
+        self.k = 0
+
+    def submit(self, rays):
+        b = self.k % 2
+        self.k += 1
+        cur = torch.cuda.current_stream(self.dev)
+        n = rays.shape[0]
+        if self.out[b] is None or self.out[b][0].shape[0] != n:
+            self.out[b] = (torch.empty((n, 3), dtype=torch.float32, device=self.dev), torch.empty((n,), dtype=torch.float32, device=self.dev))
+        st = self.streams[b]
+        st.wait_stream(cur)                        # the rays are ready, and the caller's stream has been handed this slot's previous frame (two calls ago)
+        with torch.cuda.stream(st):
+            self.model.render_rays(rays, white_bg=self.white_bg, N_samples=self.S, eps_T=self.eps_T, out=self.out[b], scratch_slot=b)
+            self.done[b].record(st)
+        self.busy[b] = True
+        prev = None
+        if self.busy[b ^ 1]:                       # hand out the frame submitted one call earlier.  The caller's stream waits for it only AFTER this frame has been
+            cur.wait_event(self.done[b ^ 1])       # queued behind the caller's earlier work: waiting first would put every frame behind the one before it
+            prev = self.out[b ^ 1]
+        return prev
+
+    def flush(self):
+        b = (self.k - 1) % 2
+        if self.k == 0 or not self.busy[b]:
+            return None
+        torch.cuda.current_stream(self.dev).wait_event(self.done[b])
+        if self.busy[b ^ 1]:
+            torch.cuda.current_stream(self.dev).wait_event(self.done[b ^ 1])
+        self.busy = [False, False]
+        return self.out[b]
+
+
 class ShardedFramePipeline:
     """A stream of frames, each split over the ranks (render_sharded's layout), with the two things a rank's 2.6 ms share of an 800x800 frame needs at N = 8:
 

@@ -490,3 +490,33 @@ def test_fp16_range_is_proven_or_reported_never_clipped(tiny_dump, tiny_arrays, 
     big.fp16_range_check, big._range_proven = "off", None
     rgb_off, _ = big.render_rays(rays, white_bg=True, N_samples=S)
     assert bool(torch.isfinite(rgb_off).all())                                  # what "silently clipped" looked like: finite and wrong
+
+
+def test_frame_stream_two_in_flight(config1_golden):
+    """render.FrameStream (round 5): two frames in flight on two streams, own scratch and output slots — every frame handed back equals the plain render of its rays bit for bit,
+    whatever overlaps with it, and the slots are reused without a frame reading another's queue."""
+    from jittor_myc_nerfs_amd import FrameStream, synthetic
+    B = synthetic.SCENE_B
+    arrs = synthetic.make_scene_arrays(B["gridSize"], B["aabb"])
+    m = make_model(arrs, dict(synthetic.HYPER, near_far=B["near_far"], step_ratio=B["step_ratio"]))
+    base = torch.tensor(config1_golden["rays"], device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(4)
+    sets = []
+    for k in range(5):
+        r = base.clone()
+        r[:, :3] += 0.05 * torch.randn(r[:, :3].shape, device="cuda", generator=g)
+        sets.append(r[: base.shape[0] - 37 * k].contiguous())                    # frames of different sizes: the slots' outputs are re-made
+    want = [tuple(t.clone() for t in m.render_rays(r, white_bg=True, N_samples=B["N_samples"])) for r in sets]
+    fs = FrameStream(m, white_bg=True, N_samples=B["N_samples"])
+    got = []
+    for r in sets:
+        o = fs.submit(r)
+        if o is not None:
+            got.append((o[0].clone(), o[1].clone()))
+    o = fs.flush()
+    got.append((o[0].clone(), o[1].clone()))
+    assert fs.submit(sets[0]) is None                                            # after a flush the stream starts empty again
+    fs.flush()
+    assert len(got) == len(want)
+    for (a, b), (c, d) in zip(got, want):
+        assert torch.equal(a, c) and torch.equal(b, d)
