@@ -30,7 +30,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define S16_WAVES 8
+#ifndef S16_WAVES
+#define S16_WAVES 8         // 4 (-DS16_WAVES=4): one wave per SIMD, a timing experiment (round 5: how much of the kernel's speed is the second wave's overlap)
+#endif
 #define S16_THREADS (64 * S16_WAVES)
 #define S16_TILE 32
 #ifndef S16_PRIO_M
@@ -87,6 +89,12 @@ __device__ __forceinline__ void sincos_pe16(float x, float &s, float &c)
 #ifndef S16_PIN
 #define S16_PIN 1         // 1: one empty-asm pin per interpolated float4 (keeps hipcc from spreading a tap set's consumers over the phase); 0: none
 #endif
+#ifndef S16_GDEPTH
+#define S16_GDEPTH 1      // units of the gather in flight ahead of the one being interpolated (24 registers each)
+#endif
+#ifndef S16_DIAG_LDS
+#define S16_DIAG_LDS 0    // timing stand-ins (WRONG pictures): 1 = layers 1 / 2 read every other weight fragment from LDS (the fragment bytes of a 64-column form), 2 = none
+#endif
 #ifndef S16_SCHED
 #define S16_SCHED 1       // 1: sched_group_barrier windows in the matrix phase; 0: hipcc's own order (A/B)
 #endif
@@ -139,7 +147,7 @@ __device__ __forceinline__ float group_max2(float a, float b)
 }
 
 template <bool RC>
-__global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev sc, const ShadeArgs a)
+__global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_kernel(const SceneDev sc, const ShadeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -273,13 +281,14 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
         Frag hf[9];
         uint4 balg0, balg1;                           // lo parts of basis k-step 3 (global)
         {
-            Taps T[2];
+            Taps T[S16_GDEPTH + 1];
             const unsigned qb0 = 32u * (unsigned)(g & 1);                                  // bytes: unit u reads float4s 4 (u % 3) + 2 (g & 1), + 1 of the texel
-            auto issue = [&](int u) { load_unit(T[u & 1], u / 3, pp[u / 3], qb0 + 64u * (unsigned)(u % 3)); };
-            issue(0);
+            auto issue = [&](int u) { load_unit(T[u % (S16_GDEPTH + 1)], u / 3, pp[u / 3], qb0 + 64u * (unsigned)(u % 3)); };
+#pragma unroll
+            for (int u0 = 0; u0 < S16_GDEPTH; ++u0) issue(u0);
 #pragma unroll
             for (int u = 0; u < 9; ++u) {
-                if (u + 1 < 9) issue(u + 1);
+                if (u + S16_GDEPTH < 9) issue(u + S16_GDEPTH);
                 if (u == 7) {                          // the tile's last global loads ride behind the last taps
                     unsigned boff = (unsigned)(lane * 16);
                     asm volatile("" : "+v"(boff));
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
                     balg1 = *(const uint4 *)((const unsigned char *)sc.basg16 + (boff + TVR16_FRAG));
                 }
                 float hv[8];
-                eval_unit(T[u & 1], pp[u / 3], hv);
+                eval_unit(T[u % (S16_GDEPTH + 1)], pp[u / 3], hv);
                 if (RC) {
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) rmax = absmax2(hv[j], hv[j + 1], rmax);
@@ -414,6 +423,8 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
             S16_LDS_BASE(W2Hb, smem + TVR16_W2H + lane * 16);
             S16_LDS_BASE(W2Lb, smem + TVR16_W2L + lane * 16);
             AF16 ring[S16_RN];
+            AF16 dfix[2];
+            if (S16_DIAG_LDS == 3) { dfix[0].h = *(const uint4 *)(W1Hb); dfix[0].l = *(const uint4 *)(W1Lb); dfix[1].h = *(const uint4 *)(W1Hb + TVR16_FRAG); dfix[1].l = *(const uint4 *)(W1Lb + TVR16_FRAG); }
             Frag bA, bB, nA, nB;
             Frag frA[4], frB[4];
 #pragma unroll
@@ -426,7 +437,11 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
 #pragma unroll
                 for (int rb = 0; rb < 8; ++rb) {
                     const int q = 8 * s + rb;
-                    if (q + S16_PD < 40) {
+                    if (S16_DIAG_LDS == 2 || (S16_DIAG_LDS == 1 && ((q + S16_PD) & 1))) {        // timing stand-in (wrong pictures): no / every other fragment read
+                    } else if (S16_DIAG_LDS == 4) {    // real reads into the ring, real waits — of two fragment addresses only (same data every other step)
+                        ring[(q + S16_PD) % S16_RN].h = *(const uint4 *)(W1Hb + ((q + S16_PD) & 1) * TVR16_FRAG);
+                        ring[(q + S16_PD) % S16_RN].l = *(const uint4 *)(W1Lb + ((q + S16_PD) & 1) * TVR16_FRAG);
+                    } else if (q + S16_PD < 40) {
                         ring[(q + S16_PD) % S16_RN].h = *(const uint4 *)(W1Hb + (q + S16_PD) * TVR16_FRAG);
                         ring[(q + S16_PD) % S16_RN].l = *(const uint4 *)(W1Lb + (q + S16_PD) * TVR16_FRAG);
                     } else {                           // layer 2's first fragments ride in the ring behind layer 1's last
@@ -434,7 +449,11 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
                         ring[(q + S16_PD) % S16_RN].h = *(const uint4 *)(W2Hb + (q2 * 8) * TVR16_FRAG);
                         ring[(q + S16_PD) % S16_RN].l = *(const uint4 *)(W2Lb + (q2 * 8) * TVR16_FRAG);
                     }
-                    mfma6(ring[q % S16_RN], bA, bB, acc1[rb][0], acc1[rb][1]);
+                    if (S16_DIAG_LDS == 3) {           // every read issued, waited for and written to registers; the MFMAs take two fixed fragments
+                        { const uint4 rh = ring[q % S16_RN].h, rl = ring[q % S16_RN].l; asm volatile("" :: "v"(rh.x), "v"(rh.y), "v"(rh.z), "v"(rh.w), "v"(rl.x), "v"(rl.y), "v"(rl.z), "v"(rl.w)); }
+                        mfma6(dfix[q & 1], bA, bB, acc1[rb][0], acc1[rb][1]);
+                    } else
+                    mfma6(ring[S16_DIAG_LDS == 2 ? (q & 1) : (S16_DIAG_LDS == 1 ? (q & ~1) % S16_RN : q % S16_RN)], bA, bB, acc1[rb][0], acc1[rb][1]);
                 }
                 if (s + 1 < 5) { l1_frag(s + 1, FA, SA, CA, nA); l1_frag(s + 1, FB, SB_, CB, nB); }
                 else { relu_frag(0, 0, frA[0]); relu_frag(0, 1, frB[0]); }              // (acc1[0], acc1[1] are complete after row block 1 of this k-step)
@@ -491,11 +510,21 @@ __global__ __launch_bounds__(S16_THREADS, 2) void shade16_kernel(const SceneDev 
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
                         const int q = 4 * rb + ks, qn = q + S16_PD;
-                        if (qn < 32) {
+                        if (S16_DIAG_LDS == 2 || ((S16_DIAG_LDS == 1 || S16_DIAG_LDS == 5) && (qn & 1))) {
+                        } else if (S16_DIAG_LDS == 4) {
+                            if (qn < 32) {
+                                ring[(40 + qn) % S16_RN].h = *(const uint4 *)(W1Hb + (qn & 1) * TVR16_FRAG);
+                                ring[(40 + qn) % S16_RN].l = *(const uint4 *)(W1Lb + (qn & 1) * TVR16_FRAG);
+                            }
+                        } else if (qn < 32) {
                             ring[(40 + qn) % S16_RN].h = *(const uint4 *)(W2Hb + (8 * (qn & 3) + (qn >> 2)) * TVR16_FRAG);
                             ring[(40 + qn) % S16_RN].l = *(const uint4 *)(W2Lb + (8 * (qn & 3) + (qn >> 2)) * TVR16_FRAG);
                         }
-                        mfma6(ring[(40 + q) % S16_RN], frA[ks], frB[ks], a2A, a2B);
+                        if (S16_DIAG_LDS == 3) {
+                            { const uint4 rh = ring[(40 + q) % S16_RN].h, rl = ring[(40 + q) % S16_RN].l; asm volatile("" :: "v"(rh.x), "v"(rh.y), "v"(rh.z), "v"(rh.w), "v"(rl.x), "v"(rl.y), "v"(rl.z), "v"(rl.w)); }
+                            mfma6(dfix[q & 1], frA[ks], frB[ks], a2A, a2B);
+                        } else
+                        mfma6(ring[S16_DIAG_LDS == 2 ? (q & 1) : ((S16_DIAG_LDS == 1 || S16_DIAG_LDS == 5) ? (40 + (q & ~1)) % S16_RN : (40 + q) % S16_RN)], frA[ks], frB[ks], a2A, a2B);
                         if (rb == 0 && ks + 1 < 4) { relu_frag(ks + 1, 0, frA[ks + 1]); relu_frag(ks + 1, 1, frB[ks + 1]); }
                     }
                     if (rb > 0) l3_block(a2pA, a2pB);
