@@ -79,6 +79,11 @@ def rgb_ssim(img0, img1, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=
 def rgb_ssim_torch(img0: torch.Tensor, img1: torch.Tensor, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03) -> float:
     """`rgb_ssim` on the tensors' device: the same separable 11-tap Gaussian, 'valid' window, float64 — two depthwise conv2d calls per
     blur instead of 30 scipy convolutions per frame (0.4 s per 800x800 frame on the host, the render itself takes 23 ms)."""
+    return float(_rgb_ssim_dev(img0, img1, max_val, filter_size, filter_sigma, k1, k2))
+
+
+def _rgb_ssim_dev(img0, img1, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03) -> torch.Tensor:
+    """The 0-dim result of rgb_ssim_torch, left on the device (no host synchronisation: the evaluation loop fetches it with the frame)."""
     x0 = img0.to(torch.float64).permute(2, 0, 1).unsqueeze(1)          # [3,1,H,W]: channels as a batch
     x1 = img1.to(device=x0.device, dtype=torch.float64).permute(2, 0, 1).unsqueeze(1)
     hw = filter_size // 2
@@ -93,14 +98,15 @@ def rgb_ssim_torch(img0: torch.Tensor, img1: torch.Tensor, max_val, filter_size=
     s01 = blur(x0 * x1) - mu01
     s01 = torch.sign(s01) * torch.minimum(torch.sqrt(s00 * s11), torch.abs(s01))
     c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
-    return float(torch.mean(((2 * mu01 + c1) * (2 * s01 + c2)) / ((mu00 + mu11 + c1) * (s00 + s11 + c2))))
+    return torch.mean(((2 * mu01 + c1) * (2 * s01 + c2)) / ((mu00 + mu11 + c1) * (s00 + s11 + c2)))
 
 
 class _ImageWriter:
     """PNG encoding off the render loop: a few worker threads (zlib releases the GIL); `close()` waits for the files."""
 
-    def __init__(self, workers: int = 4):
+    def __init__(self, workers: int = 0):
         from concurrent.futures import ThreadPoolExecutor
+        workers = workers or max(4, min(12, (os.cpu_count() or 8) // 2))
         self.pool, self.jobs = ThreadPoolExecutor(max_workers=workers), []
 
     def write(self, path, arr):
@@ -110,6 +116,45 @@ class _ImageWriter:
         for j in self.jobs:
             j.result()
         self.pool.shutdown()
+
+
+_PNG_LEVEL = int(os.environ.get("TVR_PNG_LEVEL", "1"))
+_LOOKAHEAD = os.environ.get("TVR_EVAL_LOOKAHEAD", "1") != "0"     # 0: finish every frame on the host before the next is enqueued (the A/B of scripts/eval_loop_timing.py)
+
+
+class _FrameFetch:
+    """Device -> host copies of a finished frame on a SIDE stream into pinned memory, so that the loop can enqueue frame k + 1 before it touches frame k on the host
+    (round 5: a plain `.cpu()` is ordered behind everything queued on the render stream, the next frame included; the reference synchronises per 1024-ray chunk,
+    renderer.py:23-25).  On a CPU device `start` is a plain conversion."""
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda" and torch.cuda.is_available()
+        self.stream = torch.cuda.Stream(device) if self.cuda else None
+
+    def start(self, *tensors):
+        if not self.cuda:
+            return [t.detach().cpu().numpy() for t in tensors], None
+        ready = torch.cuda.Event()
+        ready.record()                                              # behind the frame's kernels (and metrics) on the render stream
+        host = []
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            for t in tensors:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                t.record_stream(self.stream)
+                host.append(h)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return host, done
+
+    @staticmethod
+    def finish(handle):
+        host, done = handle
+        if done is None:
+            return host
+        done.synchronize()
+        return [h.numpy() for h in host]
 
 
 def visualize_depth_numpy(depth, minmax=None):
@@ -126,7 +171,9 @@ def visualize_depth_numpy(depth, minmax=None):
 
 def _imwrite(path, arr):
     from PIL import Image
-    Image.fromarray(arr).save(path)
+    # compress_level 1: the same pixels (PNG is lossless), files ~ 15 % larger, encoding 3 - 4 x faster than Pillow's default 6 — the encoder, not the renderer, sets the pace of
+    # an evaluation loop (scripts/eval_loop_timing.py: 48 ms per 800 x 800 frame with the default level against 20 ms of kernels)
+    Image.fromarray(arr).save(path, compress_level=_PNG_LEVEL)
 
 
 @torch.no_grad()
@@ -142,21 +189,41 @@ def evaluation(test_dataset, tensorf, args, renderer, savePath=None, N_vis=5, pr
     W, H = test_dataset.img_wh
     expname = getattr(args, "expname", "render") if args is not None else "render"
     writer = _ImageWriter() if savePath is not None else None
+    fetch = _FrameFetch(device)
+
+    def finish(idx, handle, n_metrics):
+        arrs = fetch.finish(handle)
+        rgb, depth, metrics = arrs[0], arrs[1], arrs[2:]
+        if n_metrics >= 1:
+            PSNRs.append(-10.0 * np.log(float(metrics[0])) / np.log(10.0))
+        if n_metrics >= 2:
+            ssims.append(float(metrics[1]))
+        img = (rgb * 255).astype('uint8')
+        if savePath is not None:
+            depth_vis, _ = visualize_depth_numpy(depth, near_far)
+            writer.write(f'{savePath}/{expname}_r_{idx}.png', img)
+            writer.write(f'{savePath}/rgbd/{prtx}{idx:03d}.png', np.concatenate((img, depth_vis), axis=1))
+
+    pending = None                                                   # one frame of lookahead: frame k is post-processed on the host while frame k + 1 renders
     for idx, samples in enumerate(test_dataset.all_rays[0::interval]):
         rays = samples.view(-1, samples.shape[-1]).to(device)
         rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=1024, N_samples=N_samples, ndc_ray=ndc_ray, white_bg=white_bg, device=device)
         rgb_dev = rgb_map.clamp(0.0, 1.0).reshape(H, W, 3)
+        metrics = []
         if len(test_dataset.all_rgbs):
             gt = test_dataset.all_rgbs[idxs[idx]].view(H, W, 3).to(rgb_dev.device)
-            loss = torch.mean((rgb_dev - gt) ** 2)
-            PSNRs.append(-10.0 * np.log(loss.item()) / np.log(10.0))
+            metrics.append(torch.mean((rgb_dev - gt) ** 2))
             if compute_extra_metrics:
-                ssims.append(rgb_ssim_torch(rgb_dev, gt, 1))                # utils.py:73-119 on the device
-        img = (rgb_dev.cpu().numpy() * 255).astype('uint8')
-        if savePath is not None:
-            depth_vis, _ = visualize_depth_numpy(depth_map.reshape(H, W).cpu().numpy(), near_far)
-            writer.write(f'{savePath}/{expname}_r_{idx}.png', img)
-            writer.write(f'{savePath}/rgbd/{prtx}{idx:03d}.png', np.concatenate((img, depth_vis), axis=1))
+                metrics.append(_rgb_ssim_dev(rgb_dev, gt, 1))                # utils.py:73-119 on the device
+        handle = fetch.start(rgb_dev, depth_map.reshape(H, W), *metrics)
+        if pending is not None:
+            finish(*pending)
+        pending = (idx, handle, len(metrics))
+        if not _LOOKAHEAD:
+            finish(*pending)
+            pending = None
+    if pending is not None:
+        finish(*pending)
     if writer is not None:
         writer.close()
     if PSNRs and savePath is not None:
@@ -176,16 +243,31 @@ def evaluation_path(test_dataset, tensorf, c2ws, renderer, savePath=None, N_vis=
     dirs = dirs / np.sqrt((dirs * dirs).sum(-1, keepdims=True))
     frames = []
     writer = _ImageWriter() if savePath is not None else None
+    fetch = _FrameFetch(device)
+
+    def finish(idx, handle):
+        rgb, depth = fetch.finish(handle)
+        img = (rgb * 255).astype('uint8')
+        frames.append(img)
+        if savePath is not None:
+            depth_vis, _ = visualize_depth_numpy(depth, test_dataset.near_far)
+            writer.write(f'{savePath}/{prtx}{idx:03d}.png', img)
+            writer.write(f'{savePath}/rgbd/{prtx}{idx:03d}.png', np.concatenate((img, depth_vis), axis=1))
+
+    pending = None
     for idx, c2w in enumerate(c2ws):
         o, d = R.get_rays(dirs, np.asarray(c2w, dtype=np.float32))
         rays = torch.from_numpy(np.ascontiguousarray(np.concatenate([o, d], 1), dtype=np.float32)).to(device)
         rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=8192, N_samples=N_samples, ndc_ray=ndc_ray, white_bg=white_bg, device=device)
-        img = (rgb_map.clamp(0.0, 1.0).reshape(H, W, 3).cpu().numpy() * 255).astype('uint8')
-        frames.append(img)
-        if savePath is not None:
-            depth_vis, _ = visualize_depth_numpy(depth_map.reshape(H, W).cpu().numpy(), test_dataset.near_far)
-            writer.write(f'{savePath}/{prtx}{idx:03d}.png', img)
-            writer.write(f'{savePath}/rgbd/{prtx}{idx:03d}.png', np.concatenate((img, depth_vis), axis=1))
+        handle = fetch.start(rgb_map.clamp(0.0, 1.0).reshape(H, W, 3), depth_map.reshape(H, W))
+        if pending is not None:
+            finish(*pending)
+        pending = (idx, handle)
+        if not _LOOKAHEAD:
+            finish(*pending)
+            pending = None
+    if pending is not None:
+        finish(*pending)
     if writer is not None:
         writer.close()
     return frames

@@ -1,20 +1,37 @@
-"""Per-frame cost of the evaluation loop (renderer.py:29-91 shape: render, PSNR, SSIM, two PNGs per frame) at 800x800 on the synthetic scene."""
-import sys, os, time, tempfile, types
+#!/usr/bin/env python3
+"""GPU box: wall time per frame of `evaluation()` (renderer.py:107-141 equivalent: render a test pose, PSNR / SSIM against its picture, write two PNGs) over the bench scene's
+8 poses at 800 x 800, with and without the one-frame lookahead of evaluation._FrameFetch (TVR_EVAL_LOOKAHEAD=0 / 1, read at import: run once per setting)."""
+import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
 from jittor_myc_nerfs_amd import OctreeRender_trilinear_fast, evaluation
-m, arrs, A = bench.build_model(torch.device("cuda"))
-fr = bench.frames(A)[:4]
-with torch.no_grad():
-    gts = [m.render_rays(f.cuda(), N_samples=512)[0].cpu().reshape(800, 800, 3) for f in fr]
-ds = types.SimpleNamespace(all_rays=torch.stack([f.cpu() for f in fr], 0), all_rgbs=torch.stack(gts, 0), near_far=A["near_far"], img_wh=(800, 800))
-args = types.SimpleNamespace(expname="t")
-for extra in (True, False):
-    with tempfile.TemporaryDirectory() as d:
-        evaluation(ds, m, args, OctreeRender_trilinear_fast, d, N_vis=-1, N_samples=512, white_bg=True, compute_extra_metrics=extra)   # warm
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        ps = evaluation(ds, m, args, OctreeRender_trilinear_fast, d, N_vis=-1, N_samples=512, white_bg=True, compute_extra_metrics=extra)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / len(fr)
-    print(f"evaluation loop, compute_extra_metrics={extra}: {dt * 1e3:.0f} ms / frame (PSNR {sum(ps) / len(ps):.1f} dB)")
+
+
+class DS:
+    pass
+
+
+def main():
+    dev = torch.device("cuda")
+    m, arrs, A = bench.build_model(dev)
+    fr = bench.frames(A)
+    W, H = A["img_wh"]
+    ds = DS()
+    ds.near_far, ds.img_wh = A["near_far"], (W, H)
+    ds.all_rays = torch.stack([f for f in fr] * 2)                  # 16 frames
+    with torch.no_grad():
+        ds.all_rgbs = torch.stack([m.render_rays(f.to(dev), white_bg=True, N_samples=512)[0].cpu().clamp(0, 1) for f in fr] * 2)
+    for extra in (False, True):
+        with tempfile.TemporaryDirectory() as d:
+            evaluation(ds, m, None, OctreeRender_trilinear_fast, savePath=d, N_vis=-1, N_samples=512, white_bg=True, compute_extra_metrics=extra, device="cuda")   # warm
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ps = evaluation(ds, m, None, OctreeRender_trilinear_fast, savePath=d, N_vis=-1, N_samples=512, white_bg=True, compute_extra_metrics=extra, device="cuda")
+            dt = (time.perf_counter() - t0) / len(ps)
+        print(f"lookahead {os.environ.get('TVR_EVAL_LOOKAHEAD', '1')}  ssim {int(extra)}  {dt * 1e3:7.1f} ms per frame of evaluation() (16 frames, PNGs written)   PSNR[0] {ps[0]:.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
