@@ -362,6 +362,22 @@ class TensorBase(torch.nn.Module):
     arith_in_effect = "f32"
     arith_max_diff = None
 
+    def scene_settled(self) -> bool:
+        """True when the next inference call will enqueue nothing but the frame's own kernels: packed images, alpha volume, range-check decision and the requested
+        arithmetic are all current for the parameters as they are now.  A pure host check.  render.FrameStream keeps two frames in flight only while this holds —
+        whatever rewrites the scene's device state (tvr_scene_update, the fp16 copies, the arithmetic gate's probe renders) must not run beside a frame that reads it."""
+        if self._scene is None or getattr(self, "_captured_update", False) or self._alpha_dirty or self._range_proven is None:
+            return False
+        if getattr(self, "_arith_set", None) != self.mlp_arith:
+            return False
+        if tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in self._param_list()) != self._sig:
+            return False
+        if self.mlp_arith != "f32" and self.view_pe <= 2 and self.fea_pe <= 2:
+            if (L.lib().tvr_scene_get_arith(self._scene) != self._ARITH[self.mlp_arith]
+                    and getattr(self, "_arith_refused_sig", None) != (self._sig, self.mlp_arith, float(self.mlp_arith_tol))):
+                return False                                                        # the gate has not measured this mode on these parameters yet
+        return True
+
     def _settle_arith(self, rays, S, white_bg, eps_T):
         """Called by the inference entry points behind _ensure_scene(): bring the requested arithmetic into effect (or not) for the current parameters."""
         if self.mlp_arith == "f32" or self.view_pe > 2 or self.fea_pe > 2:        # (more than two encoding frequencies: three products whatever the mode says, tvr.h)

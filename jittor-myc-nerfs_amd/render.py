@@ -167,6 +167,7 @@ class FrameStream:
         self.out = [None, None]
         self.busy = [False, False]
         self.k = 0
+        self._drain_next = False
 
     def submit(self, rays):
         b = self.k % 2
@@ -175,6 +176,13 @@ class FrameStream:
         n = rays.shape[0]
         if self.out[b] is None or self.out[b][0].shape[0] != n:
             self.out[b] = (torch.empty((n, 3), dtype=torch.float32, device=self.dev), torch.empty((n,), dtype=torch.float32, device=self.dev))
+        # Two frames share the scene's packed images.  A call that will re-pack them (parameters changed), convert the fp16 copies, settle the range check or run the
+        # arithmetic gate's probe renders must not overlap a frame that reads them: it waits for everything in flight, and so does the frame after it.
+        settled = bool(getattr(self.model, "scene_settled", lambda: False)())
+        if not settled or self._drain_next:
+            cur.wait_stream(self.streams[0])
+            cur.wait_stream(self.streams[1])
+        self._drain_next = not settled
         st = self.streams[b]
         st.wait_stream(cur)                        # the rays are ready, and the caller's stream has been handed this slot's previous frame (two calls ago)
         with torch.cuda.stream(st):

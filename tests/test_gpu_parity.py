@@ -520,3 +520,48 @@ def test_frame_stream_two_in_flight(config1_golden):
     assert len(got) == len(want)
     for (a, b), (c, d) in zip(got, want):
         assert torch.equal(a, c) and torch.equal(b, d)
+
+
+def test_frame_stream_serialises_around_a_scene_update(config1_golden):
+    """Parameters written between two submits: the re-pack (tvr_scene_update on the new frame's stream) must not run beside the frame still in flight on the other stream,
+    which reads the same packed images — FrameStream drains before such a frame and before the one after it (field.scene_settled).  Every frame equals the serial render
+    made with the parameters as they were at ITS submit.  (The drain is by construction: with it disabled the overlap could not be provoked on this pool —
+    scripts/debug/frame_stream_race.py, bench frame included: the small pack kernels did not get onto the CUs beside the other frame's persistent grids.  That is
+    scheduling luck, not a guarantee.)"""
+    from jittor_myc_nerfs_amd import FrameStream, synthetic
+    B = synthetic.SCENE_B
+    arrs = synthetic.make_scene_arrays(B["gridSize"], B["aabb"])
+    m = make_model(arrs, dict(synthetic.HYPER, near_far=B["near_far"], step_ratio=B["step_ratio"]))
+    rays = torch.tensor(config1_golden["rays"], device="cuda")
+    rays = torch.cat([rays] * 8)                                                # long enough for a frame to be in flight when the next is submitted
+    w0 = m.app_plane[0].detach().clone()
+    S = B["N_samples"]
+
+    def schedule(render):
+        out = []
+        for k in range(6):
+            if k in (2, 3, 5):
+                with torch.no_grad():
+                    m.app_plane[0].mul_(1.0 + 0.05 * k)
+            out.append(render(k))
+        return out
+
+    want = schedule(lambda k: tuple(t.clone() for t in m.render_rays(rays, white_bg=True, N_samples=S)))
+    assert not torch.equal(want[1][0], want[2][0]) and not torch.equal(want[2][0], want[3][0]) and not torch.equal(want[4][0], want[5][0])     # the updates are visible
+    with torch.no_grad():
+        m.app_plane[0].copy_(w0)
+    fs = FrameStream(m, white_bg=True, N_samples=S)
+    got = []
+
+    def submit(k):
+        o = fs.submit(rays)
+        if o is not None:
+            got.append((o[0].clone(), o[1].clone()))
+
+    schedule(submit)
+    o = fs.flush()
+    got.append((o[0].clone(), o[1].clone()))
+    assert len(got) == 6
+    for k, ((a, b), (c, d)) in enumerate(zip(got, want)):
+        assert torch.equal(a, c) and torch.equal(b, d), f"frame {k}"
+    assert m.scene_settled()
