@@ -78,6 +78,18 @@ def main():
         for v in names:
             rgb, depth = models[v].render_rays(fr[0], white_bg=True, N_samples=512)
             print(f"{os.environ.get('WP_TAG', ''):10s}{v:10s} sha256(rgb) {hashlib.sha256(rgb.cpu().numpy().tobytes()).hexdigest()[:16]}", flush=True)
+    loop_s = float(os.environ.get("WP_LOOP_S", "0"))               # scripts/power_vs_data.sh: keep one variant rendering for this many seconds while rocm-smi samples the board
+    if loop_s > 0:
+        import time
+        m = models[names[0]]
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < loop_s:
+            for k in range(8):
+                m.render_rays(fr[k % len(fr)], white_bg=True, N_samples=512)
+            torch.cuda.synchronize()
+            n += 8
+        print(f"{names[0]:10s} loop {n} frames  {(time.perf_counter() - t0) / n * 1e3:6.2f} ms per frame", flush=True)
+        return
     for rnd in (1, 2):
         for v in names:
             march, shade = timeit(models[v], fr)
