@@ -112,6 +112,10 @@ const char *tvr_last_error(void);
 size_t tvr_scene_packed_bytes(const tvr_scene_desc *desc);
 int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed_bytes, tvr_scene **out);
 int tvr_scene_update(tvr_scene *scene, const tvr_scene_params *params, void *stream);
+/* CONCURRENCY: a scene's packed images are shared by every call that names the scene.  Any number of tvr_render(_z) calls may be in flight on different streams at once as
+ * long as each has its own scratch and output buffers (they only READ the scene; render.py::FrameStream keeps two frames in flight this way).  Whatever WRITES the scene's
+ * device state — tvr_scene_update, tvr_scene_set_alpha, tvr_scene_validate_arith, the first TVR_ARITH_F16 render after an update (it converts the fp16 copies) — must be
+ * ordered by the caller against every call still reading it (stream waits or events); the library inserts no cross-stream synchronisation. */
 /* tvr_scene_update captured into a hipGraph (a whole training step, tvr_train_forward's host does that): every REPLAY re-packs the fp32 images on the device and runs no
  * host code, so whatever the host derived from "the parameters as last packed" is stale afterwards — (a) a range proof that switched the fp16-range check off
  * (tvr_scene_set_range_check(scene, 0)): switch it back on, or prove again, before rendering; (b) the fp16 copies of the appearance factors that TVR_ARITH_F16 gathers
