@@ -382,6 +382,9 @@ struct GridCfg {
     uint32_t hashed;                      // bit l: level l uses the spatial hash
 };
 
+#ifndef TVR_NGP_PAIR              // 1: the x neighbours of a corner pair as one 16-byte load where the table layout allows (encode_level_pair).  Round 5: bit-identical,
+#define TVR_NGP_PAIR 0            // and SLOWER — ngp_render_kernel 15.0 - 15.7 ms against 13.0 (profiles/r05_ngp_pair_loads.txt): off
+#endif
 // grid_index (HashEncode.h:75-93).  With the reference's fixed 2^19 table a level is either dense (res^3 fits: index = x + y*res +
 // z*res^2, which can exceed the table by less than its size because corner coordinates reach res) or hashed (table size a power of
 // two).  to_grid() checks that every level is one of the two, so the generic stride loop and the modulo reduce to this:
@@ -414,6 +417,64 @@ __device__ __forceinline__ float2 encode_level(const float2 *__restrict__ tab, b
         w *= (idx & 4) ? fz : 1 - fz;
         r0 = __builtin_fmaf(w, v[idx].x, r0);
         r1 = __builtin_fmaf(w, v[idx].y, r1);
+    }
+    return make_float2(r0, r1);
+}
+
+// encode_level for the fused kernels, with the two x neighbours of a (y, z) corner pair fetched as ONE 16-byte block wherever the table layout has them side by side:
+// in a dense level always (entries x and x + 1), in a hashed level whenever cx is even (x + 1 = x | 1: the two hashes differ in bit 0 only — the aligned pair idx & ~1).
+// The vector-memory path charges a random gather per lane and line; the 8-byte load of the second neighbour stays in the instruction stream (no branch: the loads of
+// INFLIGHT levels must stay in flight together) but lanes that already hold it aim it past the end of the buffer, where the hardware returns zero without a fetch.
+// `rs`: the whole table as a raw buffer; `o0`: the level's first entry.  Same entries, same blend order as encode_level: bit-identical features.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float2 encode_level_pair(__amdgpu_buffer_rsrc_t rs, uint32_t o0, bool hashed, uint32_t size, float scale, float px, float py, float pz)
+{
+    const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+    const float x = __builtin_fmaf(px, scale, 0.5f), y = __builtin_fmaf(py, scale, 0.5f), z = __builtin_fmaf(pz, scale, 0.5f);
+    const float fx0 = floorf(x), fy0 = floorf(y), fz0 = floorf(z);
+    const uint32_t cx = (uint32_t)(int)fx0, cy = (uint32_t)(int)fy0, cz = (uint32_t)(int)fz0;
+    const float fx = x - fx0, fy = y - fy0, fz = z - fz0;
+    u32x4 q[4];
+    u32x2 sv[4];
+    bool lo0[4], lo1[4], in1[4];
+    const uint32_t hm = hashed ? 0xFFFFFFFFu : 0u;              // the level's kind as a bit mask: both index forms are computed and blended (v_bfi), no branch on a lane-half-dependent flag
+    const uint32_t res2 = res * res;
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+        const uint32_t yy = cy + (yz & 1), zz = cz + (yz >> 1);
+        const uint32_t hyz = (yy * 19349663u) ^ (zz * 83492791u), dyz = yy * res + zz * res2;
+        const uint32_t d0 = cx + dyz, d1 = d0 + 1u;
+        const uint32_t e0 = min(d0 - (d0 >= size ? size : 0u), size - 1), e1 = min(d1 - (d1 >= size ? size : 0u), size - 1);      // grid_entry's dense form
+        const uint32_t h0 = (cx ^ hyz) & (size - 1), h1 = ((cx + 1u) ^ hyz) & (size - 1);                                          // ... and its hashed form
+        const uint32_t i0 = (h0 & hm) | (e0 & ~hm), i1 = (h1 & hm) | (e1 & ~hm);
+        const uint32_t bd = i0 + 1u < size ? i0 : i0 - 1u;
+        const uint32_t base = ((i0 & ~1u) & hm) | (bd & ~hm);                                 // a 16-byte block inside the level that holds entry i0 (level sizes are even)
+        lo0[yz] = i0 == base;
+        lo1[yz] = i1 == base;
+        in1[yz] = (i1 - base) < 2u;
+        q[yz] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((o0 + base) << 3), 0, 0);
+        sv[yz] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(in1[yz] ? 0xFFFFFFF8u : ((o0 + i1) << 3)), 0, 0);
+    }
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+        const int yz = idx >> 1;
+        const u32x4 Q = q[yz];
+        float vx, vy;
+        if (idx & 1) {
+            vx = __uint_as_float(in1[yz] ? (lo1[yz] ? Q.x : Q.z) : sv[yz].x);
+            vy = __uint_as_float(in1[yz] ? (lo1[yz] ? Q.y : Q.w) : sv[yz].y);
+        } else {
+            vx = __uint_as_float(lo0[yz] ? Q.x : Q.z);
+            vy = __uint_as_float(lo0[yz] ? Q.y : Q.w);
+        }
+        float w = 1.0f;
+        w *= (idx & 1) ? fx : 1 - fx;
+        w *= (idx & 2) ? fy : 1 - fy;
+        w *= (idx & 4) ? fz : 1 - fz;
+        r0 = __builtin_fmaf(w, vx, r0);
+        r1 = __builtin_fmaf(w, vy, r1);
     }
     return make_float2(r0, r1);
 }
@@ -582,6 +643,9 @@ __device__ __forceinline__ float4 field_tile(const GridCfg &g, const float2 *__r
                                              float dx, float dy, float dz)
 {
     // ---- GATHER phase: lane half hh takes the hash levels of parity hh (8 levels x 8 corners)
+#if TVR_NGP_PAIR
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, (int)(g.offsets[TVR_NGP_LEVELS] << 3), 0x00020000);
+#endif
     float f0[8], f1[8], shv[8];
     {
         float sh[16];
@@ -595,7 +659,11 @@ __device__ __forceinline__ float4 field_tile(const GridCfg &g, const float2 *__r
         const uint32_t o1 = hh ? g.offsets[2 * p + 2] : g.offsets[2 * p + 1];
         const float sc = hh ? g.scale[2 * p + 1] : g.scale[2 * p];
         const bool hashed = (g.hashed >> (2 * p + hh)) & 1u;
+#if TVR_NGP_PAIR
+        const float2 r = encode_level_pair(rs, o0, hashed, o1 - o0, sc, px, py, pz);
+#else
         const float2 r = encode_level(tab + o0, hashed, o1 - o0, sc, px, py, pz);
+#endif
         f0[p] = r.x;
         f1[p] = r.y;
         if ((p + 1) % TVR_NGP_INFLIGHT == 0) __builtin_amdgcn_sched_barrier(0);      // bounds the loads in flight (registers)
