@@ -71,6 +71,9 @@
 #else
 #define TVR_STAMP(x)
 #endif
+#ifndef TVR_TICKET
+#define TVR_TICKET 4      // tiles per ticket of the render path's dynamic tile hand-out (0: static stride)
+#endif
 #ifndef TVR_PHASE_FREE
 #define TVR_PHASE_FREE 0  // experiment (round 5): 1 = the render kernel fetches the NEXT tile's k-step-0 taps (12 global loads per lane) between layer 1 and
 #endif                    // layer 2 of the current tile, i.e. INSIDE the matrix phase — the build that settles whether the phase rule protects anything (scripts/phase_rule_test.sh)
@@ -549,8 +552,20 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     const unsigned lblk = xcd_remap(blockIdx.x, gridDim.x);       // (measured neutral against the identity: 15.4 ms both ways)
     float4 qe_next = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned qray_next = 0;
+    // Round 5: the render path's tiles are handed out in tickets of TVR_TICKET consecutive tiles (the first one static, later ones by an atomicAdd on word 16 of the
+    // scratch header, zeroed per call with the queue counter beside it) — the XCDs do not run at one speed under these kernels and equal static shares leave the fast ones
+    // idle at the end (tvr_shade16.hip, profiles/r05_shade_tail.txt).  Only tvr_render(_z) launches the queue-to-queue mode, so the header is there; GEN keeps the static
+    // stride (its layer 1 has workgroup barriers: every wave makes the same passes).  Which wave shades an entry does not matter to the entry.
+    constexpr bool TICKETS = TVR_TICKET > 0 && SRC == SH_SRC_QUEUE && DST == SH_DST_QUEUE && !GEN;
+    constexpr int TKN = TICKETS ? TVR_TICKET : 1;
+    unsigned *const tk = TICKETS ? const_cast<unsigned *>(a.counter) + 16 : nullptr;
+    const long long tick0 = (long long)gridDim.x * SH_WAVES * TKN;
+    const long long tile_first = ((long long)lblk * SH_WAVES + wave) * TKN;
+    unsigned tk_pending = 0;
+    int tk_sub = 0;
+    if constexpr (TICKETS) { if (lane == 0) tk_pending = atomicAdd(tk, (unsigned)TKN); }
     if (SRC == SH_SRC_QUEUE && n_total > 0) {
-        const long long e0 = ((long long)lblk * SH_WAVES + wave) * SH_TILE + e;
+        const long long e0 = tile_first * SH_TILE + e;
         const long long le = e0 < n_total ? e0 : n_total - 1;
         qe_next = a.q_pos[le];
         qray_next = a.q_ray[le];
@@ -569,7 +584,17 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
 #endif
     // GEN: every wave of the workgroup makes the same number of passes (its layer 1 has workgroup barriers); a pass beyond the last tile works on dead lanes
     const long long tile_end = GEN ? ((n_tiles - (long long)lblk * SH_WAVES + tile_stride - 1) / tile_stride) * tile_stride + (long long)lblk * SH_WAVES + wave : n_tiles;
-    for (long long tile = (long long)lblk * SH_WAVES + wave; tile < tile_end; tile += tile_stride) {
+    long long tile_next = 0;
+    for (long long tile = tile_first; tile < tile_end; tile = tile_next) {                // (the advance sits in the for statement: DST_FEAT leaves the body by `continue`)
+        tile_next = tile + tile_stride;
+        if constexpr (TICKETS) {
+            if (++tk_sub < TKN) tile_next = tile + 1;
+            else {
+                tile_next = tick0 + (long long)__builtin_amdgcn_readfirstlane(tk_pending);
+                tk_sub = 0;
+                if (lane == 0 && tile_next < n_tiles) tk_pending = atomicAdd(tk, (unsigned)TKN);
+            }
+        }
         const long long ent = tile * SH_TILE + e;
         const bool live = ent < n_total;
         float F[16];                               // base values: row c = acc_row(r, h) of the feature tile, column = entry
@@ -590,7 +615,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
         float4 qe = qe_next;
         unsigned qray = qray_next;
         if (SRC == SH_SRC_QUEUE) {
-            const long long en = ent + tile_stride * SH_TILE;
+            const long long en = tile_next * SH_TILE + e;
             const long long le = en < n_total ? en : n_total - 1;
             qe_next = a.q_pos[le];
             qray_next = a.q_ray[le];

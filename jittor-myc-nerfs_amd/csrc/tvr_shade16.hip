@@ -89,6 +89,9 @@ __device__ __forceinline__ void sincos_pe16(float x, float &s, float &c)
 #ifndef S16_PIN
 #define S16_PIN 1         // 1: one empty-asm pin per interpolated float4 (keeps hipcc from spreading a tap set's consumers over the phase); 0: none
 #endif
+#ifndef S16_TICKET
+#define S16_TICKET 4      // tiles per ticket of the dynamic tile hand-out (0: the static stride of rounds 1 - 4)
+#endif
 #ifndef S16_GDEPTH
 #define S16_GDEPTH 1      // units of the gather in flight ahead of the one being interpolated (24 registers each)
 #endif
@@ -194,13 +197,39 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
 
     float4 qe_next = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned qray_next = 0;
+#if S16_TICKET
+    // Tiles are handed out in tickets of S16_TICKET consecutive tiles: the first ticket of a wave is its static share, every later one an atomicAdd on word 16 of the
+    // scratch header (zeroed per call by zero_header with the queue counter it sits beside).  The chip's eight XCDs do not run at one speed under this kernel
+    // (scripts/march_timeline.py, profiles/r05_shade_tail.txt: their workgroups finished 10.83 ... 11.71 ms after the launch with equal static shares); tickets let a
+    // fast XCD take more tiles.  The atomic for ticket k + 2 is issued when ticket k + 1 is taken up, one ticket's work before its value is read: no wait on it.
+    // Which wave shades an entry does not matter to the entry (q_out[ent] depends on the entry alone): pixels are unchanged, bit for bit.
+    unsigned *const tk = const_cast<unsigned *>(a.counter) + 16;
+    const long long tick0 = (long long)gridDim.x * S16_WAVES * S16_TICKET;                     // tiles covered by the static first tickets
+    long long tile_first = ((long long)lblk * S16_WAVES + wave) * S16_TICKET;
+    unsigned tk_pending = 0;                                                                     // lane 0: the returned value of the ticket atomic in flight
+    if (lane == 0) tk_pending = atomicAdd(tk, (unsigned)S16_TICKET);
+    int tk_sub = 0;
+#else
+    long long tile_first = (long long)lblk * S16_WAVES + wave;
+#endif
     if (n_total > 0) {
-        const long long e0 = ((long long)lblk * S16_WAVES + wave) * S16_TILE + c + (up ? 16 : 0);
+        const long long e0 = tile_first * S16_TILE + c + (up ? 16 : 0);
         const long long le = e0 < n_total ? e0 : n_total - 1;
         qe_next = a.q_pos[le];
         qray_next = a.q_ray[le];
     }
-    for (long long tile = (long long)lblk * S16_WAVES + wave; tile < n_tiles; tile += tile_stride) {
+    long long tile_next = 0;
+    for (long long tile = tile_first; tile < n_tiles; tile = tile_next) {
+#if S16_TICKET
+        if (++tk_sub < S16_TICKET) tile_next = tile + 1;
+        else {
+            tile_next = tick0 + (long long)__builtin_amdgcn_readfirstlane(tk_pending);
+            tk_sub = 0;
+            if (lane == 0 && tile_next < n_tiles) tk_pending = atomicAdd(tk, (unsigned)S16_TICKET);
+        }
+#else
+        tile_next = tile + tile_stride;
+#endif
         const long long ent = tile * S16_TILE + c + (up ? 16 : 0);        // the entry this lane stores: A in groups 0, 1, B in groups 2, 3
         const bool live = ent < n_total;
 #if S16_TIMING
@@ -211,7 +240,7 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
         const float4 qe = qe_next;
         const unsigned qray = qray_next;
         {
-            const long long en = ent + tile_stride * S16_TILE;
+            const long long en = tile_next * S16_TILE + c + (up ? 16 : 0);
             const long long le = en < n_total ? en : n_total - 1;
             qe_next = a.q_pos[le];
             qray_next = a.q_ray[le];
@@ -600,6 +629,10 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
 #if S16_TIMING
     if (a.stats && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&a.stats[8 + i], tsum[i]);     // -, gather, basis, L1 (+PE), L2, -, wait for the matrix token, hand-over + layer 3 + store
+#endif
+#ifdef TVR_MARCH_TIMELINE                               // the timeline build (scripts/march_timeline.py): stats[32 + 8 b + 6 / 7] = this kernel's group b start / last wave end, 100 MHz ticks
+    if (a.stats && lane == 0) atomicMax((unsigned long long *)&a.stats[32 + 8 * blockIdx.x + 7], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (a.stats && tid == 0) a.stats[32 + 8 * blockIdx.x + 6] = ref0;
 #endif
     if (a.stats && tid == 0) {
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_SHADE_CLK], __builtin_amdgcn_s_memtime() - clk0);

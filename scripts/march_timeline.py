@@ -40,6 +40,14 @@ for n in sizes:
     print(f"  LDS filled    : min {us(t[:, 1]).min():7.1f}  median {np.median(us(t[:, 1])):7.1f}  max {us(t[:, 1]).max():7.1f} us   (fill itself: median {np.median(t[:, 1] - t[:, 0]) / 100:.1f} us)")
     print(f"  first wave end: min {us(t[:, 2]).min():7.1f}  median {np.median(us(t[:, 2])):7.1f}  max {us(t[:, 2]).max():7.1f} us")
     print(f"  last wave end : min {us(t[:, 3]).min():7.1f}  median {np.median(us(t[:, 3])):7.1f}  max {us(t[:, 3]).max():7.1f} us")
+    if t[:, 7].max() > 0:                                 # the shade kernel of the same tvr_render (csrc/tvr_shade16.hip under the same build flag)
+        s0 = t[:, 6].min()
+        su = lambda x: (x - s0) / 100.0
+        e = su(t[:, 7])
+        print(f"  shade16: group start min {su(t[:, 6]).min():7.1f} median {np.median(su(t[:, 6])):7.1f} max {su(t[:, 6]).max():7.1f} us; last wave end min {e.min():8.1f} p10 {np.percentile(e, 10):8.1f} "
+              f"median {np.median(e):8.1f} p90 {np.percentile(e, 90):8.1f} max {e.max():8.1f} us -> idle CU-time in the tail {100 * (e.max() - e.mean()) / e.max():.2f} % of the kernel")
+        x8 = [e[(np.arange(len(e)) % 8) == k].mean() for k in range(8)]
+        print("           mean end per XCD (blockIdx % 8): " + " ".join(f"{v:8.1f}" for v in x8))
     ch, ry = t[:, 4], t[:, 5]
     busy = (t[:, 3] - t[:, 1]) / 100.0
     print(f"  chunks / group: min {ch.min():.0f} median {np.median(ch):.0f} max {ch.max():.0f}; rays / group median {np.median(ry):.0f}; us per chunk and group (busy / chunks): median {np.median(busy / np.maximum(ch, 1)):.3f}")
