@@ -424,7 +424,9 @@ typedef struct tvr_mlpnet_params {   /* fp32 device pointers, row-major [out,in]
 size_t tvr_mlpnet_packed_bytes(const tvr_mlpnet_desc *desc);
 /* builds the MFMA fragment image (synchronises the stream once: packing is an explicit, rare call) */
 int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *params, void *packed, size_t packed_bytes, void *stream);
-/* pts [n,4] (inverted-sphere points, depth2pts_outside), viewdirs [ceil(n / samples_per_ray), 3] -> rgb [n,3] (sigmoid applied), sigma [n] (abs applied) */
+/* pts [n,4] (inverted-sphere points, depth2pts_outside), viewdirs [ceil(n / samples_per_ray), 3] -> rgb [n,3] (sigmoid applied), sigma [n] (abs applied).
+ * `packed` is const for the network's image; its last 256 bytes are the kernel's per-launch ticket word (dynamic hand-out of the sample tiles, round 5), zeroed
+ * and advanced by every forward: ONE forward (inference or training) at a time per packed network — launches on different streams would share the word. */
 int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
                        void *sigma, void *stream);
 /* Training (`optimizer.backward(loss)` through MLPNet, train.py:258): the same kernel also saves what the backward needs, all fp32,

@@ -282,6 +282,9 @@ __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restr
                        1.0f / (1.0f + __expf(-(eo[0][2] + lbias[582]))), fabsf(hd[0][0] + lbias[576]));
 }
 
+#ifndef TVR_BG_TICKETS
+#define TVR_BG_TICKETS 1          // 1: dynamic hand-out of the super-tiles (0: static stride over the workgroups)
+#endif
 #ifndef TVR_BG_NT
 #define TVR_BG_NT 1               // 32-sample tiles a wave carries through each LDS stage (their stage-A activations wait in registers)
 #endif
@@ -289,9 +292,10 @@ __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restr
 template <int AR>
 __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, const uint4 *__restrict__ image, const float *__restrict__ bias,
                                                                  const float *__restrict__ pts, const float *__restrict__ viewdirs, long long M,
-                                                                 float *__restrict__ rgb, float *__restrict__ sigma, const BgTrain T)
+                                                                 float *__restrict__ rgb, float *__restrict__ sigma, const BgTrain T, unsigned *__restrict__ tk)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ long long s_next;
     uint4 *lds4 = reinterpret_cast<uint4 *>(smem);
     float *lbias = reinterpret_cast<float *>(smem + BG_MAX_BLOCKS * 2048);
     for (int e = threadIdx.x; e < BG_BIAS_FLOATS; e += BG_WAVES * 64) lbias[e] = bias[e];
@@ -301,7 +305,12 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
     const uint4 *imgA = image, *imgB = image + (size_t)P.blocksA * 128;
     const int la = min(P.split, P.D);
 
-    for (long long super = blockIdx.x; super < n_super; super += gridDim.x) {
+    // Round 5: super-tiles are handed out dynamically (the first one static, later ones by an atomicAdd on `tk`, a word the launcher zeroes) — the XCDs do not run at one
+    // speed under an MFMA-heavy kernel and equal static shares leave the fast ones idle at the end (profiles/r05_shade_tail.txt).  The atomic for the tile after next is
+    // issued a whole super-tile before its value is read.  Which workgroup evaluates a sample does not matter to the sample.
+    unsigned tk_pending = 0;
+    if (tk && threadIdx.x == 0) tk_pending = atomicAdd(tk, 1u);
+    for (long long super = blockIdx.x; super < n_super;) {
         int hh = h, lane_off = lane;
         asm volatile("" : "+v"(hh), "+v"(lane_off));                // opaque per tile: keeps per-lane selects / LDS reads from being hoisted
         const uint4 *w4 = lds4 + lane_off;
@@ -337,8 +346,20 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
                 rgb[3 * s + 2] = r.z;
             }
         }
+        if (tk) {
+            if (threadIdx.x == 0) {
+                const long long nx = (long long)gridDim.x + (long long)tk_pending;
+                s_next = nx;
+                if (nx < n_super) tk_pending = atomicAdd(tk, 1u);
+            }
+            __syncthreads();
+            super = s_next;                        // (the next iteration's first barrier orders this read before thread 0's next write)
+        } else {
+            super += gridDim.x;
+        }
     }
 }
+__global__ void bg_zero_ticket_kernel(unsigned *tk) { *tk = 0u; }
 
 
 // ------------------------------------------------------------------------------------------------ background geometry and compositing
@@ -487,6 +508,11 @@ static int plan(const tvr_mlpnet_desc *d, BgLayout &L)
     return TVR_OK;
 }
 
+static size_t bg_ticket_offset(const BgLayout &L)
+{
+    return ((size_t)L.total_blocks * 2048 + BG_BIAS_FLOATS * 4 + (size_t)L.total_blocks * sizeof(PackBlock) + 255) & ~(size_t)255;
+}
+
 template <int AR>
 static int mlpnet_launch(const BgLayout &L, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma, const BgTrain &T, void *stream)
 {
@@ -498,9 +524,13 @@ static int mlpnet_launch(const BgLayout &L, const void *packed, const void *pts,
     const long long per_super = 32 * BG_WAVES * TVR_BG_NT, n_super = (n_samples + per_super - 1) / per_super;
     const unsigned blocks = (unsigned)(n_super < 256 ? n_super : 256);                     // one workgroup per CU (the LDS image)
     const char *base = static_cast<const char *>(packed);
+    // the ticket word: 256 bytes behind the pack kernel's block table (tvr_mlpnet_packed_bytes counts them; the table itself stays — tvr_mlpnet_repack reads it on the
+    // device).  ONE forward at a time per packed network: launches on different streams would share the word (include/tvr.h)
+    unsigned *tk = TVR_BG_TICKETS ? reinterpret_cast<unsigned *>(const_cast<char *>(base) + bg_ticket_offset(L)) : nullptr;
+    if (tk) hipLaunchKernelGGL(bg_zero_ticket_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), tk);
     hipLaunchKernelGGL(bg_mlp_kernel<AR>, dim3(blocks), dim3(BG_WAVES * 64), BG_LDS_BYTES, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
                        reinterpret_cast<const float *>(base + (size_t)L.total_blocks * 2048), static_cast<const float *>(pts), static_cast<const float *>(viewdirs),
-                       (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma), T);
+                       (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma), T, tk);
     HIP_TRY(hipGetLastError());
     return TVR_OK;
 }
@@ -512,7 +542,7 @@ size_t tvr_mlpnet_packed_bytes(const tvr_mlpnet_desc *desc)
     BgLayout L;
     if (plan(desc, L) != TVR_OK) return 0;
     // fragment image, biases, and the block table the pack kernel reads
-    return (size_t)L.total_blocks * 2048 + BG_BIAS_FLOATS * 4 + (size_t)L.total_blocks * sizeof(PackBlock);
+    return bg_ticket_offset(L) + 256;                               // ... and the forward kernel's ticket word (round 5)
 }
 
 int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *p, void *packed, size_t packed_bytes, void *stream)
