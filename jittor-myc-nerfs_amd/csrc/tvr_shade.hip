@@ -74,6 +74,9 @@
 #ifndef TVR_TICKET
 #define TVR_TICKET 4      // tiles per ticket of the render path's dynamic tile hand-out (0: static stride)
 #endif
+#ifndef TVR_TICKET_MIN
+#define TVR_TICKET_MIN 256  // tiles per wave from which the tickets are used
+#endif
 #ifndef TVR_PHASE_FREE
 #define TVR_PHASE_FREE 0  // experiment (round 5): 1 = the render kernel fetches the NEXT tile's k-step-0 taps (12 global loads per lane) between layer 1 and
 #endif                    // layer 2 of the current tile, i.e. INSIDE the matrix phase — the build that settles whether the phase rule protects anything (scripts/phase_rule_test.sh)
@@ -556,14 +559,18 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     // scratch header, zeroed per call with the queue counter beside it) — the XCDs do not run at one speed under these kernels and equal static shares leave the fast ones
     // idle at the end (tvr_shade16.hip, profiles/r05_shade_tail.txt).  Only tvr_render(_z) launches the queue-to-queue mode, so the header is there; GEN keeps the static
     // stride (its layer 1 has workgroup barriers: every wave makes the same passes).  Which wave shades an entry does not matter to the entry.
+    // Launches with fewer than TVR_TICKET_MIN tiles per wave keep the static stride: a ticket is a 4-tile quantum (tvr_shade16.hip).
     constexpr bool TICKETS = TVR_TICKET > 0 && SRC == SH_SRC_QUEUE && DST == SH_DST_QUEUE && !GEN;
     constexpr int TKN = TICKETS ? TVR_TICKET : 1;
+    const bool dyn = TICKETS && n_tiles >= (long long)gridDim.x * SH_WAVES * TVR_TICKET_MIN;
     unsigned *const tk = TICKETS ? const_cast<unsigned *>(a.counter) + 16 : nullptr;
     const long long tick0 = (long long)gridDim.x * SH_WAVES * TKN;
-    const long long tile_first = ((long long)lblk * SH_WAVES + wave) * TKN;
+    const long long tile_first = ((long long)lblk * SH_WAVES + wave) * (dyn ? TKN : 1);
     unsigned tk_pending = 0;
     int tk_sub = 0;
-    if constexpr (TICKETS) { if (lane == 0) tk_pending = atomicAdd(tk, (unsigned)TKN); }
+    if constexpr (TICKETS) { if (dyn && lane == 0) tk_pending = atomicAdd(tk, (unsigned)TKN); }
+    const int tk_len = dyn ? TKN : 0x7fffffff;
+    const long long tk_step = dyn ? 1 : tile_stride;
     if (SRC == SH_SRC_QUEUE && n_total > 0) {
         const long long e0 = tile_first * SH_TILE + e;
         const long long le = e0 < n_total ? e0 : n_total - 1;
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
     for (long long tile = tile_first; tile < tile_end; tile = tile_next) {                // (the advance sits in the for statement: DST_FEAT leaves the body by `continue`)
         tile_next = tile + tile_stride;
         if constexpr (TICKETS) {
-            if (++tk_sub < TKN) tile_next = tile + 1;
+            if (++tk_sub < tk_len) tile_next = tile + tk_step;            // (static mode: one endless "ticket" whose tiles lie a grid stride apart)
             else {
                 tile_next = tick0 + (long long)__builtin_amdgcn_readfirstlane(tk_pending);
                 tk_sub = 0;

@@ -92,6 +92,9 @@ __device__ __forceinline__ void sincos_pe16(float x, float &s, float &c)
 #ifndef S16_TICKET
 #define S16_TICKET 4      // tiles per ticket of the dynamic tile hand-out (0: the static stride of rounds 1 - 4)
 #endif
+#ifndef S16_TICKET_MIN
+#define S16_TICKET_MIN 256  // tiles per wave from which the tickets are used
+#endif
 #ifndef S16_GDEPTH
 #define S16_GDEPTH 1      // units of the gather in flight ahead of the one being interpolated (24 registers each)
 #endif
@@ -203,12 +206,18 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
     // (scripts/march_timeline.py, profiles/r05_shade_tail.txt: their workgroups finished 10.83 ... 11.71 ms after the launch with equal static shares); tickets let a
     // fast XCD take more tiles.  The atomic for ticket k + 2 is issued when ticket k + 1 is taken up, one ticket's work before its value is read: no wait on it.
     // Which wave shades an entry does not matter to the entry (q_out[ent] depends on the entry alone): pixels are unchanged, bit for bit.
+    // Only for launches with at least S16_TICKET_MIN tiles per wave: a ticket is a 4-tile quantum, and a call with a handful of tiles per wave (a 4096-ray chunk: 5) is
+    // better off with the static stride's one-tile quantum (157 such calls: 32.1 ms with tickets for everyone against 27.2).
     unsigned *const tk = const_cast<unsigned *>(a.counter) + 16;
+    const bool dyn = n_tiles >= (long long)gridDim.x * S16_WAVES * S16_TICKET_MIN;               // (uniform over the grid)
+    const int tkn = dyn ? S16_TICKET : 1;
     const long long tick0 = (long long)gridDim.x * S16_WAVES * S16_TICKET;                     // tiles covered by the static first tickets
-    long long tile_first = ((long long)lblk * S16_WAVES + wave) * S16_TICKET;
+    long long tile_first = ((long long)lblk * S16_WAVES + wave) * tkn;
     unsigned tk_pending = 0;                                                                     // lane 0: the returned value of the ticket atomic in flight
-    if (lane == 0) tk_pending = atomicAdd(tk, (unsigned)S16_TICKET);
+    if (dyn && lane == 0) tk_pending = atomicAdd(tk, (unsigned)S16_TICKET);
     int tk_sub = 0;
+    const int tk_len = dyn ? S16_TICKET : 0x7fffffff;
+    const long long tk_step = dyn ? 1 : tile_stride;
 #else
     long long tile_first = (long long)lblk * S16_WAVES + wave;
 #endif
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
     long long tile_next = 0;
     for (long long tile = tile_first; tile < n_tiles; tile = tile_next) {
 #if S16_TICKET
-        if (++tk_sub < S16_TICKET) tile_next = tile + 1;
+        if (++tk_sub < tk_len) tile_next = tile + tk_step;               // (static mode: one endless "ticket" whose tiles lie a grid stride apart)
         else {
             tile_next = tick0 + (long long)__builtin_amdgcn_readfirstlane(tk_pending);
             tk_sub = 0;

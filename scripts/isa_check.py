@@ -201,8 +201,13 @@ def check_kernel(name, ins_list, skip_execz):
                     outstanding = []
             i += 1
             continue
-        if mn == "s_branch":                       # unconditional: continue at the target when it lies ahead (an if/else join)
+        if mn == "s_branch":                       # unconditional: continue at the target when it lies ahead (an if/else join) ...
             j = labels.get(ins.split()[-1])
+            prev = ins_list[i - 1].split() if i > 0 else [""]
+            if prev[0].startswith("s_cbranch"):    # ... the second arm of a two-way branch (`s_cbranch L1; s_branch EXIT`): the walk follows the FIRST arm when it lies ahead
+                j1 = labels.get(prev[-1])          # (what follows the pair in the text is some other block, reached by a jump)
+                if j1 is not None and j1 > i:
+                    j = j1
             if j is not None and j > i:
                 i = j
                 continue
