@@ -89,6 +89,12 @@ def test_modes_at_full_size_against_the_default_mode_and_the_oracle():
     perm = torch.randperm(640000, generator=torch.Generator().manual_seed(7)).cuda()
     rgb_p, _ = m.render_rays(rays[perm].contiguous(), white_bg=True, N_samples=A["N_samples"])
     assert torch.equal(rgb_p, pics["f16act"][0][perm])
+    # ... and so does the equality of a merged call (tiles handed out by tickets, csrc/tvr_shade.hip TVR_TICKET) with 65536-ray calls (static stride: too few tiles per wave)
+    for mode in ("f16act", "f16"):
+        m.mlp_arith = mode
+        parts = [m.render_rays(rays[c0:c0 + 65536], white_bg=True, N_samples=A["N_samples"])[0] for c0 in range(0, rays.shape[0], 65536)]
+        assert m.arith_in_effect == mode
+        assert torch.equal(torch.cat(parts), pics[mode][0])
 
 
 def test_mlp_render_in_every_mode_and_what_the_modes_leave_alone(tiny_dump, tiny_arrays, hyper_tiny):
