@@ -642,6 +642,9 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
 #ifdef TVR_MARCH_TIMELINE                               // the timeline build (scripts/march_timeline.py): stats[32 + 8 b + 6 / 7] = this kernel's group b start / last wave end, 100 MHz ticks
     if (a.stats && lane == 0) atomicMax((unsigned long long *)&a.stats[32 + 8 * blockIdx.x + 7], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     if (a.stats && tid == 0) a.stats[32 + 8 * blockIdx.x + 6] = ref0;
+#ifdef S16_XCDCLK                                       // ... and, over the march's chunk / ray counts, wave 0's own shader-clock and reference ticks: the clock of each workgroup's CU
+    if (a.stats && tid == 0) { a.stats[32 + 8 * blockIdx.x + 4] = __builtin_amdgcn_s_memtime() - clk0; a.stats[32 + 8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime() - ref0; }
+#endif
 #endif
     if (a.stats && tid == 0) {
         atomicAdd((unsigned long long *)&a.stats[TVR_STAT_SHADE_CLK], __builtin_amdgcn_s_memtime() - clk0);

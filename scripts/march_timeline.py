@@ -48,6 +48,9 @@ for n in sizes:
               f"median {np.median(e):8.1f} p90 {np.percentile(e, 90):8.1f} max {e.max():8.1f} us -> idle CU-time in the tail {100 * (e.max() - e.mean()) / e.max():.2f} % of the kernel")
         x8 = [e[(np.arange(len(e)) % 8) == k].mean() for k in range(8)]
         print("           mean end per XCD (blockIdx % 8): " + " ".join(f"{v:8.1f}" for v in x8))
+        if os.environ.get("TL_XCDCLK"):                   # a -DS16_XCDCLK build: slots 4 / 5 hold wave 0's shader-clock / 100 MHz ticks over the shade kernel
+            ghz = 0.1 * t[:, 4] / np.maximum(t[:, 5], 1)
+            print("           shader clock per XCD, GHz      : " + " ".join(f"{ghz[(np.arange(len(ghz)) % 8) == k].mean():8.3f}" for k in range(8)))
     ch, ry = t[:, 4], t[:, 5]
     busy = (t[:, 3] - t[:, 1]) / 100.0
     print(f"  chunks / group: min {ch.min():.0f} median {np.median(ch):.0f} max {ch.max():.0f}; rays / group median {np.median(ry):.0f}; us per chunk and group (busy / chunks): median {np.median(busy / np.maximum(ch, 1)):.3f}")
