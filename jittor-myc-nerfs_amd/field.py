@@ -362,6 +362,8 @@ class TensorBase(torch.nn.Module):
     arith_in_effect = "f32"
     arith_max_diff = None
 
+    render_rays_is_the_frame = True           # render_rays(rays) IS forward(rays, is_train=False) for this class and REFTensoRF (render.FrameStream relies on it)
+
     def scene_settled(self) -> bool:
         """True when the next inference call will enqueue nothing but the frame's own kernels: packed images, alpha volume, range-check decision and the requested
         arithmetic are all current for the parameters as they are now.  A pure host check.  render.FrameStream keeps two frames in flight only while this holds —

@@ -160,6 +160,9 @@ class FrameStream:
     is not shortened."""
 
     def __init__(self, model, white_bg: bool = True, N_samples: int = -1, eps_T=None):
+        if not getattr(model, "render_rays_is_the_frame", False):
+            raise TypeError(f"FrameStream renders through model.render_rays, which is the whole frame for TensorVMSplit / REFTensoRF scenes only; "
+                            f"{type(model).__name__} composes its picture in forward() (NerfPlusPlus: the background network) — render such frames one after the other")
         self.model, self.white_bg, self.S, self.eps_T = model, white_bg, N_samples, eps_T
         self.dev = model.device
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(2)]

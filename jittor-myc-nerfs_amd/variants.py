@@ -230,6 +230,8 @@ class NerfPlusPlus(TensorVMSplit):
     HUGE_NUMBER, TINY_NUMBER, BG_SAMPLES = 1e10, 1e-6, 512                                    # :4-5, :284
     max_render_chunk = 65536      # rays per merged inference call (renderer): the background holds [rays, 512, ~20] fp32 temporaries (2.7 GB)
 
+    render_rays_is_the_frame = False          # forward() adds the background; render_rays alone is the foreground field (render.FrameStream refuses this model)
+
     def scene_settled(self) -> bool:
         """Never: the background network's packed image carries ONE per-launch ticket word and one set of [rays, 512, *] temporaries, so two frames of this model
         must not be in flight at once (render.FrameStream then renders them one after the other)."""

@@ -378,3 +378,16 @@ def test_mlpnet_abi_tail_and_errors(tiny_npp_arrays, hyper_tiny):
     assert L.lib().tvr_mlpnet_forward(C.byref(desc), None, None, None, 5, None, None, None) == -1
     assert L.lib().tvr_npp_bg_points(None, None, 3, None, 512, None, 6.0, None, None, None) == -1
     assert L.lib().tvr_npp_bg_composite(None, None, None, 0, 512, None, None) == 0
+
+
+def test_frame_stream_refuses_a_model_whose_frame_is_not_render_rays():
+    """render.FrameStream drives model.render_rays on two streams; NerfPlusPlus's picture is composed in forward() (foreground + background network, one ticket word and
+    one set of background temporaries per model): it must be refused, not rendered without its background."""
+    from jittor_myc_nerfs_amd import FrameStream, NerfPlusPlus, TensorVMSplit, REFTensoRF
+    assert TensorVMSplit.render_rays_is_the_frame and REFTensoRF.render_rays_is_the_frame and not NerfPlusPlus.render_rays_is_the_frame
+
+    class _M:                                   # what FrameStream looks at before it touches the device
+        render_rays_is_the_frame = False
+        device = torch.device("cuda")
+    with pytest.raises(TypeError, match="render_rays"):
+        FrameStream(_M())
