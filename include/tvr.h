@@ -227,7 +227,9 @@ int tvr_alpha_sample(const float *alpha_volume_dev, const int32_t agrid_xyz[3], 
  * counter u32[4] = {queue length, the march's tile counter, FAULT flag, training-workspace OVERFLOW flag (tvr_train_forward)}: the flag is non-zero if a wave of the march kernel gave up waiting for its
  * tile number (1: overtaken in the 64-slot ring, 2: spin limit; tvr_march.hip) — tvr_render then writes NaN to every pixel and depth of the call,
  * hosts that consume the queue read it with the queue length; ray_off/ray_cnt u32[n]; acc f32[n]; q_pos float4[cap] {xyz_norm, weight}; q_out float4[cap] {rgb, weight};
- * q_ray u32[cap]; q_j u32[cap]; cap = n_rays * n_samples.  Each ray's entries are contiguous and in sample order. */
+ * q_ray u32[cap]; q_j u32[cap]; cap = n_rays * n_samples.  Each ray's entries are contiguous and in sample order.
+ * The `counter` region is a 256-byte header the library zeroes at the start of every call; beyond the four words above it holds the kernels' own work counters (word 16: the
+ * shade kernels' tile tickets, word 32: the march's ray counter) — hosts must not write it between a call's launches. */
 typedef struct { size_t counter, ray_off, ray_cnt, acc, q_pos, q_out, q_ray, q_j, total; } tvr_scratch_layout;
 int tvr_scratch_describe(int64_t n_rays, int32_t n_samples, tvr_scratch_layout *out);
 
