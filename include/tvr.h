@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 130
+#define TVR_VERSION 140   /* 140 (round 6): tvr_mlpnet_forward / _train_forward take packed_bytes and a caller-owned work buffer (tvr_mlpnet_work_bytes);
+                           * tvr_mlpnet_packed_bytes no longer counts a ticket word; no entry point writes through a const pointer */
 
 typedef enum {
     TVR_OK = 0,
@@ -141,8 +142,8 @@ int tvr_scene_set_range_check(tvr_scene *scene, int32_t on);
  *                    fp16 (nearest even, 2^-12 relative); the basis product and REFTensoRF's heads keep three (their outputs feed sin / cos, where an error is amplified): 0.70 of the matrix work;
  *   TVR_ARITH_F16    one product — activations as fp16 (nearest even), weights as the HI image of the default mode, i.e. truncated toward zero to fp16 (a one-sided
  *                    2^-11 per weight instead of an unbiased 2^-12: the measured errors below include it): 1/3 of the matrix work; and the gather of tvr_render(_z) reads fp16 COPIES of the appearance
- *                    planes / lines (kept in the packed buffer, converted from the fp32 images with round-to-nearest-even by tvr_scene_update when this mode is set, else
- *                    by the first render in the mode): half the bytes through the L1 return path, interpolation still in fp32.
+ *                    planes / lines (kept in the packed buffer, converted from the fp32 images with round-to-nearest-even by the first TVR_ARITH_F16 render behind an
+ *                    update — tvr_scene_update itself converts nothing): half the bytes through the L1 return path, interpolation still in fp32.
  *                    (A hipGraph that captured a render bakes in the mode and whether a conversion was due: capture again after switching modes.)
  * fp16 rounding is RELATIVE: the reduced modes' absolute error grows with the scale of the features and hidden activations (|feature| <= 23: picture within 6.4e-5 / 3.5e-4
  * of the fp32 path in F16ACT / F16; |feature| ~ 230: 6.5e-4 / 1.5e-3) — a scene with unusually large features keeps the default.
@@ -164,13 +165,17 @@ int tvr_scene_set_range_check(tvr_scene *scene, int32_t on);
  *   tvr_scene_get_arith                the mode IN EFFECT (what the next render computes in); tvr_scene_get_arith_requested the request.
  * So tvr_render(_z) / tvr_mlp_render(_ref) cannot leave the parity bar silently through a reduced mode: either the mode was measured on this scene's own rays, or it does not run.
  * (tvr_mlpnet_desc.arith, NerfPlusPlus's background network, is a field of a stateless descriptor: the library cannot gate it — the Python host measures it the same way,
- *  variants.py::NerfPlusPlus._settle_bg_arith, and a C host must do likewise.) */
+ *  variants.py::NerfPlusPlus._settle_bg_arith, and a C host must do likewise.)
+ *   A probe that shades fewer than min(TVR_ARITH_MIN_PROBE_SAMPLES, 2 n_rays) appearance samples (rays that miss the box, empty space: both pictures are background, the difference is 0)
+ *   has measured nothing: it neither validates nor refuses — the mode stays out of effect, *probe_app_samples_out (optional) tells, and the caller probes again with
+ *   rays that hit the scene (round 6; before, such a probe opened the gate for free). */
 enum { TVR_ARITH_F32 = 0, TVR_ARITH_F16ACT = 1, TVR_ARITH_F16 = 2 };
+#define TVR_ARITH_MIN_PROBE_SAMPLES 2048
 int tvr_scene_set_arith(tvr_scene *scene, int32_t mode);
 int tvr_scene_get_arith(const tvr_scene *scene);
 int tvr_scene_get_arith_requested(const tvr_scene *scene);
 int tvr_scene_validate_arith(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, int32_t white_bg, float eps_T, float tol,
-                             void *scratch, size_t scratch_bytes, float *work, size_t work_bytes, float *max_diff_out, void *stream);
+                             void *scratch, size_t scratch_bytes, float *work, size_t work_bytes, float *max_diff_out, int64_t *probe_app_samples_out, void *stream);
 int tvr_scene_destroy(tvr_scene *scene);
 
 /* TensorBase.execute over a ray batch (tensorBase.py:476-536, ndc_ray=False; variant 1: REFTensoRF.execute,
@@ -424,13 +429,20 @@ typedef struct tvr_mlpnet_params {   /* fp32 device pointers, row-major [out,in]
 } tvr_mlpnet_params;
 
 size_t tvr_mlpnet_packed_bytes(const tvr_mlpnet_desc *desc);
+/* Byte offsets of the regions of a packed network: MFMA fragment blocks, the biases, and the block table tvr_mlpnet_pack writes ONCE and tvr_mlpnet_repack walks on the
+ * device every training step (pointers to the parameter tensors + the slice each fragment block takes).  Nothing but pack / repack writes any of it. */
+typedef struct { size_t fragments, biases, block_table, block_table_bytes, total; } tvr_mlpnet_layout;
+int tvr_mlpnet_describe(const tvr_mlpnet_desc *desc, tvr_mlpnet_layout *out);
 /* builds the MFMA fragment image (synchronises the stream once: packing is an explicit, rare call) */
 int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *params, void *packed, size_t packed_bytes, void *stream);
 /* pts [n,4] (inverted-sphere points, depth2pts_outside), viewdirs [ceil(n / samples_per_ray), 3] -> rgb [n,3] (sigmoid applied), sigma [n] (abs applied).
- * `packed` is const for the network's image; its last 256 bytes are the kernel's per-launch ticket word (dynamic hand-out of the sample tiles, round 5), zeroed
- * and advanced by every forward: ONE forward (inference or training) at a time per packed network — launches on different streams would share the word. */
-int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
-                       void *sigma, void *stream);
+ * `packed` (packed_bytes >= tvr_mlpnet_packed_bytes(), checked) is READ-ONLY to every forward: any number of forwards may share it on different streams.
+ * `work`: tvr_mlpnet_work_bytes() of caller-owned device memory, 16-byte aligned — the kernel's per-launch ticket word (dynamic hand-out of the sample tiles), zeroed and
+ * advanced by the call: one launch per work buffer at a time.  (Round 5 kept that word in 256 extra bytes of `packed` and wrote it through the const pointer without
+ * knowing the buffer's size: version 130.  DESIGN.md 11 has the abort that preceded it.) */
+size_t tvr_mlpnet_work_bytes(void);
+int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, size_t packed_bytes, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
+                       void *sigma, void *work, size_t work_bytes, void *stream);
 /* Training (`optimizer.backward(loss)` through MLPNet, train.py:258): the same kernel also saves what the backward needs, all fp32,
  * caller-owned, 16-B aligned, with byte counts that are checked before the launch:
  *   act[l] [n,128] = relu output of base layer l; rgb_hidden [n,64] = relu output of rgb_layers[0]; sigma_pre [n] = the sigma head before `abs`;
@@ -454,8 +466,8 @@ typedef struct tvr_mlpnet_saved {
     void *rgb_hidden_mask;
     size_t mask_bytes;               /* of EACH mask buffer: >= n x 16 */
 } tvr_mlpnet_saved;
-int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
-                             void *sigma, const tvr_mlpnet_saved *saved, void *stream);
+int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, size_t packed_bytes, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
+                             void *sigma, const tvr_mlpnet_saved *saved, void *work, size_t work_bytes, void *stream);
 int tvr_mlpnet_repack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *params, void *packed, size_t packed_bytes, void *stream);
 /* The input gradient of a Linear over a tall batch with the ReLU mask in front of it fused in (fp32-input MFMAs, W staged in LDS):
  *   dX[m, k] = (sum_{n < N} dY[m, n] W[n, k]) * (mask[m, k] > 0 ? 1 : 0)     (mask NULL: no mask)

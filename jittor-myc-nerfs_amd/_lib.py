@@ -65,6 +65,10 @@ class MlpnetSaved(C.Structure):          # tvr_mlpnet_saved
                 ("mask_bytes", C.c_size_t)]
 
 
+class MlpnetLayout(C.Structure):         # tvr_mlpnet_layout
+    _fields_ = [(n, C.c_size_t) for n in ("fragments", "biases", "block_table", "block_table_bytes", "total")]
+
+
 class NgpMarchCfg(C.Structure):          # tvr_ngp_march_cfg (include/tvr_ngp.h)
     _fields_ = [("aabb_lo", C.c_float * 3), ("aabb_hi", C.c_float * 3), ("near_distance", C.c_float), ("cone_angle", C.c_float),
                 ("const_dt", C.c_int32), ("rng_state", C.c_uint64), ("rng_inc", C.c_uint64), ("slab_rays", C.c_uint32)]
@@ -94,7 +98,7 @@ SYMBOLS = {
     "tvr_scene_get_arith": (C.c_int, [C.c_void_p]),
     "tvr_scene_get_arith_requested": (C.c_int, [C.c_void_p]),
     "tvr_scene_validate_arith": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                           C.POINTER(C.c_float), C.c_void_p]),
+                                           C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_void_p]),
     "tvr_scene_destroy": (C.c_int, [C.c_void_p]),
     "tvr_render_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "tvr_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
@@ -153,9 +157,12 @@ SYMBOLS = {
     "tvr_profile_destroy": (C.c_int, [C.c_void_p]),
     "tvr_mlpnet_packed_bytes": (C.c_size_t, [C.POINTER(MlpnetDesc)]),
     "tvr_mlpnet_pack": (C.c_int, [C.POINTER(MlpnetDesc), C.POINTER(MlpnetParams), C.c_void_p, C.c_size_t, C.c_void_p]),
-    "tvr_mlpnet_forward": (C.c_int, [C.POINTER(MlpnetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tvr_mlpnet_train_forward": (C.c_int, [C.POINTER(MlpnetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(MlpnetSaved),
-                                           C.c_void_p]),
+    "tvr_mlpnet_work_bytes": (C.c_size_t, []),
+    "tvr_mlpnet_describe": (C.c_int, [C.POINTER(MlpnetDesc), C.POINTER(MlpnetLayout)]),
+    "tvr_mlpnet_forward": (C.c_int, [C.POINTER(MlpnetDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
+    "tvr_mlpnet_train_forward": (C.c_int, [C.POINTER(MlpnetDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                           C.POINTER(MlpnetSaved), C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_mlpnet_repack": (C.c_int, [C.POINTER(MlpnetDesc), C.POINTER(MlpnetParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_linear_dx": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.c_int32, C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -184,6 +191,7 @@ SYMBOLS = {
     "tvr_ngp_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float * 3), C.c_void_p, C.c_void_p]),
 }
 
+ARITH_MIN_PROBE_SAMPLES = 2048          # include/tvr.h TVR_ARITH_MIN_PROBE_SAMPLES
 STAT_SAMPLES_EVAL, STAT_SAMPLES_BBOX, STAT_APP, STAT_RAYS_TERMINATED, STAT_COUNT = 0, 1, 2, 3, 8
 
 
@@ -207,6 +215,53 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+# ---- caller-owned device buffers (include/tvr.h: "ALL device memory is caller-owned ... sizes come from the *_bytes() queries") ----------------------------------
+# Every scratch / work / packed / output buffer this host hands to the library is allocated here.  Normally that is a plain torch allocation of exactly the size the
+# library's query returned.  With GUARD_BYTES > 0 (tests/test_gpu_canaries.py) each allocation carries that many 0xA5 bytes BEHIND its last byte, and check_guards()
+# tells whether any launch wrote past the size it was given — the class of bug behind round 5's abort (a kernel-owned word placed where another
+# kernel's table lived) and round 2's (an output matrix narrower than the kernel's rows).
+GUARD_BYTES = 0
+_guarded = []          # (base tensor, payload bytes, what)
+
+
+def dev_bytes(n: int, device, zero: bool = False, what: str = ""):
+    """uint8 device tensor of exactly `n` bytes, 256-byte aligned; guarded when GUARD_BYTES is set."""
+    import torch
+    n = int(n)
+    if GUARD_BYTES <= 0:
+        return (torch.zeros if zero else torch.empty)(n, dtype=torch.uint8, device=device)
+    base = torch.full((n + GUARD_BYTES,), 0xA5, dtype=torch.uint8, device=device)
+    if zero:
+        base[:n].zero_()
+    _guarded.append((base, n, what))
+    return base[:n]
+
+
+def dev_empty(shape, dtype, device, what: str = ""):
+    """torch.empty(shape, dtype) on the device through dev_bytes (outputs whose byte count the library checks)."""
+    import torch
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    if GUARD_BYTES <= 0:
+        return torch.empty(shape, dtype=dtype, device=device)
+    numel = 1
+    for x in shape:
+        numel *= x
+    return dev_bytes(numel * torch.empty((), dtype=dtype).element_size(), device, what=what).view(dtype).view(shape)
+
+
+def check_guards(clear: bool = False):
+    """[(what, payload bytes, first damaged offset behind the payload)] for every guarded buffer whose guard bytes are no longer 0xA5."""
+    bad = []
+    for base, n, what in _guarded:
+        g = base[n:]
+        hit = (g != 0xA5).nonzero()
+        if hit.numel():
+            bad.append((what, n, int(hit[0])))
+    if clear:
+        _guarded.clear()
+    return bad
 
 
 def nbytes(t) -> int:

@@ -89,8 +89,8 @@ _ONES = {}
 
 
 def _gemm_tn_call(a, lda, Ka, b, ldb, Kb, M, a_off=0, b_off=0):
-    out = torch.empty((Ka, Kb), dtype=torch.float32, device=a.device)
-    scratch = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb, M), dtype=torch.uint8, device=a.device)
+    out = L.dev_empty((Ka, Kb), torch.float32, a.device, "tvr_gemm_tn C")
+    scratch = L.dev_bytes(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb, M), a.device, what="tvr_gemm_tn scratch")
     L.check(L.lib().tvr_gemm_tn(a.data_ptr() + 4 * a_off, lda, Ka, b.data_ptr() + 4 * b_off, ldb, Kb, M, out.data_ptr(), scratch.data_ptr(), scratch.numel(),
                                 _stream_ptr(a.device)), "tvr_gemm_tn")
     return out
@@ -98,9 +98,9 @@ def _gemm_tn_call(a, lda, Ka, b, ldb, Kb, M, a_off=0, b_off=0):
 
 def _gemm_tn_bias_call(a, lda, Ka, b, ldb, Kb, M, a_off=0, b_off=0):
     """(a^T b [Ka,Kb], colsum(a) [Ka]) from ONE pass over a (tvr_gemm_tn_bias: the bias gradient rides along as a virtual ones column)."""
-    out = torch.empty((Ka, Kb), dtype=torch.float32, device=a.device)
-    cs = torch.empty(Ka, dtype=torch.float32, device=a.device)
-    scratch = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M), dtype=torch.uint8, device=a.device)
+    out = L.dev_empty((Ka, Kb), torch.float32, a.device, "tvr_gemm_tn_bias C")
+    cs = L.dev_empty(Ka, torch.float32, a.device, "tvr_gemm_tn_bias colsum")
+    scratch = L.dev_bytes(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M), a.device, what="tvr_gemm_tn_bias scratch")
     L.check(L.lib().tvr_gemm_tn_bias(a.data_ptr() + 4 * a_off, lda, Ka, b.data_ptr() + 4 * b_off, ldb, Kb, M, out.data_ptr(), cs.data_ptr(), scratch.data_ptr(),
                                      scratch.numel(), _stream_ptr(a.device)), "tvr_gemm_tn_bias")
     return out, cs
@@ -140,8 +140,8 @@ def _colsum(gy: torch.Tensor) -> torch.Tensor:
 
 def _colsum_call(a, lda, K, M, a_off=0):
     """out[k] = sum_m a[m, a_off + k] through tvr_colsum (fixed order)."""
-    out = torch.empty(K, dtype=torch.float32, device=a.device)
-    scratch = torch.empty(L.lib().tvr_colsum_scratch_bytes(), dtype=torch.uint8, device=a.device)
+    out = L.dev_empty(K, torch.float32, a.device, "tvr_colsum out")
+    scratch = L.dev_bytes(L.lib().tvr_colsum_scratch_bytes(), a.device, what="tvr_colsum scratch")
     L.check(L.lib().tvr_colsum(a.data_ptr() + 4 * a_off, lda, K, M, out.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream_ptr(a.device)), "tvr_colsum")
     return out
 
@@ -157,9 +157,9 @@ def _linear_dx(dY, ldy, N, W, ldw, n_valid, K, mask, ldm, dX, ldx, M, w_off=0, s
 
 def _gemm_tn_scaled_call(a, lda, Ka, b, ldb, Kb, M, scale, bias=True, a_off=0):
     """(a^T b, colsum(a) or None) on the fp16-split MFMAs with a * scale (tvr_gemm_tn_scaled)."""
-    out = torch.empty((Ka, Kb), dtype=torch.float32, device=a.device)
-    cs = torch.empty(Ka, dtype=torch.float32, device=a.device) if bias else None
-    scratch = torch.empty(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M), dtype=torch.uint8, device=a.device)
+    out = L.dev_empty((Ka, Kb), torch.float32, a.device, "tvr_gemm_tn_scaled C")
+    cs = L.dev_empty(Ka, torch.float32, a.device, "tvr_gemm_tn_scaled colsum") if bias else None
+    scratch = L.dev_bytes(L.lib().tvr_gemm_tn_scratch_bytes(Ka, Kb + 1, M), a.device, what="tvr_gemm_tn_scaled scratch")
     L.check(L.lib().tvr_gemm_tn_scaled(a.data_ptr() + 4 * a_off, lda, Ka, b.data_ptr(), ldb, Kb, M, out.data_ptr(), cs.data_ptr() if bias else None, scale.data_ptr(),
                                        scratch.data_ptr(), scratch.numel(), _stream_ptr(a.device)), "tvr_gemm_tn_scaled")
     return out, cs
@@ -189,7 +189,7 @@ class _BgNetFn(torch.autograd.Function):
         st["W_view"].copy_(W0[:, 256:])
         owner._bg_train_pack(desc, st)
         input_ch = 4 + 8 * desc.pos_freqs
-        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        f = lambda *shape: L.dev_empty(shape, torch.float32, dev, "tvr_mlpnet_train_forward saved / output")
         acts = [f(M, 128) for _ in range(D)]
         Hrgb, sig_pre, Epos, Eview = f(M, 64), f(M), f(M, input_ch), f(M, 16)
         rgb, sigma = f(n, N, 3), f(n, N)
@@ -201,14 +201,15 @@ class _BgNetFn(torch.autograd.Function):
         sv.sigma_pre, sv.sigma_pre_bytes = sig_pre.data_ptr(), M * 4
         sv.embed_pos, sv.embed_pos_bytes = Epos.data_ptr(), M * input_ch * 4
         sv.embed_view, sv.embed_view_bytes = Eview.data_ptr(), M * 16 * 4
-        masks = [torch.empty((M, 2), dtype=torch.int64, device=dev) for _ in range(D + 1)]       # relu masks as bits: 16 B per sample and layer for the backward
+        masks = [L.dev_empty((M, 2), torch.int64, dev, "tvr_mlpnet_train_forward mask bits") for _ in range(D + 1)]       # relu masks as bits: 16 B per sample and layer for the backward
         for l in range(D):
             sv.act_mask[l] = masks[l].data_ptr()
         sv.rgb_hidden_mask, sv.mask_bytes = masks[D].data_ptr(), M * 16
         p4 = pts.detach().to(torch.float32).contiguous()
         vd = viewdirs.detach().to(torch.float32).contiguous()
-        L.check(L.lib().tvr_mlpnet_train_forward(C.byref(desc), st["image"].data_ptr(), p4.data_ptr(), vd.data_ptr(), M, rgb.data_ptr(), sigma.data_ptr(),
-                                                 C.byref(sv), _stream_ptr(dev)), "tvr_mlpnet_train_forward")
+        wk = owner._bg_work()
+        L.check(L.lib().tvr_mlpnet_train_forward(C.byref(desc), st["image"].data_ptr(), st["image"].numel(), p4.data_ptr(), vd.data_ptr(), M, rgb.data_ptr(),
+                                                 sigma.data_ptr(), C.byref(sv), wk.data_ptr(), wk.numel(), _stream_ptr(dev)), "tvr_mlpnet_train_forward")
         ctx.save_for_backward(rgb, sig_pre, Hrgb, Epos, Eview, W0b, *acts, *masks, *P)
         ctx.meta = (D, M, input_ch, owner._bg_layer_inputs(desc), st, owner.bg_grad_scale_target, owner._get_sat_flag())
         return rgb, sigma
@@ -354,7 +355,7 @@ class _MarchFn(torch.autograd.Function):
         n = rays.shape[0]
         lay = L.ScratchLayout()
         L.check(lib.tvr_scratch_describe(n, S, C.byref(lay)), "tvr_scratch_describe")
-        scratch = torch.empty(lay.total, dtype=torch.uint8, device=model.device)      # owned by this call: backward needs it intact
+        scratch = L.dev_bytes(lay.total, model.device, what="tvr_march_forward scratch")      # owned by this call: backward needs it intact
         depth = torch.empty(n, dtype=torch.float32, device=model.device)
         lam = torch.ones(n, dtype=torch.float32, device=model.device)
         if z_vals is None:

@@ -518,11 +518,12 @@ __global__ __launch_bounds__(256) void maxdiff_kernel(const float *__restrict__ 
 }
 
 int tvr_scene_validate_arith(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, float eps_T, float tol, void *scratch, size_t scratch_bytes,
-                             float *work, size_t work_bytes, float *max_diff_out, void *stream_)
+                             float *work, size_t work_bytes, float *max_diff_out, int64_t *probe_app_samples_out, void *stream_)
 {
     if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "tvr_scene_validate_arith: scene is NULL or tvr_scene_update has not run");
     if (!max_diff_out) return fail(TVR_ERR_INVALID, "tvr_scene_validate_arith: max_diff_out is NULL");
     *max_diff_out = 0.0f;
+    if (probe_app_samples_out) *probe_app_samples_out = 0;
     if (s->arith_req == TVR_ARITH_F32) return TVR_OK;                                    // nothing to validate
     if (s->dev.gen) {                                   // more than two encoding frequencies: the lockstep kernels compute with three products whatever the mode says
         tvr_set_error(TVR_OK, "tvr_scene_validate_arith: scenes with more than two encoding frequencies compute in TVR_ARITH_F32 whatever the mode says");
@@ -546,12 +547,24 @@ int tvr_scene_validate_arith(tvr_scene *s, const float *rays, int64_t n_rays, in
     HIP_TRY(launch_zero_f32((float *)mx, 4, stream));                                   // (float4 granules: the 256 B behind the eight arrays are for this)
     hipLaunchKernelGGL(maxdiff_kernel, dim3(256), dim3(256), 0, stream, rgb0, rgb1, (long long)n_rays * 3, mx);
     HIP_TRY(hipGetLastError());
-    unsigned bits = 0;
+    unsigned bits = 0, shaded = 0;
     HIP_TRY(hipMemcpyAsync(&bits, mx, sizeof(bits), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&shaded, scratch, sizeof(shaded), hipMemcpyDeviceToHost, stream));   // word 0 of the scratch header: the probe's appearance-sample count
     HIP_TRY(hipStreamSynchronize(stream));
     float d;
     memcpy(&d, &bits, sizeof(d));
     *max_diff_out = d;
+    if (probe_app_samples_out) *probe_app_samples_out = (int64_t)shaded;
+    // A probe that shaded (almost) nothing measured nothing: rays that miss the box or cross empty space give two background pictures, d = 0.  Such a
+    // probe neither validates nor refuses — the mode stays un-measured and the caller probes again with rays that hit something.
+    const int64_t need = 2 * n_rays < TVR_ARITH_MIN_PROBE_SAMPLES ? 2 * n_rays : TVR_ARITH_MIN_PROBE_SAMPLES;      // (a probe of a few dozen rays: two samples per ray)
+    if ((int64_t)shaded < need) {
+        s->arith_valid = 0;
+        tvr_set_error(TVR_OK, "tvr_scene_validate_arith: mode %d NOT MEASURED — the %lld probe rays shaded %u appearance samples, fewer than the %lld a measurement needs; "
+                              "the scene computes in TVR_ARITH_F32 until a probe that hits the scene validates the mode", s->arith_req, (long long)n_rays, shaded,
+                      (long long)need);
+        return TVR_OK;
+    }
     if (d <= tol) {
         s->arith_valid = s->arith_req;
         s->dev.arith = s->arith_req;

@@ -508,13 +508,17 @@ static int plan(const tvr_mlpnet_desc *d, BgLayout &L)
     return TVR_OK;
 }
 
-static size_t bg_ticket_offset(const BgLayout &L)
+// The packed network: fragment image, biases, and the block table the pack kernel reads (tvr_mlpnet_repack walks it on the device every training step).
+// Nothing in it is written by a forward: the forward kernel's ticket word lives in the caller's `work` buffer (round 6; in round 5 it sat in 256 extra bytes
+// behind the table, written through the `const` image — and a working-tree form that placed it ON the table ended in a device abort).
+static size_t bg_packed_bytes(const BgLayout &L)
 {
     return ((size_t)L.total_blocks * 2048 + BG_BIAS_FLOATS * 4 + (size_t)L.total_blocks * sizeof(PackBlock) + 255) & ~(size_t)255;
 }
 
 template <int AR>
-static int mlpnet_launch(const BgLayout &L, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma, const BgTrain &T, void *stream)
+static int mlpnet_launch(const BgLayout &L, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma, const BgTrain &T, void *work,
+                         void *stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -524,9 +528,9 @@ static int mlpnet_launch(const BgLayout &L, const void *packed, const void *pts,
     const long long per_super = 32 * BG_WAVES * TVR_BG_NT, n_super = (n_samples + per_super - 1) / per_super;
     const unsigned blocks = (unsigned)(n_super < 256 ? n_super : 256);                     // one workgroup per CU (the LDS image)
     const char *base = static_cast<const char *>(packed);
-    // the ticket word: 256 bytes behind the pack kernel's block table (tvr_mlpnet_packed_bytes counts them; the table itself stays — tvr_mlpnet_repack reads it on the
-    // device).  ONE forward at a time per packed network: launches on different streams would share the word (include/tvr.h)
-    unsigned *tk = TVR_BG_TICKETS ? reinterpret_cast<unsigned *>(const_cast<char *>(base) + bg_ticket_offset(L)) : nullptr;
+    // the ticket word: word 0 of the caller's `work` buffer (tvr_mlpnet_work_bytes), zeroed here and advanced by the kernel.  One launch per work buffer at a time;
+    // launches on different streams take different work buffers and may share the (read-only) packed network.
+    unsigned *tk = TVR_BG_TICKETS ? static_cast<unsigned *>(work) : nullptr;
     if (tk) hipLaunchKernelGGL(bg_zero_ticket_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), tk);
     hipLaunchKernelGGL(bg_mlp_kernel<AR>, dim3(blocks), dim3(BG_WAVES * 64), BG_LDS_BYTES, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
                        reinterpret_cast<const float *>(base + (size_t)L.total_blocks * 2048), static_cast<const float *>(pts), static_cast<const float *>(viewdirs),
@@ -541,8 +545,22 @@ size_t tvr_mlpnet_packed_bytes(const tvr_mlpnet_desc *desc)
 {
     BgLayout L;
     if (plan(desc, L) != TVR_OK) return 0;
-    // fragment image, biases, and the block table the pack kernel reads
-    return bg_ticket_offset(L) + 256;                               // ... and the forward kernel's ticket word (round 5)
+    return bg_packed_bytes(L);
+}
+
+size_t tvr_mlpnet_work_bytes(void) { return 256; }
+
+int tvr_mlpnet_describe(const tvr_mlpnet_desc *desc, tvr_mlpnet_layout *out)
+{
+    BgLayout L;
+    if (!out) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_describe: out is NULL");
+    if (int rc = plan(desc, L)) return rc;
+    out->fragments = 0;
+    out->biases = (size_t)L.total_blocks * 2048;
+    out->block_table = out->biases + BG_BIAS_FLOATS * 4;
+    out->block_table_bytes = (size_t)L.total_blocks * sizeof(PackBlock);
+    out->total = bg_packed_bytes(L);
+    return TVR_OK;
 }
 
 int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *p, void *packed, size_t packed_bytes, void *stream)
@@ -592,29 +610,32 @@ int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *p, voi
 }
 
 // arith: TVR_ARITH_* of the INFERENCE call (tvr_mlpnet_desc.arith); the training forward passes TVR_ARITH_F32 whatever the descriptor says
-static int mlpnet_forward_impl(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
-                               const BgTrain &T, void *stream, int arith)
+static int mlpnet_forward_impl(const tvr_mlpnet_desc *desc, const void *packed, size_t packed_bytes, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
+                               void *sigma, const BgTrain &T, void *work, size_t work_bytes, void *stream, int arith)
 {
     BgLayout L;
     if (int rc = plan(desc, L)) return rc;
     if (n_samples < 0) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_forward: n_samples < 0");
     if (n_samples == 0) return TVR_OK;
     if (!packed || !pts || !viewdirs || !rgb || !sigma || misaligned(packed) || misaligned(pts)) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_forward: NULL or misaligned argument");
+    if (packed_bytes < bg_packed_bytes(L)) return tvr_set_error(TVR_ERR_SCRATCH, "tvr_mlpnet_forward: packed network smaller than tvr_mlpnet_packed_bytes()");
+    if (!work || misaligned(work) || work_bytes < tvr_mlpnet_work_bytes())
+        return tvr_set_error(work ? TVR_ERR_SCRATCH : TVR_ERR_INVALID, "tvr_mlpnet_forward: work buffer NULL, misaligned or smaller than tvr_mlpnet_work_bytes()");
     if (arith != TVR_ARITH_F32 && arith != TVR_ARITH_F16ACT && arith != TVR_ARITH_F16) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_forward: desc.arith %d is none of TVR_ARITH_*", arith);
-    if (arith == TVR_ARITH_F16ACT) return mlpnet_launch<2>(L, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream);
-    if (arith == TVR_ARITH_F16) return mlpnet_launch<1>(L, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream);
-    return mlpnet_launch<3>(L, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream);
+    if (arith == TVR_ARITH_F16ACT) return mlpnet_launch<2>(L, packed, pts, viewdirs, n_samples, rgb, sigma, T, work, stream);
+    if (arith == TVR_ARITH_F16) return mlpnet_launch<1>(L, packed, pts, viewdirs, n_samples, rgb, sigma, T, work, stream);
+    return mlpnet_launch<3>(L, packed, pts, viewdirs, n_samples, rgb, sigma, T, work, stream);
 }
 
-int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
-                       void *stream)
+int tvr_mlpnet_forward(const tvr_mlpnet_desc *desc, const void *packed, size_t packed_bytes, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
+                       void *sigma, void *work, size_t work_bytes, void *stream)
 {
     BgTrain T = {};
-    return mlpnet_forward_impl(desc, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream, desc ? desc->arith : 0);
+    return mlpnet_forward_impl(desc, packed, packed_bytes, pts, viewdirs, n_samples, rgb, sigma, T, work, work_bytes, stream, desc ? desc->arith : 0);
 }
 
-int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma,
-                             const tvr_mlpnet_saved *saved, void *stream)
+int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, size_t packed_bytes, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb,
+                             void *sigma, const tvr_mlpnet_saved *saved, void *work, size_t work_bytes, void *stream)
 {
     if (!desc || !saved) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_train_forward: desc / saved NULL");
     const size_t rows = n_samples < 0 ? 0 : (size_t)n_samples;
@@ -641,7 +662,7 @@ int tvr_mlpnet_train_forward(const tvr_mlpnet_desc *desc, const void *packed, co
         if (!saved->rgb_hidden_mask || misaligned(saved->rgb_hidden_mask)) return tvr_set_error(TVR_ERR_INVALID, "tvr_mlpnet_train_forward: rgb_hidden_mask NULL or misaligned");
         T.MH = static_cast<unsigned long long *>(saved->rgb_hidden_mask);
     }
-    if (int rc = mlpnet_forward_impl(desc, packed, pts, viewdirs, n_samples, rgb, sigma, T, stream, TVR_ARITH_F32)) return rc;
+    if (int rc = mlpnet_forward_impl(desc, packed, packed_bytes, pts, viewdirs, n_samples, rgb, sigma, T, work, work_bytes, stream, TVR_ARITH_F32)) return rc;
     if (n_samples > 0) {
         hipLaunchKernelGGL(bg_embed_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float *>(pts),
                            static_cast<const float *>(viewdirs), (long long)n_samples, input_ch, (int)desc->samples_per_ray, static_cast<float *>(saved->embed_pos),

@@ -26,6 +26,12 @@ from . import _lib as L
 from .autograd_ops import _FusedStepFn, _MlpTrainFn, _AppHFn, _MarchFn, _f32c, _linear, _mlp3, _mlp_input, _stream_ptr
 
 
+# hipGraph replays of captured training steps, as far as the host can know about them: training.make_graphed_step bumps GRAPH_REPLAYS on every replay and raises
+# GRAPH_HELPER_CAPTURING while it captures (TensorBase._replays_pending).
+GRAPH_REPLAYS = [0]
+GRAPH_HELPER_CAPTURING = [False]
+
+
 class AlphaGridMask:
     """tensorBase.py:39-59.  alpha_volume has shape (gz, gy, gx) (any leading 1s); values are used as given.
     (A plain object rather than a Module: it holds no parameters, only the occupancy volume.)"""
@@ -280,11 +286,15 @@ class TensorBase(torch.nn.Module):
                              "There is no CPU fallback.")
         ps = self._param_list()
         sig = tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in ps)
-        if getattr(self, "_captured_update", False) and not torch.cuda.is_current_stream_capturing():
+        if self._replays_pending():
             # a hipGraph replay of a captured training step packs the parameters at the START of the step and updates them at its end, bumping no version counter
-            # and running no host code: the packed images are one optimizer step behind whatever the host sees.  Every host-driven call of such a model re-packs
-            # (0.1 ms for 70 MB), which also voids the library's derived state — fp16 copies, the validated arithmetic (tvr_scene_update)
+            # and running no host code: the packed images are one optimizer step behind whatever the host sees.  The first host-driven call behind a replay re-packs
+            # (0.1 ms for 70 MB), which also voids the library's derived state — fp16 copies, the validated arithmetic (tvr_scene_update) — and the host's range
+            # proof (below).  Graphs made by training.make_graphed_step count their replays (GRAPH_REPLAYS): calls with no replay in between pay nothing (round 6,
+            # ADVICE r5 — before, ONE captured step made every later inference call re-pack and re-validate for the life of the model); a capture made any other
+            # way cannot tell the host about its replays and keeps the conservative behaviour: every call.
             force = True
+            self._replays_seen = GRAPH_REPLAYS[0]
         if self._scene is None:
             d = L.SceneDesc()
             d.aabb[:] = [float(x) for x in self.aabb.reshape(-1)]
@@ -302,7 +312,7 @@ class TensorBase(torch.nn.Module):
             nbytes = lib.tvr_scene_packed_bytes(C.byref(d))
             if nbytes == 0:
                 raise L.TvrError("unsupported field configuration: " + lib.tvr_last_error().decode())
-            self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._packed = L.dev_bytes(nbytes, self.device, what="tvr_scene packed")
             h = C.c_void_p()
             L.check(lib.tvr_scene_create(C.byref(d), self._packed.data_ptr(), nbytes, C.byref(h)), "tvr_scene_create")
             self._scene = h
@@ -326,6 +336,8 @@ class TensorBase(torch.nn.Module):
                 sp.ref_W[i], sp.ref_b[i] = lin.weight.data_ptr(), lin.bias.data_ptr()
             L.check(lib.tvr_scene_update(self._scene, C.byref(sp), _stream_ptr(self.device)), "tvr_scene_update")
             if torch.cuda.is_current_stream_capturing():
+                self._captured_raw = bool(getattr(self, "_captured_raw", False)) or not GRAPH_HELPER_CAPTURING[0]
+                self._replays_seen = GRAPH_REPLAYS[0]
                 # This update is being CAPTURED (a whole training step as a hipGraph): every replay re-packs the images on the device and runs no host code, so
                 # nothing the host caches about "the parameters as packed" — the fp16-range proof, the freshness of the fp16 factor copies — can be trusted from
                 # here on.  _settle_range_check keeps the in-kernel check on and marks the copies stale before every inference call of such a model.
@@ -340,7 +352,7 @@ class TensorBase(torch.nn.Module):
                 self._alpha_bits = None
             else:
                 ag, ab, inv = am._c_args()
-                self._alpha_bits = torch.empty(lib.tvr_alpha_bits_bytes(C.byref(ag)), dtype=torch.uint8, device=self.device)
+                self._alpha_bits = L.dev_bytes(lib.tvr_alpha_bits_bytes(C.byref(ag)), self.device, what="alpha bit volume")
                 L.check(lib.tvr_scene_set_alpha(self._scene, am.alpha_volume.data_ptr(), C.byref(ag), C.byref(ab), C.byref(inv),
                                                 self._alpha_bits.data_ptr(), self._alpha_bits.numel(), _stream_ptr(self.device)), "tvr_scene_set_alpha")
             self._alpha_dirty = False
@@ -368,7 +380,7 @@ class TensorBase(torch.nn.Module):
         """True when the next inference call will enqueue nothing but the frame's own kernels: packed images, alpha volume, range-check decision and the requested
         arithmetic are all current for the parameters as they are now.  A pure host check.  render.FrameStream keeps two frames in flight only while this holds —
         whatever rewrites the scene's device state (tvr_scene_update, the fp16 copies, the arithmetic gate's probe renders) must not run beside a frame that reads it."""
-        if self._scene is None or getattr(self, "_captured_update", False) or self._alpha_dirty or self._range_proven is None:
+        if self._scene is None or self._replays_pending() or self._alpha_dirty or self._range_proven is None:
             return False
         if getattr(self, "_arith_set", None) != self.mlp_arith:
             return False
@@ -387,12 +399,13 @@ class TensorBase(torch.nn.Module):
             return
         lib = L.lib()
         names = {v: k for k, v in self._ARITH.items()}
-        if getattr(self, "_captured_update", False):
+        raw_graph = getattr(self, "_captured_update", False) and getattr(self, "_captured_raw", True)
+        if raw_graph:
             L.check(lib.tvr_scene_touch(self._scene), "tvr_scene_touch")            # replays moved the parameters: whatever was validated is void
         if lib.tvr_scene_get_arith(self._scene) == self._ARITH[self.mlp_arith]:
             self.arith_in_effect = self.mlp_arith
             return
-        if getattr(self, "_arith_refused_sig", None) == (self._sig, self.mlp_arith, float(self.mlp_arith_tol)) and not getattr(self, "_captured_update", False):
+        if getattr(self, "_arith_refused_sig", None) == (self._sig, self.mlp_arith, float(self.mlp_arith_tol)) and not raw_graph:
             return                                                                  # measured and refused for exactly these parameters: "f32" stays
         n = rays.shape[0]
         if n == 0:
@@ -401,11 +414,18 @@ class TensorBase(torch.nn.Module):
         probe = rays if k == n else rays[torch.linspace(0, n - 1, k, device=rays.device).long()].contiguous()
         scratch = self._get_scratch(lib.tvr_render_scratch_bytes(self._scene, k, S))
         work = torch.empty(8 * k + 64, dtype=torch.float32, device=self.device)
-        md = C.c_float(0.0)
+        md, shaded = C.c_float(0.0), C.c_int64(0)
         L.check(lib.tvr_scene_validate_arith(self._scene, probe.data_ptr(), k, S, int(bool(white_bg)), float(eps_T), float(self.mlp_arith_tol), scratch.data_ptr(),
-                                             scratch.numel(), work.data_ptr(), work.numel() * 4, C.byref(md), _stream_ptr(self.device)), "tvr_scene_validate_arith")
-        self.arith_max_diff = float(md.value)
+                                             scratch.numel(), work.data_ptr(), work.numel() * 4, C.byref(md), C.byref(shaded), _stream_ptr(self.device)),
+                "tvr_scene_validate_arith")
         self.arith_in_effect = names[lib.tvr_scene_get_arith(self._scene)]
+        self.arith_probe_samples = int(shaded.value)
+        if self.arith_probe_samples < min(L.ARITH_MIN_PROBE_SAMPLES, 2 * k):
+            # the probe shaded (almost) nothing — a corner chunk, a sparse rank share, rays that miss the box: it measured nothing.  Nothing is cached:
+            # this call renders in "f32" and the next inference batch probes again.
+            self.arith_max_diff = None
+            return
+        self.arith_max_diff = float(md.value)
         if self.arith_in_effect != self.mlp_arith:
             self._arith_refused_sig = (self._sig, self.mlp_arith, float(self.mlp_arith_tol))
             import warnings
@@ -454,9 +474,16 @@ class TensorBase(torch.nn.Module):
         rep["proven"] = all(x == x and x < self._FP16_SAFE for x in b)
         return rep
 
+    def _replays_pending(self) -> bool:
+        """A tvr_scene_update of this model lives in a hipGraph and replays may have moved the parameters since the host last packed them: always, for a graph whose
+        replays the host cannot see (`_captured_raw`); for graphs of training.make_graphed_step, if their replay counter moved since the last host-driven re-pack."""
+        if not getattr(self, "_captured_update", False) or torch.cuda.is_current_stream_capturing():
+            return False
+        return bool(getattr(self, "_captured_raw", True)) or getattr(self, "_replays_seen", -1) != GRAPH_REPLAYS[0]
+
     def _settle_range_check(self):
         """Called by the inference entry points after _ensure_scene(): decide once per parameter state whether the kernels must check the fp16 range."""
-        if getattr(self, "_captured_update", False):
+        if getattr(self, "_captured_update", False) and getattr(self, "_captured_raw", True):
             # hipGraph replays of a captured training step move the parameters behind the host's back: no proof made on earlier values holds, and the fp16
             # copies the "f16" arithmetic gathers may be older than the fp32 images — check in the kernel, convert before the next "f16" render
             L.check(L.lib().tvr_scene_touch(self._scene), "tvr_scene_touch")
@@ -478,7 +505,7 @@ class TensorBase(torch.nn.Module):
     def _get_grad_scratch(self) -> torch.Tensor:
         nbytes = L.lib().tvr_grad_scratch_bytes(self._ensure_scene())
         if getattr(self, "_grad_scratch", None) is None or self._grad_scratch.numel() < nbytes:
-            self._grad_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._grad_scratch = L.dev_bytes(nbytes, self.device, what="tvr_grad_scratch")
         return self._grad_scratch
 
     def render_rays_autograd(self, rays_chunk, white_bg=True, N_samples=-1, jitter=None):
@@ -530,7 +557,7 @@ class TensorBase(torch.nn.Module):
     def _get_train_image(self) -> torch.Tensor:
         nbytes = L.lib().tvr_mlp_train_image_bytes()
         if getattr(self, "_train_image", None) is None or self._train_image.numel() < nbytes:
-            self._train_image = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._train_image = L.dev_bytes(nbytes, self.device, what="tvr_mlp_train image")
         return self._train_image
 
     # The fused backward multiplies the output gradients by a power of two that brings max |grad_rgb| to ~grad_scale_target (its matrix products
@@ -573,8 +600,8 @@ class TensorBase(torch.nn.Module):
             sc = self._ensure_scene()
             self._train_buf = None
             b = dict(key=key, cap=cap,
-                     scratch=torch.zeros(lib.tvr_render_scratch_bytes(sc, n, S), dtype=torch.uint8, device=self.device),
-                     work=torch.zeros(lib.tvr_train_work_bytes(sc, n, S, cap), dtype=torch.uint8, device=self.device))
+                     scratch=L.dev_bytes(lib.tvr_render_scratch_bytes(sc, n, S), self.device, zero=True, what="tvr_train_forward scratch"),
+                     work=L.dev_bytes(lib.tvr_train_work_bytes(sc, n, S, cap), self.device, zero=True, what="tvr_train work"))
             self._train_buf = b
         return b
 
@@ -653,11 +680,11 @@ class TensorBase(torch.nn.Module):
         if slot == 0:
             if self._scratch is None or self._scratch.numel() < nbytes:
                 self._scratch = None
-                self._scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                self._scratch = L.dev_bytes(nbytes, self.device, what="tvr_render scratch")
             return self._scratch
         extra = self.__dict__.setdefault("_scratch_slots", {})
         if slot not in extra or extra[slot].numel() < nbytes:
-            extra[slot] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            extra[slot] = L.dev_bytes(nbytes, self.device, what=f"tvr_render scratch (slot {slot})")
         return extra[slot]
 
     # ---- compute entry points ----------------------------------------------------------------------------
@@ -799,8 +826,8 @@ class TensorBase(torch.nn.Module):
                     or not depth.is_contiguous() or rgb.device != rays.device or depth.device != rays.device):
                 raise ValueError("out must be (contiguous fp32 [N,3], contiguous fp32 [N]) on the rays' device")
         else:
-            rgb = torch.empty((n, 3), dtype=torch.float32, device=self.device)
-            depth = torch.empty((n,), dtype=torch.float32, device=self.device)
+            rgb = L.dev_empty((n, 3), torch.float32, self.device, "tvr_render rgb_out")
+            depth = L.dev_empty((n,), torch.float32, self.device, "tvr_render depth_out")
         if n == 0:
             return (rgb, depth, {}) if dense else (rgb, depth)
         if eps_T is None:

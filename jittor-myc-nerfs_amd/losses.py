@@ -27,7 +27,7 @@ class _L1MeanFn(torch.autograd.Function):
         counts = (C.c_int64 * len(xs))(*[x.numel() for x in xs])
         value = torch.empty(1, dtype=torch.float32, device=dev)
         nb = L.lib().tvr_l1_mean_scratch_bytes(counts, len(xs))
-        scratch = torch.empty(max(nb, 4), dtype=torch.uint8, device=dev)
+        scratch = L.dev_bytes(max(nb, 4), dev, what="tvr_l1_mean scratch")
         L.check(L.lib().tvr_l1_mean(_ptr_array(xs), counts, len(xs), value.data_ptr(), scratch.data_ptr(), scratch.numel(),
                                     torch.cuda.current_stream(dev).cuda_stream), "tvr_l1_mean")
         ctx.save_for_backward(*xs)
@@ -56,7 +56,7 @@ class _LineOrthoFn(torch.autograd.Function):
         nc = (C.c_int32 * len(xs))(*[x.shape[1] for x in xs])
         ns = (C.c_int32 * len(xs))(*[x.numel() // x.shape[1] for x in xs])
         value = torch.empty(1, dtype=torch.float32, device=dev)
-        scratch = torch.empty(32, dtype=torch.uint8, device=dev)
+        scratch = L.dev_bytes(32, dev, what="tvr_line_ortho scratch")
         L.check(L.lib().tvr_line_ortho(_ptr_array(xs), nc, ns, len(xs), value.data_ptr(), scratch.data_ptr(), scratch.numel(),
                                        torch.cuda.current_stream(dev).cuda_stream), "tvr_line_ortho")
         ctx.save_for_backward(*xs)
@@ -84,7 +84,7 @@ class _TVFn(torch.autograd.Function):
         _, Cc, H, W = xc.shape
         value = torch.empty(1, dtype=torch.float32, device=x.device)
         grad = torch.empty_like(xc)
-        scratch = torch.empty(2048, dtype=torch.uint8, device=x.device)
+        scratch = L.dev_bytes(2048, x.device, what="tvr_tv_loss scratch")
         L.check(L.lib().tvr_tv_loss(xc.data_ptr(), Cc, H, W, float(weight), value.data_ptr(), grad.data_ptr(), scratch.data_ptr(), scratch.numel(),
                                     torch.cuda.current_stream(x.device).cuda_stream), "tvr_tv_loss")
         ctx.save_for_backward(grad)

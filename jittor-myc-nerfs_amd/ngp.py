@@ -273,7 +273,7 @@ class DensityGridSampler(torch.nn.Module):
         counter = torch.zeros(2, dtype=torch.int32, device=dev)
         need = L.lib().tvr_ngp_sample_scratch_bytes(R)
         if self._scratch is None or self._scratch.numel() < need or self._scratch.device != dev:
-            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._scratch = L.dev_bytes(need, dev, what="tvr_ngp scratch")
         cfg = self._cfg(slab_rays)
         L.check(L.lib().tvr_ngp_sample(C.byref(cfg), o.data_ptr(), d.data_ptr(), R, self.density_grid_bitfield.data_ptr(), coords.data_ptr(), max_samples,
                                        numsteps.data_ptr(), None if index is None else index.data_ptr(), counter.data_ptr(), self._scratch.data_ptr(),
@@ -326,7 +326,7 @@ class DensityGridSampler(torch.nn.Module):
         rgb = torch.empty(R, 3, device=dev)
         need = L.lib().tvr_ngp_render_scratch_bytes(R)
         if self._scratch is None or self._scratch.numel() < need or self._scratch.device != dev:
-            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._scratch = L.dev_bytes(need, dev, what="tvr_ngp scratch")
         st = torch.zeros(2, dtype=torch.int64, device=dev) if stats is not None else None
         cfg = self._cfg(self.n_rays_per_batch)
         bgc = (C.c_float * 3)(*self.background_color)

@@ -101,12 +101,18 @@ def make_graphed_step(step_fn, device=None, warmup: int = 2):
             step_fn()
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
+    from . import field as _field
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (other threads — a process group's watchdog — may call the runtime meanwhile)
-        out = step_fn()
+    _field.GRAPH_HELPER_CAPTURING[0] = True
+    try:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (other threads — a process group's watchdog — may call the runtime meanwhile)
+            out = step_fn()
+    finally:
+        _field.GRAPH_HELPER_CAPTURING[0] = False
 
     def replay():
         graph.replay()
+        _field.GRAPH_REPLAYS[0] += 1          # models whose tvr_scene_update lives in this graph re-pack on their next host-driven call, and only then
         return out
     replay.graph, replay.output = graph, out
     return replay

@@ -233,8 +233,8 @@ class NerfPlusPlus(TensorVMSplit):
     render_rays_is_the_frame = False          # forward() adds the background; render_rays alone is the foreground field (render.FrameStream refuses this model)
 
     def scene_settled(self) -> bool:
-        """Never: the background network's packed image carries ONE per-launch ticket word and one set of [rays, 512, *] temporaries, so two frames of this model
-        must not be in flight at once (render.FrameStream then renders them one after the other)."""
+        """Never: the model keeps one set of [rays, 512, *] background temporaries and composes its picture in forward(), so two frames of this model are not put
+        in flight at once (render.FrameStream then renders them one after the other).  (The background kernel's ticket word is per stream since round 6: _bg_work.)"""
         return False
 
     def __init__(self, aabb, gridSize, device, **kargs):
@@ -368,8 +368,9 @@ class NerfPlusPlus(TensorVMSplit):
             img = self._bg_packed(desc)
             rgb = torch.empty(k, 3, device=self.device)
             sigma = torch.empty(k, device=self.device)
-            L.check(L.lib().tvr_mlpnet_forward(C.byref(desc), img.data_ptr(), pts.data_ptr(), vd.data_ptr(), k, rgb.data_ptr(), sigma.data_ptr(),
-                                               _stream_ptr(self.device)), "tvr_mlpnet_forward")
+            wk = self._bg_work()
+            L.check(L.lib().tvr_mlpnet_forward(C.byref(desc), img.data_ptr(), img.numel(), pts.data_ptr(), vd.data_ptr(), k, rgb.data_ptr(), sigma.data_ptr(),
+                                               wk.data_ptr(), wk.numel(), _stream_ptr(self.device)), "tvr_mlpnet_forward")
             if z is not None:
                 col = torch.empty(k // N, 3, device=self.device)
                 L.check(L.lib().tvr_npp_bg_composite(rgb.data_ptr(), sigma.data_ptr(), z.data_ptr(), k // N, N, col.data_ptr(), _stream_ptr(self.device)), "tvr_npp_bg_composite")
@@ -389,6 +390,21 @@ class NerfPlusPlus(TensorVMSplit):
             import warnings
             warnings.warn(f"mlp_arith={self.mlp_arith!r} REFUSED for the background network: {d:.3g} off the fp32-class arithmetic on {k} probe samples "
                           f"(tolerance {self.mlp_arith_tol:g}); its kernel computes in 'f32'", RuntimeWarning, stacklevel=3)
+
+    def _bg_work(self):
+        """The forward kernel's work buffer (its ticket word; include/tvr.h tvr_mlpnet_work_bytes): one per stream, since one launch at a time may use it."""
+        key = int(_stream_ptr(self.device) or 0)
+        pool = self.__dict__.setdefault("_bg_work_pool", {})
+        if key not in pool:
+            pool[key] = L.dev_bytes(L.lib().tvr_mlpnet_work_bytes(), self.device, zero=True, what="tvr_mlpnet work")
+        return pool[key]
+
+    def _bg_params_changed(self):
+        """The background network's parameters were (or are about to be) rewritten without their version counters moving (fused optimizers, graph replays):
+        the packed image is stale AND so is a reduced arithmetic's validation, which was measured on the old weights."""
+        self._bg_sig = None
+        self._bg_arith_sig = None
+        self.bg_arith_in_effect = "f32"
 
     def _bg_packed(self, desc):
         """Fragment image of the background network.  `base_remap_layers` (Linear 128->256, no activation) is folded into the first rgb
@@ -413,7 +429,7 @@ class NerfPlusPlus(TensorVMSplit):
         nbytes = L.lib().tvr_mlpnet_packed_bytes(C.byref(desc))
         if nbytes == 0:
             raise L.TvrError("tvr_mlpnet_packed_bytes: " + L.lib().tvr_last_error().decode(errors="replace"))
-        img = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        img = L.dev_bytes(nbytes, self.device, what="tvr_mlpnet packed (inference)")
         L.check(L.lib().tvr_mlpnet_pack(C.byref(desc), C.byref(p), img.data_ptr(), nbytes, _stream_ptr(self.device)), "tvr_mlpnet_pack")
         self._bg_image, self._bg_sig = img, sig
         return img
@@ -449,7 +465,7 @@ class NerfPlusPlus(TensorVMSplit):
             if nbytes == 0:
                 raise L.TvrError("tvr_mlpnet_packed_bytes: " + L.lib().tvr_last_error().decode(errors="replace"))
             st = {"key": key, "W_eff": z(64, 128), "b_eff": z(64), "W_view": z(64, 15), "W_cat": z(72, 128),
-                  "image": torch.empty(nbytes, dtype=torch.uint8, device=self.device), "packed": False, "P": P}
+                  "image": L.dev_bytes(nbytes, self.device, what="tvr_mlpnet packed (training)"), "packed": False, "P": P}
             p = L.MlpnetParams()
             for l in range(desc.D):
                 p.base_W[l], p.base_b[l] = P[2 * l].data_ptr(), P[2 * l + 1].data_ptr()
@@ -472,7 +488,7 @@ class NerfPlusPlus(TensorVMSplit):
         n, N = bg_pts.shape[:2]
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.bg_net.parameters())
         if training:
-            self._bg_sig = None       # an optimizer step follows; fused optimizers do not bump the version counters `_bg_packed` watches
+            self._bg_params_changed()  # an optimizer step follows; fused optimizers do not bump the version counters `_bg_packed` watches
         # torch modules: under autograd, for shapes the kernel is not built for, and for host-logic checks of this class on a CPU device
         # (the foreground has no such path: it raises without the GPU)
         desc = None if bg_pts.device.type != "cuda" else self._bg_kernel_desc()
@@ -493,8 +509,9 @@ class NerfPlusPlus(TensorVMSplit):
         img = self._bg_packed(desc)
         rgb = torch.empty(n, N, 3, device=self.device)
         sigma = torch.empty(n, N, device=self.device)
-        L.check(L.lib().tvr_mlpnet_forward(C.byref(desc), img.data_ptr(), pts.data_ptr(), vd.data_ptr(), n * N, rgb.data_ptr(), sigma.data_ptr(),
-                                           _stream_ptr(self.device)), "tvr_mlpnet_forward")
+        wk = self._bg_work()
+        L.check(L.lib().tvr_mlpnet_forward(C.byref(desc), img.data_ptr(), img.numel(), pts.data_ptr(), vd.data_ptr(), n * N, rgb.data_ptr(), sigma.data_ptr(),
+                                           wk.data_ptr(), wk.numel(), _stream_ptr(self.device)), "tvr_mlpnet_forward")
         return {'rgb': rgb, 'sigma': sigma}
 
     def _background_fused(self, ray_o, ray_d, rand_bg, desc):
@@ -520,7 +537,7 @@ class NerfPlusPlus(TensorVMSplit):
         n, N = ray_d.shape[0], self.BG_SAMPLES
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.bg_net.parameters())
         if training:
-            self._bg_sig = None
+            self._bg_params_changed()
         if not training and ray_d.device.type == "cuda":
             desc = self._bg_kernel_desc()
             if desc is not None:
@@ -557,7 +574,7 @@ class NerfPlusPlus(TensorVMSplit):
         if is_train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # an optimizer step follows.  Invalidate the packed background image here, not only where the background is evaluated: a batch
             # whose rays all have bg_lambda <= 0.1 skips it, and a fused Adam still moves bg_net by momentum without bumping `_version`
-            self._bg_sig = None
+            self._bg_params_changed()
             rgb_map, depth_map, bg_lambda = self._render_z_autograd(rays, z_vals, S, eps_T)
         else:
             rgb_map, depth_map, bg_lambda = self._render_z(rays, z_vals, S, eps_T)

@@ -202,6 +202,40 @@ def test_feature_magnitude_is_where_the_modes_differ(tiny_dump, tiny_arrays, hyp
     assert err["f16"][0] > err["f16act"][0] > err["f32"][0]                    # every reduced mode's error is RELATIVE to the activations
 
 
+def test_a_probe_that_shades_nothing_validates_nothing(tiny_dump, tiny_arrays, hyper_tiny):
+    """the gate accepted on `max difference <= tol` alone — a probe whose rays miss the box (a corner chunk, a sparse rank share) compares two background
+    pictures, d = 0, and opened the gate for every later frame on these parameters.  Now such a probe neither validates nor refuses: the call renders in "f32", nothing is
+    cached, and the next batch — rays that do hit the scene — is measured."""
+    import ctypes as C
+    import warnings
+    from jittor_myc_nerfs_amd import _lib as L
+    m = make_model(tiny_arrays, hyper_tiny)
+    rays = torch.tensor(tiny_dump["rays"], device="cuda")
+    miss = rays.clone()
+    miss[:, 3:6] = -miss[:, 3:6]                                                # the cameras look away from the box
+    m.mlp_arith = "f16act"
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        bg, _ = m.render_rays(miss, white_bg=True, N_samples=TINY["N_samples"])
+    assert bool((bg == 1).all())                                                # nothing but background
+    assert m.arith_probe_samples == 0 and m.arith_in_effect == "f32" and m.arith_max_diff is None
+    assert L_get(m) == 0 and b"NOT MEASURED" in L.lib().tvr_last_error()
+    assert getattr(m, "_arith_refused_sig", None) is None and not wl and not m.scene_settled()       # neither verdict cached: the next call probes again
+    rgb, _ = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
+    assert m.arith_in_effect == "f16act" and L_get(m) == 1 and m.arith_probe_samples >= 2 * rays.shape[0] and 0 < m.arith_max_diff <= m.mlp_arith_tol
+    # the C-ABI alone: an all-miss probe leaves the mode out of effect and says how many samples it saw
+    sc = m._ensure_scene()
+    L.check(L.lib().tvr_scene_touch(sc), "touch")
+    n, S = miss.shape[0], TINY["N_samples"]
+    scratch = m._get_scratch(L.lib().tvr_render_scratch_bytes(sc, n, S))
+    work = torch.empty(8 * n + 64, dtype=torch.float32, device="cuda")
+    md, shaded = C.c_float(-1.0), C.c_int64(-1)
+    from jittor_myc_nerfs_amd.autograd_ops import _stream_ptr
+    L.check(L.lib().tvr_scene_validate_arith(sc, miss.data_ptr(), n, S, 1, 1e-4, 2.5e-4, scratch.data_ptr(), scratch.numel(), work.data_ptr(), work.numel() * 4,
+                                             C.byref(md), C.byref(shaded), _stream_ptr(miss.device)), "validate")
+    assert md.value == 0.0 and shaded.value == 0 and L_get(m) == 0
+
+
 def test_fp16_factor_copies_follow_the_parameters(tiny_arrays, hyper_tiny, tiny_dump):
     """The "f16" arithmetic gathers fp16 COPIES of the appearance planes / lines (include/tvr.h).  They are converted by the first render in the mode, and again by every
     tvr_scene_update while the mode is set: an in-place edit of a factor must show in the next picture exactly as in a model built with the edited factor."""

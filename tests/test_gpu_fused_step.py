@@ -366,8 +366,20 @@ def test_graph_replays_do_not_leave_stale_host_caches(tiny_dump, tiny_arrays, hy
         replay()
     torch.cuda.synchronize()
     rgb1, _ = m.render_rays(eval_rays, white_bg=True, N_samples=TINY["N_samples"])       # (fused Adam bumps no version counter, and a replay packs BEFORE its update: the host re-packs a captured model on every call)
-    assert m._range_proven is False                                                      # the kernel checks the range: no proof was carried over the replays
+    # no proof was carried over the replays: the forced re-pack voided it and this call proved the range again, on the moved parameters
+    assert m._range_proven == bool(m.fp16_range_report()["proven"])
     assert m.arith_in_effect == "f16"                                                    # measured again on the moved parameters
+    # round 6: the helper's graphs count their replays — with none in between the next call re-packs nothing, measures nothing, and FrameStream may overlap
+    assert not m._captured_raw and not m._replays_pending() and m.scene_settled()
+    sig_before = m._sig
+    rgb1b, _ = m.render_rays(eval_rays, white_bg=True, N_samples=TINY["N_samples"])
+    assert torch.equal(rgb1b, rgb1) and m._sig is sig_before and m.scene_settled()
+    rgb1 = rgb1.clone()
+    replay()
+    torch.cuda.synchronize()
+    assert m._replays_pending() and not m.scene_settled()                                # one more replay: the next host-driven call re-packs again
+    rgb3, _ = m.render_rays(eval_rays, white_bg=True, N_samples=TINY["N_samples"])
+    assert float((rgb3 - rgb1).abs().max()) > 0 and not m._replays_pending()
     fresh = make_model(tiny_arrays, hyper_tiny)
     fresh.mlp_arith_tol = 1e-3
     with torch.no_grad():
