@@ -380,6 +380,7 @@ def test_graph_replays_do_not_leave_stale_host_caches(tiny_dump, tiny_arrays, hy
     assert m._replays_pending() and not m.scene_settled()                                # one more replay: the next host-driven call re-packs again
     rgb3, _ = m.render_rays(eval_rays, white_bg=True, N_samples=TINY["N_samples"])
     assert float((rgb3 - rgb1).abs().max()) > 0 and not m._replays_pending()
+    rgb1 = rgb3                                                                          # (the fresh model below is loaded with the parameters as they are NOW)
     fresh = make_model(tiny_arrays, hyper_tiny)
     fresh.mlp_arith_tol = 1e-3
     with torch.no_grad():
