@@ -285,6 +285,9 @@ __device__ __forceinline__ float4 heads(const BgProgram &P, const uint4 *__restr
 #ifndef TVR_BG_TICKETS
 #define TVR_BG_TICKETS 1          // 1: dynamic hand-out of the super-tiles (0: static stride over the workgroups)
 #endif
+#ifndef TVR_BG_DIAG
+#define TVR_BG_DIAG 0             // timing stand-ins (WRONG results, never shipped): 1 = the LDS stage images are loaded for the first super-tile only (what the reloads
+#endif                            // cost), 2 = ... and no workgroup barriers around them either (what the lockstep costs)
 #ifndef TVR_BG_NT
 #define TVR_BG_NT 1               // 32-sample tiles a wave carries through each LDS stage (their stage-A activations wait in registers)
 #endif
@@ -316,9 +319,16 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
         const uint4 *w4 = lds4 + lane_off;
         f32x16 act[NT][4];
         // ---------------- stage A: base layers [0, split)
+#if TVR_BG_DIAG
+        const bool diag_first = super == (long long)blockIdx.x;
+        if (TVR_BG_DIAG < 2 || diag_first) __syncthreads();
+        if (diag_first) load_stage(lds4, imgA, P.blocksA);
+        if (TVR_BG_DIAG < 2 || diag_first) __syncthreads();
+#else
         __syncthreads();                                             // everyone is done with the previous tile's stage B
         load_stage(lds4, imgA, P.blocksA);
         __syncthreads();
+#endif
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const long long s = ((super * NT + nt) * BG_WAVES + wave) * 32 + col, sr = min(s, M - 1);
@@ -327,9 +337,13 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
             base_layers<AR>(P, 0, la, w4, lbias, hh, x, act[nt], T, s < M ? s : -1);
         }
         // ---------------- stage B: the remaining base layers and the heads
+#if TVR_BG_DIAG
+        if (TVR_BG_DIAG < 2) { __syncthreads(); __syncthreads(); }
+#else
         __syncthreads();
         load_stage(lds4, imgB, P.blocksB);
         __syncthreads();
+#endif
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const long long s = ((super * NT + nt) * BG_WAVES + wave) * 32 + col, sr = min(s, M - 1);

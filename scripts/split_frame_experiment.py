@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--model", default="TensorVMSplit")
+    ap.add_argument("--K2", default="2,3,4,6,8,12,16,24", help="piece counts tried on two streams")
+    ap.add_argument("--K3", default="6,9,12", help="piece counts tried on three streams")
+    ap.add_argument("--stagger", default="5:0.1,9:0.06", help="K:first-piece-fraction pairs (two streams)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     model, arrs, A = bench.build_model(dev, args.model)
@@ -63,11 +66,12 @@ def main():
         return rgb, depth
 
     configs = [("plain", lambda r: plain(r))]
-    for K in (2, 3, 4, 6, 8, 12, 16, 24):
-        configs.append((f"K={K} 2 streams", lambda r, K=K: split(r, K, 2)))
-    for K in (6, 9, 12):
-        configs.append((f"K={K} 3 streams", lambda r, K=K: split(r, K, 3)))
-    for K, ff in ((5, 0.1), (9, 0.06)):
+    for K in [int(x) for x in args.K2.split(",") if x]:
+        configs.append((f"K={K} 2 streams", lambda r, K=K: split(r, K, 2, align=512 if K > 100 else 4096)))
+    for K in [int(x) for x in args.K3.split(",") if x]:
+        configs.append((f"K={K} 3 streams", lambda r, K=K: split(r, K, 3, align=512 if K > 100 else 4096)))
+    for kv in [x for x in args.stagger.split(",") if x]:
+        K, ff = int(kv.split(":")[0]), float(kv.split(":")[1])
         configs.append((f"K={K} 2 streams, first piece {ff:g}", lambda r, K=K, ff=ff: split(r, K, 2, first_frac=ff)))
 
     # correctness first: every configuration equals the plain render bit for bit (pose 3)
