@@ -190,7 +190,18 @@ int tvr_scene_destroy(tvr_scene *scene);
  * |weight|, |appearance feature|, |activation| must stay below 65 504 (the conversion saturates there) and parts below 6e-8 are
  * flushed.  Leaving the range is REPORTED, not silent: with the scene's range check on (the default, tvr_scene_set_range_check) a sample
  * whose operands reach 65 504 renders as NaN.  Layer 3, the positional encoding, interpolation, density and compositing are plain fp32.  The shipped scenes and the reference's
- * 0.1 * randn initialisation are far inside this range (tests: |feature| up to ~1100, weights at 1e-4 scale). */
+ * 0.1 * randn initialisation are far inside this range (tests: |feature| up to ~1100, weights at 1e-4 scale).
+ * PIECES (round 6): a call of at least 2 x piece_rays rays (tvr_scene_set_render_pieces; default 30 720, so every call of 61 440 rays or more) is rendered as
+ * K = round(n / piece_rays) pieces of consecutive rays, piece k on library-owned stream k & 1 in that stream's half of `scratch`; the two streams fork from the caller's
+ * stream by an event and are joined back into it by two more before the call returns, so for the caller everything is still ordered on ITS stream (and a capture of
+ * the caller's stream captures the fork and join).  Why: the kernels of one piece take the CUs the other piece's kernels leave as they drain, and a march beside a shade
+ * kernel uses the chip's power budget better than either alone — the 800x800 bench frame takes 2 - 4 % less time (profiles/r06_split_frame.txt), pixels unchanged BIT
+ * FOR BIT (a ray's result does not depend on the batch it arrives in).  What a caller can notice: (a) the march's fault flag NaNs the pixels of the PIECE that raised
+ * it, not of the whole call; (b) tvr_profile records one launch set per piece and the kernels of two pieces overlap, so its sums are per-launch durations as a
+ * profiler would list them, not a partition of the call's wall time; (c) calls with `dense` are never cut; (d) one tvr_render(_z) at a time per scene from ONE host
+ * thread (the scene owns the two streams; calls from different caller streams queue their pieces on the same two).  tvr_scene_set_render_pieces(scene, 0) switches it off. */
+int tvr_scene_set_render_pieces(tvr_scene *scene, int32_t piece_rays);   /* 0: off; < 0: the library's default; else >= 1024 */
+int tvr_scene_get_render_pieces(const tvr_scene *scene);
 size_t tvr_render_scratch_bytes(const tvr_scene *scene, int64_t n_rays, int32_t n_samples);
 int tvr_render(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, int32_t white_bg,
                const float *jitter, float eps_T, float *rgb_out, float *depth_out,
@@ -397,7 +408,8 @@ int tvr_line_ortho(const float *const *vs, const int32_t *n_comp, const int32_t 
 int tvr_line_ortho_backward(const float *const *vs, float *const *grads, const int32_t *n_comp, const int32_t *n_size, int32_t n,
                             const float *grad_value, void *stream);
 
-/* Per-kernel HIP-event timing of tvr_render calls (march / shade / composite), for bench.py's roofline. */
+/* Per-kernel HIP-event timing of tvr_render calls (march / shade / composite), for bench.py's roofline.  max_calls bounds the CALLS recorded; a call rendered in
+ * pieces records one set of events per piece (created on first use). */
 int tvr_profile_create(int32_t max_calls, tvr_profile **out);
 int tvr_profile_reset(tvr_profile *prof);
 /* After the stream is synchronised: sums over recorded calls, ms[0..2] = march, shade, composite; returns #calls. */

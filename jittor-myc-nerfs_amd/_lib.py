@@ -94,6 +94,8 @@ SYMBOLS = {
                                       C.POINTER(C.c_float * 3), C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_scene_set_range_check": (C.c_int, [C.c_void_p, C.c_int32]),
     "tvr_scene_set_arith": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tvr_scene_set_render_pieces": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tvr_scene_get_render_pieces": (C.c_int, [C.c_void_p]),
     "tvr_scene_touch": (C.c_int, [C.c_void_p]),
     "tvr_scene_get_arith": (C.c_int, [C.c_void_p]),
     "tvr_scene_get_arith_requested": (C.c_int, [C.c_void_p]),

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -92,12 +93,34 @@ struct tvr_scene {
     bool h16_stale;            // the fp16 copies of the appearance factors are older than the fp32 images
     int arith_req;             // what tvr_scene_set_arith asked for; dev.arith is what the kernels RUN: arith_req once tvr_scene_validate_arith has measured it inside
     int arith_valid;           // its tolerance for the parameters as packed (0 = nothing validated), TVR_ARITH_F32 until then
+    // piecewise rendering (round 6, tvr_scene_set_render_pieces): a tvr_render(_z) call of at least 2 x piece_rays rays goes out as pieces of ~piece_rays consecutive rays,
+    // alternately on two library-owned streams that fork from and join the caller's stream by events
+    int piece_rays;
+    hipStream_t side[2];
+    hipEvent_t ev_fork, ev_join[2];
+    bool side_ready;
 };
 
 struct tvr_profile {
-    std::vector<hipEvent_t> ev;   // 4 per call
-    int max_calls, n_calls;
+    std::vector<hipEvent_t> ev;   // 4 per recorded launch set (one per call; one per PIECE of a call rendered piecewise)
+    int max_calls, n_calls;       // n_calls counts calls, n_sets launch sets
+    int n_sets;
 };
+
+// the default piece: measured on the 800x800 bench frame (scripts/split_frame_experiment.py, profiles/r06_split_frame.txt); TVR_PIECE_RAYS overrides it for experiments
+#ifndef TVR_DEFAULT_PIECE_RAYS
+#define TVR_DEFAULT_PIECE_RAYS 30720
+#endif
+static int default_piece_rays()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("TVR_PIECE_RAYS");
+        v = e ? atoi(e) : TVR_DEFAULT_PIECE_RAYS;
+        if (v < 0) v = 0;
+    }
+    return v;
+}
 
 // the appearance factors as fp16, from the packed fp32 images (the one-product arithmetic gathers these: half the bytes through L1)
 static int refresh_h16(tvr_scene *s, hipStream_t stream)
@@ -167,6 +190,10 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
     s->h16_stale = true;
     s->arith_req = TVR_ARITH_F32;
     s->arith_valid = 0;
+    s->piece_rays = default_piece_rays();
+    s->side[0] = s->side[1] = nullptr;
+    s->ev_fork = s->ev_join[0] = s->ev_join[1] = nullptr;
+    s->side_ready = false;
     SceneDev &v = s->dev;
     memset(&v, 0, sizeof(v));
     for (int k = 0; k < 3; ++k) {
@@ -324,8 +351,30 @@ int tvr_scene_get_arith_requested(const tvr_scene *s)
     return s->arith_req;
 }
 
+int tvr_scene_set_render_pieces(tvr_scene *s, int32_t piece_rays)
+{
+    if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_set_render_pieces: scene is NULL");
+    if (piece_rays < 0) piece_rays = default_piece_rays();
+    if (piece_rays != 0 && piece_rays < 1024) return fail(TVR_ERR_INVALID, "tvr_scene_set_render_pieces: piece_rays %d (0 = off, < 0 = the library's default, else at least 1024)", (int)piece_rays);
+    s->piece_rays = piece_rays;
+    return TVR_OK;
+}
+
+int tvr_scene_get_render_pieces(const tvr_scene *s)
+{
+    if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_get_render_pieces: scene is NULL");
+    return s->piece_rays;
+}
+
 int tvr_scene_destroy(tvr_scene *s)
 {
+    if (s && s->side_ready) {          // (the caller has synchronised whatever it enqueued on this scene: the side streams only ever carry work joined back to a caller's stream)
+        for (int i = 0; i < 2; ++i) {
+            if (s->side[i]) (void)hipStreamDestroy(s->side[i]);
+            if (s->ev_join[i]) (void)hipEventDestroy(s->ev_join[i]);
+        }
+        if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    }
     delete s;
     return TVR_OK;
 }
@@ -352,32 +401,35 @@ static ScratchLayout scratch_layout(int64_t n_rays, int32_t S)
     return L;
 }
 
+// Piecewise rendering: a call of n rays goes out as K = round(n / piece_rays) pieces of ceil(n / K) rays rounded up to 512 (the last one shorter), if that makes at least two.
+struct PiecePlan { int K; int64_t rays; };
+static PiecePlan piece_plan(const tvr_scene *s, int64_t n_rays)
+{
+    PiecePlan P = {1, n_rays};
+    const int64_t pr = s ? s->piece_rays : default_piece_rays();
+    if (pr <= 0 || n_rays < 2 * pr) return P;
+    const int64_t K = (n_rays + pr / 2) / pr;
+    P.rays = ((n_rays + K - 1) / K + 511) / 512 * 512;
+    P.K = (int)((n_rays + P.rays - 1) / P.rays);
+    if (P.K < 2) { P.K = 1; P.rays = n_rays; }
+    return P;
+}
+
 size_t tvr_render_scratch_bytes(const tvr_scene *s, int64_t n_rays, int32_t n_samples)
 {
-    (void)s;
     if (n_rays <= 0 || n_samples <= 0) return 256;
-    return scratch_layout(n_rays, n_samples).total;
+    const size_t whole = scratch_layout(n_rays, n_samples).total;
+    const PiecePlan P = piece_plan(s, n_rays);             // two pieces in flight, each with a scratch of its own carved from the caller's buffer
+    const size_t two = P.K > 1 ? 2 * scratch_layout(P.rays, n_samples).total : 0;
+    return whole > two ? whole : two;
 }
 
 }  // extern "C"
 
-static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, const MarchSampling &sm, float eps_T,
-                       float *rgb_out, float *depth_out, float *lam6_out, void *scratch, size_t scratch_bytes, const tvr_dense_out *dense,
-                       uint64_t *stats, tvr_profile *prof, void *stream_)
+// one launch set (header clear, march, shade, composite) on `stream`; ev: four events or nullptr
+static int render_one(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, const MarchSampling &sm, float eps_T, float *rgb_out, float *depth_out,
+                      float *lam6_out, char *b, const ScratchLayout &L, const tvr_dense_out *dense, uint64_t *stats, hipEvent_t *ev, hipStream_t stream)
 {
-    if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
-    if (n_rays == 0) return TVR_OK;
-    if (!rays || !rgb_out || !depth_out || n_rays < 0) return fail(TVR_ERR_INVALID, "rays/rgb_out/depth_out NULL or n_rays < 0");
-    if (S <= 0 || S > 4096) return fail(TVR_ERR_INVALID, "n_samples=%d out of [1,4096]", S);
-    if ((size_t)n_rays * (size_t)S >= (1ull << 32)) return fail(TVR_ERR_INVALID, "n_rays*n_samples must be < 2^32 per call (chunk the rays)");
-    if (!(eps_T >= 0.0f) || eps_T > s->desc.weight_thres)
-        return fail(TVR_ERR_INVALID, "eps_T=%g must be in [0, weight_thres=%g] so that no appearance sample is skipped", eps_T, s->desc.weight_thres);
-    ScratchLayout L = scratch_layout(n_rays, S);
-    if (!scratch || scratch_bytes < L.total) return fail(TVR_ERR_SCRATCH, "scratch %zu B < required %zu B", scratch_bytes, L.total);
-    if ((uintptr_t)scratch % 256) return fail(TVR_ERR_SCRATCH, "scratch must be 256-byte aligned");
-    if (prof && prof->n_calls >= prof->max_calls) return fail(TVR_ERR_INVALID, "profile is full (%d calls)", prof->max_calls);
-    hipStream_t stream = (hipStream_t)stream_;
-    char *b = (char *)scratch;
     MarchOut mo;
     mo.counter = (unsigned *)(b + L.counter);
     mo.ray_off = (unsigned *)(b + L.ray_off);
@@ -390,12 +442,6 @@ static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     mo.q_j = (dense && dense->rgb) ? (unsigned *)(b + L.q_j) : nullptr;
     mo.stats = (unsigned long long *)stats;
     mo.lam6 = lam6_out;
-
-    if (s->dev.arith == TVR_ARITH_F16 && !s->dev.gen && s->h16_stale) {        // the mode was set after the last tvr_scene_update
-        int rc16 = refresh_h16(s, stream);
-        if (rc16 != TVR_OK) return rc16;
-    }
-    hipEvent_t *ev = prof ? &prof->ev[(size_t)prof->n_calls * 4] : nullptr;
     HIP_TRY(launch_zero_header(mo.counter, stream));                   // [0] queue length, [1] the march's tile counter, [2] its fault flag, [3] unused here
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     HIP_TRY(launch_march(s->dev, rays, (int)n_rays, S, sm, eps_T, mo, dense, stream));
@@ -415,10 +461,78 @@ static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
         HIP_TRY(launch_scatter_rgb(mo, S, dense->rgb, stream));
     }
     HIP_TRY(launch_composite(mo, (int)n_rays, white_bg, rgb_out, stream));
-    if (ev) {
-        HIP_TRY(hipEventRecord(ev[3], stream));
-        prof->n_calls++;
+    if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
+    return TVR_OK;
+}
+
+static int ensure_side_streams(tvr_scene *s)
+{
+    if (s->side_ready) return TVR_OK;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_join[i], hipEventDisableTiming));
     }
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    s->side_ready = true;
+    return TVR_OK;
+}
+
+static hipEvent_t *profile_slot(tvr_profile *prof);
+
+static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t S, int32_t white_bg, const MarchSampling &sm, float eps_T,
+                       float *rgb_out, float *depth_out, float *lam6_out, void *scratch, size_t scratch_bytes, const tvr_dense_out *dense,
+                       uint64_t *stats, tvr_profile *prof, void *stream_)
+{
+    if (!s || !s->params_set) return fail(TVR_ERR_INVALID, "scene is NULL or tvr_scene_update has not run");
+    if (n_rays == 0) return TVR_OK;
+    if (!rays || !rgb_out || !depth_out || n_rays < 0) return fail(TVR_ERR_INVALID, "rays/rgb_out/depth_out NULL or n_rays < 0");
+    if (S <= 0 || S > 4096) return fail(TVR_ERR_INVALID, "n_samples=%d out of [1,4096]", S);
+    if ((size_t)n_rays * (size_t)S >= (1ull << 32)) return fail(TVR_ERR_INVALID, "n_rays*n_samples must be < 2^32 per call (chunk the rays)");
+    if (!(eps_T >= 0.0f) || eps_T > s->desc.weight_thres)
+        return fail(TVR_ERR_INVALID, "eps_T=%g must be in [0, weight_thres=%g] so that no appearance sample is skipped", eps_T, s->desc.weight_thres);
+    const size_t need = tvr_render_scratch_bytes(s, n_rays, S);
+    if (!scratch || scratch_bytes < need) return fail(TVR_ERR_SCRATCH, "scratch %zu B < required %zu B", scratch_bytes, need);
+    if ((uintptr_t)scratch % 256) return fail(TVR_ERR_SCRATCH, "scratch must be 256-byte aligned");
+    if (prof && prof->n_calls >= prof->max_calls) return fail(TVR_ERR_INVALID, "profile is full (%d calls)", prof->max_calls);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (s->dev.arith == TVR_ARITH_F16 && !s->dev.gen && s->h16_stale) {        // the mode was set after the last tvr_scene_update
+        int rc16 = refresh_h16(s, stream);
+        if (rc16 != TVR_OK) return rc16;
+    }
+    // the per-sample outputs of `dense` are a debugging / parity surface ([n,S,*] arrays): such calls stay one launch set
+    const PiecePlan P = dense ? PiecePlan{1, n_rays} : piece_plan(s, n_rays);
+    if (P.K == 1) {
+        hipEvent_t *ev = nullptr;
+        if (prof && !(ev = profile_slot(prof))) return fail(TVR_ERR_HIP, "tvr_profile: hipEventCreate failed");
+        int rc = render_one(s, rays, n_rays, S, white_bg, sm, eps_T, rgb_out, depth_out, lam6_out, (char *)scratch, scratch_layout(n_rays, S), dense, stats, ev, stream);
+        if (rc != TVR_OK) return rc;
+        if (prof) prof->n_calls++;
+        return TVR_OK;
+    }
+    // Piecewise (round 6): the overlap measured ACROSS frames with two frames in flight (round 5, render.FrameStream: 18.8 vs 19.7 ms) inside ONE call.  Piece k runs on
+    // library-owned stream k & 1 in that stream's half of the caller's scratch; the two streams fork from the caller's stream by an event and are joined back into it by
+    // two more, so the caller sees what it saw before: everything ordered on its stream.  The persistent kernels of one piece take the CUs the other piece's kernels leave
+    // as they drain, and a march (L1-bound, 2.1 GHz) beside a shade kernel (matrix-bound, 1.75 GHz) shares the chip's power budget better than either alone.  Every ray's
+    // result is independent of the batch it arrives in (bit for bit: tests/test_gpu_parity.py), so the pixels are those of the one-piece call.
+    int rc = ensure_side_streams(s);
+    if (rc != TVR_OK) return rc;
+    const ScratchLayout Lp = scratch_layout(P.rays, S);
+    HIP_TRY(hipEventRecord(s->ev_fork, stream));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(s->side[i], s->ev_fork, 0));
+    for (int k = 0; k < P.K; ++k) {
+        const int64_t a = (int64_t)k * P.rays, m = (a + P.rays <= n_rays) ? P.rays : n_rays - a;
+        const MarchSampling smk = {sm.jitter ? sm.jitter + a : nullptr, sm.zv ? sm.zv + (size_t)a * S : nullptr};
+        hipEvent_t *ev = nullptr;
+        if (prof && !(ev = profile_slot(prof))) return fail(TVR_ERR_HIP, "tvr_profile: hipEventCreate failed");
+        rc = render_one(s, rays + 6 * a, m, S, white_bg, smk, eps_T, rgb_out + 3 * a, depth_out + a, lam6_out ? lam6_out + a : nullptr,
+                        (char *)scratch + (size_t)(k & 1) * Lp.total, Lp, nullptr, stats, ev, s->side[k & 1]);
+        if (rc != TVR_OK) return rc;
+    }
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventRecord(s->ev_join[i], s->side[i]));
+        HIP_TRY(hipStreamWaitEvent(stream, s->ev_join[i], 0));
+    }
+    if (prof) prof->n_calls++;
     return TVR_OK;
 }
 
@@ -1269,11 +1383,8 @@ int tvr_profile_create(int32_t max_calls, tvr_profile **out)
     if (!p) return fail(TVR_ERR_INVALID, "out of host memory");
     p->max_calls = max_calls;
     p->n_calls = 0;
-    p->ev.resize((size_t)max_calls * 4);
-    for (auto &e : p->ev) {
-        hipError_t rc = hipEventCreate(&e);
-        if (rc != hipSuccess) { delete p; return fail(TVR_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(rc)); }
-    }
+    p->n_sets = 0;
+    p->ev.reserve((size_t)max_calls * 4);      // events are created as launch sets are recorded (a piecewise call records one set per piece) and kept across resets
     *out = p;
     return TVR_OK;
 }
@@ -1282,6 +1393,7 @@ int tvr_profile_reset(tvr_profile *p)
 {
     if (!p) return fail(TVR_ERR_INVALID, "profile is NULL");
     p->n_calls = 0;
+    p->n_sets = 0;
     return TVR_OK;
 }
 
@@ -1289,7 +1401,7 @@ int tvr_profile_read(tvr_profile *p, float ms[3])
 {
     if (!p || !ms) return fail(TVR_ERR_INVALID, "profile/ms is NULL");
     ms[0] = ms[1] = ms[2] = 0.f;
-    for (int c = 0; c < p->n_calls; ++c)
+    for (int c = 0; c < p->n_sets; ++c)
         for (int k = 0; k < 3; ++k) {
             float t = 0.f;
             hipError_t rc = hipEventElapsedTime(&t, p->ev[(size_t)c * 4 + k], p->ev[(size_t)c * 4 + k + 1]);
@@ -1298,6 +1410,22 @@ int tvr_profile_read(tvr_profile *p, float ms[3])
         }
     return p->n_calls;
 }
+
+}  // extern "C"
+
+// four events for the next launch set (created on first use, re-used after tvr_profile_reset)
+static hipEvent_t *profile_slot(tvr_profile *prof)
+{
+    const size_t need = ((size_t)prof->n_sets + 1) * 4;
+    while (prof->ev.size() < need) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        prof->ev.push_back(e);
+    }
+    return &prof->ev[(size_t)prof->n_sets++ * 4];
+}
+
+extern "C" {
 
 int tvr_profile_destroy(tvr_profile *p)
 {

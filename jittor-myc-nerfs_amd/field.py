@@ -319,6 +319,7 @@ class TensorBase(torch.nn.Module):
             self._sig = None
             self._alpha_dirty = True
             self._arith_set = None
+            self._pieces_set = "unset"
         if force or sig != self._sig:
             for p in ps:
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.device != self._packed.device:
@@ -356,6 +357,9 @@ class TensorBase(torch.nn.Module):
                 L.check(lib.tvr_scene_set_alpha(self._scene, am.alpha_volume.data_ptr(), C.byref(ag), C.byref(ab), C.byref(inv),
                                                 self._alpha_bits.data_ptr(), self._alpha_bits.numel(), _stream_ptr(self.device)), "tvr_scene_set_alpha")
             self._alpha_dirty = False
+        if getattr(self, "_pieces_set", "unset") != self.render_piece_rays:
+            L.check(lib.tvr_scene_set_render_pieces(self._scene, -1 if self.render_piece_rays is None else int(self.render_piece_rays)), "tvr_scene_set_render_pieces")
+            self._pieces_set = self.render_piece_rays
         if getattr(self, "_arith_set", None) != self.mlp_arith:
             if self.mlp_arith not in self._ARITH:
                 raise ValueError(f"mlp_arith must be one of {sorted(self._ARITH)}, got {self.mlp_arith!r}")
@@ -369,6 +373,10 @@ class TensorBase(torch.nn.Module):
     # compares.  max |difference| <= `mlp_arith_tol` (default 2.5e-4: a quarter of north_star's 1e-3 bar): the mode is in effect; otherwise the scene keeps computing
     # in "f32", a RuntimeWarning says so once per parameter state, and `arith_in_effect` / `arith_max_diff` tell.  No interval bound from the parameters can do this
     # job: |W| |x| bounds overestimate the error a thousandfold (scripts: DESIGN.md 4.7), a measurement on the scene's own rays does not.
+    # tvr_render in pieces (include/tvr.h, PIECES): None = the library's default piece (30 720 rays: calls of 61 440 rays or more go out as pieces on two library-owned
+    # streams, joined back into the caller's stream); 0 = one launch set per call, as before round 6; else the piece size in rays
+    render_piece_rays = None
+
     mlp_arith_tol = 2.5e-4
     arith_probe_rays = 8192
     arith_in_effect = "f32"

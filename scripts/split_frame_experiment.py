@@ -27,11 +27,15 @@ def main():
     ap.add_argument("--K2", default="2,3,4,6,8,12,16,24", help="piece counts tried on two streams")
     ap.add_argument("--K3", default="6,9,12", help="piece counts tried on three streams")
     ap.add_argument("--stagger", default="5:0.1,9:0.06", help="K:first-piece-fraction pairs (two streams)")
+    ap.add_argument("--pieces", default="", help="piece sizes in rays (uniform pieces, the last one shorter), two streams")
+    ap.add_argument("--rays", type=int, default=0, help="render only the first N rays of each frame (a rank's share)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     model, arrs, A = bench.build_model(dev, args.model)
     S = A["N_samples"]
     fr = [f.to(dev) for f in bench.frames(A)]
+    if args.rays:
+        fr = [f[:args.rays].contiguous() for f in fr]
     n = fr[0].shape[0]
     streams = [torch.cuda.Stream(dev) for _ in range(3)]
     rgb = torch.empty((n, 3), device=dev)
@@ -40,10 +44,12 @@ def main():
     def plain(rays):
         return model.render_rays(rays, white_bg=True, N_samples=S, out=(rgb, depth))
 
-    def split(rays, K, n_streams=2, first_frac=None, align=4096):
+    def split(rays, K, n_streams=2, first_frac=None, align=4096, piece=0):
         cur = torch.cuda.current_stream(dev)
         # piece boundaries: K pieces of (roughly) equal size, multiples of `align` rays; optionally a smaller first piece (a stagger)
-        if first_frac is None:
+        if piece:
+            edges = list(range(0, n, piece)) + [n]
+        elif first_frac is None:
             edges = [min(n, ((n * k // K + align - 1) // align) * align) for k in range(K)] + [n]
         else:
             first = int(n * first_frac / align) * align
@@ -73,6 +79,9 @@ def main():
     for kv in [x for x in args.stagger.split(",") if x]:
         K, ff = int(kv.split(":")[0]), float(kv.split(":")[1])
         configs.append((f"K={K} 2 streams, first piece {ff:g}", lambda r, K=K, ff=ff: split(r, K, 2, first_frac=ff)))
+
+    for ps in [int(x) for x in args.pieces.split(",") if x]:
+        configs.append((f"pieces of {ps} rays, 2 streams", lambda r, ps=ps: split(r, 0, 2, piece=ps)))
 
     # correctness first: every configuration equals the plain render bit for bit (pose 3)
     ref = [t.clone() for t in plain(fr[3])]
