@@ -192,7 +192,7 @@ int tvr_scene_destroy(tvr_scene *scene);
  * whose operands reach 65 504 renders as NaN.  Layer 3, the positional encoding, interpolation, density and compositing are plain fp32.  The shipped scenes and the reference's
  * 0.1 * randn initialisation are far inside this range (tests: |feature| up to ~1100, weights at 1e-4 scale).
  * PIECES (round 6): a call of at least 2 x piece_rays rays (tvr_scene_set_render_pieces; default 30 720, so every call of 61 440 rays or more) is rendered as
- * K = round(n / piece_rays) pieces of consecutive rays, piece k on library-owned stream k & 1 in that stream's half of `scratch`; the two streams fork from the caller's
+ * K = round(n / piece_rays) pieces of consecutive rays (equal sizes, multiples of 512 rays, the last one shorter), piece k on library-owned stream k & 1 in that stream's half of `scratch`; the two streams fork from the caller's
  * stream by an event and are joined back into it by two more before the call returns, so for the caller everything is still ordered on ITS stream (and a capture of
  * the caller's stream captures the fork and join).  Why: the kernels of one piece take the CUs the other piece's kernels leave as they drain, and a march beside a shade
  * kernel uses the chip's power budget better than either alone — the 800x800 bench frame takes 2 - 4 % less time (profiles/r06_split_frame.txt), pixels unchanged BIT
@@ -200,7 +200,7 @@ int tvr_scene_destroy(tvr_scene *scene);
  * it, not of the whole call; (b) tvr_profile records one launch set per piece and the kernels of two pieces overlap, so its sums are per-launch durations as a
  * profiler would list them, not a partition of the call's wall time; (c) calls with `dense` are never cut; (d) one tvr_render(_z) at a time per scene from ONE host
  * thread (the scene owns the two streams; calls from different caller streams queue their pieces on the same two).  tvr_scene_set_render_pieces(scene, 0) switches it off. */
-int tvr_scene_set_render_pieces(tvr_scene *scene, int32_t piece_rays);   /* 0: off; < 0: the library's default; else >= 1024 */
+int tvr_scene_set_render_pieces(tvr_scene *scene, int32_t piece_rays);   /* 0: off; < 0: the library's default; else >= 16 (pieces are rounded up to multiples of 512 rays, of 16 below 512) */
 int tvr_scene_get_render_pieces(const tvr_scene *scene);
 size_t tvr_render_scratch_bytes(const tvr_scene *scene, int64_t n_rays, int32_t n_samples);
 int tvr_render(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, int32_t white_bg,

@@ -355,7 +355,7 @@ int tvr_scene_set_render_pieces(tvr_scene *s, int32_t piece_rays)
 {
     if (!s) return fail(TVR_ERR_INVALID, "tvr_scene_set_render_pieces: scene is NULL");
     if (piece_rays < 0) piece_rays = default_piece_rays();
-    if (piece_rays != 0 && piece_rays < 1024) return fail(TVR_ERR_INVALID, "tvr_scene_set_render_pieces: piece_rays %d (0 = off, < 0 = the library's default, else at least 1024)", (int)piece_rays);
+    if (piece_rays != 0 && piece_rays < 16) return fail(TVR_ERR_INVALID, "tvr_scene_set_render_pieces: piece_rays %d (0 = off, < 0 = the library's default, else at least 16)", (int)piece_rays);
     s->piece_rays = piece_rays;
     return TVR_OK;
 }
@@ -408,8 +408,8 @@ static PiecePlan piece_plan(const tvr_scene *s, int64_t n_rays)
     PiecePlan P = {1, n_rays};
     const int64_t pr = s ? s->piece_rays : default_piece_rays();
     if (pr <= 0 || n_rays < 2 * pr) return P;
-    const int64_t K = (n_rays + pr / 2) / pr;
-    P.rays = ((n_rays + K - 1) / K + 511) / 512 * 512;
+    const int64_t K = (n_rays + pr / 2) / pr, q = pr >= 512 ? 512 : 16;          // (pieces below 512 rays: tests on tiny fixtures)
+    P.rays = ((n_rays + K - 1) / K + q - 1) / q * q;
     P.K = (int)((n_rays + P.rays - 1) / P.rays);
     if (P.K < 2) { P.K = 1; P.rays = n_rays; }
     return P;

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--K3", default="6,9,12", help="piece counts tried on three streams")
     ap.add_argument("--stagger", default="5:0.1,9:0.06", help="K:first-piece-fraction pairs (two streams)")
     ap.add_argument("--pieces", default="", help="piece sizes in rays (uniform pieces, the last one shorter), two streams")
+    ap.add_argument("--lists", default="", help="explicit piece-size lists, ';'-separated, each 'name=a,b,c*N,...' (c*N repeats; the remainder of the frame is cut into pieces of the last size)")
     ap.add_argument("--rays", type=int, default=0, help="render only the first N rays of each frame (a rank's share)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -44,10 +45,18 @@ def main():
     def plain(rays):
         return model.render_rays(rays, white_bg=True, N_samples=S, out=(rgb, depth))
 
-    def split(rays, K, n_streams=2, first_frac=None, align=4096, piece=0):
+    def split(rays, K, n_streams=2, first_frac=None, align=4096, piece=0, sizes=None):
         cur = torch.cuda.current_stream(dev)
         # piece boundaries: K pieces of (roughly) equal size, multiples of `align` rays; optionally a smaller first piece (a stagger)
-        if piece:
+        if sizes:
+            edges, a = [0], 0
+            for sz in sizes:
+                a = min(n, a + sz)
+                edges.append(a)
+            while a < n:
+                a = min(n, a + sizes[-1])
+                edges.append(a)
+        elif piece:
             edges = list(range(0, n, piece)) + [n]
         elif first_frac is None:
             edges = [min(n, ((n * k // K + align - 1) // align) * align) for k in range(K)] + [n]
@@ -82,6 +91,17 @@ def main():
 
     for ps in [int(x) for x in args.pieces.split(",") if x]:
         configs.append((f"pieces of {ps} rays, 2 streams", lambda r, ps=ps: split(r, 0, 2, piece=ps)))
+
+    for spec in [x for x in args.lists.split(";") if x]:
+        name, body = spec.split("=")
+        sizes = []
+        for tok in body.split(","):
+            if "*" in tok:
+                v, r = tok.split("*")
+                sizes += [int(v)] * int(r)
+            else:
+                sizes.append(int(tok))
+        configs.append((f"list {name}", lambda r, sizes=sizes: split(r, 0, 2, sizes=sizes)))
 
     # correctness first: every configuration equals the plain render bit for bit (pose 3)
     ref = [t.clone() for t in plain(fr[3])]

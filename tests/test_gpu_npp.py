@@ -35,6 +35,11 @@ def test_npp_render_against_golden(tiny_npp, tiny_npp_arrays, hyper_tiny):
     assert np.abs(_np(fg) - tiny_npp["out.fg_rgb_map"]).max() < 1e-4
     lam_t = torch.where(lam > 0.1, lam, torch.zeros_like(lam))
     assert np.abs(_np(lam_t) - tiny_npp["out.bg_lambda"]).max() < 1e-5
+    # tvr_render_z in pieces (round 6; z_vals, t_last_tiny and the outputs are offset per piece): four pieces of 16 rays on two streams, bit for bit the one-launch-set call
+    m.render_piece_rays = 16
+    fg_p, dep_p, lam_p = m._render_z(rays, z, TINY["N_samples"], 0.0)
+    m.render_piece_rays = None
+    assert torch.equal(fg_p, fg) and torch.equal(lam_p, lam)
     # default early termination stays inside the bar; results do not depend on the batch order
     m.eps_T = None
     with torch.no_grad():

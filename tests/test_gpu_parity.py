@@ -522,6 +522,72 @@ def test_frame_stream_two_in_flight(config1_golden):
         assert torch.equal(a, c) and torch.equal(b, d)
 
 
+def test_render_in_pieces_equals_one_launch_set(config1_golden):
+    """Round 6 (include/tvr.h, PIECES): a tvr_render call of at least two pieces' worth of rays goes out as pieces of consecutive rays on two library-owned streams, forked from
+    and joined into the caller's stream.  A ray's result does not depend on the batch it arrives in, so pixels, depths and counters equal the one-launch-set call BIT FOR BIT
+    — with jitter, with a ragged last piece, back to back (the two halves of the scratch are reused), under a profile (one event set per piece), captured into a hipGraph;
+    `dense` calls are never cut; the scratch query covers two pieces."""
+    import ctypes as C
+    from jittor_myc_nerfs_amd import _lib as L, synthetic
+    B = synthetic.SCENE_B
+    arrs = synthetic.make_scene_arrays(B["gridSize"], B["aabb"])
+    m = make_model(arrs, dict(synthetic.HYPER, near_far=B["near_far"], step_ratio=B["step_ratio"]))
+    base = torch.tensor(config1_golden["rays"], device="cuda")                      # 4096 rays
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rays = torch.cat([base + torch.cat([0.03 * torch.randn((base.shape[0], 3), device="cuda", generator=g), torch.zeros((base.shape[0], 3), device="cuda")], 1)
+                      for _ in range(3)])[: 3 * 4096 - 333].contiguous()           # 11 955 rays
+    jit = torch.rand(rays.shape[0], device="cuda", generator=g)
+    S = B["N_samples"]
+    m.render_piece_rays = 0
+    st0 = torch.zeros(8, dtype=torch.int64, device="cuda")
+    want = [t.clone() for t in m.render_rays(rays, white_bg=True, N_samples=S, stats=st0)]
+    want_j = [t.clone() for t in m.render_rays(rays, white_bg=True, N_samples=S, jitter=jit)]
+    for piece in (1024, 2560, 4096):                                                # 12 / 5 / 3 pieces, the last one ragged
+        m.render_piece_rays = piece
+        sc = m._ensure_scene()
+        assert L.lib().tvr_scene_get_render_pieces(sc) == piece
+        st1 = torch.zeros(8, dtype=torch.int64, device="cuda")
+        prof = C.c_void_p()
+        L.check(L.lib().tvr_profile_create(4, C.byref(prof)), "tvr_profile_create")
+        for rep in range(2):
+            got = m.render_rays(rays, white_bg=True, N_samples=S, stats=st1 if rep == 0 else None, profile=prof)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (piece, rep)
+        got_j = m.render_rays(rays, white_bg=True, N_samples=S, jitter=jit)
+        assert torch.equal(got_j[0], want_j[0]) and torch.equal(got_j[1], want_j[1])
+        torch.cuda.synchronize()
+        assert torch.equal(st1[:4], st0[:4])                                        # the same samples evaluated and shaded, the same rays terminated
+        ms = (C.c_float * 3)()
+        assert L.lib().tvr_profile_read(prof, C.byref(ms)) == 2 and all(x > 0 for x in ms)
+        L.lib().tvr_profile_destroy(prof)
+        # a call with per-sample outputs stays ONE launch set (and equals the piecewise picture)
+        rgb_d, dep_d, dd = m.render_rays(rays, white_bg=True, N_samples=S, dense=True)
+        assert torch.equal(rgb_d, want[0]) and dd["weight"].shape == (rays.shape[0], S)
+        # captured: the fork and the join are part of the caller's graph
+        out = (torch.empty_like(want[0]), torch.empty_like(want[1]))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m.render_rays(rays, white_bg=True, N_samples=S, out=out)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            m.render_rays(rays, white_bg=True, N_samples=S, out=out)
+        out[0].fill_(-1)
+        out[1].fill_(-1)
+        gr.replay()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]), ("graph", piece)
+        del gr
+    # the size query: two pieces' scratch fits what the query returns, and the library refuses less
+    sc = m._ensure_scene()
+    need = L.lib().tvr_render_scratch_bytes(sc, rays.shape[0], S)
+    assert need >= 2 * L.lib().tvr_render_scratch_bytes(None, 4096, S) - 4096
+    assert L.lib().tvr_scene_set_render_pieces(sc, 7) == -1 and L.lib().tvr_scene_set_render_pieces(sc, -1) == 0
+    assert L.lib().tvr_scene_get_render_pieces(sc) == 30720
+
+
 def test_frame_stream_serialises_around_a_scene_update(config1_golden):
     """Parameters written between two submits: the re-pack (tvr_scene_update on the new frame's stream) must not run beside the frame still in flight on the other stream,
     which reads the same packed images — FrameStream drains before such a frame and before the one after it (field.scene_settled).  Every frame equals the serial render
