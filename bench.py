@@ -527,18 +527,15 @@ def main():
     if args.chunk > 0 and args.chunk_stream:
         from jittor_myc_nerfs_amd import FrameStream
         chunk_fs = FrameStream(model, white_bg=True, N_samples=S, eps_T=args.eps_T)
+        chunk_out = (torch.empty((n_mine, 3), device=device), torch.empty((n_mine,), device=device))
 
     def step(s, profile=None, stats=None):
         rays = step_rays[s % n_patterns]
         if args.chunk > 0 and args.chunk_stream:                    # the same chunk loop with two calls in flight (render.FrameStream: call k on stream k % 2)
-            outs = []
-            for c0 in range(0, rays.shape[0], args.chunk):
-                prev = chunk_fs.submit(rays[c0:c0 + args.chunk])
-                if prev is not None:
-                    outs.append((prev[0].clone(), prev[1].clone()))        # (a slot's buffers come round again two submits later)
-            last = chunk_fs.flush()
-            outs.append((last[0].clone(), last[1].clone()))
-            rgb, depth = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+            rgb, depth = chunk_out
+            for c0 in range(0, rays.shape[0], args.chunk):          # every call renders into its slice of one frame-sized output pair
+                chunk_fs.submit(rays[c0:c0 + args.chunk], out=(rgb[c0:c0 + args.chunk], depth[c0:c0 + args.chunk]))
+            chunk_fs.flush()
         elif args.chunk > 0:                                        # renderer.py:16-25 chunk loop, one tvr_render per chunk, no host sync
             outs = [model.render_rays(rays[c0:c0 + args.chunk], white_bg=True, N_samples=S, eps_T=args.eps_T, stats=stats)
                     for c0 in range(0, rays.shape[0], args.chunk)]

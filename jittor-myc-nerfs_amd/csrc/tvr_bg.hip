@@ -30,6 +30,17 @@
 #ifndef TVR_BG_APF
 #define TVR_BG_APF 0
 #endif
+// Round 6: the STREAMED form (default).  The fragment image lies in the order the kernel consumes it and moves through two 64 KB halves of LDS in chunks of at most
+// BG_HALF_BLOCKS blocks: while every wave computes on the chunk in one half, the next chunk arrives in the other by LDS-DMA (global_load_lds_dwordx4: no registers, no
+// ds_write), ONE workgroup barrier per chunk.  Round 5's form (two 154 KB stages, each loaded synchronously between two barriers: 4 barriers and 300 KB of exposed
+// L2 -> LDS traffic per 256 samples, measured at 11 % of the kernel: profiles/r06_bg_kernel.txt) stays selectable with -DTVR_BG_STREAM=0 for A/B builds.
+#ifndef TVR_BG_STREAM
+#define TVR_BG_STREAM 1
+#endif
+#define BG_HALF_BLOCKS 32
+#define BG_HALF_BYTES (BG_HALF_BLOCKS * 2048)
+#define BG_MAX_CHUNKS 8
+#define BG_LDS_STREAM_BYTES (2 * BG_HALF_BYTES + BG_BIAS_FLOATS * 4)
 
 // training forward: what the backward needs (all optional, NULL = inference) — relu outputs of the base layers [M,128] each, of the rgb hidden layer
 // [M,64], and the sigma head's value before `abs` [M]
@@ -48,6 +59,12 @@ struct BgProgram {
     int base_prev[4], base_pe[4];             // does the layer read the previous activations / the point embedding
     int sig_block0, rgbh_block0, rgbo_block0; // inside stage B
     int samples_per_ray;
+    // the streamed form: the image in consumption order — per base layer [the 8 k-steps of the previous activations x 4 row blocks][the n_pe_steps of the point
+    // embedding x 4], then the heads [8 k-steps x {sigma, rgb-hidden 0, rgb-hidden 1}][view k-step x 2][4 k-steps of the rgb output].  Units (what a chunk is made of):
+    // half a layer's previous-activation part (16 blocks), a layer's embedding part (<= 12), the heads (30); bit u of bnd_mask: unit u opens a chunk.
+    int prev_blk0[4], pe_blk0[4], heads_blk0;
+    int n_chunks, chunk_blk0[BG_MAX_CHUNKS], chunk_nblk[BG_MAX_CHUNKS];
+    unsigned bnd_mask;
 };
 
 // ------------------------------------------------------------------------------------------------ packing
@@ -375,6 +392,277 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_kernel(BgProgram P, c
 }
 __global__ void bg_zero_ticket_kernel(unsigned *tk) { *tk = 0u; }
 
+// ------------------------------------------------------------------------------------------------ the streamed kernel (round 6)
+typedef __attribute__((address_space(3))) void bg_lds_void;
+typedef __attribute__((address_space(1))) const void bg_glb_void;
+struct AF { uint4 h, l; };
+#define BG_SB __builtin_amdgcn_sched_barrier(0)
+#define BG_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
+#define BG_SG_VALU(n) __builtin_amdgcn_sched_group_barrier(0x402, (n), 0)      // VALU | TRANS
+#define BG_SG_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
+#ifndef TVR_BG_SCHED
+#define TVR_BG_SCHED 1            // sched_group_barrier windows in the units (0: hipcc's own order, A/B)
+#endif
+#ifndef TVR_BG_PRIOFLIP
+#define TVR_BG_PRIOFLIP 0         // experiment: the two waves of a SIMD (w and w + 4) take turns at priority 1, k-step by k-step (keeps them abreast between the chunk barriers)
+#endif
+#ifndef TVR_BG_TIMING
+#define TVR_BG_TIMING 0           // diagnostic build: per-phase s_memtime sums of every wave into the work buffer's words 8.. (scripts/bg_phase_timing.py)
+#endif
+#if TVR_BG_TIMING
+#define BG_STAMP(x) { __builtin_amdgcn_sched_barrier(0); x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define BG_STAMP(x)
+#endif
+#ifndef TVR_BG_PD
+#define TVR_BG_PD 1               // fragment blocks read ahead of the one being multiplied (ring of TVR_BG_PD + 2 {hi, lo} pairs: 8 registers each)
+#endif
+#define BG_RN (TVR_BG_PD + 2)
+// the three products of one fragment block on ONE accumulator, back to back (a dependent chain of 32x32x16 MFMAs issues back to back: profiles/r04_mfma_issue_probe.txt);
+// per accumulator the order of the additions is tvr_mfma.h's / round 5's: Wlo*xhi, Whi*xlo, Whi*xhi
+template <int AR>
+__device__ __forceinline__ void mfma3(const AF &A, const Frag &b, f32x16 &acc)
+{
+    if constexpr (AR >= 2) acc = MFMAH(A.l, b.hi, acc);
+    if constexpr (AR >= 3) acc = MFMAH(A.h, b.lo, acc);
+    acc = MFMAH(A.h, b.hi, acc);
+}
+// One unit: NG k-steps x NB row blocks whose fragment blocks lie consecutively at `lb` (this lane's LDS address of the unit's first block).  hipcc's own schedule puts a
+// k-step's A-fragment reads right in front of their MFMAs — `ds_read, s_waitcnt, MFMA` ~75 times per tile (scripts/isa_trace.py on round 5's kernel) — so the reads run
+// TWO BLOCKS AHEAD here through a ring of four {hi, lo} pairs (32 registers), a fragment lives for three MFMAs, and the next k-step's B fragment (relu + fp16 split, or the
+// embedding's sin / cos) is derived under the MFMAs of this one (VPG vector instructions per MFMA gap), as in tvr_shade.hip's matrix phase.
+template <int NB, int NG, int AR, int VPG, typename GetB, typename Hook>
+__device__ __forceinline__ void run_unit(const unsigned char *lb, f32x16 (&acc)[NB], GetB getB, Hook hook)
+{
+    constexpr int NQ = NB * NG;
+    AF ring[BG_RN];
+    auto ld = [&](int q) {
+        ring[q % BG_RN].h = *(const uint4 *)(lb + q * 2048);
+        if constexpr (AR >= 2) ring[q % BG_RN].l = *(const uint4 *)(lb + q * 2048 + 1024);
+    };
+#pragma unroll
+    for (int q0 = 0; q0 < TVR_BG_PD; ++q0)
+        if (q0 < NQ) ld(q0);
+    Frag b = getB(0), nb = b;
+    BG_SB;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        hook();                                                         // (one LDS-DMA piece of the next chunk per k-step: see the kernel)
+        BG_SB;
+        if (g + 1 < NG) nb = getB(g + 1);
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int q = g * NB + m;
+            if (q + TVR_BG_PD < NQ) ld(q + TVR_BG_PD);
+            mfma3<AR>(ring[q % BG_RN], b, acc[m]);
+        }
+#if TVR_BG_SCHED
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            if (g * NB + m + TVR_BG_PD < NQ) BG_SG_DSR(AR >= 2 ? 2 : 1);
+            if (AR >= 2) { BG_SG_MFMA(1); if (g + 1 < NG) BG_SG_VALU(VPG); }
+            if (AR >= 3) { BG_SG_MFMA(1); if (g + 1 < NG) BG_SG_VALU(VPG); }
+            BG_SG_MFMA(1);
+            if (g + 1 < NG) BG_SG_VALU(VPG);
+        }
+#endif
+        if (g + 1 < NG) b = nb;
+        BG_SB;
+    }
+}
+
+template <int AR>
+__global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_stream_kernel(BgProgram P, const uint4 *__restrict__ image, const float *__restrict__ bias,
+                                                                        const float *__restrict__ pts, const float *__restrict__ viewdirs, long long M,
+                                                                        float *__restrict__ rgb, float *__restrict__ sigma, const BgTrain T, unsigned *__restrict__ tk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ long long s_next;
+    float *lbias = reinterpret_cast<float *>(smem + 2 * BG_HALF_BYTES);
+    for (int e = threadIdx.x; e < BG_BIAS_FLOATS; e += BG_WAVES * 64) lbias[e] = bias[e];            // (visible behind the first chunk's barrier)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, col = lane & 31;
+    constexpr int PER_SUPER = 32 * BG_WAVES;
+    const long long n_super = (M + PER_SUPER - 1) / PER_SUPER;
+
+    // ---- the chunk stream.  cn: the chunk (index within a tile) the next boundary opens; hsel: the half it arrives in.  The DMA of a chunk is issued one whole chunk of
+    // compute before its first read, by all eight waves (1 KB pieces, piece p by wave p % 8): at a boundary every wave waits for its own pieces (vmcnt(0)), the barrier
+    // then says that ALL pieces have landed and that nobody reads the other half any more — which the chunk after next may now overwrite.
+    int cn = 0, hsel = 0;
+    unsigned cur = 0;                                                   // LDS byte offset of the next unit's first block
+    // The pieces of a chunk's DMA are NOT issued in one burst behind the barrier: an LDS-DMA instruction holds its wave for ~100 cycles (measured here: 4 060 cycles per
+    // tile and wave for 37.5 pieces, with both waves of every SIMD bursting at once and nobody feeding the matrix pipe — profiles/r06_bg_kernel.txt).  A wave issues ONE
+    // piece per k-step of the chunk it computes on (dma_step, the hook of run_unit) and whatever is left at the next boundary.
+    int dma_p = 0, dma_n = 0;                                           // this wave's next piece / the chunk's piece count
+    const unsigned char *dma_src = nullptr;
+    unsigned dma_dst = 0;
+    unsigned flip = (unsigned)(wave >> 2);
+    auto dma_step = [&]() {
+#if TVR_BG_PRIOFLIP
+        flip ^= 1u;
+        if (flip) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#endif
+        if (dma_p < dma_n) {
+            __builtin_amdgcn_global_load_lds((bg_glb_void *)(dma_src + (size_t)dma_p * 1024), (bg_lds_void *)(smem + dma_dst + dma_p * 1024), 16, 0, 0);
+            dma_p += BG_WAVES;
+        }
+    };
+    auto issue_dma = [&](int c, int half) {                             // arm the DMA of chunk c into `half`
+        dma_n = P.chunk_nblk[c] * 2;
+        dma_src = reinterpret_cast<const unsigned char *>(image) + (size_t)P.chunk_blk0[c] * 2048 + lane * 16;
+        dma_dst = (unsigned)half * BG_HALF_BYTES;
+        dma_p = wave;
+    };
+#if TVR_BG_TIMING
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0, tb = 0, tc = 0, td = 0;
+#endif
+    auto enter_chunk = [&]() {
+        BG_STAMP(ta);
+        while (dma_p < dma_n) dma_step();                               // (a chunk with fewer k-steps than pieces per wave: the rest now)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BG_STAMP(tb);
+        __syncthreads();
+        BG_STAMP(tc);
+        cur = (unsigned)hsel * BG_HALF_BYTES;
+        cn = cn + 1 == P.n_chunks ? 0 : cn + 1;
+        hsel ^= 1;
+        issue_dma(cn, hsel);                                            // the NEXT chunk (the next tile's first, behind a tile's last) into the half just vacated
+        BG_STAMP(td);
+#if TVR_BG_TIMING
+        tsum[1] += tb - ta; tsum[2] += tc - tb; tsum[3] += td - tc;
+#endif
+    };
+    issue_dma(0, 0);
+
+    // Tickets (round 5) without a barrier of their own (round 6): thread 0 publishes the NEXT tile's number in front of this tile's first chunk barrier and every wave
+    // reads it behind that barrier — a whole tile before it is needed, so the next tile's points are fetched under this tile's layers.
+    unsigned tk_pending = 0;
+    if (tk && threadIdx.x == 0) tk_pending = atomicAdd(tk, 1u);
+    float4 p_next;
+    {
+        const long long s0 = ((long long)blockIdx.x * BG_WAVES + wave) * 32 + col;
+        p_next = *reinterpret_cast<const float4 *>(pts + 4 * min(s0, M - 1));
+    }
+    for (long long super = blockIdx.x; super < n_super;) {
+#if TVR_BG_TIMING
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#endif
+        BG_STAMP(t0);
+        int hh = h;
+        unsigned lane16 = (unsigned)(size_t)(smem + lane * 16);
+        asm volatile("" : "+v"(hh), "+v"(lane16));                      // opaque per tile: keeps per-lane selects / LDS addresses from being hoisted out of the loop
+        if (threadIdx.x == 0) {
+            const long long nx = tk ? (long long)gridDim.x + (long long)tk_pending : super + gridDim.x;
+            s_next = nx;
+            if (tk && nx < n_super) tk_pending = atomicAdd(tk, 1u);
+        }
+        enter_chunk();                                                  // the tile's first chunk (unit 0 always opens one)
+        const long long super_next = s_next;                            // (thread 0 writes it again in front of the NEXT tile's first barrier: four barriers from here)
+        int u = 0;                                                      // unit counter of this tile (uniform)
+        auto unit_ptr = [&]() -> const unsigned char * {                // boundary check + this lane's LDS address of the unit's first block (ONE register: the reads use immediates)
+            if (u > 0 && ((P.bnd_mask >> u) & 1u)) enter_chunk();
+            ++u;
+            unsigned a = lane16 + cur;
+            asm volatile("" : "+v"(a));
+            return (const unsigned char *)(const void __attribute__((address_space(3))) *)(size_t)a;
+        };
+        const long long s = (super * BG_WAVES + wave) * 32 + col, sr = min(s, M - 1), s_store = s < M ? s : -1;
+        const float4 p = p_next;
+        {
+            const long long sn = (super_next * BG_WAVES + wave) * 32 + col;
+            p_next = *reinterpret_cast<const float4 *>(pts + 4 * min(sn, M - 1));        // (a tile number beyond the last one reads the last sample's point: never used)
+        }
+        const float x[4] = {p.x, p.y, p.z, p.w};
+#if TVR_BG_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (timing build: the sample's point is here before the clock is read)
+#endif
+        BG_STAMP(t1);
+        f32x16 act[4];
+        // ---------------- base layers
+        for (int l = 0; l < P.D; ++l) {
+            f32x16 out[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) out[mb] = bias_acc(lbias + l * 128 + mb * 32, hh);
+            if (P.base_prev[l]) {
+                run_unit<4, 4, AR, 2>(unit_ptr(), out, [&](int g) { return relu_frag4<AR>(act, g); }, dma_step);
+                cur += 16 * 2048;
+                run_unit<4, 4, AR, 2>(unit_ptr(), out, [&](int g) { return relu_frag4<AR>(act, 4 + g); }, dma_step);
+                cur += 16 * 2048;
+            }
+            if (P.base_pe[l]) {
+                const unsigned char *lb = unit_ptr();
+                auto pe = [&](int g) { return pe_frag<AR>(g, hh, x); };
+                if (P.n_pe_steps == 3) run_unit<4, 3, AR, 4>(lb, out, pe, dma_step);
+                else if (P.n_pe_steps == 2) run_unit<4, 2, AR, 4>(lb, out, pe, dma_step);
+                else run_unit<4, 1, AR, 4>(lb, out, pe, dma_step);
+                cur += (unsigned)P.n_pe_steps * 4 * 2048;
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) act[mb] = out[mb];
+            if (T.A[0] && s_store >= 0) {
+                store_relu128(T.A[l], s_store, hh, act);
+                if (T.MA[l]) store_mask<4>(T.MA[l], s_store, hh, act);
+            }
+        }
+        BG_STAMP(t2);
+        // ---------------- heads: sigma and the 64-wide rgb hidden layer share the fragments of `base`; then the view k-step, then the rgb output (tvr_bg.hip heads())
+        {
+            const unsigned char *lb = unit_ptr();
+            f32x16 hd[3] = {{0}, bias_acc(lbias + 512, hh), bias_acc(lbias + 512 + 32, hh)};
+            const float *vp = viewdirs + 3 * (sr / P.samples_per_ray);
+            const float d[3] = {vp[0], vp[1], vp[2]};                   // (issued here: its latency passes under the eight k-steps below)
+            run_unit<3, 8, AR, 3>(lb, hd, [&](int g) { return relu_frag4<AR>(act, g); }, dma_step);
+            f32x16 rh[2] = {hd[1], hd[2]};
+            {
+                float v[8];
+                const float v0[8] = {d[0], d[1], d[2], __sinf(d[0]), __sinf(d[1]), __sinf(d[2]), __cosf(d[0]), __cosf(d[1])};
+                const float v1[8] = {__cosf(d[2]), __sinf(2.f * d[0]), __sinf(2.f * d[1]), __sinf(2.f * d[2]), __cosf(2.f * d[0]), __cosf(2.f * d[1]), __cosf(2.f * d[2]), 0.f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = hh ? v1[j] : v0[j];
+                const Frag bv = frag8<AR>(v);
+                run_unit<2, 1, AR, 1>(lb + 24 * 2048, rh, [&](int) { return bv; }, dma_step);
+            }
+            if (T.Hrgb && s_store >= 0) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(float4 *)(T.Hrgb + s_store * 64 + 32 * mb + 8 * q + 4 * hh) =
+                            make_float4(relu_f(rh[mb][4 * q]), relu_f(rh[mb][4 * q + 1]), relu_f(rh[mb][4 * q + 2]), relu_f(rh[mb][4 * q + 3]));
+                if (hh == 0) T.sig_pre[s_store] = hd[0][0] + lbias[576];
+                if (T.MH) store_mask<2>(T.MH, s_store, hh, rh);
+            }
+            f32x16 eo[1] = {{0}};
+            run_unit<1, 4, AR, 8>(lb + 26 * 2048, eo, [&](int t) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = relu_f(t < 2 ? rh[0][8 * (t & 1) + j] : rh[1][8 * (t & 1) + j]);
+                return frag8<AR>(v);
+            }, dma_step);
+            cur += 30 * 2048;
+            if (h == 0 && s < M) {
+                sigma[s] = fabsf(hd[0][0] + lbias[576]);
+                rgb[3 * s] = 1.0f / (1.0f + __expf(-(eo[0][0] + lbias[580])));
+                rgb[3 * s + 1] = 1.0f / (1.0f + __expf(-(eo[0][1] + lbias[581])));
+                rgb[3 * s + 2] = 1.0f / (1.0f + __expf(-(eo[0][2] + lbias[582])));
+            }
+        }
+        BG_STAMP(t3);
+        super = super_next;
+        BG_STAMP(t4);
+#if TVR_BG_TIMING
+        tsum[0] += t4 - t0; tsum[4] += t1 - t0; tsum[5] += t2 - t1; tsum[6] += t3 - t2; tsum[7] += t4 - t3;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the one chunk fetched ahead and never used: no DMA may outlive the wave
+#if TVR_BG_TIMING
+    // per wave: [0] tile total, [1] boundary: wait for the DMA (+ everything else outstanding), [2] boundary: barrier, [3] boundary: DMA issue, [4] tile start -> point loaded,
+    // [5] base layers (boundaries included), [6] heads (its boundary included) + stores issued, [7] the ticket barrier
+    if (tk && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(tk) + 8 + i, tsum[i]);
+#endif
+}
+
 
 // ------------------------------------------------------------------------------------------------ background geometry and compositing
 // NerfPlusPlus.execute around the network (nerfplusplus.py:280-308): perturbed depths (`perturb_samples` :196-205), inverted-sphere
@@ -519,6 +807,34 @@ static int plan(const tvr_mlpnet_desc *d, BgLayout &L)
     P.blocksA = a;
     P.blocksB = b;
     L.total_blocks = a + b;
+    // the streamed form (TVR_BG_STREAM): the same blocks in consumption order, cut into chunks of whole units that fit one LDS half
+    {
+        int pos = 0, n_units = 0, unit_blocks[16];
+        for (int l = 0; l < P.D; ++l) {
+            P.prev_blk0[l] = P.pe_blk0[l] = -1;
+            if (P.base_prev[l]) { P.prev_blk0[l] = pos; pos += 32; unit_blocks[n_units++] = 16; unit_blocks[n_units++] = 16; }
+            if (P.base_pe[l]) { P.pe_blk0[l] = pos; pos += 4 * P.n_pe_steps; unit_blocks[n_units++] = 4 * P.n_pe_steps; }
+        }
+        P.heads_blk0 = pos; pos += heads; unit_blocks[n_units++] = heads;
+        if (pos != L.total_blocks) return tvr_set_error(TVR_ERR_INVALID, "tvr_bg plan: the two layouts disagree (%d vs %d blocks)", pos, L.total_blocks);
+        P.bnd_mask = 0u;
+        P.n_chunks = 0;
+        int fill = BG_HALF_BLOCKS + 1, at = 0;                      // (the first unit always opens a chunk)
+        for (int u = 0; u < n_units; ++u) {
+            if (fill + unit_blocks[u] > BG_HALF_BLOCKS) {
+                if (P.n_chunks == BG_MAX_CHUNKS) return tvr_set_error(TVR_ERR_UNSUPPORTED, "MLPNet needs more than %d LDS chunks", BG_MAX_CHUNKS);
+                P.bnd_mask |= 1u << u;
+                P.chunk_blk0[P.n_chunks] = at;
+                P.chunk_nblk[P.n_chunks] = 0;
+                ++P.n_chunks;
+                fill = 0;
+            }
+            fill += unit_blocks[u];
+            P.chunk_nblk[P.n_chunks - 1] += unit_blocks[u];
+            at += unit_blocks[u];
+        }
+        for (int c = P.n_chunks; c < BG_MAX_CHUNKS; ++c) P.chunk_blk0[c] = P.chunk_nblk[c] = 0;
+    }
     return TVR_OK;
 }
 
@@ -534,9 +850,16 @@ template <int AR>
 static int mlpnet_launch(const BgLayout &L, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma, const BgTrain &T, void *work,
                          void *stream)
 {
+#if TVR_BG_STREAM
+    auto *kern = bg_mlp_stream_kernel<AR>;
+    const int lds_bytes = BG_LDS_STREAM_BYTES;
+#else
+    auto *kern = bg_mlp_kernel<AR>;
+    const int lds_bytes = BG_LDS_BYTES;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)bg_mlp_kernel<AR>, hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
     const long long per_super = 32 * BG_WAVES * TVR_BG_NT, n_super = (n_samples + per_super - 1) / per_super;
@@ -546,7 +869,7 @@ static int mlpnet_launch(const BgLayout &L, const void *packed, const void *pts,
     // launches on different streams take different work buffers and may share the (read-only) packed network.
     unsigned *tk = TVR_BG_TICKETS ? static_cast<unsigned *>(work) : nullptr;
     if (tk) hipLaunchKernelGGL(bg_zero_ticket_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), tk);
-    hipLaunchKernelGGL(bg_mlp_kernel<AR>, dim3(blocks), dim3(BG_WAVES * 64), BG_LDS_BYTES, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BG_WAVES * 64), lds_bytes, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
                        reinterpret_cast<const float *>(base + (size_t)L.total_blocks * 2048), static_cast<const float *>(pts), static_cast<const float *>(viewdirs),
                        (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma), T, tk);
     HIP_TRY(hipGetLastError());
@@ -589,6 +912,26 @@ int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *p, voi
     const BgProgram &P = L.P;
     hipStream_t st = static_cast<hipStream_t>(stream);
     std::vector<PackBlock> tab((size_t)L.total_blocks);
+#if TVR_BG_STREAM
+    // consumption order (BgProgram): block (k-step t, row block mb) of a part at part_blk0 + t * (row blocks of the part) + mb
+    auto put = [&](int blk, const void *W, int ld, int n_out, int row0, int kind, int t, int koff, int n_valid) {
+        tab[(size_t)blk] = PackBlock{static_cast<const float *>(W), ld, n_out, row0, kind, t, koff, n_valid};
+    };
+    for (int l = 0; l < P.D; ++l) {
+        const int prev = P.base_prev[l], pe = P.base_pe[l], ld = (prev ? 128 : 0) + (pe ? P.input_ch : 0);
+        for (int mb = 0; mb < 4; ++mb) {
+            // cat(input_pts, base): the embedding occupies the first input_ch columns, the previous activations follow (MLPNet.forward)
+            if (prev) for (int t = 0; t < 8; ++t) put(P.prev_blk0[l] + 4 * t + mb, p->base_W[l], ld, 128, mb * 32, K_PREV, t, pe ? P.input_ch : 0, 128);
+            if (pe) for (int t = 0; t < P.n_pe_steps; ++t) put(P.pe_blk0[l] + 4 * t + mb, p->base_W[l], ld, 128, mb * 32, K_PE, t, 0, P.input_ch);
+        }
+    }
+    for (int t = 0; t < 8; ++t) {
+        put(P.heads_blk0 + 3 * t, p->sigma_W, 128, 1, 0, K_PREV, t, 0, 128);
+        for (int mb = 0; mb < 2; ++mb) put(P.heads_blk0 + 3 * t + 1 + mb, p->rgbh_W_base, 128, 64, mb * 32, K_PREV, t, 0, 128);
+    }
+    for (int mb = 0; mb < 2; ++mb) put(P.heads_blk0 + 24 + mb, p->rgbh_W_view, 15, 64, mb * 32, K_VIEW, 0, 0, 15);
+    for (int t = 0; t < 4; ++t) put(P.heads_blk0 + 26 + t, p->rgbo_W, 64, 3, 0, K_PREV, t, 0, 64);
+#else
     auto put = [&](int stage, int blk, const void *W, int ld, int n_out, int row0, int kind, int t, int koff, int n_valid) {
         tab[(size_t)(stage ? P.blocksA : 0) + blk] = PackBlock{static_cast<const float *>(W), ld, n_out, row0, kind, t, koff, n_valid};
     };
@@ -608,6 +951,7 @@ int tvr_mlpnet_pack(const tvr_mlpnet_desc *desc, const tvr_mlpnet_params *p, voi
         put(1, P.rgbh_block0 + mb * 9 + 8, p->rgbh_W_view, 15, 64, mb * 32, K_VIEW, 0, 0, 15);
     }
     for (int t = 0; t < 4; ++t) put(1, P.rgbo_block0 + t, p->rgbo_W, 64, 3, 0, K_PREV, t, 0, 64);
+#endif
     char *base = static_cast<char *>(packed);
     float *bias = reinterpret_cast<float *>(base + (size_t)L.total_blocks * 2048);
     PackBlock *dtab = reinterpret_cast<PackBlock *>(base + (size_t)L.total_blocks * 2048 + BG_BIAS_FLOATS * 4);

@@ -168,17 +168,22 @@ class FrameStream:
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(2)]
         self.done = [torch.cuda.Event() for _ in range(2)]
         self.out = [None, None]
+        self._own = [None, None]
         self.busy = [False, False]
         self.k = 0
         self._drain_next = False
 
-    def submit(self, rays):
+    def submit(self, rays, out=None):
+        """`out` (optional): (rgb [n,3], depth [n]) to render into — e.g. slices of one frame-sized pair when the submits are the chunks of a frame (a chunk loop with two
+        calls in flight); the pair is what a later submit() / flush() hands back for this call.  Without it the slot's own buffers are used and come round again two submits later."""
         b = self.k % 2
         self.k += 1
         cur = torch.cuda.current_stream(self.dev)
         n = rays.shape[0]
-        if self.out[b] is None or self.out[b][0].shape[0] != n:
-            self.out[b] = (torch.empty((n, 3), dtype=torch.float32, device=self.dev), torch.empty((n,), dtype=torch.float32, device=self.dev))
+        if out is not None:
+            self.out[b] = out
+        elif self.out[b] is None or self.out[b][0].shape[0] != n or self._own[b] is not self.out[b]:
+            self.out[b] = self._own[b] = (torch.empty((n, 3), dtype=torch.float32, device=self.dev), torch.empty((n,), dtype=torch.float32, device=self.dev))
         # Two frames share the scene's packed images.  A call that will re-pack them (parameters changed), convert the fp16 copies, settle the range check or run the
         # arithmetic gate's probe renders must not overlap a frame that reads them: it waits for everything in flight, and so does the frame after it.
         settled = bool(getattr(self.model, "scene_settled", lambda: False)())

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--stagger", default="5:0.1,9:0.06", help="K:first-piece-fraction pairs (two streams)")
     ap.add_argument("--pieces", default="", help="piece sizes in rays (uniform pieces, the last one shorter), two streams")
     ap.add_argument("--lists", default="", help="explicit piece-size lists, ';'-separated, each 'name=a,b,c*N,...' (c*N repeats; the remainder of the frame is cut into pieces of the last size)")
+    ap.add_argument("--cpieces", default="", help="piece sizes handed to the LIBRARY (tvr_scene_set_render_pieces: the shipped mechanism), one configuration each")
     ap.add_argument("--rays", type=int, default=0, help="render only the first N rays of each frame (a rank's share)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -42,7 +43,8 @@ def main():
     rgb = torch.empty((n, 3), device=dev)
     depth = torch.empty((n,), device=dev)
 
-    def plain(rays):
+    def plain(rays, pieces=0):
+        model.render_piece_rays = pieces                  # 0: ONE launch set per call (the round-5 path); every Python-level split below runs its pieces that way too
         return model.render_rays(rays, white_bg=True, N_samples=S, out=(rgb, depth))
 
     def split(rays, K, n_streams=2, first_frac=None, align=4096, piece=0, sizes=None):
@@ -74,6 +76,7 @@ def main():
             if b <= a:
                 continue
             s = k % n_streams
+            model.render_piece_rays = 0
             with torch.cuda.stream(streams[s]):
                 model.render_rays(rays[a:b], white_bg=True, N_samples=S, out=(rgb[a:b], depth[a:b]), scratch_slot=s)
         for s in streams[:n_streams]:
@@ -81,6 +84,8 @@ def main():
         return rgb, depth
 
     configs = [("plain", lambda r: plain(r))]
+    for cp in [int(x) for x in args.cpieces.split(",") if x]:
+        configs.append((f"library pieces of {cp} rays", lambda r, cp=cp: plain(r, cp)))
     for K in [int(x) for x in args.K2.split(",") if x]:
         configs.append((f"K={K} 2 streams", lambda r, K=K: split(r, K, 2, align=512 if K > 100 else 4096)))
     for K in [int(x) for x in args.K3.split(",") if x]:
