@@ -495,7 +495,9 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_stream_kernel(BgProgr
     int dma_p = 0, dma_n = 0;                                           // this wave's next piece / the chunk's piece count
     const unsigned char *dma_src = nullptr;
     unsigned dma_dst = 0;
+#if TVR_BG_PRIOFLIP
     unsigned flip = (unsigned)(wave >> 2);
+#endif
     auto dma_step = [&]() {
 #if TVR_BG_PRIOFLIP
         flip ^= 1u;
