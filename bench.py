@@ -313,11 +313,20 @@ def other_configs(budget_s=240.0):
             out[key] = "skipped: time budget"
             continue
         try:
-            r = subprocess.run([sys.executable, os.path.join(root, "scripts", script)], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
-            mt = re.search(r"train step[^:]*: *([0-9.]+) ms", r.stdout)
-            ms = float(mt.group(1))
+            # Round 6 (review item 7): the eager static step is paced by the HOST (about 60 launches of 5 - 100 us kernels per step: 3.4 ms on a quiet host, 4.2 on the
+            # driver's busy one); the same step captured once and replayed as ONE hipGraph (training.make_graphed_step's way; TVR_GRAPH=1) is paced by the GPU and is what a
+            # reconstruction loop that replays gets — both are printed, the graph's first
+            res = {}
+            for tag, genv in (("graph", {"TVR_GRAPH": "1"}), ("eager", {"TVR_GRAPH": "0"})):
+                if script != "train_step_timing.py" and tag == "graph":
+                    continue
+                r = subprocess.run([sys.executable, os.path.join(root, "scripts", script)], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env, **genv))
+                mt = re.search(r"train step[^:]*: *([0-9.]+) ms", r.stdout)
+                res[tag] = float(mt.group(1))
+            ms = res.get("graph", res["eager"])
             out[key] = {"ms_per_step": ms, "iterations_per_sec": 1e3 / ms, "rays_per_sec": 4096e3 / ms,
-                        "command": " ".join(f"{k}={v}" for k, v in env.items()) + (" " if env else "") + "python scripts/" + script}
+                        "ms_per_step_whole_step_hipgraph_replay": res.get("graph"), "ms_per_step_eager_host_paced": res["eager"],
+                        "command": " ".join(f"{k}={v}" for k, v in env.items()) + (" " if env else "") + ("TVR_GRAPH=1 " if "graph" in res else "") + "python scripts/" + script}
         except Exception as e:
             out[key] = f"failed: {type(e).__name__}"
     # NerfPlusPlus inference: the background network's kernel (512 samples per ray: the bulk of a NerfPlusPlus frame) with its roofline (scripts/npp_roofline.py)

@@ -427,12 +427,13 @@ __device__ __forceinline__ void mfma3(const AF &A, const Frag &b, f32x16 &acc)
     if constexpr (AR >= 3) acc = MFMAH(A.h, b.lo, acc);
     acc = MFMAH(A.h, b.hi, acc);
 }
-// One unit: NG k-steps x NB row blocks whose fragment blocks lie consecutively at `lb` (this lane's LDS address of the unit's first block).  hipcc's own schedule puts a
-// k-step's A-fragment reads right in front of their MFMAs — `ds_read, s_waitcnt, MFMA` ~75 times per tile (scripts/isa_trace.py on round 5's kernel) — so the reads run
-// TWO BLOCKS AHEAD here through a ring of four {hi, lo} pairs (32 registers), a fragment lives for three MFMAs, and the next k-step's B fragment (relu + fp16 split, or the
-// embedding's sin / cos) is derived under the MFMAs of this one (VPG vector instructions per MFMA gap), as in tvr_shade.hip's matrix phase.
-template <int NB, int NG, int AR, int VPG, typename GetB, typename Hook>
-__device__ __forceinline__ void run_unit(const unsigned char *lb, f32x16 (&acc)[NB], GetB getB, Hook hook)
+// One unit: NG k-steps x NB row blocks whose fragment blocks lie consecutively at `lb` (this lane's LDS address of the unit's first block), for the NTW 32-sample tiles a
+// wave carries.  hipcc's own schedule puts a k-step's A-fragment reads right in front of their MFMAs — `ds_read, s_waitcnt, MFMA` ~75 times per tile (scripts/isa_trace.py on
+// round 5's kernel) — so the reads run TVR_BG_PD blocks ahead here through a ring of {hi, lo} pairs, a fragment lives for 3 NTW MFMAs (the tiles of a wave SHARE every weight
+// fragment: with two tiles the LDS reads and the DMA per sample halve), and the next k-step's B fragments (relu + fp16 split, or the embedding's sin / cos) are derived under
+// the MFMAs of this one (VPG vector instructions per MFMA gap), as in tvr_shade.hip's matrix phase.
+template <int NB, int NG, int AR, int VPG, int NTW, typename GetB, typename Hook>
+__device__ __forceinline__ void run_unit(const unsigned char *lb, f32x16 (&acc)[NTW][NB], GetB getB, Hook hook)
 {
     constexpr int NQ = NB * NG;
     AF ring[BG_RN];
@@ -443,55 +444,77 @@ __device__ __forceinline__ void run_unit(const unsigned char *lb, f32x16 (&acc)[
 #pragma unroll
     for (int q0 = 0; q0 < TVR_BG_PD; ++q0)
         if (q0 < NQ) ld(q0);
-    Frag b = getB(0), nb = b;
+    Frag b[NTW], nb[NTW];
+#pragma unroll
+    for (int w = 0; w < NTW; ++w) nb[w] = b[w] = getB(w, 0);
     BG_SB;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        hook();                                                         // (one LDS-DMA piece of the next chunk per k-step: see the kernel)
+        hook();                                                         // (the next chunk's transfer, a piece per k-step: see the kernel)
         BG_SB;
-        if (g + 1 < NG) nb = getB(g + 1);
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int w = 0; w < NTW; ++w) nb[w] = getB(w, g + 1);
+        }
 #pragma unroll
         for (int m = 0; m < NB; ++m) {
             const int q = g * NB + m;
             if (q + TVR_BG_PD < NQ) ld(q + TVR_BG_PD);
-            mfma3<AR>(ring[q % BG_RN], b, acc[m]);
+            const AF &A = ring[q % BG_RN];
+            // per accumulator the order of the additions is tvr_mfma.h's (Wlo*xhi, Whi*xlo, Whi*xhi); the tiles of the wave alternate, so no MFMA waits for the one before it
+            if constexpr (AR >= 2) {
+#pragma unroll
+                for (int w = 0; w < NTW; ++w) acc[w][m] = MFMAH(A.l, b[w].hi, acc[w][m]);
+            }
+            if constexpr (AR >= 3) {
+#pragma unroll
+                for (int w = 0; w < NTW; ++w) acc[w][m] = MFMAH(A.h, b[w].lo, acc[w][m]);
+            }
+#pragma unroll
+            for (int w = 0; w < NTW; ++w) acc[w][m] = MFMAH(A.h, b[w].hi, acc[w][m]);
         }
 #if TVR_BG_SCHED
 #pragma unroll
         for (int m = 0; m < NB; ++m) {
             if (g * NB + m + TVR_BG_PD < NQ) BG_SG_DSR(AR >= 2 ? 2 : 1);
-            if (AR >= 2) { BG_SG_MFMA(1); if (g + 1 < NG) BG_SG_VALU(VPG); }
-            if (AR >= 3) { BG_SG_MFMA(1); if (g + 1 < NG) BG_SG_VALU(VPG); }
-            BG_SG_MFMA(1);
-            if (g + 1 < NG) BG_SG_VALU(VPG);
+#pragma unroll
+            for (int i = 0; i < AR * NTW; ++i) {
+                BG_SG_MFMA(1);
+                if (g + 1 < NG) BG_SG_VALU(VPG);
+            }
         }
 #endif
-        if (g + 1 < NG) b = nb;
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int w = 0; w < NTW; ++w) b[w] = nb[w];
+        }
         BG_SB;
     }
 }
 
-template <int AR>
-__global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_stream_kernel(BgProgram P, const uint4 *__restrict__ image, const float *__restrict__ bias,
-                                                                        const float *__restrict__ pts, const float *__restrict__ viewdirs, long long M,
-                                                                        float *__restrict__ rgb, float *__restrict__ sigma, const BgTrain T, unsigned *__restrict__ tk)
+// NTW = 1, 8 waves (two per SIMD, 256 registers each): the form of this round's first half.  NTW = 2, 4 waves (ONE per SIMD, the whole register file): a wave carries two
+// tiles through every fragment — the MFMA / VALU overlap that two lock-stepped waves of a SIMD do not give each other is built into one instruction stream.
+template <int AR, int NTW, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 1) bg_mlp_stream_kernel(BgProgram P, const uint4 *__restrict__ image, const float *__restrict__ bias,
+                                                                     const float *__restrict__ pts, const float *__restrict__ viewdirs, long long M,
+                                                                     float *__restrict__ rgb, float *__restrict__ sigma, const BgTrain T, unsigned *__restrict__ tk)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ long long s_next;
     float *lbias = reinterpret_cast<float *>(smem + 2 * BG_HALF_BYTES);
-    for (int e = threadIdx.x; e < BG_BIAS_FLOATS; e += BG_WAVES * 64) lbias[e] = bias[e];            // (visible behind the first chunk's barrier)
+    for (int e = threadIdx.x; e < BG_BIAS_FLOATS; e += WAVES * 64) lbias[e] = bias[e];              // (visible behind the first chunk's barrier)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, col = lane & 31;
-    constexpr int PER_SUPER = 32 * BG_WAVES;
+    constexpr int PER_SUPER = 32 * WAVES * NTW;
     const long long n_super = (M + PER_SUPER - 1) / PER_SUPER;
 
-    // ---- the chunk stream.  cn: the chunk (index within a tile) the next boundary opens; hsel: the half it arrives in.  The DMA of a chunk is issued one whole chunk of
-    // compute before its first read, by all eight waves (1 KB pieces, piece p by wave p % 8): at a boundary every wave waits for its own pieces (vmcnt(0)), the barrier
-    // then says that ALL pieces have landed and that nobody reads the other half any more — which the chunk after next may now overwrite.
+    // ---- the chunk stream.  cn: the chunk (index within a tile) the next boundary opens; hsel: the half it arrives in.  The DMA of a chunk runs one whole chunk of
+    // compute ahead of its first read, issued by all waves (1 KB pieces, piece p by wave p % WAVES): at a boundary every wave waits for its own pieces (vmcnt(0)), the
+    // barrier then says that ALL pieces have landed and that nobody reads the other half any more — which the chunk after next may now overwrite.
     int cn = 0, hsel = 0;
     unsigned cur = 0;                                                   // LDS byte offset of the next unit's first block
-    // The pieces of a chunk's DMA are NOT issued in one burst behind the barrier: an LDS-DMA instruction holds its wave for ~100 cycles (measured here: 4 060 cycles per
-    // tile and wave for 37.5 pieces, with both waves of every SIMD bursting at once and nobody feeding the matrix pipe — profiles/r06_bg_kernel.txt).  A wave issues ONE
-    // piece per k-step of the chunk it computes on (dma_step, the hook of run_unit) and whatever is left at the next boundary.
+    // The pieces of a chunk's DMA are NOT issued in one burst behind the barrier: an LDS-DMA instruction holds its wave for ~100 cycles (measured: 4 060 cycles per
+    // tile and wave for 37.5 pieces, with both waves of every SIMD bursting at once and nobody feeding the matrix pipe — profiles/r06_bg_kernel.txt).  A wave issues
+    // its pieces k-step by k-step under the chunk it computes on (dma_step, the hook of run_unit) and whatever is left at the next boundary.
     int dma_p = 0, dma_n = 0;                                           // this wave's next piece / the chunk's piece count
     const unsigned char *dma_src = nullptr;
     unsigned dma_dst = 0;
@@ -504,10 +527,12 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_stream_kernel(BgProgr
         if (flip) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
 #endif
-        if (dma_p < dma_n) {
-            __builtin_amdgcn_global_load_lds((bg_glb_void *)(dma_src + (size_t)dma_p * 1024), (bg_lds_void *)(smem + dma_dst + dma_p * 1024), 16, 0, 0);
-            dma_p += BG_WAVES;
-        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)                                   // (two tiles per wave: half the waves, twice the pieces each, twice the MFMAs per k-step to put them under)
+            if (dma_p < dma_n) {
+                __builtin_amdgcn_global_load_lds((bg_glb_void *)(dma_src + (size_t)dma_p * 1024), (bg_lds_void *)(smem + dma_dst + dma_p * 1024), 16, 0, 0);
+                dma_p += WAVES;
+            }
     };
     auto issue_dma = [&](int c, int half) {                             // arm the DMA of chunk c into `half`
         dma_n = P.chunk_nblk[c] * 2;
@@ -540,11 +565,10 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_stream_kernel(BgProgr
     // reads it behind that barrier — a whole tile before it is needed, so the next tile's points are fetched under this tile's layers.
     unsigned tk_pending = 0;
     if (tk && threadIdx.x == 0) tk_pending = atomicAdd(tk, 1u);
-    float4 p_next;
-    {
-        const long long s0 = ((long long)blockIdx.x * BG_WAVES + wave) * 32 + col;
-        p_next = *reinterpret_cast<const float4 *>(pts + 4 * min(s0, M - 1));
-    }
+    auto sample_of = [&](long long super, int w) { return ((super * WAVES + wave) * NTW + w) * 32 + col; };
+    float4 p_next[NTW];
+#pragma unroll
+    for (int w = 0; w < NTW; ++w) p_next[w] = *reinterpret_cast<const float4 *>(pts + 4 * min(sample_of(blockIdx.x, w), M - 1));
     for (long long super = blockIdx.x; super < n_super;) {
 #if TVR_BG_TIMING
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -568,86 +592,115 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_stream_kernel(BgProgr
             asm volatile("" : "+v"(a));
             return (const unsigned char *)(const void __attribute__((address_space(3))) *)(size_t)a;
         };
-        const long long s = (super * BG_WAVES + wave) * 32 + col, sr = min(s, M - 1), s_store = s < M ? s : -1;
-        const float4 p = p_next;
-        {
-            const long long sn = (super_next * BG_WAVES + wave) * 32 + col;
-            p_next = *reinterpret_cast<const float4 *>(pts + 4 * min(sn, M - 1));        // (a tile number beyond the last one reads the last sample's point: never used)
+        long long s[NTW], sr[NTW];
+        float x[NTW][4];
+#pragma unroll
+        for (int w = 0; w < NTW; ++w) {
+            s[w] = sample_of(super, w);
+            sr[w] = min(s[w], M - 1);
+            x[w][0] = p_next[w].x; x[w][1] = p_next[w].y; x[w][2] = p_next[w].z; x[w][3] = p_next[w].w;
+            p_next[w] = *reinterpret_cast<const float4 *>(pts + 4 * min(sample_of(super_next, w), M - 1));     // (a tile number beyond the last reads the last sample's point: never used)
         }
-        const float x[4] = {p.x, p.y, p.z, p.w};
 #if TVR_BG_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (timing build: the sample's point is here before the clock is read)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (timing build: everything outstanding is here before the clock is read)
 #endif
         BG_STAMP(t1);
-        f32x16 act[4];
+        f32x16 act[NTW][4];
         // ---------------- base layers
         for (int l = 0; l < P.D; ++l) {
-            f32x16 out[4];
+            f32x16 out[NTW][4];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) out[mb] = bias_acc(lbias + l * 128 + mb * 32, hh);
+            for (int w = 0; w < NTW; ++w)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) out[w][mb] = bias_acc(lbias + l * 128 + mb * 32, hh);
             if (P.base_prev[l]) {
-                run_unit<4, 4, AR, 2>(unit_ptr(), out, [&](int g) { return relu_frag4<AR>(act, g); }, dma_step);
+                run_unit<4, 4, AR, 2, NTW>(unit_ptr(), out, [&](int w, int g) { return relu_frag4<AR>(act[w], g); }, dma_step);
                 cur += 16 * 2048;
-                run_unit<4, 4, AR, 2>(unit_ptr(), out, [&](int g) { return relu_frag4<AR>(act, 4 + g); }, dma_step);
+                run_unit<4, 4, AR, 2, NTW>(unit_ptr(), out, [&](int w, int g) { return relu_frag4<AR>(act[w], 4 + g); }, dma_step);
                 cur += 16 * 2048;
             }
             if (P.base_pe[l]) {
                 const unsigned char *lb = unit_ptr();
-                auto pe = [&](int g) { return pe_frag<AR>(g, hh, x); };
-                if (P.n_pe_steps == 3) run_unit<4, 3, AR, 4>(lb, out, pe, dma_step);
-                else if (P.n_pe_steps == 2) run_unit<4, 2, AR, 4>(lb, out, pe, dma_step);
-                else run_unit<4, 1, AR, 4>(lb, out, pe, dma_step);
+                auto pe = [&](int w, int g) { return pe_frag<AR>(g, hh, x[w]); };
+                if (P.n_pe_steps == 3) run_unit<4, 3, AR, 4, NTW>(lb, out, pe, dma_step);
+                else if (P.n_pe_steps == 2) run_unit<4, 2, AR, 4, NTW>(lb, out, pe, dma_step);
+                else run_unit<4, 1, AR, 4, NTW>(lb, out, pe, dma_step);
                 cur += (unsigned)P.n_pe_steps * 4 * 2048;
             }
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) act[mb] = out[mb];
-            if (T.A[0] && s_store >= 0) {
-                store_relu128(T.A[l], s_store, hh, act);
-                if (T.MA[l]) store_mask<4>(T.MA[l], s_store, hh, act);
+            for (int w = 0; w < NTW; ++w) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) act[w][mb] = out[w][mb];
+                if (T.A[0] && s[w] < M) {
+                    store_relu128(T.A[l], s[w], hh, act[w]);
+                    if (T.MA[l]) store_mask<4>(T.MA[l], s[w], hh, act[w]);
+                }
             }
         }
         BG_STAMP(t2);
         // ---------------- heads: sigma and the 64-wide rgb hidden layer share the fragments of `base`; then the view k-step, then the rgb output (tvr_bg.hip heads())
         {
             const unsigned char *lb = unit_ptr();
-            f32x16 hd[3] = {{0}, bias_acc(lbias + 512, hh), bias_acc(lbias + 512 + 32, hh)};
-            const float *vp = viewdirs + 3 * (sr / P.samples_per_ray);
-            const float d[3] = {vp[0], vp[1], vp[2]};                   // (issued here: its latency passes under the eight k-steps below)
-            run_unit<3, 8, AR, 3>(lb, hd, [&](int g) { return relu_frag4<AR>(act, g); }, dma_step);
-            f32x16 rh[2] = {hd[1], hd[2]};
-            {
+            float d[NTW][3];
+#pragma unroll
+            for (int w = 0; w < NTW; ++w) {                             // (issued here: the latency passes under the eight k-steps below)
+                const float *vp = viewdirs + 3 * (sr[w] / P.samples_per_ray);
+                d[w][0] = vp[0]; d[w][1] = vp[1]; d[w][2] = vp[2];
+            }
+            f32x16 hd[NTW][3];
+#pragma unroll
+            for (int w = 0; w < NTW; ++w) {
+                hd[w][0] = f32x16{0};
+                hd[w][1] = bias_acc(lbias + 512, hh);
+                hd[w][2] = bias_acc(lbias + 512 + 32, hh);
+            }
+            run_unit<3, 8, AR, 3, NTW>(lb, hd, [&](int w, int g) { return relu_frag4<AR>(act[w], g); }, dma_step);
+            f32x16 rh[NTW][2];
+            Frag bv[NTW];
+#pragma unroll
+            for (int w = 0; w < NTW; ++w) {
+                rh[w][0] = hd[w][1]; rh[w][1] = hd[w][2];
+                // view-direction embedding: [d, sin d, cos d, sin 2d, cos 2d] (15 values, one k-step)
+                const float *dd = d[w];
                 float v[8];
-                const float v0[8] = {d[0], d[1], d[2], __sinf(d[0]), __sinf(d[1]), __sinf(d[2]), __cosf(d[0]), __cosf(d[1])};
-                const float v1[8] = {__cosf(d[2]), __sinf(2.f * d[0]), __sinf(2.f * d[1]), __sinf(2.f * d[2]), __cosf(2.f * d[0]), __cosf(2.f * d[1]), __cosf(2.f * d[2]), 0.f};
+                const float v0[8] = {dd[0], dd[1], dd[2], __sinf(dd[0]), __sinf(dd[1]), __sinf(dd[2]), __cosf(dd[0]), __cosf(dd[1])};
+                const float v1[8] = {__cosf(dd[2]), __sinf(2.f * dd[0]), __sinf(2.f * dd[1]), __sinf(2.f * dd[2]), __cosf(2.f * dd[0]), __cosf(2.f * dd[1]), __cosf(2.f * dd[2]), 0.f};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = hh ? v1[j] : v0[j];
-                const Frag bv = frag8<AR>(v);
-                run_unit<2, 1, AR, 1>(lb + 24 * 2048, rh, [&](int) { return bv; }, dma_step);
+                bv[w] = frag8<AR>(v);
             }
-            if (T.Hrgb && s_store >= 0) {
+            run_unit<2, 1, AR, 1, NTW>(lb + 24 * 2048, rh, [&](int w, int) { return bv[w]; }, dma_step);
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
+            for (int w = 0; w < NTW; ++w) {
+                if (T.Hrgb && s[w] < M) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(float4 *)(T.Hrgb + s_store * 64 + 32 * mb + 8 * q + 4 * hh) =
-                            make_float4(relu_f(rh[mb][4 * q]), relu_f(rh[mb][4 * q + 1]), relu_f(rh[mb][4 * q + 2]), relu_f(rh[mb][4 * q + 3]));
-                if (hh == 0) T.sig_pre[s_store] = hd[0][0] + lbias[576];
-                if (T.MH) store_mask<2>(T.MH, s_store, hh, rh);
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *(float4 *)(T.Hrgb + s[w] * 64 + 32 * mb + 8 * q + 4 * hh) =
+                                make_float4(relu_f(rh[w][mb][4 * q]), relu_f(rh[w][mb][4 * q + 1]), relu_f(rh[w][mb][4 * q + 2]), relu_f(rh[w][mb][4 * q + 3]));
+                    if (hh == 0) T.sig_pre[s[w]] = hd[w][0][0] + lbias[576];
+                    if (T.MH) store_mask<2>(T.MH, s[w], hh, rh[w]);
+                }
             }
-            f32x16 eo[1] = {{0}};
-            run_unit<1, 4, AR, 8>(lb + 26 * 2048, eo, [&](int t) {
+            f32x16 eo[NTW][1];
+#pragma unroll
+            for (int w = 0; w < NTW; ++w) eo[w][0] = f32x16{0};
+            run_unit<1, 4, AR, 8 / NTW, NTW>(lb + 26 * 2048, eo, [&](int w, int t) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = relu_f(t < 2 ? rh[0][8 * (t & 1) + j] : rh[1][8 * (t & 1) + j]);
+                for (int j = 0; j < 8; ++j) v[j] = relu_f(t < 2 ? rh[w][0][8 * (t & 1) + j] : rh[w][1][8 * (t & 1) + j]);
                 return frag8<AR>(v);
             }, dma_step);
             cur += 30 * 2048;
-            if (h == 0 && s < M) {
-                sigma[s] = fabsf(hd[0][0] + lbias[576]);
-                rgb[3 * s] = 1.0f / (1.0f + __expf(-(eo[0][0] + lbias[580])));
-                rgb[3 * s + 1] = 1.0f / (1.0f + __expf(-(eo[0][1] + lbias[581])));
-                rgb[3 * s + 2] = 1.0f / (1.0f + __expf(-(eo[0][2] + lbias[582])));
-            }
+#pragma unroll
+            for (int w = 0; w < NTW; ++w)
+                if (h == 0 && s[w] < M) {
+                    sigma[s[w]] = fabsf(hd[w][0][0] + lbias[576]);
+                    rgb[3 * s[w]] = 1.0f / (1.0f + __expf(-(eo[w][0][0] + lbias[580])));
+                    rgb[3 * s[w] + 1] = 1.0f / (1.0f + __expf(-(eo[w][0][1] + lbias[581])));
+                    rgb[3 * s[w] + 2] = 1.0f / (1.0f + __expf(-(eo[w][0][2] + lbias[582])));
+                }
         }
         BG_STAMP(t3);
         super = super_next;
@@ -658,13 +711,12 @@ __global__ void __launch_bounds__(BG_WAVES * 64, 1) bg_mlp_stream_kernel(BgProgr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the one chunk fetched ahead and never used: no DMA may outlive the wave
 #if TVR_BG_TIMING
-    // per wave: [0] tile total, [1] boundary: wait for the DMA (+ everything else outstanding), [2] boundary: barrier, [3] boundary: DMA issue, [4] tile start -> point loaded,
-    // [5] base layers (boundaries included), [6] heads (its boundary included) + stores issued, [7] the ticket barrier
+    // per wave: [0] tile total, [1] boundary: wait for the DMA (+ everything else outstanding), [2] boundary: barrier, [3] boundary: arming the next DMA, [4] tile start (first
+    // boundary included) -> everything outstanding landed, [5] base layers (boundaries included), [6] heads (its boundary included) + stores issued, [7] -
     if (tk && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(tk) + 8 + i, tsum[i]);
 #endif
 }
-
 
 // ------------------------------------------------------------------------------------------------ background geometry and compositing
 // NerfPlusPlus.execute around the network (nerfplusplus.py:280-308): perturbed depths (`perturb_samples` :196-205), inverted-sphere
@@ -852,26 +904,32 @@ template <int AR>
 static int mlpnet_launch(const BgLayout &L, const void *packed, const void *pts, const void *viewdirs, int64_t n_samples, void *rgb, void *sigma, const BgTrain &T, void *work,
                          void *stream)
 {
-#if TVR_BG_STREAM
-    auto *kern = bg_mlp_stream_kernel<AR>;
+#if TVR_BG_STREAM == 2
+    auto *kern = bg_mlp_stream_kernel<AR, 2, 4>;                     // one wave per SIMD, two tiles per wave
     const int lds_bytes = BG_LDS_STREAM_BYTES;
+    constexpr int KW = 4, KNT = 2;
+#elif TVR_BG_STREAM
+    auto *kern = bg_mlp_stream_kernel<AR, 1, BG_WAVES>;
+    const int lds_bytes = BG_LDS_STREAM_BYTES;
+    constexpr int KW = BG_WAVES, KNT = 1;
 #else
     auto *kern = bg_mlp_kernel<AR>;
     const int lds_bytes = BG_LDS_BYTES;
+    constexpr int KW = BG_WAVES, KNT = TVR_BG_NT;
 #endif
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    const long long per_super = 32 * BG_WAVES * TVR_BG_NT, n_super = (n_samples + per_super - 1) / per_super;
+    const long long per_super = 32 * KW * KNT, n_super = (n_samples + per_super - 1) / per_super;
     const unsigned blocks = (unsigned)(n_super < 256 ? n_super : 256);                     // one workgroup per CU (the LDS image)
     const char *base = static_cast<const char *>(packed);
     // the ticket word: word 0 of the caller's `work` buffer (tvr_mlpnet_work_bytes), zeroed here and advanced by the kernel.  One launch per work buffer at a time;
     // launches on different streams take different work buffers and may share the (read-only) packed network.
     unsigned *tk = TVR_BG_TICKETS ? static_cast<unsigned *>(work) : nullptr;
     if (tk) hipLaunchKernelGGL(bg_zero_ticket_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), tk);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BG_WAVES * 64), lds_bytes, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(KW * 64), lds_bytes, static_cast<hipStream_t>(stream), L.P, reinterpret_cast<const uint4 *>(base),
                        reinterpret_cast<const float *>(base + (size_t)L.total_blocks * 2048), static_cast<const float *>(pts), static_cast<const float *>(viewdirs),
                        (long long)n_samples, static_cast<float *>(rgb), static_cast<float *>(sigma), T, tk);
     HIP_TRY(hipGetLastError());
