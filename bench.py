@@ -638,7 +638,7 @@ def main():
     # from K more frames behind the timed region rendered as ONE launch set each (pieces off: the round-5 path, same library), with their own counters and clock probes.
     pieces_now = L.lib().tvr_scene_get_render_pieces(model._ensure_scene())
     n_pieces = 1
-    if pieces_now > 0 and n_mine >= 2 * pieces_now:
+    if pieces_now > 0 and n_mine >= 6 * pieces_now:                 # (tvr_api.hip TVR_MIN_PIECES)
         k_ = (n_mine + pieces_now // 2) // pieces_now
         pr_ = ((n_mine + k_ - 1) // k_ + 511) // 512 * 512
         n_pieces = (n_mine + pr_ - 1) // pr_

@@ -191,7 +191,8 @@ int tvr_scene_destroy(tvr_scene *scene);
  * flushed.  Leaving the range is REPORTED, not silent: with the scene's range check on (the default, tvr_scene_set_range_check) a sample
  * whose operands reach 65 504 renders as NaN.  Layer 3, the positional encoding, interpolation, density and compositing are plain fp32.  The shipped scenes and the reference's
  * 0.1 * randn initialisation are far inside this range (tests: |feature| up to ~1100, weights at 1e-4 scale).
- * PIECES (round 6): a call of at least 2 x piece_rays rays (tvr_scene_set_render_pieces; default 30 720, so every call of 61 440 rays or more) is rendered as
+ * PIECES (round 6): a call of at least 6 x piece_rays rays (tvr_scene_set_render_pieces; default 30 720, so every call of 184 320 rays or more — smaller calls gain
+ * nothing from two or three pieces, measured) is rendered as
  * K = round(n / piece_rays) pieces of consecutive rays (equal sizes, multiples of 512 rays, the last one shorter), piece k on library-owned stream k & 1 in that stream's half of `scratch`; the two streams fork from the caller's
  * stream by an event and are joined back into it by two more before the call returns, so for the caller everything is still ordered on ITS stream (and a capture of
  * the caller's stream captures the fork and join).  Why: the kernels of one piece take the CUs the other piece's kernels leave as they drain, and a march beside a shade

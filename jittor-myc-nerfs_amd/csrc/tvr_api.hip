@@ -401,13 +401,18 @@ static ScratchLayout scratch_layout(int64_t n_rays, int32_t S)
     return L;
 }
 
-// Piecewise rendering: a call of n rays goes out as K = round(n / piece_rays) pieces of ceil(n / K) rays rounded up to 512 (the last one shorter), if that makes at least two.
+// Piecewise rendering: a call of n rays goes out as K = round(n / piece_rays) pieces of ceil(n / K) rays rounded up to 512 (the last one shorter), if that makes at least
+// TVR_MIN_PIECES.  Measured on one box (bench.py --emulate-world N --pieces P, profiles/r06_split_frame.txt): the 640 000-ray frame -3.6 % .. -4.6 %, a 320 000-ray share
+// -4.6 %, a 160 000-ray share +-0.5 %, an 80 000-ray share +0.9 % (two or three pieces do not settle into the overlap that pays): small calls stay one launch set.
+#ifndef TVR_MIN_PIECES
+#define TVR_MIN_PIECES 6
+#endif
 struct PiecePlan { int K; int64_t rays; };
 static PiecePlan piece_plan(const tvr_scene *s, int64_t n_rays)
 {
     PiecePlan P = {1, n_rays};
     const int64_t pr = s ? s->piece_rays : default_piece_rays();
-    if (pr <= 0 || n_rays < 2 * pr) return P;
+    if (pr <= 0 || n_rays < TVR_MIN_PIECES * pr) return P;
     const int64_t K = (n_rays + pr / 2) / pr, q = pr >= 512 ? 512 : 16;          // (pieces below 512 rays: tests on tiny fixtures)
     P.rays = ((n_rays + K - 1) / K + q - 1) / q * q;
     P.K = (int)((n_rays + P.rays - 1) / P.rays);

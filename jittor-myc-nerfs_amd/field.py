@@ -373,7 +373,7 @@ class TensorBase(torch.nn.Module):
     # compares.  max |difference| <= `mlp_arith_tol` (default 2.5e-4: a quarter of north_star's 1e-3 bar): the mode is in effect; otherwise the scene keeps computing
     # in "f32", a RuntimeWarning says so once per parameter state, and `arith_in_effect` / `arith_max_diff` tell.  No interval bound from the parameters can do this
     # job: |W| |x| bounds overestimate the error a thousandfold (scripts: DESIGN.md 4.7), a measurement on the scene's own rays does not.
-    # tvr_render in pieces (include/tvr.h, PIECES): None = the library's default piece (30 720 rays: calls of 61 440 rays or more go out as pieces on two library-owned
+    # tvr_render in pieces (include/tvr.h, PIECES): None = the library's default piece (30 720 rays: calls of 184 320 rays or more go out as pieces on two library-owned
     # streams, joined back into the caller's stream); 0 = one launch set per call, as before round 6; else the piece size in rays
     render_piece_rays = None
 

@@ -35,11 +35,14 @@ def test_npp_render_against_golden(tiny_npp, tiny_npp_arrays, hyper_tiny):
     assert np.abs(_np(fg) - tiny_npp["out.fg_rgb_map"]).max() < 1e-4
     lam_t = torch.where(lam > 0.1, lam, torch.zeros_like(lam))
     assert np.abs(_np(lam_t) - tiny_npp["out.bg_lambda"]).max() < 1e-5
-    # tvr_render_z in pieces (round 6; z_vals, t_last_tiny and the outputs are offset per piece): four pieces of 16 rays on two streams, bit for bit the one-launch-set call
+    # tvr_render_z in pieces (round 6; z_vals, t_last_tiny and the outputs are offset per piece): the batch twice over = 128 rays = eight pieces of 16 rays on two
+    # streams (fewer than six pieces stay one launch set), bit for bit the one-launch-set call
+    rays2, z2 = torch.cat([rays, rays]), torch.cat([z, z])
+    fg1, dep1, lam1 = m._render_z(rays2, z2, TINY["N_samples"], 0.0)
     m.render_piece_rays = 16
-    fg_p, dep_p, lam_p = m._render_z(rays, z, TINY["N_samples"], 0.0)
+    fg_p, dep_p, lam_p = m._render_z(rays2, z2, TINY["N_samples"], 0.0)
     m.render_piece_rays = None
-    assert torch.equal(fg_p, fg) and torch.equal(lam_p, lam)
+    assert torch.equal(fg_p, fg1) and torch.equal(lam_p, lam1) and torch.equal(dep_p, dep1) and torch.equal(fg_p[:64], fg) and torch.equal(fg_p[64:], fg)
     # default early termination stays inside the bar; results do not depend on the batch order
     m.eps_T = None
     with torch.no_grad():

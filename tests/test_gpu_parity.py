@@ -542,7 +542,7 @@ def test_render_in_pieces_equals_one_launch_set(config1_golden):
     st0 = torch.zeros(8, dtype=torch.int64, device="cuda")
     want = [t.clone() for t in m.render_rays(rays, white_bg=True, N_samples=S, stats=st0)]
     want_j = [t.clone() for t in m.render_rays(rays, white_bg=True, N_samples=S, jitter=jit)]
-    for piece in (1024, 2560, 4096):                                                # 12 / 5 / 3 pieces, the last one ragged
+    for piece in (512, 1024, 1536):                                                 # 24 / 12 / 8 pieces, the last one ragged
         m.render_piece_rays = piece
         sc = m._ensure_scene()
         assert L.lib().tvr_scene_get_render_pieces(sc) == piece
@@ -583,7 +583,7 @@ def test_render_in_pieces_equals_one_launch_set(config1_golden):
     # the size query: two pieces' scratch fits what the query returns, and the library refuses less
     sc = m._ensure_scene()
     need = L.lib().tvr_render_scratch_bytes(sc, rays.shape[0], S)
-    assert need >= 2 * L.lib().tvr_render_scratch_bytes(None, 4096, S) - 4096
+    assert need >= 2 * L.lib().tvr_render_scratch_bytes(None, 1536, S) - 4096
     assert L.lib().tvr_scene_set_render_pieces(sc, 7) == -1 and L.lib().tvr_scene_set_render_pieces(sc, -1) == 0
     assert L.lib().tvr_scene_get_render_pieces(sc) == 30720
 
