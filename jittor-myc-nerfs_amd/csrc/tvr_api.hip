@@ -51,7 +51,7 @@ static const int kVecH[3] = {2, 1, 0};
 struct PackedLayout {
     size_t dplane[3], dline[3], aplane[3], aline[3];
     size_t aplane16[3], aline16[3];            // fp16 copies of the appearance factors (TVR_ARITH_F16's gather), floats / 2
-    size_t mlp_image, basis_frag, b3, w1gen, img16, basg16, total;
+    size_t mlp_image, basis_frag, b3, w1gen, img16, basg16, refg16, total;
 };
 
 static PackedLayout packed_layout(const tvr_scene_desc &d)
@@ -72,9 +72,11 @@ static PackedLayout packed_layout(const tvr_scene_desc &d)
     // scenes with more than two encoding frequencies (TensorBase's own default is 6 / 6: 390 MLP inputs): layer 1's fragment image, 26 k-steps, streamed through LDS
     L.w1gen = (d.view_pe > 2 || d.fea_pe > 2) ? take(TVR_W1GEN_BYTES / 4) : 0;
     // the 16x16x32 render kernel's fragment images (TensorVMSplit, at most two encoding frequencies: the shape every shipped config has)
-    const bool has16 = d.variant == 0 && !(d.view_pe > 2 || d.fea_pe > 2);
+    // (round 6: REFTensoRF scenes too — check_desc admits them at the built-for shape only — with the heads' fragments beside them)
+    const bool has16 = !(d.view_pe > 2 || d.fea_pe > 2);
     L.img16 = has16 ? take(TVR16_IMAGE_BYTES / 4) : 0;
     L.basg16 = has16 ? take(TVR16_BASG_BYTES / 4) : 0;
+    L.refg16 = (has16 && d.variant == 1) ? take(TVR16_REFG_BYTES / 4) : 0;
     for (int i = 0; i < 3; ++i) {
         const size_t W = d.grid[kMatH[i][0]], H = d.grid[kMatH[i][1]], Ln = d.grid[kVecH[i]];
         L.aplane16[i] = take((H + 1) * (W + 1) * TVR_CA / 2);
@@ -214,8 +216,9 @@ int tvr_scene_create(const tvr_scene_desc *desc, void *packed_dev, size_t packed
     v.b3 = (const float *)(s->packed + L.b3);
     v.gen = (desc->view_pe > 2 || desc->fea_pe > 2) ? 1 : 0;
     v.w1gen = v.gen ? (const void *)(s->packed + L.w1gen) : nullptr;
-    v.img16 = (desc->variant == 0 && !v.gen) ? (const void *)(s->packed + L.img16) : nullptr;
+    v.img16 = !v.gen ? (const void *)(s->packed + L.img16) : nullptr;
     v.basg16 = v.img16 ? (const void *)(s->packed + L.basg16) : nullptr;
+    v.refg16 = (v.img16 && desc->variant == 1) ? (const void *)(s->packed + L.refg16) : nullptr;
     v.near_ = desc->near_;
     v.far_ = desc->far_;
     v.step = desc->step_size;
@@ -268,11 +271,14 @@ int tvr_scene_update(tvr_scene *s, const tvr_scene_params *p, void *stream_)
     for (int r = 0; r < 3; ++r) HIP_TRY(launch_copy_f32((float *)(img + TVR_IMG_W3 + r * TVR_IMG_W3_ROW), p->W3 + (size_t)r * d.featureC, d.featureC, stream));
     HIP_TRY(launch_copy_f32((float *)(s->packed + s->lay.b3), p->b3, 3, stream));
     HIP_TRY(launch_zero_f32((float *)(img + TVR_MLP_IMAGE_BYTES), (TVR_MLP_IMAGE_BYTES_REF - TVR_MLP_IMAGE_BYTES) / 4, stream));
-    if (s->dev.img16)
-        HIP_TRY(launch_pack16(p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, p->basis_mat, s->packed + s->lay.img16, s->packed + s->lay.basg16, sh, stream));
     if (d.variant == 1) {
         for (int i = 0; i < 4; ++i)
             if (!p->ref_W[i] || !p->ref_b[i]) return fail(TVR_ERR_INVALID, "REFTensoRF linear %d (normal, diffuse, specular, rho) is NULL", i);
+    }
+    if (s->dev.img16)
+        HIP_TRY(launch_pack16(p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, p->basis_mat, s->packed + s->lay.img16, s->packed + s->lay.basg16, sh, stream,
+                              d.variant == 1 ? p->ref_W : nullptr, d.variant == 1 ? p->ref_b : nullptr, d.variant == 1 ? s->packed + s->lay.refg16 : nullptr));
+    if (d.variant == 1) {
         HIP_TRY(launch_pack_ref(p->ref_W, p->ref_b, img + TVR_IMG_REFW, (float *)(img + TVR_IMG_REFB), stream));
     }
     s->params_set = true;

@@ -92,6 +92,7 @@ static_assert(TVR_MLP_IMAGE_BYTES_REF + 16 <= 160 * 1024, "REFTensoRF's LDS imag
 #define TVR16_BASL (TVR16_BASH + TVR16_BAS_BYTES)    // lo parts: k-steps 0..2 at s * 1728, k-step 4 at 3 * 1728
 #define TVR16_BASL_S4 (3 * TVR16_BAS_STEP)
 #define TVR16_IMAGE_BYTES (TVR16_BASL + TVR16_BAS_BYTES - TVR16_BAS_STEP)       // 163 360 B (+ 16 B of matrix tokens <= 163 840)
+#define TVR16_REFG_BYTES (10 * TVR16_FRAG + 256)
 #define TVR16_BASG_BYTES (2 * TVR16_FRAG)            // global: lo parts of basis k-step 3, row blocks 0 and 1 as full fragments (rows >= 27 zero)
 static_assert(TVR16_IMAGE_BYTES + 16 <= 160 * 1024, "the 16x16x32 LDS image must fit the CU's 160 KB");
 static_assert(TVR16_W3 % 16 == 0 && TVR16_BASH % 16 == 0, "float4 / uint4 reads need 16-B alignment");
@@ -111,6 +112,7 @@ struct SceneDev {
     const float *b3;              // [3]
     const void *img16;            // TVR16_IMAGE_BYTES: the LDS image of the 16x16x32 render kernel (TensorVMSplit scenes with at most two encoding frequencies), or nullptr
     const void *basg16;           // TVR16_BASG_BYTES
+    const void *refg16;           // REFTensoRF (round 6): TVR16_REFG_BYTES — the four heads as the third row block of the basis product: [5 k-steps][hi | lo] full fragments + 16 bias floats
     float near_, far_, step, shift, scale, thres;
     int act;
     int variant;                  // 0 TensorVMSplit, 1 REFTensoRF

@@ -68,7 +68,7 @@ hipError_t launch_shade(const SceneDev &sc, int src, int dst, const ShadeArgs &a
 hipError_t launch_shade16(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream);
 struct MlpShape;
 hipError_t launch_pack16(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3, const float *basis, void *img, void *basg,
-                         const MlpShape &sh, hipStream_t stream);
+                         const MlpShape &sh, hipStream_t stream, const float *const *ref_W = nullptr, const float *const *ref_b = nullptr, void *refg = nullptr);
 hipError_t launch_pack_plane(const float *in, float *out, int Cin, int C, int H, int W, hipStream_t stream);
 // the scene's MLP_Fea / basis shape as the reference holds it (<= the shape the kernels are built for; packed with zero padding)
 struct MlpShape {

@@ -1086,7 +1086,11 @@ static hipError_t launch_shade_v(const SceneDev &sc, int src, int dst, const Sha
 #endif
 #if TVR_SHADE16
     // round 5: the render path of TensorVMSplit scenes in the default arithmetic runs on 16x16x32 tiles (tvr_shade16.hip); every other mode stays here
-    if constexpr (!REF) { if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE && sc.arith == TVR_ARITH_F32 && sc.img16) return launch_shade16(sc, a, stream); }
+    // round 6: REFTensoRF's render path too (TVR_SHADE16_REF=0: A/B builds keep it on this file's kernel)
+#ifndef TVR_SHADE16_REF
+#define TVR_SHADE16_REF 1
+#endif
+    if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE && sc.arith == TVR_ARITH_F32 && sc.img16 && (!REF || (TVR_SHADE16_REF && sc.refg16))) return launch_shade16(sc, a, stream);
 #endif
     if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, REF, true>(sc, a, stream) : launch_shade_ar<SH_SRC_QUEUE, SH_DST_QUEUE, REF, false>(sc, a, stream);
     if (src == SH_SRC_XYZ && dst == SH_DST_FEAT) return rc ? launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, true>(sc, a, stream) : launch_shade_t<SH_SRC_XYZ, SH_DST_FEAT, REF, false>(sc, a, stream);

@@ -152,7 +152,26 @@ __device__ __forceinline__ float group_max2(float a, float b)
     return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
 
-template <bool RC>
+// value of lane group 0's 16-lane row in every lane group (two swaps: 16-lane rows inside a half, then the halves)
+__device__ __forceinline__ float bcast_g0(float v)
+{
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);      // q0 = {v0, v0, v2, v2}
+    unsigned lo, hi;
+    halves_u(q[0], lo, hi);
+    return __uint_as_float(lo);
+}
+// value of lane group 1's row in lane groups 0 and 1 (and group 3's in 2 and 3)
+__device__ __forceinline__ float from_g1(float v)
+{
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);      // q1 = {v1, v1, v3, v3}
+    return __uint_as_float(q[1]);
+}
+
+// REF (round 6): REFTensoRF's render path (models/REFTensoRF.py:107-133, 174-256; what configs/Scar.txt:28 runs) on the same tiles.  The four heads on h (normal 3, specular
+// tint 1, diffuse 3, rho 1) are a THIRD 16-row block of the basis product — 30 more MFMAs, A fragments from global memory (10 KB, L1 / L2 resident; the LDS is full),
+// requested behind the phase boundary and used after the two feature blocks; the normalised normal gives d.n and the reflection direction, which take the places of the
+// view direction (base rows 27..29) and of the unused row 30 (-d.n: MLPRender_Fea_Ref's input 0) in layer 1's B operands; the colour is relu(tint) * rgb_s + rgb_d.
+template <bool RC, bool REF>
 __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_kernel(const SceneDev sc, const ShadeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
 
         // ---------------------------------------------------------------- phase boundary + basis product ----
         float FA[8], FB[8];                            // base values: r < 4: row 4g + r; r >= 4: row 16 + 4g + r - 4 of the feature tile
+        float GA[4] = {0.f, 0.f, 0.f, 0.f}, GB[4] = {0.f, 0.f, 0.f, 0.f}, dotA = 0.0f, dotB = 0.0f;       // REF: head outputs of this lane's rows; -d.n of both entries
         {
             constexpr int LO = TVR16_BASL - TVR16_BASH;
             AF16 br[4];                                // ring over the ten (k-step, row block) fragments
@@ -385,6 +405,18 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
             bld(0); bld(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             S16_SB;
+            AF16 rg[REF ? 5 : 1];                      // REF: the heads' fragments (k-steps 0..4), in flight under the token wait and the 60 MFMAs of the feature blocks
+            float4 rbias = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (REF) {
+                unsigned roff = (unsigned)(lane * 16);
+                asm volatile("" : "+v"(roff));
+#pragma unroll
+                for (int s5 = 0; s5 < 5; ++s5) {
+                    rg[s5].h = *(const uint4 *)((const unsigned char *)sc.refg16 + (roff + (unsigned)((2 * s5) * TVR16_FRAG)));
+                    rg[s5].l = *(const uint4 *)((const unsigned char *)sc.refg16 + (roff + (unsigned)((2 * s5 + 1) * TVR16_FRAG)));
+                }
+                rbias = *(const float4 *)((const unsigned char *)sc.refg16 + 10 * TVR16_FRAG + 16 * g);      // head biases of rows 4g .. 4g+3 (zeros in groups 2, 3)
+            }
             S16_STAMP(tg1);
             {                                          // take the SIMD's matrix token (bounded: a stuck token costs speed, never a hang or a pixel)
 #if S16_MTOKEN
@@ -414,11 +446,33 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { FA[r] = aF[0][0][r]; FA[4 + r] = aF[1][0][r]; FB[r] = aF[0][1][r]; FB[4 + r] = aF[1][1][r]; }
+            if (REF) {                                 // the heads: rows 4g + r of the third block = {normal x y z, tint} in group 0, {diffuse r g b, rho} in group 1
+                f32x4 gA = f32x4{rbias.x, rbias.y, rbias.z, rbias.w}, gB = gA;
+#pragma unroll
+                for (int s5 = 0; s5 < 5; ++s5) mfma6(rg[s5], hA[s5], hB[s5], gA, gB);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { GA[r] = gA[r]; GB[r] = gB[r]; }
+            }
         }
         S16_STAMP(tg2);
+        if (REF) {
+            // REFTensoRF.execute :215-227 in every lane for both entries (the normal sits in group 0: broadcast): normalise, d = -view, dot = d.n,
+            // reflection = 2 dot n - d; the MLP takes the reflection as its direction and -dot as input 0 (row 30: only its t = 0 slot has a weight)
+            auto reflect = [&](const float G[4], float dv[3], float &dotin) {
+                const float n0 = bcast_g0(G[0]), n1 = bcast_g0(G[1]), n2 = bcast_g0(G[2]);
+                const float nrm = sqrtf(fmaxf((n0 * n0 + n1 * n1) + n2 * n2, 1e-30f));
+                const float nx = n0 / nrm, ny = n1 / nrm, nz = n2 / nrm;
+                const float dx = -dv[0], dy = -dv[1], dz = -dv[2];
+                const float dot = (dx * nx + dy * ny) + dz * nz;
+                dv[0] = 2.0f * dot * nx - dx; dv[1] = 2.0f * dot * ny - dy; dv[2] = 2.0f * dot * nz - dz;
+                dotin = -dot;
+            };
+            reflect(GA, dA, dotA);
+            reflect(GB, dB, dotB);
+        }
         // rows 27 (group 2, r = 7), 28, 29 (group 3, r = 4, 5): the view direction; row 30 unused; row 31 (group 3, r = 7) the constant 1 whose column is b1
         if (g == 2) { FA[7] = dA[0]; FB[7] = dB[0]; }
-        if (g == 3) { FA[4] = dA[1]; FA[5] = dA[2]; FA[6] = 0.0f; FA[7] = 1.0f; FB[4] = dB[1]; FB[5] = dB[2]; FB[6] = 0.0f; FB[7] = 1.0f; }
+        if (g == 3) { FA[4] = dA[1]; FA[5] = dA[2]; FA[6] = REF ? dotA : 0.0f; FA[7] = 1.0f; FB[4] = dB[1]; FB[5] = dB[2]; FB[6] = REF ? dotB : 0.0f; FB[7] = 1.0f; }
         if (RC) {
 #pragma unroll
             for (int r = 0; r < 8; r += 2) { rmaxA = absmax2(FA[r], FA[r + 1], rmaxA); rmaxB = absmax2(FB[r], FB[r + 1], rmaxB); }
@@ -624,6 +678,18 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
 #else
             r0 = sigmoid_f(r0 + b3.x); r1 = sigmoid_f(r1 + b3.y); r2 = sigmoid_f(r2 + b3.z);
 #endif
+            if (REF) {                                 // REFTensoRF.py:232  specular_tint * clamp(rgb_s, 0) + rgb_d, for the entry this lane stores (group 0: A, group 2: B)
+                // tint sits in group 0 (row 3), rgb_d in group 1 (rows 4..6): entry A's into group 0 by one row swap, entry B's into group 2 by a row swap and a half swap
+                float tA = GA[3], tB, tdummy;
+                halves_f(GB[3], tB, tdummy);                                     // group 0's tint of entry B in both halves
+                const float a0 = from_g1(GA[0]), a1 = from_g1(GA[1]), a2 = from_g1(GA[2]);
+                float b0, b1, b2, bd;
+                halves_f(from_g1(GB[0]), b0, bd); halves_f(from_g1(GB[1]), b1, bd); halves_f(from_g1(GB[2]), b2, bd);
+                const float tint = fmaxf(up ? tB : tA, 0.0f);
+                r0 = tint * fmaxf(r0, 0.0f) + (up ? b0 : a0);
+                r1 = tint * fmaxf(r1, 0.0f) + (up ? b1 : a1);
+                r2 = tint * fmaxf(r2, 0.0f) + (up ? b2 : a2);
+            }
             if (RC) {                                  // an operand of this entry left fp16's range: the colour is NaN, not a clipped product
                 const float m = group_max2(rmaxA, rmaxB);
                 if (!(m < TVR_F16_MAX)) r0 = r1 = r2 = __builtin_nanf("");
@@ -656,25 +722,33 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
 hipError_t launch_shade16(const SceneDev &sc, const ShadeArgs &a, hipStream_t stream)
 {
     const int lds = TVR16_IMAGE_BYTES + 16;
-    const bool rc = sc.range_check != 0;
-    hipError_t e = rc ? hipFuncSetAttribute((const void *)shade16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-                      : hipFuncSetAttribute((const void *)shade16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const bool rc = sc.range_check != 0, ref = sc.variant == 1;
+    const void *kf = ref ? (rc ? (const void *)shade16_kernel<true, true> : (const void *)shade16_kernel<false, true>)
+                         : (rc ? (const void *)shade16_kernel<true, false> : (const void *)shade16_kernel<false, false>);
+    hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     unsigned grid = 256;       // one workgroup per CU (the LDS holds the weights), persistent over 32-entry tiles
 #ifdef TVR_EXP_GRID
     if (const char *gs = getenv("TVR_EXP_GRID_SHADE")) { const long long v = atoll(gs); if (v > 0 && v < 256) grid = (unsigned)v; }
 #endif
-    if (rc) hipLaunchKernelGGL((shade16_kernel<true>), dim3(grid), dim3(S16_THREADS), lds, stream, sc, a);
-    else hipLaunchKernelGGL((shade16_kernel<false>), dim3(grid), dim3(S16_THREADS), lds, stream, sc, a);
+    if (ref) {
+        if (rc) hipLaunchKernelGGL((shade16_kernel<true, true>), dim3(grid), dim3(S16_THREADS), lds, stream, sc, a);
+        else hipLaunchKernelGGL((shade16_kernel<false, true>), dim3(grid), dim3(S16_THREADS), lds, stream, sc, a);
+    } else {
+        if (rc) hipLaunchKernelGGL((shade16_kernel<true, false>), dim3(grid), dim3(S16_THREADS), lds, stream, sc, a);
+        else hipLaunchKernelGGL((shade16_kernel<false, false>), dim3(grid), dim3(S16_THREADS), lds, stream, sc, a);
+    }
     return hipGetLastError();
 }
 
 // ---- weights -> the fragment images (tvr_device.h, TVR16_*).  One thread per (fragment, lane, j). ----
 //  mode 0: W1 [5][8] fragments; mode 1: W2 [4][8]; mode 2: basis [5][2] (compact, hi -> the image, lo -> the image or the global k-step-3 fragments)
+//  mode 3 (REFTensoRF): the heads' fragments -> refg [5 k-steps][hi | lo] as full fragments: row ci < 8 = {normal 0..2, specular, diffuse 0..2, rho}, k natural as mode 2
+struct RefHeads { const float *W[4]; };      // tvr_scene_params.ref_W order: normal [3,144], diffuse [3,144], specular [1,144], rho [1,144]
 __global__ __launch_bounds__(256) void pack16_kernel(const float *__restrict__ W, const float *__restrict__ bias, unsigned char *__restrict__ img,
-                                                     unsigned char *__restrict__ basg, int mode, const MlpShape sh)
+                                                     unsigned char *__restrict__ basg, int mode, const MlpShape sh, const RefHeads rh, int ref)
 {
-    const int nfr = mode == 0 ? 40 : (mode == 1 ? 32 : 10);
+    const int nfr = mode == 0 ? 40 : (mode == 1 ? 32 : (mode == 3 ? 5 : 10));
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfr * 512) return;
     const int fr = i >> 9, lane = (i >> 3) & 63, j = i & 7, ci = lane & 15, g = lane >> 4;
@@ -683,7 +757,8 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float *__restrict__ W
     if (mode == 0) {
         const int s = fr >> 3, rb = fr & 7, row = 16 * rb + ci, ii = 8 * s + j, r = ii / 5, t = ii % 5;
         const int cbase = r < 4 ? 4 * g + r : 16 + 4 * g + (r - 4);
-        const int idx = ref_in_index(cbase, t, sh.fea_pe, sh.view_pe);
+        int idx = ref_in_index(cbase, t, sh.fea_pe, sh.view_pe);
+        if (ref) idx = cbase == 30 ? (t == 0 ? 0 : -1) : (idx >= 0 ? idx + 1 : -1);        // MLPRender_Fea_Ref (REFTensoRF.py:19-24): input 0 is the dot product, everything else moves up by one
         if (idx >= 0 && row < sh.featureC) w = W[(size_t)row * sh.n_in + idx];
         if (cbase == 31 && t == 0 && row < sh.featureC) w = bias[row];          // the constant-1 input: b1 rides in the weight image
         ph = (unsigned short *)(img + TVR16_W1H + fr * TVR16_FRAG + lane * 16) + j;
@@ -694,6 +769,14 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float *__restrict__ W
         if (row < sh.featureC && u < sh.featureC) w = W[(size_t)row * sh.featureC + u];
         ph = (unsigned short *)(img + TVR16_W2H + fr * TVR16_FRAG + lane * 16) + j;
         pl = (unsigned short *)(img + TVR16_W2L + fr * TVR16_FRAG + lane * 16) + j;
+    } else if (mode == 3) {
+        const int s = fr, k = 32 * s + 8 * g + j;
+        if (k < TVR_KAPP && ci < 8) {
+            const float *Wh = ci < 3 ? rh.W[0] + (size_t)ci * TVR_KAPP : (ci == 3 ? rh.W[2] : (ci < 7 ? rh.W[1] + (size_t)(ci - 4) * TVR_KAPP : rh.W[3]));
+            w = Wh[k];
+        }
+        ph = (unsigned short *)(basg + (2 * s) * TVR16_FRAG + lane * 16) + j;          // (`basg` is the heads' buffer in this mode)
+        pl = (unsigned short *)(basg + (2 * s + 1) * TVR16_FRAG + lane * 16) + j;
     } else {
         // k slot (s, g, j) = 32 s + 8 g + j, the kernels' natural k = 48 * plane + channel (k-step 4: groups 0, 1 only — the kernel reads zeros in groups 2, 3)
         const int s = fr >> 1, rb = fr & 1, row = 16 * rb + ci, k = 32 * s + 8 * g + j;
@@ -715,8 +798,16 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float *__restrict__ W
     if (pl) *pl = (unsigned short)lo;
 }
 
+// the heads' biases as the initial accumulators of the third row block: [4 groups][4 rows] floats behind the ten fragments (groups 2, 3: zeros)
+__global__ void pack16_ref_bias_kernel(const float *__restrict__ bn, const float *__restrict__ bd, const float *__restrict__ bs, const float *__restrict__ br, float *__restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i >= 16) return;
+    out[i] = i < 3 ? bn[i] : (i == 3 ? bs[0] : (i < 7 ? bd[i - 4] : (i == 7 ? br[0] : 0.0f)));
+}
+
 hipError_t launch_pack16(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3, const float *basis, void *img, void *basg,
-                         const MlpShape &sh, hipStream_t stream)
+                         const MlpShape &sh, hipStream_t stream, const float *const *ref_W, const float *const *ref_b, void *refg)
 {
     unsigned char *im = (unsigned char *)img;
     hipError_t e;
@@ -726,8 +817,15 @@ hipError_t launch_pack16(const float *W1, const float *b1, const float *W2, cons
     if ((e = launch_copy_f32((float *)(im + TVR16_B3), b3, 3, stream)) != hipSuccess) return e;
     for (int r = 0; r < 3; ++r)
         if ((e = launch_copy_f32((float *)(im + TVR16_W3 + r * 512), W3 + (size_t)r * sh.featureC, sh.featureC, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pack16_kernel, dim3(40 * 512 / 256), dim3(256), 0, stream, W1, b1, im, (unsigned char *)basg, 0, sh);
-    hipLaunchKernelGGL(pack16_kernel, dim3(32 * 512 / 256), dim3(256), 0, stream, W2, nullptr, im, (unsigned char *)basg, 1, sh);
-    hipLaunchKernelGGL(pack16_kernel, dim3(10 * 512 / 256), dim3(256), 0, stream, basis, nullptr, im, (unsigned char *)basg, 2, sh);
+    RefHeads rh = {{nullptr, nullptr, nullptr, nullptr}};
+    const int ref = refg != nullptr;
+    if (ref) for (int i = 0; i < 4; ++i) rh.W[i] = ref_W[i];
+    hipLaunchKernelGGL(pack16_kernel, dim3(40 * 512 / 256), dim3(256), 0, stream, W1, b1, im, (unsigned char *)basg, 0, sh, rh, ref);
+    hipLaunchKernelGGL(pack16_kernel, dim3(32 * 512 / 256), dim3(256), 0, stream, W2, nullptr, im, (unsigned char *)basg, 1, sh, rh, ref);
+    hipLaunchKernelGGL(pack16_kernel, dim3(10 * 512 / 256), dim3(256), 0, stream, basis, nullptr, im, (unsigned char *)basg, 2, sh, rh, ref);
+    if (ref) {
+        hipLaunchKernelGGL(pack16_kernel, dim3(5 * 512 / 256), dim3(256), 0, stream, nullptr, nullptr, im, (unsigned char *)refg, 3, sh, rh, ref);
+        hipLaunchKernelGGL(pack16_ref_bias_kernel, dim3(1), dim3(64), 0, stream, ref_b[0], ref_b[1], ref_b[2], ref_b[3], (float *)((unsigned char *)refg + 10 * TVR16_FRAG));
+    }
     return hipGetLastError();
 }

@@ -71,8 +71,8 @@ def test_abi_argument_errors_without_gpu():
     assert lib.tvr_line_ortho_backward(one, one, nc, ns, 1, None, None) == -1
     d.variant = 2
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"variant" in lib.tvr_last_error()
-    d.variant = 1                                                       # REFTensoRF: the same layout (the LDS image has room for both) less the 16x16x32 fragment images
-    assert lib.tvr_scene_packed_bytes(C.byref(d)) == nbytes - 163584 - 2048
+    d.variant = 1                                                       # REFTensoRF: the same layout + (round 6) the four heads as fragments of the 16x16x32 render kernel: 10 KB + 256 B
+    assert lib.tvr_scene_packed_bytes(C.byref(d)) == nbytes + 10 * 1024 + 256
     d.featureC = 64                                                     # ... at the standard shape only
     assert lib.tvr_scene_packed_bytes(C.byref(d)) == 0 and b"REFTensoRF" in lib.tvr_last_error()
     d.featureC = 128
