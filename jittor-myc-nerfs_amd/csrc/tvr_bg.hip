@@ -403,6 +403,9 @@ struct AF { uint4 h, l; };
 #ifndef TVR_BG_SCHED
 #define TVR_BG_SCHED 1            // sched_group_barrier windows in the units (0: hipcc's own order, A/B)
 #endif
+#ifndef TVR_BG_STAGE
+#define TVR_BG_STAGE 0            // 1: the chunk transfer as global_load_dwordx4 -> registers -> ds_write_b128 one k-step later, instead of LDS-DMA (whose issue holds the wave ~100 cycles per KB)
+#endif
 #ifndef TVR_BG_PRIOFLIP
 #define TVR_BG_PRIOFLIP 0         // experiment: the two waves of a SIMD (w and w + 4) take turns at priority 1, k-step by k-step (keeps them abreast between the chunk barriers)
 #endif
@@ -521,18 +524,42 @@ __global__ void __launch_bounds__(WAVES * 64, 1) bg_mlp_stream_kernel(BgProgram 
 #if TVR_BG_PRIOFLIP
     unsigned flip = (unsigned)(wave >> 2);
 #endif
+#if TVR_BG_STAGE
+    uint4 st_val[NTW];
+    unsigned st_dst[NTW];
+    int st_have[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { st_have[i] = 0; st_dst[i] = 0; st_val[i] = make_uint4(0, 0, 0, 0); }
+#endif
     auto dma_step = [&]() {
 #if TVR_BG_PRIOFLIP
         flip ^= 1u;
         if (flip) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
 #endif
+#if TVR_BG_STAGE
+        // register-staged: the piece requested one k-step ago goes to LDS now, the next one is requested
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            if (st_have[i]) {
+                *reinterpret_cast<uint4 *>(smem + st_dst[i] + lane * 16) = st_val[i];
+                st_have[i] = 0;
+            }
+            if (dma_p < dma_n) {
+                st_val[i] = *reinterpret_cast<const uint4 *>(dma_src + (size_t)dma_p * 1024);
+                st_dst[i] = dma_dst + (unsigned)dma_p * 1024u;
+                st_have[i] = 1;
+                dma_p += WAVES;
+            }
+        }
+#else
 #pragma unroll
         for (int i = 0; i < NTW; ++i)                                   // (two tiles per wave: half the waves, twice the pieces each, twice the MFMAs per k-step to put them under)
             if (dma_p < dma_n) {
                 __builtin_amdgcn_global_load_lds((bg_glb_void *)(dma_src + (size_t)dma_p * 1024), (bg_lds_void *)(smem + dma_dst + dma_p * 1024), 16, 0, 0);
                 dma_p += WAVES;
             }
+#endif
     };
     auto issue_dma = [&](int c, int half) {                             // arm the DMA of chunk c into `half`
         dma_n = P.chunk_nblk[c] * 2;
@@ -546,6 +573,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) bg_mlp_stream_kernel(BgProgram 
     auto enter_chunk = [&]() {
         BG_STAMP(ta);
         while (dma_p < dma_n) dma_step();                               // (a chunk with fewer k-steps than pieces per wave: the rest now)
+#if TVR_BG_STAGE
+        dma_step();                                                     // (the last staged piece into LDS; the barrier below waits for the ds_write)
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BG_STAMP(tb);
         __syncthreads();

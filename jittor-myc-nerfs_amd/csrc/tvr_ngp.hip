@@ -382,6 +382,12 @@ struct GridCfg {
     uint32_t hashed;                      // bit l: level l uses the spatial hash
 };
 
+#ifndef TVR_NGP_DIAG
+#define TVR_NGP_DIAG 0            // timing stand-ins for the leave-parts-out table of profiles/r06_ngp_bound.txt (never shipped)
+#endif
+#ifndef TVR_NGP_DIAG_MASK
+#define TVR_NGP_DIAG_MASK 0xFFFFu
+#endif
 #ifndef TVR_NGP_PAIR              // 1: the x neighbours of a corner pair as one 16-byte load where the table layout allows (encode_level_pair).  Round 5: bit-identical,
 #define TVR_NGP_PAIR 0            // and SLOWER — ngp_render_kernel 15.0 - 15.7 ms against 13.0 (profiles/r05_ngp_pair_loads.txt): off
 #endif
@@ -659,7 +665,13 @@ __device__ __forceinline__ float4 field_tile(const GridCfg &g, const float2 *__r
         const uint32_t o1 = hh ? g.offsets[2 * p + 2] : g.offsets[2 * p + 1];
         const float sc = hh ? g.scale[2 * p + 1] : g.scale[2 * p];
         const bool hashed = (g.hashed >> (2 * p + hh)) & 1u;
-#if TVR_NGP_PAIR
+#if TVR_NGP_DIAG == 1 || TVR_NGP_DIAG == 3        // timing stand-ins (WRONG pictures): 1 = no table gather at all, 3 = only the levels with (mask >> level) & 1 gathered
+        float2 r = make_float2(px * sc, py * sc);
+        if (TVR_NGP_DIAG == 3 && ((TVR_NGP_DIAG_MASK >> (2 * p)) & 3u)) {
+            const bool mine = (TVR_NGP_DIAG_MASK >> (2 * p + hh)) & 1u;
+            if (mine) r = encode_level(tab + o0, hashed, o1 - o0, sc, px, py, pz);
+        }
+#elif TVR_NGP_PAIR
         const float2 r = encode_level_pair(rs, o0, hashed, o1 - o0, sc, px, py, pz);
 #else
         const float2 r = encode_level(tab + o0, hashed, o1 - o0, sc, px, py, pz);
@@ -668,6 +680,14 @@ __device__ __forceinline__ float4 field_tile(const GridCfg &g, const float2 *__r
         f1[p] = r.y;
         if ((p + 1) % TVR_NGP_INFLIGHT == 0) __builtin_amdgcn_sched_barrier(0);      // bounds the loads in flight (registers)
     }
+#if TVR_NGP_DIAG == 2                              // timing stand-in (WRONG pictures): the gather alone, no network
+    {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { s0 += f0[p]; s1 += f1[p]; }
+        return make_float4(s0, s1, s0 - s1, -4.0f + 1e-3f * (s0 + s1 + shv[0]));
+    }
+#endif
     // ---- MATRIX phase
     float density_raw;
     f32x16 e = {0};
