@@ -530,14 +530,17 @@ static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     const ScratchLayout Lp = scratch_layout(P.rays, S);
     HIP_TRY(hipEventRecord(s->ev_fork, stream));
     for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(s->side[i], s->ev_fork, 0));
-    for (int k = 0; k < P.K; ++k) {
-        const int64_t a = (int64_t)k * P.rays, m = (a + P.rays <= n_rays) ? P.rays : n_rays - a;
+    // (equal pieces: a half- or third-size first piece on stream 1 — a stagger from the start — measured 18.71 - 18.76 ms against 18.64 - 18.67, profiles/r06_split_frame.txt)
+    int64_t a = 0;
+    for (int k = 0; a < n_rays; ++k) {
+        const int64_t m = (a + P.rays <= n_rays) ? P.rays : n_rays - a;
         const MarchSampling smk = {sm.jitter ? sm.jitter + a : nullptr, sm.zv ? sm.zv + (size_t)a * S : nullptr};
         hipEvent_t *ev = nullptr;
         if (prof && !(ev = profile_slot(prof))) return fail(TVR_ERR_HIP, "tvr_profile: hipEventCreate failed");
         rc = render_one(s, rays + 6 * a, m, S, white_bg, smk, eps_T, rgb_out + 3 * a, depth_out + a, lam6_out ? lam6_out + a : nullptr,
                         (char *)scratch + (size_t)(k & 1) * Lp.total, Lp, nullptr, stats, ev, s->side[k & 1]);
         if (rc != TVR_OK) return rc;
+        a += m;
     }
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipEventRecord(s->ev_join[i], s->side[i]));
