@@ -31,8 +31,8 @@ def report():
 def test_every_shade_kernel_variant_is_audited(report):
     # {queue, xyz->features, features->rgb} x {fp16 range check on, off} + the training forward (h -> rgb + activations), each x {TensorVMSplit, REFTensoRF},
     # + the render and mlp_render kernels in the two reduced-product arithmetics (2 kernels x 2 models x 2 range-check states x 2 modes)
-    # + the backward kernels (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps) + shade16_kernel x 2 range-check states
-    assert len(report) == 36, sorted(report)
+    # + the backward kernels (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps) + shade16_kernel x 2 range-check states x {TensorVMSplit, REFTensoRF (round 6)}
+    assert len(report) == 38, sorted(report)
 
     assert all(v["mfma"] >= 27 for v in report.values())
 
@@ -43,6 +43,8 @@ def test_vmcnt_accounting_of_mfma_kernels(report):
 
 
 def test_phase_rule_of_mfma_kernels(report):
+    # (shade16_kernel<RC, REF = true>, round 6, requests the heads' ten fragments from global memory behind its phase boundary: hipcc issues all ten in front of the first MFMA,
+    #  so the shipped code satisfies the rule although the kernel does not rely on it)
     for name, v in report.items():
         assert v["vmem_loads_between_first_and_last_mfma"] == 0, f"{name}: a global (or spill) load sits between the MFMAs of a tile"
         assert v["war_adjacent"] == 0, (name, v["examples"]["war"])
