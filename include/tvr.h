@@ -204,6 +204,8 @@ int tvr_scene_destroy(tvr_scene *scene);
 int tvr_scene_set_render_pieces(tvr_scene *scene, int32_t piece_rays);   /* 0: off; < 0: the library's default; else >= 16 (pieces are rounded up to multiples of 512 rays, of 16 below 512) */
 int tvr_scene_get_render_pieces(const tvr_scene *scene);
 size_t tvr_render_scratch_bytes(const tvr_scene *scene, int64_t n_rays, int32_t n_samples);
+/* enough for a call WITHOUT `dense`: two pieces' worth when the call is rendered in pieces (1.3 GB instead of 13 GB for an 800x800 x 512 frame), else the same as above */
+size_t tvr_render_scratch_bytes_min(const tvr_scene *scene, int64_t n_rays, int32_t n_samples);
 int tvr_render(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, int32_t white_bg,
                const float *jitter, float eps_T, float *rgb_out, float *depth_out,
                void *scratch, size_t scratch_bytes, const tvr_dense_out *dense, uint64_t *stats,

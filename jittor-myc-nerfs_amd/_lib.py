@@ -103,6 +103,7 @@ SYMBOLS = {
                                            C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_void_p]),
     "tvr_scene_destroy": (C.c_int, [C.c_void_p]),
     "tvr_render_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
+    "tvr_render_scratch_bytes_min": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "tvr_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DenseOut), C.c_void_p,
                              C.c_void_p, C.c_void_p]),

@@ -435,6 +435,15 @@ size_t tvr_render_scratch_bytes(const tvr_scene *s, int64_t n_rays, int32_t n_sa
     return whole > two ? whole : two;
 }
 
+// What a call WITHOUT `dense` needs: a call rendered in pieces works in two pieces' scratch (1.3 GB instead of 13 GB for the 800x800 x 512 frame: the queue is sized for the
+// worst case, every sample of every ray shaded); a `dense` call is one launch set over the whole batch and needs tvr_render_scratch_bytes().
+size_t tvr_render_scratch_bytes_min(const tvr_scene *s, int64_t n_rays, int32_t n_samples)
+{
+    if (n_rays <= 0 || n_samples <= 0) return 256;
+    const PiecePlan P = piece_plan(s, n_rays);
+    return P.K > 1 ? 2 * scratch_layout(P.rays, n_samples).total : scratch_layout(n_rays, n_samples).total;
+}
+
 }  // extern "C"
 
 // one launch set (header clear, march, shade, composite) on `stream`; ev: four events or nullptr
@@ -501,7 +510,7 @@ static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     if ((size_t)n_rays * (size_t)S >= (1ull << 32)) return fail(TVR_ERR_INVALID, "n_rays*n_samples must be < 2^32 per call (chunk the rays)");
     if (!(eps_T >= 0.0f) || eps_T > s->desc.weight_thres)
         return fail(TVR_ERR_INVALID, "eps_T=%g must be in [0, weight_thres=%g] so that no appearance sample is skipped", eps_T, s->desc.weight_thres);
-    const size_t need = tvr_render_scratch_bytes(s, n_rays, S);
+    const size_t need = dense ? scratch_layout(n_rays, S).total : tvr_render_scratch_bytes_min(s, n_rays, S);
     if (!scratch || scratch_bytes < need) return fail(TVR_ERR_SCRATCH, "scratch %zu B < required %zu B", scratch_bytes, need);
     if ((uintptr_t)scratch % 256) return fail(TVR_ERR_SCRATCH, "scratch must be 256-byte aligned");
     if (prof && prof->n_calls >= prof->max_calls) return fail(TVR_ERR_INVALID, "profile is full (%d calls)", prof->max_calls);

@@ -418,9 +418,11 @@ struct AF { uint4 h, l; };
 #define BG_STAMP(x)
 #endif
 #ifndef TVR_BG_PD
-#define TVR_BG_PD 1               // fragment blocks read ahead of the one being multiplied (ring of TVR_BG_PD + 2 {hi, lo} pairs: 8 registers each)
+#define TVR_BG_PD 1               // fragment blocks read ahead of the one being multiplied (ring of PD + 2 {hi, lo} pairs: 8 registers each) in the embedding units
 #endif
-#define BG_RN (TVR_BG_PD + 2)
+#ifndef TVR_BG_PD_PREV
+#define TVR_BG_PD_PREV 1          // ... in the previous-activation units and the heads (2: measured below)
+#endif
 // the three products of one fragment block on ONE accumulator, back to back (a dependent chain of 32x32x16 MFMAs issues back to back: profiles/r04_mfma_issue_probe.txt);
 // per accumulator the order of the additions is tvr_mfma.h's / round 5's: Wlo*xhi, Whi*xlo, Whi*xhi
 template <int AR>
@@ -435,17 +437,17 @@ __device__ __forceinline__ void mfma3(const AF &A, const Frag &b, f32x16 &acc)
 // round 5's kernel) — so the reads run TVR_BG_PD blocks ahead here through a ring of {hi, lo} pairs, a fragment lives for 3 NTW MFMAs (the tiles of a wave SHARE every weight
 // fragment: with two tiles the LDS reads and the DMA per sample halve), and the next k-step's B fragments (relu + fp16 split, or the embedding's sin / cos) are derived under
 // the MFMAs of this one (VPG vector instructions per MFMA gap), as in tvr_shade.hip's matrix phase.
-template <int NB, int NG, int AR, int VPG, int NTW, typename GetB, typename Hook>
+template <int NB, int NG, int AR, int VPG, int NTW, int PD = TVR_BG_PD, typename GetB, typename Hook>
 __device__ __forceinline__ void run_unit(const unsigned char *lb, f32x16 (&acc)[NTW][NB], GetB getB, Hook hook)
 {
-    constexpr int NQ = NB * NG;
-    AF ring[BG_RN];
+    constexpr int NQ = NB * NG, RN = PD + 2;
+    AF ring[RN];
     auto ld = [&](int q) {
-        ring[q % BG_RN].h = *(const uint4 *)(lb + q * 2048);
-        if constexpr (AR >= 2) ring[q % BG_RN].l = *(const uint4 *)(lb + q * 2048 + 1024);
+        ring[q % RN].h = *(const uint4 *)(lb + q * 2048);
+        if constexpr (AR >= 2) ring[q % RN].l = *(const uint4 *)(lb + q * 2048 + 1024);
     };
 #pragma unroll
-    for (int q0 = 0; q0 < TVR_BG_PD; ++q0)
+    for (int q0 = 0; q0 < PD; ++q0)
         if (q0 < NQ) ld(q0);
     Frag b[NTW], nb[NTW];
 #pragma unroll
@@ -462,8 +464,8 @@ __device__ __forceinline__ void run_unit(const unsigned char *lb, f32x16 (&acc)[
 #pragma unroll
         for (int m = 0; m < NB; ++m) {
             const int q = g * NB + m;
-            if (q + TVR_BG_PD < NQ) ld(q + TVR_BG_PD);
-            const AF &A = ring[q % BG_RN];
+            if (q + PD < NQ) ld(q + PD);
+            const AF &A = ring[q % RN];
             // per accumulator the order of the additions is tvr_mfma.h's (Wlo*xhi, Whi*xlo, Whi*xhi); the tiles of the wave alternate, so no MFMA waits for the one before it
             if constexpr (AR >= 2) {
 #pragma unroll
@@ -479,7 +481,7 @@ __device__ __forceinline__ void run_unit(const unsigned char *lb, f32x16 (&acc)[
 #if TVR_BG_SCHED
 #pragma unroll
         for (int m = 0; m < NB; ++m) {
-            if (g * NB + m + TVR_BG_PD < NQ) BG_SG_DSR(AR >= 2 ? 2 : 1);
+            if (g * NB + m + PD < NQ) BG_SG_DSR(AR >= 2 ? 2 : 1);
 #pragma unroll
             for (int i = 0; i < AR * NTW; ++i) {
                 BG_SG_MFMA(1);
@@ -644,9 +646,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) bg_mlp_stream_kernel(BgProgram 
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) out[w][mb] = bias_acc(lbias + l * 128 + mb * 32, hh);
             if (P.base_prev[l]) {
-                run_unit<4, 4, AR, 2, NTW>(unit_ptr(), out, [&](int w, int g) { return relu_frag4<AR>(act[w], g); }, dma_step);
+                run_unit<4, 4, AR, 2, NTW, TVR_BG_PD_PREV>(unit_ptr(), out, [&](int w, int g) { return relu_frag4<AR>(act[w], g); }, dma_step);
                 cur += 16 * 2048;
-                run_unit<4, 4, AR, 2, NTW>(unit_ptr(), out, [&](int w, int g) { return relu_frag4<AR>(act[w], 4 + g); }, dma_step);
+                run_unit<4, 4, AR, 2, NTW, TVR_BG_PD_PREV>(unit_ptr(), out, [&](int w, int g) { return relu_frag4<AR>(act[w], 4 + g); }, dma_step);
                 cur += 16 * 2048;
             }
             if (P.base_pe[l]) {
@@ -684,7 +686,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) bg_mlp_stream_kernel(BgProgram 
                 hd[w][1] = bias_acc(lbias + 512, hh);
                 hd[w][2] = bias_acc(lbias + 512 + 32, hh);
             }
-            run_unit<3, 8, AR, 3, NTW>(lb, hd, [&](int w, int g) { return relu_frag4<AR>(act[w], g); }, dma_step);
+            run_unit<3, 8, AR, 3, NTW, TVR_BG_PD_PREV>(lb, hd, [&](int w, int g) { return relu_frag4<AR>(act[w], g); }, dma_step);
             f32x16 rh[NTW][2];
             Frag bv[NTW];
 #pragma unroll

@@ -841,7 +841,7 @@ class TensorBase(torch.nn.Module):
         if eps_T is None:
             eps_T = self.eps_T if self.eps_T is not None else float(self.rayMarch_weight_thres)
         self._settle_arith(rays, S, white_bg, eps_T)
-        nbytes = lib.tvr_render_scratch_bytes(sc, n, S)
+        nbytes = lib.tvr_render_scratch_bytes(sc, n, S) if dense else lib.tvr_render_scratch_bytes_min(sc, n, S)      # (a frame in pieces: two pieces' queue, 1.3 GB instead of 13)
         scratch = self._get_scratch(nbytes, scratch_slot)
         jit = None if jitter is None else _f32c(jitter, self.device).view(-1)
         if jit is not None and jit.shape[0] != n:
