@@ -228,7 +228,8 @@ class NerfPlusPlus(TensorVMSplit):
     background (Embedder + MLPNet over 512 samples per ray) is plain torch.  `rand_fg` / `rand_bg` inject the two jt.rand_like draws."""
 
     HUGE_NUMBER, TINY_NUMBER, BG_SAMPLES = 1e10, 1e-6, 512                                    # :4-5, :284
-    max_render_chunk = 65536      # rays per merged inference call (renderer): the background holds [rays, 512, ~20] fp32 temporaries (2.7 GB)
+    max_render_chunk = 655360     # rays per merged inference call (renderer): the background holds [rays, 512, ~20] fp32 temporaries — 24 GB for a whole 800x800 frame of the 288 GB
+                                  # this card has (round 6: 103.3 -> 98.7 ms per frame against 65 536-ray calls, which also stayed below tvr_render's pieces; lower it on smaller cards)
 
     render_rays_is_the_frame = False          # forward() adds the background; render_rays alone is the foreground field (render.FrameStream refuses this model)
 
