@@ -619,9 +619,13 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     if not prof_in_region:
+        keep_pieces = model.render_piece_rays
+        model.render_piece_rays = 0                                 # kernel durations of launches that have the chip (a 320 000-ray share would go out in pieces: see below)
         for s in range(args.steps):
             step(args.warmup + s, profile=prof, stats=stats if pipe is not None else None)    # (the graph replays carry neither events nor counters)
         torch.cuda.synchronize()
+        model.render_piece_rays = keep_pieces
+        model._ensure_scene()
     if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -643,6 +647,8 @@ def main():
         pr_ = ((n_mine + k_ - 1) // k_ + 511) // 512 * 512
         n_pieces = (n_mine + pr_ - 1) // pr_
     k_ms_timed, stats_timed = list(k_ms), stats
+    if not prof_in_region:
+        n_pieces = 1                                                # (the kernel durations above were taken with pieces off)
     if n_pieces > 1 and args.chunk == 0 and split == 1:
         keep = model.render_piece_rays
         model.render_piece_rays = 0
