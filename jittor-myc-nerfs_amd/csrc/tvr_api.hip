@@ -541,20 +541,23 @@ static int render_impl(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(s->side[i], s->ev_fork, 0));
     // (equal pieces: a half- or third-size first piece on stream 1 — a stagger from the start — measured 18.71 - 18.76 ms against 18.64 - 18.67, profiles/r06_split_frame.txt)
     int64_t a = 0;
-    for (int k = 0; a < n_rays; ++k) {
+    for (int k = 0; a < n_rays && rc == TVR_OK; ++k) {
         const int64_t m = (a + P.rays <= n_rays) ? P.rays : n_rays - a;
         const MarchSampling smk = {sm.jitter ? sm.jitter + a : nullptr, sm.zv ? sm.zv + (size_t)a * S : nullptr};
         hipEvent_t *ev = nullptr;
-        if (prof && !(ev = profile_slot(prof))) return fail(TVR_ERR_HIP, "tvr_profile: hipEventCreate failed");
+        if (prof && !(ev = profile_slot(prof))) { rc = fail(TVR_ERR_HIP, "tvr_profile: hipEventCreate failed"); break; }
         rc = render_one(s, rays + 6 * a, m, S, white_bg, smk, eps_T, rgb_out + 3 * a, depth_out + a, lam6_out ? lam6_out + a : nullptr,
                         (char *)scratch + (size_t)(k & 1) * Lp.total, Lp, nullptr, stats, ev, s->side[k & 1]);
-        if (rc != TVR_OK) return rc;
         a += m;
     }
+    // the join is enqueued whatever happened above: whatever DID go out on the two streams is ordered in front of the caller's next work (an error leaves the outputs
+    // undefined, never a side stream still writing them behind the caller's back)
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipEventRecord(s->ev_join[i], s->side[i]));
-        HIP_TRY(hipStreamWaitEvent(stream, s->ev_join[i], 0));
+        const hipError_t e1 = hipEventRecord(s->ev_join[i], s->side[i]);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(stream, s->ev_join[i], 0) : e1;
+        if (e2 != hipSuccess && rc == TVR_OK) rc = fail(TVR_ERR_HIP, "tvr_render: joining the piece streams: %s", hipGetErrorString(e2));
     }
+    if (rc != TVR_OK) return rc;
     if (prof) prof->n_calls++;
     return TVR_OK;
 }

@@ -67,20 +67,24 @@ if GRAPH:
         print("after capture", hdr(), flush=True)
         for i in range(4):
             graph.replay(); print("replay", i, hdr(), flush=True)
-    for _ in range(3): graph.replay()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(N): graph.replay()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
+    for _ in range(10): graph.replay()
+    dt = 1e9
+    for _blk in range(3):                             # fastest of three blocks: the first block of a fresh process on a fresh box has read 4.2 - 4.6 ms for 3.4 (round 6)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(N): graph.replay()
+        torch.cuda.synchronize(); dt = min(dt, (time.perf_counter() - t0) / N)
     fault = m.check_training_faults()                 # (None on a healthy run; 'overflow' means the timed steps worked on a truncated queue)
     if fault is not None: print("WARNING: check_training_faults() ->", fault)
 else:
     SYNC = int(os.environ.get("TVR_LOOP_SYNC", "0"))          # 1: read the loss and the fault flags on the host after every step, as train.py:262 does;
                                                               # 2: reconstruct.py's loop — the flags guard the fused Adam on the device, no host read
     for _ in range(3): step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(N):
-        l = step()
-        if SYNC == 1:
-            m.check_training_faults(); float(l.detach())
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
+    dt = 1e9
+    for _blk in range(3):                             # fastest of three blocks (a host-paced step on a shared host)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(N):
+            l = step()
+            if SYNC == 1:
+                m.check_training_faults(); float(l.detach())
+        torch.cuda.synchronize(); dt = min(dt, (time.perf_counter() - t0) / N)
 if rank == 0: print(f"{MODEL} (fused MLP kernels {int(m.fused_mlp_training)}, static step {int(m.static_training)}, hipGraph {int(GRAPH)}) train step ({world} rank(s), {4096 // world} rays each): {dt * 1e3:.2f} ms  ({1 / dt:.1f} it/s), batch 4096 rays x {nS} samples, loss {float(l.detach()):.3e}")
