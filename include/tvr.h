@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define TVR_VERSION 140   /* 140 (round 6): tvr_mlpnet_forward / _train_forward take packed_bytes and a caller-owned work buffer (tvr_mlpnet_work_bytes);
+#define TVR_VERSION 141   /* 141 (round 6): tvr_train_forward / _backward take TensorVMSplit scenes with up to six encoding frequencies; tvr_train_work_describe.
+                           * 140 (round 6): tvr_mlpnet_forward / _train_forward take packed_bytes and a caller-owned work buffer (tvr_mlpnet_work_bytes);
                            * tvr_mlpnet_packed_bytes no longer counts a ticket word; no entry point writes through a const pointer */
 
 typedef enum {
@@ -357,10 +358,20 @@ int tvr_mlp_train_backward_ref(const float *W1, const float *W2, const float *W3
  *             normal penalty (REFTensoRF.py:236-239).
  *   backward: grad_rgb_map [n,3], grad_pen_ray [n] or NULL -> gradients of every parameter: the VM factors through `vm_out` (all twelve), the network
  *             through `mlp_out` (reference layouts; heads: variant 1 only).  `weights`: the CURRENT parameters (reference layout), packed by the call.
- *             grad_scale_target: see tvr_mlp_train_backward's gscale (64 is the tested default); sat_flag_dev as there. */
+ *             grad_scale_target: see tvr_mlp_train_backward's gscale (64 is the tested default); sat_flag_dev as there.
+ * SHAPES (round 6): 48 appearance components per plane, featureC 128, and view_pe = fea_pe = 2 — or, TensorVMSplit scenes, any view_pe / fea_pe up to 6 with at least
+ * one above 2 (TensorBase's own defaults are 6 / 6, tensorBase.py:141-145): the forward is then the lockstep layer-1 kernel of tvr_render, the backward takes dX slot by
+ * slot over a streamed W1^T image and dW1 in column blocks (csrc/tvr_mlp_train.hip).  Other shapes: TVR_ERR_UNSUPPORTED (hosts train them through the per-op entry points). */
 typedef struct { const float *W1, *W2, *W3, *basis; const float *heads_W[4]; } tvr_train_weights;   /* heads_W: normal, diffuse, specular, rho (variant 1) */
 typedef struct { float *W1, *b1, *W2, *b2, *W3, *b3, *basis; float *heads_W[4], *heads_b[4]; } tvr_train_mlp_grads;
 size_t tvr_train_work_bytes(const tvr_scene *scene, int64_t n_rays, int32_t n_samples, int64_t app_cap);
+/* Byte offsets inside `work` of what a step leaves there (version 141), for hosts that inspect a step — the parity tests check every stage of the backward against
+ * fp64 arithmetic on these very tensors.  Saved by the forward: h [cap,144], feats32 [cap,32], h1 / h2 [cap,128] (relu outputs), rgb [cap,3]; written by the backward:
+ * grgb [cap,3] (gradient of the per-sample colours), d_out4 [cap,4], dh2 / dh1 [cap,128], dfeats32 [cap,32], dh [cap,144], X (the MLP input: [cap,150] / [cap,151], or for
+ * scenes with more than two encoding frequencies x_blocks column blocks of x_block_cols columns, block b a contiguous [cap, w_b] matrix at X + b * cap * x_block_cols
+ * floats, w_b = the block's columns rounded up to 4).  Rows beyond the step's queue length (scratch header word 0) are undefined. */
+typedef struct { size_t h, feats32, h1, h2, rgb, grgb, d_out4, dh2, dh1, dfeats32, dh, X, total; int32_t x_blocks, x_block_cols; } tvr_train_work_layout;
+int tvr_train_work_describe(const tvr_scene *scene, int64_t n_rays, int32_t n_samples, int64_t app_cap, tvr_train_work_layout *out);
 int tvr_train_forward(tvr_scene *scene, const float *rays, int64_t n_rays, int32_t n_samples, const float *jitter, float eps_T, int32_t white_bg,
                       void *fwd_scratch, size_t fwd_scratch_bytes, void *work, size_t work_bytes, int64_t app_cap,
                       float *rgb_map, float *depth, float *pen_ray, void *stream);

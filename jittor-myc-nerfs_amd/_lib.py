@@ -31,6 +31,10 @@ class ScratchLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("counter", "ray_off", "ray_cnt", "acc", "q_pos", "q_out", "q_ray", "q_j", "total")]
 
 
+class TrainWorkLayout(C.Structure):     # tvr_train_work_layout
+    _fields_ = [(n, C.c_size_t) for n in ("h", "feats32", "h1", "h2", "rgb", "grgb", "d_out4", "dh2", "dh1", "dfeats32", "dh", "X", "total")] + [("x_blocks", C.c_int32), ("x_block_cols", C.c_int32)]
+
+
 class VmGrads(C.Structure):
     _fields_ = [("density_plane", C.c_void_p * 3), ("density_line", C.c_void_p * 3), ("app_plane", C.c_void_p * 3), ("app_line", C.c_void_p * 3)]
 
@@ -135,6 +139,7 @@ SYMBOLS = {
     "tvr_mlp_train_backward_ref": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(C.c_void_p * 4)] + [C.c_void_p] * 8 + [C.c_int64, C.c_void_p] + [C.c_void_p, C.c_size_t] * 6 +
                                    [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tvr_train_work_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64]),
+    "tvr_train_work_describe": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.POINTER(TrainWorkLayout)]),
     "tvr_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tvr_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int64,

@@ -95,14 +95,22 @@ hipError_t launch_pe_concat_strided(const float *feat, int fs, const float *dir,
                                     long long m_cap, const unsigned *m_dev, float *X, hipStream_t stream);
 hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const float *gX, long long m, int with_dot, float *gfeat, float *gdir,
                                      float *gdot, hipStream_t stream);
+// more than two encoding frequencies: X as column blocks of TVR_GENX_W columns, block b a contiguous [m_cap, w_b] matrix at X + b * m_cap * TVR_GENX_W (tvr_train.hip)
+#define TVR_GENX_W 152
+#define TVR_GENX_FLOATS (3 * TVR_GENX_W)          // per entry, at most: 390 columns = 152 + 152 + 88
+hipError_t launch_pe_concat_gen(const float *feat, int fs, const float *rays, const unsigned *q_ray, int fea_pe, int view_pe, long long m_cap, const unsigned *m_dev, float *X,
+                                hipStream_t stream);
+hipError_t launch_copy_cols(float *dst, int ldd, int col0, const float *src, int lds, int ncols, int nrows, hipStream_t stream);
 size_t mlp_train_image_bytes();
 // heads: REFTensoRF's {normal [3,144], diffuse [3,144], specular [1,144], rho [1,144]} weights, or nullptr (TensorVMSplit)
-hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream);
+// fea_pe / view_pe > 2 (TensorVMSplit only): W1 is [128, 30 + 54 fea_pe + 6 view_pe] and is packed into the streamed image behind the LDS image (tvr_mlp_train.hip, TI_W1G)
+hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream,
+                                   int fea_pe = 2, int view_pe = 2);
 // REFTensoRF's additions to the backward: raw head outputs, view directions, optional gradient of the -dot output; dg8 [m,8] is written
 struct MlpRefBwd { const float *g8, *viewdirs, *grad_in0; float *dg8; const float *rays; const unsigned *q_ray; };   // q_ray set: the direction of entry e is rays[q_ray[e]][3..5]
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
                                      float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, void *image, const MlpRefBwd *ref,
-                                     hipStream_t stream, const unsigned *m_dev = nullptr);
+                                     hipStream_t stream, const unsigned *m_dev = nullptr, int gen = 0);
 // up to 8 parameter tensors of a regulariser (tvr_reg.hip): x / grad pointers, element counts, rows (line factors: n_comp), launch blocks
 #define TVR_REG_MAX 8
 struct RegList {

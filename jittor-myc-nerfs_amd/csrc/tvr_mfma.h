@@ -44,6 +44,29 @@ __device__ __forceinline__ Frag split8(const float v[8])
     split2(v[6], v[7], f.hi.w, f.lo.w);
     return f;
 }
+// split8 with the four pairs' operations BATCHED — four cvt_pkrtz, eight v_fma_mix_f32, four cvt_pkrtz — instead of pair by pair: written pair by pair, hipcc emits
+// `v_fma_mix_f32, v_fma_mix_f32, s_nop 0, v_cvt_pkrtz` for every pair (the packed conversion reads the second residual one instruction after it is written: a wait state),
+// 60 - 100 s_nop per shade tile in a kernel whose vector-issue port is full (round 6).  The same operations on the same values: bit-identical fragments.
+__device__ __forceinline__ Frag split8b(const float v[8])
+{
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    float m1 = -1.0f;
+    asm("" : "+s"(m1));
+    fp16x2 hb[4];
+    float r[8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) hb[p] = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        r[2 * p] = __builtin_fmaf((float)hb[p].x, m1, v[2 * p]);
+        r[2 * p + 1] = __builtin_fmaf((float)hb[p].y, m1, v[2 * p + 1]);
+    }
+    Frag f;
+    f.hi = make_uint4(__builtin_bit_cast(unsigned, hb[0]), __builtin_bit_cast(unsigned, hb[1]), __builtin_bit_cast(unsigned, hb[2]), __builtin_bit_cast(unsigned, hb[3]));
+    f.lo = make_uint4(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r[0], r[1])), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r[2], r[3])),
+                      __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r[4], r[5])), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r[6], r[7])));
+    return f;
+}
 // the one-part form of the reduced-product arithmetics (tvr_shade.hip, AR < 3): round to nearest even, one v_cvt_pk_f16_f32 per pair; no lo part.
 // (|x| > 65504 becomes inf here, not 65504: the range check / the host's proof keeps such values out, include/tvr.h)
 __device__ __forceinline__ Frag round8(const float v[8])

@@ -31,6 +31,12 @@
                                                      // KS = 2 (27 features, padded to 32); REFTensoRF: KS = 3, k 32..39 = the eight head outputs
 #define TI_SCAL (TI_BAST + 5 * 3 * 2 * 32 * 32)      // REFTensoRF: {max |dg8| bits, the heads' own gradient scale} (the normal's gradient carries 1 / |n|: its range is not the network's)
 #define TI_BYTES (TI_SCAL + 64)                      // 188 992 B (sized for KS = 3)
+// Round 6 — scenes with more than two encoding frequencies (TVR_GEN_*, tvr_device.h; tensorBase.py:141-145): W1^T does not fit the LDS (13 derived values x 32 base
+// rows x 128 units, hi + lo: 208 KB).  Its fragments live in global memory behind the image in the order the backward reads them — [slot t (13)][k-step s (8)][hi | lo]
+// [lane (64)] uint4, lane (e, h) = row e (base value), k 16 s + 8 h .. + 7 — and every wave streams them from L2, half a slot (8 KB) ahead of its MFMAs.
+#define TI_W1G ((TI_BYTES + 255) / 256 * 256)
+#define TI_W1G_BYTES (TVR_GEN_T * 8 * 2 * 1024)      // 212 992 B
+#define TI_BYTES_ALL (TI_W1G + TI_W1G_BYTES)
 
 #define MT_WAVES 8
 #define MT_THREADS (64 * MT_WAVES)
@@ -52,7 +58,7 @@ __device__ __forceinline__ float head_weight(const HeadPtrs &hp, int i, int ch)
 // one thread per element of the three transposed images.  ref: W1 is MLPRender_Fea_Ref's [128,151] (REFTensoRF.py:9-16: every input index moves up
 // by one, base row 30's plain slot is input 0 = -dot) and Bas^T gets a third k-step holding the heads' weights.
 __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
-                                                               const float *__restrict__ Bas, const HeadPtrs hp, const int ref, unsigned char *__restrict__ img)
+                                                               const float *__restrict__ Bas, const HeadPtrs hp, const int ref, const int gen, unsigned char *__restrict__ img)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *(unsigned *)(img + TI_SCAL) = 0u;
@@ -69,7 +75,8 @@ __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__re
         const int c = row & 31, t = row >> 5;
         int idx = ref_in_index(c, t);
         if (ref) idx = (c == TVR_APPDIM + 3) ? (t == 0 ? 0 : -1) : (idx >= 0 ? idx + 1 : -1);
-        const float w = idx >= 0 ? W1[(size_t)unit_of_kpos(kpos) * (ref ? TVR_NIN_REF : TVR_NIN) + idx] : 0.0f;
+        // (gen: W1 is [128, 30 + 54 fea_pe + 6 view_pe] and goes to the streamed image, pack_train_w1gen_kernel; this region stays zero)
+        const float w = (idx >= 0 && !gen) ? W1[(size_t)unit_of_kpos(kpos) * (ref ? TVR_NIN_REF : TVR_NIN) + idx] : 0.0f;
         unsigned hi, lo;
         split2(w, 0.0f, hi, lo);
         ((unsigned short *)(img + TI_W1T_H + row * TI_ROW))[kpos] = (unsigned short)hi;
@@ -92,6 +99,26 @@ __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__re
         o[j] = (unsigned short)hi;
         o[8 + j] = (unsigned short)lo;
     }
+}
+
+// one thread per (slot t, k-step s, lane): the hi and the lo uint4 of the streamed W1^T image (TI_W1G)
+__global__ __launch_bounds__(256) void pack_train_w1gen_kernel(const float *__restrict__ W1, const int fea_pe, const int view_pe, unsigned char *__restrict__ img)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= TVR_GEN_T * 8 * 64) return;
+    const int lane = i & 63, s = (i >> 6) & 7, t = i >> 9;
+    const int e = lane & 31, h = lane >> 5;
+    const int nin = TVR_APPDIM + 3 + 2 * TVR_APPDIM * fea_pe + 6 * view_pe;
+    const int idx = gen_in_index(e, t, fea_pe, view_pe);
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const int u0 = unit_of_kpos(16 * s + 8 * h + j), u1 = unit_of_kpos(16 * s + 8 * h + j + 1);
+        split2(idx >= 0 ? W1[(size_t)u0 * nin + idx] : 0.0f, idx >= 0 ? W1[(size_t)u1 * nin + idx] : 0.0f, hi[j >> 1], lo[j >> 1]);
+    }
+    uint4 *o = (uint4 *)(img + TI_W1G) + (size_t)((t * 8 + s) * 2) * 64 + lane;
+    o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    o[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 struct AFragN { uint4 h[5], l[5]; };
@@ -131,9 +158,12 @@ struct MlpBwdArgs {
 // REF: MLPRender_Fea_Ref inside REFTensoRF.execute (REFTensoRF.py:229-232): the colour is relu(tint) * rgb_s + rgb_d, so the gradient entering the
 // network is relu(tint) * grad_rgb and `rgb` is rgb_s; the direction rows 27..29 (the reflection) and row 30 (-dot) of layer 1's input are
 // functions of h as well: their gradients come out in dfeats columns 27..30 (ref_heads_backward_kernel takes them to the heads).
-template <bool REF>
+// GEN (round 6): layer 1 has 13 derived values per base value (up to six frequencies); dX runs slot by slot over the streamed image TI_W1G, the gradient of the
+// positional encoding is taken per slot — d sin(2^f v) = 2^f cos(2^f v), d cos(2^f v) = -2^f sin(2^f v), from the forward's own reduced argument — and summed into dF.
+template <bool REF, bool GEN = false>
 __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_kernel(const MlpBwdArgs a)
 {
+    static_assert(!(REF && GEN), "REFTensoRF scenes have two encoding frequencies");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -252,6 +282,93 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
                         make_float4(dh1[rb][4 * q] * inv_scale, dh1[rb][4 * q + 1] * inv_scale, dh1[rb][4 * q + 2] * inv_scale, dh1[rb][4 * q + 3] * inv_scale);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GEN) {
+            // ---------------------------------------------------------------- dX slot by slot, dF accumulated ----
+            Frag bf[8];                                                        // dH1 as the eight B fragments every slot multiplies
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { x[j] = dh1[s >> 1][8 * (s & 1) + j]; amax = fmaxf(amax, fabsf(x[j])); }
+                bf[s] = split8(x);
+                asm volatile("" : "+v"(amax));                                 // taken HERE (left alone, hipcc sinks the max chain to the tile's end and keeps dH1's 64 registers alive for it)
+            }
+            __builtin_amdgcn_sched_barrier(0);                                 // (every dH1 register has been read: the MFMAs of dH1 have completed)
+            float TR[16];                                                      // the forward's reduced arguments, in revolutions (tvr_shade.hip gen_frag)
+            {
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 f4 = *(const float4 *)(a.feats + le * 32 + 8 * q + 4 * h);
+                    v[4 * q] = f4.x; v[4 * q + 1] = f4.y; v[4 * q + 2] = f4.z; v[4 * q + 3] = f4.w;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float k = rintf(v[r] * 0.15915494309189535f);
+                    float rr = __builtin_fmaf(k, -6.2831854820251465f, v[r]);
+                    rr = __builtin_fmaf(k, 1.7484555e-7f, rr);
+                    TR[r] = rr * 0.15915494309189535f;
+                }
+            }
+            float df[16];
+            // half slot c: uint4 (8 c + i) * 64 + lane, i = 2 k + {0: hi, 1: lo} of k-step 4 (c & 1) + k.  Addressing: the image's scalar base + a 32-bit offset per 4 KB (taken where it is
+            // used) + an immediate < 4 KB — left to itself hipcc computes the 208 lane addresses once per kernel and spills them (578 VGPRs)
+            unsigned loff = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(loff));
+            auto ld_half = [&](int c, uint4 (&dst)[8]) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    unsigned cb = (unsigned)(TI_W1G + c * 8192 + q * 4096);
+                    asm volatile("" : "+s"(cb));
+                    const unsigned vo = cb + loff;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dst[4 * q + i] = *(const uint4 *)(a.image + ((size_t)vo + (size_t)(i * 1024)));
+                }
+            };
+            uint4 A[2][8];
+            ld_half(0, A[0]);
+            f32x16 acc = f32x16{0};
+            float drain = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 2 * TVR_GEN_T; ++c) {
+                const int t = c >> 1, half = c & 1;
+                // the next half slot's fragments are requested BEFORE this one's MFMAs, into the registers the half slot before this one used: its MFMAs have
+                // completed (each half slot ends with a read of its last accumulator, as tvr_gemm.hip's chunks do)
+                if (c + 1 < 2 * TVR_GEN_T) ld_half(c + 1, A[(c + 1) & 1]);
+                if (half == 0) acc = f32x16{0};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const Frag &b = bf[4 * half + k];
+                    acc = MFMAH(A[c & 1][2 * k + 1], b.hi, acc);
+                    acc = MFMAH(A[c & 1][2 * k], b.lo, acc);
+                    acc = MFMAH(A[c & 1][2 * k], b.hi, acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (half == 0) drain += acc[15];
+                else {
+                    const int f = t == 0 ? 0 : (t <= TVR_GEN_PE ? t - 1 : t - 1 - TVR_GEN_PE);
+                    const float p2 = (float)(1 << f);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (t == 0) df[r] = acc[r];
+                        else if (t <= TVR_GEN_PE) df[r] = __builtin_fmaf(p2 * __builtin_amdgcn_cosf(TR[r] * p2), acc[r], df[r]);
+                        else df[r] = __builtin_fmaf(-p2 * __builtin_amdgcn_sinf(TR[r] * p2), acc[r], df[r]);
+                        asm volatile("" : "+v"(df[r]));                        // taken HERE (left alone, hipcc defers the thirteen slots' sums to the tile's end and keeps their 208 accumulator registers)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (drain == 1.2345e-30f) amax = 65504.0f;                         // keeps `drain` alive; never true for a finite accumulator sum of this size
+#pragma unroll
+            for (int r = 0; r < 16; ++r) df[r] = acc_row(r, h) < TVR_APPDIM ? df[r] * inv_scale : 0.0f;
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4 *)(a.dfeats + ent * 32 + 8 * q + 4 * h) = make_float4(df[4 * q], df[4 * q + 1], df[4 * q + 2], df[4 * q + 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         // ---------------------------------------------------------------- dX = W1^T dH1  (5 row blocks: block t = derived value t) ----
         f32x16 dx[5];
 #pragma unroll
@@ -317,6 +434,7 @@ __global__ __launch_bounds__(MT_THREADS, MT_WAVES / 4) void mlp_train_backward_k
                 *(float4 *)(a.dfeats + ent * 32 + 8 * q + 4 * h) = make_float4(df[4 * q], df[4 * q + 1], df[4 * q + 2], df[4 * q + 3]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        }           // !GEN
     }
     if (a.sat && amax >= 65504.0f) atomicOr(a.sat, 1u);
 }
@@ -470,23 +588,27 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
     if (sat && amax >= 65504.0f) atomicOr(sat, 1u);
 }
 
-size_t mlp_train_image_bytes() { return TI_BYTES; }
+size_t mlp_train_image_bytes() { return TI_BYTES_ALL; }
 
-hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream)
+hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream,
+                                   int fea_pe, int view_pe)
 {
     HeadPtrs hp;
     for (int i = 0; i < 4; ++i) hp.W[i] = heads ? heads[i] : nullptr;
-    const int ref = heads ? 1 : 0;
+    const int ref = heads ? 1 : 0, gen = (fea_pe > 2 || view_pe > 2) ? 1 : 0;
+    if (gen && (ref || fea_pe > TVR_GEN_PE || view_pe > TVR_GEN_PE || fea_pe < 0 || view_pe < 0)) return hipErrorInvalidValue;
     const int n = 128 * 128 + 160 * 128 + 3 * 128 + 160 * (ref ? 48 : 32);
-    hipLaunchKernelGGL(pack_train_image_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W1, W2, W3, Bas, hp, ref, (unsigned char *)image);
+    hipLaunchKernelGGL(pack_train_image_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W1, W2, W3, Bas, hp, ref, gen, (unsigned char *)image);
+    if (gen) hipLaunchKernelGGL(pack_train_w1gen_kernel, dim3((TVR_GEN_T * 8 * 64 + 255) / 256), dim3(256), 0, stream, W1, fea_pe, view_pe, (unsigned char *)image);
     return hipGetLastError();
 }
 
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,
                                      float *d_out, float *dh2, float *dh1, float *dfeats, float *dh, unsigned *sat_flag, void *image, const MlpRefBwd *ref,
-                                     hipStream_t stream, const unsigned *m_dev)
+                                     hipStream_t stream, const unsigned *m_dev, int gen)
 {
-    hipError_t rc = hipFuncSetAttribute(ref ? (const void *)mlp_train_backward_kernel<true> : (const void *)mlp_train_backward_kernel<false>,
+    if (gen && ref) return hipErrorInvalidValue;
+    hipError_t rc = hipFuncSetAttribute(ref ? (const void *)mlp_train_backward_kernel<true> : (gen ? (const void *)mlp_train_backward_kernel<false, true> : (const void *)mlp_train_backward_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, TI_LDS_BYTES);
     if (rc != hipSuccess) return rc;
     MlpBwdArgs a;
@@ -496,6 +618,7 @@ hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, co
     const long long groups = (m + 32 * MT_WAVES - 1) / (32 * MT_WAVES);
     unsigned grid = groups < 256 ? (unsigned)(groups > 0 ? groups : 1) : 256u;
     if (ref) hipLaunchKernelGGL(mlp_train_backward_kernel<true>, dim3(grid), dim3(MT_THREADS), TI_LDS_BYTES, stream, a);
+    else if (gen) hipLaunchKernelGGL((mlp_train_backward_kernel<false, true>), dim3(grid), dim3(MT_THREADS), TI_LDS_BYTES, stream, a);
     else hipLaunchKernelGGL(mlp_train_backward_kernel<false>, dim3(grid), dim3(MT_THREADS), TI_LDS_BYTES, stream, a);
     rc = hipGetLastError();
     if (rc != hipSuccess) return rc;

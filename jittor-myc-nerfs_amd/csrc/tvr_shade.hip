@@ -1078,7 +1078,7 @@ static hipError_t launch_shade_v(const SceneDev &sc, int src, int dst, const Sha
         if (sc.gen) {                              // more than two encoding frequencies: the lockstep layer 1 (TensorVMSplit scenes only; check_desc refuses the rest)
             if (src == SH_SRC_QUEUE && dst == SH_DST_QUEUE) return rc ? launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false, true, true>(sc, a, stream) : launch_shade_t<SH_SRC_QUEUE, SH_DST_QUEUE, false, false, true>(sc, a, stream);
             if (src == SH_SRC_FEAT && dst == SH_DST_RGB) return rc ? launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false, true, true>(sc, a, stream) : launch_shade_t<SH_SRC_FEAT, SH_DST_RGB, false, false, true>(sc, a, stream);
-            if (src == SH_SRC_H && dst == SH_DST_TRAIN) return hipErrorInvalidValue;
+            if (src == SH_SRC_H && dst == SH_DST_TRAIN) return launch_shade_t<SH_SRC_H, SH_DST_TRAIN, false, false, true>(sc, a, stream);     // round 6: the fused training step of such scenes
         }
     }
 #ifndef TVR_SHADE16

@@ -101,6 +101,14 @@ __device__ __forceinline__ void sincos_pe16(float x, float &s, float &c)
 #ifndef S16_DIAG_LDS
 #define S16_DIAG_LDS 0    // timing stand-ins (WRONG pictures): 1 = layers 1 / 2 read every other weight fragment from LDS (the fragment bytes of a 64-column form), 2 = none
 #endif
+#ifndef S16_SPLITB
+#define S16_SPLITB 1      // 1: tvr_mfma.h's split8b (the four pairs' operations batched: no s_nop between a pair's residuals and their packed conversion); 0: split8 (A/B)
+#endif
+#if S16_SPLITB
+#define S16_SPLIT8 split8b
+#else
+#define S16_SPLIT8 split8
+#endif
 #ifndef S16_SCHED
 #define S16_SCHED 1       // 1: sched_group_barrier windows in the matrix phase; 0: hipcc's own order (A/B)
 #endif
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
                     for (int j = 0; j < 8; j += 2) rmax = absmax2(hv[j], hv[j + 1], rmax);
                     asm volatile("" : "+v"(rmax));
                 }
-                hf[u] = split8(hv);
+                hf[u] = S16_SPLIT8(hv);
                 asm volatile("" : "+v"(hf[u].hi.x), "+v"(hf[u].hi.y), "+v"(hf[u].hi.z), "+v"(hf[u].hi.w), "+v"(hf[u].lo.x), "+v"(hf[u].lo.y), "+v"(hf[u].lo.z), "+v"(hf[u].lo.w));
                 S16_SB;
             }
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
                     if (t == 0) sincos_pe16(F[r], S1[r], C1[r]);
                     v[j] = t == 0 ? F[r] : (t == 1 ? S1[r] : (t == 2 ? 2.0f * S1[r] * C1[r] : (t == 3 ? C1[r] : __builtin_fmaf(-2.0f * S1[r], S1[r], 1.0f))));
                 }
-                b = split8(v);
+                b = S16_SPLIT8(v);
             };
             auto relu_frag = [&](int ks, int ct, Frag &b) {           // layer 2's B fragment of k-step ks: the layer-1 accumulators of row blocks 2 ks, 2 ks + 1
                 float v[8];
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 1 : 2) void shade16_k
                     for (int j = 0; j < 8; j += 2) rm = fmaxf(fmaxf(v[j], v[j + 1]), rm);
                     asm volatile("" : "+v"(rm));
                 }
-                b = split8(v);
+                b = S16_SPLIT8(v);
             };
             S16_LDS_BASE(W1Hb, smem + TVR16_W1H + lane * 16);
             S16_LDS_BASE(W1Lb, smem + TVR16_W1L + lane * 16);

@@ -778,6 +778,74 @@ hipError_t launch_pe_concat_strided(const float *feat, int fs, const float *dir,
     return hipGetLastError();
 }
 
+// Round 6 — the MLP input of a scene with more than two encoding frequencies (tensorBase.py:76-82 with view_pe / fea_pe up to 6: 30 + 54 fea_pe + 6 view_pe columns, 390
+// at the constructor's defaults), for the weight gradient dW1 = dH1^T X of the fused training step.  X is written as COLUMN BLOCKS of TVR_GENX_W columns, block b a
+// contiguous [m_cap, w_b] matrix at X + b * m_cap * TVR_GENX_W (w_b = the block's columns rounded up to 4, zero-filled): each block is then one tvr_gemm_tn product in its
+// fastest staging mode (contiguous 16-B rows, <= 5 column tiles with the bias column).  sin / cos exactly as the forward kernel's lockstep layer 1 takes them
+// (tvr_shade.hip gen_frag): the hardware units on the once-reduced argument times 2^f.
+__global__ __launch_bounds__(256) void pe_concat_gen_kernel(const PeSrc p, const long long m_cap, const int fea_pe, const int view_pe, float *__restrict__ X)
+{
+    extern __shared__ __attribute__((aligned(16))) float gtile[];            // [block][PE_TILE rows][w_b]
+    const long long m = p.m_dev ? ((long long)*p.m_dev < m_cap ? (long long)*p.m_dev : m_cap) : m_cap;
+    const long long e0 = (long long)blockIdx.x * PE_TILE;
+    if (e0 >= m) return;
+    const int rows = (int)(m - e0 < PE_TILE ? m - e0 : PE_TILE);
+    const int nin = TVR_APPDIM + 3 + 2 * TVR_APPDIM * fea_pe + 6 * view_pe, nb = (nin + TVR_GENX_W - 1) / TVR_GENX_W;
+    const int wl = ((nin - (nb - 1) * TVR_GENX_W) + 3) & ~3;                  // width of the last block
+    for (int i = threadIdx.x; i < PE_TILE * ((nb - 1) * TVR_GENX_W + wl); i += 256) gtile[i] = 0.0f;
+    __syncthreads();
+    for (int it = threadIdx.x; it < rows * 30; it += 256) {
+        const int r = it / 30, c = it - r * 30;
+        const long long ent = e0 + r;
+        const float v = c < 27 ? p.feat[ent * p.fs + c] : (p.q_ray ? p.rays[(size_t)p.q_ray[ent] * 6 + 3 + (c - 27)] : p.dir[ent * p.ds + (c - 27)]);
+        const float k = rintf(v * 0.15915494309189535f);
+        float rr = __builtin_fmaf(k, -6.2831854820251465f, v);
+        rr = __builtin_fmaf(k, 1.7484555e-7f, rr);
+        const float tr = rr * 0.15915494309189535f;
+#pragma unroll
+        for (int t = 0; t < TVR_GEN_T; ++t) {
+            const int idx = gen_in_index(c, t, fea_pe, view_pe);
+            if (idx < 0) continue;
+            const int f = t == 0 ? 0 : (t <= TVR_GEN_PE ? t - 1 : t - 1 - TVR_GEN_PE);
+            const float val = t == 0 ? v : (t <= TVR_GEN_PE ? __builtin_amdgcn_sinf(tr * (float)(1 << f)) : __builtin_amdgcn_cosf(tr * (float)(1 << f)));
+            const int b = idx / TVR_GENX_W, col = idx - b * TVR_GENX_W, wb = b == nb - 1 ? wl : TVR_GENX_W;
+            gtile[b * PE_TILE * TVR_GENX_W + r * wb + col] = val;
+        }
+    }
+    __syncthreads();
+    for (int b = 0; b < nb; ++b) {
+        const int wb = b == nb - 1 ? wl : TVR_GENX_W;
+        float4 *__restrict__ dst = (float4 *)(X + (size_t)b * (size_t)m_cap * TVR_GENX_W + (size_t)e0 * wb);       // 16-B aligned: m_cap * 152 * 4 and 32 * wb * 4 are multiples of 16
+        const float4 *src = (const float4 *)(gtile + b * PE_TILE * TVR_GENX_W);
+        for (int i = threadIdx.x; i < rows * wb / 4; i += 256) dst[i] = src[i];
+    }
+}
+
+hipError_t launch_pe_concat_gen(const float *feat, int fs, const float *rays, const unsigned *q_ray, int fea_pe, int view_pe, long long m_cap, const unsigned *m_dev, float *X,
+                                hipStream_t stream)
+{
+    PeSrc p = {feat, nullptr, nullptr, rays, q_ray, m_dev, fs, 0, 0};
+    const int nin = TVR_APPDIM + 3 + 2 * TVR_APPDIM * fea_pe + 6 * view_pe, nb = (nin + TVR_GENX_W - 1) / TVR_GENX_W;
+    const int lds = PE_TILE * nb * TVR_GENX_W * (int)sizeof(float);          // <= 58 368 B
+    hipLaunchKernelGGL(pe_concat_gen_kernel, dim3((unsigned)((m_cap + PE_TILE - 1) / PE_TILE)), dim3(256), lds, stream, p, m_cap, fea_pe, view_pe, X);
+    return hipGetLastError();
+}
+
+// dst[r * ldd + col0 + c] = src[r * lds + c], c < ncols, r < nrows (a column block of a weight gradient into its place)
+__global__ __launch_bounds__(256) void copy_cols_kernel(float *__restrict__ dst, const int ldd, const int col0, const float *__restrict__ src, const int lds, const int ncols, const int nrows)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncols * nrows) return;
+    const int r = i / ncols, c = i - r * ncols;
+    dst[(size_t)r * ldd + col0 + c] = src[(size_t)r * lds + c];
+}
+
+hipError_t launch_copy_cols(float *dst, int ldd, int col0, const float *src, int lds, int ncols, int nrows, hipStream_t stream)
+{
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((ncols * nrows + 255) / 256)), dim3(256), 0, stream, dst, ldd, col0, src, lds, ncols, nrows);
+    return hipGetLastError();
+}
+
 hipError_t launch_pe_concat_backward(const float *feat, const float *dir, const float *gX, long long m, int with_dot, float *gfeat, float *gdir,
                                      float *gdot, hipStream_t stream)
 {

@@ -680,8 +680,11 @@ class TensorBase(torch.nn.Module):
 
     def _fused_step_ok(self) -> bool:
         rm = self.renderModule
+        fe, ve = getattr(rm, "feape", -1), getattr(rm, "viewpe", -1)
+        # two encoding frequencies each — or, TensorVMSplit scenes (round 6), up to six: the lockstep layer 1 forward and the streamed W1^T backward (tvr_mlp_train.hip)
+        pe_ok = (fe == 2 and ve == 2) or (getattr(self, "_variant", 0) == 0 and 0 <= fe <= 6 and 0 <= ve <= 6 and (fe > 2 or ve > 2))
         return (self.static_training and self.fused_mlp_training and list(self.app_n_comp) == [48, 48, 48] and self.app_dim == 27
-                and getattr(rm, "feape", 0) == 2 and getattr(rm, "viewpe", 0) == 2 and rm.mlp[0].out_features == 128 and str(self.device).startswith("cuda"))
+                and pe_ok and rm.mlp[0].out_features == 128 and str(self.device).startswith("cuda"))
 
     def _get_scratch(self, nbytes: int, slot: int = 0) -> torch.Tensor:
         """The render scratch (march queue etc.).  slot > 0: a second buffer for a second frame in flight on another stream (render.FrameStream)."""

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(l, n), f"libtvr.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and include/*.h disagree"
-    assert _lib.lib().tvr_version() == 140
+    assert _lib.lib().tvr_version() == 141
 
 
 def test_abi_argument_errors_without_gpu():

@@ -170,6 +170,145 @@ def test_static_step_is_reproducible_and_agrees_with_the_eager_chain(tiny_dump, 
     assert all(_close(x, y) for x, y in zip(na + va, ne + ve))
 
 
+@pytest.mark.parametrize("vpe,fpe", [(6, 6), (3, 5)])
+def test_static_step_with_more_than_two_frequencies(tiny_dump, hyper_tiny, vpe, fpe):
+    """Round 6 (tensorBase.py:141-145: the constructor's view_pe = fea_pe = 6): the fused step of such a scene — lockstep layer 1 forward, dX slot by slot over the streamed
+    W1^T image, dW1 in column blocks — against the eager chain of autograd Functions on the same batch; bit-reproducible picture and network gradients run to run; and it
+    is the SAME forward as the render path's (torch.equal with render_rays)."""
+    from jittor_myc_nerfs_amd import TensorVMSplit, synthetic
+    arrs = synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=5, view_pe=vpe, fea_pe=fpe)
+    rays = _batch(tiny_dump, 16)
+    cw = torch.randn((rays.shape[0], 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+
+    def model():
+        m = TensorVMSplit(arrs["aabb"], [int(x) for x in arrs["gridSize"]], "cuda", density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
+                          near_far=hyper_tiny["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=hyper_tiny["density_shift"],
+                          distance_scale=hyper_tiny["distance_scale"], rayMarch_weight_thres=hyper_tiny["rayMarch_weight_thres"], pos_pe=6, view_pe=vpe, fea_pe=fpe,
+                          featureC=128, step_ratio=hyper_tiny["step_ratio"], fea2denseAct=hyper_tiny["fea2denseAct"])
+        m.load_arrays(arrs)
+        return m
+
+    def grads(static):
+        m = model()
+        m.static_training = static
+        rgb, _ = m.render_rays_autograd(rays, white_bg=True, N_samples=TINY["N_samples"])
+        assert type(rgb.grad_fn).__name__.startswith("_FusedStepFn") == static
+        (rgb * cw).sum().backward()
+        net, vm = _net_and_vm(m)
+        return rgb.detach(), [p.grad.clone() for p in net], [p.grad.clone() for p in vm], m
+    rgb_a, na, va, m = grads(True)
+    assert m.renderModule.mlp[0].weight.shape == (128, 30 + 54 * fpe + 6 * vpe)
+    assert m.check_training_faults() is None
+    rgb_b, nb, vb, _ = grads(True)
+    assert torch.equal(rgb_a, rgb_b)
+    for i, (x, y) in enumerate(zip(na, nb)):
+        assert torch.equal(x, y), f"network gradient {i} {tuple(x.shape)} differs between two runs on the same batch: {float((x - y).abs().max()):.3e}"
+    assert all(_close(x, y, 2e-6) for x, y in zip(va, vb))
+    rgb_e, ne, ve, _ = grads(False)
+    # (the eager chain takes sin / cos of 2^f v from libm, the kernels from the hardware units on the once-reduced argument: 2e-6 at two frequencies, more at 2^5 v)
+    assert float((rgb_a - rgb_e).abs().max()) < 2e-5
+    # Two correct forwards that differ by 1e-6 put a handful of hidden units (pre-activation within rounding of zero) on different sides of the relu; each such unit
+    # moves one sample's whole contribution, 1e-3 .. 1e-2 of a gradient entry at this batch size.  So whole steps agree in the L2 sense here; the arithmetic of every
+    # stage is checked to 2e-5 on the step's own tensors (test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors).
+    for i, (x, y) in enumerate(zip(na + va, ne + ve)):
+        l2 = float((x - y).norm() / y.norm().clamp_min(1e-12))
+        assert l2 < 3e-2 and _close(x, y, 5e-2), f"gradient {i} {tuple(x.shape)}: fused vs eager L2 {l2:.3e}, max {float((x - y).abs().max()):.3e} of {float(y.abs().max()):.3e}"
+    with torch.no_grad():
+        rgb_r, _ = m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
+    assert float((rgb_a - rgb_r).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("vpe,fpe", [(2, 2), (6, 6), (3, 5), (6, 0)])
+def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_dump, hyper_tiny, vpe, fpe):
+    """The step's workspace (tvr_train_work_describe) holds what the forward saved and what every backward stage wrote.  Each stage is recomputed in fp64 FROM THE
+    TENSORS THE KERNELS THEMSELVES USED — the relu masks are those of the saved activations, so a hidden unit whose pre-activation sits within rounding of zero cannot
+    turn a 1e-6 difference of two correct forwards into a 1e-3 difference of two correct gradients (which is what a comparison of whole steps against the oracle's
+    autograd measures at six frequencies, scripts/debug/gen_step_check.py).  tensorBase.py:76-86 (MLPRender_Fea.execute), :9-15 (positional_encoding)."""
+    import ctypes as C
+    from jittor_myc_nerfs_amd import TensorVMSplit, synthetic, _lib as L
+    arrs = synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=5, view_pe=vpe, fea_pe=fpe)
+    m = TensorVMSplit(arrs["aabb"], [int(x) for x in arrs["gridSize"]], "cuda", density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
+                      near_far=hyper_tiny["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=hyper_tiny["density_shift"],
+                      distance_scale=hyper_tiny["distance_scale"], rayMarch_weight_thres=hyper_tiny["rayMarch_weight_thres"], pos_pe=6, view_pe=vpe, fea_pe=fpe,
+                      featureC=128, step_ratio=hyper_tiny["step_ratio"], fea2denseAct=hyper_tiny["fea2denseAct"])
+    m.load_arrays(arrs)
+    rays = _batch(tiny_dump, 16)
+    n, S = rays.shape[0], TINY["N_samples"]
+    cw = torch.randn((n, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    rgb, _ = m.render_rays_autograd(rays, white_bg=True, N_samples=S)
+    assert type(rgb.grad_fn).__name__.startswith("_FusedStepFn")
+    (rgb * cw).sum().backward()
+    assert m.check_training_faults() is None
+    B = m._train_buf
+    sl, wl = L.ScratchLayout(), L.TrainWorkLayout()
+    L.check(L.lib().tvr_scratch_describe(n, S, C.byref(sl)), "tvr_scratch_describe")
+    L.check(L.lib().tvr_train_work_describe(m._ensure_scene(), n, S, B["cap"], C.byref(wl)), "tvr_train_work_describe")
+    assert wl.total == L.lib().tvr_train_work_bytes(m._ensure_scene(), n, S, B["cap"]) <= B["work"].numel()
+    cnt = int(B["scratch"][sl.counter:sl.counter + 4].view(torch.int32).item())
+    assert 1000 < cnt <= B["cap"]
+    cap = B["cap"]
+
+    def mat(off, cols, rows=cnt, dtype=torch.float32):
+        return B["work"][off:off + cap * cols * 4].view(dtype).view(cap, cols)[:rows]
+    f64 = lambda t: t.double()
+    h, feats, h1, h2, rgb_s = (f64(mat(o, c)) for o, c in ((wl.h, 144), (wl.feats32, 32), (wl.h1, 128), (wl.h2, 128), (wl.rgb, 3)))
+    grgb, d_out, dh2, dh1, dfe, dh = (f64(mat(o, c)) for o, c in ((wl.grgb, 3), (wl.d_out4, 4), (wl.dh2, 128), (wl.dh1, 128), (wl.dfeats32, 32), (wl.dh, 144)))
+    mlp = m.renderModule.mlp
+    W1, W2, W3, Bas = (f64(t.detach()) for t in (mlp[0].weight, mlp[2].weight, mlp[4].weight, m.basis_mat.weight))
+    n_in = 30 + 54 * fpe + 6 * vpe
+    assert W1.shape == (128, n_in)
+    q_ray = B["scratch"][sl.q_ray:sl.q_ray + 4 * cnt].view(torch.int32).long()
+    dirs = f64(rays[q_ray, 3:6])
+
+    def close(got, want, what, rel=2e-5):
+        err, ref = float((got - want).abs().max()), float(want.abs().max())
+        assert err <= rel * max(ref, 1e-12), f"{what}: {err:.3e} of {ref:.3e}"
+    close(d_out[:, :3], grgb * rgb_s * (1 - rgb_s), "d_out")
+    close(dh2, (h2 > 0) * (d_out[:, :3] @ W3), "dH2")
+    close(dh1, (h1 > 0) * (dh2 @ W2), "dH1")
+    # the MLP input from the saved features and the entries' view directions (reference column order), and the kernels' own X
+    F = feats[:, :27]
+
+    def pe(x, freqs):
+        if freqs == 0:
+            return x[:, :0]
+        pts = (x[:, :, None] * (2.0 ** torch.arange(freqs, device="cuda", dtype=torch.float64))).reshape(x.shape[0], -1)
+        return torch.cat([torch.sin(pts), torch.cos(pts)], dim=1)
+    X = torch.cat([F, dirs, pe(F, fpe), pe(dirs, vpe)], dim=1)
+    assert X.shape[1] == n_in
+    if wl.x_blocks == 1 and wl.x_block_cols == 150:
+        Xk = f64(mat(wl.X, 150))
+    else:
+        assert wl.x_block_cols == 152 and wl.x_blocks == (n_in + 151) // 152
+        parts = []
+        for b in range(wl.x_blocks):
+            cols = min(152, n_in - 152 * b)
+            wb = (cols + 3) & ~3
+            blk = B["work"][wl.X + b * cap * 152 * 4:wl.X + b * cap * 152 * 4 + cap * wb * 4].view(torch.float32).view(cap, wb)[:cnt]
+            assert float(blk[:, cols:].abs().max()) == 0.0 if wb > cols else True
+            parts.append(f64(blk[:, :cols]))
+        Xk = torch.cat(parts, dim=1)
+    assert float((Xk - X).abs().max()) < (2e-6 if max(vpe, fpe) <= 2 else 2e-5)       # hardware sin / cos of the reduced argument times 2^f against fp64
+    # dX and the gradient through the positional encoding
+    dX = dh1 @ W1
+    dF = dX[:, :27].clone()
+    for f in range(fpe):
+        si, ci = 30 + torch.arange(27, device="cuda") * fpe + f, 30 + 27 * fpe + torch.arange(27, device="cuda") * fpe + f
+        dF += (2.0 ** f) * (torch.cos(F * 2.0 ** f) * dX[:, si] - torch.sin(F * 2.0 ** f) * dX[:, ci])
+    close(dfe[:, :27], dF, "dF")
+    assert float(dfe[:, 27:].abs().max()) == 0.0
+    close(dh, dF @ Bas, "dh")
+    # the weight gradients the step returned
+    g = lambda p: f64(p.grad)
+    close(g(mlp[4].weight), d_out[:, :3].t() @ h2, "dW3")
+    close(g(mlp[4].bias), d_out[:, :3].sum(0), "db3")
+    close(g(mlp[2].weight), dh2.t() @ h1, "dW2")
+    close(g(mlp[2].bias), dh2.sum(0), "db2")
+    close(g(mlp[0].weight), dh1.t() @ Xk, "dW1")
+    close(g(mlp[0].bias), dh1.sum(0), "db1")
+    close(g(m.basis_mat.weight), dfe[:, :27].t() @ h, "dBasis")
+
+
 def test_workspace_overflow_is_flagged_not_truncated(tiny_dump, tiny_arrays, hyper_tiny):
     rays = _batch(tiny_dump, 64)                                       # 4096 rays
     m = make_model(tiny_arrays, hyper_tiny)

@@ -18,7 +18,9 @@ SHAPES = [([8, 8, 8], [24, 24, 24], 128, 2, 2),          # TensorBase's default 
           # more than two encoding frequencies (round 4): layer 1 runs in lockstep from a streamed 26-k-step image (tvr_device.h TVR_GEN_*)
           ([8, 8, 8], [24, 24, 24], 128, 6, 6),          # TensorBase.__init__'s own defaults, component counts and frequencies (tensorBase.py:141-145): 390 MLP inputs
           ([16, 16, 16], [48, 48, 48], 128, 4, 3),
-          ([16, 16, 16], [48, 48, 48], 64, 0, 6)]
+          ([16, 16, 16], [48, 48, 48], 64, 0, 6),
+          # round 6: the kernels' own component counts with the constructor's six frequencies — what the FUSED training step takes at more than two frequencies
+          ([16, 16, 16], [48, 48, 48], 128, 6, 6)]
 
 
 def _scene(dc, ac, fc, vpe, fpe, hyper_tiny):
@@ -58,17 +60,23 @@ def test_zero_padded_shapes_render_like_the_oracle(tiny_dump, hyper_tiny, dc, ac
     assert float((m._mlp_render(vd.cuda(), feat.cuda()).cpu() - TO.mlp_render_fea(sc, vd, feat)).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("dc,ac,fc,vpe,fpe,hip_mm", [SHAPES[0] + (False,), SHAPES[1] + (False,), SHAPES[5] + (False,), SHAPES[5] + (True,), SHAPES[6] + (True,)])
+@pytest.mark.parametrize("dc,ac,fc,vpe,fpe,hip_mm", [SHAPES[0] + (False,), SHAPES[1] + (False,), SHAPES[5] + (False,), SHAPES[5] + (True,), SHAPES[6] + (True,),
+                                                     SHAPES[6] + (None,), SHAPES[8] + (None,)])
 def test_zero_padded_shapes_train(tiny_dump, hyper_tiny, monkeypatch, dc, ac, fc, vpe, fpe, hip_mm):
     """Gradients of every parameter tensor at its own (unpadded) shape against autograd through the oracle.  hip_mm: the eager chain's Linears forced onto the HIP
-    kernels whatever the batch size (round 5: what a 4096-ray training batch of a six-frequency scene runs — tvr_linear_dx forward and dX, tvr_gemm_tn dW; no
-    library GEMM, scripts/pe6_train_trace.sh)."""
+    kernels whatever the batch size (round 5: what a 4096-ray training batch of a six-frequency scene with fewer than 48 components runs — tvr_linear_dx forward and dX,
+    tvr_gemm_tn dW; no library GEMM, scripts/pe6_train_trace.sh).  hip_mm None (round 6): 16 / 48 components, width 128 and 3..6 frequencies go through the FUSED step
+    (tvr_train_forward / tvr_train_backward: lockstep layer 1, streamed W1^T backward, dW1 in column blocks) — asserted; True / False: the eager chain."""
     from oracle import tensorf_oracle as TO
     from test_gpu_training import _oracle_with_grads
     if hip_mm:
         from jittor_myc_nerfs_amd import autograd_ops
         monkeypatch.setattr(autograd_ops, "_HIP_MM_MIN_ROWS", 1)
     arrs, hyper, m = _scene(dc, ac, fc, vpe, fpe, hyper_tiny)
+    if hip_mm is None:
+        assert m._fused_step_ok()
+    else:
+        m.static_training = False
     rays_np = tiny_dump["rays"]
     S = TINY["N_samples"]
     cw = torch.tensor(np.random.default_rng(12).standard_normal((rays_np.shape[0], 3)).astype(np.float32))
@@ -78,6 +86,8 @@ def test_zero_padded_shapes_train(tiny_dump, hyper_tiny, monkeypatch, dc, ac, fc
     m.eps_T = 0.0
     rgb, _ = m.render_rays_autograd(torch.tensor(rays_np, device="cuda"), white_bg=True, N_samples=S)
     assert np.abs(rgb.detach().cpu().numpy() - rgb_o.detach().numpy()).max() < 2e-4
+    if hip_mm is None:
+        assert type(rgb.grad_fn).__name__.startswith("_FusedStepFn"), type(rgb.grad_fn).__name__
     (rgb * cw.cuda()).sum().backward()
     mlp = m.renderModule.mlp
     got = {"basis_mat": m.basis_mat.weight.grad, "W1": mlp[0].weight.grad, "b1": mlp[0].bias.grad, "W2": mlp[2].weight.grad,

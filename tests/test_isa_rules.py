@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 LIB = os.path.join(ROOT, "jittor-myc-nerfs_amd", "lib", "libtvr.so")
 GEN = "Lb1ELi3EEv8SceneDev"     # shade_kernel<SRC, DST, REF, RC, GEN = true, AR = 3>: the lockstep layer 1 of scenes with more than two encoding frequencies fetches W1's next
                                  # k-step from global memory between its MFMAs — by design outside the phase rule (csrc/tvr_shade.hip), and not the measured path
+BWD_GEN = "mlp_train_backward_kernelILb0ELb1EE"        # its backward (round 6), csrc/tvr_mlp_train.hip
 
 
 @pytest.fixture(scope="module")
@@ -32,7 +33,8 @@ def test_every_shade_kernel_variant_is_audited(report):
     # {queue, xyz->features, features->rgb} x {fp16 range check on, off} + the training forward (h -> rgb + activations), each x {TensorVMSplit, REFTensoRF},
     # + the render and mlp_render kernels in the two reduced-product arithmetics (2 kernels x 2 models x 2 range-check states x 2 modes)
     # + the backward kernels (mlp_train_backward x 2 models, basis_backward with 2 / 3 k-steps) + shade16_kernel x 2 range-check states x {TensorVMSplit, REFTensoRF (round 6)}
-    assert len(report) == 38, sorted(report)
+    # + mlp_train_backward_kernel<REF = false, GEN = true> (round 6: the fused training step of scenes with more than two encoding frequencies)
+    assert len(report) == 39, sorted(report)
 
     assert all(v["mfma"] >= 27 for v in report.values())
 
@@ -46,6 +48,12 @@ def test_phase_rule_of_mfma_kernels(report):
     # (shade16_kernel<RC, REF = true>, round 6, requests the heads' ten fragments from global memory behind its phase boundary: hipcc issues all ten in front of the first MFMA,
     #  so the shipped code satisfies the rule although the kernel does not rely on it)
     for name, v in report.items():
+        if BWD_GEN in name:
+            # by design outside the phase rule, like the forward's lockstep layer 1: W1^T (208 KB) does not fit the LDS, every wave streams its fragments from L2 half a
+            # slot ahead of the MFMAs that read them, into the registers of the half slot before, whose MFMAs have completed (each half slot ends with a read of its
+            # accumulator — the discipline of tvr_gemm.hip's chunks).  The vmcnt accounting and the VALU -> MFMA rule hold for it like for every other kernel.
+            assert v["vmem_loads_between_first_and_last_mfma"] > 0
+            continue
         assert v["vmem_loads_between_first_and_last_mfma"] == 0, f"{name}: a global (or spill) load sits between the MFMAs of a tile"
         assert v["war_adjacent"] == 0, (name, v["examples"]["war"])
 
