@@ -308,6 +308,8 @@ def other_configs(budget_s=240.0):
     root = os.path.dirname(os.path.abspath(__file__))
     for key, script, env in (("training step: TensorVMSplit 300^3, 4096 rays x 1039 samples", "train_step_timing.py", {"TVR_MODEL": "TensorVMSplit"}),
                              ("training step: REFTensoRF 300^3 (configs/Scar.txt), 4096 rays x 1039 samples", "train_step_timing.py", {"TVR_MODEL": "REFTensoRF"}),
+                             # round 6: TensorBase.__init__'s own encoding frequencies (tensorBase.py:141-145: view_pe = fea_pe = 6, 390 MLP inputs) through the fused step
+                             ("training step: TensorVMSplit 300^3 with view_pe = fea_pe = 6, 4096 rays x 1039 samples", "train_step_timing.py", {"TVR_MODEL": "TensorVMSplit", "TVR_PE": "6"}),
                              ("training step: NerfPlusPlus 300^3 (configs/Scarf.txt), 4096 rays x (1039 + 512 background) samples", "npp_train_step_timing.py", {})):
         if time.time() - t0 > budget_s:
             out[key] = "skipped: time budget"
