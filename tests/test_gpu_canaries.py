@@ -68,6 +68,23 @@ def test_render_and_training_write_nothing_behind_their_buffers(guards, tiny_dum
             loss.backward()
         torch.cuda.synchronize()
         assert L.check_guards() == [], L.check_guards()
+    # round 6: a scene with TensorBase's own six encoding frequencies — the fused step's wider workspace (X as three column blocks, the [128,152] temporary, the
+    # streamed W1^T image behind the LDS image of the training image buffer) and the lockstep render path
+    from jittor_myc_nerfs_amd import TensorVMSplit, synthetic
+    arrs6 = synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=5, view_pe=6, fea_pe=6)
+    m = TensorVMSplit(arrs6["aabb"], [int(x) for x in arrs6["gridSize"]], "cuda", density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
+                      near_far=hyper_tiny["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=hyper_tiny["density_shift"],
+                      distance_scale=hyper_tiny["distance_scale"], rayMarch_weight_thres=hyper_tiny["rayMarch_weight_thres"], pos_pe=6, view_pe=6, fea_pe=6,
+                      featureC=128, step_ratio=hyper_tiny["step_ratio"], fea2denseAct=hyper_tiny["fea2denseAct"])
+    m.load_arrays(arrs6)
+    m.render_rays(rays, white_bg=True, N_samples=TINY["N_samples"])
+    for static in (True, False):
+        m.static_training = static
+        rgb, _ = m.render_rays_autograd(rays, white_bg=True, N_samples=TINY["N_samples"])
+        assert type(rgb.grad_fn).__name__.startswith("_FusedStepFn") == static
+        (rgb ** 2).mean().backward()
+    torch.cuda.synchronize()
+    assert L.check_guards() == [], L.check_guards()
     names = _names(L)
     print(f"{len(L._guarded)} guarded buffers: {names}")
     for want in ("tvr_scene packed", "tvr_render scratch", "tvr_render scratch (slot 1)", "tvr_render rgb_out", "tvr_train work", "tvr_train_forward scratch",
