@@ -408,6 +408,9 @@ __device__ __forceinline__ void finish_tile(const Carry &c, const unsigned char 
 #define TVR_TOKEN_PHASE 1     // which phase the per-SIMD token makes mutually exclusive: 1 the matrix phase (shipped); 2 the GATHER phase (experiment: the two
 #endif                        // waves' matrix phases may then overlap — one's splits / sin / cos under the other's MFMAs — and "both gathering, pipe idle" cannot happen)
 #if TVR_TOKEN_PHASE == 1
+#ifndef TVR_GEN_PF
+#define TVR_GEN_PF 2       // k-steps between a thread's fetch of its uint4 of the streamed layer-1 image and the LDS store that stages it
+#endif
 // (GEN, the lockstep kernel of scenes with more than two encoding frequencies: no token — its waves meet at a barrier per layer-1 k-step anyway)
 #define TVR_ENTER_MATRIX() do { if (!GEN) TVR_TOKEN_TAKE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_M); } while (0)
 #define TVR_LEAVE_MATRIX() do { if (!GEN) TVR_TOKEN_GIVE(mtok); __builtin_amdgcn_s_setprio(TVR_PRIO_G); } while (0)
@@ -882,24 +885,50 @@ __global__ __launch_bounds__(SH_THREADS, SH_MINW) void shade_kernel(const SceneD
                     b = split8(v);
                 };
                 const uint4 *gsrc = (const uint4 *)sc.w1gen + tid;                       // k-step s: uint4 s * 512 + tid of the image (hi 256 | lo 256 uint4)
-                uint4 *slot = (uint4 *)(smem + TVR_IMG_W1H) + tid;                        // two 8 KB staging slots at the head of the (otherwise unused) W1 region
-                slot[0] = gsrc[0];                                                       // (the last readers of slot 0 passed two barriers since)
+                uint4 *slot = (uint4 *)(smem + TVR_IMG_W1H) + tid;                        // THREE 8 KB staging slots at the head of the (otherwise unused) W1 region
+                // Round 6 — what a k-step of round 4's form cost and why (scripts/phase_timing.py with TVR_PE=6: 1 455 cycles for the 768 cycles of its two waves' MFMAs):
+                // every wave reads the whole 8 KB slot (64 KB per k-step and CU: ~512 cycles of the LDS) and, in lockstep, every wave did so right behind the barrier and
+                // multiplied afterwards — reads and MFMAs in series.  Not the barrier count (groups of 2 / 4 / 5 k-steps per barrier: slower), not the order of the fragment
+                // derivation (pinned under the MFMAs: equal), not the fetch distance (1 .. 6 k-steps ahead: equal).  Now the image is staged TWO k-steps ahead (three slots), so
+                // that the fragments of row blocks 2, 3 are read under the MFMAs of row blocks 0, 1 and the NEXT k-step's fragments of row blocks 0, 1 under those of row blocks
+                // 2, 3.  Per accumulator the products come in mfma3x4's order (lo*hi, hi*lo, hi*hi): bit-identical results.
+                constexpr int PFG = TVR_GEN_PF;
+                uint4 wq[PFG];                                                            // wq[i]: k-step s + 2 + i, in flight
+                slot[0] = gsrc[0];                                                       // (the last readers of these slots passed a barrier since)
+                slot[512] = gsrc[512];
+#pragma unroll
+                for (int i = 0; i < PFG; ++i) wq[i] = (2 + i < TVR_GEN_KS) ? gsrc[(2 + i) * 512] : make_uint4(0u, 0u, 0u, 0u);
                 gen_frag(0, bcur);
                 __syncthreads();
+                uint4 Ah[4], Al[4];
+                auto rd2 = [&](int s_, int rb0) {                                        // the fragments of row blocks rb0, rb0 + 1 of k-step s_
+                    const unsigned char *sb = smem + TVR_IMG_W1H + (s_ % 3) * 8192 + rowoff;
+#pragma unroll
+                    for (int rb = rb0; rb < rb0 + 2; ++rb) { Ah[rb] = *(const uint4 *)(sb + rb * TVR_IMG_RB); Al[rb] = *(const uint4 *)(sb + 4096 + rb * TVR_IMG_RB); }
+                };
+                auto mm2 = [&](int rb0) {
+#pragma unroll
+                    for (int rb = rb0; rb < rb0 + 2; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, Al[rb]), __builtin_bit_cast(h8, bcur.hi), acc[rb], 0, 0, 0);
+#pragma unroll
+                    for (int rb = rb0; rb < rb0 + 2; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, Ah[rb]), __builtin_bit_cast(h8, bcur.lo), acc[rb], 0, 0, 0);
+#pragma unroll
+                    for (int rb = rb0; rb < rb0 + 2; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, Ah[rb]), __builtin_bit_cast(h8, bcur.hi), acc[rb], 0, 0, 0);
+                };
+                rd2(0, 0);
 #pragma unroll
                 for (int s = 0; s < TVR_GEN_KS; ++s) {
-                    uint4 wn = make_uint4(0u, 0u, 0u, 0u);
-                    if (s + 1 < TVR_GEN_KS) wn = gsrc[(s + 1) * 512];
-                    const unsigned char *sb = smem + TVR_IMG_W1H + (s & 1) * 8192 + rowoff;
-                    AFrag4 A;
+                    const uint4 wn = wq[0];                                              // k-step s + 2: requested PFG steps ago
 #pragma unroll
-                    for (int rb = 0; rb < 4; ++rb) { A.h[rb] = *(const uint4 *)(sb + rb * TVR_IMG_RB); A.l[rb] = *(const uint4 *)(sb + 4096 + rb * TVR_IMG_RB); }
+                    for (int i = 0; i + 1 < PFG; ++i) wq[i] = wq[i + 1];
+                    wq[PFG - 1] = (s + 2 + PFG < TVR_GEN_KS) ? gsrc[(s + 2 + PFG) * 512] : make_uint4(0u, 0u, 0u, 0u);
+                    rd2(s, 2);
                     if (s + 1 < TVR_GEN_KS) gen_frag(s + 1, bnxt);
-                    mfma3x4(A, bcur, acc);
-                    if (s + 1 < TVR_GEN_KS) {
-                        slot[((s + 1) & 1) * 512] = wn;
-                        bcur = bnxt;
-                    }
+                    mm2(0);
+                    TVR_SB;
+                    if (s + 1 < TVR_GEN_KS) rd2(s + 1, 0);                               // (slot (s + 1) % 3 was complete at the last barrier)
+                    mm2(2);
+                    if (s + 2 < TVR_GEN_KS) slot[((s + 2) % 3) * 512] = wn;               // (slot (s + 2) % 3 = (s - 1) % 3: its last readers passed the last barrier)
+                    if (s + 1 < TVR_GEN_KS) bcur = bnxt;
                     __syncthreads();
                 }
                 // layer 2's prologue: b2 -> the initial accumulators, W2's first fragment pairs, relu(layer 1) of k-step 0
