@@ -792,8 +792,9 @@ __global__ __launch_bounds__(256) void pe_concat_gen_kernel(const PeSrc p, const
     const int rows = (int)(m - e0 < PE_TILE ? m - e0 : PE_TILE);
     const int nin = TVR_APPDIM + 3 + 2 * TVR_APPDIM * fea_pe + 6 * view_pe, nb = (nin + TVR_GENX_W - 1) / TVR_GENX_W;
     const int wl = ((nin - (nb - 1) * TVR_GENX_W) + 3) & ~3;                  // width of the last block
-    for (int i = threadIdx.x; i < PE_TILE * ((nb - 1) * TVR_GENX_W + wl); i += 256) gtile[i] = 0.0f;
-    __syncthreads();
+    // (every real column of a row is written below; only the last block's zero columns need a value — clearing the whole 50 KB tile first cost as much as filling it)
+    const int npad = wl - (nin - (nb - 1) * TVR_GENX_W);
+    for (int i = threadIdx.x; i < PE_TILE * npad; i += 256) gtile[(nb - 1) * PE_TILE * TVR_GENX_W + (i / npad) * wl + (wl - npad) + (i % npad)] = 0.0f;
     for (int it = threadIdx.x; it < rows * 30; it += 256) {
         const int r = it / 30, c = it - r * 30;
         const long long ent = e0 + r;
