@@ -990,9 +990,11 @@ static int train_args_ok(tvr_scene *s, const float *rays, int64_t n_rays, int32_
     if (rc != TVR_OK) return rc;
     const tvr_scene_desc &d = s->desc;
     // round 6: view_pe / fea_pe up to 6 (TensorVMSplit scenes: the lockstep layer 1 forward, the streamed W1^T backward); REFTensoRF keeps 2 / 2
+    // and (TensorVMSplit) any component counts the kernels hold, <= 16 / 48 per plane — TensorBase's own defaults are 8 / 24: the packed scene carries zero channels, basis_mat's
+    // columns are mapped in pack_train_image_kernel and its gradient is copied back plane by plane
     bool std_shape = d.featureC == TVR_FEATC && ((d.view_pe == 2 && d.fea_pe == 2) || (s->dev.gen && d.variant == 0));
-    for (int i = 0; i < 3; ++i) std_shape = std_shape && d.app_n_comp[i] == TVR_CA;
-    if (!std_shape) return fail(TVR_ERR_UNSUPPORTED, "the fused training step takes 48 appearance components, featureC 128, view_pe = fea_pe = 2 (TensorVMSplit: up to 6 each)");
+    for (int i = 0; i < 3; ++i) std_shape = std_shape && (d.app_n_comp[i] == TVR_CA || (d.variant == 0 && d.app_n_comp[i] >= 1 && d.app_n_comp[i] <= TVR_CA));
+    if (!std_shape) return fail(TVR_ERR_UNSUPPORTED, "the fused training step takes featureC 128, view_pe = fea_pe = 2 and 48 appearance components per plane (TensorVMSplit: up to 6 frequencies each, 1 .. 48 components)");
     if (!rays || n_rays <= 0 || S <= 0 || S > 4096 || app_cap <= 0) return fail(TVR_ERR_INVALID, "rays NULL, or n_rays / n_samples / app_cap out of range");
     if ((size_t)n_rays * (size_t)S >= (1ull << 32) || (uint64_t)app_cap * 576u >= (1ull << 32)) return fail(TVR_ERR_INVALID, "n_rays * n_samples and app_cap * 576 must be < 2^32");
     if (!fwd_scratch || fwd_bytes < scratch_layout(n_rays, S).total || (uintptr_t)fwd_scratch % 256) return fail(TVR_ERR_SCRATCH, "forward scratch too small or misaligned");
@@ -1076,7 +1078,7 @@ int tvr_train_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     HIP_TRY(launch_composite_train_backward(mo, (int)n_rays, app_cap, white_bg, F(W.rgb), F(W.feats32), ref ? F(W.g8) : nullptr, F(W.pre), grad_rgb_map, ref ? grad_pen_ray : nullptr,
                                             F(W.grgb), F(W.gin0), F(W.grad_w), F(W.grad_acc), amax, grad_scale_target, gscale, stream));
     // 2. the network backward (register-resident MFMA chains), dh through basis_mat (and the heads)
-    HIP_TRY(launch_pack_train_image(wt->W1, wt->W2, wt->W3, wt->basis, ref ? wt->heads_W : nullptr, w + W.image, stream, s->desc.fea_pe, s->desc.view_pe));
+    HIP_TRY(launch_pack_train_image(wt->W1, wt->W2, wt->W3, wt->basis, ref ? wt->heads_W : nullptr, w + W.image, stream, s->desc.fea_pe, s->desc.view_pe, s->desc.app_n_comp));
     MlpRefBwd rb;
     rb.g8 = F(W.g8); rb.viewdirs = nullptr; rb.grad_in0 = F(W.gin0); rb.dg8 = F(W.dg8); rb.rays = rays; rb.q_ray = mo.q_ray;
     HIP_TRY(launch_mlp_train_backward(F(W.grgb), ref ? F(W.rgb_s) : F(W.rgb), F(W.feats32), F(W.h1), F(W.h2), app_cap, gscale, F(W.d_out4), F(W.dh2), F(W.dh1), F(W.dfeats32),
@@ -1105,7 +1107,14 @@ int tvr_train_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     } else
     HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X), nin, nin, app_cap, mo_->W1, gsc, stream, mdev, mo_->b1, gscale));
     HIP_TRY(launch_gemm_tn(F(W.dfeats32), 32, 32, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev, nullptr, gscale));
-    HIP_TRY(launch_copy_f32(mo_->basis, tmp, TVR_APPDIM * TVR_KAPP, stream));
+    {
+        int k_app = 0;
+        for (int i = 0; i < 3; ++i) k_app += s->desc.app_n_comp[i];
+        if (k_app == TVR_KAPP) HIP_TRY(launch_copy_f32(mo_->basis, tmp, TVR_APPDIM * TVR_KAPP, stream));
+        else                                     // fewer components: the gradient's [27, k_app] takes plane p's columns 48 p .. 48 p + n_p of the [32,144] product
+            for (int i = 0, off = 0; i < 3; off += s->desc.app_n_comp[i], ++i)
+                HIP_TRY(launch_copy_cols(mo_->basis, k_app, off, tmp + i * TVR_CA, TVR_KAPP, s->desc.app_n_comp[i], TVR_APPDIM, stream));
+    }
     if (ref) {
         HIP_TRY(launch_gemm_tn(F(W.dg8), 8, 8, F(W.h), TVR_KAPP, TVR_KAPP, app_cap, tmp, gsc, stream, mdev));      // rows: normal 0..2, specular 3, diffuse 4..6, rho 7
         HIP_TRY(launch_copy_f32(mo_->heads_W[0], tmp, 3 * TVR_KAPP, stream));

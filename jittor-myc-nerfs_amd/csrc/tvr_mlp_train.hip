@@ -50,6 +50,8 @@ __device__ __forceinline__ int unit_of_kpos(int kpos)
 
 // REFTensoRF's four heads on h (REFTensoRF.py:86-96), in the order of the shade kernel's second row block: normal 0..2, specular 3, diffuse 4..6, rho 7
 struct HeadPtrs { const float *W[4]; };              // normal [3,144], diffuse [3,144], specular [1,144], rho [1,144]; all NULL: TensorVMSplit
+// basis_mat as the reference holds it: [27][k_app] with plane p's n[p] <= 48 components at columns off[p] .. (tensoRF.py:150, 228-244); the kernels' channel 48 p + c
+struct AppCols { int n[3], off[3], k_app; };
 __device__ __forceinline__ float head_weight(const HeadPtrs &hp, int i, int ch)
 {
     return i < 3 ? hp.W[0][i * TVR_KAPP + ch] : (i == 3 ? hp.W[2][ch] : (i < 7 ? hp.W[1][(i - 4) * TVR_KAPP + ch] : hp.W[3][ch]));
@@ -58,7 +60,8 @@ __device__ __forceinline__ float head_weight(const HeadPtrs &hp, int i, int ch)
 // one thread per element of the three transposed images.  ref: W1 is MLPRender_Fea_Ref's [128,151] (REFTensoRF.py:9-16: every input index moves up
 // by one, base row 30's plain slot is input 0 = -dot) and Bas^T gets a third k-step holding the heads' weights.
 __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
-                                                               const float *__restrict__ Bas, const HeadPtrs hp, const int ref, const int gen, unsigned char *__restrict__ img)
+                                                               const float *__restrict__ Bas, const HeadPtrs hp, const int ref, const int gen, const AppCols ac,
+                                                               unsigned char *__restrict__ img)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *(unsigned *)(img + TI_SCAL) = 0u;
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__re
         const int f = unit_of_kpos(kpos);
         float w = 0.0f;
         if (row < TVR_KAPP) {
-            if (f < TVR_APPDIM) w = Bas[(size_t)f * TVR_KAPP + row];
+            const int pl = row / TVR_CA, c = row - pl * TVR_CA;                   // (a scene with fewer components: zero rows behind plane pl's own, as in the packed scene)
+            if (f < TVR_APPDIM) w = c < ac.n[pl] ? Bas[(size_t)f * ac.k_app + ac.off[pl] + c] : 0.0f;
             else if (ref && f >= 32 && f < 40) w = head_weight(hp, f - 32, row);
         }
         unsigned hi, lo;
@@ -591,14 +595,18 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
 size_t mlp_train_image_bytes() { return TI_BYTES_ALL; }
 
 hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream,
-                                   int fea_pe, int view_pe)
+                                   int fea_pe, int view_pe, const int *app_n_comp)
 {
+    AppCols ac;
+    ac.k_app = 0;
+    for (int i = 0; i < 3; ++i) { ac.n[i] = app_n_comp ? app_n_comp[i] : TVR_CA; ac.off[i] = ac.k_app; ac.k_app += ac.n[i]; }
+    if (heads && ac.k_app != TVR_KAPP) return hipErrorInvalidValue;           // (REFTensoRF's heads are packed at 144 columns)
     HeadPtrs hp;
     for (int i = 0; i < 4; ++i) hp.W[i] = heads ? heads[i] : nullptr;
     const int ref = heads ? 1 : 0, gen = (fea_pe > 2 || view_pe > 2) ? 1 : 0;
     if (gen && (ref || fea_pe > TVR_GEN_PE || view_pe > TVR_GEN_PE || fea_pe < 0 || view_pe < 0)) return hipErrorInvalidValue;
     const int n = 128 * 128 + 160 * 128 + 3 * 128 + 160 * (ref ? 48 : 32);
-    hipLaunchKernelGGL(pack_train_image_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W1, W2, W3, Bas, hp, ref, gen, (unsigned char *)image);
+    hipLaunchKernelGGL(pack_train_image_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W1, W2, W3, Bas, hp, ref, gen, ac, (unsigned char *)image);
     if (gen) hipLaunchKernelGGL(pack_train_w1gen_kernel, dim3((TVR_GEN_T * 8 * 64 + 255) / 256), dim3(256), 0, stream, W1, fea_pe, view_pe, (unsigned char *)image);
     return hipGetLastError();
 }

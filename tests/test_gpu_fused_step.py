@@ -218,16 +218,19 @@ def test_static_step_with_more_than_two_frequencies(tiny_dump, hyper_tiny, vpe, 
     assert float((rgb_a - rgb_r).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("vpe,fpe", [(2, 2), (6, 6), (3, 5), (6, 0)])
-def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_dump, hyper_tiny, vpe, fpe):
+@pytest.mark.parametrize("vpe,fpe,dc,ac", [(2, 2, 16, 48), (6, 6, 16, 48), (3, 5, 16, 48), (6, 0, 16, 48),
+                                           (6, 6, 8, 24),                      # TensorBase.__init__'s own defaults, component counts AND frequencies (tensorBase.py:141-145)
+                                           (2, 2, (5, 16, 9), (48, 7, 30))])   # ragged component counts
+def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_dump, hyper_tiny, vpe, fpe, dc, ac):
     """The step's workspace (tvr_train_work_describe) holds what the forward saved and what every backward stage wrote.  Each stage is recomputed in fp64 FROM THE
     TENSORS THE KERNELS THEMSELVES USED — the relu masks are those of the saved activations, so a hidden unit whose pre-activation sits within rounding of zero cannot
     turn a 1e-6 difference of two correct forwards into a 1e-3 difference of two correct gradients (which is what a comparison of whole steps against the oracle's
     autograd measures at six frequencies, scripts/debug/gen_step_check.py).  tensorBase.py:76-86 (MLPRender_Fea.execute), :9-15 (positional_encoding)."""
     import ctypes as C
     from jittor_myc_nerfs_amd import TensorVMSplit, synthetic, _lib as L
-    arrs = synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=5, view_pe=vpe, fea_pe=fpe)
-    m = TensorVMSplit(arrs["aabb"], [int(x) for x in arrs["gridSize"]], "cuda", density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
+    dc, ac = ([dc] * 3 if isinstance(dc, int) else list(dc)), ([ac] * 3 if isinstance(ac, int) else list(ac))
+    arrs = synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=5, view_pe=vpe, fea_pe=fpe, density_n_comp=dc, appearance_n_comp=ac)
+    m = TensorVMSplit(arrs["aabb"], [int(x) for x in arrs["gridSize"]], "cuda", density_n_comp=dc, appearance_n_comp=ac, app_dim=27,
                       near_far=hyper_tiny["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=hyper_tiny["density_shift"],
                       distance_scale=hyper_tiny["distance_scale"], rayMarch_weight_thres=hyper_tiny["rayMarch_weight_thres"], pos_pe=6, view_pe=vpe, fea_pe=fpe,
                       featureC=128, step_ratio=hyper_tiny["step_ratio"], fea2denseAct=hyper_tiny["fea2denseAct"])
@@ -254,7 +257,15 @@ def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_
     h, feats, h1, h2, rgb_s = (f64(mat(o, c)) for o, c in ((wl.h, 144), (wl.feats32, 32), (wl.h1, 128), (wl.h2, 128), (wl.rgb, 3)))
     grgb, d_out, dh2, dh1, dfe, dh = (f64(mat(o, c)) for o, c in ((wl.grgb, 3), (wl.d_out4, 4), (wl.dh2, 128), (wl.dh1, 128), (wl.dfeats32, 32), (wl.dh, 144)))
     mlp = m.renderModule.mlp
-    W1, W2, W3, Bas = (f64(t.detach()) for t in (mlp[0].weight, mlp[2].weight, mlp[4].weight, m.basis_mat.weight))
+    W1, W2, W3, Bas_ref = (f64(t.detach()) for t in (mlp[0].weight, mlp[2].weight, mlp[4].weight, m.basis_mat.weight))
+    # basis_mat in the kernels' channel order: plane p's components at columns 48 p .. (zero columns behind them: the packed scene's zero channels)
+    bcols = torch.cat([torch.arange(48 * p, 48 * p + c) for p, c in enumerate(ac)]).cuda()
+    assert Bas_ref.shape == (27, sum(ac))
+    Bas = torch.zeros((27, 144), dtype=torch.float64, device="cuda")
+    Bas[:, bcols] = Bas_ref
+    pad = torch.ones(144, dtype=torch.bool, device="cuda")
+    pad[bcols] = False
+    assert float(h[:, pad].abs().max()) == 0.0 if bool(pad.any()) else True
     n_in = 30 + 54 * fpe + 6 * vpe
     assert W1.shape == (128, n_in)
     q_ray = B["scratch"][sl.q_ray:sl.q_ray + 4 * cnt].view(torch.int32).long()
@@ -306,7 +317,7 @@ def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_
     close(g(mlp[2].bias), dh2.sum(0), "db2")
     close(g(mlp[0].weight), dh1.t() @ Xk, "dW1")
     close(g(mlp[0].bias), dh1.sum(0), "db1")
-    close(g(m.basis_mat.weight), dfe[:, :27].t() @ h, "dBasis")
+    close(g(m.basis_mat.weight), (dfe[:, :27].t() @ h)[:, bcols], "dBasis")
 
 
 def test_workspace_overflow_is_flagged_not_truncated(tiny_dump, tiny_arrays, hyper_tiny):
