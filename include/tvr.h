@@ -359,11 +359,12 @@ int tvr_mlp_train_backward_ref(const float *W1, const float *W2, const float *W3
  *   backward: grad_rgb_map [n,3], grad_pen_ray [n] or NULL -> gradients of every parameter: the VM factors through `vm_out` (all twelve), the network
  *             through `mlp_out` (reference layouts; heads: variant 1 only).  `weights`: the CURRENT parameters (reference layout), packed by the call.
  *             grad_scale_target: see tvr_mlp_train_backward's gscale (64 is the tested default); sat_flag_dev as there.
- * SHAPES (round 6): featureC 128; 48 appearance components per plane and view_pe = fea_pe = 2 — or, TensorVMSplit scenes, any component counts the kernels hold
- * (1 .. 16 density, 1 .. 48 appearance per plane: zero channels in the packed scene, basis_mat's [27, sum n] columns mapped on the way in and out) and any view_pe / fea_pe
- * up to 6 with at least one above 2.  TensorBase's own defaults — 8 / 24 components, 6 / 6 frequencies, tensorBase.py:141-145 — are among them: the forward is then the
- * lockstep layer-1 kernel of tvr_render, the backward takes dX slot by slot over a streamed W1^T image and dW1 in column blocks (csrc/tvr_mlp_train.hip).
- * Other shapes (featureC < 128, one or zero frequencies on one input only): TVR_ERR_UNSUPPORTED — hosts train them through the per-op entry points. */
+ * SHAPES (round 6): REFTensoRF scenes: featureC 128, view_pe = fea_pe = 2, 48 appearance components per plane.  TensorVMSplit scenes: EVERY shape the scene accepts —
+ * 1 .. 16 density and 1 .. 48 appearance components per plane (zero channels in the packed scene; basis_mat's [27, sum n] columns mapped on the way in and out), featureC
+ * 1 .. 128 (units that do not exist are zero rows / columns of the packed weights, their gradients are cropped out of the 128-wide products), view_pe / fea_pe 0 .. 6.
+ * TensorBase's own defaults — 8 / 24 components, 6 / 6 frequencies, tensorBase.py:141-145 — are among them.  With more than two frequencies the forward is the lockstep
+ * layer-1 kernel of tvr_render and the backward takes dX slot by slot over a streamed W1^T image; for every shape but 2 / 2 at width 128 dW1 is reduced in column blocks
+ * of 152 columns (csrc/tvr_mlp_train.hip, tvr_train.hip pe_concat_gen_kernel). */
 typedef struct { const float *W1, *W2, *W3, *basis; const float *heads_W[4]; } tvr_train_weights;   /* heads_W: normal, diffuse, specular, rho (variant 1) */
 typedef struct { float *W1, *b1, *W2, *b2, *W3, *b3, *basis; float *heads_W[4], *heads_b[4]; } tvr_train_mlp_grads;
 size_t tvr_train_work_bytes(const tvr_scene *scene, int64_t n_rays, int32_t n_samples, int64_t app_cap);

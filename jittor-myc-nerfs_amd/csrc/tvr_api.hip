@@ -972,9 +972,9 @@ static WorkLayout work_layout(int64_t n_rays, int32_t S, int64_t cap, bool gen =
     L.g8 = take(c * 8); L.rgb_s = take(c * 3); L.pre = take(n * 3);
     L.grgb = take(c * 3); L.gin0 = take(c); L.grad_w = take(n * (size_t)S); L.grad_acc = take(n);
     L.d_out4 = take(c * 4); L.dh2 = take(c * TVR_FEATC); L.dh1 = take(c * TVR_FEATC); L.dfeats32 = take(c * 32); L.dg8 = take(c * 8); L.dh = take(c * TVR_KAPP);
-    L.X = take(c * (gen ? (size_t)TVR_GENX_FLOATS : (size_t)TVR_NIN_REF));   // (more than two encoding frequencies: three column blocks of 152, tvr_train.hip pe_concat_gen_kernel)
-    L.tmp = take(gen ? (size_t)TVR_FEATC * TVR_GENX_W + 128 : 32 * TVR_KAPP + 128);   // gemm_tn results that are wider than the gradient they feed ([4,128], [32,144], [8,144]; a [128,152] block of dW1) and bias sums
-    size_t g = gemm_tn_scratch_bytes(TVR_FEATC, (gen ? TVR_GENX_W : TVR_NIN_REF) + 1, cap);        // (+ 1: the ones column that carries the bias gradient)
+    L.X = take(c * (gen ? (size_t)TVR_GENX_FLOATS : (size_t)TVR_GENX_W));    // (more than two encoding frequencies: three column blocks of 152, tvr_train.hip pe_concat_gen_kernel; otherwise one block or [cap,150 / 151])
+    L.tmp = take((size_t)TVR_FEATC * TVR_GENX_W + 256);       // gemm_tn results that are wider than the gradient they feed ([4,128], [32,144], [8,144]; a [128,152] block of dW1, dW2 of a narrow network) and bias sums
+    size_t g = gemm_tn_scratch_bytes(TVR_FEATC, TVR_GENX_W + 1, cap);        // (+ 1: the ones column that carries the bias gradient)
     L.gemm = take(g / sizeof(float) + 64);
     L.colsum = take(colsum_scratch_bytes() / sizeof(float));
     L.image = take(mlp_train_image_bytes() / sizeof(float) + 64);
@@ -992,9 +992,11 @@ static int train_args_ok(tvr_scene *s, const float *rays, int64_t n_rays, int32_
     // round 6: view_pe / fea_pe up to 6 (TensorVMSplit scenes: the lockstep layer 1 forward, the streamed W1^T backward); REFTensoRF keeps 2 / 2
     // and (TensorVMSplit) any component counts the kernels hold, <= 16 / 48 per plane — TensorBase's own defaults are 8 / 24: the packed scene carries zero channels, basis_mat's
     // columns are mapped in pack_train_image_kernel and its gradient is copied back plane by plane
-    bool std_shape = d.featureC == TVR_FEATC && ((d.view_pe == 2 && d.fea_pe == 2) || (s->dev.gen && d.variant == 0));
+    // — and any hidden width up to 128 and any frequencies 0 .. 6: every TensorVMSplit shape the scene itself accepts (check_desc) trains through the fused step
+    bool std_shape = d.variant == 0 ? (d.featureC >= 1 && d.featureC <= TVR_FEATC && d.view_pe >= 0 && d.view_pe <= TVR_GEN_PE && d.fea_pe >= 0 && d.fea_pe <= TVR_GEN_PE)
+                                    : (d.featureC == TVR_FEATC && d.view_pe == 2 && d.fea_pe == 2);
     for (int i = 0; i < 3; ++i) std_shape = std_shape && (d.app_n_comp[i] == TVR_CA || (d.variant == 0 && d.app_n_comp[i] >= 1 && d.app_n_comp[i] <= TVR_CA));
-    if (!std_shape) return fail(TVR_ERR_UNSUPPORTED, "the fused training step takes featureC 128, view_pe = fea_pe = 2 and 48 appearance components per plane (TensorVMSplit: up to 6 frequencies each, 1 .. 48 components)");
+    if (!std_shape) return fail(TVR_ERR_UNSUPPORTED, "the fused training step takes REFTensoRF scenes at featureC 128, view_pe = fea_pe = 2, 48 appearance components per plane (TensorVMSplit: any shape the scene accepts)");
     if (!rays || n_rays <= 0 || S <= 0 || S > 4096 || app_cap <= 0) return fail(TVR_ERR_INVALID, "rays NULL, or n_rays / n_samples / app_cap out of range");
     if ((size_t)n_rays * (size_t)S >= (1ull << 32) || (uint64_t)app_cap * 576u >= (1ull << 32)) return fail(TVR_ERR_INVALID, "n_rays * n_samples and app_cap * 576 must be < 2^32");
     if (!fwd_scratch || fwd_bytes < scratch_layout(n_rays, S).total || (uintptr_t)fwd_scratch % 256) return fail(TVR_ERR_SCRATCH, "forward scratch too small or misaligned");
@@ -1018,8 +1020,9 @@ int tvr_train_work_describe(const tvr_scene *s, int64_t n_rays, int32_t n_sample
     out->h = W.h; out->feats32 = W.feats32; out->h1 = W.h1; out->h2 = W.h2; out->rgb = W.rgb; out->grgb = W.grgb; out->d_out4 = W.d_out4; out->dh2 = W.dh2; out->dh1 = W.dh1;
     out->dfeats32 = W.dfeats32; out->dh = W.dh; out->X = W.X; out->total = W.total;
     const int n_in = TVR_APPDIM + 3 + 2 * TVR_APPDIM * s->desc.fea_pe + 6 * s->desc.view_pe;
-    out->x_blocks = gen ? (n_in + TVR_GENX_W - 1) / TVR_GENX_W : 1;
-    out->x_block_cols = gen ? TVR_GENX_W : (s->desc.variant == 1 ? TVR_NIN_REF : TVR_NIN);
+    const bool blocks = s->desc.variant == 0 && (gen || s->desc.fea_pe != 2 || s->desc.view_pe != 2 || s->desc.featureC < TVR_FEATC);
+    out->x_blocks = blocks ? (n_in + TVR_GENX_W - 1) / TVR_GENX_W : 1;
+    out->x_block_cols = blocks ? TVR_GENX_W : (s->desc.variant == 1 ? TVR_NIN_REF : TVR_NIN);
     return TVR_OK;
 }
 
@@ -1078,31 +1081,43 @@ int tvr_train_backward(tvr_scene *s, const float *rays, int64_t n_rays, int32_t 
     HIP_TRY(launch_composite_train_backward(mo, (int)n_rays, app_cap, white_bg, F(W.rgb), F(W.feats32), ref ? F(W.g8) : nullptr, F(W.pre), grad_rgb_map, ref ? grad_pen_ray : nullptr,
                                             F(W.grgb), F(W.gin0), F(W.grad_w), F(W.grad_acc), amax, grad_scale_target, gscale, stream));
     // 2. the network backward (register-resident MFMA chains), dh through basis_mat (and the heads)
-    HIP_TRY(launch_pack_train_image(wt->W1, wt->W2, wt->W3, wt->basis, ref ? wt->heads_W : nullptr, w + W.image, stream, s->desc.fea_pe, s->desc.view_pe, s->desc.app_n_comp));
+    const int fc = s->desc.featureC;
+    // dW1 in column blocks (tvr_train.hip pe_concat_gen_kernel) for every shape but the kernels' own 2 / 2 at width 128: more than two frequencies (three blocks), fewer (one block
+    // of 30 .. 144 columns), a narrower network (its gradients are cropped out of the 128-wide products)
+    const bool blocks = !ref && (gen || s->desc.fea_pe != 2 || s->desc.view_pe != 2 || fc < TVR_FEATC);
+    HIP_TRY(launch_pack_train_image(wt->W1, wt->W2, wt->W3, wt->basis, ref ? wt->heads_W : nullptr, w + W.image, stream, s->desc.fea_pe, s->desc.view_pe, s->desc.app_n_comp, fc));
     MlpRefBwd rb;
     rb.g8 = F(W.g8); rb.viewdirs = nullptr; rb.grad_in0 = F(W.gin0); rb.dg8 = F(W.dg8); rb.rays = rays; rb.q_ray = mo.q_ray;
     HIP_TRY(launch_mlp_train_backward(F(W.grgb), ref ? F(W.rgb_s) : F(W.rgb), F(W.feats32), F(W.h1), F(W.h2), app_cap, gscale, F(W.d_out4), F(W.dh2), F(W.dh1), F(W.dfeats32),
                                       F(W.dh), sat_flag_dev, w + W.image, ref ? &rb : nullptr, stream, mdev, gen ? 1 : 0));
     // 3. weight gradients: dW = dY^T X over the step's appearance samples (tall-skinny reductions, fixed order), bias gradients = column sums
-    if (gen) HIP_TRY(launch_pe_concat_gen(F(W.feats32), 32, rays, mo.q_ray, s->desc.fea_pe, s->desc.view_pe, app_cap, mdev, F(W.X), stream));
+    if (blocks) HIP_TRY(launch_pe_concat_gen(F(W.feats32), 32, rays, mo.q_ray, s->desc.fea_pe, s->desc.view_pe, app_cap, mdev, F(W.X), stream));
     else if (ref) HIP_TRY(launch_pe_concat_strided(F(W.feats32), 32, F(W.feats32) + 27, 32, nullptr, nullptr, F(W.feats32) + 30, 32, app_cap, mdev, F(W.X), stream));
     else HIP_TRY(launch_pe_concat_strided(F(W.feats32), 32, nullptr, 0, rays, mo.q_ray, nullptr, 0, app_cap, mdev, F(W.X), stream));
     float *tmp = F(W.tmp), *gsc = F(W.gemm), *csc = F(W.colsum);
     // (the bias gradients ride along as a virtual ones column of the second operand: no second pass over d_out / dh2 / dh1)
-    float *bs3 = tmp + 32 * TVR_KAPP + 16;
+    float *bs3 = tmp + 32 * TVR_KAPP + 16, *btmp = tmp + TVR_FEATC * TVR_GENX_W + 64;          // (btmp: a 128-entry bias sum of a product whose rows are cropped afterwards)
     // The products run on the fp16-split MFMAs at the backward's own gradient scale (the same values went through fp16 at that scale inside
     // mlp_train_backward / basis_backward, which raise the saturation flag if they do not fit): the kernel then runs at its staging rate.
     HIP_TRY(launch_gemm_tn(F(W.d_out4), 4, 4, F(W.h2), TVR_FEATC, TVR_FEATC, app_cap, tmp, gsc, stream, mdev, bs3, gscale));
-    HIP_TRY(launch_copy_f32(mo_->W3, tmp, 3 * TVR_FEATC, stream));
+    if (fc == TVR_FEATC) HIP_TRY(launch_copy_f32(mo_->W3, tmp, 3 * TVR_FEATC, stream));
+    else HIP_TRY(launch_copy_cols(mo_->W3, fc, 0, tmp, TVR_FEATC, fc, 3, stream));             // W3's gradient is [3, fc]: the first fc columns of the [4,128] product
     HIP_TRY(launch_copy_f32(mo_->b3, bs3, 3, stream));
-    HIP_TRY(launch_gemm_tn(F(W.dh2), TVR_FEATC, TVR_FEATC, F(W.h1), TVR_FEATC, TVR_FEATC, app_cap, mo_->W2, gsc, stream, mdev, mo_->b2, gscale));
-    if (gen) {
-        // dW1 [128, n_in] block by block (tvr_train.hip pe_concat_gen_kernel): each block's product lands in `tmp` and is copied to its columns; the bias rides with block 0
+    if (fc == TVR_FEATC) HIP_TRY(launch_gemm_tn(F(W.dh2), TVR_FEATC, TVR_FEATC, F(W.h1), TVR_FEATC, TVR_FEATC, app_cap, mo_->W2, gsc, stream, mdev, mo_->b2, gscale));
+    else {                                                                                      // [fc, fc] and [fc] out of the 128-wide product (units that do not exist: exact zeros)
+        HIP_TRY(launch_gemm_tn(F(W.dh2), TVR_FEATC, TVR_FEATC, F(W.h1), TVR_FEATC, TVR_FEATC, app_cap, tmp, gsc, stream, mdev, btmp, gscale));
+        HIP_TRY(launch_copy_cols(mo_->W2, fc, 0, tmp, TVR_FEATC, fc, fc, stream));
+        HIP_TRY(launch_copy_f32(mo_->b2, btmp, fc, stream));
+    }
+    if (blocks) {
+        // dW1 [fc, n_in] block by block (tvr_train.hip pe_concat_gen_kernel): each block's product lands in `tmp` and is copied to its columns; the bias rides with block 0
         const int n_in = TVR_APPDIM + 3 + 2 * TVR_APPDIM * s->desc.fea_pe + 6 * s->desc.view_pe, nb = (n_in + TVR_GENX_W - 1) / TVR_GENX_W;
         for (int b = 0; b < nb; ++b) {
             const int cols = b == nb - 1 ? n_in - b * TVR_GENX_W : TVR_GENX_W, wb = (cols + 3) & ~3;
-            HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X) + (size_t)b * (size_t)app_cap * TVR_GENX_W, wb, wb, app_cap, tmp, gsc, stream, mdev, b == 0 ? mo_->b1 : nullptr, gscale));
-            HIP_TRY(launch_copy_cols(mo_->W1, n_in, b * TVR_GENX_W, tmp, wb, cols, TVR_FEATC, stream));
+            HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X) + (size_t)b * (size_t)app_cap * TVR_GENX_W, wb, wb, app_cap, tmp, gsc, stream, mdev,
+                                   b == 0 ? (fc == TVR_FEATC ? mo_->b1 : btmp) : nullptr, gscale));
+            HIP_TRY(launch_copy_cols(mo_->W1, n_in, b * TVR_GENX_W, tmp, wb, cols, fc, stream));
+            if (b == 0 && fc < TVR_FEATC) HIP_TRY(launch_copy_f32(mo_->b1, btmp, fc, stream));
         }
     } else
     HIP_TRY(launch_gemm_tn(F(W.dh1), TVR_FEATC, TVR_FEATC, F(W.X), nin, nin, app_cap, mo_->W1, gsc, stream, mdev, mo_->b1, gscale));

@@ -105,7 +105,8 @@ size_t mlp_train_image_bytes();
 // heads: REFTensoRF's {normal [3,144], diffuse [3,144], specular [1,144], rho [1,144]} weights, or nullptr (TensorVMSplit)
 // fea_pe / view_pe > 2 (TensorVMSplit only): W1 is [128, 30 + 54 fea_pe + 6 view_pe] and is packed into the streamed image behind the LDS image (tvr_mlp_train.hip, TI_W1G)
 hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream,
-                                   int fea_pe = 2, int view_pe = 2, const int *app_n_comp = nullptr);     // app_n_comp[3] <= 48 each (nullptr: 48): basis is [27, sum app_n_comp]
+                                   int fea_pe = 2, int view_pe = 2, const int *app_n_comp = nullptr,      // app_n_comp[3] <= 48 each (nullptr: 48): basis is [27, sum app_n_comp]
+                                   int featureC = 128);                                                    // <= 128: W1 [fc, n_in], W2 [fc, fc], W3 [3, fc]
 // REFTensoRF's additions to the backward: raw head outputs, view directions, optional gradient of the -dot output; dg8 [m,8] is written
 struct MlpRefBwd { const float *g8, *viewdirs, *grad_in0; float *dg8; const float *rays; const unsigned *q_ray; };   // q_ray set: the direction of entry e is rays[q_ray[e]][3..5]
 hipError_t launch_mlp_train_backward(const float *grad_rgb, const float *rgb, const float *feats, const float *h1, const float *h2, long long m, const float *gscale,

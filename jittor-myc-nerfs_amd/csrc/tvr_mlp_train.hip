@@ -61,7 +61,7 @@ __device__ __forceinline__ float head_weight(const HeadPtrs &hp, int i, int ch)
 // by one, base row 30's plain slot is input 0 = -dot) and Bas^T gets a third k-step holding the heads' weights.
 __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
                                                                const float *__restrict__ Bas, const HeadPtrs hp, const int ref, const int gen, const AppCols ac,
-                                                               unsigned char *__restrict__ img)
+                                                               const int fc, const int fea_pe, const int view_pe, unsigned char *__restrict__ img)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *(unsigned *)(img + TI_SCAL) = 0u;
@@ -70,23 +70,26 @@ __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__re
     if (i < n_w2) {
         const int row = i >> 7, kpos = i & 127;                                   // row = layer-1 unit, k = layer-2 unit
         unsigned hi, lo;
-        split2(W2[(size_t)unit_of_kpos(kpos) * TVR_FEATC + row], 0.0f, hi, lo);
+        const int u2 = unit_of_kpos(kpos);                                        // (fc < 128: W2 is [fc, fc]; units that do not exist are zero rows and columns)
+        split2((u2 < fc && row < fc) ? W2[(size_t)u2 * fc + row] : 0.0f, 0.0f, hi, lo);
         ((unsigned short *)(img + TI_W2T_H + row * TI_ROW))[kpos] = (unsigned short)hi;
         ((unsigned short *)(img + TI_W2T_L + row * TI_ROW))[kpos] = (unsigned short)lo;
     } else if (i < n_w2 + n_w1) {
         const int k = i - n_w2, row = k >> 7, kpos = k & 127;                     // row = 32 t + c: derived value t of base value c; k = layer-1 unit
         const int c = row & 31, t = row >> 5;
-        int idx = ref_in_index(c, t);
+        int idx = ref ? ref_in_index(c, t) : ref_in_index(c, t, fea_pe, view_pe);      // (fewer than two frequencies: the slots that do not exist have no column, weight 0)
         if (ref) idx = (c == TVR_APPDIM + 3) ? (t == 0 ? 0 : -1) : (idx >= 0 ? idx + 1 : -1);
-        // (gen: W1 is [128, 30 + 54 fea_pe + 6 view_pe] and goes to the streamed image, pack_train_w1gen_kernel; this region stays zero)
-        const float w = (idx >= 0 && !gen) ? W1[(size_t)unit_of_kpos(kpos) * (ref ? TVR_NIN_REF : TVR_NIN) + idx] : 0.0f;
+        // (gen: W1 is [fc, 30 + 54 fea_pe + 6 view_pe] and goes to the streamed image, pack_train_w1gen_kernel; this region stays zero)
+        const int u1 = unit_of_kpos(kpos), nin1 = ref ? TVR_NIN_REF : TVR_APPDIM + 3 + 2 * TVR_APPDIM * fea_pe + 6 * view_pe;
+        const float w = (idx >= 0 && !gen && u1 < fc) ? W1[(size_t)u1 * nin1 + idx] : 0.0f;
         unsigned hi, lo;
         split2(w, 0.0f, hi, lo);
         ((unsigned short *)(img + TI_W1T_H + row * TI_ROW))[kpos] = (unsigned short)hi;
         ((unsigned short *)(img + TI_W1T_L + row * TI_ROW))[kpos] = (unsigned short)lo;
     } else if (i < n_w2 + n_w1 + n_w3) {
         const int k = i - n_w2 - n_w1;
-        ((float *)(img + TI_W3))[k] = W3[k];
+        const int c3 = k >> 7, u3 = k & 127;
+        ((float *)(img + TI_W3))[k] = u3 < fc ? W3[c3 * fc + u3] : 0.0f;
     } else if (i < n_w2 + n_w1 + n_w3 + n_b) {
         const int k = i - n_w2 - n_w1 - n_w3, row = k / KB, kpos = k - row * KB;  // row = channel (144, padded to 160), k = feature (27, padded to 32) [+ 8 heads, padded to 16]
         const int f = unit_of_kpos(kpos);
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void pack_train_image_kernel(const float *__re
 }
 
 // one thread per (slot t, k-step s, lane): the hi and the lo uint4 of the streamed W1^T image (TI_W1G)
-__global__ __launch_bounds__(256) void pack_train_w1gen_kernel(const float *__restrict__ W1, const int fea_pe, const int view_pe, unsigned char *__restrict__ img)
+__global__ __launch_bounds__(256) void pack_train_w1gen_kernel(const float *__restrict__ W1, const int fc, const int fea_pe, const int view_pe, unsigned char *__restrict__ img)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= TVR_GEN_T * 8 * 64) return;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void pack_train_w1gen_kernel(const float *__re
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
         const int u0 = unit_of_kpos(16 * s + 8 * h + j), u1 = unit_of_kpos(16 * s + 8 * h + j + 1);
-        split2(idx >= 0 ? W1[(size_t)u0 * nin + idx] : 0.0f, idx >= 0 ? W1[(size_t)u1 * nin + idx] : 0.0f, hi[j >> 1], lo[j >> 1]);
+        split2((idx >= 0 && u0 < fc) ? W1[(size_t)u0 * nin + idx] : 0.0f, (idx >= 0 && u1 < fc) ? W1[(size_t)u1 * nin + idx] : 0.0f, hi[j >> 1], lo[j >> 1]);
     }
     uint4 *o = (uint4 *)(img + TI_W1G) + (size_t)((t * 8 + s) * 2) * 64 + lane;
     o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
@@ -595,8 +598,9 @@ __global__ __launch_bounds__(256, 2) void basis_backward_kernel(const float *__r
 size_t mlp_train_image_bytes() { return TI_BYTES_ALL; }
 
 hipError_t launch_pack_train_image(const float *W1, const float *W2, const float *W3, const float *Bas, const float *const heads[4], void *image, hipStream_t stream,
-                                   int fea_pe, int view_pe, const int *app_n_comp)
+                                   int fea_pe, int view_pe, const int *app_n_comp, int featureC)
 {
+    if (featureC < 1 || featureC > TVR_FEATC || (heads && (featureC != TVR_FEATC || fea_pe != 2 || view_pe != 2))) return hipErrorInvalidValue;
     AppCols ac;
     ac.k_app = 0;
     for (int i = 0; i < 3; ++i) { ac.n[i] = app_n_comp ? app_n_comp[i] : TVR_CA; ac.off[i] = ac.k_app; ac.k_app += ac.n[i]; }
@@ -606,8 +610,8 @@ hipError_t launch_pack_train_image(const float *W1, const float *W2, const float
     const int ref = heads ? 1 : 0, gen = (fea_pe > 2 || view_pe > 2) ? 1 : 0;
     if (gen && (ref || fea_pe > TVR_GEN_PE || view_pe > TVR_GEN_PE || fea_pe < 0 || view_pe < 0)) return hipErrorInvalidValue;
     const int n = 128 * 128 + 160 * 128 + 3 * 128 + 160 * (ref ? 48 : 32);
-    hipLaunchKernelGGL(pack_train_image_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W1, W2, W3, Bas, hp, ref, gen, ac, (unsigned char *)image);
-    if (gen) hipLaunchKernelGGL(pack_train_w1gen_kernel, dim3((TVR_GEN_T * 8 * 64 + 255) / 256), dim3(256), 0, stream, W1, fea_pe, view_pe, (unsigned char *)image);
+    hipLaunchKernelGGL(pack_train_image_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W1, W2, W3, Bas, hp, ref, gen, ac, featureC, fea_pe, view_pe, (unsigned char *)image);
+    if (gen) hipLaunchKernelGGL(pack_train_w1gen_kernel, dim3((TVR_GEN_T * 8 * 64 + 255) / 256), dim3(256), 0, stream, W1, featureC, fea_pe, view_pe, (unsigned char *)image);
     return hipGetLastError();
 }
 

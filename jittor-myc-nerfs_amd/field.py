@@ -681,13 +681,15 @@ class TensorBase(torch.nn.Module):
     def _fused_step_ok(self) -> bool:
         rm = self.renderModule
         fe, ve = getattr(rm, "feape", -1), getattr(rm, "viewpe", -1)
-        # two encoding frequencies each — or, TensorVMSplit scenes (round 6), up to six: the lockstep layer 1 forward and the streamed W1^T backward (tvr_mlp_train.hip)
-        pe_ok = (fe == 2 and ve == 2) or (getattr(self, "_variant", 0) == 0 and 0 <= fe <= 6 and 0 <= ve <= 6 and (fe > 2 or ve > 2))
-        # 48 appearance components per plane — or, TensorVMSplit scenes (round 6), any count the kernels hold (TensorBase's own defaults are 8 / 24, tensorBase.py:141)
-        comps_ok = list(self.app_n_comp) == [48, 48, 48] or (getattr(self, "_variant", 0) == 0 and all(1 <= int(c) <= 48 for c in self.app_n_comp)
-                                                             and all(1 <= int(c) <= 16 for c in self.density_n_comp))
-        return (self.static_training and self.fused_mlp_training and comps_ok and self.app_dim == 27
-                and pe_ok and rm.mlp[0].out_features == 128 and str(self.device).startswith("cuda"))
+        width = rm.mlp[0].out_features
+        if getattr(self, "_variant", 0) == 0:
+            # TensorVMSplit (round 6): every shape the scene itself accepts — 1 .. 16 / 1 .. 48 components per plane (TensorBase's own defaults are 8 / 24, tensorBase.py:141),
+            # hidden width up to 128, 0 .. 6 encoding frequencies on either input (6 / 6 by default, :144-145) — tvr_train_forward / _backward, include/tvr.h "SHAPES"
+            shape_ok = (all(1 <= int(c) <= 48 for c in self.app_n_comp) and all(1 <= int(c) <= 16 for c in self.density_n_comp)
+                        and 1 <= width <= 128 and 0 <= fe <= 6 and 0 <= ve <= 6)
+        else:
+            shape_ok = list(self.app_n_comp) == [48, 48, 48] and width == 128 and fe == 2 and ve == 2
+        return (self.static_training and self.fused_mlp_training and shape_ok and self.app_dim == 27 and str(self.device).startswith("cuda"))
 
     def _get_scratch(self, nbytes: int, slot: int = 0) -> torch.Tensor:
         """The render scratch (march queue etc.).  slot > 0: a second buffer for a second frame in flight on another stream (render.FrameStream)."""

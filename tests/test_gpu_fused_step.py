@@ -218,10 +218,11 @@ def test_static_step_with_more_than_two_frequencies(tiny_dump, hyper_tiny, vpe, 
     assert float((rgb_a - rgb_r).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("vpe,fpe,dc,ac", [(2, 2, 16, 48), (6, 6, 16, 48), (3, 5, 16, 48), (6, 0, 16, 48),
-                                           (6, 6, 8, 24),                      # TensorBase.__init__'s own defaults, component counts AND frequencies (tensorBase.py:141-145)
-                                           (2, 2, (5, 16, 9), (48, 7, 30))])   # ragged component counts
-def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_dump, hyper_tiny, vpe, fpe, dc, ac):
+@pytest.mark.parametrize("vpe,fpe,dc,ac,fc", [(2, 2, 16, 48, 128), (6, 6, 16, 48, 128), (3, 5, 16, 48, 128), (6, 0, 16, 48, 128),
+                                              (6, 6, 8, 24, 128),                     # TensorBase.__init__'s own defaults, component counts AND frequencies (tensorBase.py:141-145)
+                                              (2, 2, (5, 16, 9), (48, 7, 30), 128),   # ragged component counts
+                                              (1, 2, 16, 48, 96), (0, 0, (5, 16, 9), (48, 7, 30), 64), (4, 1, 8, 24, 33)])   # narrower networks, fewer than two frequencies
+def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_dump, hyper_tiny, vpe, fpe, dc, ac, fc):
     """The step's workspace (tvr_train_work_describe) holds what the forward saved and what every backward stage wrote.  Each stage is recomputed in fp64 FROM THE
     TENSORS THE KERNELS THEMSELVES USED — the relu masks are those of the saved activations, so a hidden unit whose pre-activation sits within rounding of zero cannot
     turn a 1e-6 difference of two correct forwards into a 1e-3 difference of two correct gradients (which is what a comparison of whole steps against the oracle's
@@ -229,11 +230,11 @@ def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_
     import ctypes as C
     from jittor_myc_nerfs_amd import TensorVMSplit, synthetic, _lib as L
     dc, ac = ([dc] * 3 if isinstance(dc, int) else list(dc)), ([ac] * 3 if isinstance(ac, int) else list(ac))
-    arrs = synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=5, view_pe=vpe, fea_pe=fpe, density_n_comp=dc, appearance_n_comp=ac)
+    arrs = synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=5, view_pe=vpe, fea_pe=fpe, density_n_comp=dc, appearance_n_comp=ac, featureC=fc)
     m = TensorVMSplit(arrs["aabb"], [int(x) for x in arrs["gridSize"]], "cuda", density_n_comp=dc, appearance_n_comp=ac, app_dim=27,
                       near_far=hyper_tiny["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=hyper_tiny["density_shift"],
                       distance_scale=hyper_tiny["distance_scale"], rayMarch_weight_thres=hyper_tiny["rayMarch_weight_thres"], pos_pe=6, view_pe=vpe, fea_pe=fpe,
-                      featureC=128, step_ratio=hyper_tiny["step_ratio"], fea2denseAct=hyper_tiny["fea2denseAct"])
+                      featureC=fc, step_ratio=hyper_tiny["step_ratio"], fea2denseAct=hyper_tiny["fea2denseAct"])
     m.load_arrays(arrs)
     rays = _batch(tiny_dump, 16)
     n, S = rays.shape[0], TINY["N_samples"]
@@ -257,7 +258,14 @@ def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_
     h, feats, h1, h2, rgb_s = (f64(mat(o, c)) for o, c in ((wl.h, 144), (wl.feats32, 32), (wl.h1, 128), (wl.h2, 128), (wl.rgb, 3)))
     grgb, d_out, dh2, dh1, dfe, dh = (f64(mat(o, c)) for o, c in ((wl.grgb, 3), (wl.d_out4, 4), (wl.dh2, 128), (wl.dh1, 128), (wl.dfeats32, 32), (wl.dh, 144)))
     mlp = m.renderModule.mlp
-    W1, W2, W3, Bas_ref = (f64(t.detach()) for t in (mlp[0].weight, mlp[2].weight, mlp[4].weight, m.basis_mat.weight))
+    W1r, W2r, W3r, Bas_ref = (f64(t.detach()) for t in (mlp[0].weight, mlp[2].weight, mlp[4].weight, m.basis_mat.weight))
+    n_in = 30 + 54 * fpe + 6 * vpe
+    assert W1r.shape == (fc, n_in) and W2r.shape == (fc, fc) and W3r.shape == (3, fc)
+    # the network at the kernels' width: units that do not exist are zero rows / columns (their activations and gradients must come out as exact zeros)
+    W1, W2, W3 = (torch.zeros(sh, dtype=torch.float64, device="cuda") for sh in ((128, n_in), (128, 128), (3, 128)))
+    W1[:fc], W2[:fc, :fc], W3[:, :fc] = W1r, W2r, W3r
+    if fc < 128:
+        assert float(h1[:, fc:].abs().max()) == 0.0 and float(h2[:, fc:].abs().max()) == 0.0 and float(dh1[:, fc:].abs().max()) == 0.0 and float(dh2[:, fc:].abs().max()) == 0.0
     # basis_mat in the kernels' channel order: plane p's components at columns 48 p .. (zero columns behind them: the packed scene's zero channels)
     bcols = torch.cat([torch.arange(48 * p, 48 * p + c) for p, c in enumerate(ac)]).cuda()
     assert Bas_ref.shape == (27, sum(ac))
@@ -266,8 +274,6 @@ def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_
     pad = torch.ones(144, dtype=torch.bool, device="cuda")
     pad[bcols] = False
     assert float(h[:, pad].abs().max()) == 0.0 if bool(pad.any()) else True
-    n_in = 30 + 54 * fpe + 6 * vpe
-    assert W1.shape == (128, n_in)
     q_ray = B["scratch"][sl.q_ray:sl.q_ray + 4 * cnt].view(torch.int32).long()
     dirs = f64(rays[q_ray, 3:6])
 
@@ -287,7 +293,8 @@ def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_
         return torch.cat([torch.sin(pts), torch.cos(pts)], dim=1)
     X = torch.cat([F, dirs, pe(F, fpe), pe(dirs, vpe)], dim=1)
     assert X.shape[1] == n_in
-    if wl.x_blocks == 1 and wl.x_block_cols == 150:
+    if wl.x_block_cols == 150:
+        assert wl.x_blocks == 1 and (vpe, fpe, fc) == (2, 2, 128)
         Xk = f64(mat(wl.X, 150))
     else:
         assert wl.x_block_cols == 152 and wl.x_blocks == (n_in + 151) // 152
@@ -303,7 +310,7 @@ def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_
     # dX and the gradient through the positional encoding
     dX = dh1 @ W1
     dF = dX[:, :27].clone()
-    for f in range(fpe):
+    for f in range(fpe):                                                                     # (fea_pe = 0: the features enter layer 1 plainly only)
         si, ci = 30 + torch.arange(27, device="cuda") * fpe + f, 30 + 27 * fpe + torch.arange(27, device="cuda") * fpe + f
         dF += (2.0 ** f) * (torch.cos(F * 2.0 ** f) * dX[:, si] - torch.sin(F * 2.0 ** f) * dX[:, ci])
     close(dfe[:, :27], dF, "dF")
@@ -311,12 +318,12 @@ def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_
     close(dh, dF @ Bas, "dh")
     # the weight gradients the step returned
     g = lambda p: f64(p.grad)
-    close(g(mlp[4].weight), d_out[:, :3].t() @ h2, "dW3")
+    close(g(mlp[4].weight), (d_out[:, :3].t() @ h2)[:, :fc], "dW3")
     close(g(mlp[4].bias), d_out[:, :3].sum(0), "db3")
-    close(g(mlp[2].weight), dh2.t() @ h1, "dW2")
-    close(g(mlp[2].bias), dh2.sum(0), "db2")
-    close(g(mlp[0].weight), dh1.t() @ Xk, "dW1")
-    close(g(mlp[0].bias), dh1.sum(0), "db1")
+    close(g(mlp[2].weight), (dh2.t() @ h1)[:fc, :fc], "dW2")
+    close(g(mlp[2].bias), dh2.sum(0)[:fc], "db2")
+    close(g(mlp[0].weight), (dh1.t() @ Xk)[:fc], "dW1")
+    close(g(mlp[0].bias), dh1.sum(0)[:fc], "db1")
     close(g(m.basis_mat.weight), (dfe[:, :27].t() @ h)[:, bcols], "dBasis")
 
 

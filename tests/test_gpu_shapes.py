@@ -61,11 +61,12 @@ def test_zero_padded_shapes_render_like_the_oracle(tiny_dump, hyper_tiny, dc, ac
 
 
 @pytest.mark.parametrize("dc,ac,fc,vpe,fpe,hip_mm", [SHAPES[0] + (False,), SHAPES[1] + (False,), SHAPES[5] + (False,), SHAPES[5] + (True,), SHAPES[6] + (True,),
-                                                     SHAPES[6] + (None,), SHAPES[8] + (None,), SHAPES[0] + (None,), SHAPES[5] + (None,)])
+                                                     SHAPES[6] + (None,), SHAPES[8] + (None,), SHAPES[0] + (None,), SHAPES[5] + (None,),
+                                                     SHAPES[1] + (None,), SHAPES[2] + (None,), SHAPES[3] + (None,), SHAPES[4] + (None,), SHAPES[7] + (None,)])
 def test_zero_padded_shapes_train(tiny_dump, hyper_tiny, monkeypatch, dc, ac, fc, vpe, fpe, hip_mm):
     """Gradients of every parameter tensor at its own (unpadded) shape against autograd through the oracle.  hip_mm: the eager chain's Linears forced onto the HIP
     kernels whatever the batch size (round 5: what a 4096-ray training batch of a six-frequency scene with fewer than 48 components runs — tvr_linear_dx forward and dX,
-    tvr_gemm_tn dW; no library GEMM, scripts/pe6_train_trace.sh).  hip_mm None (round 6): width 128, up to 16 / 48 components and 2 / 2 or 3..6 frequencies — TensorBase's exact defaults 8 / 24 with 6 / 6 among them — go through the FUSED step
+    tvr_gemm_tn dW; no library GEMM, scripts/pe6_train_trace.sh).  hip_mm None (round 6): EVERY shape of the list — TensorBase's exact defaults 8 / 24 with 6 / 6, ragged components, widths 1 / 64 / 96, 0 .. 6 frequencies — goes through the FUSED step
     (tvr_train_forward / tvr_train_backward: lockstep layer 1, streamed W1^T backward, dW1 in column blocks) — asserted; True / False: the eager chain."""
     from oracle import tensorf_oracle as TO
     from test_gpu_training import _oracle_with_grads
