@@ -452,6 +452,8 @@ def main():
     ap.add_argument("--arith", choices=["f32", "f16act", "f16"], default="f32",
                     help="arithmetic of the appearance network's matrix products (tvr_scene_set_arith): f32 = three fp16 products per fp32 product, fp32-class — the headline; "
                          "f16act / f16 = the opt-in reduced modes (two / one product).  The default run reports all three under `arith_modes`")
+    ap.add_argument("--two-shares-in-flight", action="store_true", help="split frames: two shares in flight on two render streams (ShardedFramePipeline(two_in_flight=True), round 6: "
+                                                                       "-3 % in the local emulation, not reproducible through RCCL's own stream — off by default, render.py)")
     ap.add_argument("--pieces", type=int, default=None, help="rays per piece of a tvr_render call rendered in pieces on two library-owned streams (include/tvr.h, PIECES): "
                                                               "default = the library's (30 720); 0 = one launch set per call, as before round 6")
     ap.add_argument("--chunk-stream", action="store_true", help="with --chunk: the chunk calls go through render.FrameStream (two calls in flight on two streams) "
@@ -573,7 +575,7 @@ def main():
     pipe = None
     if use_pipe:
         pipe = ShardedFramePipeline(model, R_step, rank if dist_on else 0, world if dist_on else split, tile=TILE, white_bg=True, N_samples=S, eps_T=args.eps_T,
-                                    exchange=("dist" if dist_on else (None if args.no_overlap_exchange else "local")), graph=args.graph)
+                                    exchange=("dist" if dist_on else (None if args.no_overlap_exchange else "local")), graph=args.graph, two_in_flight=args.two_shares_in_flight)
 
         def pipe_step(s):
             return pipe.submit(s % n_patterns, step_rays[s % n_patterns])
@@ -858,7 +860,7 @@ def main():
         "roofline_all": {"march": roof_march, "shade": roof_shade},
     }
     if pipe is not None:
-        result["split_step"] = {"pipeline": "ShardedFramePipeline", "hipgraph": pipe.use_graph, "exchange": pipe.exchange,
+        result["split_step"] = {"pipeline": "ShardedFramePipeline", "hipgraph": pipe.use_graph, "exchange": pipe.exchange, "two_shares_in_flight": bool(pipe.two),
                                 "note": "the exchange of frame k (all_gather + un-permute; 'local' = its device-side half at N-way sizes, one process) runs on a side stream "
                                         "behind frame k + 1's kernels; hipgraph: the per-rank render replayed as one graph per pose"}
     if dist_on:

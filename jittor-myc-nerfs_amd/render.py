@@ -230,7 +230,7 @@ class ShardedFramePipeline:
     at N-way sizes, scripts/strong_emulation.py) or None (render only)."""
 
     def __init__(self, model, n_rays: int, rank: int, world: int, tile: int = SHARD_TILE, white_bg: bool = True, N_samples: int = -1, eps_T=None,
-                 group=None, exchange: Optional[str] = "dist", graph: bool = False):
+                 group=None, exchange: Optional[str] = "dist", graph: bool = False, two_in_flight: bool = False):
         import torch.distributed as dist
         self.model, self.R, self.rank, self.world, self.tile = model, int(n_rays), rank, world, tile
         self.white_bg, self.S, self.eps_T, self.group, self.exchange, self.use_graph = white_bg, N_samples, eps_T, group, exchange, graph
@@ -240,6 +240,16 @@ class ShardedFramePipeline:
         self.mine = [torch.zeros((4 * self.cap,), device=self.dev) for _ in range(2)]
         self.gathered = [torch.empty((world * 4 * self.cap,), device=self.dev) for _ in range(2)] if exchange else [None, None]
         self.views = [shard_send_views(m, self.cap, self.n_mine) for m in self.mine]
+        # Round 6, OPTIONAL (`two_in_flight=True`, bench.py --two-shares-in-flight): frame k is rendered on render stream k % 2 into scratch slot k % 2, so the march of frame
+        # k + 1 runs beside the shade kernel of frame k and fills what its drain leaves (FrameStream's mechanism across the frames of the split stream: an 80 000-ray share is too
+        # small for pieces INSIDE a call to settle, include/tvr.h PIECES, but a stream of such shares never drains).  Measured (profiles/r06_share_in_flight_ab.txt): with the
+        # device-side exchange emulated locally — four streams on HIP's four hardware queues — the 8-way share takes 2.51 ms instead of 2.59 (-3.3 %; 4-way -3.2 %, 2-way +-0),
+        # i.e. t1 / (8 t8) = 0.95 - 0.956; through a ONE-member RCCL group — five streams: RCCL brings its own — 2.40 / 2.50 / 2.56 ms in three processes against a steady
+        # 2.455 - 2.461 (which two streams share a queue differs from process to process), and 2.47 against 2.43 with GPU_MAX_HW_QUEUES=8.  Not reproducible where it matters
+        # and not measurable on eight cards here: OFF by default.  Never under `graph` (a captured render belongs to one stream) or off the GPU.
+        self.two = bool(two_in_flight) and not graph and str(self.dev).startswith("cuda") and bool(getattr(model, "render_rays_is_the_frame", False))
+        self.rstreams = [torch.cuda.Stream(self.dev) for _ in range(2)] if self.two else None
+        self._drain_next = False
         self.side = torch.cuda.Stream(self.dev) if exchange else None
         self.rendered = [torch.cuda.Event() for _ in range(2)]       # frame in buffer b is rendered (compute stream -> side stream)
         self.exchanged = [torch.cuda.Event() for _ in range(2)]      # buffer b's exchange has finished (side stream -> compute stream)
@@ -256,7 +266,10 @@ class ShardedFramePipeline:
         self._gloo = bool(exchange == "dist" and dist.is_initialized() and dist.get_backend(group) == "gloo")
 
     def _render(self, sub, b):
-        self.model.render_rays(sub, white_bg=self.white_bg, N_samples=self.S, eps_T=self.eps_T, out=self.views[b])
+        if self.two:
+            self.model.render_rays(sub, white_bg=self.white_bg, N_samples=self.S, eps_T=self.eps_T, out=self.views[b], scratch_slot=b)
+        else:
+            self.model.render_rays(sub, white_bg=self.white_bg, N_samples=self.S, eps_T=self.eps_T, out=self.views[b])
 
     def _replay(self, key, sub, b):
         if not self.use_graph or self.n_mine == 0:
@@ -315,13 +328,33 @@ class ShardedFramePipeline:
         reads that storage).  Returns the (rgb [R,3], depth [R]) of the frame submitted one call earlier, or None."""
         b = self.k % 2
         cur = torch.cuda.current_stream(self.dev)
-        if self.busy[b] and self._waited != (b, cur.cuda_stream):     # (the previous submit already made this stream wait for that very event: one barrier packet less per frame)
-            cur.wait_event(self.exchanged[b])                         # the exchange that last read this send buffer is done before it is rendered into again
-        self._waited = None
-        self._replay(key, sub_rays, b)
+        rs = cur
+        if self.two:
+            # (as FrameStream: a call that re-packs the scene, converts fp16 copies or runs the arithmetic gate's probes must not overlap a frame that reads the packed images)
+            settled = bool(getattr(self.model, "scene_settled", lambda: False)())
+            if not settled or self._drain_next:
+                cur.wait_stream(self.rstreams[0])
+                cur.wait_stream(self.rstreams[1])
+            self._drain_next = not settled
+            rs = self.rstreams[b]
+            rs.wait_stream(cur)                                       # the rays are ready; and (through the caller's stream) the frame handed out by the previous submit
+            if self.busy[b]:
+                rs.wait_event(self.exchanged[b] if self.exchange else self.rendered[b])
+            with torch.cuda.stream(rs):
+                self._replay(key, sub_rays, b)
+                self.rendered[b].record(rs)
+            # (the exchange stays on the side stream: riding on the frame's own render stream — one stream fewer — it delays that stream's next frame; measured +4 % through a
+            #  one-member RCCL group and -0.8 % instead of -3.3 % in the local emulation, profiles/r06_share_in_flight_ab.txt)
+            self._waited = None
+        else:
+            if self.busy[b] and self._waited != (b, cur.cuda_stream):     # (the previous submit already made this stream wait for that very event: one barrier packet less per frame)
+                cur.wait_event(self.exchanged[b])                         # the exchange that last read this send buffer is done before it is rendered into again
+            self._waited = None
+            self._replay(key, sub_rays, b)
         prev = None
         if self.exchange:
-            self.rendered[b].record(cur)
+            if not self.two:
+                self.rendered[b].record(cur)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.rendered[b])
                 self._exchange(b)
@@ -333,6 +366,10 @@ class ShardedFramePipeline:
                 prev = self.out[pb]
                 self._waited = (pb, cur.cuda_stream)
         else:
+            if self.two:
+                self.busy[b] = True
+                if self.k > 0:
+                    cur.wait_event(self.rendered[1 - b])
             prev = (self.views[1 - b][0], self.views[1 - b][1]) if self.k > 0 else None
         self.k += 1
         return prev
@@ -343,6 +380,12 @@ class ShardedFramePipeline:
             return None
         b = (self.k - 1) % 2
         if not self.exchange:
+            if self.two:
+                torch.cuda.current_stream(self.dev).wait_event(self.rendered[b])
+                if self.k > 1:
+                    torch.cuda.current_stream(self.dev).wait_event(self.rendered[1 - b])
             return self.views[b][0], self.views[b][1]
         torch.cuda.current_stream(self.dev).wait_event(self.exchanged[b])
+        if self.two and self.k > 1:
+            torch.cuda.current_stream(self.dev).wait_event(self.exchanged[1 - b])
         return self.out[b]

@@ -210,8 +210,10 @@ def _rccl_worker(port, arrs, hyper, rays_np, q):
     from jittor_myc_nerfs_amd import ShardedFramePipeline, shard_indices
     sets = [rays, rays.flip(0).contiguous(), torch.roll(rays, 7, 0).contiguous()]
     plain = [m.render_rays(r, white_bg=True, N_samples=TINY["N_samples"]) for r in sets]
-    for graph in (False, True):
-        pipe = ShardedFramePipeline(m, rays.shape[0], 0, 1, tile=16, white_bg=True, N_samples=TINY["N_samples"], exchange="dist", graph=graph)
+    # (round 6: optionally two shares in flight on two render streams with their own scratch slots; the default is the one-stream form)
+    for graph, two in ((False, True), (False, False), (True, False)):
+        pipe = ShardedFramePipeline(m, rays.shape[0], 0, 1, tile=16, white_bg=True, N_samples=TINY["N_samples"], exchange="dist", graph=graph, two_in_flight=two)
+        assert pipe.two == two
         subs = [r.index_select(0, shard_indices(r.shape[0], 0, 1, 16).cuda()).contiguous() for r in sets]
         ok, got = True, []
         for i in range(7):                                 # more frames than buffers: both send buffers come round several times
@@ -225,7 +227,7 @@ def _rccl_worker(port, arrs, hyper, rays_np, q):
         torch.cuda.synchronize()
         for i, rgb_i, depth_i in got:
             ok = ok and bool(torch.equal(rgb_i, plain[i % 3][0]) and torch.equal(depth_i, plain[i % 3][1]))
-        out["pipeline_graph" if graph else "pipeline"] = ok
+        out["pipeline_graph" if graph else ("pipeline" if two else "pipeline_one_in_flight")] = ok
     # the training side's one collective: the flat gradient bucket through an RCCL all_reduce (a one-member SUM returns its input)
     b = GradBucket(m)
     b.flat.copy_(torch.arange(b.numel, device="cuda", dtype=torch.float32) % 97)
@@ -254,7 +256,7 @@ def test_render_sharded_over_rccl_with_one_rank(tiny_arrays, hyper_tiny, tiny_du
     p.join(120)
     assert p.exitcode == 0
     assert out["backend"] == "nccl" and out[16] and out[4096] and out["bucket"], out
-    assert out["pipeline"] and out["pipeline_graph"], out
+    assert out["pipeline"] and out["pipeline_one_in_flight"] and out["pipeline_graph"], out
 
 
 @pytest.mark.gpu
