@@ -27,6 +27,7 @@ ap.add_argument("--views", type=int, default=100)
 ap.add_argument("--img", type=int, default=800)
 ap.add_argument("--model", default="TensorVMSplit", choices=["TensorVMSplit", "REFTensoRF"])
 ap.add_argument("--teacher", default="TensorVMSplit", choices=["TensorVMSplit", "REFTensoRF"], help="the model that renders the synthetic training set")
+ap.add_argument("--pe", type=int, default=2, help="view_pe = fea_pe of the model that is trained (6: opt.py's and TensorBase.__init__'s own default, 390 MLP inputs — the fused step since round 6)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 t_all = time.perf_counter()
@@ -60,7 +61,7 @@ del frames, rgbs
 tmp = tempfile.mkdtemp(prefix="recon_")
 cmd = ["--dataset_name", "blender", "--expname", "timing", "--basedir", tmp, "--n_iters", str(a.iters), "--batch_size", "4096",
        "--N_voxel_init", str(128 ** 3), "--N_voxel_final", str(300 ** 3), "--N_vis", "0", "--vis_every", "100000", "--progress_refresh_rate", "10",
-       "--model_name", a.model, "--shadingMode", "MLP_Fea", "--fea2denseAct", "softplus", "--view_pe", "2", "--fea_pe", "2",
+       "--model_name", a.model, "--shadingMode", "MLP_Fea", "--fea2denseAct", "softplus", "--view_pe", str(a.pe), "--fea_pe", str(a.pe),
        "--white_bkgd"]
 if a.model == "REFTensoRF":        # configs/Scar.txt: no L1 term, TV 2, the normal penalty 0.5, a 400 000-iteration decay (the first --iters of them are run)
     cmd += ["--TV_weight_density", "2.0", "--TV_weight_app", "2.0", "--rm_weight_mask_thre", "1e-6", "--normal_vector_penalty_weight", "0.5", "--lr_decay_iters", "400000"]
