@@ -783,18 +783,21 @@ hipError_t launch_pe_concat_strided(const float *feat, int fs, const float *dir,
 // contiguous [m_cap, w_b] matrix at X + b * m_cap * TVR_GENX_W (w_b = the block's columns rounded up to 4, zero-filled): each block is then one tvr_gemm_tn product in its
 // fastest staging mode (contiguous 16-B rows, <= 5 column tiles with the bias column).  sin / cos exactly as the forward kernel's lockstep layer 1 takes them
 // (tvr_shade.hip gen_frag): the hardware units on the once-reduced argument times 2^f.
+// (PEG_TILE entries per workgroup: 8 — one entry x base value per thread in ONE round, 14.6 KB of LDS, ten workgroups per CU; with the 2 / 2 kernel's 32 entries, 50 KB and four
+//  rounds of dependent loads per thread the kernel took 0.27 - 0.30 ms per step for the 0.11 ms its 550 MB of stores need)
+#define PEG_TILE 8
 __global__ __launch_bounds__(256) void pe_concat_gen_kernel(const PeSrc p, const long long m_cap, const int fea_pe, const int view_pe, float *__restrict__ X)
 {
-    extern __shared__ __attribute__((aligned(16))) float gtile[];            // [block][PE_TILE rows][w_b]
+    extern __shared__ __attribute__((aligned(16))) float gtile[];            // [block][PEG_TILE rows][w_b]
     const long long m = p.m_dev ? ((long long)*p.m_dev < m_cap ? (long long)*p.m_dev : m_cap) : m_cap;
-    const long long e0 = (long long)blockIdx.x * PE_TILE;
+    const long long e0 = (long long)blockIdx.x * PEG_TILE;
     if (e0 >= m) return;
-    const int rows = (int)(m - e0 < PE_TILE ? m - e0 : PE_TILE);
+    const int rows = (int)(m - e0 < PEG_TILE ? m - e0 : PEG_TILE);
     const int nin = TVR_APPDIM + 3 + 2 * TVR_APPDIM * fea_pe + 6 * view_pe, nb = (nin + TVR_GENX_W - 1) / TVR_GENX_W;
     const int wl = ((nin - (nb - 1) * TVR_GENX_W) + 3) & ~3;                  // width of the last block
     // (every real column of a row is written below; only the last block's zero columns need a value — clearing the whole 50 KB tile first cost as much as filling it)
     const int npad = wl - (nin - (nb - 1) * TVR_GENX_W);
-    for (int i = threadIdx.x; i < PE_TILE * npad; i += 256) gtile[(nb - 1) * PE_TILE * TVR_GENX_W + (i / npad) * wl + (wl - npad) + (i % npad)] = 0.0f;
+    for (int i = threadIdx.x; i < PEG_TILE * npad; i += 256) gtile[(nb - 1) * PEG_TILE * TVR_GENX_W + (i / npad) * wl + (wl - npad) + (i % npad)] = 0.0f;
     for (int it = threadIdx.x; it < rows * 30; it += 256) {
         const int r = it / 30, c = it - r * 30;
         const long long ent = e0 + r;
@@ -810,14 +813,14 @@ __global__ __launch_bounds__(256) void pe_concat_gen_kernel(const PeSrc p, const
             const int f = t == 0 ? 0 : (t <= TVR_GEN_PE ? t - 1 : t - 1 - TVR_GEN_PE);
             const float val = t == 0 ? v : (t <= TVR_GEN_PE ? __builtin_amdgcn_sinf(tr * (float)(1 << f)) : __builtin_amdgcn_cosf(tr * (float)(1 << f)));
             const int b = idx / TVR_GENX_W, col = idx - b * TVR_GENX_W, wb = b == nb - 1 ? wl : TVR_GENX_W;
-            gtile[b * PE_TILE * TVR_GENX_W + r * wb + col] = val;
+            gtile[b * PEG_TILE * TVR_GENX_W + r * wb + col] = val;
         }
     }
     __syncthreads();
     for (int b = 0; b < nb; ++b) {
         const int wb = b == nb - 1 ? wl : TVR_GENX_W;
         float4 *__restrict__ dst = (float4 *)(X + (size_t)b * (size_t)m_cap * TVR_GENX_W + (size_t)e0 * wb);       // 16-B aligned: m_cap * 152 * 4 and 32 * wb * 4 are multiples of 16
-        const float4 *src = (const float4 *)(gtile + b * PE_TILE * TVR_GENX_W);
+        const float4 *src = (const float4 *)(gtile + b * PEG_TILE * TVR_GENX_W);
         for (int i = threadIdx.x; i < rows * wb / 4; i += 256) dst[i] = src[i];
     }
 }
@@ -827,8 +830,8 @@ hipError_t launch_pe_concat_gen(const float *feat, int fs, const float *rays, co
 {
     PeSrc p = {feat, nullptr, nullptr, rays, q_ray, m_dev, fs, 0, 0};
     const int nin = TVR_APPDIM + 3 + 2 * TVR_APPDIM * fea_pe + 6 * view_pe, nb = (nin + TVR_GENX_W - 1) / TVR_GENX_W;
-    const int lds = PE_TILE * nb * TVR_GENX_W * (int)sizeof(float);          // <= 58 368 B
-    hipLaunchKernelGGL(pe_concat_gen_kernel, dim3((unsigned)((m_cap + PE_TILE - 1) / PE_TILE)), dim3(256), lds, stream, p, m_cap, fea_pe, view_pe, X);
+    const int lds = PEG_TILE * nb * TVR_GENX_W * (int)sizeof(float);          // <= 14 592 B
+    hipLaunchKernelGGL(pe_concat_gen_kernel, dim3((unsigned)((m_cap + PEG_TILE - 1) / PEG_TILE)), dim3(256), lds, stream, p, m_cap, fea_pe, view_pe, X);
     return hipGetLastError();
 }
 
