@@ -416,7 +416,8 @@ int tvr_tv_loss(const float *x, int32_t C, int32_t H, int32_t W, float weight, f
  *   tvr_l1_mean:    value[0] = sum_t mean |xs[t]|                         TensorVMSplit.density_L1, tensoRF.py:190-194 (3 planes + 3 lines)
  *   tvr_line_ortho: value[0] = sum_t mean |offdiag(V_t V_t^T)|, V_t = vs[t] as (n_comp[t], n_size[t]), 2..48 components
  *                                                                          TensorVMSplit.vector_comp_diffs / vectorDiffs, tensoRF.py:178-188
- * scratch: tvr_l1_mean_scratch_bytes(counts, n) / 32 bytes. */
+ * scratch: tvr_l1_mean_scratch_bytes(counts, n) / TVR_LINE_ORTHO_SCRATCH_BYTES (256 since version 141: eight workgroups per line factor, one partial sum each; 32 before). */
+#define TVR_LINE_ORTHO_SCRATCH_BYTES 256
 size_t tvr_l1_mean_scratch_bytes(const int64_t *counts, int32_t n);
 int tvr_l1_mean(const float *const *xs, const int64_t *counts, int32_t n, float *value, void *scratch, size_t scratch_bytes, void *stream);
 int tvr_l1_mean_backward(const float *const *xs, float *const *grads, const int64_t *counts, int32_t n, const float *grad_value, void *stream);

@@ -1250,7 +1250,7 @@ int tvr_line_ortho(const float *const *vs, const int32_t *n_comp, const int32_t 
     int rc = ortho_list(L, vs, nullptr, n_comp, n_size, n, false);
     if (rc != TVR_OK) return rc;
     if (!value) return fail(TVR_ERR_INVALID, "value NULL");
-    if (!scratch || scratch_bytes < TVR_REG_MAX * sizeof(float)) return fail(TVR_ERR_SCRATCH, "tvr_line_ortho needs %d bytes of scratch", (int)(TVR_REG_MAX * sizeof(float)));
+    if (!scratch || scratch_bytes < TVR_LINE_ORTHO_SCRATCH_BYTES) return fail(TVR_ERR_SCRATCH, "tvr_line_ortho needs %d bytes of scratch", (int)TVR_LINE_ORTHO_SCRATCH_BYTES);
     HIP_TRY(launch_ortho(L, nullptr, value, (float *)scratch, (hipStream_t)stream));
     return TVR_OK;
 }

@@ -56,7 +56,7 @@ class _LineOrthoFn(torch.autograd.Function):
         nc = (C.c_int32 * len(xs))(*[x.shape[1] for x in xs])
         ns = (C.c_int32 * len(xs))(*[x.numel() // x.shape[1] for x in xs])
         value = torch.empty(1, dtype=torch.float32, device=dev)
-        scratch = L.dev_bytes(32, dev, what="tvr_line_ortho scratch")
+        scratch = L.dev_bytes(256, dev, what="tvr_line_ortho scratch")        # TVR_LINE_ORTHO_SCRATCH_BYTES
         L.check(L.lib().tvr_line_ortho(_ptr_array(xs), nc, ns, len(xs), value.data_ptr(), scratch.data_ptr(), scratch.numel(),
                                        torch.cuda.current_stream(dev).cuda_stream), "tvr_line_ortho")
         ctx.save_for_backward(*xs)
