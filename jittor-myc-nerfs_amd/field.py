@@ -377,6 +377,51 @@ class TensorBase(torch.nn.Module):
     # streams, joined back into the caller's stream); 0 = one launch set per call, as before round 6; else the piece size in rays
     render_piece_rays = None
 
+    def autotune_render_pieces(self, ray_sets, white_bg=True, N_samples=-1, eps_T=None, blocks: int = 2, frames_per_block: int = 8):
+        """Decide ON THIS CARD whether calls of this size go out in pieces.  Whether a frame in pieces beats one launch set depends on the card: over nine boxes of the
+        build pool the difference was -4.6 ... +0.6 % (the chip's power management decides how much a march kernel beside a shade kernel is worth).  Renders
+        `blocks` blocks of `frames_per_block` frames in each form, alternating (pieces, one launch set, pieces, ...), timed by events on the current stream, keeps the faster
+        form in `render_piece_rays` and returns what it measured.  `ray_sets`: one [n,6] tensor or a list of them (poses are cycled).  Calls too small for pieces
+        (include/tvr.h: fewer than six pieces' worth of rays) return None and change nothing.  Pixels do not depend on the choice (bit for bit)."""
+        sets = [ray_sets] if torch.is_tensor(ray_sets) else list(ray_sets)
+        sets = [_f32c(r, self.device) for r in sets]
+        if self.render_piece_rays not in (None, 0):
+            return None                                           # the caller fixed a piece size
+        default_piece = 30720                                     # csrc/tvr_api.hip TVR_DEFAULT_PIECE_RAYS
+        if sets[0].shape[0] < 6 * default_piece or not str(self.device).startswith("cuda"):
+            return None
+        keep = self.render_piece_rays
+        ms = {None: 0.0, 0: 0.0}
+        k = 0
+        try:
+            for mode in (None, 0):                                # one untimed frame each: scratch, packed scene, the side streams exist
+                self.render_piece_rays = mode
+                self.render_rays(sets[0], white_bg=white_bg, N_samples=N_samples, eps_T=eps_T)
+            # every block is enqueued back to back and the host waits ONCE at the end: a wait between blocks lets the chip's clocks recover, and a frame rendered after a
+            # pause is 2 - 3 % faster than the same frame in a sustained stream (measured: 19.0 ms per frame in 4-frame blocks with a wait each, 19.5 in the stream that followed)
+            marks = []
+            for _ in range(blocks):
+                for mode in (None, 0):
+                    self.render_piece_rays = mode
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record()
+                    for _f in range(frames_per_block):
+                        self.render_rays(sets[k % len(sets)], white_bg=white_bg, N_samples=N_samples, eps_T=eps_T)
+                        k += 1
+                    t1.record()
+                    marks.append((mode, t0, t1))
+            marks[-1][2].synchronize()
+            for mode, t0, t1 in marks:
+                ms[mode] += t0.elapsed_time(t1)
+        except Exception:
+            self.render_piece_rays = keep
+            raise
+        n = blocks * frames_per_block
+        res = {"ms_per_frame_in_pieces": ms[None] / n, "ms_per_frame_one_launch_set": ms[0] / n, "frames_each": n}
+        self.render_piece_rays = None if ms[None] <= ms[0] else 0
+        res["chosen"] = "pieces" if self.render_piece_rays is None else "one launch set"
+        return res
+
     mlp_arith_tol = 2.5e-4
     arith_probe_rays = 8192
     arith_in_effect = "f32"

@@ -522,6 +522,30 @@ def test_frame_stream_two_in_flight(config1_golden):
         assert torch.equal(a, c) and torch.equal(b, d)
 
 
+def test_autotune_of_the_pieces_changes_no_pixel(config1_golden):
+    """field.autotune_render_pieces decides pieces / one launch set on the card (the gain is -4.6 ... +0.6 % by box): it must leave `render_piece_rays` at one of the two
+    forms, report both timings, change no pixel, and leave small calls and a caller-fixed piece size alone."""
+    from jittor_myc_nerfs_amd import synthetic
+    B = synthetic.SCENE_B
+    arrs = synthetic.make_scene_arrays(B["gridSize"], B["aabb"])
+    m = make_model(arrs, dict(synthetic.HYPER, near_far=B["near_far"], step_ratio=B["step_ratio"]))
+    base = torch.tensor(config1_golden["rays"], device="cuda")                      # 4096 rays
+    S = B["N_samples"]
+    assert m.autotune_render_pieces(base, N_samples=S) is None and m.render_piece_rays is None          # too small for pieces: nothing measured, nothing changed
+    big = base.repeat(46, 1).contiguous()                                           # 188 416 rays: six pieces' worth
+    m.render_piece_rays = 0
+    want = [t.clone() for t in m.render_rays(big, white_bg=True, N_samples=S)]
+    m.render_piece_rays = 4096
+    assert m.autotune_render_pieces(big, N_samples=S) is None and m.render_piece_rays == 4096           # a piece size the caller fixed stays
+    m.render_piece_rays = None
+    res = m.autotune_render_pieces([big, big.flip(0).contiguous()], N_samples=S, blocks=1, frames_per_block=2)
+    assert res["chosen"] in ("pieces", "one launch set") and res["frames_each"] == 2
+    assert res["ms_per_frame_in_pieces"] > 0 and res["ms_per_frame_one_launch_set"] > 0
+    assert m.render_piece_rays == (None if res["chosen"] == "pieces" else 0)
+    got = m.render_rays(big, white_bg=True, N_samples=S)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
 def test_render_in_pieces_equals_one_launch_set(config1_golden):
     """Round 6 (include/tvr.h, PIECES): a tvr_render call of at least two pieces' worth of rays goes out as pieces of consecutive rays on two library-owned streams, forked from
     and joined into the caller's stream.  A ray's result does not depend on the batch it arrives in, so pixels, depths and counters equal the one-launch-set call BIT FOR BIT
