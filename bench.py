@@ -452,7 +452,7 @@ def main():
     ap.add_argument("--arith", choices=["f32", "f16act", "f16"], default="f32",
                     help="arithmetic of the appearance network's matrix products (tvr_scene_set_arith): f32 = three fp16 products per fp32 product, fp32-class — the headline; "
                          "f16act / f16 = the opt-in reduced modes (two / one product).  The default run reports all three under `arith_modes`")
-    ap.add_argument("--no-autotune", action="store_true", help="do not decide pieces / one launch set on this card in the warm-up (model.autotune_render_pieces): the library's default (pieces) stays")
+    ap.add_argument("--autotune", action="store_true", help="decide pieces / one launch set on this card in the warm-up (model.autotune_render_pieces) instead of the library's default (pieces)")
     ap.add_argument("--two-shares-in-flight", action="store_true", help="split frames: two shares in flight on two render streams (ShardedFramePipeline(two_in_flight=True), round 6: "
                                                                        "-3 % in the local emulation, not reproducible through RCCL's own stream — off by default, render.py)")
     ap.add_argument("--pieces", type=int, default=None, help="rays per piece of a tvr_render call rendered in pieces on two library-owned streams (include/tvr.h, PIECES): "
@@ -588,10 +588,12 @@ def main():
     L.check(L.lib().tvr_profile_create(max(args.warmup, 1), C.byref(prof_w)), "tvr_profile_create")
     for s in range(args.warmup):
         step(s, profile=prof_w if prof_in_region else None)
-    # Round 6: whether a frame in pieces beats one launch set depends on the card (-4.6 ... +0.6 % over nine boxes): the library's user decides it ON the card,
-    # once, outside the timed region (model.autotune_render_pieces: 2 x 4 frames in each form, alternating) — unless --pieces fixed it.  Pixels do not depend on the choice.
+    # Round 6, opt-in (--autotune): whether a frame in pieces beats one launch set depends on the card and on how long it has been under load: a library user
+    # can decide it ON the card (model.autotune_render_pieces: 2 x 8 frames in each form, alternating).  NOT the default of this bench: the chip slows down under sustained load
+    # (one launch set: 18.7 -> 19.25 ms per frame within the first second on one box; pieces: flat), so a decision taken in the first second can be the wrong one for the
+    # stream that follows, and its 34 extra frames push the timed region itself into the slower regime (19.50 - 19.55 ms against 19.29 - 19.40 for the same form without them).
     pieces_autotune = None
-    if args.pieces is None and split == 1 and args.chunk == 0 and not dist_on and hasattr(model, "autotune_render_pieces") and not args.no_autotune:
+    if args.autotune and args.pieces is None and split == 1 and args.chunk == 0 and not dist_on and hasattr(model, "autotune_render_pieces"):
         pieces_autotune = model.autotune_render_pieces(step_rays, white_bg=True, N_samples=S, eps_T=args.eps_T)
         for s in range(min(args.warmup, 2)):                        # (and the chosen form is warm again)
             step(s)
@@ -868,7 +870,7 @@ def main():
         "roofline_all": {"march": roof_march, "shade": roof_shade},
     }
     if pieces_autotune is not None:
-        result["config"]["pieces_autotune"] = dict(pieces_autotune, note="decided on this card in the warm-up (model.autotune_render_pieces); --pieces N fixes it, --no-autotune keeps the library's default")
+        result["config"]["pieces_autotune"] = dict(pieces_autotune, note="--autotune: decided on this card in the warm-up (model.autotune_render_pieces)")
     if pipe is not None:
         result["split_step"] = {"pipeline": "ShardedFramePipeline", "hipgraph": pipe.use_graph, "exchange": pipe.exchange, "two_shares_in_flight": bool(pipe.two),
                                 "note": "the exchange of frame k (all_gather + un-permute; 'local' = its device-side half at N-way sizes, one process) runs on a side stream "

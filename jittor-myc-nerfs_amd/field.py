@@ -382,7 +382,9 @@ class TensorBase(torch.nn.Module):
         build pool the difference was -4.6 ... +0.6 % (the chip's power management decides how much a march kernel beside a shade kernel is worth).  Renders
         `blocks` blocks of `frames_per_block` frames in each form, alternating (pieces, one launch set, pieces, ...), timed by events on the current stream, keeps the faster
         form in `render_piece_rays` and returns what it measured.  `ray_sets`: one [n,6] tensor or a list of them (poses are cycled).  Calls too small for pieces
-        (include/tvr.h: fewer than six pieces' worth of rays) return None and change nothing.  Pixels do not depend on the choice (bit for bit)."""
+        (include/tvr.h: fewer than six pieces' worth of rays) return None and change nothing.  Pixels do not depend on the choice (bit for bit).
+        CALL IT ON A WARM CARD: the chip slows down within the first second or two of sustained load and the two forms do so differently (one launch set 18.7 -> 19.25 ms per frame
+        on one box while the pieces stayed at 18.85) — a decision taken in a fresh process's first second can be the wrong one for the stream that follows."""
         sets = [ray_sets] if torch.is_tensor(ray_sets) else list(ray_sets)
         sets = [_f32c(r, self.device) for r in sets]
         if self.render_piece_rays not in (None, 0):
