@@ -454,7 +454,7 @@ def main():
                          "f16act / f16 = the opt-in reduced modes (two / one product).  The default run reports all three under `arith_modes`")
     ap.add_argument("--autotune", action="store_true", help="decide pieces / one launch set on this card in the warm-up (model.autotune_render_pieces) instead of the library's default (pieces)")
     ap.add_argument("--two-shares-in-flight", action="store_true", help="split frames: two shares in flight on two render streams (ShardedFramePipeline(two_in_flight=True), round 6: "
-                                                                       "-3 % in the local emulation, not reproducible through RCCL's own stream — off by default, render.py)")
+                                                                       "-3 %% in the local emulation, not reproducible through RCCL's own stream — off by default, render.py)")
     ap.add_argument("--pieces", type=int, default=None, help="rays per piece of a tvr_render call rendered in pieces on two library-owned streams (include/tvr.h, PIECES): "
                                                               "default = the library's (30 720); 0 = one launch set per call, as before round 6")
     ap.add_argument("--chunk-stream", action="store_true", help="with --chunk: the chunk calls go through render.FrameStream (two calls in flight on two streams) "
