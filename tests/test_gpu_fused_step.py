@@ -327,9 +327,20 @@ def test_every_stage_of_the_fused_backward_against_fp64_on_its_own_tensors(tiny_
     close(g(m.basis_mat.weight), (dfe[:, :27].t() @ h)[:, bcols], "dBasis")
 
 
-def test_workspace_overflow_is_flagged_not_truncated(tiny_dump, tiny_arrays, hyper_tiny):
+@pytest.mark.parametrize("shape", ["2/2", "6/6, 8/24 components, width 96"])
+def test_workspace_overflow_is_flagged_not_truncated(tiny_dump, tiny_arrays, hyper_tiny, shape):
     rays = _batch(tiny_dump, 64)                                       # 4096 rays
-    m = make_model(tiny_arrays, hyper_tiny)
+    if shape == "2/2":
+        m = make_model(tiny_arrays, hyper_tiny)
+    else:                                                              # round 6: the column-block form of dW1, the streamed W1^T backward, cropped gradients — the same void-step contract
+        from jittor_myc_nerfs_amd import TensorVMSplit, synthetic
+        arrs6 = synthetic.make_scene_arrays(TINY["gridSize"], TINY["aabb"], seed=5, view_pe=6, fea_pe=6, density_n_comp=[8, 8, 8], appearance_n_comp=[24, 24, 24], featureC=96)
+        m = TensorVMSplit(arrs6["aabb"], [int(x) for x in arrs6["gridSize"]], "cuda", density_n_comp=[8, 8, 8], appearance_n_comp=[24, 24, 24], app_dim=27,
+                          near_far=hyper_tiny["near_far"], shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=hyper_tiny["density_shift"],
+                          distance_scale=hyper_tiny["distance_scale"], rayMarch_weight_thres=hyper_tiny["rayMarch_weight_thres"], pos_pe=6, view_pe=6, fea_pe=6,
+                          featureC=96, step_ratio=hyper_tiny["step_ratio"], fea2denseAct=hyper_tiny["fea2denseAct"])
+        m.load_arrays(arrs6)
+        assert m._fused_step_ok()
     m.train_app_samples_per_ray = 1                                    # capacity max(4096, 1 x 4096) = 4096 entries; the batch shades more
     rgb, _ = m.render_rays_autograd(rays, white_bg=True, N_samples=TINY["N_samples"])
     rgb.sum().backward()
