@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void pe_concat_gen_kernel(const PeSrc p, const
     __syncthreads();
     for (int b = 0; b < nb; ++b) {
         const int wb = b == nb - 1 ? wl : TVR_GENX_W;
-        float4 *__restrict__ dst = (float4 *)(X + (size_t)b * (size_t)m_cap * TVR_GENX_W + (size_t)e0 * wb);       // 16-B aligned: m_cap * 152 * 4 and 32 * wb * 4 are multiples of 16
+        float4 *__restrict__ dst = (float4 *)(X + (size_t)b * (size_t)m_cap * TVR_GENX_W + (size_t)e0 * wb);       // 16-B aligned: m_cap * 152 * 4 and PEG_TILE * wb * 4 are multiples of 16
         const float4 *src = (const float4 *)(gtile + b * PEG_TILE * TVR_GENX_W);
         for (int i = threadIdx.x; i < rows * wb / 4; i += 256) dst[i] = src[i];
     }
