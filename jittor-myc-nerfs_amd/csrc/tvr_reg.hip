@@ -7,7 +7,7 @@
 #include "tvr_kernels.h"
 
 #define REG_THREADS 256
-#define L1_CHUNK 16384                   // elements per workgroup of the L1 forward (one partial sum each)
+#define L1_CHUNK 4096                    // elements per workgroup of the L1 forward (one partial sum each; 16384 until round 6: 264 workgroups for the bench scene, 31 + 24 us)
 
 __device__ __forceinline__ float block_sum_256(float v, float *sh)
 {
