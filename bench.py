@@ -469,6 +469,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or args.one_rank_exchange:
+        # A rank of a split frame drives FOUR to FIVE streams (the caller's, the exchange's side stream, RCCL's own, the two piece streams of a large share) and HIP maps
+        # streams onto four hardware queues by default: two of them then share a queue and serialise.  Eight queues (a ROCclr setting, read when the runtime starts —
+        # nothing has touched the GPU yet): the 8-way share through a one-member RCCL group 2.43 -> 2.41 ms, the 4-way share 5.09 -> 5.04 (profiles/r06_share_in_flight_ab.txt, block 7).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if world != args.gpus:
         if args.gpus != 1 and world == 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
