@@ -624,7 +624,9 @@ def main():
         if pipe is not None:
             pipe_step(args.warmup + s)
         else:
-            step(args.warmup + s, profile=prof if prof_in_region else None, stats=stats)
+            # per-kernel events on every FOURTH timed step: a frame in 21 pieces records 84 events, +0.05 ... 0.15 ms per frame (scripts/debug/instr_cost.py); kernel_ms is
+            # the average over the recorded steps (kernel_ms.calls of them), the in-kernel statistics cover every step
+            step(args.warmup + s, profile=prof if (prof_in_region and s % 4 == 0) else None, stats=stats)
         if trace is not None:
             trace.append(time.perf_counter() - t0)
     if pipe is not None:
@@ -870,7 +872,8 @@ def main():
                       "app_samples_per_ray": m_app / n_mine},
         "kernel_ms": {"march": k_ms_timed[0], "shade": k_ms_timed[1], "composite": k_ms_timed[2], "calls": n_calls, "pieces_per_call": n_pieces,
                       "note": ("sums over the pieces of a call of the HIP-event durations of the TIMED launches; two pieces are in flight at a time on two streams, so these are "
-                               "durations under co-scheduling (march + shade + composite > ms_per_step)" if n_pieces > 1 else "HIP events around each kernel of the timed launches")},
+                               "durations under co-scheduling (march + shade + composite > ms_per_step)" if n_pieces > 1 else "HIP events around each kernel of the timed launches")
+                              + ("; recorded on every fourth timed step (`calls` of them)" if prof_in_region else "")},
         "roofline": dominant,
         "roofline_all": {"march": roof_march, "shade": roof_shade},
     }
